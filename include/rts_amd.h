@@ -1,0 +1,228 @@
+/* rts_amd.h -- C-ABI of the MI355X-native RTS hot path (librts_amd.so).
+ *
+ * Drop-in boundary for the ray-traced radar return path of ymartin101/RTS:
+ *   ray launch -> closest triangle hit (LBVH built on device) -> reflect shading ->
+ *   receiver-sphere capture -> host/device finalisation -> per-receiver path aggregation.
+ * Each entry point cites the reference interface it replaces (file:line in the reference
+ * repository).  Plain pointers and sizes only: no HIP, torch or C++ types.
+ *
+ * Conventions
+ *   - every function returns an int status (RTS_OK == 0); nothing ever exit()s or aborts
+ *     (the reference aborts the process: RT_CHECK_ERROR, aggregation.cu:17-27);
+ *     rts_last_error() returns a description of the last failure on the calling thread.
+ *   - the library owns all device memory; the caller owns every host array it passes.
+ *   - a handle is not thread-safe: one handle per host thread (and per GPU).
+ *   - there is NO CPU fallback: every compute entry point fails with RTS_ERR_NO_DEVICE when
+ *     no gfx950 device is usable.
+ */
+#ifndef RTS_AMD_H
+#define RTS_AMD_H
+
+#include <stdint.h>
+#include "rts_prd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct RtsContext* RtsHandle;
+
+enum {
+    RTS_OK = 0,
+    RTS_ERR_INVALID = 1,      /* bad argument                                       */
+    RTS_ERR_NO_DEVICE = 2,    /* no usable HIP device / kernels not loadable        */
+    RTS_ERR_HIP = 3,          /* a HIP runtime call failed                          */
+    RTS_ERR_UNSUPPORTED = 4,  /* feature outside the built scope    */
+    RTS_ERR_CAPACITY = 5,     /* caller buffer too small                            */
+    RTS_ERR_IO = 6            /* mesh file could not be read                        */
+};
+
+/* Launch-invariant parameters: rsParameters::GetRTSVariables() and friends
+ * (ray_tracer.cpp:600-605, 645-648). */
+typedef struct RtsParams {
+    uint32_t width;              /* W: rays per lattice dimension, rayTotal = W^3 (rts_vars.x)          */
+    uint32_t max_refl;           /* h_maxReflDepth (rts_vars.y)                                         */
+    uint32_t max_refr;           /* h_maxRefrDepth (rts_vars.z); >0 is clamped to 2 as the reference    */
+    uint32_t interpolate_smooth; /* rsParameters::interpolate_smooth()                                  */
+    int32_t device;              /* HIP device ordinal                                                  */
+    uint32_t flags;              /* RTS_FLAG_*                                                          */
+} RtsParams;
+
+#define RTS_FLAG_KEEP_ALL_RAYS 1u /* also keep the full per-ray output buffers of the reference
+                                     (dbuf_results / dbuf_targ_intersect / dbuf_rcs_angle for EVERY
+                                     launch index) plus the per-segment hit trace -- parity/debug */
+#define RTS_FLAG_COUNT_TRAVERSAL 2u /* run the counting build of the trace kernel (node visits and
+                                     triangle tests per segment, for the roofline accounting)        */
+
+/* One target mesh in its own frame, i.e. after the t = 0 rotation of the mesh builders and
+ * BEFORE the per-pulse displacement (ray_tracer.cpp:963-987).  Mirrors the per-instance
+ * buffers dbuf_triangles / dbuf_triVertices / dbuf_normals and variables d_targReflCoeff /
+ * d_targRefrIndex (ray_tracer.cpp:1043-1114).  n_normals > n_vertices selects the "rect"
+ * per-face normal rule of triangle_mesh.cu:178-180. */
+typedef struct RtsMesh {
+    const uint32_t* triangles;   /* [n_triangles][3] vertex indices                     */
+    const double* vertices;      /* [n_vertices][3]                                     */
+    const double* normals;       /* [n_normals][3]                                      */
+    uint32_t n_triangles, n_vertices, n_normals;
+    uint32_t reserved;
+    double refl_coeff;           /* Target::GetReflCoeff()                              */
+    double refr_index;           /* Target::GetRefrIndex()                              */
+} RtsMesh;
+
+/* Per-pulse placement of one target: ray_tracer.cpp:941-948 (positions), :993-1007 (time
+ * varying rotation applied to the t = 0 mesh), :1010-1014 (displacement), :1144-1145
+ * (velocity = (pos(t + Ts) - pos(t)) / Ts). */
+typedef struct RtsTargetMotion {
+    double position[3];
+    double velocity[3];
+    double rotation[9];          /* row-major R_total = Rz*Ry*Rx, used only if has_rotation  */
+    int32_t has_rotation;
+    int32_t reserved;
+} RtsTargetMotion;
+
+/* Receiver capture sphere: dbuf_sphCentre / sphRadius / min,maxTheta / min,maxPhi
+ * (ray_tracer.cu:33-38), values as computed at ray_tracer.cpp:894-918. */
+typedef struct RtsReceiverSphere {
+    double centre[3];
+    double radius;
+    double min_theta, max_theta, min_phi, max_phi;
+} RtsReceiverSphere;
+
+/* One launch (one transmitter, one pulse): d_rayOrigin / d_txSpan / d_txDir
+ * (ray_tracer.cu:41-43; ray_tracer.cpp:818,881-890).  ray_first/ray_count select a contiguous
+ * range of the W^3 launch indices (multi-GPU sharding); ray_count == 0 means all. */
+typedef struct RtsPulse {
+    double ray_origin[3];
+    double tx_span[3];           /* azimuth span, elevation span, launch range           */
+    double tx_dir[2];            /* boresight azimuth, elevation                         */
+    uint64_t ray_first;
+    uint64_t ray_count;
+    const RtsTargetMotion* motion; /* [n_targets]; NULL = keep the previous placement    */
+} RtsPulse;
+
+/* Per-pulse counters and stage timings (the reference prints four wall-clock timers,
+ * ray_tracer.cpp:1158,1170,1332; aggregation.cu:166). */
+typedef struct RtsStats {
+    uint64_t rays;               /* launch indices traced in this call                  */
+    uint64_t segments;           /* rtTrace calls: primary + bounce segments            */
+    uint64_t shaded;             /* closest-hit invocations that passed the depth gate   */
+    uint64_t received;           /* rays with received >= 0                             */
+    uint64_t node_visits;        /* BVH nodes fetched   (RTS_FLAG_COUNT_TRAVERSAL only) */
+    uint64_t tri_tests;          /* triangle tests      (RTS_FLAG_COUNT_TRAVERSAL only) */
+    uint32_t n_prims, n_nodes;
+    float ms_scene;              /* transform + bounds + LBVH build                     */
+    float ms_trace;              /* trace kernel                                        */
+    float ms_compact;            /* received-ray ordering + record expansion            */
+    float ms_aggregate;          /* finalise + group-by                                 */
+    uint32_t bvh_rebuilt;        /* 1 if the LBVH was rebuilt for this pulse            */
+    uint32_t stack_overflows;    /* traversal stack spills to global memory             */
+} RtsStats;
+
+/* One aggregated return: what ray_tracer.cpp:1301-1321 turns into an InterpPoint/Response. */
+typedef struct RtsResponse {
+    uint64_t ray;                /* index in the received list of the representative ray */
+    int32_t rx;                  /* receiver index                                       */
+    uint32_t n;                  /* rays aggregated                                      */
+    double power, delay, doppler, phase;
+} RtsResponse;
+
+/* Partial sums of one (receiver, path) group -- the unit exchanged between GPUs. */
+#define RTS_MAX_DEPTH 16
+typedef struct RtsGroup {
+    int32_t rx;
+    uint32_t direct;             /* 1 if this is the direct-transmission group           */
+    int32_t path[RTS_MAX_DEPTH]; /* target index per depth, -1 padded                    */
+    uint64_t min_ray;            /* smallest received-list index in the group (global)   */
+    double n, sum_sqrt_power, sum_delay, sum_phase, sum_doppler;
+} RtsGroup;
+
+/* ---------------------------------------------------------------- life cycle */
+int rts_create(const RtsParams* params, RtsHandle* out);      /* rtContextCreate .. ray_tracer.cpp:532-800 */
+int rts_destroy(RtsHandle h);                                 /* ray_tracer.cpp:1342-1360                  */
+const char* rts_last_error(void);
+int rts_device_count(int* n);
+
+/* ---------------------------------------------------------------- scene */
+int rts_set_scene(RtsHandle h, const RtsMesh* meshes, uint32_t n_targets);          /* ray_tracer.cpp:1020-1117 */
+int rts_set_receivers(RtsHandle h, const RtsReceiverSphere* rx, uint32_t n_rx);     /* ray_tracer.cpp:670-715,894-925 */
+
+/* ---------------------------------------------------------------- launch
+ * Replaces rtContextValidate/Compile/Launch3D (ray_tracer.cpp:1126-1165): places the targets,
+ * (re)builds the LBVH on the device if any target moved, traces ray_count launch indices and
+ * leaves the received rays on the device, ordered by ascending launch index (the order of the
+ * host scan at ray_tracer.cpp:1190).  Blocking. */
+int rts_trace_pulse(RtsHandle h, const RtsPulse* pulse);
+int rts_get_stats(RtsHandle h, RtsStats* out);
+
+/* Received rays of the last pulse (ray_tracer.cpp:1186-1257 before the gain/RCS update):
+ * rays[R], paths[R][D] (h_rx_intersects, D = max_refr + max_refl), rcs_angles[R][D][2],
+ * slots[R] = global launch index.  Any output pointer may be NULL.  capacity in rays. */
+int rts_received_count(RtsHandle h, uint64_t* count);
+int rts_get_received(RtsHandle h, struct PerRayData* rays, int32_t* paths, double* rcs_angles, uint64_t* slots,
+                     uint64_t capacity);
+
+/* Full per-launch-index buffers (RTS_FLAG_KEEP_ALL_RAYS): results[n] / targ_intersect[n][D] /
+ * rcs_angle[n][D][2] as mapped at ray_tracer.cpp:1180-1182, plus hit_prim[n][max_refl+1] (global
+ * primitive id of the closest hit of each segment of the reflection chain, -1 = miss, -2 = not
+ * traced) and hit_t[n][max_refl+1] (its f32 distance). */
+int rts_get_all_rays(RtsHandle h, struct PerRayData* results, int32_t* targ_intersect, double* rcs_angle,
+                     int32_t* hit_prim, float* hit_t, uint64_t capacity);
+
+/* ---------------------------------------------------------------- finalise + aggregate on the device
+ * rts_finalise_uniform: the per-received-ray update of ray_tracer.cpp:1219-1253 for the case
+ * where RCS is a constant per target and the antenna gains are constants (isotropic antennas):
+ *   power *= prod RCS[targ_k] ; power *= wavelength^2 * gt * gr ;
+ *   doppler = carrier * ((1 + Vr/c) / (1 - Vr/c) - 1), Vr = doppler / 2.
+ * With SOARS antenna / RCS callbacks use rts_get_received + rs::kernel_wrapper instead. */
+int rts_finalise_uniform(RtsHandle h, const double* rcs_per_target, double wavelength, double gt, double gr,
+                         double carrier, double cspeed);
+
+/* rts_aggregate: myKernel1 + myKernel2 + unique paths (aggregation.cu:32-97,
+ * ray_tracer.cpp:1283-1292) on the device-resident received set, as a sort/group-by.
+ * recv_index_base offsets the received-list indices (multi-GPU: number of received rays on
+ * lower ranks). */
+int rts_aggregate(RtsHandle h, double cspeed, double carrier, uint64_t recv_index_base);
+int rts_group_count(RtsHandle h, uint32_t* count);
+int rts_get_groups(RtsHandle h, RtsGroup* groups, uint32_t capacity);
+/* Per-ray aggregation outputs of the last rts_aggregate (what kernel_wrapper returns). */
+int rts_get_aggregated(RtsHandle h, struct PerRayData* rays, double* delay, double* phase, int32_t* path_match,
+                       uint64_t capacity);
+
+/* Host-side: merge group tables (concatenated from several GPUs) and derive the responses
+ * that ray_tracer.cpp:1290-1321 would emit.  Pure host code, no device needed. */
+int rts_merge_groups(const RtsGroup* in, uint32_t n_in, uint32_t depth, RtsGroup* out, uint32_t* n_out);
+int rts_groups_to_responses(const RtsGroup* groups, uint32_t n_groups, RtsResponse* out, uint32_t capacity,
+                            uint32_t* n_out);
+
+/* ---------------------------------------------------------------- the reference's inner C-like boundary
+ * Same argument list and in/out behaviour as rs::kernel_wrapper (aggregation.cuh:19-22,
+ * aggregation.cu:103-184); the C++ symbol rs::kernel_wrapper is exported by the library too
+ * (include/rts_adapter.hpp).  Returns a status instead of exiting. */
+int rts_kernel_wrapper(struct PerRayData* h_rx_results_arr, int* h_rx_intersects_arr, unsigned int receivedRays,
+                       unsigned int depthTotal, unsigned int MaxThreads, unsigned int MaxBlocks, double cspeed,
+                       double carrier, double* h_npath_arr, double* h_power_arr, double* h_doppler_arr,
+                       double* h_delay_arr, double* h_phase_arr, int* h_pathMatch);
+
+/* ---------------------------------------------------------------- host scene helpers (ray_tracer.cpp:85-504, 894-918)
+ * Two-call pattern for the variable-size builders: pass NULL outputs to obtain the sizes. */
+int rts_vertex_rotation(double* vertices, uint32_t n, float yaw, float pitch, float roll);          /* :156-170 */
+int rts_rotation_matrix(float yaw, float pitch, float roll, double* r9);                             /* :159-162 */
+int rts_rect_mesh(float w, float h, float d, float yaw, float pitch, float roll, double* vertices24,
+                  uint32_t* triangles36, double* normals36);                                         /* :226-297 */
+int rts_sphere_mesh(uint32_t subdivisions, float radius, float yaw, float pitch, float roll, double* vertices,
+                    uint32_t* n_vertices, uint32_t* triangles, uint32_t* n_triangles, double* normals); /* :300-426 */
+int rts_file_mesh(const char* v_file, const char* n_file, float yaw, float pitch, float roll, double* vertices,
+                  uint32_t* triangles, double* normals, uint32_t* n_triangles);                      /* :429-504 */
+int rts_rx_sphere(const double* rx_position, double azimuth, double elevation, double radius, double theta_span,
+                  double phi_span, RtsReceiverSphere* out);                                          /* :894-918 */
+
+/* ---------------------------------------------------------------- introspection (tests)
+ * LBVH of the last pulse: nodes[n_nodes][16] floats-as-stored (64-byte records), leaf_prim[n_prims]. */
+int rts_get_bvh(RtsHandle h, void* nodes64, uint32_t* leaf_prim, uint32_t node_capacity, uint32_t prim_capacity);
+int rts_self_test_math(RtsHandle h, const float* y, const float* x, float* atan2f_out, const double* a,
+                       const double* b, double* div_out, double* sqrt_out, uint32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTS_AMD_H */

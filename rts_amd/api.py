@@ -1,0 +1,201 @@
+"""Thin Python harness over the C-ABI (tests and bench.py drive the product through this).
+
+Nothing here computes: every method marshals numpy arrays into one call of librts_amd.so.
+The production caller is C++ (include/rts_adapter.hpp, rs::RTS); see INTEGRATION.md.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import PRD_DTYPE, RESPONSE_DTYPE, GROUP_DTYPE, check, ptr
+
+
+# ------------------------------------------------------------------------------- host scene helpers
+def rect_mesh(w, h, d, yaw=0.0, pitch=0.0, roll=0.0):
+    v = np.zeros((8, 3)); t = np.zeros((12, 3), np.uint32); n = np.zeros((12, 3))
+    check(L.lib().rts_rect_mesh(w, h, d, yaw, pitch, roll, ptr(v), ptr(t), ptr(n)))
+    return v, t, n
+
+
+def sphere_mesh(subdivisions, radius, yaw=0.0, pitch=0.0, roll=0.0):
+    nv = C.c_uint32(); nt = C.c_uint32()
+    check(L.lib().rts_sphere_mesh(subdivisions, radius, yaw, pitch, roll, None, C.byref(nv), None, C.byref(nt), None))
+    v = np.zeros((nv.value, 3)); t = np.zeros((nt.value, 3), np.uint32); n = np.zeros((nv.value, 3))
+    check(L.lib().rts_sphere_mesh(subdivisions, radius, yaw, pitch, roll, ptr(v), C.byref(nv), ptr(t), C.byref(nt), ptr(n)))
+    return v, t, n
+
+
+def file_mesh(v_file, n_file, yaw=0.0, pitch=0.0, roll=0.0):
+    nt = C.c_uint32(0)
+    check(L.lib().rts_file_mesh(v_file.encode(), n_file.encode(), yaw, pitch, roll, None, None, None, C.byref(nt)))
+    v = np.zeros((3 * nt.value, 3)); t = np.zeros((nt.value, 3), np.uint32); n = np.zeros((3 * nt.value, 3))
+    check(L.lib().rts_file_mesh(v_file.encode(), n_file.encode(), yaw, pitch, roll, ptr(v), ptr(t), ptr(n), C.byref(nt)))
+    return v, t, n
+
+
+def vertex_rotation(verts, yaw, pitch, roll):
+    v = np.ascontiguousarray(verts, np.float64).copy()
+    check(L.lib().rts_vertex_rotation(ptr(v), v.shape[0], yaw, pitch, roll))
+    return v
+
+
+def rotation_matrix(yaw, pitch, roll):
+    r = np.zeros(9)
+    check(L.lib().rts_rotation_matrix(yaw, pitch, roll, ptr(r)))
+    return r
+
+
+def rx_sphere(pos, az, el, radius, theta_span, phi_span):
+    out = L.RtsReceiverSphere(); p = np.ascontiguousarray(pos, np.float64)
+    check(L.lib().rts_rx_sphere(ptr(p), az, el, radius, theta_span, phi_span, C.byref(out)))
+    return dict(centre=np.array(out.centre[:]), radius=out.radius, minTheta=out.min_theta, maxTheta=out.max_theta,
+                minPhi=out.min_phi, maxPhi=out.max_phi)
+
+
+def merge_groups(groups, depth):
+    g = np.ascontiguousarray(groups, GROUP_DTYPE)
+    out = np.zeros(max(len(g), 1), GROUP_DTYPE); n = C.c_uint32(len(out))
+    check(L.lib().rts_merge_groups(ptr(g), len(g), depth, ptr(out), C.byref(n)))
+    return out[:n.value].copy()
+
+
+def groups_to_responses(groups):
+    g = np.ascontiguousarray(groups, GROUP_DTYPE)
+    out = np.zeros(max(len(g), 1), RESPONSE_DTYPE); n = C.c_uint32(0)
+    check(L.lib().rts_groups_to_responses(ptr(g), len(g), ptr(out), len(out), C.byref(n)))
+    return out[:n.value].copy()
+
+
+def kernel_wrapper(rx_results, rx_intersects, cspeed, carrier, ray_total, max_threads=1024, max_blocks=65535):
+    """rs::kernel_wrapper with the caller-side pre-fill of ray_tracer.cpp:1266-1271."""
+    R = rx_results.shape[0]; D = rx_intersects.shape[1] if rx_intersects.ndim == 2 else 0
+    res = np.ascontiguousarray(rx_results, PRD_DTYPE).copy()
+    paths = np.ascontiguousarray(rx_intersects, np.int32)
+    npath = np.zeros(R); power = np.zeros(R); dop = np.zeros(R); delay = np.zeros(R); phase = np.zeros(R)
+    pm = np.full(R, ray_total + 1, np.int32)
+    check(L.lib().rts_kernel_wrapper(ptr(res), ptr(paths), R, D, max_threads, max_blocks, cspeed, carrier, ptr(npath),
+                                     ptr(power), ptr(dop), ptr(delay), ptr(phase), ptr(pm)))
+    return dict(results=res, delay=delay, phase=phase, pathMatch=pm)
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = L.lib().rts_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+# ------------------------------------------------------------------------------- the tracer handle
+class Tracer:
+    """One RtsHandle: scene + receivers + per-pulse launch on one GPU."""
+
+    def __init__(self, width, max_refl, max_refr=0, smooth=True, device=0, keep_all=False, count_traversal=False):
+        p = L.RtsParams(width, max_refl, max_refr, 1 if smooth else 0, device,
+                        (L.RTS_FLAG_KEEP_ALL_RAYS if keep_all else 0) | (L.RTS_FLAG_COUNT_TRAVERSAL if count_traversal else 0))
+        self.h = C.c_void_p()
+        check(L.lib().rts_create(C.byref(p), C.byref(self.h)))
+        self.width = width; self.max_refl = max_refl; self.depth = max_refl + (2 if max_refr else 0)
+        self.n_targets = 0; self.keep_all = keep_all
+        self._keep = []
+
+    def close(self):
+        if self.h:
+            L.lib().rts_destroy(self.h); self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_scene(self, meshes):
+        """meshes: list of dict(tris, verts, normals, refl_coeff, refr_index) in the target's own frame."""
+        arr = (L.RtsMesh * max(len(meshes), 1))()
+        keep = []
+        for i, m in enumerate(meshes):
+            t = np.ascontiguousarray(m["tris"], np.uint32); v = np.ascontiguousarray(m["verts"], np.float64)
+            n = np.ascontiguousarray(m["normals"], np.float64)
+            keep += [t, v, n]
+            arr[i] = L.RtsMesh(t.ctypes.data, v.ctypes.data, n.ctypes.data, t.shape[0], v.shape[0], n.shape[0], 0,
+                               float(m.get("refl_coeff", 1.0)), float(m.get("refr_index", 1.0)))
+        check(L.lib().rts_set_scene(self.h, arr, len(meshes)))
+        self.n_targets = len(meshes)
+
+    def set_receivers(self, spheres):
+        arr = (L.RtsReceiverSphere * max(len(spheres), 1))()
+        for i, s in enumerate(spheres):
+            arr[i] = L.RtsReceiverSphere((C.c_double * 3)(*s["centre"]), s["radius"], s["minTheta"], s["maxTheta"],
+                                         s["minPhi"], s["maxPhi"])
+        check(L.lib().rts_set_receivers(self.h, arr, len(spheres)))
+
+    def trace(self, origin, tx_span, tx_dir, motion=None, ray_first=0, ray_count=0):
+        """motion: list of dict(position, velocity[, rotation(9)]) per target, or None to keep placement."""
+        p = L.RtsPulse()
+        p.ray_origin[:] = list(origin); p.tx_span[:] = list(tx_span); p.tx_dir[:] = list(tx_dir)
+        p.ray_first = ray_first; p.ray_count = ray_count
+        if motion is not None:
+            assert len(motion) == self.n_targets
+            marr = (L.RtsTargetMotion * max(len(motion), 1))()
+            for i, m in enumerate(motion):
+                marr[i].position[:] = list(m["position"]); marr[i].velocity[:] = list(m.get("velocity", (0, 0, 0)))
+                rot = m.get("rotation")
+                if rot is not None:
+                    marr[i].rotation[:] = list(np.asarray(rot, np.float64).reshape(9)); marr[i].has_rotation = 1
+            p.motion = C.cast(marr, C.POINTER(L.RtsTargetMotion))
+            self._keep = [marr]
+        check(L.lib().rts_trace_pulse(self.h, C.byref(p)))
+        return self.stats()
+
+    def stats(self):
+        s = L.RtsStats()
+        check(L.lib().rts_get_stats(self.h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in L.RtsStats._fields_}
+
+    def received_count(self):
+        n = C.c_uint64(0)
+        check(L.lib().rts_received_count(self.h, C.byref(n)))
+        return n.value
+
+    def received(self):
+        R = self.received_count(); D = self.depth
+        rays = np.zeros(R, PRD_DTYPE); paths = np.zeros((R, D), np.int32); ang = np.zeros((R, D, 2)); slots = np.zeros(R, np.uint64)
+        check(L.lib().rts_get_received(self.h, ptr(rays), ptr(paths), ptr(ang), ptr(slots), R))
+        return dict(results=rays, path=paths, rcs_angle=ang, slots=slots)
+
+    def all_rays(self, n):
+        D = self.depth; H = self.max_refl + 1
+        res = np.zeros(n, PRD_DTYPE); path = np.zeros((n, D), np.int32); ang = np.zeros((n, D, 2))
+        hp = np.zeros((n, H), np.int32); ht = np.zeros((n, H), np.float32)
+        check(L.lib().rts_get_all_rays(self.h, ptr(res), ptr(path), ptr(ang), ptr(hp), ptr(ht), n))
+        return dict(results=res, path=path, rcs_angle=ang, hit_prim=hp, hit_t=ht)
+
+    def finalise_uniform(self, rcs_per_target, wavelength, gt, gr, carrier, cspeed):
+        r = np.ascontiguousarray(rcs_per_target, np.float64) if rcs_per_target is not None else None
+        check(L.lib().rts_finalise_uniform(self.h, ptr(r), wavelength, gt, gr, carrier, cspeed))
+
+    def aggregate(self, cspeed, carrier, recv_index_base=0):
+        check(L.lib().rts_aggregate(self.h, cspeed, carrier, recv_index_base))
+        n = C.c_uint32(0)
+        check(L.lib().rts_group_count(self.h, C.byref(n)))
+        g = np.zeros(max(n.value, 1), GROUP_DTYPE)
+        check(L.lib().rts_get_groups(self.h, ptr(g), len(g)))
+        return g[:n.value].copy()
+
+    def aggregated(self):
+        R = self.received_count()
+        rays = np.zeros(R, PRD_DTYPE); delay = np.zeros(R); phase = np.zeros(R); pm = np.zeros(R, np.int32)
+        check(L.lib().rts_get_aggregated(self.h, ptr(rays), ptr(delay), ptr(phase), ptr(pm), R))
+        return dict(results=rays, delay=delay, phase=phase, pathMatch=pm)
+
+    def bvh(self):
+        s = self.stats()
+        nodes = np.zeros((max(s["n_nodes"], 1), 16), np.float32); leaf = np.zeros(max(s["n_prims"], 1), np.uint32)
+        check(L.lib().rts_get_bvh(self.h, ptr(nodes), ptr(leaf), nodes.shape[0], leaf.shape[0]))
+        return nodes[:s["n_nodes"]], leaf[:s["n_prims"]]
+
+    def self_test_math(self, y, x, a, b):
+        y = np.ascontiguousarray(y, np.float32); x = np.ascontiguousarray(x, np.float32)
+        a = np.ascontiguousarray(a, np.float64); b = np.ascontiguousarray(b, np.float64)
+        n = len(y); at = np.zeros(n, np.float32); dv = np.zeros(n); sq = np.zeros(n)
+        check(L.lib().rts_self_test_math(self.h, ptr(y), ptr(x), ptr(at), ptr(a), ptr(b), ptr(dv), ptr(sq), n))
+        return at, dv, sq

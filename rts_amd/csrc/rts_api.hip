@@ -1,0 +1,547 @@
+// rts_api.hip -- host side of librts_amd.so: the C-ABI of include/rts_amd.h.
+//
+// Mirrors the host driver rs::RTS of the reference (ray_tracer.cpp:507-1364) from the point
+// where it owns device state: context set-up, per-pulse scene placement, launch, read-back,
+// aggregation.  There is no CPU compute path: without a usable HIP device every compute
+// entry point fails with RTS_ERR_NO_DEVICE.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <algorithm>
+#include <map>
+#include "rts_internal.h"
+
+static thread_local char g_err[1024] = "";
+void rts_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap); }
+extern "C" const char* rts_last_error(void) { return g_err; }
+
+extern int rts_fill_i32(hipStream_t st, int32_t* p, int32_t v, size_t n);
+
+extern "C" int rts_device_count(int* n)
+{
+    if (!n) { rts_set_error("rts_device_count: null output"); return RTS_ERR_INVALID; }
+    int k = 0; hipError_t e = hipGetDeviceCount(&k);
+    if (e != hipSuccess) { *n = 0; rts_set_error("hipGetDeviceCount: %s", hipGetErrorString(e)); return RTS_ERR_NO_DEVICE; }
+    *n = k; return RTS_OK;
+}
+
+extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
+{
+    if (!p || !out) { rts_set_error("rts_create: null argument"); return RTS_ERR_INVALID; }
+    *out = nullptr;
+    if (p->width == 0) { rts_set_error("rts_create: width must be >= 1"); return RTS_ERR_INVALID; }
+    if ((uint64_t)p->width * p->width * p->width > 0xffffffffULL) {      // rayIndex is unsigned int, ray_tracer.cu:151
+        rts_set_error("rts_create: W^3 must fit 32 bits (W <= 1625)"); return RTS_ERR_INVALID; }
+    if (p->max_refr != 0) { rts_set_error("rts_create: refraction (max_refr > 0) is not built yet"); return RTS_ERR_UNSUPPORTED; }
+    if (p->max_refl > RTS_MAX_DEPTH) { rts_set_error("rts_create: max_refl > %d", RTS_MAX_DEPTH); return RTS_ERR_UNSUPPORTED; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { rts_set_error("rts_create: no HIP device (there is no CPU fallback)"); return RTS_ERR_NO_DEVICE; }
+    if (p->device < 0 || p->device >= ndev) { rts_set_error("rts_create: device %d out of range (%d devices)", p->device, ndev); return RTS_ERR_INVALID; }
+    RTS_HIP(hipSetDevice(p->device));
+    RtsContext* c = new RtsContext();
+    c->params = *p; c->depth = p->max_refr + p->max_refl; c->device = p->device;
+    memset(&c->stats, 0, sizeof(c->stats));
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; rts_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return RTS_ERR_HIP; }
+    for (int i = 0; i < 8; i++) { e = hipEventCreate(&c->ev[i]); if (e != hipSuccess) { delete c; rts_set_error("hipEventCreate: %s", hipGetErrorString(e)); return RTS_ERR_HIP; } }
+    *out = c;
+    return RTS_OK;
+}
+
+extern "C" int rts_destroy(RtsHandle c)
+{
+    if (!c) return RTS_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    c->d_tri_vidx.release(); c->d_tri_nidx.release(); c->d_vert_targ.release(); c->d_norm_targ.release(); c->d_prim_targ.release();
+    c->d_verts_local.release(); c->d_normals_local.release(); c->d_verts_world.release(); c->d_normals_world.release();
+    c->d_motion.release(); c->d_targets.release(); c->d_prim_box.release(); c->d_node_box.release(); c->d_keys.release(); c->d_keys_sorted.release();
+    c->d_vals.release(); c->d_vals_sorted.release(); c->d_bounds.release(); c->d_parent.release(); c->d_leaf_parent.release(); c->d_flags.release();
+    c->d_nodes.release(); c->d_leaves.release(); c->d_sort_tmp.release(); c->d_rx.release(); c->d_recv.release(); c->d_all.release();
+    c->d_counters.release(); c->d_dir_hist.release(); c->d_hit_prim.release(); c->d_hit_t.release(); c->d_stack_ovf.release();
+    c->d_rk.release(); c->d_rk_sorted.release(); c->d_ri.release(); c->d_ri_sorted.release(); c->d_rx_rays.release(); c->d_rx_paths.release();
+    c->d_rx_angles.release(); c->d_rx_slots.release(); c->d_all_rays.release(); c->d_all_paths.release(); c->d_all_angles.release();
+    c->d_akeys.release(); c->d_akeys_sorted.release(); c->d_aidx.release(); c->d_aidx_sorted.release(); c->d_ghead.release(); c->d_gid.release();
+    c->d_gsum.release(); c->d_gmin.release(); c->d_gkey.release(); c->d_gcount.release(); c->d_delay.release(); c->d_phase.release();
+    c->d_pathmatch.release(); c->d_rcs.release();
+    for (int i = 0; i < 8; i++) (void)hipEventDestroy(c->ev[i]);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return RTS_OK;
+}
+
+#define CHECK_HANDLE(c) do { if (!(c)) { rts_set_error("null handle"); return RTS_ERR_INVALID; } RTS_HIP(hipSetDevice((c)->device)); } while (0)
+
+// ------------------------------------------------------------------------------------- scene
+extern "C" int rts_set_scene(RtsHandle c, const RtsMesh* meshes, uint32_t n_targets)
+{
+    CHECK_HANDLE(c);
+    if (n_targets && !meshes) { rts_set_error("rts_set_scene: null meshes"); return RTS_ERR_INVALID; }
+    if (n_targets > 254) { rts_set_error("rts_set_scene: more than 254 targets"); return RTS_ERR_UNSUPPORTED; }
+    std::vector<RtsMeshHost> mh(n_targets);
+    uint64_t nt = 0, nv = 0, nn = 0;
+    for (uint32_t t = 0; t < n_targets; t++) {
+        const RtsMesh& m = meshes[t];
+        if ((m.n_triangles && !m.triangles) || (m.n_vertices && !m.vertices) || (m.n_normals && !m.normals)) { rts_set_error("rts_set_scene: target %u has null arrays", t); return RTS_ERR_INVALID; }
+        mh[t].n_tris = m.n_triangles; mh[t].n_verts = m.n_vertices; mh[t].n_normals = m.n_normals;
+        mh[t].tri_base = (uint32_t)nt; mh[t].vert_base = (uint32_t)nv; mh[t].normal_base = (uint32_t)nn;
+        mh[t].refl_coeff = m.refl_coeff; mh[t].refr_index = m.refr_index;
+        mh[t].perface = m.n_normals > m.n_vertices;                              // triangle_mesh.cu:178
+        nt += m.n_triangles; nv += m.n_vertices; nn += m.n_normals;
+        if (nt > 0x7ffffff0ULL || nv > 0x7ffffff0ULL || nn > 0x7ffffff0ULL) { rts_set_error("rts_set_scene: scene too large"); return RTS_ERR_UNSUPPORTED; }
+    }
+    std::vector<uint32_t> vidx(3*nt), nidx(3*nt), vtarg(nv), ntarg(nn), ptarg(nt);
+    std::vector<double> verts(3*nv), normals(3*nn);
+    for (uint32_t t = 0; t < n_targets; t++) {
+        const RtsMesh& m = meshes[t]; const RtsMeshHost& h = mh[t];
+        for (uint32_t i = 0; i < m.n_triangles; i++) {
+            for (int k = 0; k < 3; k++) {
+                uint32_t v = m.triangles[3*(size_t)i + k];
+                if (v >= m.n_vertices) { rts_set_error("rts_set_scene: target %u triangle %u references vertex %u >= %u", t, i, v, m.n_vertices); return RTS_ERR_INVALID; }
+                vidx[3*((size_t)h.tri_base + i) + k] = h.vert_base + v;
+                // dbuf_normals is indexed by the vertex index (triangle_mesh.cu:170-172), or by the
+                // primitive index for per-face ("rect") normals (:178-180)
+                uint32_t ni = h.perface ? i : v;
+                if (m.n_normals == 0) ni = 0; else if (ni >= m.n_normals) { rts_set_error("rts_set_scene: target %u normal index %u >= %u", t, ni, m.n_normals); return RTS_ERR_INVALID; }
+                nidx[3*((size_t)h.tri_base + i) + k] = h.normal_base + ni;
+            }
+            ptarg[(size_t)h.tri_base + i] = t;
+        }
+        if (m.n_triangles && m.n_normals == 0 && c->params.interpolate_smooth) { rts_set_error("rts_set_scene: target %u has no normals but interpolate_smooth is set", t); return RTS_ERR_INVALID; }
+        for (uint32_t i = 0; i < m.n_vertices; i++) { vtarg[(size_t)h.vert_base + i] = t; for (int k = 0; k < 3; k++) verts[3*((size_t)h.vert_base + i) + k] = m.vertices[3*(size_t)i + k]; }
+        for (uint32_t i = 0; i < m.n_normals; i++) { ntarg[(size_t)h.normal_base + i] = t; for (int k = 0; k < 3; k++) normals[3*((size_t)h.normal_base + i) + k] = m.normals[3*(size_t)i + k]; }
+    }
+    RTS_HIP(hipStreamSynchronize(c->stream));
+    RTS_HIP(c->d_tri_vidx.reserve(3*nt + 1)); RTS_HIP(c->d_tri_nidx.reserve(3*nt + 1)); RTS_HIP(c->d_vert_targ.reserve(nv + 1)); RTS_HIP(c->d_norm_targ.reserve(nn + 1));
+    RTS_HIP(c->d_prim_targ.reserve(nt + 1)); RTS_HIP(c->d_verts_local.reserve(3*nv + 1)); RTS_HIP(c->d_normals_local.reserve(3*nn + 1));
+    RTS_HIP(c->d_verts_world.reserve(3*nv + 1)); RTS_HIP(c->d_normals_world.reserve(3*nn + 1));
+    RTS_HIP(c->d_motion.reserve(n_targets + 1)); RTS_HIP(c->d_targets.reserve(n_targets + 1));
+    if (nt) { RTS_HIP(hipMemcpy(c->d_tri_vidx.p, vidx.data(), sizeof(uint32_t)*3*nt, hipMemcpyHostToDevice)); RTS_HIP(hipMemcpy(c->d_tri_nidx.p, nidx.data(), sizeof(uint32_t)*3*nt, hipMemcpyHostToDevice));
+              RTS_HIP(hipMemcpy(c->d_prim_targ.p, ptarg.data(), sizeof(uint32_t)*nt, hipMemcpyHostToDevice)); }
+    if (nv) { RTS_HIP(hipMemcpy(c->d_vert_targ.p, vtarg.data(), sizeof(uint32_t)*nv, hipMemcpyHostToDevice)); RTS_HIP(hipMemcpy(c->d_verts_local.p, verts.data(), sizeof(double)*3*nv, hipMemcpyHostToDevice)); }
+    if (nn) { RTS_HIP(hipMemcpy(c->d_norm_targ.p, ntarg.data(), sizeof(uint32_t)*nn, hipMemcpyHostToDevice)); RTS_HIP(hipMemcpy(c->d_normals_local.p, normals.data(), sizeof(double)*3*nn, hipMemcpyHostToDevice)); }
+    c->meshes = mh; c->n_prims = (uint32_t)nt; c->n_verts = (uint32_t)nv; c->n_normals = (uint32_t)nn;
+    c->motion.assign(n_targets, RtsTargetMotion{}); c->motion_valid = false; c->bvh_valid = false;
+    return RTS_OK;
+}
+
+extern "C" int rts_set_receivers(RtsHandle c, const RtsReceiverSphere* rx, uint32_t n_rx)
+{
+    CHECK_HANDLE(c);
+    if (n_rx && !rx) { rts_set_error("rts_set_receivers: null array"); return RTS_ERR_INVALID; }
+    if (n_rx > 65535) { rts_set_error("rts_set_receivers: more than 65535 receivers"); return RTS_ERR_UNSUPPORTED; }
+    std::vector<RtsRxDev> h(n_rx);
+    for (uint32_t i = 0; i < n_rx; i++) {
+        const RtsReceiverSphere& r = rx[i];
+        const double vals[8] = { r.centre[0], r.centre[1], r.centre[2], r.radius, r.min_theta, r.max_theta, r.min_phi, r.max_phi };
+        for (int k = 0; k < 8; k++) if (!std::isfinite(vals[k])) { rts_set_error("rts_set_receivers: receiver %u has a non-finite field", i); return RTS_ERR_INVALID; }
+        // normalise_angle (ray_tracer.cu:53-57) walks in steps of 2 pi: keep the walk short
+        if (std::fabs(r.min_theta) > 1e4 || std::fabs(r.max_theta) > 1e4 || std::fabs(r.min_phi) > 1e4 || std::fabs(r.max_phi) > 1e4) { rts_set_error("rts_set_receivers: receiver %u window angle magnitude > 1e4 rad", i); return RTS_ERR_INVALID; }
+        h[i] = RtsRxDev{ r.centre[0], r.centre[1], r.centre[2], r.radius, r.min_theta, r.max_theta, r.min_phi, r.max_phi };
+    }
+    RTS_HIP(hipStreamSynchronize(c->stream));
+    RTS_HIP(c->d_rx.reserve(n_rx + 1));
+    if (n_rx) RTS_HIP(hipMemcpy(c->d_rx.p, h.data(), sizeof(RtsRxDev)*n_rx, hipMemcpyHostToDevice));
+    c->n_rx = n_rx;
+    return RTS_OK;
+}
+
+// ------------------------------------------------------------------------------------- launch constants
+// sph_to_cart (ray_tracer.cu:132-139) and the launch-uniform part of ray_generation
+// (ray_tracer.cu:155-156, 167-169 step factors, 173-175 Rot, 186-196 orth_vec and Rot1),
+// evaluated once on the host in the reference's expression order.
+static inline dvec3 host_sph_to_cart(double azi, double ele) { dvec3 c; c.x = std::cos(azi)*std::cos(ele); c.y = std::sin(azi)*std::cos(ele); c.z = std::sin(ele); return c; }
+
+static void fill_launch_constants(RtsTraceArgs& a, const RtsPulse& p, uint32_t W)
+{
+    const double spx = p.tx_span[0], spy = p.tx_span[1], spz = p.tx_span[2];
+    const double dx = p.tx_dir[0], dy = p.tx_dir[1];
+    a.ox = p.ray_origin[0]; a.oy = p.ray_origin[1]; a.oz = p.ray_origin[2];
+    const dvec3 beamStart = host_sph_to_cart(-spx/2, -spy/2);
+    const dvec3 beamEnd = host_sph_to_cart(spx/2, spy/2);
+    a.bsx = beamStart.x; a.bsy = beamStart.y; a.bsz = beamStart.z;
+    const dvec3 w1 = host_sph_to_cart(dx, dy);
+    a.w1x = w1.x; a.w1y = w1.y; a.w1z = w1.z;
+    a.stx = a.sty = a.stz = 0;
+    if (W > 1) {
+        a.stx = (((beamEnd.x*(1 + spz)) - beamStart.x)/(W - 1));
+        a.sty = ((beamEnd.y - beamStart.y)/(W - 1));
+        a.stz = ((beamEnd.z - beamStart.z)/(W - 1));
+    }
+    const double Rot[3][3] = {{std::cos(dx), -std::sin(dx), 0}, {std::sin(dx), std::cos(dx), 0}, {0, 0, 1}};
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) a.rot[3*i + j] = Rot[i][j];
+    dvec3 rotated; rotated.x = 0; rotated.y = 0; rotated.z = 0;
+    rotated.x += Rot[0][1]; rotated.y += Rot[1][1]; rotated.z += Rot[2][1];
+    const double on = std::sqrt(rotated.x*rotated.x + rotated.y*rotated.y + rotated.z*rotated.z);
+    const dvec3 orth_vec = mk3(rotated.x/on, rotated.y/on, rotated.z/on);
+    const double Rot1[3][3] = {
+        {std::cos(dy) + orth_vec.x*orth_vec.x*(1 - std::cos(dy)), orth_vec.x*orth_vec.y*(1 - std::cos(dy)) + orth_vec.z*std::sin(dy), orth_vec.x*orth_vec.z*(1 - std::cos(dy)) - orth_vec.y*std::sin(dy)},
+        {orth_vec.y*orth_vec.x*(1 - std::cos(dy)) - orth_vec.z*std::sin(dy), std::cos(dy) + orth_vec.y*orth_vec.y*(1 - std::cos(dy)), orth_vec.y*orth_vec.z*(1 - std::cos(dy)) + orth_vec.x*std::sin(dy)},
+        {orth_vec.z*orth_vec.x*(1 - std::cos(dy)) + orth_vec.y*std::sin(dy), orth_vec.z*orth_vec.y*(1 - std::cos(dy)) - orth_vec.x*std::sin(dy), std::cos(dy) + orth_vec.z*orth_vec.z*(1 - std::cos(dy))}};
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) a.rot1[3*i + j] = Rot1[i][j];
+}
+
+// ------------------------------------------------------------------------------------- launch
+extern "C" int rts_trace_pulse(RtsHandle c, const RtsPulse* p)
+{
+    CHECK_HANDLE(c);
+    if (!p) { rts_set_error("rts_trace_pulse: null pulse"); return RTS_ERR_INVALID; }
+    const uint32_t W = c->params.width;
+    const uint64_t total = (uint64_t)W * W * W;
+    uint64_t first = p->ray_first, count = p->ray_count ? p->ray_count : (total > first ? total - first : 0);
+    if (first > total || count > total - first) { rts_set_error("rts_trace_pulse: ray range [%llu, +%llu) outside W^3 = %llu", (unsigned long long)first, (unsigned long long)count, (unsigned long long)total); return RTS_ERR_INVALID; }
+    const uint32_t n_targets = (uint32_t)c->meshes.size();
+    hipStream_t st = c->stream;
+    c->agg_valid = false; c->n_recv = 0;
+
+    // ---- scene placement: rebuild the LBVH only when a target actually moved
+    RTS_HIP(hipEventRecord(c->ev[0], st));
+    bool moved = !c->bvh_valid;
+    if (p->motion) {
+        if (!c->motion_valid || memcmp(c->motion.data(), p->motion, sizeof(RtsTargetMotion)*n_targets) != 0) moved = true;
+        if (n_targets) memcpy(c->motion.data(), p->motion, sizeof(RtsTargetMotion)*n_targets);
+        c->motion_valid = true;
+    } else if (!c->motion_valid) {
+        for (auto& m : c->motion) memset(&m, 0, sizeof(m));
+        c->motion_valid = true; moved = true;
+    }
+    c->stats.bvh_rebuilt = 0;
+    if (moved) {
+        for (uint32_t t = 0; t < n_targets; t++) for (int k = 0; k < 3; k++)
+            if (!std::isfinite(c->motion[t].position[k]) || !std::isfinite(c->motion[t].velocity[k])) { rts_set_error("rts_trace_pulse: target %u has a non-finite position/velocity", t); return RTS_ERR_INVALID; }
+        std::vector<RtsTargetDev> td(n_targets);
+        for (uint32_t t = 0; t < n_targets; t++) {
+            td[t].reflCoeff = c->meshes[t].refl_coeff; td[t].vx = c->motion[t].velocity[0]; td[t].vy = c->motion[t].velocity[1]; td[t].vz = c->motion[t].velocity[2];
+            td[t].tri_base = c->meshes[t].tri_base; td[t].perface_normals = c->meshes[t].perface ? 1u : 0u; td[t].pad0 = td[t].pad1 = 0;
+        }
+        if (n_targets) {
+            RTS_HIP(hipMemcpyAsync(c->d_motion.p, c->motion.data(), sizeof(RtsTargetMotion)*n_targets, hipMemcpyHostToDevice, st));
+            RTS_HIP(hipMemcpyAsync(c->d_targets.p, td.data(), sizeof(RtsTargetDev)*n_targets, hipMemcpyHostToDevice, st));
+            RTS_HIP(hipStreamSynchronize(st));      // td / motion are host temporaries
+        }
+        int rc = rts_bvh_build(c); if (rc != RTS_OK) return rc;
+        c->bvh_valid = true; c->stats.bvh_rebuilt = 1;
+    }
+    RTS_HIP(hipEventRecord(c->ev[1], st));
+
+    // ---- per-pulse buffers
+    const uint32_t n = (uint32_t)count;
+    c->ray_first = first; c->n_rays = n;
+    const bool keep_all = (c->params.flags & RTS_FLAG_KEEP_ALL_RAYS) != 0;
+    const bool count_trav = (c->params.flags & RTS_FLAG_COUNT_TRAVERSAL) != 0;
+    hipDeviceProp_t prop; RTS_HIP(hipGetDeviceProperties(&prop, c->device));
+    uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)n + RTS_BLOCK - 1) / RTS_BLOCK, (uint64_t)prop.multiProcessorCount * 16);
+    if (grid == 0) grid = 1;
+    RtsTraceArgs a; memset(&a, 0, sizeof(a));
+    fill_launch_constants(a, *p, W);
+    a.ray_first = first; a.n_rays = n; a.W = W; a.max_refl = c->params.max_refl; a.smooth = c->params.interpolate_smooth ? 1u : 0u;
+    a.n_prims = c->n_prims; a.n_targets = n_targets; a.n_rx = c->n_rx; a.keep_all = keep_all ? 1u : 0u;
+    a.total_threads = grid * RTS_BLOCK;
+    RTS_HIP(c->d_recv.reserve((size_t)n + 1)); RTS_HIP(c->d_counters.reserve(16));
+    RTS_HIP(c->d_dir_hist.reserve((size_t)std::max<uint32_t>(c->params.max_refl, 1) * 3 * n + 4));
+    RTS_HIP(c->d_stack_ovf.reserve((size_t)RTS_STACK_OVF * a.total_threads));
+    if (keep_all) {
+        RTS_HIP(c->d_all.reserve((size_t)n + 1)); RTS_HIP(c->d_hit_prim.reserve((size_t)n * (c->params.max_refl + 1) + 1)); RTS_HIP(c->d_hit_t.reserve((size_t)n * (c->params.max_refl + 1) + 1));
+        rts_fill_i32(st, c->d_hit_prim.p, -2, (size_t)n * (c->params.max_refl + 1));
+        RTS_HIP(hipMemsetAsync(c->d_hit_t.p, 0, sizeof(float) * (size_t)n * (c->params.max_refl + 1), st));
+    }
+    RTS_HIP(hipMemsetAsync(c->d_counters.p, 0, sizeof(unsigned long long) * 16, st));
+    a.nodes = c->d_nodes.p; a.leaves = c->d_leaves.p; a.tri_nidx = c->d_tri_nidx.p; a.normals = c->d_normals_world.p;
+    a.targets = c->d_targets.p; a.rx = c->d_rx.p;
+    a.recv_records = c->d_recv.p; a.all_records = c->d_all.p; a.counters = c->d_counters.p; a.dir_hist = c->d_dir_hist.p;
+    a.hit_prim = c->d_hit_prim.p; a.hit_t = c->d_hit_t.p; a.stack_ovf = c->d_stack_ovf.p;
+    c->last_args = a;
+
+    // ---- trace
+    RTS_HIP(hipEventRecord(c->ev[2], st));
+    int rc = rts_trace_launch(c, a, count_trav); if (rc != RTS_OK) return rc;
+    RTS_HIP(hipEventRecord(c->ev[3], st));
+    unsigned long long cnt[8];
+    RTS_HIP(hipMemcpyAsync(cnt, c->d_counters.p, sizeof(cnt), hipMemcpyDeviceToHost, st));
+    RTS_HIP(hipStreamSynchronize(st));
+    if (cnt[6]) { rts_set_error("rts_trace_pulse: traversal stack overflow / malformed BVH guard tripped on %llu waves", cnt[6]); return RTS_ERR_HIP; }
+    c->n_recv = cnt[0];
+
+    // ---- order + expand the received rays (and the keep-all buffers)
+    RTS_HIP(hipEventRecord(c->ev[4], st));
+    rc = rts_post_order_and_expand(c); if (rc != RTS_OK) return rc;
+    if (keep_all) { rc = rts_post_expand_all(c); if (rc != RTS_OK) return rc; }
+    RTS_HIP(hipEventRecord(c->ev[5], st));
+    RTS_HIP(hipStreamSynchronize(st));
+
+    RtsStats& s = c->stats;
+    s.rays = n; s.segments = cnt[1]; s.shaded = cnt[2]; s.received = cnt[0]; s.node_visits = cnt[3]; s.tri_tests = cnt[4]; s.stack_overflows = (uint32_t)cnt[5];
+    s.n_prims = c->n_prims; s.n_nodes = c->n_nodes;
+    RTS_HIP(hipEventElapsedTime(&s.ms_scene, c->ev[0], c->ev[1]));
+    RTS_HIP(hipEventElapsedTime(&s.ms_trace, c->ev[2], c->ev[3]));
+    RTS_HIP(hipEventElapsedTime(&s.ms_compact, c->ev[4], c->ev[5]));
+    s.ms_aggregate = 0;
+    return RTS_OK;
+}
+
+extern "C" int rts_get_stats(RtsHandle c, RtsStats* out)
+{
+    if (!c || !out) { rts_set_error("rts_get_stats: null argument"); return RTS_ERR_INVALID; }
+    *out = c->stats; return RTS_OK;
+}
+
+extern "C" int rts_received_count(RtsHandle c, uint64_t* count)
+{
+    if (!c || !count) { rts_set_error("rts_received_count: null argument"); return RTS_ERR_INVALID; }
+    *count = c->n_recv; return RTS_OK;
+}
+
+extern "C" int rts_get_received(RtsHandle c, PerRayData* rays, int32_t* paths, double* rcs_angles, uint64_t* slots, uint64_t capacity)
+{
+    CHECK_HANDLE(c);
+    const uint64_t R = c->n_recv; const uint32_t D = c->depth;
+    if (capacity < R) { rts_set_error("rts_get_received: capacity %llu < %llu received rays", (unsigned long long)capacity, (unsigned long long)R); return RTS_ERR_CAPACITY; }
+    if (R == 0) return RTS_OK;
+    RTS_HIP(hipStreamSynchronize(c->stream));
+    if (rays) RTS_HIP(hipMemcpy(rays, c->d_rx_rays.p, sizeof(PerRayData)*R, hipMemcpyDeviceToHost));
+    if (paths && D) RTS_HIP(hipMemcpy(paths, c->d_rx_paths.p, sizeof(int32_t)*R*D, hipMemcpyDeviceToHost));
+    if (rcs_angles && D) RTS_HIP(hipMemcpy(rcs_angles, c->d_rx_angles.p, sizeof(double)*2*R*D, hipMemcpyDeviceToHost));
+    if (slots) RTS_HIP(hipMemcpy(slots, c->d_rx_slots.p, sizeof(uint64_t)*R, hipMemcpyDeviceToHost));
+    return RTS_OK;
+}
+
+extern "C" int rts_get_all_rays(RtsHandle c, PerRayData* results, int32_t* targ_intersect, double* rcs_angle, int32_t* hit_prim, float* hit_t, uint64_t capacity)
+{
+    CHECK_HANDLE(c);
+    if (!(c->params.flags & RTS_FLAG_KEEP_ALL_RAYS)) { rts_set_error("rts_get_all_rays: handle was not created with RTS_FLAG_KEEP_ALL_RAYS"); return RTS_ERR_INVALID; }
+    const uint64_t n = c->n_rays; const uint32_t D = c->depth, H = c->params.max_refl + 1;
+    if (capacity < n) { rts_set_error("rts_get_all_rays: capacity too small"); return RTS_ERR_CAPACITY; }
+    if (n == 0) return RTS_OK;
+    RTS_HIP(hipStreamSynchronize(c->stream));
+    if (results) RTS_HIP(hipMemcpy(results, c->d_all_rays.p, sizeof(PerRayData)*n, hipMemcpyDeviceToHost));
+    if (targ_intersect && D) RTS_HIP(hipMemcpy(targ_intersect, c->d_all_paths.p, sizeof(int32_t)*n*D, hipMemcpyDeviceToHost));
+    if (rcs_angle && D) RTS_HIP(hipMemcpy(rcs_angle, c->d_all_angles.p, sizeof(double)*2*n*D, hipMemcpyDeviceToHost));
+    if (hit_prim) RTS_HIP(hipMemcpy(hit_prim, c->d_hit_prim.p, sizeof(int32_t)*n*H, hipMemcpyDeviceToHost));
+    if (hit_t) RTS_HIP(hipMemcpy(hit_t, c->d_hit_t.p, sizeof(float)*n*H, hipMemcpyDeviceToHost));
+    return RTS_OK;
+}
+
+// ------------------------------------------------------------------------------------- finalise + aggregate
+extern "C" int rts_finalise_uniform(RtsHandle c, const double* rcs_per_target, double wavelength, double gt, double gr, double carrier, double cspeed)
+{
+    CHECK_HANDLE(c);
+    std::vector<double> ones;
+    if (!rcs_per_target) { ones.assign(c->meshes.size() + 1, 1.0); rcs_per_target = ones.data(); }
+    RTS_HIP(hipEventRecord(c->ev[6], c->stream));
+    int rc = rts_post_finalise(c, rcs_per_target, wavelength, gt, gr, carrier, cspeed); if (rc != RTS_OK) return rc;
+    RTS_HIP(hipEventRecord(c->ev[7], c->stream));
+    RTS_HIP(hipStreamSynchronize(c->stream));
+    float ms = 0; RTS_HIP(hipEventElapsedTime(&ms, c->ev[6], c->ev[7])); c->stats.ms_aggregate = ms;
+    c->agg_valid = false;
+    return RTS_OK;
+}
+
+extern "C" int rts_aggregate(RtsHandle c, double cspeed, double carrier, uint64_t recv_index_base)
+{
+    CHECK_HANDLE(c);
+    const uint64_t R = c->n_recv;
+    c->groups.clear(); c->recv_index_base = recv_index_base;
+    if (R == 0) { c->agg_valid = true; return RTS_OK; }
+    RTS_HIP(c->d_delay.reserve(R)); RTS_HIP(c->d_phase.reserve(R)); RTS_HIP(c->d_pathmatch.reserve(R));
+    RTS_HIP(hipEventRecord(c->ev[6], c->stream));
+    RTS_HIP(hipMemsetAsync(c->d_delay.p, 0, sizeof(double)*R, c->stream));
+    RTS_HIP(hipMemsetAsync(c->d_phase.p, 0, sizeof(double)*R, c->stream));
+    int rc = rts_aggregate_device(c, nullptr, c->d_rx_paths.p, R, c->depth, cspeed, carrier, recv_index_base, c->d_rx_rays.p,
+                                  c->d_delay.p, c->d_phase.p, c->d_pathmatch.p, &c->groups, nullptr, nullptr, nullptr, INT32_MAX);
+    if (rc != RTS_OK) return rc;
+    RTS_HIP(hipEventRecord(c->ev[7], c->stream));
+    RTS_HIP(hipStreamSynchronize(c->stream));
+    float ms = 0; RTS_HIP(hipEventElapsedTime(&ms, c->ev[6], c->ev[7])); c->stats.ms_aggregate += ms;
+    c->agg_valid = true;
+    return RTS_OK;
+}
+
+extern "C" int rts_group_count(RtsHandle c, uint32_t* count)
+{
+    if (!c || !count) { rts_set_error("rts_group_count: null argument"); return RTS_ERR_INVALID; }
+    if (!c->agg_valid) { rts_set_error("rts_group_count: call rts_aggregate first"); return RTS_ERR_INVALID; }
+    *count = (uint32_t)c->groups.size(); return RTS_OK;
+}
+
+extern "C" int rts_get_groups(RtsHandle c, RtsGroup* groups, uint32_t capacity)
+{
+    if (!c || (!groups && capacity)) { rts_set_error("rts_get_groups: null argument"); return RTS_ERR_INVALID; }
+    if (!c->agg_valid) { rts_set_error("rts_get_groups: call rts_aggregate first"); return RTS_ERR_INVALID; }
+    if (capacity < c->groups.size()) { rts_set_error("rts_get_groups: capacity too small"); return RTS_ERR_CAPACITY; }
+    if (!c->groups.empty()) memcpy(groups, c->groups.data(), sizeof(RtsGroup)*c->groups.size());
+    return RTS_OK;
+}
+
+extern "C" int rts_get_aggregated(RtsHandle c, PerRayData* rays, double* delay, double* phase, int32_t* path_match, uint64_t capacity)
+{
+    CHECK_HANDLE(c);
+    if (!c->agg_valid) { rts_set_error("rts_get_aggregated: call rts_aggregate first"); return RTS_ERR_INVALID; }
+    const uint64_t R = c->n_recv;
+    if (capacity < R) { rts_set_error("rts_get_aggregated: capacity too small"); return RTS_ERR_CAPACITY; }
+    if (R == 0) return RTS_OK;
+    if (rays) RTS_HIP(hipMemcpy(rays, c->d_rx_rays.p, sizeof(PerRayData)*R, hipMemcpyDeviceToHost));
+    if (delay) RTS_HIP(hipMemcpy(delay, c->d_delay.p, sizeof(double)*R, hipMemcpyDeviceToHost));
+    if (phase) RTS_HIP(hipMemcpy(phase, c->d_phase.p, sizeof(double)*R, hipMemcpyDeviceToHost));
+    if (path_match) RTS_HIP(hipMemcpy(path_match, c->d_pathmatch.p, sizeof(int32_t)*R, hipMemcpyDeviceToHost));
+    return RTS_OK;
+}
+
+// ------------------------------------------------------------------------------------- host-side group algebra
+// Merge partial group tables (one per GPU): same (rx, path) => sums add, min_ray takes the minimum.
+// Groups are combined in input order, output sorted by (rx, path) so the result does not depend
+// on how many tables were concatenated beyond f64 rounding of the sums.
+extern "C" int rts_merge_groups(const RtsGroup* in, uint32_t n_in, uint32_t depth, RtsGroup* out, uint32_t* n_out)
+{
+    if ((!in && n_in) || !n_out) { rts_set_error("rts_merge_groups: null argument"); return RTS_ERR_INVALID; }
+    if (depth > RTS_MAX_DEPTH) { rts_set_error("rts_merge_groups: depth > %d", RTS_MAX_DEPTH); return RTS_ERR_INVALID; }
+    typedef std::vector<int32_t> Key;
+    std::map<Key, RtsGroup> m;
+    for (uint32_t i = 0; i < n_in; i++) {
+        Key k(1 + RTS_MAX_DEPTH); k[0] = in[i].rx; for (int d = 0; d < RTS_MAX_DEPTH; d++) k[1 + d] = in[i].path[d];
+        auto it = m.find(k);
+        if (it == m.end()) m.emplace(k, in[i]);
+        else {
+            RtsGroup& g = it->second;
+            g.n += in[i].n; g.sum_sqrt_power += in[i].sum_sqrt_power; g.sum_delay += in[i].sum_delay; g.sum_phase += in[i].sum_phase; g.sum_doppler += in[i].sum_doppler;
+            g.min_ray = std::min(g.min_ray, in[i].min_ray); g.direct = g.direct | in[i].direct;
+        }
+    }
+    if (out) { if (*n_out < m.size()) { rts_set_error("rts_merge_groups: capacity too small"); *n_out = (uint32_t)m.size(); return RTS_ERR_CAPACITY; }
+               uint32_t j = 0; for (auto& kv : m) out[j++] = kv.second; }
+    *n_out = (uint32_t)m.size();
+    return RTS_OK;
+}
+
+// Responses the reference would emit (ray_tracer.cpp:1290-1321) from a complete group table:
+//   every non-direct group -> one response at its smallest ray, with the group means
+//   (aggregation.cu:88-93); a receiver's direct group -> pathMatch = smallest ray of ANY group
+//   at that receiver and sums over ALL its rays (aggregation.cu:56): emitted only if that
+//   smallest ray is itself direct, otherwise it collapses onto the reflected group (quirk 9).
+extern "C" int rts_groups_to_responses(const RtsGroup* groups, uint32_t n_groups, RtsResponse* out, uint32_t capacity, uint32_t* n_out)
+{
+    if ((!groups && n_groups) || !n_out) { rts_set_error("rts_groups_to_responses: null argument"); return RTS_ERR_INVALID; }
+    struct Tot { double n = 0, sp = 0, dl = 0, ph = 0, dp = 0; uint64_t mn = ~0ULL; bool mn_direct = false; bool has_direct = false; };
+    std::map<int32_t, Tot> tot;
+    for (uint32_t i = 0; i < n_groups; i++) {
+        Tot& t = tot[groups[i].rx];
+        t.n += groups[i].n; t.sp += groups[i].sum_sqrt_power; t.dl += groups[i].sum_delay; t.ph += groups[i].sum_phase; t.dp += groups[i].sum_doppler;
+        if (groups[i].min_ray < t.mn) { t.mn = groups[i].min_ray; t.mn_direct = groups[i].direct != 0; }
+        if (groups[i].direct) t.has_direct = true;
+    }
+    std::vector<RtsResponse> r;
+    for (uint32_t i = 0; i < n_groups; i++) {
+        const RtsGroup& g = groups[i];
+        RtsResponse q; q.rx = g.rx;
+        if (!g.direct) {
+            if (!(g.n > 0)) continue;
+            double v = g.sum_sqrt_power / g.n;
+            q.ray = g.min_ray; q.n = (uint32_t)g.n; q.power = v*v; q.delay = g.sum_delay / g.n; q.phase = g.sum_phase / g.n; q.doppler = g.sum_doppler / g.n;
+            r.push_back(q);
+        } else {
+            const Tot& t = tot[g.rx];
+            if (!t.mn_direct || !(t.n > 0)) continue;       // direct response lost (quirk 9) when a reflected ray has the smallest index
+            double v = t.sp / t.n;
+            q.ray = t.mn; q.n = (uint32_t)t.n; q.power = v*v; q.delay = t.dl / t.n; q.phase = t.ph / t.n; q.doppler = t.dp / t.n;
+            r.push_back(q);
+        }
+    }
+    std::sort(r.begin(), r.end(), [](const RtsResponse& a, const RtsResponse& b) { return a.ray < b.ray; });   // sort + unique of pathMatch (:1290-1292)
+    *n_out = (uint32_t)r.size();
+    if (out) { if (capacity < r.size()) { rts_set_error("rts_groups_to_responses: capacity too small"); return RTS_ERR_CAPACITY; }
+               if (!r.empty()) memcpy(out, r.data(), sizeof(RtsResponse)*r.size()); }
+    return RTS_OK;
+}
+
+// ------------------------------------------------------------------------------------- rs::kernel_wrapper
+static RtsContext* g_wrapper_ctx = nullptr;
+
+extern "C" int rts_kernel_wrapper(PerRayData* h_rx_results_arr, int* h_rx_intersects_arr, unsigned int receivedRays,
+                                  unsigned int depthTotal, unsigned int MaxThreads, unsigned int MaxBlocks, double cspeed,
+                                  double carrier, double* h_npath_arr, double* h_power_arr, double* h_doppler_arr,
+                                  double* h_delay_arr, double* h_phase_arr, int* h_pathMatch)
+{
+    (void)MaxThreads; (void)MaxBlocks;   // launch shapes are chosen by the library (aggregation.cu:142-160 picks them from these)
+    if (receivedRays == 0) return RTS_OK;
+    if (!h_rx_results_arr || (depthTotal && !h_rx_intersects_arr) || !h_delay_arr || !h_phase_arr || !h_pathMatch) { rts_set_error("rts_kernel_wrapper: null array"); return RTS_ERR_INVALID; }
+    if (!g_wrapper_ctx) {
+        RtsParams p; memset(&p, 0, sizeof(p)); p.width = 1; p.max_refl = 1;
+        int cur = 0; if (hipGetDevice(&cur) == hipSuccess) p.device = cur;
+        int rc = rts_create(&p, &g_wrapper_ctx); if (rc != RTS_OK) return rc;
+    }
+    RtsContext* c = g_wrapper_ctx;
+    RTS_HIP(hipSetDevice(c->device));
+    const size_t R = receivedRays, D = depthTotal;
+    RTS_HIP(c->d_rx_rays.reserve(R)); RTS_HIP(c->d_rx_paths.reserve(R*D + 1)); RTS_HIP(c->d_delay.reserve(R)); RTS_HIP(c->d_phase.reserve(R)); RTS_HIP(c->d_pathmatch.reserve(R));
+    RTS_HIP(c->d_rx_angles.reserve(3*R + 1));     // scratch: npath / power / doppler initial sums
+    hipStream_t st = c->stream;
+    RTS_HIP(hipMemcpyAsync(c->d_rx_rays.p, h_rx_results_arr, sizeof(PerRayData)*R, hipMemcpyHostToDevice, st));
+    if (D) RTS_HIP(hipMemcpyAsync(c->d_rx_paths.p, h_rx_intersects_arr, sizeof(int)*R*D, hipMemcpyHostToDevice, st));
+    RTS_HIP(hipMemcpyAsync(c->d_delay.p, h_delay_arr, sizeof(double)*R, hipMemcpyHostToDevice, st));
+    RTS_HIP(hipMemcpyAsync(c->d_phase.p, h_phase_arr, sizeof(double)*R, hipMemcpyHostToDevice, st));
+    RTS_HIP(hipMemcpyAsync(c->d_pathmatch.p, h_pathMatch, sizeof(int)*R, hipMemcpyHostToDevice, st));
+    double* d_np = nullptr; double* d_pw = nullptr; double* d_dp = nullptr;
+    if (h_npath_arr) { d_np = c->d_rx_angles.p; RTS_HIP(hipMemcpyAsync(d_np, h_npath_arr, sizeof(double)*R, hipMemcpyHostToDevice, st)); }
+    if (h_power_arr) { d_pw = c->d_rx_angles.p + R; RTS_HIP(hipMemcpyAsync(d_pw, h_power_arr, sizeof(double)*R, hipMemcpyHostToDevice, st)); }
+    if (h_doppler_arr) { d_dp = c->d_rx_angles.p + 2*R; RTS_HIP(hipMemcpyAsync(d_dp, h_doppler_arr, sizeof(double)*R, hipMemcpyHostToDevice, st)); }
+    int rc = rts_aggregate_device(c, nullptr, c->d_rx_paths.p, R, (uint32_t)D, cspeed, carrier, 0, c->d_rx_rays.p, c->d_delay.p, c->d_phase.p,
+                                  c->d_pathmatch.p, nullptr, d_np, d_pw, d_dp, INT32_MIN /* use the caller's h_pathMatch */);
+    if (rc != RTS_OK) return rc;
+    // copy back what the reference copies back (aggregation.cu:169-172)
+    RTS_HIP(hipMemcpyAsync(h_rx_results_arr, c->d_rx_rays.p, sizeof(PerRayData)*R, hipMemcpyDeviceToHost, st));
+    RTS_HIP(hipMemcpyAsync(h_delay_arr, c->d_delay.p, sizeof(double)*R, hipMemcpyDeviceToHost, st));
+    RTS_HIP(hipMemcpyAsync(h_phase_arr, c->d_phase.p, sizeof(double)*R, hipMemcpyDeviceToHost, st));
+    RTS_HIP(hipMemcpyAsync(h_pathMatch, c->d_pathmatch.p, sizeof(int)*R, hipMemcpyDeviceToHost, st));
+    RTS_HIP(hipStreamSynchronize(st));
+    return RTS_OK;
+}
+
+// the C++ symbol the reference's caller links against (aggregation.cuh:19-22)
+namespace rs {
+void kernel_wrapper(PerRayData* h_rx_results_arr, int* h_rx_intersects_arr, unsigned int receivedRays, unsigned int depthTotal,
+                    unsigned int MaxThreads, unsigned int MaxBlocks, double cspeed, double carrier, double* h_npath_arr,
+                    double* h_power_arr, double* h_doppler_arr, double* h_delay_arr, double* h_phase_arr, int* h_pathMatch)
+{
+    int rc = rts_kernel_wrapper(h_rx_results_arr, h_rx_intersects_arr, receivedRays, depthTotal, MaxThreads, MaxBlocks, cspeed, carrier,
+                                h_npath_arr, h_power_arr, h_doppler_arr, h_delay_arr, h_phase_arr, h_pathMatch);
+    if (rc != RTS_OK) fprintf(stderr, "rs::kernel_wrapper: %s\n", rts_last_error());   // the reference prints and exit(1)s (aggregation.cu:17-27)
+}
+}
+
+// ------------------------------------------------------------------------------------- introspection
+extern "C" int rts_get_bvh(RtsHandle c, void* nodes64, uint32_t* leaf_prim, uint32_t node_capacity, uint32_t prim_capacity)
+{
+    CHECK_HANDLE(c);
+    if (!c->bvh_valid) { rts_set_error("rts_get_bvh: no BVH built yet"); return RTS_ERR_INVALID; }
+    if (node_capacity < c->n_nodes || prim_capacity < c->n_prims) { rts_set_error("rts_get_bvh: capacity too small"); return RTS_ERR_CAPACITY; }
+    RTS_HIP(hipStreamSynchronize(c->stream));
+    if (nodes64 && c->n_nodes) RTS_HIP(hipMemcpy(nodes64, c->d_nodes.p, sizeof(RtsNode)*c->n_nodes, hipMemcpyDeviceToHost));
+    if (leaf_prim && c->n_prims) RTS_HIP(hipMemcpy(leaf_prim, c->d_vals_sorted.p, sizeof(uint32_t)*c->n_prims, hipMemcpyDeviceToHost));
+    return RTS_OK;
+}
+
+__global__ void k_self_test_math(const float* y, const float* x, float* at, const double* a, const double* b, double* dv, double* sq, uint32_t n)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    at[i] = rts_atan2f(y[i], x[i]);
+    dv[i] = a[i] / b[i];
+    sq[i] = sqrt(fabs(a[i]));
+}
+
+extern "C" int rts_self_test_math(RtsHandle c, const float* y, const float* x, float* atan2f_out, const double* a, const double* b,
+                                  double* div_out, double* sqrt_out, uint32_t n)
+{
+    CHECK_HANDLE(c);
+    if (n == 0) return RTS_OK;
+    float *dy, *dx, *dat; double *da, *db, *ddv, *dsq;
+    RTS_HIP(hipMalloc((void**)&dy, 4*n)); RTS_HIP(hipMalloc((void**)&dx, 4*n)); RTS_HIP(hipMalloc((void**)&dat, 4*n));
+    RTS_HIP(hipMalloc((void**)&da, 8*n)); RTS_HIP(hipMalloc((void**)&db, 8*n)); RTS_HIP(hipMalloc((void**)&ddv, 8*n)); RTS_HIP(hipMalloc((void**)&dsq, 8*n));
+    RTS_HIP(hipMemcpy(dy, y, 4*n, hipMemcpyHostToDevice)); RTS_HIP(hipMemcpy(dx, x, 4*n, hipMemcpyHostToDevice));
+    RTS_HIP(hipMemcpy(da, a, 8*n, hipMemcpyHostToDevice)); RTS_HIP(hipMemcpy(db, b, 8*n, hipMemcpyHostToDevice));
+    k_self_test_math<<<(n + 255)/256, 256, 0, c->stream>>>(dy, dx, dat, da, db, ddv, dsq, n);
+    RTS_HIP(hipGetLastError()); RTS_HIP(hipStreamSynchronize(c->stream));
+    RTS_HIP(hipMemcpy(atan2f_out, dat, 4*n, hipMemcpyDeviceToHost)); RTS_HIP(hipMemcpy(div_out, ddv, 8*n, hipMemcpyDeviceToHost)); RTS_HIP(hipMemcpy(sqrt_out, dsq, 8*n, hipMemcpyDeviceToHost));
+    (void)hipFree(dy); (void)hipFree(dx); (void)hipFree(dat); (void)hipFree(da); (void)hipFree(db); (void)hipFree(ddv); (void)hipFree(dsq);
+    return RTS_OK;
+}

@@ -1,0 +1,162 @@
+// rts_internal.h -- device-side data layout and the host context of librts_amd.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/rts_amd.h"
+#include "rts_device_math.h"
+
+// ----------------------------------------------------------------------------- HBM layout
+// BVH2 node, 64 B = one half cache line, fetched as 4 x dwordx4 by the lane that visits it.
+// A node stores the (padded, f32) boxes of its two children, so one fetch decides both.
+struct __attribute__((aligned(64))) RtsNode {
+    float lo0x, lo0y, lo0z, hi0x;   // q0
+    float hi0y, hi0z, lo1x, lo1y;   // q1
+    float lo1z, hi1x, hi1y, hi1z;   // q2
+    int32_t c0, c1;                 // q3: child >= 0 -> node index, < 0 -> ~leaf index
+    int32_t pad0, pad1;
+};
+static_assert(sizeof(RtsNode) == 64, "node size");
+
+// Leaf record, 80 B, in Morton (leaf) order: the three f64 vertices the f64 intersection
+// test needs, pre-gathered (the reference gathers through dbuf_triangles ->
+// dbuf_triVertices per test, triangle_mesh.cu:147-154), plus the global primitive id.
+struct __attribute__((aligned(16))) RtsLeafTri {
+    double p0x, p0y, p0z, p1x, p1y, p1z, p2x, p2y, p2z;
+    uint32_t prim;                  // global primitive id (targets concatenated in order)
+    uint32_t targ;                  // target index
+};
+static_assert(sizeof(RtsLeafTri) == 80, "leaf size");
+
+struct RtsTargetDev {               // per target, per pulse
+    double reflCoeff;               // d_targReflCoeff
+    double vx, vy, vz;              // dbuf_targ_vel[targ]
+    uint32_t tri_base;              // first global primitive id
+    uint32_t perface_normals;       // triangle_mesh.cu:178 (normals.size() > vertices.size())
+    uint32_t pad0, pad1;
+};
+
+struct RtsRxDev { double cx, cy, cz, radius, minTheta, maxTheta, minPhi, maxPhi; };
+
+// End-of-ray record written by the trace kernel (received rays; every ray in KEEP_ALL mode).
+struct __attribute__((aligned(16))) RtsEndRecord {
+    double rayLength, power, doppler;
+    double prevx, prevy, prevz;
+    double firstx, firsty, firstz;
+    uint64_t path_lo, path_hi;      // (targ + 1) per depth, 8 bits each, depth 0 in the low byte
+    uint32_t slot;                  // local launch index (ray_first + slot = global index)
+    int32_t received;
+    uint32_t reflDepth;
+    uint32_t pad;
+};
+static_assert(sizeof(RtsEndRecord) == 112, "end record size");
+
+#define RTS_BLOCK 256
+#define RTS_STACK_LDS 24            // traversal stack entries kept in LDS per lane
+#define RTS_STACK_OVF 80            // further entries spilled to global memory (rare)
+
+struct RtsTraceArgs {
+    // launch constants (hoisted ray_generation trig, ray_tracer.cu:155-203)
+    double ox, oy, oz;              // d_rayOrigin
+    double bsx, bsy, bsz;           // beamStart
+    double stx, sty, stz;           // lattice step per launch index
+    double rot[9];                  // Rot  (azimuth)
+    double rot1[9];                 // Rot1 (elevation about the rotated y axis)
+    double w1x, w1y, w1z;           // direction for W == 1
+    uint64_t ray_first;
+    uint32_t n_rays, W;
+    uint32_t max_refl, smooth;
+    uint32_t n_prims, n_targets, n_rx, keep_all;
+    // scene
+    const RtsNode* nodes;
+    const RtsLeafTri* leaves;
+    const uint32_t* tri_nidx;       // [n_prims][3] indices into normals
+    const double* normals;          // world-space normals [.][3]
+    const RtsTargetDev* targets;
+    const RtsRxDev* rx;
+    // outputs
+    RtsEndRecord* recv_records;     // appended (unordered), capacity n_rays
+    RtsEndRecord* all_records;      // [n_rays] (keep_all)
+    unsigned long long* counters;   // [0] recv count [1] segments [2] shaded [3] node visits [4] tri tests [5] spills [6] hard overflow
+    float* dir_hist;                // [max_refl][3][n_rays] reflected directions (f32)
+    int32_t* hit_prim;              // [n_rays][max_refl+1] (keep_all)
+    float* hit_t;                   // [n_rays][max_refl+1] (keep_all)
+    int32_t* stack_ovf;             // [RTS_STACK_OVF][grid threads]
+    uint32_t total_threads;
+};
+
+// ----------------------------------------------------------------------------- host context
+struct RtsMeshHost {
+    uint32_t n_tris, n_verts, n_normals;
+    uint32_t tri_base, vert_base, normal_base;
+    double refl_coeff, refr_index;
+    bool perface;
+};
+
+template <typename T> struct DevBuf {
+    T* p = nullptr; size_t cap = 0;
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = n + n / 8 + 16;
+        hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct RtsContext {
+    RtsParams params;
+    uint32_t depth;                 // D = max_refr + max_refl
+    int device;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8];
+    // scene (static part)
+    std::vector<RtsMeshHost> meshes;
+    uint32_t n_prims = 0, n_verts = 0, n_normals = 0;
+    DevBuf<uint32_t> d_tri_vidx, d_tri_nidx, d_vert_targ, d_norm_targ, d_prim_targ;
+    DevBuf<double> d_verts_local, d_normals_local, d_verts_world, d_normals_world;
+    std::vector<RtsTargetMotion> motion; bool motion_valid = false; bool bvh_valid = false;
+    DevBuf<RtsTargetMotion> d_motion;
+    DevBuf<RtsTargetDev> d_targets;
+    // BVH
+    DevBuf<float> d_prim_box, d_node_box; DevBuf<uint64_t> d_keys, d_keys_sorted; DevBuf<uint32_t> d_vals, d_vals_sorted;
+    DevBuf<uint32_t> d_bounds; DevBuf<int32_t> d_parent, d_leaf_parent; DevBuf<uint32_t> d_flags;
+    DevBuf<RtsNode> d_nodes; DevBuf<RtsLeafTri> d_leaves; DevBuf<char> d_sort_tmp;
+    uint32_t n_nodes = 0;
+    // receivers
+    DevBuf<RtsRxDev> d_rx; uint32_t n_rx = 0;
+    // per pulse
+    uint64_t ray_first = 0; uint32_t n_rays = 0;
+    DevBuf<RtsEndRecord> d_recv, d_all; DevBuf<unsigned long long> d_counters; DevBuf<float> d_dir_hist;
+    DevBuf<int32_t> d_hit_prim; DevBuf<float> d_hit_t; DevBuf<int32_t> d_stack_ovf;
+    RtsTraceArgs last_args;
+    // received set (ordered, expanded)
+    uint64_t n_recv = 0;
+    DevBuf<uint32_t> d_rk, d_rk_sorted, d_ri, d_ri_sorted;
+    DevBuf<PerRayData> d_rx_rays; DevBuf<int32_t> d_rx_paths; DevBuf<double> d_rx_angles; DevBuf<uint64_t> d_rx_slots;
+    DevBuf<PerRayData> d_all_rays; DevBuf<int32_t> d_all_paths; DevBuf<double> d_all_angles;
+    // aggregation
+    DevBuf<uint64_t> d_akeys, d_akeys_sorted; DevBuf<uint32_t> d_aidx, d_aidx_sorted; DevBuf<uint32_t> d_ghead, d_gid;
+    DevBuf<double> d_gsum; DevBuf<uint32_t> d_gmin; DevBuf<uint64_t> d_gkey; DevBuf<uint32_t> d_gcount;
+    DevBuf<double> d_delay, d_phase; DevBuf<int32_t> d_pathmatch; DevBuf<double> d_rcs;
+    std::vector<RtsGroup> groups; bool agg_valid = false; uint64_t recv_index_base = 0;
+    RtsStats stats;
+};
+
+// implemented in the .hip units
+int rts_bvh_build(RtsContext* c);
+int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a, bool count_traversal);
+int rts_post_order_and_expand(RtsContext* c);
+int rts_post_expand_all(RtsContext* c);
+int rts_post_finalise(RtsContext* c, const double* rcs_host, double wl, double gt, double gr, double carrier, double cspeed);
+int rts_aggregate_device(RtsContext* c, const PerRayData* d_rays, const int32_t* d_paths, uint64_t R, uint32_t D,
+                         double cspeed, double carrier, uint64_t base, PerRayData* d_rays_out, double* d_delay,
+                         double* d_phase, int32_t* d_pm, std::vector<RtsGroup>* groups, double* d_npath,
+                         double* d_power_sum, double* d_doppler_sum, int32_t pm_init);
+void rts_set_error(const char* fmt, ...);
+
+#define RTS_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    rts_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return RTS_ERR_HIP; } } while (0)

@@ -1,0 +1,372 @@
+// rts_post.hip -- everything after the trace kernel, on the device:
+//   * ordering of the received rays by launch index and expansion into the reference's
+//     output records (PerRayData + path row + RCS-angle row)        ray_tracer.cpp:1180-1257
+//   * the uniform-gain finalisation                                  ray_tracer.cpp:1219-1253
+//   * the aggregation (myKernel1/myKernel2 + unique paths) as a sort / group-by instead of
+//     the reference's O(R^2 D) all-pairs scan                        aggregation.cu:32-97
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+#include "rts_internal.h"
+#include "rts_raygen.h"
+
+static inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+
+// --------------------------------------------------------------------------- record expansion
+__global__ void k_recv_keys(const RtsEndRecord* __restrict__ rec, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t n)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { keys[i] = rec[i].slot; vals[i] = i; }
+}
+
+// cart_to_sph, normal_shader.cu:118-124
+__device__ __forceinline__ void cart_to_sph(dvec3 v, double& az, double& el) { az = atan2(v.y, v.x); el = atan2(v.z, sqrt(v.x*v.x + v.y*v.y)); }
+
+// One thread per output row j.  perm == nullptr: row j is record j (keep-all buffers, row == launch
+// index); otherwise row j is record perm[j] (received rays in ascending launch index).
+__global__ void k_expand(const RtsTraceArgs a, const RtsEndRecord* __restrict__ rec, const uint32_t* __restrict__ perm, uint32_t n, uint32_t D,
+                         PerRayData* __restrict__ rays, int32_t* __restrict__ paths, double* __restrict__ angles, uint64_t* __restrict__ slots)
+{
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const RtsEndRecord r = rec[perm ? perm[j] : j];
+    // dbuf_results[rayIndex] as left by ray_generation: initialised fields (ray_tracer.cu:227-240)
+    // overwritten by the eight written-back ones (:246-253)
+    PerRayData o;
+    __builtin_memset(&o, 0, sizeof(o));
+    o.rayLength = r.rayLength; o.refrIndex.x = 1; o.refrIndex.y = 1;
+    o.reflDepth = r.reflDepth; o.refrDepth = 0; o.maxRayIndex = 0;
+    o.firstHitPoint.x = r.firstx; o.firstHitPoint.y = r.firsty; o.firstHitPoint.z = r.firstz;
+    o.prevHitPoint.x = r.prevx; o.prevHitPoint.y = r.prevy; o.prevHitPoint.z = r.prevz;
+    o.power = r.power; o.doppler = r.doppler; o.received = r.received; o.end = false;
+    rays[j] = o;
+    if (slots) slots[j] = a.ray_first + r.slot;
+    // path row: dbuf_targ_intersect[row][col], -1 default (ray_tracer.cpp:854-857, normal_shader.cu:140-146)
+    for (uint32_t col = 0; col < D; col++) {
+        int code = 0;
+        if (col < 8) code = (int)((r.path_lo >> (8*col)) & 0xff); else if (col < 16) code = (int)((r.path_hi >> (8*(col-8))) & 0xff);
+        paths[(size_t)j*D + col] = code - 1;
+    }
+    // RCS angle row (normal_shader.cu:320-326): tAngle = sph(k0) + sph(-k1) per reflection,
+    // -1e6 default (ray_tracer.cpp:861-867); k0/k1 rebuilt from the f32 direction history
+    dvec3 kin = unit3(rts_primary_dir(a, r.slot));
+    for (uint32_t col = 0; col < D; col++) {
+        double ax = -1000000, ay = -1000000;
+        if (col < r.reflDepth) {
+            const float* dh = a.dir_hist + (size_t)col * 3 * a.n_rays;
+            const dvec3 k1 = unit3(mk3((double)dh[r.slot], (double)dh[(size_t)a.n_rays + r.slot], (double)dh[2*(size_t)a.n_rays + r.slot]));
+            double a0, e0, a1, e1;
+            cart_to_sph(kin, a0, e0);
+            cart_to_sph(mk3(-k1.x, -k1.y, -k1.z), a1, e1);
+            ax = a0 + a1; ay = e0 + e1;
+            kin = k1;
+        }
+        angles[((size_t)j*D + col)*2] = ax; angles[((size_t)j*D + col)*2 + 1] = ay;
+    }
+}
+
+__global__ void k_fill_i32(int32_t* p, int32_t v, size_t n) { size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
+int rts_fill_i32(hipStream_t st, int32_t* p, int32_t v, size_t n) { if (n) k_fill_i32<<<blocks_for(n, 256), 256, 0, st>>>(p, v, n); return RTS_OK; }
+
+int rts_post_order_and_expand(RtsContext* c)
+{
+    const uint32_t R = (uint32_t)c->n_recv, D = c->depth;
+    if (R == 0) return RTS_OK;
+    hipStream_t st = c->stream;
+    RTS_HIP(c->d_rk.reserve(R)); RTS_HIP(c->d_rk_sorted.reserve(R)); RTS_HIP(c->d_ri.reserve(R)); RTS_HIP(c->d_ri_sorted.reserve(R));
+    RTS_HIP(c->d_rx_rays.reserve(R)); RTS_HIP(c->d_rx_paths.reserve((size_t)R*D + 1)); RTS_HIP(c->d_rx_angles.reserve((size_t)R*D*2 + 1)); RTS_HIP(c->d_rx_slots.reserve(R));
+    k_recv_keys<<<blocks_for(R, 256), 256, 0, st>>>(c->d_recv.p, c->d_rk.p, c->d_ri.p, R);
+    size_t tmp = 0;
+    RTS_HIP(rocprim::radix_sort_pairs(nullptr, tmp, c->d_rk.p, c->d_rk_sorted.p, c->d_ri.p, c->d_ri_sorted.p, R, 0, 32, st));
+    RTS_HIP(c->d_sort_tmp.reserve(tmp));
+    RTS_HIP(rocprim::radix_sort_pairs(c->d_sort_tmp.p, tmp, c->d_rk.p, c->d_rk_sorted.p, c->d_ri.p, c->d_ri_sorted.p, R, 0, 32, st));
+    k_expand<<<blocks_for(R, 256), 256, 0, st>>>(c->last_args, c->d_recv.p, c->d_ri_sorted.p, R, D, c->d_rx_rays.p, c->d_rx_paths.p, c->d_rx_angles.p, c->d_rx_slots.p);
+    RTS_HIP(hipGetLastError());
+    return RTS_OK;
+}
+
+int rts_post_expand_all(RtsContext* c)
+{
+    const uint32_t n = c->n_rays, D = c->depth;
+    if (n == 0) return RTS_OK;
+    RTS_HIP(c->d_all_rays.reserve(n)); RTS_HIP(c->d_all_paths.reserve((size_t)n*D + 1)); RTS_HIP(c->d_all_angles.reserve((size_t)n*D*2 + 1));
+    k_expand<<<blocks_for(n, 256), 256, 0, c->stream>>>(c->last_args, c->d_all.p, nullptr, n, D, c->d_all_rays.p, c->d_all_paths.p, c->d_all_angles.p, nullptr);
+    RTS_HIP(hipGetLastError());
+    return RTS_OK;
+}
+
+// --------------------------------------------------------------------------- uniform finalisation, ray_tracer.cpp:1219-1253
+__global__ void k_finalise(PerRayData* __restrict__ rays, const int32_t* __restrict__ paths, uint32_t R, uint32_t D,
+                           const double* __restrict__ rcs, uint32_t n_targets, double wl, double gt, double gr, double carrier, double cspeed)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    double power = rays[i].power;
+    for (uint32_t k = 0; k < D; k++) {
+        int targ_k = paths[(size_t)i*D + k];
+        if (targ_k >= 0) { double targRCS = ((uint32_t)targ_k < n_targets) ? rcs[targ_k] : 1.0; power *= targRCS; }   // :1225-1229
+    }
+    power *= (wl*wl*gt*gr);                                                  // :1247
+    double Vr = rays[i].doppler/2;                                           // :1252
+    rays[i].doppler = carrier*(((1 + Vr/cspeed)/(1 - Vr/cspeed)) - 1);       // :1253
+    rays[i].power = power;
+}
+
+int rts_post_finalise(RtsContext* c, const double* rcs_host, double wl, double gt, double gr, double carrier, double cspeed)
+{
+    const uint32_t R = (uint32_t)c->n_recv;
+    if (R == 0) return RTS_OK;
+    const uint32_t nt = (uint32_t)c->meshes.size();
+    RTS_HIP(c->d_rcs.reserve(nt + 1));
+    if (nt) RTS_HIP(hipMemcpyAsync(c->d_rcs.p, rcs_host, sizeof(double)*nt, hipMemcpyHostToDevice, c->stream));
+    k_finalise<<<blocks_for(R, 256), 256, 0, c->stream>>>(c->d_rx_rays.p, c->d_rx_paths.p, R, c->depth, c->d_rcs.p, nt, wl, gt, gr, carrier, cspeed);
+    RTS_HIP(hipGetLastError());
+    return RTS_OK;
+}
+
+// --------------------------------------------------------------------------- aggregation (group-by)
+// key = rx << (D*B) | sum_k (path[k] + 1) << (k*B): equal keys <=> same receiver and identical
+// path row, which is the row_equal test of myKernel1 (aggregation.cu:46-53).
+__global__ void k_agg_keys(const PerRayData* __restrict__ rays, const int32_t* __restrict__ paths, uint32_t R, uint32_t D, uint32_t B,
+                           uint64_t* __restrict__ keys, uint32_t* __restrict__ idx)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    uint64_t k = 0;
+    for (uint32_t c = 0; c < D; c++) k |= (uint64_t)(uint32_t)(paths[(size_t)i*D + c] + 1) << (c*B);
+    k |= (uint64_t)(uint32_t)rays[i].received << (D*B);
+    keys[i] = k; idx[i] = i;
+}
+
+__global__ void k_agg_heads(const uint64_t* __restrict__ keys, uint32_t* __restrict__ head, uint32_t R)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < R) head[i] = (i == 0 || keys[i] != keys[i-1]) ? 1u : 0u;
+}
+
+// group start positions: gstart[gid] = i for head elements; gstart[G] = R
+__global__ void k_agg_starts(const uint32_t* __restrict__ head, const uint32_t* __restrict__ gid_incl, uint32_t* __restrict__ gstart, uint32_t R)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < R && head[i]) gstart[gid_incl[i] - 1] = i;
+    if (i == R - 1) gstart[gid_incl[i]] = R;
+}
+
+#define AGG_TILE 256
+// Per-ray contributions (aggregation.cu:59-65) summed per group with a FIXED reduction shape
+// (segmented Hillis-Steele scan inside 256-element tiles, then tile partials in tile order), so
+// the f64 sums are reproducible run to run.  vals: 5 doubles {n, sqrt(power), delay, phase, doppler}.
+__global__ void __launch_bounds__(AGG_TILE) k_agg_tiles(const PerRayData* __restrict__ rays, const uint32_t* __restrict__ idx_sorted,
+        const uint32_t* __restrict__ gid_incl, const uint32_t* __restrict__ gstart, uint32_t R, double cspeed, double carrier,
+        double* __restrict__ gsum, double* __restrict__ tile_first, double* __restrict__ tile_last)
+{
+    __shared__ double s_v[2][5][AGG_TILE];
+    __shared__ uint32_t s_g[AGG_TILE];
+    const uint32_t t = threadIdx.x, tile = blockIdx.x, i = tile * AGG_TILE + t;
+    const bool valid = i < R;
+    uint32_t g = 0xffffffffu;
+    double v[5] = {0, 0, 0, 0, 0};
+    if (valid) {
+        const PerRayData r = rays[idx_sorted[i]];
+        g = gid_incl[i] - 1;
+        const double delay = (r.rayLength)/cspeed;                            // aggregation.cu:59
+        const double phase = -fmod(delay*2*RTS_PI*carrier, 2*RTS_PI);         // :60
+        v[0] = 1; v[1] = sqrt(r.power); v[2] = delay; v[3] = phase; v[4] = r.doppler;
+    }
+    s_g[t] = g;
+    for (int k = 0; k < 5; k++) s_v[0][k][t] = v[k];
+    __syncthreads();
+    int cur = 0;
+    for (uint32_t off = 1; off < AGG_TILE; off <<= 1) {
+        const bool take = (t >= off) && (s_g[t - off] == g);
+        for (int k = 0; k < 5; k++) {
+            double x = s_v[cur][k][t];
+            if (take) x = s_v[cur][k][t - off] + x;
+            s_v[cur ^ 1][k][t] = x;
+        }
+        cur ^= 1;
+        __syncthreads();
+    }
+    if (!valid) return;
+    const bool run_end = (t == AGG_TILE - 1) || (i == R - 1) || (s_g[t + 1] != g);
+    if (!run_end) return;
+    const uint32_t gs = gstart[g], ge = gstart[g + 1];
+    const uint32_t tile_lo = tile * AGG_TILE, tile_hi = tile_lo + AGG_TILE;
+    double* dst;
+    if (gs >= tile_lo && ge <= tile_hi) dst = gsum + 5*(size_t)g;            // group lies inside this tile: final
+    else if (gs < tile_lo) dst = tile_first + 5*(size_t)tile;                // run continues from the previous tile
+    else dst = tile_last + 5*(size_t)tile;                                   // run continues into the next tile
+    for (int k = 0; k < 5; k++) dst[k] = s_v[cur][k][t];
+}
+
+// groups spanning several tiles: partials added in tile order by one wave, fixed shape
+__global__ void __launch_bounds__(64) k_agg_span(const uint32_t* __restrict__ gstart, uint32_t G, const double* __restrict__ tile_first,
+                                                  const double* __restrict__ tile_last, double* __restrict__ gsum)
+{
+    const uint32_t g = blockIdx.x, lane = threadIdx.x;
+    if (g >= G) return;
+    const uint32_t gs = gstart[g], ge = gstart[g + 1];
+    const uint32_t T0 = gs / AGG_TILE, T1 = (ge - 1) / AGG_TILE;
+    if (T0 == T1) return;
+    double acc[5] = {0, 0, 0, 0, 0};
+    // pieces in order: piece 0 = the run that starts in T0 (stored as that tile's "last" partial),
+    // pieces 1.. = tiles T0+1 .. T1 (each that tile's "first" partial)
+    const uint32_t npieces = T1 - T0 + 1;
+    for (uint32_t p = lane; p < npieces; p += 64) {
+        const double* src = (p == 0) ? tile_last + 5*(size_t)T0 : tile_first + 5*(size_t)(T0 + p);
+        for (int k = 0; k < 5; k++) acc[k] += src[k];
+    }
+    for (int off = 32; off > 0; off >>= 1) for (int k = 0; k < 5; k++) acc[k] += __shfl_down(acc[k], off);
+    if (lane == 0) for (int k = 0; k < 5; k++) gsum[5*(size_t)g + k] = acc[k];
+}
+
+__global__ void k_agg_groupinfo(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ idx_sorted, const uint64_t* __restrict__ keys_sorted,
+                                uint32_t G, uint32_t* __restrict__ gmin, uint64_t* __restrict__ gkey)
+{
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    gmin[g] = idx_sorted[gstart[g]];          // stable sort: first element of the run has the smallest ray index
+    gkey[g] = keys_sorted[gstart[g]];
+}
+
+// myKernel1's per-ray totals + myKernel2 (aggregation.cu:56-69, 88-93), scattered back per ray.
+// rxtot: per receiver {n, sum sqrt p, sum delay, sum phase, sum doppler}, rxmin: smallest ray index.
+__global__ void k_agg_scatter(PerRayData* __restrict__ rays, const uint32_t* __restrict__ idx_sorted, const uint32_t* __restrict__ gid_incl,
+                              const double* __restrict__ gsum, const uint32_t* __restrict__ gmin, const double* __restrict__ rxtot,
+                              const uint32_t* __restrict__ rxmin, uint32_t n_rx_tab, uint32_t R, int64_t base,
+                              const double* __restrict__ npath0, const double* __restrict__ power0, const double* __restrict__ doppler0,
+                              double* __restrict__ delay, double* __restrict__ phase, int32_t* __restrict__ pm, int32_t pm_init_const, int use_pm_in)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    const uint32_t r = idx_sorted[i], g = gid_incl[i] - 1;
+    PerRayData ray = rays[r];
+    const bool direct = (ray.reflDepth == 0) && (ray.refrDepth == 0);
+    const double* s; uint32_t mn;
+    const uint32_t rx = (uint32_t)ray.received;
+    if (direct && rx < n_rx_tab) { s = rxtot + 5*(size_t)rx; mn = rxmin[rx]; } else { s = gsum + 5*(size_t)g; mn = gmin[g]; }
+    const double npath = (npath0 ? npath0[r] : 0.0) + s[0];
+    const double psum = (power0 ? power0[r] : 0.0) + s[1];
+    const double dsum = delay[r] + s[2];
+    const double phsum = phase[r] + s[3];
+    const double dopsum = (doppler0 ? doppler0[r] : 0.0) + s[4];
+    double dly = dsum, ph = phsum;
+    if (npath > 0) {                                                          // myKernel2
+        const double v = psum/npath;
+        ray.power = v*v;                                                      // pow(x, 2)
+        dly = dsum/npath; ph = phsum/npath;
+        ray.doppler = dopsum/npath;
+        rays[r].power = ray.power; rays[r].doppler = ray.doppler;
+    }
+    delay[r] = dly; phase[r] = ph;
+    const int64_t m = base + (int64_t)mn;
+    const int32_t prev = use_pm_in ? pm[r] : pm_init_const;
+    pm[r] = (m < (int64_t)prev) ? (int32_t)m : prev;                          // if (r < d_pathMatch[i]) d_pathMatch[i] = r
+}
+
+// Aggregates R device-resident rays.  d_delay/d_phase/d_pm are in-out (initial values as the
+// caller's h_delay_arr/h_phase_arr/h_pathMatch); d_npath/d_power_sum/d_doppler_sum optional
+// initial values (read only).  groups (optional) receives the host copy of the group table.
+int rts_aggregate_device(RtsContext* c, const PerRayData* d_rays_in, const int32_t* d_paths, uint64_t R64, uint32_t D,
+                         double cspeed, double carrier, uint64_t base, PerRayData* d_rays, double* d_delay,
+                         double* d_phase, int32_t* d_pm, std::vector<RtsGroup>* groups, double* d_npath,
+                         double* d_power_sum, double* d_doppler_sum, int32_t pm_init)
+{
+    (void)d_rays_in;
+    if (groups) groups->clear();
+    if (R64 == 0) return RTS_OK;
+    if (R64 > 0x7fffffffULL) { rts_set_error("aggregate: more than 2^31 received rays"); return RTS_ERR_UNSUPPORTED; }
+    const uint32_t R = (uint32_t)R64;
+    hipStream_t st = c->stream;
+    // key packing: B bits per path entry, the rest for the receiver index
+    int32_t maxv[2] = {0, 0};
+    {
+        // max path entry and max receiver index decide the packing; computed with a rocPRIM reduce
+        struct MaxOp { __device__ int32_t operator()(int32_t a, int32_t b) const { return a > b ? a : b; } };
+        RTS_HIP(c->d_gcount.reserve(4));
+        size_t tmp = 0;
+        if ((size_t)R * D > 0) {
+            RTS_HIP(rocprim::reduce(nullptr, tmp, d_paths, (int32_t*)c->d_gcount.p, (int32_t)-1, (size_t)R * D, MaxOp(), st));
+            RTS_HIP(c->d_sort_tmp.reserve(tmp));
+            RTS_HIP(rocprim::reduce(c->d_sort_tmp.p, tmp, d_paths, (int32_t*)c->d_gcount.p, (int32_t)-1, (size_t)R * D, MaxOp(), st));
+            RTS_HIP(hipMemcpyAsync(&maxv[0], c->d_gcount.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        } else maxv[0] = -1;
+        auto rx_it = rocprim::make_transform_iterator(d_rays, [] __device__ (const PerRayData& r) { return r.received; });
+        RTS_HIP(rocprim::reduce(nullptr, tmp, rx_it, (int32_t*)c->d_gcount.p + 1, (int32_t)0, (size_t)R, MaxOp(), st));
+        RTS_HIP(c->d_sort_tmp.reserve(tmp));
+        RTS_HIP(rocprim::reduce(c->d_sort_tmp.p, tmp, rx_it, (int32_t*)c->d_gcount.p + 1, (int32_t)0, (size_t)R, MaxOp(), st));
+        RTS_HIP(hipMemcpyAsync(&maxv[1], (int32_t*)c->d_gcount.p + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        RTS_HIP(hipStreamSynchronize(st));
+    }
+    uint32_t B = 1; while (((uint64_t)1 << B) < (uint64_t)(maxv[0] + 2)) B++;
+    uint32_t RXB = 1; while (((uint64_t)1 << RXB) < (uint64_t)(maxv[1] + 1)) RXB++;
+    if (D == 0) B = 0;
+    if ((uint64_t)D * B + RXB > 64 || D > RTS_MAX_DEPTH) {
+        rts_set_error("aggregate: (receiver, path) key needs %u x %u + %u bits > 64 or depth > %d", D, B, RXB, RTS_MAX_DEPTH);
+        return RTS_ERR_UNSUPPORTED;
+    }
+    const uint32_t key_bits = D * B + RXB;
+    RTS_HIP(c->d_akeys.reserve(R)); RTS_HIP(c->d_akeys_sorted.reserve(R)); RTS_HIP(c->d_aidx.reserve(R)); RTS_HIP(c->d_aidx_sorted.reserve(R));
+    RTS_HIP(c->d_ghead.reserve(R)); RTS_HIP(c->d_gid.reserve(R));
+    k_agg_keys<<<blocks_for(R, 256), 256, 0, st>>>(d_rays, d_paths, R, D, B, c->d_akeys.p, c->d_aidx.p);
+    size_t tmp = 0;
+    RTS_HIP(rocprim::radix_sort_pairs(nullptr, tmp, c->d_akeys.p, c->d_akeys_sorted.p, c->d_aidx.p, c->d_aidx_sorted.p, R, 0, key_bits, st));
+    RTS_HIP(c->d_sort_tmp.reserve(tmp));
+    RTS_HIP(rocprim::radix_sort_pairs(c->d_sort_tmp.p, tmp, c->d_akeys.p, c->d_akeys_sorted.p, c->d_aidx.p, c->d_aidx_sorted.p, R, 0, key_bits, st));
+    k_agg_heads<<<blocks_for(R, 256), 256, 0, st>>>(c->d_akeys_sorted.p, c->d_ghead.p, R);
+    RTS_HIP(rocprim::inclusive_scan(nullptr, tmp, c->d_ghead.p, c->d_gid.p, R, rocprim::plus<uint32_t>(), st));
+    RTS_HIP(c->d_sort_tmp.reserve(tmp));
+    RTS_HIP(rocprim::inclusive_scan(c->d_sort_tmp.p, tmp, c->d_ghead.p, c->d_gid.p, R, rocprim::plus<uint32_t>(), st));
+    uint32_t G = 0;
+    RTS_HIP(hipMemcpyAsync(&G, c->d_gid.p + (R - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    RTS_HIP(hipStreamSynchronize(st));
+    const uint32_t ntiles = blocks_for(R, AGG_TILE);
+    // d_gcount reused as gstart [G+1]
+    RTS_HIP(c->d_gcount.reserve((size_t)G + 2)); RTS_HIP(c->d_gsum.reserve(5*((size_t)G + 2*(size_t)ntiles) + 16));
+    RTS_HIP(c->d_gmin.reserve(G)); RTS_HIP(c->d_gkey.reserve(G));
+    uint32_t* gstart = c->d_gcount.p;
+    double* gsum = c->d_gsum.p; double* tile_first = gsum + 5*(size_t)G; double* tile_last = tile_first + 5*(size_t)ntiles;
+    k_agg_starts<<<blocks_for(R, 256), 256, 0, st>>>(c->d_ghead.p, c->d_gid.p, gstart, R);
+    k_agg_tiles<<<ntiles, AGG_TILE, 0, st>>>(d_rays, c->d_aidx_sorted.p, c->d_gid.p, gstart, R, cspeed, carrier, gsum, tile_first, tile_last);
+    k_agg_span<<<G, 64, 0, st>>>(gstart, G, tile_first, tile_last, gsum);
+    k_agg_groupinfo<<<blocks_for(G, 256), 256, 0, st>>>(gstart, c->d_aidx_sorted.p, c->d_akeys_sorted.p, G, c->d_gmin.p, c->d_gkey.p);
+    RTS_HIP(hipGetLastError());
+    // group table to the host; per-receiver totals (the direct-ray rule of aggregation.cu:56) in group order
+    std::vector<double> h_gsum(5*(size_t)G); std::vector<uint32_t> h_gmin(G); std::vector<uint64_t> h_gkey(G);
+    RTS_HIP(hipMemcpyAsync(h_gsum.data(), gsum, sizeof(double)*5*G, hipMemcpyDeviceToHost, st));
+    RTS_HIP(hipMemcpyAsync(h_gmin.data(), c->d_gmin.p, sizeof(uint32_t)*G, hipMemcpyDeviceToHost, st));
+    RTS_HIP(hipMemcpyAsync(h_gkey.data(), c->d_gkey.p, sizeof(uint64_t)*G, hipMemcpyDeviceToHost, st));
+    RTS_HIP(hipStreamSynchronize(st));
+    const uint32_t n_rx_tab = (uint32_t)maxv[1] + 1;
+    std::vector<double> rxtot(5*(size_t)n_rx_tab, 0.0); std::vector<uint32_t> rxmin(n_rx_tab, 0xffffffffu);
+    const uint64_t pmask = (D*B >= 64) ? ~0ULL : (((uint64_t)1 << (D*B)) - 1);
+    for (uint32_t g = 0; g < G; g++) {
+        const uint32_t rx = (D*B >= 64) ? 0u : (uint32_t)(h_gkey[g] >> (D*B));
+        if (rx < n_rx_tab) { for (int k = 0; k < 5; k++) rxtot[5*(size_t)rx + k] += h_gsum[5*(size_t)g + k]; rxmin[rx] = std::min(rxmin[rx], h_gmin[g]); }
+        if (groups) {
+            RtsGroup gr; memset(&gr, 0, sizeof(gr));
+            gr.rx = (int32_t)rx;
+            bool all_neg = true;
+            for (uint32_t k = 0; k < RTS_MAX_DEPTH; k++) {
+                int v = -1;
+                if (k < D) v = (int)(((h_gkey[g] & pmask) >> (k*B)) & (((uint64_t)1 << B) - 1)) - 1;
+                gr.path[k] = v; if (v >= 0) all_neg = false;
+            }
+            gr.direct = all_neg ? 1u : 0u;
+            gr.min_ray = base + h_gmin[g];
+            gr.n = h_gsum[5*(size_t)g]; gr.sum_sqrt_power = h_gsum[5*(size_t)g + 1]; gr.sum_delay = h_gsum[5*(size_t)g + 2];
+            gr.sum_phase = h_gsum[5*(size_t)g + 3]; gr.sum_doppler = h_gsum[5*(size_t)g + 4];
+            groups->push_back(gr);
+        }
+    }
+    // upload receiver totals, scatter per-ray results
+    RTS_HIP(c->d_rcs.reserve(5*(size_t)n_rx_tab + n_rx_tab + 8));
+    double* d_rxtot = c->d_rcs.p; uint32_t* d_rxmin = (uint32_t*)(c->d_rcs.p + 5*(size_t)n_rx_tab);
+    RTS_HIP(hipMemcpyAsync(d_rxtot, rxtot.data(), sizeof(double)*5*n_rx_tab, hipMemcpyHostToDevice, st));
+    RTS_HIP(hipMemcpyAsync(d_rxmin, rxmin.data(), sizeof(uint32_t)*n_rx_tab, hipMemcpyHostToDevice, st));
+    k_agg_scatter<<<blocks_for(R, 256), 256, 0, st>>>(d_rays, c->d_aidx_sorted.p, c->d_gid.p, gsum, c->d_gmin.p, d_rxtot, d_rxmin, n_rx_tab, R,
+                                                       (int64_t)base, d_npath, d_power_sum, d_doppler_sum, d_delay, d_phase, d_pm, pm_init, pm_init == INT32_MIN ? 1 : 0);
+    RTS_HIP(hipGetLastError());
+    RTS_HIP(hipStreamSynchronize(st));
+    return RTS_OK;
+}

@@ -1,0 +1,25 @@
+// rts_raygen.h -- primary ray direction of one launch index (ray_generation, ray_tracer.cu:144-205).
+// All trigonometry of the reference's ray generation depends only on launch constants
+// (d_txSpan, d_txDir); it is hoisted to the host (rts_api: fill_launch_constants) and the
+// device evaluates the remaining per-ray expression tree in the reference's order.
+#pragma once
+#include "rts_internal.h"
+
+__device__ __forceinline__ dvec3 rts_primary_dir(const RtsTraceArgs& a, uint32_t slot)
+{
+    if (a.W == 1) return mk3(a.w1x, a.w1y, a.w1z);                       // ray_tracer.cu:160-161
+    const uint64_t g = a.ray_first + slot;                                // rayIndex = z*W*W + y*W + x  :151
+    const uint32_t lx = (uint32_t)(g % a.W), ly = (uint32_t)((g / a.W) % a.W), lz = (uint32_t)(g / ((uint64_t)a.W * a.W));
+    dvec3 v = mk3(a.bsx + a.stx * (double)lx, a.bsy + a.sty * (double)ly, a.bsz + a.stz * (double)lz);   // :167-169
+    v = unit3(v);                                                         // :170
+    dvec3 r;                                                              // rotated = 0; rotated += Rot*v  :178-182
+    r.x = 0.0 + (a.rot[0]*v.x + a.rot[1]*v.y + a.rot[2]*v.z);
+    r.y = 0.0 + (a.rot[3]*v.x + a.rot[4]*v.y + a.rot[5]*v.z);
+    r.z = 0.0 + (a.rot[6]*v.x + a.rot[7]*v.y + a.rot[8]*v.z);
+    v = unit3(r);
+    dvec3 dir;                                                            // :199-203 (left un-normalised)
+    dir.x = 0.0 + (a.rot1[0]*v.x + a.rot1[1]*v.y + a.rot1[2]*v.z);
+    dir.y = 0.0 + (a.rot1[3]*v.x + a.rot1[4]*v.y + a.rot1[5]*v.z);
+    dir.z = 0.0 + (a.rot1[6]*v.x + a.rot1[7]*v.y + a.rot1[8]*v.z);
+    return dir;
+}

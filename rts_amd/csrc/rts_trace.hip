@@ -1,0 +1,304 @@
+// rts_trace.hip -- the hot kernel: ray generation, LBVH traversal with the f64 triangle
+// test, reflection shading and receiver capture, for one launch (one pulse).
+//
+// Replaces the OptiX programs of the reference:
+//   ray_generation  ray_tracer.cu:144-255      miss         ray_tracer.cu:260-478
+//   intersect       triangle_mesh.cu:121-200   closest_hit  normal_shader.cu:128-340
+// and OptiX's closed-source "Bvh" traverser (ray_tracer.cpp:1127-1128).
+//
+// Mixed-precision contract (reference quirks 1-3):
+//   - the triangle test runs in f64 on the payload's origin/direction (prevHitPoint,
+//     rayDirection), t is compared in f64 against the f32 constants and then narrowed to f32;
+//   - the hit point is prev + (double)t_f32 * dir, rayLength += t_f32;
+//   - the bounce direction is optixu reflect() in f32 on the f32 ray direction, widened
+//     to f64 WITHOUT renormalisation.
+// Closest hit = smallest f32 t; equal f32 t resolved to the lowest global primitive id
+// (OptiX keeps whichever it met first; order there is unknowable).
+//
+// Structure: one lane per launch index, grid-stride over the shard; each lane iterates its
+// bounces (the reference recurses through rtTrace).  The traversal stack lives in LDS
+// (entry-major, lane-minor: conflict free), spilling to a global slab when deeper.
+#include "rts_internal.h"
+#include "rts_raygen.h"
+
+struct TriHit { double t, beta, gamma; dvec3 n; bool ok; };
+
+// intersect_triangle_doubles, triangle_mesh.cu:121-137 (tmin/tmax are the f32 ray constants)
+__device__ __forceinline__ TriHit tri_test(const RtsLeafTri& L, dvec3 o, dvec3 d, float tmin, float tmax)
+{
+    const dvec3 p0 = mk3(L.p0x, L.p0y, L.p0z), p1 = mk3(L.p1x, L.p1y, L.p1z), p2 = mk3(L.p2x, L.p2y, L.p2z);
+    const dvec3 e0 = sub3(p1, p0);
+    const dvec3 e1 = sub3(p0, p2);
+    TriHit h;
+    h.n = cross3(e1, e0);
+    const dvec3 e2 = scale3(1 / dot3(h.n, d), sub3(p0, o));
+    const dvec3 i = cross3(d, e2);
+    h.beta = dot3(i, e1);
+    h.gamma = dot3(i, e0);
+    h.t = dot3(h.n, e2);
+    h.ok = (h.t < (double)tmax) & (h.t > (double)tmin) & (h.beta >= 0.0) & (h.gamma >= 0.0) & (h.beta + h.gamma <= 1);
+    return h;
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(RTS_BLOCK) k_trace(const RtsTraceArgs a)
+{
+    __shared__ int32_t s_stack[RTS_STACK_LDS * RTS_BLOCK];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t gtid = blockIdx.x * RTS_BLOCK + tid;
+    const dvec3 origin = mk3(a.ox, a.oy, a.oz);
+    unsigned long long n_seg = 0, n_shaded = 0, n_nodes = 0, n_tris = 0, n_spill = 0;
+    bool hard_overflow = false;
+
+    for (uint32_t slot = gtid; slot < a.n_rays; slot += a.total_threads) {
+        // ---------------------------------------------------------------- ray_generation
+        dvec3 dir = rts_primary_dir(a, slot);
+        // payload, ray_tracer.cu:212-224
+        dvec3 prev = origin;
+        dvec3 first = mk3(0.0, 0.0, 0.0);
+        double rayLength = 0, power = 0, doppler = 0;
+        uint32_t reflDepth = 0;
+        int received = -1;
+        bool end = false;
+        uint64_t path_lo = 0, path_hi = 0;
+
+        for (;;) {
+            // ------------------------------------------------------------ rtTrace: closest hit over the LBVH
+            n_seg++;
+            const float tmin = (reflDepth == 0) ? SCENE_EPS : SCENE_EPS_R;     // ray_tracer.cu:209, normal_shader.cu:297
+            float best_t = RTS_DEFAULT_TMAX;
+            int best_leaf = -1; uint32_t best_prim = 0xffffffffu;
+            if (a.n_prims > 0) {
+                const double ix = 1.0 / dir.x, iy = 1.0 / dir.y, iz = 1.0 / dir.z;
+                double t_prune = (double)RTS_DEFAULT_TMAX;
+                int sp = 0;
+                int node = 0;
+                const int SENTINEL = 0x7fffffff;
+                uint32_t steps = 0;
+                while (node != SENTINEL) {
+                    if (++steps > (1u << 24)) { hard_overflow = true; break; }   // malformed tree guard: every wave must drain
+                    if (node >= 0) {
+                        const float4* np = reinterpret_cast<const float4*>(a.nodes + node);
+                        const float4 q0 = np[0], q1 = np[1], q2 = np[2];
+                        const int4 q3 = reinterpret_cast<const int4*>(np)[3];
+                        if (COUNT) n_nodes++;
+                        // f64 slab test on the padded f32 child boxes (conservative, see rts_bvh.hip)
+                        double t1, t2, tn0, tf0, tn1, tf1;
+                        t1 = ((double)q0.x - prev.x) * ix; t2 = ((double)q0.w - prev.x) * ix; tn0 = fmin(t1, t2); tf0 = fmax(t1, t2);
+                        t1 = ((double)q0.y - prev.y) * iy; t2 = ((double)q1.x - prev.y) * iy; tn0 = fmax(tn0, fmin(t1, t2)); tf0 = fmin(tf0, fmax(t1, t2));
+                        t1 = ((double)q0.z - prev.z) * iz; t2 = ((double)q1.y - prev.z) * iz; tn0 = fmax(tn0, fmin(t1, t2)); tf0 = fmin(tf0, fmax(t1, t2));
+                        t1 = ((double)q1.z - prev.x) * ix; t2 = ((double)q2.y - prev.x) * ix; tn1 = fmin(t1, t2); tf1 = fmax(t1, t2);
+                        t1 = ((double)q1.w - prev.y) * iy; t2 = ((double)q2.z - prev.y) * iy; tn1 = fmax(tn1, fmin(t1, t2)); tf1 = fmin(tf1, fmax(t1, t2));
+                        t1 = ((double)q2.x - prev.z) * iz; t2 = ((double)q2.w - prev.z) * iz; tn1 = fmax(tn1, fmin(t1, t2)); tf1 = fmin(tf1, fmax(t1, t2));
+                        const bool h0 = fmax(tn0, 0.0) <= fmin(tf0, t_prune);
+                        const bool h1 = fmax(tn1, 0.0) <= fmin(tf1, t_prune);
+                        if (h0 && h1) {
+                            const bool swap = tn1 < tn0;
+                            const int nearc = swap ? q3.y : q3.x, farc = swap ? q3.x : q3.y;
+                            if (sp < RTS_STACK_LDS) s_stack[sp * RTS_BLOCK + tid] = farc;
+                            else if (sp < RTS_STACK_LDS + RTS_STACK_OVF) { a.stack_ovf[(size_t)(sp - RTS_STACK_LDS) * a.total_threads + gtid] = farc; n_spill++; }
+                            else hard_overflow = true;
+                            if (sp < RTS_STACK_LDS + RTS_STACK_OVF) sp++;
+                            node = nearc;
+                        } else if (h0) node = q3.x;
+                        else if (h1) node = q3.y;
+                        else {
+                            if (sp == 0) node = SENTINEL;
+                            else { sp--; node = (sp < RTS_STACK_LDS) ? s_stack[sp * RTS_BLOCK + tid] : a.stack_ovf[(size_t)(sp - RTS_STACK_LDS) * a.total_threads + gtid]; }
+                        }
+                    } else {
+                        const int leaf = ~node;
+                        const RtsLeafTri L = a.leaves[leaf];
+                        if (COUNT) n_tris++;
+                        const TriHit h = tri_test(L, prev, dir, tmin, RTS_DEFAULT_TMAX);
+                        if (h.ok) {
+                            const float tf = (float)h.t;                      // rtPotentialIntersection takes float, triangle_mesh.cu:167
+                            if ((tf > tmin) && (tf < best_t || (tf == best_t && L.prim < best_prim))) {
+                                best_t = tf; best_leaf = leaf; best_prim = L.prim;
+                                t_prune = (double)f32_next_up_pos(tf);         // keep equal-t candidates reachable
+                            }
+                        }
+                        if (sp == 0) node = SENTINEL;
+                        else { sp--; node = (sp < RTS_STACK_LDS) ? s_stack[sp * RTS_BLOCK + tid] : a.stack_ovf[(size_t)(sp - RTS_STACK_LDS) * a.total_threads + gtid]; }
+                    }
+                }
+            }
+            if (a.keep_all) {
+                const size_t hidx = (size_t)slot * (a.max_refl + 1) + reflDepth;
+                a.hit_prim[hidx] = (best_leaf >= 0) ? (int32_t)best_prim : -1;
+                a.hit_t[hidx] = (best_leaf >= 0) ? best_t : 0.0f;
+            }
+
+            if (best_leaf < 0) {
+                // -------------------------------------------------------- miss, ray_tracer.cu:260-478
+                if (end == false) {
+                    for (uint32_t Rx_i = 0; Rx_i < a.n_rx; Rx_i++) {
+                        const RtsRxDev rx = a.rx[Rx_i];
+                        double t[2] = {0, 0};
+                        const double A = (dir.x)*(dir.x) + (dir.y)*(dir.y) + (dir.z)*(dir.z);
+                        const double B = 2*(((prev.x - rx.cx)*dir.x) + ((prev.y - rx.cy)*dir.y) + ((prev.z - rx.cz)*dir.z));
+                        const double C = prev.x*prev.x + prev.y*prev.y + prev.z*prev.z + (rx.cx*rx.cx) + (rx.cy*rx.cy) + (rx.cz*rx.cz) -
+                                         2*((rx.cx*prev.x) + (rx.cy*prev.y) + (rx.cz*prev.z)) - rx.radius*rx.radius;
+                        double discriminant = B*B - 4*A*C;
+                        if (discriminant > 0.f) {
+                            discriminant = sqrt(discriminant);
+                            t[0] = (-B - discriminant)/(2*A);
+                            t[1] = (-B + discriminant)/(2*A);
+                            unsigned int received_root = 2;
+#pragma unroll
+                            for (int i = 0; i < 2; i++) {
+                                if ((t[i] >= 0) && ((rayLength + t[i]) > SCENE_EPS) && ((rayLength + t[i]) > SCENE_EPS_R)) {
+                                    const dvec3 ep = mk3(prev.x + t[i]*dir.x, prev.y + t[i]*dir.y, prev.z + t[i]*dir.z);
+                                    // atan2f(float, float): arguments narrow to f32 first (:326-329)
+                                    double theta = rts_atan2f((float)(ep.y - rx.cy), (float)(ep.x - rx.cx));
+                                    double phi = rts_atan2f((float)(ep.z - rx.cz), (float)sqrt(((ep.y - rx.cy) * (ep.y - rx.cy)) + ((ep.x - rx.cx) * (ep.x - rx.cx))));
+                                    if ((phi < -RTS_PI/2)) { theta += RTS_PI; phi = -RTS_PI - phi; }
+                                    if ((phi > RTS_PI/2)) { theta += RTS_PI; phi = RTS_PI - phi; }
+                                    double maxTheta1 = rx.maxTheta, minTheta1 = rx.minTheta, maxTheta2 = maxTheta1, minTheta2 = minTheta1;
+                                    double maxPhi1 = rx.maxPhi, minPhi1 = rx.minPhi, maxPhi2 = maxPhi1, minPhi2 = minPhi1;
+                                    if ((minPhi1 < -RTS_PI/2)) { maxTheta2 += RTS_PI; minTheta2 += RTS_PI; maxPhi2 = -RTS_PI - minPhi1; minPhi2 = -RTS_PI/2; minPhi1 = -RTS_PI/2; }
+                                    if ((maxPhi1 > RTS_PI/2)) { maxTheta2 += RTS_PI; minTheta2 += RTS_PI; minPhi2 = RTS_PI - maxPhi1; maxPhi2 = RTS_PI/2; maxPhi1 = RTS_PI/2; }
+                                    if (((rts_angle_in_range(theta, minTheta1, maxTheta1)) && (rts_angle_in_range(phi, minPhi1, maxPhi1))) ||
+                                        ((rts_angle_in_range(theta, minTheta2, maxTheta2)) && (rts_angle_in_range(phi, minPhi2, maxPhi2)))) {
+                                        if (received_root == 2) received_root = i;
+                                        else if (t[received_root] > t[i]) received_root = i;
+                                    }
+                                }
+                            }
+                            if (received_root < 2) {
+                                end = true;                                                    // :396
+                                const double tr = received_root == 0 ? t[0] : t[1];
+                                const dvec3 ep = mk3(prev.x + tr*dir.x, prev.y + tr*dir.y, prev.z + tr*dir.z);
+                                if (reflDepth == 0) {                                          // direct transmission :410-417
+                                    const dvec3 RxRange = sub3(ep, origin);
+                                    if (len3(RxRange) >= SCENE_EPS) {
+                                        power = 1/(4*RTS_PI*4*RTS_PI*(magsq3(RxRange)));
+                                        doppler = 0;
+                                        rayLength += tr;
+                                        received = (int)Rx_i;
+                                    }
+                                } else {                                                       // :419-425
+                                    const dvec3 RxRange = sub3(ep, prev);
+                                    if (len3(RxRange) >= SCENE_EPS_R) {
+                                        power *= 1/((magsq3(RxRange))*4*RTS_PI*4*RTS_PI);
+                                        rayLength += tr;
+                                        received = (int)Rx_i;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+                if (end == false) {                                                            // Earth sphere :438-476
+                    const double d_earthRadius = 6378136;
+                    const double A = (dir.x)*(dir.x) + (dir.y)*(dir.y) + (dir.z)*(dir.z);
+                    const double B = 2*(prev.x*dir.x + prev.y*dir.y + prev.z*dir.z);
+                    const double C = prev.x*prev.x + prev.y*prev.y + prev.z*prev.z - d_earthRadius*d_earthRadius;
+                    double discriminant = B*B - 4*A*C;
+                    if (discriminant > 0.f) {
+                        discriminant = sqrt(discriminant);
+                        const double t0 = (-B - discriminant)/(2*A), t1 = (-B + discriminant)/(2*A);
+                        if ((t0 >= 0) && (rayLength > 0)) { end = true; rayLength += t0; }
+                        if ((t1 >= 0) && (rayLength > 0)) { end = true; rayLength += t1; }
+                    }
+                }
+                break;
+            }
+
+            // ------------------------------------------------------------ closest_hit, normal_shader.cu:128-340 (maxRefr == 0)
+            if (!((end == false) && (reflDepth < a.max_refl))) break;          // gate :134 ; absorbed hit leaves the payload untouched
+            n_shaded++;
+            const RtsLeafTri L = a.leaves[best_leaf];
+            const RtsTargetDev T = a.targets[L.targ];
+            {   // path column = reflDepth < D always holds here (:140-146)
+                const uint64_t code = (uint64_t)(L.targ + 1);
+                if (reflDepth < 8) path_lo |= code << (8 * reflDepth); else path_hi |= code << (8 * (reflDepth - 8));
+            }
+            const float hit_t = best_t;
+            const dvec3 hitPoint = mk3(prev.x + (double)hit_t*dir.x, prev.y + (double)hit_t*dir.y, prev.z + (double)hit_t*dir.z);   // :149-152
+            rayLength += hit_t;                                                // :153
+            if (reflDepth == 0) {                                              // :159-166
+                first = hitPoint;
+                const dvec3 TxRange = sub3(first, origin);
+                if (len3(TxRange) >= SCENE_EPS) power = 1/((magsq3(TxRange))*4*RTS_PI);
+                else end = true;
+            } else {                                                           // :167-173
+                const dvec3 TargRange = sub3(hitPoint, prev);
+                if (len3(TargRange) >= SCENE_EPS_R) power *= 1/((magsq3(TargRange))*4*RTS_PI);
+                else end = true;
+            }
+            // attribute normal (triangle_mesh.cu:169-194): recompute the accepted test, same bits
+            const TriHit h = tri_test(L, prev, dir, tmin, RTS_DEFAULT_TMAX);
+            prev = hitPoint;                                                   // :176
+            dvec3 normal;
+            if (a.smooth) {
+                const uint32_t* ni = a.tri_nidx + 3*(size_t)L.prim;
+                if (T.perface_normals) {
+                    const double* n = a.normals + 3*(size_t)ni[0];
+                    normal = mk3(n[0], n[1], n[2]);
+                } else {
+                    const double* n0 = a.normals + 3*(size_t)ni[0]; const double* n1 = a.normals + 3*(size_t)ni[1]; const double* n2 = a.normals + 3*(size_t)ni[2];
+                    const double w = 1.0f - h.beta - h.gamma;
+                    normal = mk3(n1[0]*h.beta + n2[0]*h.gamma + n0[0]*w, n1[1]*h.beta + n2[1]*h.gamma + n0[1]*w, n1[2]*h.beta + n2[2]*h.gamma + n0[2]*w);
+                }
+                normal = unit3(normal);
+            } else {
+                normal = unit3(h.n);
+            }
+            // f32 direction of the current OptiX ray: primary = normalise_float3(rayDir_d3) (ray_tracer.cu:208),
+            // bounce = the f32 reflect() result itself (normal_shader.cu:296-297)
+            const fvec3 dirf = (reflDepth == 0) ? unit3_to_f32(dir) : mk3f((float)dir.x, (float)dir.y, (float)dir.z);
+            reflDepth++;                                                       // :286
+            // reflDepth < d_maxReflDepth (= max_refl + 1) always holds after the gate (:293)
+            const fvec3 nd = reflect3f(dirf, unit3_to_f32(normal));            // :296
+            power *= T.reflCoeff;                                              // :298
+            const dvec3 k0 = unit3(dir);                                       // :302
+            dir = widen3(nd);                                                  // :303
+            const dvec3 k1 = unit3(dir);                                       // :304
+            doppler += dot3(mk3(T.vx, T.vy, T.vz), sub3(k1, k0));              // :314
+            {   // direction history: the RCS angles of received rays are rebuilt from it (:320-326)
+                float* dh = a.dir_hist + (size_t)(reflDepth - 1) * 3 * a.n_rays;
+                dh[slot] = nd.x; dh[(size_t)a.n_rays + slot] = nd.y; dh[2*(size_t)a.n_rays + slot] = nd.z;
+            }
+        }
+
+        // ---------------------------------------------------------------- write-back (ray_tracer.cu:246-253)
+        const bool recv = received >= 0;
+        if (recv || a.keep_all) {
+            RtsEndRecord r;
+            r.rayLength = rayLength; r.power = power; r.doppler = doppler;
+            r.prevx = prev.x; r.prevy = prev.y; r.prevz = prev.z;
+            r.firstx = first.x; r.firsty = first.y; r.firstz = first.z;
+            r.path_lo = path_lo; r.path_hi = path_hi; r.slot = slot; r.received = received; r.reflDepth = reflDepth; r.pad = 0;
+            if (a.keep_all) a.all_records[slot] = r;
+            if (recv) {
+                // the compiler folds this into one atomic per wave (v_mbcnt + s_bcnt1)
+                unsigned long long idx = atomicAdd(&a.counters[0], 1ULL);
+                a.recv_records[idx] = r;
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------ counters: wave reduce, one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) {
+        n_seg += __shfl_down(n_seg, off); n_shaded += __shfl_down(n_shaded, off);
+        if (COUNT) { n_nodes += __shfl_down(n_nodes, off); n_tris += __shfl_down(n_tris, off); }
+        n_spill += __shfl_down(n_spill, off);
+    }
+    if ((tid & 63) == 0) {
+        atomicAdd(&a.counters[1], n_seg); atomicAdd(&a.counters[2], n_shaded);
+        if (COUNT) { atomicAdd(&a.counters[3], n_nodes); atomicAdd(&a.counters[4], n_tris); }
+        if (n_spill) atomicAdd(&a.counters[5], n_spill);
+    }
+    if (hard_overflow) atomicAdd(&a.counters[6], 1ULL);
+}
+
+int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a, bool count_traversal)
+{
+    if (a.n_rays == 0) return RTS_OK;
+    const unsigned grid = a.total_threads / RTS_BLOCK;
+    if (count_traversal) k_trace<true><<<grid, RTS_BLOCK, 0, c->stream>>>(a);
+    else k_trace<false><<<grid, RTS_BLOCK, 0, c->stream>>>(a);
+    RTS_HIP(hipGetLastError());
+    return RTS_OK;
+}

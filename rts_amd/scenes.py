@@ -1,0 +1,165 @@
+"""Synthetic scenes for the BASELINE.json configurations.
+
+The reference ships no scenes; these are this repository's own seeded generators.  They only
+build INPUT arrays (meshes in the target frame, per-pulse placements, receiver spheres, beam
+parameters) through the library's host helpers (rts_rect_mesh / rts_sphere_mesh / rts_rx_sphere)
+and numpy; tests feed the identical arrays to the product and to the oracle.
+
+Conventions: Tx at (-range, 0, 0) looking along +x at targets near the origin (the Earth test of
+ray_tracer.cu:438-476 is inert for received rays), isotropic antennas, RCS = 1,
+c = 299 792 458 m/s, fc = 10 GHz, cw_sample_rate = 1 kHz.
+"""
+import math
+
+import numpy as np
+
+from . import api
+
+C0 = 299792458.0
+FC = 10.0e9
+SAMPLE_TIME = 1.0e-3
+
+
+def _ellipsoid(nu, nv, semi, centre=(0, 0, 0), yaw=0.0):
+    """Closed ellipsoid with 2*nu*(nv-1) triangles (pole fans + quad bands), shared vertices,
+    analytic unit normals; long axis first in `semi`."""
+    a, b, c = semi
+    lat = np.linspace(-math.pi / 2, math.pi / 2, nv + 1)[1:-1]          # nv-1 interior rings
+    lon = np.linspace(0.0, 2 * math.pi, nu, endpoint=False)
+    cl, sl = np.cos(lat)[:, None], np.sin(lat)[:, None]
+    ring = np.stack([np.broadcast_to(sl, (nv - 1, nu)), cl * np.cos(lon)[None, :], cl * np.sin(lon)[None, :]], -1)
+    unit = np.concatenate([np.array([[-1.0, 0, 0]]), ring.reshape(-1, 3), np.array([[1.0, 0, 0]])], 0)   # poles on the long axis
+    verts = unit * np.array([a, b, c])
+    nrm = unit / np.array([a, b, c])
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    tris = []
+    south, north = 0, 1 + (nv - 1) * nu
+
+    def vid(r, k):
+        return 1 + r * nu + (k % nu)
+    for k in range(nu):
+        tris.append((south, vid(0, k + 1), vid(0, k)))
+        tris.append((north, vid(nv - 2, k), vid(nv - 2, k + 1)))
+    for r in range(nv - 2):
+        for k in range(nu):
+            tris.append((vid(r, k), vid(r, k + 1), vid(r + 1, k + 1)))
+            tris.append((vid(r, k), vid(r + 1, k + 1), vid(r + 1, k)))
+    tris = np.array(tris, np.uint32)
+    if yaw:
+        cy, sy = math.cos(yaw), math.sin(yaw)
+        R = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1.0]])
+        verts = verts @ R.T; nrm = nrm @ R.T
+    verts = verts + np.array(centre, np.float64)
+    return verts, tris, nrm
+
+
+def _merge(parts):
+    vs, ts, ns, off = [], [], [], 0
+    for v, t, n in parts:
+        vs.append(v); ns.append(n); ts.append(t + off); off += v.shape[0]
+    return np.concatenate(vs), np.concatenate(ts).astype(np.uint32), np.concatenate(ns)
+
+
+def aircraft_mesh(scale=1.0, detail=1.0):
+    """'Aircraft-like' union of four ellipsoids: fuselage, wing, tailplane, fin.
+    detail = 1 gives exactly 100 000 triangles."""
+    d = math.sqrt(detail)
+
+    def n(x):
+        return max(8, int(round(x * d)))
+    parts = [
+        _ellipsoid(n(250), n(120) + 1, (15.0 * scale, 1.8 * scale, 1.8 * scale)),
+        _ellipsoid(n(200), n(50) + 1, (2.5 * scale, 16.0 * scale, 0.35 * scale), centre=(1.0 * scale, 0, -0.3 * scale)),
+        _ellipsoid(n(100), n(50) + 1, (1.2 * scale, 5.5 * scale, 0.2 * scale), centre=(-13.0 * scale, 0, 0.4 * scale)),
+        _ellipsoid(n(100), n(50) + 1, (1.8 * scale, 0.2 * scale, 3.2 * scale), centre=(-13.0 * scale, 0, 2.5 * scale)),
+    ]
+    return _merge(parts)
+
+
+def plate_mesh(size):
+    """Two-triangle square plate in the local y-z plane facing -x (file_mesh-style unshared vertices)."""
+    h = size / 2.0
+    v = np.array([[0, -h, -h], [0, h, -h], [0, h, h], [0, -h, -h], [0, h, h], [0, -h, h]], np.float64)
+    t = np.array([[0, 1, 2], [3, 4, 5]], np.uint32)
+    n = np.tile(np.array([[-1.0, 0, 0]]), (6, 1))
+    return v, t, n
+
+
+def _rx_at(pos, look_at, radius, span):
+    d = np.asarray(look_at, np.float64) - np.asarray(pos, np.float64)
+    az = math.atan2(d[1], d[0]); el = math.atan2(d[2], math.hypot(d[0], d[1]))
+    return api.rx_sphere(pos, az, el, radius, span, span)
+
+
+def _static_motion(n_targets, positions=None, velocities=None):
+    out = []
+    for i in range(n_targets):
+        out.append(dict(position=tuple(positions[i]) if positions is not None else (0.0, 0.0, 0.0),
+                        velocity=tuple(velocities[i]) if velocities is not None else (0.0, 0.0, 0.0)))
+    return out
+
+
+def config1():
+    """C1: flat plate (2 triangles) at 1 km, W = 22, 1 bounce, monostatic rx sphere r = 10 m."""
+    v, t, n = plate_mesh(10.0)
+    return dict(name="C1-plate-2tri", W=22, max_refl=1, smooth=True, n_pulses=1,
+                meshes=[dict(tris=t, verts=v, normals=n, refl_coeff=0.9, refr_index=1.0)],
+                motion=_static_motion(1, [(0.0, 0.0, 0.0)], [(0.0, 0.0, 0.0)]),
+                tx=dict(origin=(-1000.0, 0.0, 0.0), span=(0.02, 0.02, 0.0), dir=(0.0, 0.0)),
+                rx=[_rx_at((-1000.0, 0.0, 0.0), (0, 0, 0), 10.0, math.pi / 2)], carrier=FC, c=C0)
+
+
+def config2(subdiv=5, W=100, rx_radius=50.0):
+    """C2: icosphere (n = 5: 20 480 triangles) radius 5 m at 1 km, W = 100, 4 bounces, 64 pulses, static."""
+    v, t, n = api.sphere_mesh(subdiv, 5.0)
+    return dict(name="C2-icosphere-%dtri" % t.shape[0], W=W, max_refl=4, smooth=True, n_pulses=64,
+                meshes=[dict(tris=t, verts=v, normals=n, refl_coeff=0.9, refr_index=1.0)],
+                motion=_static_motion(1, [(0.0, 0.0, 0.0)], [(30.0, 0.0, 0.0)]),
+                tx=dict(origin=(-1000.0, 0.0, 0.0), span=(0.011, 0.011, 0.1), dir=(0.0, 0.0)),
+                rx=[_rx_at((-1000.0, 0.0, 0.0), (0, 0, 0), rx_radius, math.pi / 2)], carrier=FC, c=C0)
+
+
+def config3(W=216, detail=1.0, rx_radius=50.0, n_rx=4):
+    """C3: aircraft-like mesh, 100 000 triangles, 1 Tx / 4 Rx on a 2 km arc, W = 216, 6 bounces, 256 pulses."""
+    v, t, n = aircraft_mesh(detail=detail)
+    yaw = math.radians(25.0)
+    R = api.rotation_matrix(yaw, math.radians(4.0), math.radians(8.0)).reshape(3, 3)
+    v = v @ R.T; n = n @ R.T
+    rx = []
+    for k in range(n_rx):
+        ang = math.radians(-30.0 + 60.0 * k / max(n_rx - 1, 1)) if n_rx > 1 else 0.0
+        pos = (-1000.0 * math.cos(ang), 1000.0 * math.sin(ang), 0.0)
+        rx.append(_rx_at(pos, (0, 0, 0), rx_radius, math.pi / 2))
+    return dict(name="C3-aircraft-%dtri" % t.shape[0], W=W, max_refl=6, smooth=True, n_pulses=256,
+                meshes=[dict(tris=t, verts=v, normals=n, refl_coeff=0.9, refr_index=1.0)],
+                motion=_static_motion(1, [(0.0, 0.0, 0.0)], [(200.0, 20.0, 0.0)]),
+                tx=dict(origin=(-1000.0, 0.0, 0.0), span=(0.036, 0.036, 0.1), dir=(0.0, 0.0)),
+                rx=rx, carrier=FC, c=C0)
+
+
+def config5_motion(pulse, speed=200.0, yaw_rate=1.0, prf=1000.0):
+    """C5: per-pulse rigid transform of the C3 mesh (v = 200 m/s along +y, 1 rad/s yaw)."""
+    tt = pulse / prf
+    R = api.rotation_matrix(yaw_rate * tt, 0.0, 0.0)
+    return [dict(position=(0.0, speed * tt, 0.0), velocity=(0.0, speed, 0.0), rotation=R)]
+
+
+def world_vertices(mesh, motion):
+    """World-space vertices/normals exactly as the device placement kernel computes them
+    (R * v accumulated from zero in k order, then + position; ray_tracer.cpp:120-137, 1010-1014)."""
+    v = np.asarray(mesh["verts"], np.float64); n = np.asarray(mesh["normals"], np.float64)
+    rot = motion.get("rotation")
+    if rot is not None:
+        R = np.asarray(rot, np.float64).reshape(3, 3)
+
+        def rotate(a):
+            out = np.zeros_like(a)
+            for i in range(3):
+                s = np.zeros(a.shape[0])
+                for k in range(3):
+                    s = s + R[i, k] * a[:, k]
+                out[:, i] = s
+            return out
+        v = rotate(v); n = rotate(n)
+    p = np.asarray(motion["position"], np.float64)
+    return v + p[None, :], n
