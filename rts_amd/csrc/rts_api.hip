@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <algorithm>
 #include <map>
 #include "rts_internal.h"
@@ -17,6 +18,18 @@ void rts_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vsnpri
 extern "C" const char* rts_last_error(void) { return g_err; }
 
 extern int rts_fill_i32(hipStream_t st, int32_t* p, int32_t v, size_t n);
+
+int rts_debug_stage(RtsContext* c, const char* name)
+{
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("RTS_DEBUG_SYNC"); on = (e && e[0] == '1') ? 1 : 0; }
+    if (!on) return RTS_OK;
+    fprintf(stderr, "[rts] stage %s ... ", name); fflush(stderr);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { fprintf(stderr, "FAILED: %s\n", hipGetErrorString(e)); rts_set_error("stage %s: %s", name, hipGetErrorString(e)); return RTS_ERR_HIP; }
+    fprintf(stderr, "ok\n"); fflush(stderr);
+    return RTS_OK;
+}
 
 extern "C" int rts_device_count(int* n)
 {
@@ -59,7 +72,7 @@ extern "C" int rts_destroy(RtsHandle c)
     c->d_motion.release(); c->d_targets.release(); c->d_prim_box.release(); c->d_node_box.release(); c->d_keys.release(); c->d_keys_sorted.release();
     c->d_vals.release(); c->d_vals_sorted.release(); c->d_bounds.release(); c->d_parent.release(); c->d_leaf_parent.release(); c->d_flags.release();
     c->d_nodes.release(); c->d_leaves.release(); c->d_sort_tmp.release(); c->d_rx.release(); c->d_recv.release(); c->d_all.release();
-    c->d_counters.release(); c->d_dir_hist.release(); c->d_hit_prim.release(); c->d_hit_t.release(); c->d_stack_ovf.release();
+    c->d_counters.release(); c->d_lc.release(); c->d_dir_hist.release(); c->d_hit_prim.release(); c->d_hit_t.release(); c->d_stack_ovf.release();
     c->d_rk.release(); c->d_rk_sorted.release(); c->d_ri.release(); c->d_ri_sorted.release(); c->d_rx_rays.release(); c->d_rx_paths.release();
     c->d_rx_angles.release(); c->d_rx_slots.release(); c->d_all_rays.release(); c->d_all_paths.release(); c->d_all_angles.release();
     c->d_akeys.release(); c->d_akeys_sorted.release(); c->d_aidx.release(); c->d_aidx_sorted.release(); c->d_ghead.release(); c->d_gid.release();
@@ -153,7 +166,7 @@ extern "C" int rts_set_receivers(RtsHandle c, const RtsReceiverSphere* rx, uint3
 // evaluated once on the host in the reference's expression order.
 static inline dvec3 host_sph_to_cart(double azi, double ele) { dvec3 c; c.x = std::cos(azi)*std::cos(ele); c.y = std::sin(azi)*std::cos(ele); c.z = std::sin(ele); return c; }
 
-static void fill_launch_constants(RtsTraceArgs& a, const RtsPulse& p, uint32_t W)
+static void fill_launch_constants(RtsLaunchConsts& a, const RtsPulse& p, uint32_t W)
 {
     const double spx = p.tx_span[0], spy = p.tx_span[1], spz = p.tx_span[2];
     const double dx = p.tx_dir[0], dy = p.tx_dir[1];
@@ -221,6 +234,7 @@ extern "C" int rts_trace_pulse(RtsHandle c, const RtsPulse* p)
             RTS_HIP(hipStreamSynchronize(st));      // td / motion are host temporaries
         }
         int rc = rts_bvh_build(c); if (rc != RTS_OK) return rc;
+        RTS_STAGE(c, "bvh_build");
         c->bvh_valid = true; c->stats.bvh_rebuilt = 1;
     }
     RTS_HIP(hipEventRecord(c->ev[1], st));
@@ -234,7 +248,12 @@ extern "C" int rts_trace_pulse(RtsHandle c, const RtsPulse* p)
     uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)n + RTS_BLOCK - 1) / RTS_BLOCK, (uint64_t)prop.multiProcessorCount * 16);
     if (grid == 0) grid = 1;
     RtsTraceArgs a; memset(&a, 0, sizeof(a));
-    fill_launch_constants(a, *p, W);
+    RtsLaunchConsts& lc = c->last_lc; memset(&lc, 0, sizeof(lc));
+    fill_launch_constants(lc, *p, W);
+    lc.ray_first = first; lc.W = W;
+    RTS_HIP(c->d_lc.reserve(1));
+    RTS_HIP(hipMemcpyAsync(c->d_lc.p, &lc, sizeof(lc), hipMemcpyHostToDevice, st));
+    a.lc = c->d_lc.p;
     a.ray_first = first; a.n_rays = n; a.W = W; a.max_refl = c->params.max_refl; a.smooth = c->params.interpolate_smooth ? 1u : 0u;
     a.n_prims = c->n_prims; a.n_targets = n_targets; a.n_rx = c->n_rx; a.keep_all = keep_all ? 1u : 0u;
     a.total_threads = grid * RTS_BLOCK;
@@ -255,7 +274,9 @@ extern "C" int rts_trace_pulse(RtsHandle c, const RtsPulse* p)
 
     // ---- trace
     RTS_HIP(hipEventRecord(c->ev[2], st));
+    RTS_STAGE(c, "pre-trace");
     int rc = rts_trace_launch(c, a, count_trav); if (rc != RTS_OK) return rc;
+    RTS_STAGE(c, "k_trace");
     RTS_HIP(hipEventRecord(c->ev[3], st));
     unsigned long long cnt[8];
     RTS_HIP(hipMemcpyAsync(cnt, c->d_counters.p, sizeof(cnt), hipMemcpyDeviceToHost, st));

@@ -56,14 +56,22 @@ static_assert(sizeof(RtsEndRecord) == 112, "end record size");
 #define RTS_STACK_LDS 24            // traversal stack entries kept in LDS per lane
 #define RTS_STACK_OVF 80            // further entries spilled to global memory (rare)
 
-struct RtsTraceArgs {
-    // launch constants (hoisted ray_generation trig, ray_tracer.cu:155-203)
+// Launch constants of ray_generation (hoisted trig, ray_tracer.cu:155-203).  Device resident and
+// read through a pointer: keeping these 30 doubles as by-value kernel arguments pinned ~60
+// SGPRs for the whole kernel (SGPR spills to VGPR lanes).
+struct RtsLaunchConsts {
     double ox, oy, oz;              // d_rayOrigin
     double bsx, bsy, bsz;           // beamStart
     double stx, sty, stz;           // lattice step per launch index
     double rot[9];                  // Rot  (azimuth)
     double rot1[9];                 // Rot1 (elevation about the rotated y axis)
     double w1x, w1y, w1z;           // direction for W == 1
+    uint64_t ray_first;
+    uint32_t W, pad;
+};
+
+struct RtsTraceArgs {
+    const RtsLaunchConsts* lc;      // device copy of the launch constants
     uint64_t ray_first;
     uint32_t n_rays, W;
     uint32_t max_refl, smooth;
@@ -132,7 +140,7 @@ struct RtsContext {
     uint64_t ray_first = 0; uint32_t n_rays = 0;
     DevBuf<RtsEndRecord> d_recv, d_all; DevBuf<unsigned long long> d_counters; DevBuf<float> d_dir_hist;
     DevBuf<int32_t> d_hit_prim; DevBuf<float> d_hit_t; DevBuf<int32_t> d_stack_ovf;
-    RtsTraceArgs last_args;
+    RtsTraceArgs last_args; RtsLaunchConsts last_lc; DevBuf<RtsLaunchConsts> d_lc;
     // received set (ordered, expanded)
     uint64_t n_recv = 0;
     DevBuf<uint32_t> d_rk, d_rk_sorted, d_ri, d_ri_sorted;
@@ -157,6 +165,10 @@ int rts_aggregate_device(RtsContext* c, const PerRayData* d_rays, const int32_t*
                          double* d_phase, int32_t* d_pm, std::vector<RtsGroup>* groups, double* d_npath,
                          double* d_power_sum, double* d_doppler_sum, int32_t pm_init);
 void rts_set_error(const char* fmt, ...);
+// RTS_DEBUG_SYNC=1: synchronise after every stage and name it on stderr, so that a device
+// fault is attributed to the kernel that caused it
+int rts_debug_stage(RtsContext* c, const char* name);
+#define RTS_STAGE(c, name) do { int rc_ = rts_debug_stage((c), (name)); if (rc_ != RTS_OK) return rc_; } while (0)
 
 #define RTS_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
     rts_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return RTS_ERR_HIP; } } while (0)

@@ -49,7 +49,7 @@ __global__ void k_expand(const RtsTraceArgs a, const RtsEndRecord* __restrict__ 
     }
     // RCS angle row (normal_shader.cu:320-326): tAngle = sph(k0) + sph(-k1) per reflection,
     // -1e6 default (ray_tracer.cpp:861-867); k0/k1 rebuilt from the f32 direction history
-    dvec3 kin = unit3(rts_primary_dir(a, r.slot));
+    dvec3 kin = unit3(rts_primary_dir(*a.lc, r.slot));
     for (uint32_t col = 0; col < D; col++) {
         double ax = -1000000, ay = -1000000;
         if (col < r.reflDepth) {
@@ -76,11 +76,14 @@ int rts_post_order_and_expand(RtsContext* c)
     RTS_HIP(c->d_rk.reserve(R)); RTS_HIP(c->d_rk_sorted.reserve(R)); RTS_HIP(c->d_ri.reserve(R)); RTS_HIP(c->d_ri_sorted.reserve(R));
     RTS_HIP(c->d_rx_rays.reserve(R)); RTS_HIP(c->d_rx_paths.reserve((size_t)R*D + 1)); RTS_HIP(c->d_rx_angles.reserve((size_t)R*D*2 + 1)); RTS_HIP(c->d_rx_slots.reserve(R));
     k_recv_keys<<<blocks_for(R, 256), 256, 0, st>>>(c->d_recv.p, c->d_rk.p, c->d_ri.p, R);
+    RTS_STAGE(c, "k_recv_keys");
     size_t tmp = 0;
     RTS_HIP(rocprim::radix_sort_pairs(nullptr, tmp, c->d_rk.p, c->d_rk_sorted.p, c->d_ri.p, c->d_ri_sorted.p, R, 0, 32, st));
     RTS_HIP(c->d_sort_tmp.reserve(tmp));
     RTS_HIP(rocprim::radix_sort_pairs(c->d_sort_tmp.p, tmp, c->d_rk.p, c->d_rk_sorted.p, c->d_ri.p, c->d_ri_sorted.p, R, 0, 32, st));
+    RTS_STAGE(c, "recv sort");
     k_expand<<<blocks_for(R, 256), 256, 0, st>>>(c->last_args, c->d_recv.p, c->d_ri_sorted.p, R, D, c->d_rx_rays.p, c->d_rx_paths.p, c->d_rx_angles.p, c->d_rx_slots.p);
+    RTS_STAGE(c, "k_expand");
     RTS_HIP(hipGetLastError());
     return RTS_OK;
 }

@@ -5,7 +5,7 @@
 #pragma once
 #include "rts_internal.h"
 
-__device__ __forceinline__ dvec3 rts_primary_dir(const RtsTraceArgs& a, uint32_t slot)
+__device__ __forceinline__ dvec3 rts_primary_dir(const RtsLaunchConsts& a, uint32_t slot)
 {
     if (a.W == 1) return mk3(a.w1x, a.w1y, a.w1z);                       // ray_tracer.cu:160-161
     const uint64_t g = a.ray_first + slot;                                // rayIndex = z*W*W + y*W + x  :151

@@ -40,19 +40,24 @@ __device__ __forceinline__ TriHit tri_test(const RtsLeafTri& L, dvec3 o, dvec3 d
     return h;
 }
 
-template <bool COUNT>
+// KEEP_ALL is a template parameter, not a run-time flag: hipcc (ROCm 7.2) lowered the uniform
+// `if (a.keep_all)` to a per-lane v_cmp mask computed under the divergent exec of the bounce loop
+// and re-used it at the write-back under a different exec, so lanes that were inactive at the
+// definition stored through the null all_records pointer.
+template <bool COUNT, bool KEEP_ALL>
 __global__ void __launch_bounds__(RTS_BLOCK) k_trace(const RtsTraceArgs a)
 {
     __shared__ int32_t s_stack[RTS_STACK_LDS * RTS_BLOCK];
     const uint32_t tid = threadIdx.x;
     const uint32_t gtid = blockIdx.x * RTS_BLOCK + tid;
-    const dvec3 origin = mk3(a.ox, a.oy, a.oz);
+    const RtsLaunchConsts& lc = *a.lc;
+    const dvec3 origin = mk3(lc.ox, lc.oy, lc.oz);
     unsigned long long n_seg = 0, n_shaded = 0, n_nodes = 0, n_tris = 0, n_spill = 0;
     bool hard_overflow = false;
 
     for (uint32_t slot = gtid; slot < a.n_rays; slot += a.total_threads) {
         // ---------------------------------------------------------------- ray_generation
-        dvec3 dir = rts_primary_dir(a, slot);
+        dvec3 dir = rts_primary_dir(lc, slot);
         // payload, ray_tracer.cu:212-224
         dvec3 prev = origin;
         dvec3 first = mk3(0.0, 0.0, 0.0);
@@ -123,7 +128,7 @@ __global__ void __launch_bounds__(RTS_BLOCK) k_trace(const RtsTraceArgs a)
                     }
                 }
             }
-            if (a.keep_all) {
+            if (KEEP_ALL) {
                 const size_t hidx = (size_t)slot * (a.max_refl + 1) + reflDepth;
                 a.hit_prim[hidx] = (best_leaf >= 0) ? (int32_t)best_prim : -1;
                 a.hit_t[hidx] = (best_leaf >= 0) ? best_t : 0.0f;
@@ -264,13 +269,13 @@ __global__ void __launch_bounds__(RTS_BLOCK) k_trace(const RtsTraceArgs a)
 
         // ---------------------------------------------------------------- write-back (ray_tracer.cu:246-253)
         const bool recv = received >= 0;
-        if (recv || a.keep_all) {
+        if (recv || KEEP_ALL) {
             RtsEndRecord r;
             r.rayLength = rayLength; r.power = power; r.doppler = doppler;
             r.prevx = prev.x; r.prevy = prev.y; r.prevz = prev.z;
             r.firstx = first.x; r.firsty = first.y; r.firstz = first.z;
             r.path_lo = path_lo; r.path_hi = path_hi; r.slot = slot; r.received = received; r.reflDepth = reflDepth; r.pad = 0;
-            if (a.keep_all) a.all_records[slot] = r;
+            if (KEEP_ALL) a.all_records[slot] = r;
             if (recv) {
                 // the compiler folds this into one atomic per wave (v_mbcnt + s_bcnt1)
                 unsigned long long idx = atomicAdd(&a.counters[0], 1ULL);
@@ -297,8 +302,13 @@ int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a, bool count_traversal)
 {
     if (a.n_rays == 0) return RTS_OK;
     const unsigned grid = a.total_threads / RTS_BLOCK;
-    if (count_traversal) k_trace<true><<<grid, RTS_BLOCK, 0, c->stream>>>(a);
-    else k_trace<false><<<grid, RTS_BLOCK, 0, c->stream>>>(a);
+    if (a.keep_all) {
+        if (count_traversal) k_trace<true, true><<<grid, RTS_BLOCK, 0, c->stream>>>(a);
+        else k_trace<false, true><<<grid, RTS_BLOCK, 0, c->stream>>>(a);
+    } else {
+        if (count_traversal) k_trace<true, false><<<grid, RTS_BLOCK, 0, c->stream>>>(a);
+        else k_trace<false, false><<<grid, RTS_BLOCK, 0, c->stream>>>(a);
+    }
     RTS_HIP(hipGetLastError());
     return RTS_OK;
 }
