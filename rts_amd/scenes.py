@@ -137,6 +137,23 @@ def config3(W=216, detail=1.0, rx_radius=50.0, n_rx=4):
                 rx=rx, carrier=FC, c=C0)
 
 
+def config_multi(W=16, rx_radius=90.0, max_refl=4, smooth=True):
+    """Small multi-target scene for the parity tests: icosphere + rotated "rect" box (per-face normal
+    rule, triangle_mesh.cu:178-180) + file-style plate, two receivers, inter-target bounces."""
+    sv, st, sn = api.sphere_mesh(2, 4.0)
+    bv, bt, bn = api.rect_mesh(5.0, 5.0, 5.0, 0.5, 0.2, 0.1)
+    pv, pt, pn = plate_mesh(14.0)
+    Rp = api.rotation_matrix(math.radians(35.0), 0.0, 0.0).reshape(3, 3)
+    pv = pv @ Rp.T; pn = pn @ Rp.T
+    meshes = [dict(tris=st, verts=sv, normals=sn, refl_coeff=0.9, refr_index=1.0),
+              dict(tris=bt, verts=bv, normals=bn, refl_coeff=0.8, refr_index=1.0),
+              dict(tris=pt, verts=pv, normals=pn, refl_coeff=0.7, refr_index=1.0)]
+    motion = _static_motion(3, [(0.0, 0.0, 0.0), (2.0, 9.0, 1.0), (9.0, -7.0, 0.0)], [(10.0, 0.0, 0.0), (0.0, -5.0, 0.0), (0.0, 0.0, 3.0)])
+    rx = [_rx_at((-200.0, 0.0, 0.0), (0, 0, 0), rx_radius, 2.6), _rx_at((-150.0, 130.0, 10.0), (0, 0, 0), rx_radius, 2.6)]
+    return dict(name="multi-3targets", W=W, max_refl=max_refl, smooth=smooth, n_pulses=1, meshes=meshes, motion=motion,
+                tx=dict(origin=(-200.0, 0.0, 0.0), span=(0.16, 0.12, 0.05), dir=(0.0, 0.0)), rx=rx, carrier=FC, c=C0)
+
+
 def config5_motion(pulse, speed=200.0, yaw_rate=1.0, prf=1000.0):
     """C5: per-pulse rigid transform of the C3 mesh (v = 200 m/s along +y, 1 rad/s yaw)."""
     tt = pulse / prf

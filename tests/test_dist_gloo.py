@@ -1,0 +1,83 @@
+"""The N > 1 path on the CPU: two gloo ranks shard a pulse's launch indices, each rank reduces ITS
+received rays to a (receiver, path) group table, the tables travel through
+rts_amd.multigpu (all-gather) and are merged by librts_amd's host routines.  The merged
+responses must equal the literal single-process aggregation of the whole pulse.
+
+On the CPU there is no device to trace with, so each rank's received set is produced by the
+oracle for the rank's launch-index range (the oracle stands in for the device here, as the
+checker's input generator); what is under test is the product's sharding arithmetic, the
+exchange and the merge."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+C0 = 299792458.0
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from rts_amd import scenes, multigpu
+    import helpers as H
+    from test_host_logic import numpy_group_table
+    spec = scenes.config_multi(W=16)
+    total = spec["W"] ** 3
+    first, count = multigpu.shard_range(total, rank, world)
+    o = H.oracle_trace(O, spec, ray_first=first, ray_stride=1, n_rays=count)
+    wl = spec["c"] / spec["carrier"]
+    rx, rxi, slots = O.filter_finalise(o["results"], o["path"], [1.0] * 3, wl, 1.0, 1.0, spec["carrier"], spec["c"])
+    base, counts = multigpu.exchange_received_base(len(rx), dist, torch)
+    local = numpy_group_table(rx, rxi, spec["c"], spec["carrier"], base=base)
+    allg = multigpu.gather_groups(local, dist, torch)
+    resp, merged = multigpu.merge_and_respond(allg, spec["max_refl"])
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), resp=resp, merged=merged, counts=np.array(counts), base=base, first=first, count=count)
+    dist.barrier(); dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_rank_sharded_pulse(tmp_path, world, oracle):
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, HERE)
+    from rts_amd import scenes
+    import helpers as H
+    spec = scenes.config_multi(W=16)
+    o = H.oracle_trace(oracle, spec)
+    wl = spec["c"] / spec["carrier"]
+    rx, rxi, slots = oracle.filter_finalise(o["results"], o["path"], [1.0] * 3, wl, 1.0, 1.0, spec["carrier"], spec["c"])
+    lit = oracle.aggregate_literal(rx, rxi, spec["c"], spec["carrier"], spec["W"] ** 3)
+    uniq = oracle.unique_paths(lit["pathMatch"])
+    outs = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    assert sum(int(x["count"]) for x in outs) == spec["W"] ** 3
+    assert [int(x["first"]) for x in outs] == sorted(int(x["first"]) for x in outs)
+    assert int(outs[0]["counts"].sum()) == len(rx)
+    for x in outs:                                            # every rank ends with the same, complete answer
+        resp = x["resp"]
+        assert np.array_equal(resp["ray"].astype(np.int64), uniq.astype(np.int64))
+        np.testing.assert_allclose(resp["power"], lit["results"]["power"][uniq], rtol=1e-12)
+        np.testing.assert_allclose(resp["delay"], lit["delay"][uniq], rtol=1e-12)
+        np.testing.assert_allclose(resp["doppler"], lit["results"]["doppler"][uniq], rtol=1e-12, atol=1e-12)
+        assert int(x["merged"]["n"].sum()) == len(rx)
+
+
+def test_shard_ranges_cover_exactly():
+    from rts_amd import multigpu
+    for total in (1, 7, 10648, 216 ** 3):
+        for world in (1, 2, 3, 8):
+            r = [multigpu.shard_range(total, k, world) for k in range(world)]
+            assert r[0][0] == 0 and sum(c for _, c in r) == total
+            assert all(r[k][0] + r[k][1] == r[k + 1][0] for k in range(world - 1))
+            assert max(c for _, c in r) - min(c for _, c in r) <= 1

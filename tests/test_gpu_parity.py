@@ -1,0 +1,311 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C-ABI (ctypes -> librts_amd.so),
+against the CPU oracle and the committed golden vectors.
+
+Bar (BASELINE.json north_star): closest-hit primitive ids, f32 hit distances, depths, target
+paths, received flags and every f64 field of the per-ray record BIT-EXACT; RCS angles (libm vs
+OCML atan2) within 1e-12 rad; aggregated returns within 1e-9 relative (the north star allows
+1e-5), pathMatch exact.
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import helpers as H  # noqa: E402
+import make_golden  # noqa: E402
+from test_golden import check_against_golden, NAMES  # noqa: E402
+from test_host_logic import random_received_set  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+C0 = 299792458.0
+
+
+@pytest.fixture(scope="module")
+def scenes():
+    from rts_amd import scenes as S
+    return S
+
+
+def full_parity(api, O, spec, motion=None, bvh=False):
+    n = spec["W"] ** 3
+    tr, st = H.gpu_trace(api, spec, motion=motion)
+    g = tr.all_rays(n)
+    o = H.oracle_trace(O, spec, motion=motion, use_bvh=bvh, threads=4 if bvh else 1)
+    H.compare_full(o, g, n)
+    assert st["segments"] == o["counters"]["segments"] and st["shaded"] == o["counters"]["shaded"]
+    rec = tr.received()
+    idx = np.nonzero(o["results"]["received"] >= 0)[0]
+    assert st["received"] == len(idx)
+    assert np.array_equal(rec["slots"], idx.astype(np.uint64))           # ascending launch index == host scan order (ray_tracer.cpp:1190)
+    H.assert_prd_equal(o["results"][idx], rec["results"], "received records")
+    assert np.array_equal(o["path"][idx], rec["path"])
+    np.testing.assert_allclose(rec["rcs_angle"], o["rcs_angle"][idx], rtol=0, atol=1e-12)
+    return tr, st, o, g
+
+
+def test_device_math_is_ieee(rts, oracle):
+    """f64 divide / sqrt correctly rounded on gfx950 and the basic-op atan2f identical to the oracle's"""
+    tr = rts.Tracer(2, 1)
+    rng = np.random.default_rng(0)
+    n = 200000
+    y = (rng.normal(size=n) * 10.0 ** rng.uniform(-6, 6, n)).astype(np.float32)
+    x = (rng.normal(size=n) * 10.0 ** rng.uniform(-6, 6, n)).astype(np.float32)
+    y[:8] = [0, 0, 1, -1, 0, -0.0, 3, -3]; x[:8] = [1, -1, 0, 0, 0, -1, 3, -3]
+    a = rng.normal(size=n) * 10.0 ** rng.uniform(-100, 100, n); b = rng.normal(size=n) * 10.0 ** rng.uniform(-100, 100, n)
+    at, dv, sq = tr.self_test_math(y, x, a, b)
+    assert np.array_equal(dv.view(np.uint64), (a / b).view(np.uint64))
+    assert np.array_equal(sq.view(np.uint64), np.sqrt(np.abs(a)).view(np.uint64))
+    want = np.array([oracle.atan2f(yy, xx) for yy, xx in zip(y[:20000], x[:20000])], np.float32)
+    assert np.array_equal(at[:20000].view(np.uint32), want.view(np.uint32))
+    tr.close()
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_gpu_matches_golden(rts, name):
+    spec = make_golden.golden_specs()[name]
+    g = np.load(os.path.join(HERE, "golden", name + ".npz"))
+    n = spec["W"] ** 3
+    tr, st = H.gpu_trace(rts, spec)
+    a = tr.all_rays(n)
+    check_against_golden(g, a["results"], a["path"], a["hit_prim"], a["hit_t"], a["rcs_angle"])
+    assert st["segments"] == g["counters"][0] and st["shaded"] == g["counters"][1]
+    # finalise + aggregate on the device vs the golden literal aggregation
+    wl = spec["c"] / spec["carrier"]
+    tr.finalise_uniform([1.0] * len(spec["meshes"]), wl, 1.0, 1.0, spec["carrier"], spec["c"])
+    fin = tr.received()["results"]
+    assert np.array_equal(fin["power"], g["fin_power"]) and np.array_equal(fin["doppler"], g["fin_doppler"])
+    groups = tr.aggregate(spec["c"], spec["carrier"])
+    ag = tr.aggregated()
+    assert np.array_equal(ag["pathMatch"], g["agg_pathMatch"])
+    np.testing.assert_allclose(ag["results"]["power"], g["agg_power"], rtol=1e-12)
+    np.testing.assert_allclose(ag["results"]["doppler"], g["agg_doppler"], rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(ag["delay"], g["agg_delay"], rtol=1e-12)
+    np.testing.assert_allclose(ag["phase"], g["agg_phase"], rtol=1e-9, atol=1e-12)
+    resp = rts.groups_to_responses(groups)
+    assert np.array_equal(resp["ray"].astype(np.int64), g["unique"].astype(np.int64))
+    tr.close()
+
+
+def test_c1_plate_full(rts, oracle, scenes):
+    """BASELINE configs[0]: 2-triangle plate, 1 Tx / 1 Rx, 10 648 launch indices, 1 bounce"""
+    tr, st, o, g = full_parity(rts, oracle, scenes.config1())
+    assert st["rays"] == 22 ** 3 and st["received"] > 1000
+    tr.close()
+
+
+@pytest.mark.parametrize("smooth", [True, False])
+def test_sphere_smooth_and_flat(rts, oracle, scenes, smooth):
+    """interpolated vertex normals vs flat face normals (triangle_mesh.cu:175-194)"""
+    spec = scenes.config2(subdiv=3, W=20, rx_radius=400.0)
+    spec["smooth"] = smooth
+    tr, st, o, g = full_parity(rts, oracle, spec)
+    assert st["received"] > 0 and st["shaded"] > 3000
+    tr.close()
+
+
+@pytest.mark.parametrize("max_refl", [0, 1, 4, 9])
+def test_multi_target_depths(rts, oracle, scenes, max_refl):
+    """three targets incl. the "rect" per-face-normal rule, two receivers, inter-target bounces; depth 0 = every hit absorbed;
+    depth 9 exercises the second path word"""
+    spec = scenes.config_multi(W=18, max_refl=max_refl)
+    tr, st, o, g = full_parity(rts, oracle, spec)
+    if max_refl >= 4:
+        assert o["results"]["reflDepth"].max() >= 3
+        assert len(np.unique(o["path"][o["results"]["received"] >= 0], axis=0)) >= 2
+    tr.close()
+
+
+def test_aircraft_bvh_mode(rts, oracle, scenes):
+    """8 000-triangle airframe, 4 receivers: the device LBVH finds exactly the brute-force closest hits"""
+    spec = scenes.config3(W=22, detail=0.08, rx_radius=400.0)
+    tr, st, o, g = full_parity(rts, oracle, spec, bvh=True)
+    assert (g["hit_prim"][:, 0] >= 0).mean() > 0.1
+    tr.close()
+
+
+def test_rotating_moving_target(rts, oracle, scenes):
+    """per-pulse rigid transform (ray_tracer.cpp:993-1014): rotation of vertices AND normals, displacement, velocity"""
+    spec = scenes.config_multi(W=14)
+    tr = H.gpu_tracer(rts, spec, keep_all=True)
+    n = spec["W"] ** 3
+    for k in range(3):
+        mo = [dict(position=(0.3 * k, 0.1 * k, 0.0), velocity=(300.0, 100.0, 0.0), rotation=rts.rotation_matrix(0.2 * k, 0.05 * k, -0.1 * k)),
+              dict(position=(2.0, 9.0 - 0.5 * k, 1.0), velocity=(0.0, -500.0, 0.0)),
+              dict(position=(9.0, -7.0, 0.2 * k), velocity=(0.0, 0.0, 200.0), rotation=rts.rotation_matrix(0.0, 0.0, 0.3 * k))]
+        _, st = H.gpu_trace(rts, spec, tr=tr, motion=mo)
+        assert st["bvh_rebuilt"] == 1
+        H.compare_full(H.oracle_trace(oracle, spec, motion=mo), tr.all_rays(n), n)
+    _, st = H.gpu_trace(rts, spec, tr=tr, motion=mo)
+    assert st["bvh_rebuilt"] == 0                                        # unchanged placement: the LBVH is reused
+    tr.close()
+
+
+def test_edge_cases(rts, oracle, scenes):
+    # W = 1: boresight ray only (ray_tracer.cu:160-161), axis-aligned direction (zero components in the slab test)
+    spec = scenes.config1(); spec["W"] = 1
+    full_parity(rts, oracle, spec)[0].close()
+    # no targets at all: every ray goes straight to the miss program
+    spec = scenes.config1(); spec["W"] = 6; spec["meshes"] = []; spec["motion"] = []
+    spec["rx"] = [oracle.rx_sphere((500.0, 0.0, 0.0), math.pi, 0.0, 40.0, 2.0, 2.0)]
+    tr, st, o, g = full_parity(rts, oracle, spec)
+    assert st["shaded"] == 0 and st["received"] > 0 and (o["results"]["reflDepth"] == 0).all()   # direct rays
+    tr.close()
+    # no receivers: nothing can be received
+    spec = scenes.config2(subdiv=1, W=8); spec["rx"] = []
+    tr, st, o, g = full_parity(rts, oracle, spec)
+    assert st["received"] == 0 and tr.received()["results"].shape[0] == 0
+    tr.close()
+    # a degenerate (zero-area) triangle and a sliver next to real geometry, single-primitive scene
+    v = np.array([[0, -5, -5], [0, 5, -5], [0, 5, 5], [0, 0, 0], [0, 0, 0], [0, 1, 1], [0, -5, -5], [0, 5, 5], [0, -5, 5]], np.float64)
+    t = np.array([[0, 1, 2], [3, 4, 5], [6, 7, 8]], np.uint32); nrm = np.tile(np.array([[-1.0, 0, 0]]), (9, 1))
+    spec = scenes.config1(); spec["W"] = 12
+    spec["meshes"] = [dict(tris=t, verts=v, normals=nrm, refl_coeff=0.5, refr_index=1.0)]
+    full_parity(rts, oracle, spec)[0].close()
+    spec["meshes"] = [dict(tris=t[:1], verts=v[:3], normals=nrm[:3], refl_coeff=0.5, refr_index=1.0)]
+    full_parity(rts, oracle, spec)[0].close()
+
+
+def test_ragged_shards_equal_whole(rts, scenes):
+    """ray_first / ray_count ranges (multi-GPU sharding): concatenated shard outputs == the whole launch"""
+    spec = scenes.config_multi(W=16)
+    n = spec["W"] ** 3
+    tr = H.gpu_tracer(rts, spec)
+    H.gpu_trace(rts, spec, tr=tr)
+    whole = tr.received()
+    parts = []
+    for lo, hi in [(0, 1), (1, 1000), (1000, 1001), (1001, 4095), (4095, 4096)]:
+        _, st = H.gpu_trace(rts, spec, tr=tr, ray_first=lo, ray_count=hi - lo)
+        assert st["rays"] == hi - lo
+        parts.append(tr.received())
+    H.assert_prd_equal(np.concatenate([p["results"] for p in parts]), whole["results"], "shards")
+    assert np.array_equal(np.concatenate([p["slots"] for p in parts]), whole["slots"])
+    assert np.array_equal(np.concatenate([p["path"] for p in parts]), whole["path"])
+    from rts_amd import _lib
+    with pytest.raises(_lib.RtsError):
+        H.gpu_trace(rts, spec, tr=tr, ray_first=n - 5, ray_count=10)    # range outside W^3
+    tr.close()
+
+
+def test_bvh_invariants(rts, scenes):
+    """every primitive in exactly one leaf; every node reachable once; child boxes contain their subtrees"""
+    spec = scenes.config3(W=4, detail=0.2)
+    tr = H.gpu_tracer(rts, spec)
+    H.gpu_trace(rts, spec, tr=tr)
+    nodes, leaf_prim = tr.bvh()
+    nprim = spec["meshes"][0]["tris"].shape[0]
+    assert len(leaf_prim) == nprim and sorted(leaf_prim) == list(range(nprim)) and len(nodes) == nprim - 1
+    child = nodes[:, 12:14].copy().view(np.int32)
+    boxes = nodes[:, :12]
+    v = spec["meshes"][0]["verts"]; t = spec["meshes"][0]["tris"]
+    lo_p = v[t].min(axis=1); hi_p = v[t].max(axis=1)
+    seen_nodes = np.zeros(len(nodes), bool); seen_leaves = np.zeros(nprim, bool)
+    stack = [(0, np.full(3, -np.inf), np.full(3, np.inf))]
+    while stack:
+        i, plo, phi = stack.pop()
+        assert not seen_nodes[i]; seen_nodes[i] = True
+        b = boxes[i]
+        for c, lo, hi in ((child[i, 0], b[[0, 1, 2]], b[[3, 4, 5]]), (child[i, 1], b[[6, 7, 8]], b[[9, 10, 11]])):
+            assert (lo >= plo).all() and (hi <= phi).all()                 # nested in the parent's box
+            if c < 0:
+                leaf = ~c; assert not seen_leaves[leaf]; seen_leaves[leaf] = True
+                p = leaf_prim[leaf]
+                assert (lo.astype(np.float64) < lo_p[p]).all() and (hi.astype(np.float64) > hi_p[p]).all()   # padded outward
+            else:
+                stack.append((int(c), lo, hi))
+    assert seen_nodes.all() and seen_leaves.all()
+    tr.close()
+
+
+@pytest.mark.parametrize("seed,R,D,n_rx,n_targ", [(1, 50, 3, 2, 2), (2, 3000, 4, 4, 3), (3, 700, 1, 1, 1), (4, 5000, 6, 3, 1), (5, 1, 2, 1, 1)])
+def test_kernel_wrapper_equals_literal(rts, oracle, seed, R, D, n_rx, n_targ):
+    """rs::kernel_wrapper drop-in (aggregation.cuh:19-22): same in/out arrays as the O(R^2) myKernel1/2"""
+    rng = np.random.default_rng(seed)
+    a, paths = random_received_set(oracle, rng, R, D, n_rx, n_targ)
+    fc = 10e9
+    lit = oracle.aggregate_literal(a, paths, C0, fc, 10 ** 6)
+    got = rts.kernel_wrapper(a, paths, C0, fc, 10 ** 6)
+    assert np.array_equal(got["pathMatch"], lit["pathMatch"])
+    np.testing.assert_allclose(got["results"]["power"], lit["results"]["power"], rtol=1e-11)
+    np.testing.assert_allclose(got["results"]["doppler"], lit["results"]["doppler"], rtol=1e-10, atol=1e-9)
+    np.testing.assert_allclose(got["delay"], lit["delay"], rtol=1e-12)
+    np.testing.assert_allclose(got["phase"], lit["phase"], rtol=1e-9, atol=1e-11)
+    for f in ("rayLength", "received", "reflDepth", "firstHitPoint", "prevHitPoint"):
+        assert np.array_equal(got["results"][f], a[f])                   # untouched fields come back unchanged
+
+
+def test_aggregation_one_huge_group_is_deterministic(rts, oracle):
+    """200 000 rays in ONE (rx, path) group spanning hundreds of tiles: fixed-shape reduction, same bits every run"""
+    rng = np.random.default_rng(7)
+    R = 200000
+    a, paths = random_received_set(oracle, rng, R, 2, 1, 1, p_direct=0.0)
+    paths[:] = [0, -1]; a["reflDepth"] = 1
+    g1 = rts.kernel_wrapper(a, paths, C0, 1e10, 10 ** 7)
+    g2 = rts.kernel_wrapper(a, paths, C0, 1e10, 10 ** 7)
+    assert np.array_equal(g1["results"]["power"].view(np.uint64), g2["results"]["power"].view(np.uint64))
+    assert np.array_equal(g1["phase"].view(np.uint64), g2["phase"].view(np.uint64))
+    assert (g1["pathMatch"] == 0).all()
+    want = (np.sqrt(a["power"]).sum() / R) ** 2
+    np.testing.assert_allclose(g1["results"]["power"], want, rtol=1e-12)
+    np.testing.assert_allclose(g1["delay"], (a["rayLength"] / C0).mean(), rtol=1e-12)
+
+
+def test_full_size_properties(rts, oracle, scenes):
+    """BASELINE configs[2] at full size (100 000 triangles, W = 216, 10 077 696 launch indices):
+    size-independent properties + sampled parity against the oracle (BVH mode)."""
+    spec = scenes.config3(rx_radius=200.0)
+    n = spec["W"] ** 3
+    tr = H.gpu_tracer(rts, spec)
+    _, st = H.gpu_trace(rts, spec, tr=tr)
+    whole = tr.received()
+    assert st["rays"] == n and st["segments"] == n + st["shaded"]       # every shaded hit spawns exactly one more segment
+    assert st["stack_overflows"] == 0 or st["stack_overflows"] > 0      # spills are allowed, hard overflow would have raised
+    R = st["received"]
+    assert R == len(whole["slots"]) and R > 100
+    assert (np.diff(whole["slots"].astype(np.int64)) > 0).all()         # strictly ascending launch indices
+    # determinism: same bits on a second run
+    _, st2 = H.gpu_trace(rts, spec, tr=tr)
+    again = tr.received()
+    H.assert_prd_equal(whole["results"], again["results"], "run-to-run")
+    assert st2["bvh_rebuilt"] == 0
+    # shard invariance: two halves == whole
+    h = n // 2 + 12345
+    _, _ = H.gpu_trace(rts, spec, tr=tr, ray_first=0, ray_count=h); a = tr.received()
+    _, _ = H.gpu_trace(rts, spec, tr=tr, ray_first=h, ray_count=n - h); b = tr.received()
+    H.assert_prd_equal(np.concatenate([a["results"], b["results"]]), whole["results"], "halves")
+    assert np.array_equal(np.concatenate([a["slots"], b["slots"]]), whole["slots"])
+    # sampled parity: every 499th launch index through the oracle; its received subset must match record for record
+    stride = 499; m = n // stride
+    o = H.oracle_trace(oracle, spec, ray_first=7, ray_stride=stride, n_rays=m, use_bvh=True, threads=8, debug=False)
+    samp = 7 + stride * np.arange(m, dtype=np.int64)
+    o_idx = np.nonzero(o["results"]["received"] >= 0)[0]
+    pos = np.searchsorted(whole["slots"].astype(np.int64), samp)
+    pos_c = np.minimum(pos, R - 1)
+    is_recv = whole["slots"].astype(np.int64)[pos_c] == samp
+    assert np.array_equal(np.nonzero(is_recv)[0], o_idx)
+    H.assert_prd_equal(o["results"][o_idx], whole["results"][pos_c[is_recv]], "sampled received records")
+    assert np.array_equal(o["path"][o_idx], whole["path"][pos_c[is_recv]])
+    # aggregation closure: group counts add up to R; responses unique and ascending
+    wl = spec["c"] / spec["carrier"]
+    _, _ = H.gpu_trace(rts, spec, tr=tr)
+    tr.finalise_uniform(None, wl, 1.0, 1.0, spec["carrier"], spec["c"])
+    groups = tr.aggregate(spec["c"], spec["carrier"])
+    assert int(groups["n"].sum()) == R
+    resp = rts.groups_to_responses(groups)
+    assert (np.diff(resp["ray"].astype(np.int64)) > 0).all() and len(resp) >= 1
+    ag = tr.aggregated()
+    assert set(np.unique(ag["pathMatch"])) == set(resp["ray"].astype(np.int64))
+    tr.close()
+
+
+def test_traversal_counters(rts, scenes):
+    """counting build: node visits / triangle tests are reported and the result set is unchanged"""
+    spec = scenes.config2(subdiv=3, W=24, rx_radius=400.0)
+    tr = H.gpu_tracer(rts, spec); _, s0 = H.gpu_trace(rts, spec, tr=tr); r0 = tr.received(); tr.close()
+    tc = H.gpu_tracer(rts, spec, count_traversal=True); _, s1 = H.gpu_trace(rts, spec, tr=tc); r1 = tc.received(); tc.close()
+    assert s0["node_visits"] == 0 and s1["node_visits"] > s1["segments"] and s1["tri_tests"] > 0
+    assert s0["segments"] == s1["segments"]
+    H.assert_prd_equal(r0["results"], r1["results"], "counting build")

@@ -1,0 +1,192 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every declared
+symbol, the host scene helpers reproduce the reference's builders bit-for-bit (checked against
+the oracle), the group-table algebra reproduces the reference's aggregation semantics, and the
+compute entry points refuse to run without a GPU (there is no CPU fallback)."""
+import ctypes as C
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+C0 = 299792458.0
+
+
+def test_library_exports_every_declared_symbol(rts):
+    from rts_amd import _lib
+    L = _lib.lib()
+    hdr = open(os.path.join(ROOT, "include", "rts_amd.h")).read()
+    declared = sorted(set(re.findall(r"\b(rts_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(L, name), "librts_amd.so does not export %s" % name
+    assert sorted(_lib.EXPORTS) == declared
+    # the C++ symbol SOARS links against: rs::kernel_wrapper(PerRayData*, int*, unsigned, unsigned, unsigned, unsigned,
+    # double, double, double*, double*, double*, double*, double*, int*)   (aggregation.cuh:19-22)
+    assert hasattr(L, "_ZN2rs14kernel_wrapperEP10PerRayDataPijjjjddPdS3_S3_S3_S3_S2_")
+
+
+def test_no_cpu_fallback(rts):
+    """without a GPU the compute path must fail loudly, not silently compute on the host"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu tests")
+    from rts_amd import _lib
+    with pytest.raises(_lib.RtsError) as e:
+        rts.Tracer(4, 1)
+    assert e.value.code == _lib.RTS_ERR_NO_DEVICE
+    z = np.zeros(1, _lib.PRD_DTYPE)
+    with pytest.raises(_lib.RtsError):
+        rts.kernel_wrapper(z, np.zeros((1, 1), np.int32), C0, 1e9, 10)
+
+
+def test_prd_header_layout_matches_reference_struct():
+    """include/rts_prd.h compiles as plain C++ and has the 144-byte layout"""
+    import subprocess, tempfile
+    src = '#include "rts_prd.h"\n#include <cstdio>\nint main(){ printf("%zu %zu", sizeof(PerRayData), alignof(PerRayData)); return 0; }\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.cpp"), "w").write(src)
+        subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.cpp"), "-o", os.path.join(d, "t")])
+        out = subprocess.check_output([os.path.join(d, "t")]).decode()
+    assert out == "144 16"
+
+
+@pytest.mark.parametrize("ypr", [(0.0, 0.0, 0.0), (0.3, -0.2, 1.1), (math.pi / 2, math.pi, -2.5)])
+def test_rect_mesh_matches_oracle(rts, oracle, ypr):
+    a = rts.rect_mesh(2.0, 3.5, 0.25, *ypr); b = oracle.rect_mesh(2.0, 3.5, 0.25, *ypr)
+    for x, y in zip(a, b):
+        assert x.dtype == y.dtype and np.array_equal(x.view(np.uint8), y.view(np.uint8))
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 4])
+def test_sphere_mesh_matches_oracle(rts, oracle, n):
+    """the sort-based de-duplication must give the std::set vertex/triangle ORDER of ray_tracer.cpp:397-418"""
+    a = rts.sphere_mesh(n, 5.0, 0.4, 0.1, -0.7); b = oracle.sphere_mesh(n, 5.0, 0.4, 0.1, -0.7)
+    for x, y in zip(a, b):
+        assert x.shape == y.shape and np.array_equal(x.view(np.uint8), y.view(np.uint8))
+
+
+def test_file_mesh_matches_oracle(rts, oracle, tmp_path):
+    rng = np.random.default_rng(11)
+    vf, nf = tmp_path / "v.txt", tmp_path / "n.txt"
+    for f in (vf, nf):
+        with open(f, "w") as fh:
+            for row in rng.normal(size=(33, 9)) * 10:
+                fh.write("%.17g %.17g %.17g, %.17g %.17g %.17g, %.17g %.17g %.17g,\n" % tuple(row))
+    a = rts.file_mesh(str(vf), str(nf), 0.2, 0.3, 0.4); b = oracle.file_mesh(str(vf), str(nf), 0.2, 0.3, 0.4)
+    for x, y in zip(a, b):
+        assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
+    from rts_amd import _lib
+    with pytest.raises(_lib.RtsError) as e:            # the reference exit()s (ray_tracer.cpp:455-458); the library returns a status
+        rts.file_mesh(str(tmp_path / "nope"), str(nf))
+    assert e.value.code == _lib.RTS_ERR_IO
+
+
+def test_vertex_rotation_and_rx_sphere_match_oracle(rts, oracle):
+    rng = np.random.default_rng(2)
+    v = rng.normal(size=(50, 3))
+    for ypr in [(0.1, 0.2, 0.3), (-2.0, 1.0, 0.5)]:
+        assert np.array_equal(rts.vertex_rotation(v, *ypr), oracle.vertex_rotation(v, *ypr))
+        R = rts.rotation_matrix(*ypr).reshape(3, 3)
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-6)          # float trig: orthonormal to f32 accuracy only
+    for pos, az, el in [((-1000.0, 5.0, 2.0), 0.3, -0.1), ((10.0, 20.0, 30.0), 2.5, 0.7), ((0.0, 0.0, 0.0), -3.0, 1.2)]:
+        a = rts.rx_sphere(pos, az, el, 25.0, 1.0, 0.5); b = oracle.rx_sphere(pos, az, el, 25.0, 1.0, 0.5)
+        for k in ("radius", "minTheta", "maxTheta", "minPhi", "maxPhi"):
+            assert a[k] == b[k]
+        assert np.array_equal(a["centre"], b["centre"])
+
+
+# ------------------------------------------------------------------------------- group-table algebra
+def numpy_group_table(rx_results, rx_paths, cspeed, carrier, base=0):
+    """test-side reference group-by: (rx, path) -> partial sums (what rts_aggregate produces on the GPU)"""
+    from rts_amd._lib import GROUP_DTYPE, RTS_MAX_DEPTH
+    groups = {}
+    for i in range(len(rx_results)):
+        key = (int(rx_results["received"][i]),) + tuple(int(x) for x in rx_paths[i])
+        delay = rx_results["rayLength"][i] / cspeed
+        phase = -math.fmod(delay * 2 * math.pi * carrier, 2 * math.pi)
+        g = groups.setdefault(key, [0.0, 0.0, 0.0, 0.0, 0.0, base + i])
+        g[0] += 1; g[1] += math.sqrt(rx_results["power"][i]); g[2] += delay; g[3] += phase; g[4] += rx_results["doppler"][i]
+    out = np.zeros(len(groups), GROUP_DTYPE)
+    for j, (key, g) in enumerate(sorted(groups.items())):
+        out[j]["rx"] = key[0]; out[j]["path"][:] = -1; out[j]["path"][:len(key) - 1] = key[1:]
+        out[j]["direct"] = 1 if all(k < 0 for k in key[1:]) else 0
+        out[j]["n"], out[j]["sum_sqrt_power"], out[j]["sum_delay"], out[j]["sum_phase"], out[j]["sum_doppler"] = g[:5]
+        out[j]["min_ray"] = g[5]
+    return out
+
+
+def random_received_set(oracle, rng, R, D, n_rx, n_targ, p_direct=0.2):
+    a = np.zeros(R, oracle.PRD_DTYPE)
+    a["received"] = rng.integers(0, n_rx, R); a["refrIndex"] = 1.0
+    a["power"] = rng.uniform(1e-12, 1e-9, R); a["rayLength"] = rng.uniform(1000, 3000, R); a["doppler"] = rng.normal(size=R) * 100
+    paths = np.full((R, D), -1, np.int32)
+    depth = rng.integers(1, D + 1, R)
+    direct = rng.random(R) < p_direct
+    depth[direct] = 0
+    for i in range(R):
+        paths[i, :depth[i]] = rng.integers(0, n_targ, depth[i])
+    a["reflDepth"] = depth
+    return a, paths
+
+
+@pytest.mark.parametrize("seed,R,D,n_rx,n_targ", [(1, 60, 3, 2, 2), (2, 400, 4, 4, 3), (3, 25, 1, 1, 1), (4, 300, 6, 3, 1)])
+def test_groups_to_responses_equals_reference_aggregation(rts, oracle, seed, R, D, n_rx, n_targ):
+    """responses derived from the (receiver, path) group table == unique-path responses of the literal
+    O(R^2) restatement of myKernel1/2 (aggregation.cu:32-97, ray_tracer.cpp:1290-1321), including the
+    direct-ray rule and its collapse (quirk 9)"""
+    rng = np.random.default_rng(seed)
+    a, paths = random_received_set(oracle, rng, R, D, n_rx, n_targ)
+    fc = 10e9
+    lit = oracle.aggregate_literal(a, paths, C0, fc, 10 ** 6)
+    uniq = oracle.unique_paths(lit["pathMatch"])
+    resp = rts.groups_to_responses(numpy_group_table(a, paths, C0, fc))
+    assert np.array_equal(resp["ray"].astype(np.int64), uniq.astype(np.int64))
+    assert np.array_equal(resp["rx"], lit["results"]["received"][uniq])
+    np.testing.assert_allclose(resp["power"], lit["results"]["power"][uniq], rtol=1e-12)
+    np.testing.assert_allclose(resp["doppler"], lit["results"]["doppler"][uniq], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(resp["delay"], lit["delay"][uniq], rtol=1e-12)
+    np.testing.assert_allclose(resp["phase"], lit["phase"][uniq], rtol=1e-9, atol=1e-12)
+    assert np.array_equal(resp["n"], lit["npath"][uniq].astype(np.uint32))
+
+
+def test_merge_groups_is_shard_invariant(rts, oracle):
+    """splitting the received list into contiguous shards, grouping each and merging == grouping the whole"""
+    rng = np.random.default_rng(9)
+    a, paths = random_received_set(oracle, rng, 500, 4, 3, 2)
+    fc = 10e9
+    whole = numpy_group_table(a, paths, C0, fc)
+    for cuts in ([0, 250, 500], [0, 10, 11, 300, 500], [0, 500], [0, 0, 123, 500]):
+        parts = [numpy_group_table(a[lo:hi], paths[lo:hi], C0, fc, base=lo) for lo, hi in zip(cuts[:-1], cuts[1:])]
+        merged = rts.merge_groups(np.concatenate(parts), 4)
+        assert len(merged) == len(whole)
+        assert np.array_equal(merged["rx"], whole["rx"]) and np.array_equal(merged["path"], whole["path"])
+        assert np.array_equal(merged["min_ray"], whole["min_ray"]) and np.array_equal(merged["n"], whole["n"])
+        for f in ("sum_sqrt_power", "sum_delay", "sum_phase", "sum_doppler"):
+            np.testing.assert_allclose(merged[f], whole[f], rtol=1e-12, atol=1e-15)
+        ra = rts.groups_to_responses(merged); rb = rts.groups_to_responses(whole)
+        assert np.array_equal(ra["ray"], rb["ray"])
+        np.testing.assert_allclose(ra["power"], rb["power"], rtol=1e-12)
+
+
+def test_empty_tables(rts):
+    from rts_amd._lib import GROUP_DTYPE
+    assert len(rts.merge_groups(np.zeros(0, GROUP_DTYPE), 3)) == 0
+    assert len(rts.groups_to_responses(np.zeros(0, GROUP_DTYPE))) == 0
+
+
+def test_scene_generators():
+    from rts_amd import scenes
+    v, t, n = scenes.aircraft_mesh()
+    assert t.shape == (100000, 3) and t.max() == v.shape[0] - 1 and n.shape == v.shape
+    a = v[t[:, 1]] - v[t[:, 0]]; b = v[t[:, 2]] - v[t[:, 0]]
+    assert (np.linalg.norm(np.cross(a, b), axis=1) > 0).all()            # no degenerate triangles
+    assert np.allclose(np.linalg.norm(n, axis=1), 1.0)
+    s = scenes.config3()
+    assert s["W"] == 216 and s["max_refl"] == 6 and len(s["rx"]) == 4 and s["meshes"][0]["tris"].shape[0] == 100000
+    s2 = scenes.config2()
+    assert s2["meshes"][0]["tris"].shape[0] == 20480 and s2["W"] == 100 and s2["max_refl"] == 4
+    s1 = scenes.config1()
+    assert s1["meshes"][0]["tris"].shape[0] == 2 and s1["W"] == 22 and s1["max_refl"] == 1
