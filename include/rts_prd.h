@@ -10,6 +10,9 @@
 #define RTS_PRD_H
 
 #include <stddef.h>
+#ifndef __cplusplus
+#include <stdbool.h>
+#endif
 
 #ifndef SCENE_EPS
 #define SCENE_EPS 0.005f   /* minimum incident / refracted ray length   (ray_tracer.h:9)  */
@@ -26,7 +29,7 @@ typedef double3 rts_double3;
 #else
 typedef struct rts_double2_s { double x, y; } __attribute__((aligned(16))) rts_double2;
 typedef struct rts_double3_s { double x, y, z; } rts_double3;
-#ifndef RTS_NO_VECTOR_ALIASES
+#ifdef RTS_DEFINE_VECTOR_ALIASES   /* opt-in: CUDA/HIP spellings for host code that has no vector header */
 typedef rts_double2 double2;
 typedef rts_double3 double3;
 #endif

@@ -309,3 +309,51 @@ def test_traversal_counters(rts, scenes):
     assert s0["node_visits"] == 0 and s1["node_visits"] > s1["segments"] and s1["tri_tests"] > 0
     assert s0["segments"] == s1["segments"]
     H.assert_prd_equal(r0["results"], r1["results"], "counting build")
+
+
+def test_adapter_end_to_end(rts, oracle, tmp_path):
+    """rs::RTS drop-in: include/rts_adapter.hpp driven by a mock SOARS World (3 pulses, moving + rotating targets,
+    2 receivers) emits exactly the responses of the literal pipeline: oracle trace -> host finalise
+    (ray_tracer.cpp:1190-1258) -> O(R^2) aggregation -> unique paths (ray_tracer.cpp:1290-1321)."""
+    import subprocess
+    from test_host_logic import build_adapter_binary
+    exe = build_adapter_binary(str(tmp_path / "adapter_main"))
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    got = np.array([[float(x) for x in line.split()] for line in out.stdout.strip().splitlines()])
+    # the same scene through the oracle
+    c, fc, Ts, W, max_refl = C0, 10e9, 1e-3, 16, 4
+    sv, st_, sn = oracle.sphere_mesh(2, 4.0)
+    bv, bt, bn = oracle.rect_mesh(5.0, 5.0, 5.0, 0.5, 0.2, 0.1)
+    pv, pt, pn = oracle.rect_mesh(0.2, 14.0, 14.0, 0.6, 0.0, 0.0)
+    p0 = np.array([[0, 0, 0], [2, 9, 1], [9, -7, 0]], np.float64); vel = np.array([[10, 0, 0], [0, -5, 0], [0, 0, 3]], np.float64)
+    rxs = [oracle.rx_sphere((-200.0, 0.0, 0.0), 0.0, 0.0, 90.0, 2.6, 2.6),
+           oracle.rx_sphere((-150.0, 130.0, 10.0), math.atan2(-130.0, 150.0), math.atan2(-10.0, math.hypot(150.0, 130.0)), 90.0, 2.6, 2.6)]
+    want = []
+    for k in range(3):
+        t = k * Ts
+        sc = oracle.Scene()
+        for i, (v, tri, nrm, refl) in enumerate([(sv, st_, sn, 0.9), (bv, bt, bn, 0.8), (pv, pt, pn, 0.7)]):
+            pos = p0[i] + vel[i] * t; pos1 = p0[i] + vel[i] * (t + Ts)
+            vv, nn = v, nrm
+            if i == 1 and t > 0.0:                            # rotating target: ypr(t) applied to the t = 0 mesh (ray_tracer.cpp:993-1007)
+                ypr = (np.float32(0.5 + 30.0 * t), np.float32(0.2), np.float32(0.1))
+                vv = oracle.vertex_rotation(v, *ypr); nn = oracle.vertex_rotation(nrm, *ypr)
+            sc.add_mesh(tri, vv + pos, nn, refl, 1.0, (pos1 - pos) / Ts)
+        sc.set_receivers(rxs)
+        o = sc.trace((-200.0, 0.0, 0.0), (0.16, 0.12, 0.05), (0.0, 0.0), W, max_refl)
+        rx, rxi, slots = oracle.filter_finalise(o["results"], o["path"], [1.0, 1.0, 1.0], c / fc, 1.0, 1.0, fc, c)
+        lit = oracle.aggregate_literal(rx, rxi, c, fc, W ** 3)
+        for u in oracle.unique_paths(lit["pathMatch"]):
+            want.append([t, lit["results"]["received"][u], lit["results"]["power"][u], lit["delay"][u], lit["results"]["doppler"][u], lit["phase"][u]])
+    want = np.array(want)
+    assert len(want) > 3
+    key = lambda a: np.lexsort((a[:, 3], a[:, 1], np.round(a[:, 0] * 1e6)))          # order by (pulse, rx, delay)
+    got = got[key(got)]; want = want[key(want)]
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got[:, 0], want[:, 0], atol=1e-12)
+    assert np.array_equal(got[:, 1], want[:, 1])
+    np.testing.assert_allclose(got[:, 2], want[:, 2], rtol=1e-9)                    # power
+    np.testing.assert_allclose(got[:, 3], want[:, 3], rtol=1e-12)                   # delay
+    np.testing.assert_allclose(got[:, 4], want[:, 4], rtol=1e-9, atol=1e-6)         # doppler [Hz]
+    np.testing.assert_allclose(got[:, 5], want[:, 5], rtol=1e-9, atol=1e-9)         # phase

@@ -190,3 +190,19 @@ def test_scene_generators():
     assert s2["meshes"][0]["tris"].shape[0] == 20480 and s2["W"] == 100 and s2["max_refl"] == 4
     s1 = scenes.config1()
     assert s1["meshes"][0]["tris"].shape[0] == 2 and s1["W"] == 22 and s1["max_refl"] == 1
+
+
+def build_adapter_binary(out_path):
+    """compiles tests/adapter/adapter_main.cpp (include/rts_adapter.hpp over the mock SOARS World) with g++"""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "adapter", "adapter_main.cpp")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tests", "adapter"),
+                           src, "-L", os.path.join(ROOT, "rts_amd"), "-lrts_amd", "-Wl,-rpath," + os.path.join(ROOT, "rts_amd"), "-o", out_path])
+    return out_path
+
+
+def test_adapter_header_compiles_and_links(rts, tmp_path):
+    """the rs::RTS replacement (header-only, templated on the simulator's types) builds with a plain host
+    compiler against the C-ABI and resolves rs::kernel_wrapper from librts_amd.so"""
+    exe = build_adapter_binary(str(tmp_path / "adapter_main"))
+    assert os.path.exists(exe)
