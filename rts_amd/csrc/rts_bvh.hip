@@ -71,16 +71,22 @@ __global__ void k_prim_boxes(const uint32_t* __restrict__ tri_vidx, const double
         }
         if (!ok) { o[0] = o[1] = o[2] = 3.0e38f; o[3] = o[4] = o[5] = -3.0e38f; }   // empty box: never hit
     }
-    // wave reduction of centre bounds, one atomic set per wave
+    // block reduction of centre bounds (wave shuffles, then LDS), one atomic set per block
     float mnx = ok ? cx : 3.0e38f, mny = ok ? cy : 3.0e38f, mnz = ok ? cz : 3.0e38f;
     float mxx = ok ? cx : -3.0e38f, mxy = ok ? cy : -3.0e38f, mxz = ok ? cz : -3.0e38f;
     for (int off = 32; off > 0; off >>= 1) {
         mnx = fminf(mnx, __shfl_down(mnx, off)); mny = fminf(mny, __shfl_down(mny, off)); mnz = fminf(mnz, __shfl_down(mnz, off));
         mxx = fmaxf(mxx, __shfl_down(mxx, off)); mxy = fmaxf(mxy, __shfl_down(mxy, off)); mxz = fmaxf(mxz, __shfl_down(mxz, off));
     }
-    if ((threadIdx.x & 63) == 0) {
-        atomicMin(&bounds[0], f2ord(mnx)); atomicMin(&bounds[1], f2ord(mny)); atomicMin(&bounds[2], f2ord(mnz));
-        atomicMax(&bounds[3], f2ord(mxx)); atomicMax(&bounds[4], f2ord(mxy)); atomicMax(&bounds[5], f2ord(mxz));
+    __shared__ float s_red[4][6];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_red[wave][0] = mnx; s_red[wave][1] = mny; s_red[wave][2] = mnz; s_red[wave][3] = mxx; s_red[wave][4] = mxy; s_red[wave][5] = mxz; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        float v = s_red[0][k];
+        for (int w = 1; w < (int)(blockDim.x >> 6); w++) v = (k < 3) ? fminf(v, s_red[w][k]) : fmaxf(v, s_red[w][k]);
+        if (k < 3) atomicMin(&bounds[k], f2ord(v)); else atomicMax(&bounds[k], f2ord(v));
     }
 }
 
@@ -136,7 +142,7 @@ __device__ __forceinline__ int lcp(const uint64_t* __restrict__ keys, int n, int
 }
 
 __global__ void k_hierarchy(const uint64_t* __restrict__ keys, RtsNode* __restrict__ nodes, int32_t* __restrict__ parent,
-                            int32_t* __restrict__ leaf_parent, int n)
+                            int32_t* __restrict__ leaf_parent, int2* __restrict__ range, int n)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
@@ -159,48 +165,92 @@ __global__ void k_hierarchy(const uint64_t* __restrict__ keys, RtsNode* __restri
     if (lo == gamma) { left = ~gamma; leaf_parent[gamma] = i; } else { left = gamma; parent[gamma] = i; }
     if (hi == gamma + 1) { right = ~(gamma + 1); leaf_parent[gamma + 1] = i; } else { right = gamma + 1; parent[gamma + 1] = i; }
     nodes[i].c0 = left; nodes[i].c1 = right; nodes[i].pad0 = 0; nodes[i].pad1 = 0;
+    range[i] = make_int2(lo, hi);
     if (i == 0) parent[0] = -1;
 }
 
-__device__ __forceinline__ void load_box(const float* __restrict__ prim_box, const uint32_t* __restrict__ sorted_prim,
-                                         const float* node_box, int child, float b[6])
+// Bottom-up refit.  Each node record stores the boxes of its two children; a walker that
+// carries the finished box of a subtree writes it into its parent's child slot and bumps the
+// parent's arrival counter: the first arriver stops, the second reads the sibling box, forms the
+// union and carries on upward.
+//   * local phase: one workgroup owns RF_CHUNK consecutive leaves; every node whose leaf range
+//     lies inside the chunk (it then has index in [c0, c0+RF_CHUNK)) is resolved through LDS
+//     counters and LDS copies of the child boxes -- no inter-workgroup traffic at all;
+//   * global phase: the O(log n) subtree roots per chunk whose parents span chunks go through
+//     global memory: sc1 stores of the box, ONE acq_rel agent-scope counter bump per level (per-XCD
+//     L2s and per-CU L1s are not coherent), sc1 loads of the sibling box.
+#define RF_CHUNK 1024
+#define RF_THREADS 256
+#define RF_PEND 256
+
+__device__ __forceinline__ void box_union(float a[6], const float b[6]) {
+    a[0] = fminf(a[0], b[0]); a[1] = fminf(a[1], b[1]); a[2] = fminf(a[2], b[2]);
+    a[3] = fmaxf(a[3], b[3]); a[4] = fmaxf(a[4], b[4]); a[5] = fmaxf(a[5], b[5]);
+}
+
+__device__ __forceinline__ void refit_global_walk(RtsNode* nodes, const int32_t* __restrict__ parent, uint32_t* flags, int p, int child, float box[6])
 {
-    if (child < 0) {
-        const float* p = prim_box + 6*(size_t)sorted_prim[~child];
-        for (int k = 0; k < 6; k++) b[k] = p[k];
-    } else {
-        // written by another workgroup in this launch: read past the (non-coherent) L1
-        for (int k = 0; k < 6; k++) b[k] = __hip_atomic_load(node_box + 6*(size_t)child + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (p >= 0) {
+        float* nd = reinterpret_cast<float*>(nodes + p);
+        const int slot = (reinterpret_cast<const int32_t*>(nd)[12] == child) ? 0 : 1;
+        for (int k = 0; k < 6; k++) __hip_atomic_store(nd + 6*slot + k, box[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned old = __hip_atomic_fetch_add(&flags[p], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == 0) return;
+        float sib[6];
+        for (int k = 0; k < 6; k++) sib[k] = __hip_atomic_load(nd + 6*(slot ^ 1) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        box_union(box, sib);
+        child = p; p = parent[p];
     }
 }
 
-__global__ void k_refit(const float* __restrict__ prim_box, const uint32_t* __restrict__ sorted_prim, RtsNode* nodes,
-                        float* node_box, const int32_t* __restrict__ parent, const int32_t* __restrict__ leaf_parent,
-                        uint32_t* flags, int n)
+__global__ void __launch_bounds__(RF_THREADS) k_refit(const float* __restrict__ prim_box, const uint32_t* __restrict__ sorted_prim, RtsNode* nodes,
+        const int32_t* __restrict__ parent, const int32_t* __restrict__ leaf_parent, const int2* __restrict__ range, uint32_t* flags, int n)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int node = leaf_parent[i];
-    while (node >= 0) {
-        // second arriver proceeds; acq_rel at agent scope publishes our node_box stores
-        // and makes the sibling's visible (per-XCD L2s / per-CU L1s are not coherent)
-        unsigned old = __hip_atomic_fetch_add(&flags[node], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == 0) return;
-        int c0 = nodes[node].c0, c1 = nodes[node].c1;
-        float a[6], b[6];
-        load_box(prim_box, sorted_prim, node_box, c0, a);
-        load_box(prim_box, sorted_prim, node_box, c1, b);
-        RtsNode* nd = nodes + node;
-        nd->lo0x = a[0]; nd->lo0y = a[1]; nd->lo0z = a[2]; nd->hi0x = a[3]; nd->hi0y = a[4]; nd->hi0z = a[5];
-        nd->lo1x = b[0]; nd->lo1y = b[1]; nd->lo1z = b[2]; nd->hi1x = b[3]; nd->hi1y = b[4]; nd->hi1z = b[5];
-        float* nb = node_box + 6*(size_t)node;
-        __hip_atomic_store(nb + 0, fminf(a[0], b[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(nb + 1, fminf(a[1], b[1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(nb + 2, fminf(a[2], b[2]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(nb + 3, fmaxf(a[3], b[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(nb + 4, fmaxf(a[4], b[4]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(nb + 5, fmaxf(a[5], b[5]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        node = parent[node];
+    __shared__ float s_cbox[RF_CHUNK][2][6];
+    __shared__ int s_flag[RF_CHUNK];
+    __shared__ float s_pbox[RF_PEND][6];
+    __shared__ int s_pnode[RF_PEND], s_pchild[RF_PEND];
+    __shared__ int s_npend;
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * RF_CHUNK;
+    const int c1 = min(c0 + RF_CHUNK, n) - 1;
+    for (int k = tid; k < RF_CHUNK; k += RF_THREADS) s_flag[k] = 0;
+    if (tid == 0) s_npend = 0;
+    __syncthreads();
+    for (int k = 0; k < RF_CHUNK / RF_THREADS; k++) {
+        const int leaf = c0 + k * RF_THREADS + tid;
+        if (leaf > c1) continue;
+        float box[6];
+        { const float* pb = prim_box + 6*(size_t)sorted_prim[leaf]; for (int q = 0; q < 6; q++) box[q] = pb[q]; }
+        int child = ~leaf, p = leaf_parent[leaf];
+        while (p >= 0) {
+            const int2 r = range[p];
+            if (r.x < c0 || r.y > c1) {                       // parent spans chunks: hand over to the global phase
+                const int idx = atomicAdd(&s_npend, 1);
+                if (idx < RF_PEND) { s_pnode[idx] = p; s_pchild[idx] = child; for (int q = 0; q < 6; q++) s_pbox[idx][q] = box[q]; }
+                else refit_global_walk(nodes, parent, flags, p, child, box);      // list full (cannot happen for depth < 128)
+                break;
+            }
+            float* nd = reinterpret_cast<float*>(nodes + p);
+            const int slot = (reinterpret_cast<const int32_t*>(nd)[12] == child) ? 0 : 1;
+            const int li = p - c0;
+            for (int q = 0; q < 6; q++) { nd[6*slot + q] = box[q]; s_cbox[li][slot][q] = box[q]; }
+            __threadfence_block();
+            const int old = atomicAdd(&s_flag[li], 1);
+            if (old == 0) break;
+            __threadfence_block();
+            float sib[6];
+            for (int q = 0; q < 6; q++) sib[q] = s_cbox[li][slot ^ 1][q];
+            box_union(box, sib);
+            child = p; p = parent[p];
+        }
+    }
+    __syncthreads();
+    const int np = min(s_npend, RF_PEND);
+    for (int i = tid; i < np; i += RF_THREADS) {
+        float box[6];
+        for (int q = 0; q < 6; q++) box[q] = s_pbox[i][q];
+        refit_global_walk(nodes, parent, flags, s_pnode[i], s_pchild[i], box);
     }
 }
 
@@ -243,8 +293,8 @@ int rts_bvh_build(RtsContext* c)
         c->n_nodes = 1;
     } else {
         RTS_HIP(hipMemsetAsync(c->d_flags.p, 0, sizeof(uint32_t) * n, st));
-        k_hierarchy<<<blocks_for(n - 1, 256), 256, 0, st>>>(c->d_keys_sorted.p, c->d_nodes.p, c->d_parent.p, c->d_leaf_parent.p, (int)n);
-        k_refit<<<blocks_for(n, 256), 256, 0, st>>>(c->d_prim_box.p, c->d_vals_sorted.p, c->d_nodes.p, c->d_node_box.p, c->d_parent.p, c->d_leaf_parent.p, c->d_flags.p, (int)n);
+        k_hierarchy<<<blocks_for(n - 1, 256), 256, 0, st>>>(c->d_keys_sorted.p, c->d_nodes.p, c->d_parent.p, c->d_leaf_parent.p, (int2*)c->d_node_box.p, (int)n);
+        k_refit<<<blocks_for(n, RF_CHUNK), RF_THREADS, 0, st>>>(c->d_prim_box.p, c->d_vals_sorted.p, c->d_nodes.p, c->d_parent.p, c->d_leaf_parent.p, (const int2*)c->d_node_box.p, c->d_flags.p, (int)n);
         c->n_nodes = n - 1;
     }
     RTS_HIP(hipGetLastError());

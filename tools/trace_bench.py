@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Kernel-level A/B harness: times the stages of one pulse (HIP events inside the library) on the
+bench scenes and prints a checksum of the received set, so that a kernel change that alters any
+result bit is caught immediately.   python tools/trace_bench.py [c2|c3|c3s] [reps]"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from rts_amd import api, scenes  # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else "c3"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+spec = {"c2": lambda: scenes.config2(rx_radius=200.0), "c3": lambda: scenes.config3(rx_radius=50.0),
+        "c3s": lambda: scenes.config3(W=100, rx_radius=50.0)}[which]()
+tr = api.Tracer(spec["W"], spec["max_refl"], 0, spec["smooth"])
+tr.set_scene(spec["meshes"]); tr.set_receivers(spec["rx"])
+tx = spec["tx"]
+ms = []
+for k in range(reps + 1):
+    mo = [dict(position=(0.2 * k, 0.02 * k, 0.0), velocity=(200.0, 20.0, 0.0)) for _ in spec["meshes"]]
+    st = tr.trace(tx["origin"], tx["span"], tx["dir"], mo)
+    if k:
+        ms.append((st["ms_scene"], st["ms_trace"], st["ms_compact"]))
+rec = tr.received()
+h = hashlib.sha1(np.ascontiguousarray(rec["results"]["power"]).tobytes() + np.ascontiguousarray(rec["slots"]).tobytes() +
+                 np.ascontiguousarray(rec["path"]).tobytes()).hexdigest()[:16]
+ms = np.array(ms)
+print("%s: segs %d recv %d | scene %.3f trace %.3f (min %.3f) compact %.3f ms | %.2f Gseg/s | sha %s" %
+      (spec["name"], st["segments"], st["received"], ms[:, 0].mean(), ms[:, 1].mean(), ms[:, 1].min(), ms[:, 2].mean(),
+       st["segments"] / ms[:, 1].min() / 1e6, h))
