@@ -10,12 +10,16 @@ metric ("Mrays/s ... 100k-tri scene") is quoted on.  Synthetic mesh, isotropic a
 
 A step is ONE PULSE end to end: target placement for that pulse (the target moves every
 pulse, so the LBVH is rebuilt on the device inside the timed region, as the reference rebuilds
-its acceleration structure every pulse), trace of this rank's share of the W^3 launch
-indices, ordering + expansion of the received rays, finalisation, group-by aggregation and --
-for N > 1 -- the all-gather of the per-(receiver, path) group tables over RCCL and their
-merge into the pulse's responses.  A "ray" in Mrays/s is one traced segment (one rtTrace of
-the reference: primary or bounce).  Scaling is strong: the pulse's W^3 launch indices are
-split into N contiguous ranges.
+its acceleration structure every pulse), trace of the pulse's W^3 launch indices, ordering +
+expansion of the received rays, finalisation and group-by aggregation into the pulse's
+responses.  A "ray" in Mrays/s is one traced segment (one rtTrace of the reference: primary or
+bounce).
+
+Scaling is strong: the K timed pulses form one coherent processing interval whose K * W^3
+(pulse, launch index) pairs are split into N contiguous ranges (rts_amd/multigpu.py: a rank owns
+whole pulses plus at most two partial ones; K = 1 is plain ray sharding).  The per-(receiver,
+path) group tables of all pulse parts are exchanged ONCE, at the end of the timed region and inside
+it, by an all-gather over RCCL, and merged into the per-pulse responses on every rank.
 """
 import argparse
 import json
@@ -40,15 +44,10 @@ def pulse_motion(spec, k):
     return out
 
 
-def shard(total, rank, world):
-    lo = total * rank // world
-    hi = total * (rank + 1) // world
-    return lo, hi - lo
-
-
-def cpu_baseline(spec, seconds_target=15.0):
-    """The CPU restatement (oracle, BVH mode, all host threads) timed on a strided sample of
-    the same pulse.  kind = "port": the reference has no CPU path and cannot be built here."""
+def cpu_baseline(spec, seconds_target=12.0):
+    """The CPU restatement (oracle, BVH mode, all host threads) timed on whole pulses of the same
+    workload, repeated until ~seconds_target of CPU work.  kind = "port": the reference has no CPU
+    path and cannot be built here."""
     from oracle import oracle as O
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import helpers as H
@@ -56,25 +55,28 @@ def cpu_baseline(spec, seconds_target=15.0):
     sc = H.oracle_scene(O, spec, pulse_motion(spec, 0))
     tx = spec["tx"]; W = spec["W"]; total = W ** 3
     n = 20000
+    kw = dict(use_bvh=True, threads=threads, debug=False)
+    sc.trace(tx["origin"], tx["span"], tx["dir"], W, spec["max_refl"], 0, spec["smooth"], ray_first=0, ray_stride=total // n, n_rays=n, **kw)   # builds the BVH
     t0 = time.time()
-    r = sc.trace(tx["origin"], tx["span"], tx["dir"], W, spec["max_refl"], 0, spec["smooth"], ray_first=0,
-                 ray_stride=total // n, n_rays=n, use_bvh=True, threads=threads, debug=False)     # includes the BVH build
-    t_first = time.time() - t0
-    t0 = time.time()
-    r = sc.trace(tx["origin"], tx["span"], tx["dir"], W, spec["max_refl"], 0, spec["smooth"], ray_first=0,
-                 ray_stride=total // n, n_rays=n, use_bvh=True, threads=threads, debug=False)
+    r = sc.trace(tx["origin"], tx["span"], tx["dir"], W, spec["max_refl"], 0, spec["smooth"], ray_first=0, ray_stride=total // n, n_rays=n, **kw)
+    rate = r["counters"]["segments"] / max(time.time() - t0, 1e-3)
+    want = rate * seconds_target                           # segments to trace
+    seg = 0; rays = 0; t0 = time.time(); reps = 0
+    per_pulse = max(r["counters"]["segments"] * total / n, 1)
+    if want >= per_pulse:                                  # whole pulses, a few of them
+        while seg < want and reps < 64:
+            r = sc.trace(tx["origin"], tx["span"], tx["dir"], W, spec["max_refl"], 0, spec["smooth"], ray_first=0, ray_stride=1, n_rays=total, **kw)
+            seg += r["counters"]["segments"]; rays += total; reps += 1
+        what = "%d whole pulses (%d launch indices each)" % (reps, total)
+    else:                                                  # a strided sample of one pulse
+        stride = max(int(per_pulse / want), 1)
+        m = total // stride
+        r = sc.trace(tx["origin"], tx["span"], tx["dir"], W, spec["max_refl"], 0, spec["smooth"], ray_first=0, ray_stride=stride, n_rays=m, **kw)
+        seg = r["counters"]["segments"]; rays = m
+        what = "every %d-th of the %d launch indices of one pulse" % (stride, total)
     dt = time.time() - t0
-    rate = r["counters"]["segments"] / dt
-    n2 = int(min(total, max(n, rate and n * seconds_target / max(dt, 1e-3))))
-    stride = max(total // n2, 1)
-    n2 = min(n2, total // stride)
-    t0 = time.time()
-    r = sc.trace(tx["origin"], tx["span"], tx["dir"], W, spec["max_refl"], 0, spec["smooth"], ray_first=0,
-                 ray_stride=stride, n_rays=n2, use_bvh=True, threads=threads, debug=False)
-    dt = time.time() - t0
-    return dict(value=r["counters"]["segments"] / dt / 1e6, unit="Mrays/s", cores=threads, kind="port",
-                sample="%d of %d launch indices (stride %d) of one pulse, %d segments in %.1f s, oracle BVH mode" %
-                       (n2, total, stride, r["counters"]["segments"], dt))
+    return dict(value=seg / dt / 1e6, unit="Mrays/s", cores=threads, kind="port",
+                sample="%s: %d segments in %.1f s, oracle BVH mode, %d threads" % (what, seg, dt, threads))
 
 
 def main():
@@ -107,21 +109,26 @@ def main():
     rts_amd.build()
     spec = scenes.config3(W=args.width) if args.config == "c3" else scenes.config2(W=args.width if args.width != 216 else 100)
     W = spec["W"]; total = W ** 3
-    first, count = shard(total, rank, world)
     tx = spec["tx"]; wl = spec["c"] / spec["carrier"]
 
     tr = api.Tracer(W, spec["max_refl"], 0, spec["smooth"], device=local_rank)
     tr.set_scene(spec["meshes"]); tr.set_receivers(spec["rx"])
 
-    def step(k):
-        st = tr.trace(tx["origin"], tx["span"], tx["dir"], pulse_motion(spec, k), ray_first=first, ray_count=count)
-        tr.finalise_uniform(None, wl, 1.0, 1.0, spec["carrier"], spec["c"])
-        if world > 1:
-            resp, st2 = multigpu.aggregate_sharded(tr, spec["c"], spec["carrier"], dist, torch)
-        else:
+    def run_cpi(k0, n_pulses):
+        """pulses k0 .. k0+n_pulses-1 as one coherent processing interval, sharded over the ranks"""
+        parts = []; acc = dict(segments=0, shaded=0, received=0, ms_scene=0.0, ms_trace=0.0, ms_post=0.0, launches=0)
+        for (k, first, count) in multigpu.plan_cpi(total, n_pulses, rank, world):
+            tr.trace(tx["origin"], tx["span"], tx["dir"], pulse_motion(spec, k0 + k), ray_first=first, ray_count=count, want_stats=False)
+            tr.finalise_uniform(None, wl, 1.0, 1.0, spec["carrier"], spec["c"])
             groups = tr.aggregate(spec["c"], spec["carrier"], 0)
-            resp = api.groups_to_responses(groups)
-        return tr.stats(), resp
+            st = tr.stats()                                   # stream already drained by the aggregation's table fetch
+            parts.append(dict(pulse=k, ray_first=first, n_recv=st["received"], groups=groups))
+            acc["segments"] += st["segments"]; acc["shaded"] += st["shaded"]; acc["received"] += st["received"]
+            acc["ms_scene"] += st["ms_scene"]; acc["ms_trace"] += st["ms_trace"]; acc["ms_post"] += st["ms_compact"] + st["ms_aggregate"]
+            acc["launches"] += 1
+        allp = multigpu.exchange_parts(parts, dist, torch)    # ONE exchange per CPI (RCCL all-gather), inside the timed region
+        resp = multigpu.merge_cpi(allp, spec["max_refl"])
+        return acc, resp
 
     def sync():
         torch.cuda.synchronize()
@@ -129,17 +136,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        step(k)
+    if args.warmup:
+        run_cpi(0, args.warmup)
     sync()
-    seg = 0; ms_trace = 0.0; ms_scene = 0.0; ms_post = 0.0; shaded = 0; received = 0
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        st, resp = step(args.warmup + k)
-        seg += st["segments"]; ms_trace += st["ms_trace"]; ms_scene += st["ms_scene"]; ms_post += st["ms_compact"] + st["ms_aggregate"]
-        shaded += st["shaded"]; received += st["received"]
+    acc, resp = run_cpi(args.warmup, args.steps)
     sync()
     dt = time.perf_counter() - t0
+    assert len(resp) == args.steps, "every pulse of the interval must come back with its responses"
+    seg = acc["segments"]; ms_trace = acc["ms_trace"]; ms_scene = acc["ms_scene"]; ms_post = acc["ms_post"]
+    shaded = acc["shaded"]; received = acc["received"]; launches = max(acc["launches"], 1)
 
     # whole-job aggregates: max time over ranks, sum of segments
     if dist is not None:
@@ -153,12 +159,12 @@ def main():
         # traversal counts for the roofline accounting: one untimed pulse of the counting build
         trc = api.Tracer(W, spec["max_refl"], 0, spec["smooth"], device=local_rank, count_traversal=True)
         trc.set_scene(spec["meshes"]); trc.set_receivers(spec["rx"])
-        sc = trc.trace(tx["origin"], tx["span"], tx["dir"], pulse_motion(spec, args.warmup), ray_first=first, ray_count=count)
+        sc = trc.trace(tx["origin"], tx["span"], tx["dir"], pulse_motion(spec, args.warmup))
         trc.close()
         V = sc["node_visits"] / max(sc["segments"], 1); T = sc["tri_tests"] / max(sc["segments"], 1); Hh = sc["shaded"] / max(sc["segments"], 1)
         bytes_per_seg = 288.0 + 64.0 * V + 72.0 * T + 96.0 * Hh           # SURVEY.md section 8(d), figure (B)
-        seg_per_launch = seg / max(args.steps, 1)                          # rank 0's launches
-        ms_launch = ms_trace / max(args.steps, 1)
+        seg_per_launch = seg / launches                                    # rank 0's launches
+        ms_launch = ms_trace / launches
         achieved = bytes_per_seg * seg_per_launch / (ms_launch * 1e-3) / 1e9 if ms_launch > 0 else 0.0
         out = {
             "metric": "Mrays/s (primary+bounces) & ms/pulse, 100k-tri scene",
@@ -168,8 +174,8 @@ def main():
             "config": {"workload": "BASELINE.json configs[2]: %s, 1 Tx / %d Rx, W=%d (%d launch indices/pulse), maxRefl=%d, target moves every pulse (LBVH rebuilt per pulse)"
                                    % (spec["name"], len(spec["rx"]), W, total, spec["max_refl"]),
                        "rays_per_pulse": total, "segments_per_pulse": seg_all / args.steps, "received_per_pulse": received_all / args.steps,
-                       "primary_Mrays_per_s": total * args.steps / dt / 1e6, "sharding": "contiguous launch-index ranges x%d" % world,
-                       "stage_ms_rank0": {"scene+lbvh": ms_scene / args.steps, "trace": ms_launch, "order+finalise+aggregate": ms_post / args.steps}},
+                       "primary_Mrays_per_s": total * args.steps / dt / 1e6, "sharding": "contiguous (pulse, launch index) ranges of the %d-pulse interval x%d ranks, one group-table all-gather per interval" % (args.steps, world),
+                       "stage_ms_per_launch_rank0": {"scene+lbvh": ms_scene / launches, "trace": ms_launch, "order+finalise+aggregate": ms_post / launches}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "k_trace", "bytes_per_segment": bytes_per_seg,
                          "nodes_per_segment": V, "tri_tests_per_segment": T, "shaded_per_segment": Hh,

@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librts_amd.so")
+LIB_PATH = os.environ.get("RTS_AMD_LIB", os.path.join(_HERE, "librts_amd.so"))   # override: kernel A/B experiments
 CSRC = os.path.join(_HERE, "csrc")
 
 RTS_OK, RTS_ERR_INVALID, RTS_ERR_NO_DEVICE, RTS_ERR_HIP, RTS_ERR_UNSUPPORTED, RTS_ERR_CAPACITY, RTS_ERR_IO = range(7)

@@ -128,7 +128,7 @@ class Tracer:
                                          s["minPhi"], s["maxPhi"])
         check(L.lib().rts_set_receivers(self.h, arr, len(spheres)))
 
-    def trace(self, origin, tx_span, tx_dir, motion=None, ray_first=0, ray_count=0):
+    def trace(self, origin, tx_span, tx_dir, motion=None, ray_first=0, ray_count=0, want_stats=True):
         """motion: list of dict(position, velocity[, rotation(9)]) per target, or None to keep placement."""
         p = L.RtsPulse()
         p.ray_origin[:] = list(origin); p.tx_span[:] = list(tx_span); p.tx_dir[:] = list(tx_dir)
@@ -144,7 +144,7 @@ class Tracer:
             p.motion = C.cast(marr, C.POINTER(L.RtsTargetMotion))
             self._keep = [marr]
         check(L.lib().rts_trace_pulse(self.h, C.byref(p)))
-        return self.stats()
+        return self.stats() if want_stats else None     # reading the stage timers drains the stream
 
     def stats(self):
         s = L.RtsStats()

@@ -58,6 +58,12 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; rts_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return RTS_ERR_HIP; }
     for (int i = 0; i < 8; i++) { e = hipEventCreate(&c->ev[i]); if (e != hipSuccess) { delete c; rts_set_error("hipEventCreate: %s", hipGetErrorString(e)); return RTS_ERR_HIP; } }
+    e = hipHostMalloc((void**)&c->pin, sizeof(RtsPinned), hipHostMallocDefault);
+    if (e != hipSuccess) { delete c; rts_set_error("hipHostMalloc: %s", hipGetErrorString(e)); return RTS_ERR_HIP; }
+    memset(c->pin, 0, sizeof(RtsPinned));
+    hipDeviceProp_t prop; e = hipGetDeviceProperties(&prop, p->device);
+    if (e != hipSuccess) { delete c; rts_set_error("hipGetDeviceProperties: %s", hipGetErrorString(e)); return RTS_ERR_HIP; }
+    c->n_cu = prop.multiProcessorCount;
     *out = c;
     return RTS_OK;
 }
@@ -77,7 +83,8 @@ extern "C" int rts_destroy(RtsHandle c)
     c->d_rx_angles.release(); c->d_rx_slots.release(); c->d_all_rays.release(); c->d_all_paths.release(); c->d_all_angles.release();
     c->d_akeys.release(); c->d_akeys_sorted.release(); c->d_aidx.release(); c->d_aidx_sorted.release(); c->d_ghead.release(); c->d_gid.release();
     c->d_gsum.release(); c->d_gmin.release(); c->d_gkey.release(); c->d_gcount.release(); c->d_delay.release(); c->d_phase.release();
-    c->d_pathmatch.release(); c->d_rcs.release();
+    c->d_pathmatch.release(); c->d_rcs.release(); c->d_rcsval.release();
+    if (c->pin) (void)hipHostFree(c->pin);
     for (int i = 0; i < 8; i++) (void)hipEventDestroy(c->ev[i]);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -223,15 +230,18 @@ extern "C" int rts_trace_pulse(RtsHandle c, const RtsPulse* p)
     if (moved) {
         for (uint32_t t = 0; t < n_targets; t++) for (int k = 0; k < 3; k++)
             if (!std::isfinite(c->motion[t].position[k]) || !std::isfinite(c->motion[t].velocity[k])) { rts_set_error("rts_trace_pulse: target %u has a non-finite position/velocity", t); return RTS_ERR_INVALID; }
-        std::vector<RtsTargetDev> td(n_targets);
+        if (n_targets > 256) { rts_set_error("rts_trace_pulse: more than 256 targets"); return RTS_ERR_UNSUPPORTED; }
+        // pinned staging is safe to rewrite: every earlier upload precedes the previous launch's trace kernel, whose
+        // completion the host already waited for (received-count readback)
+        RtsTargetDev* td = c->pin->td;
         for (uint32_t t = 0; t < n_targets; t++) {
             td[t].reflCoeff = c->meshes[t].refl_coeff; td[t].vx = c->motion[t].velocity[0]; td[t].vy = c->motion[t].velocity[1]; td[t].vz = c->motion[t].velocity[2];
             td[t].tri_base = c->meshes[t].tri_base; td[t].perface_normals = c->meshes[t].perface ? 1u : 0u; td[t].pad0 = td[t].pad1 = 0;
+            c->pin->motion[t] = c->motion[t];
         }
         if (n_targets) {
-            RTS_HIP(hipMemcpyAsync(c->d_motion.p, c->motion.data(), sizeof(RtsTargetMotion)*n_targets, hipMemcpyHostToDevice, st));
-            RTS_HIP(hipMemcpyAsync(c->d_targets.p, td.data(), sizeof(RtsTargetDev)*n_targets, hipMemcpyHostToDevice, st));
-            RTS_HIP(hipStreamSynchronize(st));      // td / motion are host temporaries
+            RTS_HIP(hipMemcpyAsync(c->d_motion.p, c->pin->motion, sizeof(RtsTargetMotion)*n_targets, hipMemcpyHostToDevice, st));
+            RTS_HIP(hipMemcpyAsync(c->d_targets.p, td, sizeof(RtsTargetDev)*n_targets, hipMemcpyHostToDevice, st));
         }
         int rc = rts_bvh_build(c); if (rc != RTS_OK) return rc;
         RTS_STAGE(c, "bvh_build");
@@ -244,15 +254,15 @@ extern "C" int rts_trace_pulse(RtsHandle c, const RtsPulse* p)
     c->ray_first = first; c->n_rays = n;
     const bool keep_all = (c->params.flags & RTS_FLAG_KEEP_ALL_RAYS) != 0;
     const bool count_trav = (c->params.flags & RTS_FLAG_COUNT_TRAVERSAL) != 0;
-    hipDeviceProp_t prop; RTS_HIP(hipGetDeviceProperties(&prop, c->device));
-    uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)n + RTS_BLOCK - 1) / RTS_BLOCK, (uint64_t)prop.multiProcessorCount * 16);
+    uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)n + RTS_BLOCK - 1) / RTS_BLOCK, (uint64_t)c->n_cu * 16);
     if (grid == 0) grid = 1;
     RtsTraceArgs a; memset(&a, 0, sizeof(a));
     RtsLaunchConsts& lc = c->last_lc; memset(&lc, 0, sizeof(lc));
     fill_launch_constants(lc, *p, W);
     lc.ray_first = first; lc.W = W;
     RTS_HIP(c->d_lc.reserve(1));
-    RTS_HIP(hipMemcpyAsync(c->d_lc.p, &lc, sizeof(lc), hipMemcpyHostToDevice, st));
+    c->pin->lc = lc;
+    RTS_HIP(hipMemcpyAsync(c->d_lc.p, &c->pin->lc, sizeof(lc), hipMemcpyHostToDevice, st));
     a.lc = c->d_lc.p;
     a.ray_first = first; a.n_rays = n; a.W = W; a.max_refl = c->params.max_refl; a.smooth = c->params.interpolate_smooth ? 1u : 0u;
     a.n_prims = c->n_prims; a.n_targets = n_targets; a.n_rx = c->n_rx; a.keep_all = keep_all ? 1u : 0u;
@@ -278,32 +288,40 @@ extern "C" int rts_trace_pulse(RtsHandle c, const RtsPulse* p)
     int rc = rts_trace_launch(c, a, count_trav); if (rc != RTS_OK) return rc;
     RTS_STAGE(c, "k_trace");
     RTS_HIP(hipEventRecord(c->ev[3], st));
-    unsigned long long cnt[8];
-    RTS_HIP(hipMemcpyAsync(cnt, c->d_counters.p, sizeof(cnt), hipMemcpyDeviceToHost, st));
-    RTS_HIP(hipStreamSynchronize(st));
+    unsigned long long* cnt = c->pin->cnt;
+    RTS_HIP(hipMemcpyAsync(cnt, c->d_counters.p, sizeof(unsigned long long) * 8, hipMemcpyDeviceToHost, st));
+    RTS_HIP(hipStreamSynchronize(st));              // the one host sync of the launch: the received count sizes what follows
     if (cnt[6]) { rts_set_error("rts_trace_pulse: traversal stack overflow / malformed BVH guard tripped on %llu waves", cnt[6]); return RTS_ERR_HIP; }
     c->n_recv = cnt[0];
 
-    // ---- order + expand the received rays (and the keep-all buffers)
+    // ---- order + expand the received rays (and the keep-all buffers); left in flight on the stream
     RTS_HIP(hipEventRecord(c->ev[4], st));
     rc = rts_post_order_and_expand(c); if (rc != RTS_OK) return rc;
     if (keep_all) { rc = rts_post_expand_all(c); if (rc != RTS_OK) return rc; }
     RTS_HIP(hipEventRecord(c->ev[5], st));
-    RTS_HIP(hipStreamSynchronize(st));
 
     RtsStats& s = c->stats;
     s.rays = n; s.segments = cnt[1]; s.shaded = cnt[2]; s.received = cnt[0]; s.node_visits = cnt[3]; s.tri_tests = cnt[4]; s.stack_overflows = (uint32_t)cnt[5];
     s.n_prims = c->n_prims; s.n_nodes = c->n_nodes;
-    RTS_HIP(hipEventElapsedTime(&s.ms_scene, c->ev[0], c->ev[1]));
-    RTS_HIP(hipEventElapsedTime(&s.ms_trace, c->ev[2], c->ev[3]));
-    RTS_HIP(hipEventElapsedTime(&s.ms_compact, c->ev[4], c->ev[5]));
-    s.ms_aggregate = 0;
+    s.ms_scene = s.ms_trace = s.ms_compact = s.ms_aggregate = 0;
+    c->stats_pending = true; c->agg_timed = false; c->fin_timed = false;
     return RTS_OK;
 }
 
 extern "C" int rts_get_stats(RtsHandle c, RtsStats* out)
 {
     if (!c || !out) { rts_set_error("rts_get_stats: null argument"); return RTS_ERR_INVALID; }
+    if (c->stats_pending) {                          // stage timers are resolved lazily: reading them drains the stream
+        RTS_HIP(hipSetDevice(c->device));
+        RTS_HIP(hipStreamSynchronize(c->stream));
+        RtsStats& s = c->stats; float ms = 0;
+        RTS_HIP(hipEventElapsedTime(&s.ms_scene, c->ev[0], c->ev[1]));
+        RTS_HIP(hipEventElapsedTime(&s.ms_trace, c->ev[2], c->ev[3]));
+        RTS_HIP(hipEventElapsedTime(&s.ms_compact, c->ev[4], c->ev[5]));
+        s.ms_aggregate = 0;
+        if (c->fin_timed || c->agg_timed) { RTS_HIP(hipEventElapsedTime(&ms, c->ev[6], c->ev[7])); s.ms_aggregate = ms; }
+        c->stats_pending = false;
+    }
     *out = c->stats; return RTS_OK;
 }
 
@@ -352,8 +370,7 @@ extern "C" int rts_finalise_uniform(RtsHandle c, const double* rcs_per_target, d
     RTS_HIP(hipEventRecord(c->ev[6], c->stream));
     int rc = rts_post_finalise(c, rcs_per_target, wavelength, gt, gr, carrier, cspeed); if (rc != RTS_OK) return rc;
     RTS_HIP(hipEventRecord(c->ev[7], c->stream));
-    RTS_HIP(hipStreamSynchronize(c->stream));
-    float ms = 0; RTS_HIP(hipEventElapsedTime(&ms, c->ev[6], c->ev[7])); c->stats.ms_aggregate = ms;
+    c->fin_timed = true; c->stats_pending = true;
     c->agg_valid = false;
     return RTS_OK;
 }
@@ -365,15 +382,15 @@ extern "C" int rts_aggregate(RtsHandle c, double cspeed, double carrier, uint64_
     c->groups.clear(); c->recv_index_base = recv_index_base;
     if (R == 0) { c->agg_valid = true; return RTS_OK; }
     RTS_HIP(c->d_delay.reserve(R)); RTS_HIP(c->d_phase.reserve(R)); RTS_HIP(c->d_pathmatch.reserve(R));
-    RTS_HIP(hipEventRecord(c->ev[6], c->stream));
+    if (!c->fin_timed) RTS_HIP(hipEventRecord(c->ev[6], c->stream));
     RTS_HIP(hipMemsetAsync(c->d_delay.p, 0, sizeof(double)*R, c->stream));
     RTS_HIP(hipMemsetAsync(c->d_phase.p, 0, sizeof(double)*R, c->stream));
-    int rc = rts_aggregate_device(c, nullptr, c->d_rx_paths.p, R, c->depth, cspeed, carrier, recv_index_base, c->d_rx_rays.p,
+    const int32_t max_path = (int32_t)c->meshes.size() - 1, max_rx = c->n_rx ? (int32_t)c->n_rx - 1 : 0;
+    int rc = rts_aggregate_device(c, max_path, max_rx, c->d_rx_paths.p, R, c->depth, cspeed, carrier, recv_index_base, c->d_rx_rays.p,
                                   c->d_delay.p, c->d_phase.p, c->d_pathmatch.p, &c->groups, nullptr, nullptr, nullptr, INT32_MAX);
     if (rc != RTS_OK) return rc;
     RTS_HIP(hipEventRecord(c->ev[7], c->stream));
-    RTS_HIP(hipStreamSynchronize(c->stream));
-    float ms = 0; RTS_HIP(hipEventElapsedTime(&ms, c->ev[6], c->ev[7])); c->stats.ms_aggregate += ms;
+    c->agg_timed = true; c->stats_pending = true;
     c->agg_valid = true;
     return RTS_OK;
 }
@@ -401,6 +418,7 @@ extern "C" int rts_get_aggregated(RtsHandle c, PerRayData* rays, double* delay, 
     const uint64_t R = c->n_recv;
     if (capacity < R) { rts_set_error("rts_get_aggregated: capacity too small"); return RTS_ERR_CAPACITY; }
     if (R == 0) return RTS_OK;
+    RTS_HIP(hipStreamSynchronize(c->stream));
     if (rays) RTS_HIP(hipMemcpy(rays, c->d_rx_rays.p, sizeof(PerRayData)*R, hipMemcpyDeviceToHost));
     if (delay) RTS_HIP(hipMemcpy(delay, c->d_delay.p, sizeof(double)*R, hipMemcpyDeviceToHost));
     if (phase) RTS_HIP(hipMemcpy(phase, c->d_phase.p, sizeof(double)*R, hipMemcpyDeviceToHost));
@@ -505,7 +523,10 @@ extern "C" int rts_kernel_wrapper(PerRayData* h_rx_results_arr, int* h_rx_inters
     if (h_npath_arr) { d_np = c->d_rx_angles.p; RTS_HIP(hipMemcpyAsync(d_np, h_npath_arr, sizeof(double)*R, hipMemcpyHostToDevice, st)); }
     if (h_power_arr) { d_pw = c->d_rx_angles.p + R; RTS_HIP(hipMemcpyAsync(d_pw, h_power_arr, sizeof(double)*R, hipMemcpyHostToDevice, st)); }
     if (h_doppler_arr) { d_dp = c->d_rx_angles.p + 2*R; RTS_HIP(hipMemcpyAsync(d_dp, h_doppler_arr, sizeof(double)*R, hipMemcpyHostToDevice, st)); }
-    int rc = rts_aggregate_device(c, nullptr, c->d_rx_paths.p, R, (uint32_t)D, cspeed, carrier, 0, c->d_rx_rays.p, c->d_delay.p, c->d_phase.p,
+    int32_t max_path = -1, max_rx = 0;
+    for (size_t i = 0; i < R * D; i++) { if (h_rx_intersects_arr[i] < -1) { rts_set_error("rts_kernel_wrapper: path entry < -1"); return RTS_ERR_INVALID; } max_path = std::max(max_path, (int32_t)h_rx_intersects_arr[i]); }
+    for (size_t i = 0; i < R; i++) { if (h_rx_results_arr[i].received < 0) { rts_set_error("rts_kernel_wrapper: ray %zu is not a received ray", i); return RTS_ERR_INVALID; } max_rx = std::max(max_rx, h_rx_results_arr[i].received); }
+    int rc = rts_aggregate_device(c, max_path, max_rx, c->d_rx_paths.p, R, (uint32_t)D, cspeed, carrier, 0, c->d_rx_rays.p, c->d_delay.p, c->d_phase.p,
                                   c->d_pathmatch.p, nullptr, d_np, d_pw, d_dp, INT32_MIN /* use the caller's h_pathMatch */);
     if (rc != RTS_OK) return rc;
     // copy back what the reference copies back (aggregation.cu:169-172)

@@ -102,6 +102,19 @@ struct RtsMeshHost {
     bool perface;
 };
 
+// Pinned host staging (hipHostMalloc): every small per-pulse upload/readback goes through it, so the
+// stream never has to be drained just to recycle a pageable temporary.
+#define RTS_PIN_GROUPS 4096
+struct RtsPinned {
+    RtsLaunchConsts lc;
+    unsigned long long cnt[16];
+    uint32_t G, pad;
+    RtsTargetMotion motion[256];
+    RtsTargetDev td[256];
+    double rcs[256];
+    double gsum[5 * RTS_PIN_GROUPS]; uint64_t gkey[RTS_PIN_GROUPS]; uint32_t gmin[RTS_PIN_GROUPS];
+};
+
 template <typename T> struct DevBuf {
     T* p = nullptr; size_t cap = 0;
     hipError_t reserve(size_t n) {
@@ -151,6 +164,7 @@ struct RtsContext {
     DevBuf<double> d_gsum; DevBuf<uint32_t> d_gmin; DevBuf<uint64_t> d_gkey; DevBuf<uint32_t> d_gcount;
     DevBuf<double> d_delay, d_phase; DevBuf<int32_t> d_pathmatch; DevBuf<double> d_rcs;
     std::vector<RtsGroup> groups; bool agg_valid = false; uint64_t recv_index_base = 0;
+    RtsPinned* pin = nullptr; DevBuf<double> d_rcsval; int n_cu = 0; bool stats_pending = false; bool agg_timed = false, fin_timed = false;
     RtsStats stats;
 };
 
@@ -160,8 +174,8 @@ int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a, bool count_traversal)
 int rts_post_order_and_expand(RtsContext* c);
 int rts_post_expand_all(RtsContext* c);
 int rts_post_finalise(RtsContext* c, const double* rcs_host, double wl, double gt, double gr, double carrier, double cspeed);
-int rts_aggregate_device(RtsContext* c, const PerRayData* d_rays, const int32_t* d_paths, uint64_t R, uint32_t D,
-                         double cspeed, double carrier, uint64_t base, PerRayData* d_rays_out, double* d_delay,
+int rts_aggregate_device(RtsContext* c, int32_t max_path, int32_t max_rx, const int32_t* d_paths, uint64_t R, uint32_t D,
+                         double cspeed, double carrier, uint64_t base, PerRayData* d_rays, double* d_delay,
                          double* d_phase, int32_t* d_pm, std::vector<RtsGroup>* groups, double* d_npath,
                          double* d_power_sum, double* d_doppler_sum, int32_t pm_init);
 void rts_set_error(const char* fmt, ...);

@@ -120,9 +120,10 @@ int rts_post_finalise(RtsContext* c, const double* rcs_host, double wl, double g
     const uint32_t R = (uint32_t)c->n_recv;
     if (R == 0) return RTS_OK;
     const uint32_t nt = (uint32_t)c->meshes.size();
-    RTS_HIP(c->d_rcs.reserve(nt + 1));
-    if (nt) RTS_HIP(hipMemcpyAsync(c->d_rcs.p, rcs_host, sizeof(double)*nt, hipMemcpyHostToDevice, c->stream));
-    k_finalise<<<blocks_for(R, 256), 256, 0, c->stream>>>(c->d_rx_rays.p, c->d_rx_paths.p, R, c->depth, c->d_rcs.p, nt, wl, gt, gr, carrier, cspeed);
+    RTS_HIP(c->d_rcsval.reserve(nt + 1));
+    for (uint32_t t = 0; t < nt && t < 256; t++) c->pin->rcs[t] = rcs_host[t];
+    if (nt) RTS_HIP(hipMemcpyAsync(c->d_rcsval.p, c->pin->rcs, sizeof(double)*nt, hipMemcpyHostToDevice, c->stream));
+    k_finalise<<<blocks_for(R, 256), 256, 0, c->stream>>>(c->d_rx_rays.p, c->d_rx_paths.p, R, c->depth, c->d_rcsval.p, nt, wl, gt, gr, carrier, cspeed);
     RTS_HIP(hipGetLastError());
     return RTS_OK;
 }
@@ -202,15 +203,19 @@ __global__ void __launch_bounds__(AGG_TILE) k_agg_tiles(const PerRayData* __rest
     for (int k = 0; k < 5; k++) dst[k] = s_v[cur][k][t];
 }
 
-// groups spanning several tiles: partials added in tile order by one wave, fixed shape
-__global__ void __launch_bounds__(64) k_agg_span(const uint32_t* __restrict__ gstart, uint32_t G, const double* __restrict__ tile_first,
-                                                  const double* __restrict__ tile_last, double* __restrict__ gsum)
+// groups spanning several tiles: partials added in tile order by one wave, fixed shape.  One wave per
+// TILE (the tile in which such a group starts does the work), so the launch needs no group count.
+__global__ void __launch_bounds__(64) k_agg_span(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ gid_incl, uint32_t R,
+                                                  const double* __restrict__ tile_first, const double* __restrict__ tile_last, double* __restrict__ gsum)
 {
-    const uint32_t g = blockIdx.x, lane = threadIdx.x;
-    if (g >= G) return;
+    const uint32_t T0 = blockIdx.x, lane = threadIdx.x;
+    const uint32_t tile_lo = T0 * AGG_TILE;
+    if (tile_lo >= R) return;
+    const uint32_t tile_hi = min(tile_lo + AGG_TILE, R);
+    const uint32_t g = gid_incl[tile_hi - 1] - 1;                 // the run that touches the end of this tile
     const uint32_t gs = gstart[g], ge = gstart[g + 1];
-    const uint32_t T0 = gs / AGG_TILE, T1 = (ge - 1) / AGG_TILE;
-    if (T0 == T1) return;
+    if (gs < tile_lo || ge <= tile_lo + AGG_TILE) return;         // started earlier, or ends inside this tile
+    const uint32_t T1 = (ge - 1) / AGG_TILE;
     double acc[5] = {0, 0, 0, 0, 0};
     // pieces in order: piece 0 = the run that starts in T0 (stored as that tile's "last" partial),
     // pieces 1.. = tiles T0+1 .. T1 (each that tile's "first" partial)
@@ -224,12 +229,33 @@ __global__ void __launch_bounds__(64) k_agg_span(const uint32_t* __restrict__ gs
 }
 
 __global__ void k_agg_groupinfo(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ idx_sorted, const uint64_t* __restrict__ keys_sorted,
-                                uint32_t G, uint32_t* __restrict__ gmin, uint64_t* __restrict__ gkey)
+                                const uint32_t* __restrict__ gid_incl, uint32_t R, uint32_t* __restrict__ gmin, uint64_t* __restrict__ gkey, uint32_t* __restrict__ g_out)
 {
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t G = gid_incl[R - 1];
+    if (g == 0) *g_out = G;
     if (g >= G) return;
     gmin[g] = idx_sorted[gstart[g]];          // stable sort: first element of the run has the smallest ray index
     gkey[g] = keys_sorted[gstart[g]];
+}
+
+// Per-receiver totals for the direct-ray rule (aggregation.cu:56): groups are sorted by key with the
+// receiver in the top bits, so a receiver's groups are one contiguous run; one wave per receiver adds
+// them with a fixed shape.  rxtot[rx][5], rxmin[rx].
+__global__ void __launch_bounds__(64) k_agg_rxtot(const uint64_t* __restrict__ gkey, const double* __restrict__ gsum, const uint32_t* __restrict__ gmin,
+                                                   const uint32_t* __restrict__ g_count, uint32_t shift, double* __restrict__ rxtot, uint32_t* __restrict__ rxmin)
+{
+    const uint32_t rx = blockIdx.x, lane = threadIdx.x, G = *g_count;
+    auto lower = [&](uint64_t rxv) {            // first group whose receiver field is >= rxv
+        uint32_t lo = 0, hi = G;
+        while (lo < hi) { uint32_t mid = (lo + hi) >> 1; uint64_t r = (shift >= 64) ? 0 : (gkey[mid] >> shift); if (r < rxv) lo = mid + 1; else hi = mid; }
+        return lo;
+    };
+    const uint32_t glo = lower(rx), ghi = lower((uint64_t)rx + 1);
+    double acc[5] = {0, 0, 0, 0, 0}; uint32_t mn = 0xffffffffu;
+    for (uint32_t g = glo + lane; g < ghi; g += 64) { for (int k = 0; k < 5; k++) acc[k] += gsum[5*(size_t)g + k]; mn = min(mn, gmin[g]); }
+    for (int off = 32; off > 0; off >>= 1) { for (int k = 0; k < 5; k++) acc[k] += __shfl_down(acc[k], off); mn = min(mn, (uint32_t)__shfl_down((int)mn, off)); }
+    if (lane == 0) { for (int k = 0; k < 5; k++) rxtot[5*(size_t)rx + k] = acc[k]; rxmin[rx] = mn; }
 }
 
 // myKernel1's per-ray totals + myKernel2 (aggregation.cu:56-69, 88-93), scattered back per ray.
@@ -270,47 +296,37 @@ __global__ void k_agg_scatter(PerRayData* __restrict__ rays, const uint32_t* __r
 // Aggregates R device-resident rays.  d_delay/d_phase/d_pm are in-out (initial values as the
 // caller's h_delay_arr/h_phase_arr/h_pathMatch); d_npath/d_power_sum/d_doppler_sum optional
 // initial values (read only).  groups (optional) receives the host copy of the group table.
-int rts_aggregate_device(RtsContext* c, const PerRayData* d_rays_in, const int32_t* d_paths, uint64_t R64, uint32_t D,
+// max_path / max_rx: largest path entry and receiver index that can occur (decide the key packing).
+// One host synchronisation: the group count is consumed on the device, the table is fetched at the end.
+int rts_aggregate_device(RtsContext* c, int32_t max_path, int32_t max_rx, const int32_t* d_paths, uint64_t R64, uint32_t D,
                          double cspeed, double carrier, uint64_t base, PerRayData* d_rays, double* d_delay,
                          double* d_phase, int32_t* d_pm, std::vector<RtsGroup>* groups, double* d_npath,
                          double* d_power_sum, double* d_doppler_sum, int32_t pm_init)
 {
-    (void)d_rays_in;
     if (groups) groups->clear();
     if (R64 == 0) return RTS_OK;
     if (R64 > 0x7fffffffULL) { rts_set_error("aggregate: more than 2^31 received rays"); return RTS_ERR_UNSUPPORTED; }
     const uint32_t R = (uint32_t)R64;
     hipStream_t st = c->stream;
-    // key packing: B bits per path entry, the rest for the receiver index
-    int32_t maxv[2] = {0, 0};
-    {
-        // max path entry and max receiver index decide the packing; computed with a rocPRIM reduce
-        struct MaxOp { __device__ int32_t operator()(int32_t a, int32_t b) const { return a > b ? a : b; } };
-        RTS_HIP(c->d_gcount.reserve(4));
-        size_t tmp = 0;
-        if ((size_t)R * D > 0) {
-            RTS_HIP(rocprim::reduce(nullptr, tmp, d_paths, (int32_t*)c->d_gcount.p, (int32_t)-1, (size_t)R * D, MaxOp(), st));
-            RTS_HIP(c->d_sort_tmp.reserve(tmp));
-            RTS_HIP(rocprim::reduce(c->d_sort_tmp.p, tmp, d_paths, (int32_t*)c->d_gcount.p, (int32_t)-1, (size_t)R * D, MaxOp(), st));
-            RTS_HIP(hipMemcpyAsync(&maxv[0], c->d_gcount.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        } else maxv[0] = -1;
-        auto rx_it = rocprim::make_transform_iterator(d_rays, [] __device__ (const PerRayData& r) { return r.received; });
-        RTS_HIP(rocprim::reduce(nullptr, tmp, rx_it, (int32_t*)c->d_gcount.p + 1, (int32_t)0, (size_t)R, MaxOp(), st));
-        RTS_HIP(c->d_sort_tmp.reserve(tmp));
-        RTS_HIP(rocprim::reduce(c->d_sort_tmp.p, tmp, rx_it, (int32_t*)c->d_gcount.p + 1, (int32_t)0, (size_t)R, MaxOp(), st));
-        RTS_HIP(hipMemcpyAsync(&maxv[1], (int32_t*)c->d_gcount.p + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        RTS_HIP(hipStreamSynchronize(st));
-    }
-    uint32_t B = 1; while (((uint64_t)1 << B) < (uint64_t)(maxv[0] + 2)) B++;
-    uint32_t RXB = 1; while (((uint64_t)1 << RXB) < (uint64_t)(maxv[1] + 1)) RXB++;
+    uint32_t B = 1; while (((uint64_t)1 << B) < (uint64_t)(max_path + 2)) B++;
+    uint32_t RXB = 1; while (((uint64_t)1 << RXB) < (uint64_t)(max_rx + 1)) RXB++;
     if (D == 0) B = 0;
     if ((uint64_t)D * B + RXB > 64 || D > RTS_MAX_DEPTH) {
         rts_set_error("aggregate: (receiver, path) key needs %u x %u + %u bits > 64 or depth > %d", D, B, RXB, RTS_MAX_DEPTH);
         return RTS_ERR_UNSUPPORTED;
     }
-    const uint32_t key_bits = D * B + RXB;
+    const uint32_t key_bits = D * B + RXB, shift = D * B;
+    const uint32_t n_rx_tab = (uint32_t)max_rx + 1;
+    const uint32_t ntiles = blocks_for(R, AGG_TILE);
     RTS_HIP(c->d_akeys.reserve(R)); RTS_HIP(c->d_akeys_sorted.reserve(R)); RTS_HIP(c->d_aidx.reserve(R)); RTS_HIP(c->d_aidx_sorted.reserve(R));
     RTS_HIP(c->d_ghead.reserve(R)); RTS_HIP(c->d_gid.reserve(R));
+    RTS_HIP(c->d_gcount.reserve((size_t)R + 4)); RTS_HIP(c->d_gsum.reserve(5*((size_t)R + 2*(size_t)ntiles) + 16));
+    RTS_HIP(c->d_gmin.reserve(R)); RTS_HIP(c->d_gkey.reserve(R));
+    RTS_HIP(c->d_rcs.reserve(5*(size_t)n_rx_tab + n_rx_tab + 8));
+    uint32_t* gstart = c->d_gcount.p;                 // [<= R + 1]
+    uint32_t* d_G = c->d_gcount.p + (size_t)R + 2;    // group count, device resident
+    double* gsum = c->d_gsum.p; double* tile_first = gsum + 5*(size_t)R; double* tile_last = tile_first + 5*(size_t)ntiles;
+    double* d_rxtot = c->d_rcs.p; uint32_t* d_rxmin = (uint32_t*)(c->d_rcs.p + 5*(size_t)n_rx_tab);
     k_agg_keys<<<blocks_for(R, 256), 256, 0, st>>>(d_rays, d_paths, R, D, B, c->d_akeys.p, c->d_aidx.p);
     size_t tmp = 0;
     RTS_HIP(rocprim::radix_sort_pairs(nullptr, tmp, c->d_akeys.p, c->d_akeys_sorted.p, c->d_aidx.p, c->d_aidx_sorted.p, R, 0, key_bits, st));
@@ -320,56 +336,48 @@ int rts_aggregate_device(RtsContext* c, const PerRayData* d_rays_in, const int32
     RTS_HIP(rocprim::inclusive_scan(nullptr, tmp, c->d_ghead.p, c->d_gid.p, R, rocprim::plus<uint32_t>(), st));
     RTS_HIP(c->d_sort_tmp.reserve(tmp));
     RTS_HIP(rocprim::inclusive_scan(c->d_sort_tmp.p, tmp, c->d_ghead.p, c->d_gid.p, R, rocprim::plus<uint32_t>(), st));
-    uint32_t G = 0;
-    RTS_HIP(hipMemcpyAsync(&G, c->d_gid.p + (R - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    RTS_HIP(hipStreamSynchronize(st));
-    const uint32_t ntiles = blocks_for(R, AGG_TILE);
-    // d_gcount reused as gstart [G+1]
-    RTS_HIP(c->d_gcount.reserve((size_t)G + 2)); RTS_HIP(c->d_gsum.reserve(5*((size_t)G + 2*(size_t)ntiles) + 16));
-    RTS_HIP(c->d_gmin.reserve(G)); RTS_HIP(c->d_gkey.reserve(G));
-    uint32_t* gstart = c->d_gcount.p;
-    double* gsum = c->d_gsum.p; double* tile_first = gsum + 5*(size_t)G; double* tile_last = tile_first + 5*(size_t)ntiles;
     k_agg_starts<<<blocks_for(R, 256), 256, 0, st>>>(c->d_ghead.p, c->d_gid.p, gstart, R);
     k_agg_tiles<<<ntiles, AGG_TILE, 0, st>>>(d_rays, c->d_aidx_sorted.p, c->d_gid.p, gstart, R, cspeed, carrier, gsum, tile_first, tile_last);
-    k_agg_span<<<G, 64, 0, st>>>(gstart, G, tile_first, tile_last, gsum);
-    k_agg_groupinfo<<<blocks_for(G, 256), 256, 0, st>>>(gstart, c->d_aidx_sorted.p, c->d_akeys_sorted.p, G, c->d_gmin.p, c->d_gkey.p);
-    RTS_HIP(hipGetLastError());
-    // group table to the host; per-receiver totals (the direct-ray rule of aggregation.cu:56) in group order
-    std::vector<double> h_gsum(5*(size_t)G); std::vector<uint32_t> h_gmin(G); std::vector<uint64_t> h_gkey(G);
-    RTS_HIP(hipMemcpyAsync(h_gsum.data(), gsum, sizeof(double)*5*G, hipMemcpyDeviceToHost, st));
-    RTS_HIP(hipMemcpyAsync(h_gmin.data(), c->d_gmin.p, sizeof(uint32_t)*G, hipMemcpyDeviceToHost, st));
-    RTS_HIP(hipMemcpyAsync(h_gkey.data(), c->d_gkey.p, sizeof(uint64_t)*G, hipMemcpyDeviceToHost, st));
-    RTS_HIP(hipStreamSynchronize(st));
-    const uint32_t n_rx_tab = (uint32_t)maxv[1] + 1;
-    std::vector<double> rxtot(5*(size_t)n_rx_tab, 0.0); std::vector<uint32_t> rxmin(n_rx_tab, 0xffffffffu);
-    const uint64_t pmask = (D*B >= 64) ? ~0ULL : (((uint64_t)1 << (D*B)) - 1);
-    for (uint32_t g = 0; g < G; g++) {
-        const uint32_t rx = (D*B >= 64) ? 0u : (uint32_t)(h_gkey[g] >> (D*B));
-        if (rx < n_rx_tab) { for (int k = 0; k < 5; k++) rxtot[5*(size_t)rx + k] += h_gsum[5*(size_t)g + k]; rxmin[rx] = std::min(rxmin[rx], h_gmin[g]); }
-        if (groups) {
-            RtsGroup gr; memset(&gr, 0, sizeof(gr));
-            gr.rx = (int32_t)rx;
-            bool all_neg = true;
-            for (uint32_t k = 0; k < RTS_MAX_DEPTH; k++) {
-                int v = -1;
-                if (k < D) v = (int)(((h_gkey[g] & pmask) >> (k*B)) & (((uint64_t)1 << B) - 1)) - 1;
-                gr.path[k] = v; if (v >= 0) all_neg = false;
-            }
-            gr.direct = all_neg ? 1u : 0u;
-            gr.min_ray = base + h_gmin[g];
-            gr.n = h_gsum[5*(size_t)g]; gr.sum_sqrt_power = h_gsum[5*(size_t)g + 1]; gr.sum_delay = h_gsum[5*(size_t)g + 2];
-            gr.sum_phase = h_gsum[5*(size_t)g + 3]; gr.sum_doppler = h_gsum[5*(size_t)g + 4];
-            groups->push_back(gr);
-        }
-    }
-    // upload receiver totals, scatter per-ray results
-    RTS_HIP(c->d_rcs.reserve(5*(size_t)n_rx_tab + n_rx_tab + 8));
-    double* d_rxtot = c->d_rcs.p; uint32_t* d_rxmin = (uint32_t*)(c->d_rcs.p + 5*(size_t)n_rx_tab);
-    RTS_HIP(hipMemcpyAsync(d_rxtot, rxtot.data(), sizeof(double)*5*n_rx_tab, hipMemcpyHostToDevice, st));
-    RTS_HIP(hipMemcpyAsync(d_rxmin, rxmin.data(), sizeof(uint32_t)*n_rx_tab, hipMemcpyHostToDevice, st));
+    k_agg_span<<<ntiles, 64, 0, st>>>(gstart, c->d_gid.p, R, tile_first, tile_last, gsum);
+    k_agg_groupinfo<<<blocks_for(R, 256), 256, 0, st>>>(gstart, c->d_aidx_sorted.p, c->d_akeys_sorted.p, c->d_gid.p, R, c->d_gmin.p, c->d_gkey.p, d_G);
+    k_agg_rxtot<<<n_rx_tab, 64, 0, st>>>(c->d_gkey.p, gsum, c->d_gmin.p, d_G, shift, d_rxtot, d_rxmin);
     k_agg_scatter<<<blocks_for(R, 256), 256, 0, st>>>(d_rays, c->d_aidx_sorted.p, c->d_gid.p, gsum, c->d_gmin.p, d_rxtot, d_rxmin, n_rx_tab, R,
                                                        (int64_t)base, d_npath, d_power_sum, d_doppler_sum, d_delay, d_phase, d_pm, pm_init, pm_init == INT32_MIN ? 1 : 0);
     RTS_HIP(hipGetLastError());
+    if (!groups) { RTS_HIP(hipStreamSynchronize(st)); return RTS_OK; }
+    // group table to the host: count + the first AGG_SPEC groups speculatively in one batch (pinned), rest on demand
+    RtsPinned* pin = c->pin;
+    const uint32_t spec = std::min<uint32_t>(R, RTS_PIN_GROUPS);
+    RTS_HIP(hipMemcpyAsync(&pin->G, d_G, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    RTS_HIP(hipMemcpyAsync(pin->gsum, gsum, sizeof(double)*5*spec, hipMemcpyDeviceToHost, st));
+    RTS_HIP(hipMemcpyAsync(pin->gmin, c->d_gmin.p, sizeof(uint32_t)*spec, hipMemcpyDeviceToHost, st));
+    RTS_HIP(hipMemcpyAsync(pin->gkey, c->d_gkey.p, sizeof(uint64_t)*spec, hipMemcpyDeviceToHost, st));
     RTS_HIP(hipStreamSynchronize(st));
+    const uint32_t G = pin->G;
+    const double* h_gsum = pin->gsum; const uint32_t* h_gmin = pin->gmin; const uint64_t* h_gkey = pin->gkey;
+    std::vector<double> v_gsum; std::vector<uint32_t> v_gmin; std::vector<uint64_t> v_gkey;
+    if (G > spec) {
+        v_gsum.resize(5*(size_t)G); v_gmin.resize(G); v_gkey.resize(G);
+        RTS_HIP(hipMemcpy(v_gsum.data(), gsum, sizeof(double)*5*G, hipMemcpyDeviceToHost));
+        RTS_HIP(hipMemcpy(v_gmin.data(), c->d_gmin.p, sizeof(uint32_t)*G, hipMemcpyDeviceToHost));
+        RTS_HIP(hipMemcpy(v_gkey.data(), c->d_gkey.p, sizeof(uint64_t)*G, hipMemcpyDeviceToHost));
+        h_gsum = v_gsum.data(); h_gmin = v_gmin.data(); h_gkey = v_gkey.data();
+    }
+    const uint64_t pmask = (shift >= 64) ? ~0ULL : (((uint64_t)1 << shift) - 1);
+    groups->resize(G);
+    for (uint32_t g = 0; g < G; g++) {
+        RtsGroup& gr = (*groups)[g]; memset(&gr, 0, sizeof(gr));
+        gr.rx = (int32_t)((shift >= 64) ? 0u : (uint32_t)(h_gkey[g] >> shift));
+        bool all_neg = true;
+        for (uint32_t k = 0; k < RTS_MAX_DEPTH; k++) {
+            int v = -1;
+            if (k < D) v = (int)(((h_gkey[g] & pmask) >> (k*B)) & (((uint64_t)1 << B) - 1)) - 1;
+            gr.path[k] = v; if (v >= 0) all_neg = false;
+        }
+        gr.direct = all_neg ? 1u : 0u;
+        gr.min_ray = base + h_gmin[g];
+        gr.n = h_gsum[5*(size_t)g]; gr.sum_sqrt_power = h_gsum[5*(size_t)g + 1]; gr.sum_delay = h_gsum[5*(size_t)g + 2];
+        gr.sum_phase = h_gsum[5*(size_t)g + 3]; gr.sum_doppler = h_gsum[5*(size_t)g + 4];
+    }
     return RTS_OK;
 }

@@ -73,6 +73,69 @@ def test_two_rank_sharded_pulse(tmp_path, world, oracle):
         assert int(x["merged"]["n"].sum()) == len(rx)
 
 
+def _cpi_worker(rank, world, port, out_dir, n_pulses):
+    sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from rts_amd import scenes, multigpu
+    import helpers as H
+    from test_host_logic import numpy_group_table
+    spec = scenes.config_multi(W=12)
+    total = spec["W"] ** 3
+    wl = spec["c"] / spec["carrier"]
+    parts = []
+    for (k, first, count) in multigpu.plan_cpi(total, n_pulses, rank, world):
+        mo = [dict(position=tuple(np.add(m["position"], (0.3 * k, 0.0, 0.1 * k))), velocity=m["velocity"]) for m in spec["motion"]]
+        o = H.oracle_trace(O, spec, motion=mo, ray_first=first, ray_stride=1, n_rays=count)
+        rx, rxi, slots = O.filter_finalise(o["results"], o["path"], [1.0] * 3, wl, 1.0, 1.0, spec["carrier"], spec["c"])
+        parts.append(dict(pulse=k, ray_first=first, n_recv=len(rx), groups=numpy_group_table(rx, rxi, spec["c"], spec["carrier"], base=0)))
+    allp = multigpu.exchange_parts(parts, dist, torch)
+    merged = multigpu.merge_cpi(allp, spec["max_refl"])
+    np.savez(os.path.join(out_dir, "cpi_rank%d.npz" % rank), pulses=np.array(sorted(merged)), **{"resp%d" % k: merged[k][0] for k in merged})
+    dist.barrier(); dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_pulses", [(2, 3), (3, 2), (2, 1)])
+def test_cpi_sharding(tmp_path, world, n_pulses, oracle):
+    """pulse x ray sharding of a CPI: ranks own whole and partial pulses, ONE exchange, per-pulse responses
+    identical to the literal single-process pipeline (global received-list indices included)"""
+    mp.spawn(_cpi_worker, args=(world, _free_port(), str(tmp_path), n_pulses), nprocs=world, join=True)
+    sys.path.insert(0, HERE)
+    from rts_amd import scenes
+    import helpers as H
+    spec = scenes.config_multi(W=12)
+    wl = spec["c"] / spec["carrier"]
+    outs = [np.load(os.path.join(str(tmp_path), "cpi_rank%d.npz" % r)) for r in range(world)]
+    for k in range(n_pulses):
+        mo = [dict(position=tuple(np.add(m["position"], (0.3 * k, 0.0, 0.1 * k))), velocity=m["velocity"]) for m in spec["motion"]]
+        o = H.oracle_trace(oracle, spec, motion=mo)
+        rx, rxi, slots = oracle.filter_finalise(o["results"], o["path"], [1.0] * 3, wl, 1.0, 1.0, spec["carrier"], spec["c"])
+        lit = oracle.aggregate_literal(rx, rxi, spec["c"], spec["carrier"], spec["W"] ** 3)
+        uniq = oracle.unique_paths(lit["pathMatch"])
+        for x in outs:
+            assert list(x["pulses"]) == list(range(n_pulses))
+            resp = x["resp%d" % k]
+            assert np.array_equal(resp["ray"].astype(np.int64), uniq.astype(np.int64))
+            np.testing.assert_allclose(resp["power"], lit["results"]["power"][uniq], rtol=1e-12)
+            np.testing.assert_allclose(resp["delay"], lit["delay"][uniq], rtol=1e-12)
+
+
+def test_plan_cpi_covers_exactly():
+    from rts_amd import multigpu
+    for total in (1000, 216 ** 3):
+        for K, N in [(1, 8), (8, 8), (5, 3), (20, 8), (3, 1), (1, 1)]:
+            allp = [multigpu.plan_cpi(total, K, r, N) for r in range(N)]
+            cover = sorted(x for ps in allp for x in ps)
+            pos = 0
+            for k, f, c in cover:
+                assert k * total + f == pos and c > 0 and f + c <= total
+                pos += c
+            assert pos == total * K
+            loads = [sum(c for _, _, c in ps) for ps in allp]
+            assert max(loads) - min(loads) <= 1
+
+
 def test_shard_ranges_cover_exactly():
     from rts_amd import multigpu
     for total in (1, 7, 10648, 216 ** 3):
