@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--width", type=int, default=216, help="W (launch indices per pulse = W^3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config", default="c3", choices=["c2", "c3"])
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks")
     args = ap.parse_args()
 
     import torch
@@ -97,12 +98,17 @@ def main():
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the RTS hot path")
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()       # rehearsal: ranks may share a device
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import rts_amd
     from rts_amd import api, scenes, multigpu
@@ -149,8 +155,9 @@ def main():
 
     # whole-job aggregates: max time over ranks, sum of segments
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda"); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
-        ss = torch.tensor([seg, shaded, received], dtype=torch.float64, device="cuda"); dist.all_reduce(ss, op=dist.ReduceOp.SUM)
+        rdev = "cuda" if args.backend == "nccl" else "cpu"
+        tt = torch.tensor([dt], dtype=torch.float64, device=rdev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
+        ss = torch.tensor([seg, shaded, received], dtype=torch.float64, device=rdev); dist.all_reduce(ss, op=dist.ReduceOp.SUM)
         seg_all, shaded_all, received_all = [int(x) for x in ss.tolist()]
     else:
         seg_all, shaded_all, received_all = seg, shaded, received

@@ -74,8 +74,24 @@ __global__ void __launch_bounds__(RTS_BLOCK) k_trace(const RtsTraceArgs a)
             float best_t = RTS_DEFAULT_TMAX;
             int best_leaf = -1; uint32_t best_prim = 0xffffffffu;
             if (a.n_prims > 0) {
-                const double ix = 1.0 / dir.x, iy = 1.0 / dir.y, iz = 1.0 / dir.z;
-                double t_prune = (double)RTS_DEFAULT_TMAX;
+                // f32 slab test with an explicit error budget (the traversal only has to be CONSERVATIVE with
+                // respect to the f64 triangle test; the boxes are padded f32 already, see rts_bvh.hip):
+                //   o32 = fl32(o), |o - o32| <= 2^-24 |o|;  E = 3e-7 * max|o| covers that and the rounding of o32 +- E;
+                //   near planes are measured from the origin pushed E TOWARDS them, far planes from the origin
+                //   pushed E AWAY, so every per-axis interval contains the exact one; the f32 roundings of the
+                //   subtraction, of 1/d and of the product (< 2e-7 relative) are covered by scaling the near
+                //   reciprocal by (1 - 4e-7) and the far one by (1 + 4e-7).  Signs follow 1/d so that a zero
+                //   direction component (1/d = +-inf) gives (-inf, +inf) when the origin is inside the slab.
+                const float Eo = fmaxf(fmaxf(fabsf((float)prev.x), fabsf((float)prev.y)), fabsf((float)prev.z)) * 3.0e-7f + 1.0e-30f;
+                const float ivx = (float)(1.0 / dir.x), ivy = (float)(1.0 / dir.y), ivz = (float)(1.0 / dir.z);
+                const bool spx = !(ivx < 0.0f), spy = !(ivy < 0.0f), spz = !(ivz < 0.0f);
+                const float oNx = (float)prev.x + (spx ? Eo : -Eo), oFx = (float)prev.x - (spx ? Eo : -Eo);
+                const float oNy = (float)prev.y + (spy ? Eo : -Eo), oFy = (float)prev.y - (spy ? Eo : -Eo);
+                const float oNz = (float)prev.z + (spz ? Eo : -Eo), oFz = (float)prev.z - (spz ? Eo : -Eo);
+                const float iNx = ivx * 0.9999996f, iFx = ivx * 1.0000004f;
+                const float iNy = ivy * 0.9999996f, iFy = ivy * 1.0000004f;
+                const float iNz = ivz * 0.9999996f, iFz = ivz * 1.0000004f;
+                float t_prune = RTS_DEFAULT_TMAX;
                 int sp = 0;
                 int node = 0;
                 const int SENTINEL = 0x7fffffff;
@@ -87,16 +103,16 @@ __global__ void __launch_bounds__(RTS_BLOCK) k_trace(const RtsTraceArgs a)
                         const float4 q0 = np[0], q1 = np[1], q2 = np[2];
                         const int4 q3 = reinterpret_cast<const int4*>(np)[3];
                         if (COUNT) n_nodes++;
-                        // f64 slab test on the padded f32 child boxes (conservative, see rts_bvh.hip)
-                        double t1, t2, tn0, tf0, tn1, tf1;
-                        t1 = ((double)q0.x - prev.x) * ix; t2 = ((double)q0.w - prev.x) * ix; tn0 = fmin(t1, t2); tf0 = fmax(t1, t2);
-                        t1 = ((double)q0.y - prev.y) * iy; t2 = ((double)q1.x - prev.y) * iy; tn0 = fmax(tn0, fmin(t1, t2)); tf0 = fmin(tf0, fmax(t1, t2));
-                        t1 = ((double)q0.z - prev.z) * iz; t2 = ((double)q1.y - prev.z) * iz; tn0 = fmax(tn0, fmin(t1, t2)); tf0 = fmin(tf0, fmax(t1, t2));
-                        t1 = ((double)q1.z - prev.x) * ix; t2 = ((double)q2.y - prev.x) * ix; tn1 = fmin(t1, t2); tf1 = fmax(t1, t2);
-                        t1 = ((double)q1.w - prev.y) * iy; t2 = ((double)q2.z - prev.y) * iy; tn1 = fmax(tn1, fmin(t1, t2)); tf1 = fmin(tf1, fmax(t1, t2));
-                        t1 = ((double)q2.x - prev.z) * iz; t2 = ((double)q2.w - prev.z) * iz; tn1 = fmax(tn1, fmin(t1, t2)); tf1 = fmin(tf1, fmax(t1, t2));
-                        const bool h0 = fmax(tn0, 0.0) <= fmin(tf0, t_prune);
-                        const bool h1 = fmax(tn1, 0.0) <= fmin(tf1, t_prune);
+                        // child 0: lo = (q0.x, q0.y, q0.z), hi = (q0.w, q1.x, q1.y); child 1: lo = (q1.z, q1.w, q2.x), hi = (q2.y, q2.z, q2.w)
+                        float tn0, tf0, tn1, tf1;
+                        tn0 = ((spx ? q0.x : q0.w) - oNx) * iNx; tf0 = ((spx ? q0.w : q0.x) - oFx) * iFx;
+                        tn0 = fmaxf(tn0, ((spy ? q0.y : q1.x) - oNy) * iNy); tf0 = fminf(tf0, ((spy ? q1.x : q0.y) - oFy) * iFy);
+                        tn0 = fmaxf(tn0, ((spz ? q0.z : q1.y) - oNz) * iNz); tf0 = fminf(tf0, ((spz ? q1.y : q0.z) - oFz) * iFz);
+                        tn1 = ((spx ? q1.z : q2.y) - oNx) * iNx; tf1 = ((spx ? q2.y : q1.z) - oFx) * iFx;
+                        tn1 = fmaxf(tn1, ((spy ? q1.w : q2.z) - oNy) * iNy); tf1 = fminf(tf1, ((spy ? q2.z : q1.w) - oFy) * iFy);
+                        tn1 = fmaxf(tn1, ((spz ? q2.x : q2.w) - oNz) * iNz); tf1 = fminf(tf1, ((spz ? q2.w : q2.x) - oFz) * iFz);
+                        const bool h0 = fmaxf(tn0, 0.0f) <= fminf(tf0, t_prune);
+                        const bool h1 = fmaxf(tn1, 0.0f) <= fminf(tf1, t_prune);
                         if (h0 && h1) {
                             const bool swap = tn1 < tn0;
                             const int nearc = swap ? q3.y : q3.x, farc = swap ? q3.x : q3.y;
@@ -120,7 +136,7 @@ __global__ void __launch_bounds__(RTS_BLOCK) k_trace(const RtsTraceArgs a)
                             const float tf = (float)h.t;                      // rtPotentialIntersection takes float, triangle_mesh.cu:167
                             if ((tf > tmin) && (tf < best_t || (tf == best_t && L.prim < best_prim))) {
                                 best_t = tf; best_leaf = leaf; best_prim = L.prim;
-                                t_prune = (double)f32_next_up_pos(tf);         // keep equal-t candidates reachable
+                                t_prune = f32_next_up_pos(tf);                 // keep equal-t candidates reachable
                             }
                         }
                         if (sp == 0) node = SENTINEL;
