@@ -42,7 +42,9 @@ enum {
 typedef struct RtsParams {
     uint32_t width;              /* W: rays per lattice dimension, rayTotal = W^3 (rts_vars.x)          */
     uint32_t max_refl;           /* h_maxReflDepth (rts_vars.y)                                         */
-    uint32_t max_refr;           /* h_maxRefrDepth (rts_vars.z); >0 is clamped to 2 as the reference    */
+    uint32_t max_refr;           /* h_maxRefrDepth (rts_vars.z); >0 is clamped to 2 as the reference:
+                                    every output buffer then has max_refl + 3 rows per launch index,
+                                    row = launch index + k * W^3 (ray_tracer.cpp:604-626)               */
     uint32_t interpolate_smooth; /* rsParameters::interpolate_smooth()                                  */
     int32_t device;              /* HIP device ordinal                                                  */
     uint32_t flags;              /* RTS_FLAG_*                                                          */

@@ -162,10 +162,13 @@ class Tracer:
         check(L.lib().rts_get_received(self.h, ptr(rays), ptr(paths), ptr(ang), ptr(slots), R))
         return dict(results=rays, path=paths, rcs_angle=ang, slots=slots)
 
-    def all_rays(self, n):
+    def all_rays(self, n_rays, rows=None):
+        """full per-row buffers (keep_all): rows * n_rays records (rows = max_refl + 3 with refraction, else 1)"""
         D = self.depth; H = self.max_refl + 1
+        rows = rows if rows is not None else (self.max_refl + 3 if self.depth > self.max_refl else 1)
+        n = n_rays * rows
         res = np.zeros(n, PRD_DTYPE); path = np.zeros((n, D), np.int32); ang = np.zeros((n, D, 2))
-        hp = np.zeros((n, H), np.int32); ht = np.zeros((n, H), np.float32)
+        hp = np.zeros((n_rays, H), np.int32); ht = np.zeros((n_rays, H), np.float32)
         check(L.lib().rts_get_all_rays(self.h, ptr(res), ptr(path), ptr(ang), ptr(hp), ptr(ht), n))
         return dict(results=res, path=path, rcs_angle=ang, hit_prim=hp, hit_t=ht)
 

@@ -46,14 +46,14 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     if (p->width == 0) { rts_set_error("rts_create: width must be >= 1"); return RTS_ERR_INVALID; }
     if ((uint64_t)p->width * p->width * p->width > 0xffffffffULL) {      // rayIndex is unsigned int, ray_tracer.cu:151
         rts_set_error("rts_create: W^3 must fit 32 bits (W <= 1625)"); return RTS_ERR_INVALID; }
-    if (p->max_refr != 0) { rts_set_error("rts_create: refraction (max_refr > 0) is not built yet"); return RTS_ERR_UNSUPPORTED; }
-    if (p->max_refl > RTS_MAX_DEPTH) { rts_set_error("rts_create: max_refl > %d", RTS_MAX_DEPTH); return RTS_ERR_UNSUPPORTED; }
+    const uint32_t refr = p->max_refr > 0 ? 2u : 0u;                       // ">0 is forced to exactly 2", ray_tracer.cpp:604-605
+    if (p->max_refl + refr > RTS_MAX_DEPTH) { rts_set_error("rts_create: max_refl + max_refr > %d", RTS_MAX_DEPTH); return RTS_ERR_UNSUPPORTED; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { rts_set_error("rts_create: no HIP device (there is no CPU fallback)"); return RTS_ERR_NO_DEVICE; }
     if (p->device < 0 || p->device >= ndev) { rts_set_error("rts_create: device %d out of range (%d devices)", p->device, ndev); return RTS_ERR_INVALID; }
     RTS_HIP(hipSetDevice(p->device));
     RtsContext* c = new RtsContext();
-    c->params = *p; c->depth = p->max_refr + p->max_refl; c->device = p->device;
+    c->params = *p; c->params.max_refr = refr; c->depth = refr + p->max_refl; c->device = p->device;
     memset(&c->stats, 0, sizeof(c->stats));
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; rts_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return RTS_ERR_HIP; }
@@ -78,7 +78,7 @@ extern "C" int rts_destroy(RtsHandle c)
     c->d_motion.release(); c->d_targets.release(); c->d_prim_box.release(); c->d_node_box.release(); c->d_keys.release(); c->d_keys_sorted.release();
     c->d_vals.release(); c->d_vals_sorted.release(); c->d_bounds.release(); c->d_parent.release(); c->d_leaf_parent.release(); c->d_flags.release();
     c->d_nodes.release(); c->d_leaves.release(); c->d_sort_tmp.release(); c->d_rx.release(); c->d_recv.release(); c->d_all.release();
-    c->d_counters.release(); c->d_lc.release(); c->d_dir_hist.release(); c->d_hit_prim.release(); c->d_hit_t.release(); c->d_stack_ovf.release();
+    c->d_counters.release(); c->d_lc.release(); c->d_dir_hist.release(); c->d_child.release(); c->d_rk64.release(); c->d_rk64_sorted.release(); c->d_hit_prim.release(); c->d_hit_t.release(); c->d_stack_ovf.release();
     c->d_rk.release(); c->d_rk_sorted.release(); c->d_ri.release(); c->d_ri_sorted.release(); c->d_rx_rays.release(); c->d_rx_paths.release();
     c->d_rx_angles.release(); c->d_rx_slots.release(); c->d_all_rays.release(); c->d_all_paths.release(); c->d_all_angles.release();
     c->d_akeys.release(); c->d_akeys_sorted.release(); c->d_aidx.release(); c->d_aidx_sorted.release(); c->d_ghead.release(); c->d_gid.release();
@@ -236,7 +236,7 @@ extern "C" int rts_trace_pulse(RtsHandle c, const RtsPulse* p)
         RtsTargetDev* td = c->pin->td;
         for (uint32_t t = 0; t < n_targets; t++) {
             td[t].reflCoeff = c->meshes[t].refl_coeff; td[t].vx = c->motion[t].velocity[0]; td[t].vy = c->motion[t].velocity[1]; td[t].vz = c->motion[t].velocity[2];
-            td[t].tri_base = c->meshes[t].tri_base; td[t].perface_normals = c->meshes[t].perface ? 1u : 0u; td[t].pad0 = td[t].pad1 = 0;
+            td[t].tri_base = c->meshes[t].tri_base; td[t].perface_normals = c->meshes[t].perface ? 1u : 0u; td[t].refrIndex = c->meshes[t].refr_index;
             c->pin->motion[t] = c->motion[t];
         }
         if (n_targets) {
@@ -266,12 +266,16 @@ extern "C" int rts_trace_pulse(RtsHandle c, const RtsPulse* p)
     a.lc = c->d_lc.p;
     a.ray_first = first; a.n_rays = n; a.W = W; a.max_refl = c->params.max_refl; a.smooth = c->params.interpolate_smooth ? 1u : 0u;
     a.n_prims = c->n_prims; a.n_targets = n_targets; a.n_rx = c->n_rx; a.keep_all = keep_all ? 1u : 0u;
+    a.max_refr = c->params.max_refr; a.rows = a.max_refr ? c->params.max_refl + 3 : 1;
+    const uint32_t chains = a.max_refr ? 3u : 1u;
+    if ((uint64_t)n * chains > 0xfffffff0ULL) { rts_set_error("rts_trace_pulse: rays x chains exceeds 2^32"); return RTS_ERR_UNSUPPORTED; }
     a.total_threads = grid * RTS_BLOCK;
-    RTS_HIP(c->d_recv.reserve((size_t)n + 1)); RTS_HIP(c->d_counters.reserve(16));
-    RTS_HIP(c->d_dir_hist.reserve((size_t)std::max<uint32_t>(c->params.max_refl, 1) * 3 * n + 4));
+    RTS_HIP(c->d_recv.reserve((size_t)n * chains + 1)); RTS_HIP(c->d_counters.reserve(16));
+    RTS_HIP(c->d_dir_hist.reserve((size_t)(a.max_refr ? 3 * (c->params.max_refl + 1) : std::max<uint32_t>(c->params.max_refl, 1)) * 3 * n + 4));
+    if (a.max_refr) RTS_HIP(c->d_child.reserve((size_t)2 * a.total_threads));
     RTS_HIP(c->d_stack_ovf.reserve((size_t)RTS_STACK_OVF * a.total_threads));
     if (keep_all) {
-        RTS_HIP(c->d_all.reserve((size_t)n + 1)); RTS_HIP(c->d_hit_prim.reserve((size_t)n * (c->params.max_refl + 1) + 1)); RTS_HIP(c->d_hit_t.reserve((size_t)n * (c->params.max_refl + 1) + 1));
+        RTS_HIP(c->d_all.reserve((size_t)n * chains + 1)); RTS_HIP(c->d_hit_prim.reserve((size_t)n * (c->params.max_refl + 1) + 1)); RTS_HIP(c->d_hit_t.reserve((size_t)n * (c->params.max_refl + 1) + 1));
         rts_fill_i32(st, c->d_hit_prim.p, -2, (size_t)n * (c->params.max_refl + 1));
         RTS_HIP(hipMemsetAsync(c->d_hit_t.p, 0, sizeof(float) * (size_t)n * (c->params.max_refl + 1), st));
     }
@@ -279,7 +283,7 @@ extern "C" int rts_trace_pulse(RtsHandle c, const RtsPulse* p)
     a.nodes = c->d_nodes.p; a.leaves = c->d_leaves.p; a.tri_nidx = c->d_tri_nidx.p; a.normals = c->d_normals_world.p;
     a.targets = c->d_targets.p; a.rx = c->d_rx.p;
     a.recv_records = c->d_recv.p; a.all_records = c->d_all.p; a.counters = c->d_counters.p; a.dir_hist = c->d_dir_hist.p;
-    a.hit_prim = c->d_hit_prim.p; a.hit_t = c->d_hit_t.p; a.stack_ovf = c->d_stack_ovf.p;
+    a.hit_prim = c->d_hit_prim.p; a.hit_t = c->d_hit_t.p; a.stack_ovf = c->d_stack_ovf.p; a.child = c->d_child.p;
     c->last_args = a;
 
     // ---- trace
@@ -349,15 +353,15 @@ extern "C" int rts_get_all_rays(RtsHandle c, PerRayData* results, int32_t* targ_
 {
     CHECK_HANDLE(c);
     if (!(c->params.flags & RTS_FLAG_KEEP_ALL_RAYS)) { rts_set_error("rts_get_all_rays: handle was not created with RTS_FLAG_KEEP_ALL_RAYS"); return RTS_ERR_INVALID; }
-    const uint64_t n = c->n_rays; const uint32_t D = c->depth, H = c->params.max_refl + 1;
-    if (capacity < n) { rts_set_error("rts_get_all_rays: capacity too small"); return RTS_ERR_CAPACITY; }
+    const uint64_t n1 = c->n_rays, n = n1 * c->last_args.rows; const uint32_t D = c->depth, H = c->params.max_refl + 1;
+    if (capacity < n) { rts_set_error("rts_get_all_rays: capacity too small (%llu rows)", (unsigned long long)n); return RTS_ERR_CAPACITY; }
     if (n == 0) return RTS_OK;
     RTS_HIP(hipStreamSynchronize(c->stream));
     if (results) RTS_HIP(hipMemcpy(results, c->d_all_rays.p, sizeof(PerRayData)*n, hipMemcpyDeviceToHost));
     if (targ_intersect && D) RTS_HIP(hipMemcpy(targ_intersect, c->d_all_paths.p, sizeof(int32_t)*n*D, hipMemcpyDeviceToHost));
     if (rcs_angle && D) RTS_HIP(hipMemcpy(rcs_angle, c->d_all_angles.p, sizeof(double)*2*n*D, hipMemcpyDeviceToHost));
-    if (hit_prim) RTS_HIP(hipMemcpy(hit_prim, c->d_hit_prim.p, sizeof(int32_t)*n*H, hipMemcpyDeviceToHost));
-    if (hit_t) RTS_HIP(hipMemcpy(hit_t, c->d_hit_t.p, sizeof(float)*n*H, hipMemcpyDeviceToHost));
+    if (hit_prim) RTS_HIP(hipMemcpy(hit_prim, c->d_hit_prim.p, sizeof(int32_t)*n1*H, hipMemcpyDeviceToHost));
+    if (hit_t) RTS_HIP(hipMemcpy(hit_t, c->d_hit_t.p, sizeof(float)*n1*H, hipMemcpyDeviceToHost));
     return RTS_OK;
 }
 

@@ -40,6 +40,25 @@ RTS_HD fvec3 reflect3f(fvec3 i, fvec3 n) {
     return mk3f(i.x - (2.0f*n.x)*d, i.y - (2.0f*n.y)*d, i.z - (2.0f*n.z)*d);
 }
 
+// OptiX SDK optixu refract(r, i, n, ior) (call site normal_shader.cu:212), f32:
+//   c = dot(i, n); if c > 0 { eta = ior; n = -n; c = -c } else eta = 1/ior;
+//   k = 1 - eta^2 (1 - c^2); k < 0 -> r = 0, false (total internal reflection);
+//   else r = normalize(eta*i - (eta*c + sqrtf(k))*n), normalize(v) = v * (1 / sqrtf(dot(v, v)))
+RTS_HD bool refract3f(fvec3& r, fvec3 i, fvec3 n, float ior) {
+    fvec3 nn = n;
+    float negNdotV = dot3f(i, nn);
+    float eta;
+    if (negNdotV > 0.0f) { eta = ior; nn = mk3f(-n.x, -n.y, -n.z); negNdotV = -negNdotV; }
+    else { eta = 1.f / ior; }
+    const float k = 1.f - eta*eta * (1.f - negNdotV * negNdotV);
+    if (k < 0.0f) { r = mk3f(0.f, 0.f, 0.f); return false; }
+    const float sc = eta*negNdotV + sqrtf(k);
+    const fvec3 v = mk3f(eta*i.x - sc*nn.x, eta*i.y - sc*nn.y, eta*i.z - sc*nn.z);
+    const float inv = 1.0f / sqrtf(dot3f(v, v));
+    r = mk3f(v.x*inv, v.y*inv, v.z*inv);
+    return true;
+}
+
 // f64 -> f32 rounded toward -inf / +inf (__double2float_rd/ru, triangle_mesh.cu:228-229)
 RTS_HD float f32_down(double v) {
     float f = (float)v;

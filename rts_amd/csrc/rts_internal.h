@@ -31,10 +31,10 @@ static_assert(sizeof(RtsLeafTri) == 80, "leaf size");
 
 struct RtsTargetDev {               // per target, per pulse
     double reflCoeff;               // d_targReflCoeff
+    double refrIndex;               // d_targRefrIndex
     double vx, vy, vz;              // dbuf_targ_vel[targ]
     uint32_t tri_base;              // first global primitive id
     uint32_t perface_normals;       // triangle_mesh.cu:178 (normals.size() > vertices.size())
-    uint32_t pad0, pad1;
 };
 
 struct RtsRxDev { double cx, cy, cz, radius, minTheta, maxTheta, minPhi, maxPhi; };
@@ -51,6 +51,17 @@ struct __attribute__((aligned(16))) RtsEndRecord {
     uint32_t pad;
 };
 static_assert(sizeof(RtsEndRecord) == 112, "end record size");
+// RtsEndRecord::pad : bits 0-1 chain (output row = chain * n + slot), 2-3 refrDepth, 8-15 (target + 1) of chain 0's
+// refraction (path prefill of rows >= 3), 16-17 children spawned
+
+// State of a refracted child ray parked between chains (normal_shader.cu:191-256: the copy prd_refr).
+struct __attribute__((aligned(16))) RtsChildState {
+    double prevx, prevy, prevz, firstx, firsty, firstz;
+    double rayLength, power, doppler, refx, refy;
+    float dx, dy, dz;               // new_direction of refract(), exactly
+    uint32_t refrDepth, refr_code, end, pad0, pad1;
+};
+static_assert(sizeof(RtsChildState) == 128, "child state size");
 
 #define RTS_BLOCK 256
 #define RTS_STACK_LDS 24            // traversal stack entries kept in LDS per lane
@@ -76,6 +87,8 @@ struct RtsTraceArgs {
     uint32_t n_rays, W;
     uint32_t max_refl, smooth;
     uint32_t n_prims, n_targets, n_rx, keep_all;
+    uint32_t max_refr, rows;        // 0 or 2; output rows per launch index (1 or max_refl + 3)
+    RtsChildState* child;           // [2][grid threads] (refraction only)
     // scene
     const RtsNode* nodes;
     const RtsLeafTri* leaves;
@@ -152,7 +165,8 @@ struct RtsContext {
     // per pulse
     uint64_t ray_first = 0; uint32_t n_rays = 0;
     DevBuf<RtsEndRecord> d_recv, d_all; DevBuf<unsigned long long> d_counters; DevBuf<float> d_dir_hist;
-    DevBuf<int32_t> d_hit_prim; DevBuf<float> d_hit_t; DevBuf<int32_t> d_stack_ovf;
+    DevBuf<int32_t> d_hit_prim; DevBuf<float> d_hit_t; DevBuf<int32_t> d_stack_ovf; DevBuf<RtsChildState> d_child;
+    DevBuf<uint64_t> d_rk64, d_rk64_sorted;
     RtsTraceArgs last_args; RtsLaunchConsts last_lc; DevBuf<RtsLaunchConsts> d_lc;
     // received set (ordered, expanded)
     uint64_t n_recv = 0;

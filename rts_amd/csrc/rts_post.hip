@@ -13,55 +13,96 @@
 static inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 
 // --------------------------------------------------------------------------- record expansion
+// received rays are ordered as the reference's host scan meets them (ray_tracer.cpp:1190): ascending buffer
+// row = chain * n + launch slot
 __global__ void k_recv_keys(const RtsEndRecord* __restrict__ rec, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t n)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { keys[i] = rec[i].slot; vals[i] = i; }
 }
+__global__ void k_recv_keys64(const RtsEndRecord* __restrict__ rec, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t n, uint32_t n_rays)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { keys[i] = (uint64_t)(rec[i].pad & 3u) * n_rays + rec[i].slot; vals[i] = i; }
+}
 
 // cart_to_sph, normal_shader.cu:118-124
 __device__ __forceinline__ void cart_to_sph(dvec3 v, double& az, double& el) { az = atan2(v.y, v.x); el = atan2(v.z, sqrt(v.x*v.x + v.y*v.y)); }
 
-// One thread per output row j.  perm == nullptr: row j is record j (keep-all buffers, row == launch
-// index); otherwise row j is record perm[j] (received rays in ascending launch index).
-__global__ void k_expand(const RtsTraceArgs a, const RtsEndRecord* __restrict__ rec, const uint32_t* __restrict__ perm, uint32_t n, uint32_t D,
+__device__ __forceinline__ dvec3 hist_dir(const RtsTraceArgs& a, size_t plane, uint32_t slot) {
+    const float* dh = a.dir_hist + plane * 3 * a.n_rays;
+    return unit3(mk3((double)dh[slot], (double)dh[(size_t)a.n_rays + slot], (double)dh[2*(size_t)a.n_rays + slot]));
+}
+__device__ __forceinline__ void put_angle(double* angles, size_t row, uint32_t D, uint32_t col, dvec3 k0, dvec3 k1) {
+    double a0, e0, a1, e1;                     // tAngle = sph(k0) + sph(-k1)   (normal_shader.cu:259-265, 320-326)
+    cart_to_sph(k0, a0, e0);
+    cart_to_sph(mk3(-k1.x, -k1.y, -k1.z), a1, e1);
+    angles[(row*D + col)*2] = a0 + a1; angles[(row*D + col)*2 + 1] = e0 + e1;
+}
+
+// One thread per output row j.  perm != nullptr: row j is received record perm[j].  perm == nullptr: the full
+// buffers of the reference (keep-all): row j = chain * n + slot for chain < rows, rec = all_records.
+__global__ void k_expand(const RtsTraceArgs a, const RtsEndRecord* __restrict__ rec, const uint32_t* __restrict__ perm, uint32_t n_out, uint32_t D,
                          PerRayData* __restrict__ rays, int32_t* __restrict__ paths, double* __restrict__ angles, uint64_t* __restrict__ slots)
 {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const RtsEndRecord r = rec[perm ? perm[j] : j];
-    // dbuf_results[rayIndex] as left by ray_generation: initialised fields (ray_tracer.cu:227-240)
-    // overwritten by the eight written-back ones (:246-253)
+    if (j >= n_out) return;
+    RtsEndRecord r; bool valid = true; uint32_t chain, slot, prefill_code = 0;
+    if (perm) { r = rec[perm[j]]; chain = r.pad & 3u; slot = r.slot; }
+    else {
+        chain = j / a.n_rays; slot = j - chain * a.n_rays;
+        const RtsEndRecord r0 = rec[slot];
+        prefill_code = (r0.pad >> 8) & 0xffu;
+        if (chain == 0) r = r0;
+        else if (chain == 1) { valid = (r0.pad >> 16) & 1u; if (valid) r = rec[(size_t)a.n_rays + slot]; }
+        else if (chain == 2) { valid = (r0.pad >> 16) & 1u; if (valid) { const RtsEndRecord r1 = rec[(size_t)a.n_rays + slot]; valid = (r1.pad >> 17) & 1u; if (valid) r = rec[2*(size_t)a.n_rays + slot]; } }
+        else valid = false;
+    }
+    // dbuf_results[row] as left by ray_generation: initialised fields (ray_tracer.cu:227-240) overwritten by the
+    // eight written-back ones (:246-253, normal_shader.cu:272-279)
     PerRayData o;
     __builtin_memset(&o, 0, sizeof(o));
-    o.rayLength = r.rayLength; o.refrIndex.x = 1; o.refrIndex.y = 1;
-    o.reflDepth = r.reflDepth; o.refrDepth = 0; o.maxRayIndex = 0;
-    o.firstHitPoint.x = r.firstx; o.firstHitPoint.y = r.firsty; o.firstHitPoint.z = r.firstz;
-    o.prevHitPoint.x = r.prevx; o.prevHitPoint.y = r.prevy; o.prevHitPoint.z = r.prevz;
-    o.power = r.power; o.doppler = r.doppler; o.received = r.received; o.end = false;
+    o.refrIndex.x = 1; o.refrIndex.y = 1; o.received = -1; o.end = false;
+    if (valid) {
+        o.rayLength = r.rayLength; o.reflDepth = r.reflDepth; o.refrDepth = (r.pad >> 2) & 3u;
+        o.firstHitPoint.x = r.firstx; o.firstHitPoint.y = r.firsty; o.firstHitPoint.z = r.firstz;
+        o.prevHitPoint.x = r.prevx; o.prevHitPoint.y = r.prevy; o.prevHitPoint.z = r.prevz;
+        o.power = r.power; o.doppler = r.doppler; o.received = r.received;
+    }
     rays[j] = o;
-    if (slots) slots[j] = a.ray_first + r.slot;
-    // path row: dbuf_targ_intersect[row][col], -1 default (ray_tracer.cpp:854-857, normal_shader.cu:140-146)
+    if (slots) slots[j] = a.ray_first + slot + (uint64_t)chain * ((uint64_t)a.W * a.W * a.W);
+    // path row: dbuf_targ_intersect[row][col], -1 default (ray_tracer.cpp:854-857, normal_shader.cu:140-146, 221-239)
     for (uint32_t col = 0; col < D; col++) {
         int code = 0;
-        if (col < 8) code = (int)((r.path_lo >> (8*col)) & 0xff); else if (col < 16) code = (int)((r.path_hi >> (8*(col-8))) & 0xff);
+        if (valid) { if (col < 8) code = (int)((r.path_lo >> (8*col)) & 0xff); else if (col < 16) code = (int)((r.path_hi >> (8*(col-8))) & 0xff); }
+        else if (chain >= 1 && prefill_code && (chain == 1 || col < chain)) code = (int)prefill_code;
         paths[(size_t)j*D + col] = code - 1;
     }
-    // RCS angle row (normal_shader.cu:320-326): tAngle = sph(k0) + sph(-k1) per reflection,
-    // -1e6 default (ray_tracer.cpp:861-867); k0/k1 rebuilt from the f32 direction history
-    dvec3 kin = unit3(rts_primary_dir(*a.lc, r.slot));
-    for (uint32_t col = 0; col < D; col++) {
-        double ax = -1000000, ay = -1000000;
-        if (col < r.reflDepth) {
-            const float* dh = a.dir_hist + (size_t)col * 3 * a.n_rays;
-            const dvec3 k1 = unit3(mk3((double)dh[r.slot], (double)dh[(size_t)a.n_rays + r.slot], (double)dh[2*(size_t)a.n_rays + r.slot]));
-            double a0, e0, a1, e1;
-            cart_to_sph(kin, a0, e0);
-            cart_to_sph(mk3(-k1.x, -k1.y, -k1.z), a1, e1);
-            ax = a0 + a1; ay = e0 + e1;
-            kin = k1;
+    for (uint32_t col = 0; col < D; col++) { angles[((size_t)j*D + col)*2] = -1000000; angles[((size_t)j*D + col)*2 + 1] = -1000000; }   // ray_tracer.cpp:861-867
+    if (!valid) return;
+    // RCS angle rows, rebuilt from the f32 direction history
+    const dvec3 kprim = unit3(rts_primary_dir(*a.lc, slot));
+    if (a.max_refr == 0) {
+        dvec3 kin = kprim;
+        for (uint32_t c = 0; c < r.reflDepth && c < D; c++) { const dvec3 k1 = hist_dir(a, c, slot); put_angle(angles, j, D, c, kin, k1); kin = k1; }
+    } else {
+        const size_t P = a.max_refl + 1;
+        // with refraction enabled the depth gate (normal_shader.cu:134) also shades a hit at reflDepth == maxRefl,
+        // which then does NOT reflect (:293): reflections performed = min(reflDepth, maxRefl)
+        const uint32_t nrefl = r.reflDepth < a.max_refl ? r.reflDepth : a.max_refl;
+        if (chain == 0) {
+            dvec3 kin = kprim;
+            for (uint32_t c = 0; c < nrefl && c < D; c++) { const dvec3 k1 = hist_dir(a, c + 1, slot); put_angle(angles, j, D, c, kin, k1); kin = k1; }
+        } else if (chain == 1) {
+            dvec3 kin = hist_dir(a, P, slot);
+            put_angle(angles, j, D, 0, kprim, kin);
+            for (uint32_t q = 1; q <= nrefl && q < D; q++) { const dvec3 k1 = hist_dir(a, P + q, slot); put_angle(angles, j, D, q, kin, k1); kin = k1; }
+        } else {
+            const dvec3 kpar = hist_dir(a, P, slot);
+            dvec3 kin = hist_dir(a, 2*P, slot);
+            put_angle(angles, j, D, 1, kpar, kin);
+            for (uint32_t q = 1; q <= nrefl && q + 1 < D; q++) { const dvec3 k1 = hist_dir(a, 2*P + q, slot); put_angle(angles, j, D, q + 1, kin, k1); kin = k1; }
         }
-        angles[((size_t)j*D + col)*2] = ax; angles[((size_t)j*D + col)*2 + 1] = ay;
     }
 }
 
@@ -73,14 +114,23 @@ int rts_post_order_and_expand(RtsContext* c)
     const uint32_t R = (uint32_t)c->n_recv, D = c->depth;
     if (R == 0) return RTS_OK;
     hipStream_t st = c->stream;
-    RTS_HIP(c->d_rk.reserve(R)); RTS_HIP(c->d_rk_sorted.reserve(R)); RTS_HIP(c->d_ri.reserve(R)); RTS_HIP(c->d_ri_sorted.reserve(R));
+    RTS_HIP(c->d_ri.reserve(R)); RTS_HIP(c->d_ri_sorted.reserve(R));
     RTS_HIP(c->d_rx_rays.reserve(R)); RTS_HIP(c->d_rx_paths.reserve((size_t)R*D + 1)); RTS_HIP(c->d_rx_angles.reserve((size_t)R*D*2 + 1)); RTS_HIP(c->d_rx_slots.reserve(R));
-    k_recv_keys<<<blocks_for(R, 256), 256, 0, st>>>(c->d_recv.p, c->d_rk.p, c->d_ri.p, R);
-    RTS_STAGE(c, "k_recv_keys");
     size_t tmp = 0;
-    RTS_HIP(rocprim::radix_sort_pairs(nullptr, tmp, c->d_rk.p, c->d_rk_sorted.p, c->d_ri.p, c->d_ri_sorted.p, R, 0, 32, st));
-    RTS_HIP(c->d_sort_tmp.reserve(tmp));
-    RTS_HIP(rocprim::radix_sort_pairs(c->d_sort_tmp.p, tmp, c->d_rk.p, c->d_rk_sorted.p, c->d_ri.p, c->d_ri_sorted.p, R, 0, 32, st));
+    if (c->last_args.max_refr == 0) {
+        RTS_HIP(c->d_rk.reserve(R)); RTS_HIP(c->d_rk_sorted.reserve(R));
+        k_recv_keys<<<blocks_for(R, 256), 256, 0, st>>>(c->d_recv.p, c->d_rk.p, c->d_ri.p, R);
+        RTS_STAGE(c, "k_recv_keys");
+        RTS_HIP(rocprim::radix_sort_pairs(nullptr, tmp, c->d_rk.p, c->d_rk_sorted.p, c->d_ri.p, c->d_ri_sorted.p, R, 0, 32, st));
+        RTS_HIP(c->d_sort_tmp.reserve(tmp));
+        RTS_HIP(rocprim::radix_sort_pairs(c->d_sort_tmp.p, tmp, c->d_rk.p, c->d_rk_sorted.p, c->d_ri.p, c->d_ri_sorted.p, R, 0, 32, st));
+    } else {
+        RTS_HIP(c->d_rk64.reserve(R)); RTS_HIP(c->d_rk64_sorted.reserve(R));
+        k_recv_keys64<<<blocks_for(R, 256), 256, 0, st>>>(c->d_recv.p, c->d_rk64.p, c->d_ri.p, R, c->n_rays);
+        RTS_HIP(rocprim::radix_sort_pairs(nullptr, tmp, c->d_rk64.p, c->d_rk64_sorted.p, c->d_ri.p, c->d_ri_sorted.p, R, 0, 34, st));
+        RTS_HIP(c->d_sort_tmp.reserve(tmp));
+        RTS_HIP(rocprim::radix_sort_pairs(c->d_sort_tmp.p, tmp, c->d_rk64.p, c->d_rk64_sorted.p, c->d_ri.p, c->d_ri_sorted.p, R, 0, 34, st));
+    }
     RTS_STAGE(c, "recv sort");
     k_expand<<<blocks_for(R, 256), 256, 0, st>>>(c->last_args, c->d_recv.p, c->d_ri_sorted.p, R, D, c->d_rx_rays.p, c->d_rx_paths.p, c->d_rx_angles.p, c->d_rx_slots.p);
     RTS_STAGE(c, "k_expand");
@@ -90,8 +140,10 @@ int rts_post_order_and_expand(RtsContext* c)
 
 int rts_post_expand_all(RtsContext* c)
 {
-    const uint32_t n = c->n_rays, D = c->depth;
-    if (n == 0) return RTS_OK;
+    const uint64_t n64 = (uint64_t)c->n_rays * c->last_args.rows; const uint32_t D = c->depth;
+    if (n64 == 0) return RTS_OK;
+    if (n64 > 0xffffffffULL) { rts_set_error("keep-all buffers: rows * rays exceeds 2^32"); return RTS_ERR_UNSUPPORTED; }
+    const uint32_t n = (uint32_t)n64;
     RTS_HIP(c->d_all_rays.reserve(n)); RTS_HIP(c->d_all_paths.reserve((size_t)n*D + 1)); RTS_HIP(c->d_all_angles.reserve((size_t)n*D*2 + 1));
     k_expand<<<blocks_for(n, 256), 256, 0, c->stream>>>(c->last_args, c->d_all.p, nullptr, n, D, c->d_all_rays.p, c->d_all_paths.p, c->d_all_angles.p, nullptr);
     RTS_HIP(hipGetLastError());

@@ -44,7 +44,13 @@ __device__ __forceinline__ TriHit tri_test(const RtsLeafTri& L, dvec3 o, dvec3 d
 // `if (a.keep_all)` to a per-lane v_cmp mask computed under the divergent exec of the bounce loop
 // and re-used it at the write-back under a different exec, so lanes that were inactive at the
 // definition stored through the null all_records pointer.
-template <bool COUNT, bool KEEP_ALL>
+// REFR builds the refraction branch of closest_hit (normal_shader.cu:191-282): a launch index then owns up
+// to three independent ray chains -- 0: the reflection chain, 1: the ray refracted INTO the first-hit
+// target (spawned by chain 0 at its first hit), 2: the ray refracted back OUT (spawned by chain 1 at its
+// first hit) -- whose results live in rows rayIndex + k*W^3 of the output buffers (:214, :272-279).
+// The reference recurses depth first; the chains are independent once spawned (the payload is copied,
+// :191), so they are traced one after the other and the spawned state is parked in global memory.
+template <bool COUNT, bool KEEP_ALL, bool REFR>
 __global__ void __launch_bounds__(RTS_BLOCK) k_trace(const RtsTraceArgs a)
 {
     __shared__ int32_t s_stack[RTS_STACK_LDS * RTS_BLOCK];
@@ -54,23 +60,41 @@ __global__ void __launch_bounds__(RTS_BLOCK) k_trace(const RtsTraceArgs a)
     const dvec3 origin = mk3(lc.ox, lc.oy, lc.oz);
     unsigned long long n_seg = 0, n_shaded = 0, n_nodes = 0, n_tris = 0, n_spill = 0;
     bool hard_overflow = false;
+    const uint32_t max_refr = REFR ? 2u : 0u;
+    const uint32_t D = a.max_refl + max_refr;
 
     for (uint32_t slot = gtid; slot < a.n_rays; slot += a.total_threads) {
-        // ---------------------------------------------------------------- ray_generation
-        dvec3 dir = rts_primary_dir(lc, slot);
-        // payload, ray_tracer.cu:212-224
-        dvec3 prev = origin;
-        dvec3 first = mk3(0.0, 0.0, 0.0);
-        double rayLength = 0, power = 0, doppler = 0;
-        uint32_t reflDepth = 0;
+      uint32_t pending = 0;                   // bit k: chain k has been spawned
+      uint32_t refr_code0 = 0;                // (target + 1) of chain 0's refraction, for the path prefill of rows >= 3
+      for (uint32_t chain = 0; chain < (REFR ? 3u : 1u); chain++) {
+        dvec3 dir, prev, first;
+        double rayLength, power, doppler, refx = 1, refy = 1;
+        uint32_t reflDepth = 0, refrDepth = 0;
         int received = -1;
         bool end = false;
         uint64_t path_lo = 0, path_hi = 0;
+        if (chain == 0) {
+            // ------------------------------------------------------------ ray_generation + payload, ray_tracer.cu:144-224
+            dir = rts_primary_dir(lc, slot);
+            prev = origin; first = mk3(0.0, 0.0, 0.0);
+            rayLength = 0; power = 0; doppler = 0;
+        } else {
+            if (!REFR || !(pending & (1u << chain))) continue;
+            const RtsChildState cs = a.child[(size_t)(chain - 1) * a.total_threads + gtid];
+            dir = mk3((double)cs.dx, (double)cs.dy, (double)cs.dz);          // prd_refr.rayDirection = widened f32 refract() result (:252)
+            prev = mk3(cs.prevx, cs.prevy, cs.prevz); first = mk3(cs.firstx, cs.firsty, cs.firstz);
+            rayLength = cs.rayLength; power = cs.power; doppler = cs.doppler; refx = cs.refx; refy = cs.refy;
+            refrDepth = cs.refrDepth; end = cs.end != 0;
+            // path prefill by the FIRST refraction (:221-239): row W^3 gets every column, row 2 W^3 columns 0..1
+            const uint64_t code = cs.refr_code;
+            for (uint32_t col = 0; col < (chain == 1 ? D : 2u); col++) { if (col < 8) path_lo |= code << (8 * col); else path_hi |= code << (8 * (col - 8)); }
+        }
+        bool chain_start = true;               // first segment of this chain: incident epsilon, f32 direction rule below
 
         for (;;) {
             // ------------------------------------------------------------ rtTrace: closest hit over the LBVH
             n_seg++;
-            const float tmin = (reflDepth == 0) ? SCENE_EPS : SCENE_EPS_R;     // ray_tracer.cu:209, normal_shader.cu:297
+            const float tmin = chain_start ? SCENE_EPS : SCENE_EPS_R;          // ray_tracer.cu:209, normal_shader.cu:242,297
             float best_t = RTS_DEFAULT_TMAX;
             int best_leaf = -1; uint32_t best_prim = 0xffffffffu;
             if (a.n_prims > 0) {
@@ -144,7 +168,7 @@ __global__ void __launch_bounds__(RTS_BLOCK) k_trace(const RtsTraceArgs a)
                     }
                 }
             }
-            if (KEEP_ALL) {
+            if (KEEP_ALL && chain == 0) {
                 const size_t hidx = (size_t)slot * (a.max_refl + 1) + reflDepth;
                 a.hit_prim[hidx] = (best_leaf >= 0) ? (int32_t)best_prim : -1;
                 a.hit_t[hidx] = (best_leaf >= 0) ? best_t : 0.0f;
@@ -190,7 +214,7 @@ __global__ void __launch_bounds__(RTS_BLOCK) k_trace(const RtsTraceArgs a)
                                 end = true;                                                    // :396
                                 const double tr = received_root == 0 ? t[0] : t[1];
                                 const dvec3 ep = mk3(prev.x + tr*dir.x, prev.y + tr*dir.y, prev.z + tr*dir.z);
-                                if (reflDepth == 0) {                                          // direct transmission :410-417
+                                if ((reflDepth == 0) && (refrDepth == 0)) {                    // direct transmission :410-417
                                     const dvec3 RxRange = sub3(ep, origin);
                                     if (len3(RxRange) >= SCENE_EPS) {
                                         power = 1/(4*RTS_PI*4*RTS_PI*(magsq3(RxRange)));
@@ -226,19 +250,23 @@ __global__ void __launch_bounds__(RTS_BLOCK) k_trace(const RtsTraceArgs a)
                 break;
             }
 
-            // ------------------------------------------------------------ closest_hit, normal_shader.cu:128-340 (maxRefr == 0)
-            if (!((end == false) && (reflDepth < a.max_refl))) break;          // gate :134 ; absorbed hit leaves the payload untouched
+            // ------------------------------------------------------------ closest_hit, normal_shader.cu:128-340
+            if (!((end == false) && ((refrDepth < max_refr) || (reflDepth < a.max_refl)))) break;   // gate :134 ; absorbed hit leaves the payload untouched
             n_shaded++;
             const RtsLeafTri L = a.leaves[best_leaf];
             const RtsTargetDev T = a.targets[L.targ];
-            {   // path column = reflDepth < D always holds here (:140-146)
-                const uint64_t code = (uint64_t)(L.targ + 1);
-                if (reflDepth < 8) path_lo |= code << (8 * reflDepth); else path_hi |= code << (8 * (reflDepth - 8));
+            if (refrDepth != 1) {                                              // path column (:140-146)
+                const uint32_t col = reflDepth + refrDepth;
+                if (col < D) {
+                    const uint64_t code = (uint64_t)(L.targ + 1);
+                    if (col < 8) path_lo = (path_lo & ~(0xffULL << (8 * col))) | (code << (8 * col));
+                    else path_hi = (path_hi & ~(0xffULL << (8 * (col - 8)))) | (code << (8 * (col - 8)));
+                }
             }
             const float hit_t = best_t;
             const dvec3 hitPoint = mk3(prev.x + (double)hit_t*dir.x, prev.y + (double)hit_t*dir.y, prev.z + (double)hit_t*dir.z);   // :149-152
             rayLength += hit_t;                                                // :153
-            if (reflDepth == 0) {                                              // :159-166
+            if ((reflDepth == 0) && (refrDepth == 0)) {                        // :159-166
                 first = hitPoint;
                 const dvec3 TxRange = sub3(first, origin);
                 if (len3(TxRange) >= SCENE_EPS) power = 1/((magsq3(TxRange))*4*RTS_PI);
@@ -266,38 +294,75 @@ __global__ void __launch_bounds__(RTS_BLOCK) k_trace(const RtsTraceArgs a)
             } else {
                 normal = unit3(h.n);
             }
-            // f32 direction of the current OptiX ray: primary = normalise_float3(rayDir_d3) (ray_tracer.cu:208),
-            // bounce = the f32 reflect() result itself (normal_shader.cu:296-297)
-            const fvec3 dirf = (reflDepth == 0) ? unit3_to_f32(dir) : mk3f((float)dir.x, (float)dir.y, (float)dir.z);
+            // f32 direction of the current OptiX ray: primary = normalise_float3(rayDir_d3) (ray_tracer.cu:208);
+            // bounce / refracted = the f32 reflect()/refract() result itself (normal_shader.cu:242,296-297)
+            const fvec3 dirf = (chain == 0 && chain_start) ? unit3_to_f32(dir) : mk3f((float)dir.x, (float)dir.y, (float)dir.z);
+            const fvec3 nf = unit3_to_f32(normal);
+
+            // ---- refraction branch (:191-282): prd_refr = prd; prd_refr.refrIndex.x = prd_refr.refrIndex.y
+            const double rrefx = refy;                                         // prd_refr.refrIndex.x
+            if (REFR) {
+                if ((fabs(T.reflCoeff) != 1.00000f) && (refrDepth < max_refr) && (reflDepth == 0)) {   // :198
+                    const double rrefy = (rrefx == 1) ? T.refrIndex : 1.0;     // :201-206
+                    const float ratio = (float)(rrefy / rrefx);                // :209
+                    fvec3 rd;
+                    if (refract3f(rd, dirf, nf, ratio)) {                      // :212
+                        RtsChildState cs;
+                        cs.prevx = prev.x; cs.prevy = prev.y; cs.prevz = prev.z; cs.firstx = first.x; cs.firsty = first.y; cs.firstz = first.z;
+                        cs.rayLength = rayLength; cs.refx = rrefx; cs.refy = rrefy; cs.end = end ? 1u : 0u;
+                        double cpower = power;
+                        if ((reflDepth + 1) < (a.max_refl + 1)) cpower *= (1 - fabs(T.reflCoeff));   // :245-246
+                        cs.power = cpower;
+                        cs.refrDepth = refrDepth + 1;                           // :247
+                        const dvec3 k0 = unit3(dir);                            // :251-256
+                        const dvec3 nd3 = widen3(rd);
+                        const dvec3 k1 = unit3(nd3);
+                        cs.doppler = doppler + dot3(mk3(T.vx, T.vy, T.vz), sub3(k1, k0));
+                        cs.dx = rd.x; cs.dy = rd.y; cs.dz = rd.z;
+                        cs.refr_code = (chain == 0) ? (L.targ + 1) : (uint32_t)((path_lo) & 0xff);   // prefill code travels with the first refraction only
+                        if (chain == 0) refr_code0 = L.targ + 1;
+                        a.child[(size_t)chain * a.total_threads + gtid] = cs;
+                        pending |= 1u << (chain + 1);
+                        // direction history plane 0 of the child chain: RCS angle of the refraction event (:259-265)
+                        float* dh = a.dir_hist + (size_t)((chain + 1) * (a.max_refl + 1)) * 3 * a.n_rays;
+                        dh[slot] = rd.x; dh[(size_t)a.n_rays + slot] = rd.y; dh[2*(size_t)a.n_rays + slot] = rd.z;
+                    }
+                }
+            }
             reflDepth++;                                                       // :286
-            // reflDepth < d_maxReflDepth (= max_refl + 1) always holds after the gate (:293)
-            const fvec3 nd = reflect3f(dirf, unit3_to_f32(normal));            // :296
+            refy = rrefx; refx = rrefx;                                        // :289-290
+            chain_start = false;
+            if (!(reflDepth < a.max_refl + 1)) break;                          // :293 (can fail only inside a refracted chain)
+            const fvec3 nd = reflect3f(dirf, nf);                              // :296
             power *= T.reflCoeff;                                              // :298
             const dvec3 k0 = unit3(dir);                                       // :302
             dir = widen3(nd);                                                  // :303
             const dvec3 k1 = unit3(dir);                                       // :304
             doppler += dot3(mk3(T.vx, T.vy, T.vz), sub3(k1, k0));              // :314
             {   // direction history: the RCS angles of received rays are rebuilt from it (:320-326)
-                float* dh = a.dir_hist + (size_t)(reflDepth - 1) * 3 * a.n_rays;
+                const size_t plane = REFR ? (size_t)chain * (a.max_refl + 1) + reflDepth : (size_t)(reflDepth - 1);
+                float* dh = a.dir_hist + plane * 3 * a.n_rays;
                 dh[slot] = nd.x; dh[(size_t)a.n_rays + slot] = nd.y; dh[2*(size_t)a.n_rays + slot] = nd.z;
             }
         }
 
-        // ---------------------------------------------------------------- write-back (ray_tracer.cu:246-253)
+        // ---------------------------------------------------------------- write-back (ray_tracer.cu:246-253, normal_shader.cu:272-279)
         const bool recv = received >= 0;
         if (recv || KEEP_ALL) {
             RtsEndRecord r;
             r.rayLength = rayLength; r.power = power; r.doppler = doppler;
             r.prevx = prev.x; r.prevy = prev.y; r.prevz = prev.z;
             r.firstx = first.x; r.firsty = first.y; r.firstz = first.z;
-            r.path_lo = path_lo; r.path_hi = path_hi; r.slot = slot; r.received = received; r.reflDepth = reflDepth; r.pad = 0;
-            if (KEEP_ALL) a.all_records[slot] = r;
+            r.path_lo = path_lo; r.path_hi = path_hi; r.slot = slot; r.received = received; r.reflDepth = reflDepth;
+            r.pad = chain | (refrDepth << 2) | ((chain == 0 ? refr_code0 : 0u) << 8) | ((pending & 6u) << 15);   // chain, refrDepth, prefill code, spawned children
+            if (KEEP_ALL) a.all_records[(size_t)chain * a.n_rays + slot] = r;
             if (recv) {
                 // the compiler folds this into one atomic per wave (v_mbcnt + s_bcnt1)
                 unsigned long long idx = atomicAdd(&a.counters[0], 1ULL);
                 a.recv_records[idx] = r;
             }
         }
+      }   // chain
     }
 
     // ------------------------------------------------------------------ counters: wave reduce, one atomic per wave
@@ -318,12 +383,17 @@ int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a, bool count_traversal)
 {
     if (a.n_rays == 0) return RTS_OK;
     const unsigned grid = a.total_threads / RTS_BLOCK;
-    if (a.keep_all) {
-        if (count_traversal) k_trace<true, true><<<grid, RTS_BLOCK, 0, c->stream>>>(a);
-        else k_trace<false, true><<<grid, RTS_BLOCK, 0, c->stream>>>(a);
-    } else {
-        if (count_traversal) k_trace<true, false><<<grid, RTS_BLOCK, 0, c->stream>>>(a);
-        else k_trace<false, false><<<grid, RTS_BLOCK, 0, c->stream>>>(a);
+    hipStream_t st = c->stream;
+    const int sel = (a.max_refr ? 4 : 0) | (a.keep_all ? 2 : 0) | (count_traversal ? 1 : 0);
+    switch (sel) {
+        case 0: k_trace<false, false, false><<<grid, RTS_BLOCK, 0, st>>>(a); break;
+        case 1: k_trace<true, false, false><<<grid, RTS_BLOCK, 0, st>>>(a); break;
+        case 2: k_trace<false, true, false><<<grid, RTS_BLOCK, 0, st>>>(a); break;
+        case 3: k_trace<true, true, false><<<grid, RTS_BLOCK, 0, st>>>(a); break;
+        case 4: k_trace<false, false, true><<<grid, RTS_BLOCK, 0, st>>>(a); break;
+        case 5: k_trace<true, false, true><<<grid, RTS_BLOCK, 0, st>>>(a); break;
+        case 6: k_trace<false, true, true><<<grid, RTS_BLOCK, 0, st>>>(a); break;
+        default: k_trace<true, true, true><<<grid, RTS_BLOCK, 0, st>>>(a); break;
     }
     RTS_HIP(hipGetLastError());
     return RTS_OK;

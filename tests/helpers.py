@@ -18,11 +18,11 @@ def oracle_scene(O, spec, motion=None):
 def oracle_trace(O, spec, motion=None, **kw):
     sc = oracle_scene(O, spec, motion)
     tx = spec["tx"]
-    return sc.trace(tx["origin"], tx["span"], tx["dir"], spec["W"], spec["max_refl"], 0, spec["smooth"], **kw)
+    return sc.trace(tx["origin"], tx["span"], tx["dir"], spec["W"], spec["max_refl"], spec.get("max_refr", 0), spec["smooth"], **kw)
 
 
 def gpu_tracer(api, spec, **kw):
-    tr = api.Tracer(spec["W"], spec["max_refl"], 0, spec["smooth"], **kw)
+    tr = api.Tracer(spec["W"], spec["max_refl"], spec.get("max_refr", 0), spec["smooth"], **kw)
     tr.set_scene(spec["meshes"])
     tr.set_receivers(spec["rx"])
     return tr
@@ -57,9 +57,10 @@ def assert_prd_equal(a, b, what=""):
 
 
 def compare_full(o, g, n):
-    """o: oracle trace dict (all rays), g: product rts_get_all_rays dict."""
-    assert np.array_equal(o["hit_prim"][:n], g["hit_prim"][:n]), "closest-hit primitive ids differ"
-    assert np.array_equal(o["hit_t"][:n].view(np.uint32), g["hit_t"][:n].view(np.uint32)), "f32 hit distances differ"
+    """o: oracle trace dict (all rows), g: product rts_get_all_rays dict; n = number of output rows."""
+    nh = o["hit_prim"].shape[0]
+    assert np.array_equal(o["hit_prim"], g["hit_prim"][:nh]), "closest-hit primitive ids differ"
+    assert np.array_equal(o["hit_t"].view(np.uint32), g["hit_t"][:nh].view(np.uint32)), "f32 hit distances differ"
     assert np.array_equal(o["path"][:n], g["path"][:n]), "target paths differ"
     assert_prd_equal(o["results"][:n], g["results"][:n], "per-ray records")
     # RCS angles come from libm / OCML atan2: tolerance, not bits

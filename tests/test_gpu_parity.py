@@ -31,9 +31,10 @@ def scenes():
 
 
 def full_parity(api, O, spec, motion=None, bvh=False):
-    n = spec["W"] ** 3
+    rows = spec["max_refl"] + 3 if spec.get("max_refr", 0) else 1
+    n = spec["W"] ** 3 * rows
     tr, st = H.gpu_trace(api, spec, motion=motion)
-    g = tr.all_rays(n)
+    g = tr.all_rays(spec["W"] ** 3)
     o = H.oracle_trace(O, spec, motion=motion, use_bvh=bvh, threads=4 if bvh else 1)
     H.compare_full(o, g, n)
     assert st["segments"] == o["counters"]["segments"] and st["shaded"] == o["counters"]["shaded"]
@@ -116,6 +117,35 @@ def test_multi_target_depths(rts, oracle, scenes, max_refl):
     if max_refl >= 4:
         assert o["results"]["reflDepth"].max() >= 3
         assert len(np.unique(o["path"][o["results"]["received"] >= 0], axis=0)) >= 2
+    tr.close()
+
+
+@pytest.mark.parametrize("max_refl,smooth", [(1, True), (3, True), (3, False), (0, True)])
+def test_refraction(rts, oracle, scenes, max_refl, smooth):
+    """refraction branch (normal_shader.cu:191-282, maxRefr forced to 2): rows rayIndex + k W^3 for the ray refracted
+    into (k = 1) and back out of (k = 2) the first-hit target, path prefill, (1 - |Gamma|) power split, refract()"""
+    spec = scenes.config_multi(W=14, max_refl=max_refl, smooth=smooth)
+    spec["max_refr"] = 1
+    spec["meshes"][0]["refr_index"] = 1.5; spec["meshes"][0]["refl_coeff"] = 0.5
+    spec["meshes"][1]["refr_index"] = 2.2; spec["meshes"][1]["refl_coeff"] = -0.6
+    spec["meshes"][2]["refl_coeff"] = 1.0                                 # |Gamma| = 1: never refracts (:198)
+    spec["rx"] = spec["rx"] + [scenes._rx_at((200.0, 0.0, 0.0), (0, 0, 0), 90.0, 2.6)]   # behind the targets: catches transmitted rays
+    tr, st, o, g = full_parity(rts, oracle, spec)
+    n = spec["W"] ** 3
+    res = o["results"]
+    assert (res["refrDepth"][n:2 * n] >= 1).any() and (res["refrDepth"][2 * n:3 * n] == 2).any()
+    assert (res["received"][2 * n:3 * n] >= 0).any()                      # rays refracted through a target reach the far receiver
+    # finalise + aggregate over rows of all chains vs the literal pipeline
+    wl = spec["c"] / spec["carrier"]
+    tr.finalise_uniform([1.0, 1.0, 1.0], wl, 1.0, 1.0, spec["carrier"], spec["c"])
+    groups = tr.aggregate(spec["c"], spec["carrier"])
+    rx, rxi, slots = oracle.filter_finalise(o["results"], o["path"], [1.0] * 3, wl, 1.0, 1.0, spec["carrier"], spec["c"])
+    lit = oracle.aggregate_literal(rx, rxi, spec["c"], spec["carrier"], len(res))
+    ag = tr.aggregated()
+    assert np.array_equal(ag["pathMatch"], lit["pathMatch"])
+    np.testing.assert_allclose(ag["results"]["power"], lit["results"]["power"], rtol=1e-11)
+    resp = rts.groups_to_responses(groups)
+    assert np.array_equal(resp["ray"].astype(np.int64), oracle.unique_paths(lit["pathMatch"]).astype(np.int64))
     tr.close()
 
 
