@@ -120,12 +120,20 @@ def main():
     tr = api.Tracer(W, spec["max_refl"], 0, spec["smooth"], device=local_rank)
     tr.set_scene(spec["meshes"]); tr.set_receivers(spec["rx"])
 
+    # complex return cube [rx][pulse][range bin] (derived product; the dense buffer that is all-reduced over RCCL)
+    n_bins = 1024; r0 = 2.0 * abs(tx["origin"][0])
+    cube_t0 = (r0 - 150.0) / spec["c"]; cube_dt = 300.0 / spec["c"] / n_bins
+    cube = torch.zeros((len(spec["rx"]), max(args.steps, args.warmup, 1), n_bins), dtype=torch.complex128, device="cuda")
+    tr.cube_attach(cube.shape[0], cube.shape[1], n_bins, cube_t0, cube_dt, device_ptr=cube.data_ptr())
+
     def run_cpi(k0, n_pulses):
         """pulses k0 .. k0+n_pulses-1 as one coherent processing interval, sharded over the ranks"""
         parts = []; acc = dict(segments=0, shaded=0, received=0, ms_scene=0.0, ms_trace=0.0, ms_post=0.0, launches=0)
+        cube.zero_(); torch.cuda.synchronize()
         for (k, first, count) in multigpu.plan_cpi(total, n_pulses, rank, world):
             tr.trace(tx["origin"], tx["span"], tx["dir"], pulse_motion(spec, k0 + k), ray_first=first, ray_count=count, want_stats=False)
             tr.finalise_uniform(None, wl, 1.0, 1.0, spec["carrier"], spec["c"])
+            tr.cube_accumulate(k, spec["c"], spec["carrier"])
             groups = tr.aggregate(spec["c"], spec["carrier"], 0)
             st = tr.stats()                                   # stream already drained by the aggregation's table fetch
             parts.append(dict(pulse=k, ray_first=first, n_recv=st["received"], groups=groups))
@@ -134,6 +142,12 @@ def main():
             acc["launches"] += 1
         allp = multigpu.exchange_parts(parts, dist, torch)    # ONE exchange per CPI (RCCL all-gather), inside the timed region
         resp = multigpu.merge_cpi(allp, spec["max_refl"])
+        if dist is not None:                                  # dense per-receiver return buffers: sum over the ranks
+            if args.backend == "nccl":
+                dist.all_reduce(torch.view_as_real(cube), op=dist.ReduceOp.SUM)
+            else:
+                cc = torch.view_as_real(cube).cpu(); dist.all_reduce(cc, op=dist.ReduceOp.SUM); cube.copy_(torch.view_as_complex(cc))
+        acc["range_doppler_peak"] = float(torch.fft.fft(cube[:, :n_pulses], dim=1).abs().max().item()) if n_pulses > 0 else 0.0
         return acc, resp
 
     def sync():
@@ -181,7 +195,7 @@ def main():
             "config": {"workload": "BASELINE.json configs[2]: %s, 1 Tx / %d Rx, W=%d (%d launch indices/pulse), maxRefl=%d, target moves every pulse (LBVH rebuilt per pulse)"
                                    % (spec["name"], len(spec["rx"]), W, total, spec["max_refl"]),
                        "rays_per_pulse": total, "segments_per_pulse": seg_all / args.steps, "received_per_pulse": received_all / args.steps,
-                       "primary_Mrays_per_s": total * args.steps / dt / 1e6, "sharding": "contiguous (pulse, launch index) ranges of the %d-pulse interval x%d ranks, one group-table all-gather per interval" % (args.steps, world),
+                       "primary_Mrays_per_s": total * args.steps / dt / 1e6, "return_cube": "complex128 [%d rx][%d pulses][%d bins], all-reduced once per interval" % (cube.shape[0], args.steps, n_bins), "sharding": "contiguous (pulse, launch index) ranges of the %d-pulse interval x%d ranks, one group-table all-gather per interval" % (args.steps, world),
                        "stage_ms_per_launch_rank0": {"scene+lbvh": ms_scene / launches, "trace": ms_launch, "order+finalise+aggregate": ms_post / launches}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "k_trace", "bytes_per_segment": bytes_per_seg,

@@ -196,6 +196,22 @@ int rts_merge_groups(const RtsGroup* in, uint32_t n_in, uint32_t depth, RtsGroup
 int rts_groups_to_responses(const RtsGroup* groups, uint32_t n_groups, RtsResponse* out, uint32_t capacity,
                             uint32_t* n_out);
 
+/* ---------------------------------------------------------------- complex return cube (derived product)
+ * Not in the reference (SOARS' rsresponse renders the responses); the north star asks for "atomic complex
+ * accumulation into per-receiver range-Doppler bins" with an RCCL reduce of the per-receiver return buffers.
+ * cube[rx][pulse][bin] (complex128, interleaved re/im) += sqrt(power) * exp(j * phase) for every received,
+ * finalised ray of the last pulse, with delay = rayLength / c, phase = -fmod(2 pi fc delay, 2 pi) (the phase
+ * convention of aggregation.cu:59-60) and bin = floor((delay - t0) / dt); rays outside [0, n_bins) are dropped.
+ * The storage may be caller-owned DEVICE memory (device_ptr != NULL, e.g. a torch tensor that is then
+ * all-reduced over RCCL) or library-owned (device_ptr == NULL). */
+typedef struct RtsCubeParams {
+    uint32_t n_rx, n_pulses, n_bins, reserved;
+    double t0, dt;
+} RtsCubeParams;
+int rts_cube_attach(RtsHandle h, const RtsCubeParams* params, void* device_ptr);
+int rts_cube_accumulate(RtsHandle h, uint32_t pulse_index, double cspeed, double carrier);
+int rts_cube_get(RtsHandle h, double* host_out, uint64_t capacity_doubles);
+
 /* ---------------------------------------------------------------- the reference's inner C-like boundary
  * Same argument list and in/out behaviour as rs::kernel_wrapper (aggregation.cuh:19-22,
  * aggregation.cu:103-184); the C++ symbol rs::kernel_wrapper is exported by the library too

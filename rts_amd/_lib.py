@@ -55,6 +55,11 @@ class RtsPulse(C.Structure):
                 ("ray_first", C.c_uint64), ("ray_count", C.c_uint64), ("motion", C.POINTER(RtsTargetMotion))]
 
 
+class RtsCubeParams(C.Structure):
+    _fields_ = [("n_rx", C.c_uint32), ("n_pulses", C.c_uint32), ("n_bins", C.c_uint32), ("reserved", C.c_uint32),
+                ("t0", C.c_double), ("dt", C.c_double)]
+
+
 class RtsStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("segments", C.c_uint64), ("shaded", C.c_uint64), ("received", C.c_uint64),
                 ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64), ("n_prims", C.c_uint32), ("n_nodes", C.c_uint32),
@@ -89,7 +94,7 @@ EXPORTS = ["rts_create", "rts_destroy", "rts_last_error", "rts_device_count", "r
            "rts_finalise_uniform", "rts_aggregate", "rts_group_count", "rts_get_groups", "rts_get_aggregated",
            "rts_merge_groups", "rts_groups_to_responses", "rts_kernel_wrapper", "rts_vertex_rotation",
            "rts_rotation_matrix", "rts_rect_mesh", "rts_sphere_mesh", "rts_file_mesh", "rts_rx_sphere", "rts_get_bvh",
-           "rts_self_test_math"]
+           "rts_self_test_math", "rts_cube_attach", "rts_cube_accumulate", "rts_cube_get"]
 
 
 def lib():
@@ -128,6 +133,9 @@ def lib():
         "rts_file_mesh": [C.c_char_p, C.c_char_p, C.c_float, C.c_float, C.c_float, vp, vp, vp, C.POINTER(u32)],
         "rts_rx_sphere": [vp, dbl, dbl, dbl, dbl, dbl, C.POINTER(RtsReceiverSphere)],
         "rts_get_bvh": [vp, vp, vp, u32, u32],
+        "rts_cube_attach": [vp, C.POINTER(RtsCubeParams), vp],
+        "rts_cube_accumulate": [vp, u32, dbl, dbl],
+        "rts_cube_get": [vp, vp, u64],
         "rts_self_test_math": [vp, vp, vp, vp, vp, vp, vp, vp, u32],
     }
     for name, args in sig.items():

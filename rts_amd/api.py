@@ -190,6 +190,20 @@ class Tracer:
         check(L.lib().rts_get_aggregated(self.h, ptr(rays), ptr(delay), ptr(phase), ptr(pm), R))
         return dict(results=rays, delay=delay, phase=phase, pathMatch=pm)
 
+    def cube_attach(self, n_rx, n_pulses, n_bins, t0, dt, device_ptr=None):
+        """complex return cube [n_rx][n_pulses][n_bins]; device_ptr = data_ptr() of a zeroed complex128 device tensor, or None"""
+        q = L.RtsCubeParams(n_rx, n_pulses, n_bins, 0, t0, dt)
+        check(L.lib().rts_cube_attach(self.h, C.byref(q), C.c_void_p(device_ptr) if device_ptr else None))
+        self._cube_shape = (n_rx, n_pulses, n_bins)
+
+    def cube_accumulate(self, pulse_index, cspeed, carrier):
+        check(L.lib().rts_cube_accumulate(self.h, pulse_index, cspeed, carrier))
+
+    def cube(self):
+        out = np.zeros(self._cube_shape + (2,), np.float64)
+        check(L.lib().rts_cube_get(self.h, ptr(out), out.size))
+        return out[..., 0] + 1j * out[..., 1]
+
     def bvh(self):
         s = self.stats()
         nodes = np.zeros((max(s["n_nodes"], 1), 16), np.float32); leaf = np.zeros(max(s["n_prims"], 1), np.uint32)

@@ -83,7 +83,7 @@ extern "C" int rts_destroy(RtsHandle c)
     c->d_rx_angles.release(); c->d_rx_slots.release(); c->d_all_rays.release(); c->d_all_paths.release(); c->d_all_angles.release();
     c->d_akeys.release(); c->d_akeys_sorted.release(); c->d_aidx.release(); c->d_aidx_sorted.release(); c->d_ghead.release(); c->d_gid.release();
     c->d_gsum.release(); c->d_gmin.release(); c->d_gkey.release(); c->d_gcount.release(); c->d_delay.release(); c->d_phase.release();
-    c->d_pathmatch.release(); c->d_rcs.release(); c->d_rcsval.release();
+    c->d_pathmatch.release(); c->d_rcs.release(); c->d_rcsval.release(); c->d_cube_own.release();
     if (c->pin) (void)hipHostFree(c->pin);
     for (int i = 0; i < 8; i++) (void)hipEventDestroy(c->ev[i]);
     (void)hipStreamDestroy(c->stream);
@@ -427,6 +427,39 @@ extern "C" int rts_get_aggregated(RtsHandle c, PerRayData* rays, double* delay, 
     if (delay) RTS_HIP(hipMemcpy(delay, c->d_delay.p, sizeof(double)*R, hipMemcpyDeviceToHost));
     if (phase) RTS_HIP(hipMemcpy(phase, c->d_phase.p, sizeof(double)*R, hipMemcpyDeviceToHost));
     if (path_match) RTS_HIP(hipMemcpy(path_match, c->d_pathmatch.p, sizeof(int32_t)*R, hipMemcpyDeviceToHost));
+    return RTS_OK;
+}
+
+// ------------------------------------------------------------------------------------- complex return cube
+extern "C" int rts_cube_attach(RtsHandle c, const RtsCubeParams* p, void* device_ptr)
+{
+    CHECK_HANDLE(c);
+    if (!p || p->n_rx == 0 || p->n_pulses == 0 || p->n_bins == 0 || !(p->dt > 0) || !std::isfinite(p->t0)) { rts_set_error("rts_cube_attach: bad parameters"); return RTS_ERR_INVALID; }
+    const size_t doubles = 2 * (size_t)p->n_rx * p->n_pulses * p->n_bins;
+    RTS_HIP(hipStreamSynchronize(c->stream));
+    c->cube_params = *p;
+    if (device_ptr) c->cube = (double*)device_ptr;          // caller-owned (and caller-zeroed) device memory
+    else { RTS_HIP(c->d_cube_own.reserve(doubles)); c->cube = c->d_cube_own.p; RTS_HIP(hipMemset(c->cube, 0, sizeof(double) * doubles)); }
+    c->cube_set = true;
+    return RTS_OK;
+}
+
+extern "C" int rts_cube_accumulate(RtsHandle c, uint32_t pulse_index, double cspeed, double carrier)
+{
+    CHECK_HANDLE(c);
+    if (!c->cube_set) { rts_set_error("rts_cube_accumulate: call rts_cube_attach first"); return RTS_ERR_INVALID; }
+    if (pulse_index >= c->cube_params.n_pulses) { rts_set_error("rts_cube_accumulate: pulse %u >= %u", pulse_index, c->cube_params.n_pulses); return RTS_ERR_INVALID; }
+    return rts_cube_accumulate_device(c, pulse_index, cspeed, carrier);
+}
+
+extern "C" int rts_cube_get(RtsHandle c, double* host_out, uint64_t capacity_doubles)
+{
+    CHECK_HANDLE(c);
+    if (!c->cube_set || !host_out) { rts_set_error("rts_cube_get: no cube / null output"); return RTS_ERR_INVALID; }
+    const size_t doubles = 2 * (size_t)c->cube_params.n_rx * c->cube_params.n_pulses * c->cube_params.n_bins;
+    if (capacity_doubles < doubles) { rts_set_error("rts_cube_get: capacity too small"); return RTS_ERR_CAPACITY; }
+    RTS_HIP(hipStreamSynchronize(c->stream));
+    RTS_HIP(hipMemcpy(host_out, c->cube, sizeof(double) * doubles, hipMemcpyDeviceToHost));
     return RTS_OK;
 }
 

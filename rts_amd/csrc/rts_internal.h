@@ -178,6 +178,7 @@ struct RtsContext {
     DevBuf<double> d_gsum; DevBuf<uint32_t> d_gmin; DevBuf<uint64_t> d_gkey; DevBuf<uint32_t> d_gcount;
     DevBuf<double> d_delay, d_phase; DevBuf<int32_t> d_pathmatch; DevBuf<double> d_rcs;
     std::vector<RtsGroup> groups; bool agg_valid = false; uint64_t recv_index_base = 0;
+    RtsCubeParams cube_params; double* cube = nullptr; DevBuf<double> d_cube_own; bool cube_set = false;
     RtsPinned* pin = nullptr; DevBuf<double> d_rcsval; int n_cu = 0; bool stats_pending = false; bool agg_timed = false, fin_timed = false;
     RtsStats stats;
 };
@@ -187,6 +188,7 @@ int rts_bvh_build(RtsContext* c);
 int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a, bool count_traversal);
 int rts_post_order_and_expand(RtsContext* c);
 int rts_post_expand_all(RtsContext* c);
+int rts_cube_accumulate_device(RtsContext* c, uint32_t pulse_index, double cspeed, double carrier);
 int rts_post_finalise(RtsContext* c, const double* rcs_host, double wl, double gt, double gr, double carrier, double cspeed);
 int rts_aggregate_device(RtsContext* c, int32_t max_path, int32_t max_rx, const int32_t* d_paths, uint64_t R, uint32_t D,
                          double cspeed, double carrier, uint64_t base, PerRayData* d_rays, double* d_delay,

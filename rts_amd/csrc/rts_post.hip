@@ -180,6 +180,35 @@ int rts_post_finalise(RtsContext* c, const double* rcs_host, double wl, double g
     return RTS_OK;
 }
 
+// --------------------------------------------------------------------------- complex return cube
+// one lane per received ray, two f64 atomics (global_atomic_add_f64) into cube[rx][pulse][bin]
+__global__ void k_cube_accumulate(const PerRayData* __restrict__ rays, uint32_t R, double* __restrict__ cube, uint32_t n_rx, uint32_t n_pulses,
+                                  uint32_t n_bins, uint32_t pulse, double t0, double dt, double cspeed, double carrier)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    const PerRayData r = rays[i];
+    if (r.received < 0 || (uint32_t)r.received >= n_rx) return;
+    const double delay = (r.rayLength)/cspeed;                               // aggregation.cu:59
+    const double phase = -fmod(delay*2*RTS_PI*carrier, 2*RTS_PI);            // aggregation.cu:60
+    const double b = floor((delay - t0) / dt);
+    if (!(b >= 0.0) || !(b < (double)n_bins)) return;
+    const double amp = sqrt(r.power);
+    double sn, cs; sincos(phase, &sn, &cs);
+    double* cell = cube + 2 * (((size_t)r.received * n_pulses + pulse) * n_bins + (size_t)b);
+    atomicAdd(cell, amp * cs); atomicAdd(cell + 1, amp * sn);
+}
+
+int rts_cube_accumulate_device(RtsContext* c, uint32_t pulse_index, double cspeed, double carrier)
+{
+    const uint32_t R = (uint32_t)c->n_recv;
+    if (R == 0) return RTS_OK;
+    const RtsCubeParams& q = c->cube_params;
+    k_cube_accumulate<<<blocks_for(R, 256), 256, 0, c->stream>>>(c->d_rx_rays.p, R, c->cube, q.n_rx, q.n_pulses, q.n_bins, pulse_index, q.t0, q.dt, cspeed, carrier);
+    RTS_HIP(hipGetLastError());
+    return RTS_OK;
+}
+
 // --------------------------------------------------------------------------- aggregation (group-by)
 // key = rx << (D*B) | sum_k (path[k] + 1) << (k*B): equal keys <=> same receiver and identical
 // path row, which is the row_equal test of myKernel1 (aggregation.cu:46-53).

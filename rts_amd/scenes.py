@@ -154,6 +154,35 @@ def config_multi(W=16, rx_radius=90.0, max_refl=4, smooth=True):
                 tx=dict(origin=(-200.0, 0.0, 0.0), span=(0.16, 0.12, 0.05), dir=(0.0, 0.0)), rx=rx, carrier=FC, c=C0)
 
 
+def config4(W=465, detail=2.5, rx_radius=80.0, n_rx=8, n_tx=2):
+    """C4: four aircraft-like meshes of 250 000 triangles each (1 M triangles), 50 m apart, bistatic 2 Tx / 8 Rx,
+    W = 465 (100 544 625 launch indices per pulse), 8 bounces.  Returns the spec for transmitter `tx_index`
+    via spec["tx_list"]; spec["tx"] is transmitter 0."""
+    v, t, n = aircraft_mesh(detail=detail)
+    meshes, motion = [], []
+    offs = [(-25.0, -25.0, 0.0), (25.0, -25.0, 5.0), (-25.0, 25.0, -5.0), (25.0, 25.0, 0.0)]
+    for i, o in enumerate(offs):
+        R = api.rotation_matrix(math.radians(70.0 - 25.0 * i), math.radians(5.0 * i), math.radians(35.0 - 10.0 * i)).reshape(3, 3)
+        meshes.append(dict(tris=t, verts=v @ R.T, normals=n @ R.T, refl_coeff=0.9 - 0.05 * i, refr_index=1.0))
+        motion.append(dict(position=o, velocity=(150.0 + 20.0 * i, 10.0 * i, 0.0)))
+    rx = []
+    for k in range(n_rx):
+        ang = math.radians(-70.0 + 140.0 * k / max(n_rx - 1, 1))
+        rx.append(_rx_at((-1500.0 * math.cos(ang), 1500.0 * math.sin(ang), 50.0 * (k % 3)), (0, 0, 0), rx_radius, math.pi / 2))
+    txs = [dict(origin=(-1500.0, -200.0, 0.0), span=(0.07, 0.07, 0.1), dir=(math.atan2(200.0, 1500.0), 0.0)),
+           dict(origin=(-1400.0, 600.0, 100.0), span=(0.07, 0.07, 0.1), dir=(math.atan2(-600.0, 1400.0), math.atan2(-100.0, math.hypot(1400.0, 600.0))))][:n_tx]
+    return dict(name="C4-4aircraft-%dtri" % (4 * t.shape[0]), W=W, max_refl=8, smooth=True, n_pulses=512, meshes=meshes, motion=motion,
+                tx=txs[0], tx_list=txs, rx=rx, carrier=FC, c=C0)
+
+
+def config5(W=216, detail=1.0, rx_radius=50.0):
+    """C5: the C3 airframe with a per-pulse rigid transform (v = 200 m/s along +y, 1 rad/s yaw), 1024-pulse CPI"""
+    s = config3(W=W, detail=detail, rx_radius=rx_radius, n_rx=1)
+    s["name"] = s["name"].replace("C3", "C5-moving"); s["n_pulses"] = 1024
+    s["motion_fn"] = config5_motion
+    return s
+
+
 def config5_motion(pulse, speed=200.0, yaw_rate=1.0, prf=1000.0):
     """C5: per-pulse rigid transform of the C3 mesh (v = 200 m/s along +y, 1 rad/s yaw)."""
     tt = pulse / prf

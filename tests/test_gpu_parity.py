@@ -387,3 +387,51 @@ def test_adapter_end_to_end(rts, oracle, tmp_path):
     np.testing.assert_allclose(got[:, 3], want[:, 3], rtol=1e-12)                   # delay
     np.testing.assert_allclose(got[:, 4], want[:, 4], rtol=1e-9, atol=1e-6)         # doppler [Hz]
     np.testing.assert_allclose(got[:, 5], want[:, 5], rtol=1e-9, atol=1e-9)         # phase
+
+
+def test_c4_c5_shapes(rts, oracle, scenes):
+    """BASELINE configs[3] and [4] at reduced size: four targets / two transmitters / eight receivers / 8 bounces,
+    and the per-pulse rotating + translating target (LBVH rebuilt every pulse)"""
+    spec = scenes.config4(W=40, detail=0.1, rx_radius=300.0)
+    for tx in spec["tx_list"]:
+        spec["tx"] = tx
+        tr, st, o, g = full_parity(rts, oracle, spec, bvh=True)
+        assert st["n_prims"] == sum(m["tris"].shape[0] for m in spec["meshes"]) and st["received"] > 0
+        tr.close()
+    spec = scenes.config5(W=36, detail=0.1, rx_radius=300.0)
+    tr = H.gpu_tracer(rts, spec, keep_all=True)
+    n = spec["W"] ** 3
+    for k in (0, 5, 400):
+        mo = spec["motion_fn"](k)
+        _, st = H.gpu_trace(rts, spec, tr=tr, motion=mo)
+        assert st["bvh_rebuilt"] == 1
+        H.compare_full(H.oracle_trace(oracle, spec, motion=mo, use_bvh=True, threads=4), tr.all_rays(n), n)
+    tr.close()
+
+
+def test_return_cube(rts, scenes):
+    """complex return cube (north-star product, not in the reference): device accumulation of sqrt(P) e^{j phi} into
+    [rx][pulse][range bin] vs a numpy accumulation of the same received, finalised rays"""
+    spec = scenes.config_multi(W=20)
+    tr = H.gpu_tracer(rts, spec)
+    wl = spec["c"] / spec["carrier"]
+    n_bins, t0, dt = 64, 1.2e-6, 5.0e-9
+    tr.cube_attach(len(spec["rx"]), 3, n_bins, t0, dt)
+    want = np.zeros((len(spec["rx"]), 3, n_bins), np.complex128)
+    total = 0
+    for k in range(3):
+        mo = [dict(position=tuple(np.add(m["position"], (0.5 * k, 0, 0))), velocity=m["velocity"]) for m in spec["motion"]]
+        H.gpu_trace(rts, spec, tr=tr, motion=mo)
+        tr.finalise_uniform(None, wl, 1.0, 1.0, spec["carrier"], spec["c"])
+        tr.cube_accumulate(k, spec["c"], spec["carrier"])
+        r = tr.received()["results"]
+        delay = r["rayLength"] / spec["c"]
+        phase = -np.fmod(delay * 2 * math.pi * spec["carrier"], 2 * math.pi)
+        b = np.floor((delay - t0) / dt)
+        ok = (b >= 0) & (b < n_bins)
+        np.add.at(want, (r["received"][ok], k, b[ok].astype(int)), np.sqrt(r["power"][ok]) * np.exp(1j * phase[ok]))
+        total += int(ok.sum())
+    got = tr.cube()
+    assert total > 20 and np.count_nonzero(want) > 3
+    np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-22)
+    tr.close()

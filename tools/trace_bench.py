@@ -16,7 +16,8 @@ which = sys.argv[1] if len(sys.argv) > 1 else "c3"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 spec = {"c2": lambda: scenes.config2(rx_radius=200.0), "c3": lambda: scenes.config3(rx_radius=50.0),
         "c3s": lambda: scenes.config3(W=100, rx_radius=50.0), "c3nomesh": lambda: scenes.config3(rx_radius=50.0),
-        "c3norx": lambda: scenes.config3(rx_radius=50.0), "c3narrow": lambda: scenes.config3(rx_radius=50.0)}[which]()
+        "c3norx": lambda: scenes.config3(rx_radius=50.0), "c3narrow": lambda: scenes.config3(rx_radius=50.0),
+        "c4s": lambda: scenes.config4(W=232), "c4": lambda: scenes.config4(), "c5": lambda: scenes.config5()}[which]()
 if which == "c3nomesh":
     spec["meshes"] = []
 if which == "c3norx":
@@ -27,9 +28,14 @@ tr = api.Tracer(spec["W"], spec["max_refl"], 0, spec["smooth"])
 tr.set_scene(spec["meshes"]); tr.set_receivers(spec["rx"])
 tx = spec["tx"]
 ms = []
+shard = int(os.environ.get("RTS_SHARD", "1"))                     # trace 1/shard of the launch indices (C4: one GPU's share of 8)
+count = spec["W"] ** 3 // shard
 for k in range(reps + 1):
-    mo = [dict(position=(0.2 * k, 0.02 * k, 0.0), velocity=(200.0, 20.0, 0.0)) for _ in spec["meshes"]]
-    st = tr.trace(tx["origin"], tx["span"], tx["dir"], mo)
+    if "motion_fn" in spec:
+        mo = spec["motion_fn"](k)
+    else:
+        mo = [dict(position=tuple(np.add(m["position"], (0.2 * k, 0.02 * k, 0.0))), velocity=m["velocity"]) for m in spec["motion"]]
+    st = tr.trace(tx["origin"], tx["span"], tx["dir"], mo, ray_first=0, ray_count=count)
     if k:
         ms.append((st["ms_scene"], st["ms_trace"], st["ms_compact"]))
 rec = tr.received()
