@@ -188,6 +188,12 @@ def main():
         seg_per_launch = seg / launches                                    # rank 0's launches
         ms_launch = ms_trace / launches
         achieved = bytes_per_seg * seg_per_launch / (ms_launch * 1e-3) / 1e9 if ms_launch > 0 else 0.0
+        # HBM traffic cannot be read live (PMC needs rocprofv3 passes of their own): taken from the committed profile of
+        # THIS workload (profiles/r01_pmc_k_trace.json), null for any other configuration
+        traffic = None; traffic_src = None
+        pj = os.path.join(ROOT, "profiles", "r01_pmc_k_trace.json")
+        if args.config == "c3" and W == 216 and world == 1 and os.path.exists(pj):
+            traffic = json.load(open(pj))["hbm_bytes_per_launch"]; traffic_src = "profiles/r01_pmc_k_trace.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
         out = {
             "metric": "Mrays/s (primary+bounces) & ms/pulse, 100k-tri scene",
             "value": seg_all / dt / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -199,7 +205,7 @@ def main():
                        "primary_Mrays_per_s": total * args.steps / dt / 1e6, "return_cube": "complex128 [%d rx][%d pulses][%d bins], all-reduced once per interval" % (cube.shape[0], args.steps, n_bins), "sharding": "contiguous (pulse, launch index) ranges of the %d-pulse interval x%d ranks, one group-table all-gather per interval" % (args.steps, world),
                        "stage_ms_per_launch_rank0": {"scene+lbvh": ms_scene / launches, "trace": ms_launch, "order+finalise+aggregate": ms_post / launches}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_trace", "bytes_per_segment": bytes_per_seg,
+                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": bytes_per_seg * seg_per_launch, "kernel": "k_trace", "bytes_per_segment": bytes_per_seg,
                          "nodes_per_segment": V, "tri_tests_per_segment": T, "shaded_per_segment": Hh,
                          "kernel_ms_avg": ms_launch, "segments_per_launch": seg_per_launch},
         }
