@@ -435,3 +435,65 @@ def test_return_cube(rts, scenes):
     assert total > 20 and np.count_nonzero(want) > 3
     np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-22)
     tr.close()
+
+
+def test_deep_tree_spills_stack(rts, oracle, scenes):
+    """plates stacked at geometrically shrinking offsets give a Morton tree ~60 levels deep; rays that pierce all
+    of their boxes overflow the 24-entry LDS traversal stack into the global spill slab -- results must not change"""
+    K = 56
+    vs, ts, ns = [], [], []
+    for k in range(K):
+        x = 100.0 * (0.6 ** k)                                     # centres 100, 60, 36, ... -> one Morton split per plate
+        s = 50.0 + k                                               # all plates cover the beam axis
+        v = np.array([[x, -s, -s], [x, s, -s], [x, s, s], [x, -s, -s], [x, s, s], [x, -s, s]], np.float64)
+        vs.append(v); ts.append(np.array([[0, 1, 2], [3, 4, 5]], np.uint32) + 6 * k); ns.append(np.tile(np.array([[-1.0, 0.0, 0.0]]), (6, 1)))
+    mesh = dict(tris=np.concatenate(ts), verts=np.concatenate(vs), normals=np.concatenate(ns), refl_coeff=0.9, refr_index=1.0)
+    spec = scenes.config1()
+    spec.update(W=10, max_refl=3, meshes=[mesh], motion=[dict(position=(0.0, 0.0, 0.0), velocity=(0.0, 0.0, 0.0))])
+    spec["tx"] = dict(origin=(-1000.0, 3.0, 2.0), span=(0.02, 0.02, 0.1), dir=(0.0, 0.0))
+    tr, st, o, g = full_parity(rts, oracle, spec)
+    assert st["shaded"] > 0
+    assert st["stack_overflows"] > 0, "this scene is meant to exercise the spill path"
+    tr.close()
+
+
+def test_file_mesh_on_device(rts, oracle, scenes, tmp_path):
+    """"file" targets (ray_tracer.cpp:429-504): unshared vertices, per-vertex normals from a second file, rotated"""
+    rng = np.random.default_rng(3)
+    sv, st_, sn = oracle.sphere_mesh(2, 6.0)
+    tri_v = sv[st_].reshape(-1, 9); tri_n = sn[st_].reshape(-1, 9)
+    vf, nf = tmp_path / "v.txt", tmp_path / "n.txt"
+    for f, a in ((vf, tri_v), (nf, tri_n)):
+        with open(f, "w") as fh:
+            for row in a:
+                fh.write("%.17g %.17g %.17g, %.17g %.17g %.17g, %.17g %.17g %.17g,\\n" % tuple(row))
+    v, t, n = rts.file_mesh(str(vf), str(nf), 0.3, -0.2, 0.1)
+    spec = scenes.config_multi(W=14)
+    spec["meshes"][0] = dict(tris=t, verts=v, normals=n, refl_coeff=0.9, refr_index=1.0)
+    full_parity(rts, oracle, spec)[0].close()
+
+
+def test_api_errors(rts, scenes):
+    from rts_amd import _lib
+    with pytest.raises(_lib.RtsError) as e:
+        rts.Tracer(2000, 1)                                       # W^3 must fit 32 bits (rayIndex is unsigned int, ray_tracer.cu:151)
+    assert e.value.code == _lib.RTS_ERR_INVALID
+    with pytest.raises(_lib.RtsError) as e:
+        rts.Tracer(4, 17)                                         # depth limit of the packed path keys
+    assert e.value.code == _lib.RTS_ERR_UNSUPPORTED
+    with pytest.raises(_lib.RtsError):
+        rts.Tracer(4, 1, device=99)
+    spec = scenes.config1()
+    tr = H.gpu_tracer(rts, spec)
+    bad = dict(spec["meshes"][0]); bad["tris"] = np.array([[0, 1, 99]], np.uint32)
+    with pytest.raises(_lib.RtsError) as e:
+        tr.set_scene([bad])                                       # vertex index out of range is rejected on the host, never reaches a kernel
+    assert e.value.code == _lib.RTS_ERR_INVALID
+    rx = dict(spec["rx"][0]); rx["minTheta"] = float("nan")
+    with pytest.raises(_lib.RtsError):
+        tr.set_receivers([rx])
+    with pytest.raises(_lib.RtsError):
+        tr.all_rays(10)                                           # handle was not created with RTS_FLAG_KEEP_ALL_RAYS
+    with pytest.raises(_lib.RtsError):
+        tr.aggregated()                                           # nothing aggregated yet
+    tr.close()
