@@ -16,8 +16,8 @@ responses.  A "ray" in Mrays/s is one traced segment (one rtTrace of the referen
 bounce).
 
 Scaling is strong: the K timed pulses form one coherent processing interval whose K * W^3
-(pulse, launch index) pairs are split into N contiguous ranges (rts_amd/multigpu.py: a rank owns
-whole pulses plus at most two partial ones; K = 1 is plain ray sharding).  The per-(receiver,
+(pulse, launch index) pairs are dealt to the N ranks (rts_amd/multigpu.py: whole pulses first; each of the K % N
+left-over pulses is shared by a group of ranks in interleaved 4096-index tiles; K = 1 is plain ray sharding).  The per-(receiver,
 path) group tables of all pulse parts are exchanged ONCE, at the end of the timed region and inside
 it, by an all-gather over RCCL, and merged into the per-pulse responses on every rank.
 """
@@ -130,13 +130,13 @@ def main():
         """pulses k0 .. k0+n_pulses-1 as one coherent processing interval, sharded over the ranks"""
         parts = []; acc = dict(segments=0, shaded=0, received=0, ms_scene=0.0, ms_trace=0.0, ms_post=0.0, launches=0)
         cube.zero_(); torch.cuda.synchronize()
-        for (k, first, count) in multigpu.plan_cpi(total, n_pulses, rank, world):
-            tr.trace(tx["origin"], tx["span"], tx["dir"], pulse_motion(spec, k0 + k), ray_first=first, ray_count=count, want_stats=False)
+        for (k, first, count, il) in multigpu.plan_cpi(total, n_pulses, rank, world):
+            tr.trace(tx["origin"], tx["span"], tx["dir"], pulse_motion(spec, k0 + k), ray_first=first, ray_count=count, want_stats=False, interleave=il)
             tr.finalise_uniform(None, wl, 1.0, 1.0, spec["carrier"], spec["c"])
             tr.cube_accumulate(k, spec["c"], spec["carrier"])
-            groups = tr.aggregate(spec["c"], spec["carrier"], 0)
+            groups = tr.aggregate(spec["c"], spec["carrier"], rts_amd._lib.RTS_BASE_USE_ROWS)
             st = tr.stats()                                   # stream already drained by the aggregation's table fetch
-            parts.append(dict(pulse=k, ray_first=first, n_recv=st["received"], groups=groups))
+            parts.append(dict(pulse=k, groups=groups))
             acc["segments"] += st["segments"]; acc["shaded"] += st["shaded"]; acc["received"] += st["received"]
             acc["ms_scene"] += st["ms_scene"]; acc["ms_trace"] += st["ms_trace"]; acc["ms_post"] += st["ms_compact"] + st["ms_aggregate"]
             acc["launches"] += 1
@@ -202,7 +202,7 @@ def main():
             "config": {"workload": "BASELINE.json configs[2]: %s, 1 Tx / %d Rx, W=%d (%d launch indices/pulse), maxRefl=%d, target moves every pulse (LBVH rebuilt per pulse)"
                                    % (spec["name"], len(spec["rx"]), W, total, spec["max_refl"]),
                        "rays_per_pulse": total, "segments_per_pulse": seg_all / args.steps, "received_per_pulse": received_all / args.steps,
-                       "primary_Mrays_per_s": total * args.steps / dt / 1e6, "return_cube": "complex128 [%d rx][%d pulses][%d bins], all-reduced once per interval" % (cube.shape[0], args.steps, n_bins), "sharding": "contiguous (pulse, launch index) ranges of the %d-pulse interval x%d ranks, one group-table all-gather per interval" % (args.steps, world),
+                       "primary_Mrays_per_s": total * args.steps / dt / 1e6, "return_cube": "complex128 [%d rx][%d pulses][%d bins], all-reduced once per interval" % (cube.shape[0], args.steps, n_bins), "sharding": "%d-pulse interval over %d ranks: whole pulses, left-over pulses in interleaved 4096-index tiles; one group-table all-gather + one cube all-reduce per interval" % (args.steps, world),
                        "stage_ms_per_launch_rank0": {"scene+lbvh": ms_scene / launches, "trace": ms_launch, "order+finalise+aggregate": ms_post / launches}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": bytes_per_seg * seg_per_launch, "kernel": "k_trace", "bytes_per_segment": bytes_per_seg,

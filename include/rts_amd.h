@@ -100,6 +100,11 @@ typedef struct RtsPulse {
     uint64_t ray_first;
     uint64_t ray_count;
     const RtsTargetMotion* motion; /* [n_targets]; NULL = keep the previous placement    */
+    /* Interleaved sharding inside [ray_first, ray_first + ray_count): the range is cut into tiles of
+     * interleave_tile launch indices and this launch traces tiles part, part + parts, part + 2 parts, ...
+     * (parts <= 1: the whole range).  Rays that hit cluster in launch-index space, so ranks that share one
+     * pulse balance far better with interleaved tiles than with contiguous sub-ranges. */
+    uint32_t interleave_tile, interleave_parts, interleave_part, reserved;
 } RtsPulse;
 
 /* Per-pulse counters and stage timings (the reference prints four wall-clock timers,
@@ -181,8 +186,11 @@ int rts_finalise_uniform(RtsHandle h, const double* rcs_per_target, double wavel
 
 /* rts_aggregate: myKernel1 + myKernel2 + unique paths (aggregation.cu:32-97,
  * ray_tracer.cpp:1283-1292) on the device-resident received set, as a sort/group-by.
- * recv_index_base offsets the received-list indices (multi-GPU: number of received rays on
- * lower ranks). */
+ * recv_index_base offsets the received-list indices (multi-GPU with contiguous ranges: number of received
+ * rays on lower ranks).  RTS_BASE_USE_ROWS makes RtsGroup.min_ray the GLOBAL BUFFER ROW (launch index + k W^3)
+ * of the group's first ray instead: rows order rays exactly as received-list indices do, and they are comparable
+ * across ranks whatever the sharding (interleaved tiles). */
+#define RTS_BASE_USE_ROWS 0xffffffffffffffffULL
 int rts_aggregate(RtsHandle h, double cspeed, double carrier, uint64_t recv_index_base);
 int rts_group_count(RtsHandle h, uint32_t* count);
 int rts_get_groups(RtsHandle h, RtsGroup* groups, uint32_t capacity);

@@ -18,6 +18,7 @@ RTS_OK, RTS_ERR_INVALID, RTS_ERR_NO_DEVICE, RTS_ERR_HIP, RTS_ERR_UNSUPPORTED, RT
 RTS_FLAG_KEEP_ALL_RAYS = 1
 RTS_FLAG_COUNT_TRAVERSAL = 2
 RTS_MAX_DEPTH = 16
+RTS_BASE_USE_ROWS = 0xffffffffffffffff
 
 # PerRayData (include/rts_prd.h == reference ray_tracer.h:13-28)
 PRD_DTYPE = np.dtype({
@@ -52,7 +53,8 @@ class RtsReceiverSphere(C.Structure):
 
 class RtsPulse(C.Structure):
     _fields_ = [("ray_origin", C.c_double * 3), ("tx_span", C.c_double * 3), ("tx_dir", C.c_double * 2),
-                ("ray_first", C.c_uint64), ("ray_count", C.c_uint64), ("motion", C.POINTER(RtsTargetMotion))]
+                ("ray_first", C.c_uint64), ("ray_count", C.c_uint64), ("motion", C.POINTER(RtsTargetMotion)),
+                ("interleave_tile", C.c_uint32), ("interleave_parts", C.c_uint32), ("interleave_part", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class RtsCubeParams(C.Structure):

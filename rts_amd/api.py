@@ -128,11 +128,13 @@ class Tracer:
                                          s["minPhi"], s["maxPhi"])
         check(L.lib().rts_set_receivers(self.h, arr, len(spheres)))
 
-    def trace(self, origin, tx_span, tx_dir, motion=None, ray_first=0, ray_count=0, want_stats=True):
+    def trace(self, origin, tx_span, tx_dir, motion=None, ray_first=0, ray_count=0, want_stats=True, interleave=None):
         """motion: list of dict(position, velocity[, rotation(9)]) per target, or None to keep placement."""
         p = L.RtsPulse()
         p.ray_origin[:] = list(origin); p.tx_span[:] = list(tx_span); p.tx_dir[:] = list(tx_dir)
         p.ray_first = ray_first; p.ray_count = ray_count
+        if interleave is not None:                                   # (tile, parts, part)
+            p.interleave_tile, p.interleave_parts, p.interleave_part = interleave
         if motion is not None:
             assert len(motion) == self.n_targets
             marr = (L.RtsTargetMotion * max(len(motion), 1))()

@@ -82,7 +82,7 @@ extern "C" int rts_destroy(RtsHandle c)
     c->d_rk.release(); c->d_rk_sorted.release(); c->d_ri.release(); c->d_ri_sorted.release(); c->d_rx_rays.release(); c->d_rx_paths.release();
     c->d_rx_angles.release(); c->d_rx_slots.release(); c->d_all_rays.release(); c->d_all_paths.release(); c->d_all_angles.release();
     c->d_akeys.release(); c->d_akeys_sorted.release(); c->d_aidx.release(); c->d_aidx_sorted.release(); c->d_ghead.release(); c->d_gid.release();
-    c->d_gsum.release(); c->d_gmin.release(); c->d_gkey.release(); c->d_gcount.release(); c->d_delay.release(); c->d_phase.release();
+    c->d_gsum.release(); c->d_gmin.release(); c->d_gkey.release(); c->d_grow.release(); c->d_gcount.release(); c->d_delay.release(); c->d_phase.release();
     c->d_pathmatch.release(); c->d_rcs.release(); c->d_rcsval.release(); c->d_cube_own.release();
     if (c->pin) (void)hipHostFree(c->pin);
     for (int i = 0; i < 8; i++) (void)hipEventDestroy(c->ev[i]);
@@ -210,6 +210,11 @@ extern "C" int rts_trace_pulse(RtsHandle c, const RtsPulse* p)
     const uint32_t W = c->params.width;
     const uint64_t total = (uint64_t)W * W * W;
     uint64_t first = p->ray_first, count = p->ray_count ? p->ray_count : (total > first ? total - first : 0);
+    uint32_t il_tile = 0, il_parts = 0, il_part = 0;
+    if (p->interleave_parts > 1) {
+        il_tile = p->interleave_tile; il_parts = p->interleave_parts; il_part = p->interleave_part;
+        if (il_tile == 0 || il_part >= il_parts) { rts_set_error("rts_trace_pulse: bad interleave (tile %u, part %u of %u)", il_tile, il_part, il_parts); return RTS_ERR_INVALID; }
+    }
     if (first > total || count > total - first) { rts_set_error("rts_trace_pulse: ray range [%llu, +%llu) outside W^3 = %llu", (unsigned long long)first, (unsigned long long)count, (unsigned long long)total); return RTS_ERR_INVALID; }
     const uint32_t n_targets = (uint32_t)c->meshes.size();
     hipStream_t st = c->stream;
@@ -250,6 +255,11 @@ extern "C" int rts_trace_pulse(RtsHandle c, const RtsPulse* p)
     RTS_HIP(hipEventRecord(c->ev[1], st));
 
     // ---- per-pulse buffers
+    if (il_parts > 1) {      // number of launch indices of the range that fall into this part's tiles
+        const uint64_t stride = (uint64_t)il_tile * il_parts, full = count / stride, rem = count % stride;
+        const uint64_t lo = (uint64_t)il_part * il_tile;
+        count = full * il_tile + (rem > lo ? std::min<uint64_t>(rem - lo, il_tile) : 0);
+    }
     const uint32_t n = (uint32_t)count;
     c->ray_first = first; c->n_rays = n;
     const bool keep_all = (c->params.flags & RTS_FLAG_KEEP_ALL_RAYS) != 0;
@@ -259,7 +269,7 @@ extern "C" int rts_trace_pulse(RtsHandle c, const RtsPulse* p)
     RtsTraceArgs a; memset(&a, 0, sizeof(a));
     RtsLaunchConsts& lc = c->last_lc; memset(&lc, 0, sizeof(lc));
     fill_launch_constants(lc, *p, W);
-    lc.ray_first = first; lc.W = W;
+    lc.ray_first = first; lc.W = W; lc.il_tile = il_tile; lc.il_parts = il_parts; lc.il_part = il_part;
     RTS_HIP(c->d_lc.reserve(1));
     c->pin->lc = lc;
     RTS_HIP(hipMemcpyAsync(c->d_lc.p, &c->pin->lc, sizeof(lc), hipMemcpyHostToDevice, st));
@@ -390,8 +400,9 @@ extern "C" int rts_aggregate(RtsHandle c, double cspeed, double carrier, uint64_
     RTS_HIP(hipMemsetAsync(c->d_delay.p, 0, sizeof(double)*R, c->stream));
     RTS_HIP(hipMemsetAsync(c->d_phase.p, 0, sizeof(double)*R, c->stream));
     const int32_t max_path = (int32_t)c->meshes.size() - 1, max_rx = c->n_rx ? (int32_t)c->n_rx - 1 : 0;
-    int rc = rts_aggregate_device(c, max_path, max_rx, c->d_rx_paths.p, R, c->depth, cspeed, carrier, recv_index_base, c->d_rx_rays.p,
-                                  c->d_delay.p, c->d_phase.p, c->d_pathmatch.p, &c->groups, nullptr, nullptr, nullptr, INT32_MAX);
+    const bool use_rows = recv_index_base == RTS_BASE_USE_ROWS;
+    int rc = rts_aggregate_device(c, max_path, max_rx, c->d_rx_paths.p, R, c->depth, cspeed, carrier, use_rows ? 0 : recv_index_base, c->d_rx_rays.p,
+                                  c->d_delay.p, c->d_phase.p, c->d_pathmatch.p, &c->groups, nullptr, nullptr, nullptr, INT32_MAX, use_rows ? c->d_rx_slots.p : nullptr);
     if (rc != RTS_OK) return rc;
     RTS_HIP(hipEventRecord(c->ev[7], c->stream));
     c->agg_timed = true; c->stats_pending = true;
@@ -564,7 +575,7 @@ extern "C" int rts_kernel_wrapper(PerRayData* h_rx_results_arr, int* h_rx_inters
     for (size_t i = 0; i < R * D; i++) { if (h_rx_intersects_arr[i] < -1) { rts_set_error("rts_kernel_wrapper: path entry < -1"); return RTS_ERR_INVALID; } max_path = std::max(max_path, (int32_t)h_rx_intersects_arr[i]); }
     for (size_t i = 0; i < R; i++) { if (h_rx_results_arr[i].received < 0) { rts_set_error("rts_kernel_wrapper: ray %zu is not a received ray", i); return RTS_ERR_INVALID; } max_rx = std::max(max_rx, h_rx_results_arr[i].received); }
     int rc = rts_aggregate_device(c, max_path, max_rx, c->d_rx_paths.p, R, (uint32_t)D, cspeed, carrier, 0, c->d_rx_rays.p, c->d_delay.p, c->d_phase.p,
-                                  c->d_pathmatch.p, nullptr, d_np, d_pw, d_dp, INT32_MIN /* use the caller's h_pathMatch */);
+                                  c->d_pathmatch.p, nullptr, d_np, d_pw, d_dp, INT32_MIN /* use the caller's h_pathMatch */, nullptr);
     if (rc != RTS_OK) return rc;
     // copy back what the reference copies back (aggregation.cu:169-172)
     RTS_HIP(hipMemcpyAsync(h_rx_results_arr, c->d_rx_rays.p, sizeof(PerRayData)*R, hipMemcpyDeviceToHost, st));

@@ -79,6 +79,7 @@ struct RtsLaunchConsts {
     double w1x, w1y, w1z;           // direction for W == 1
     uint64_t ray_first;
     uint32_t W, pad;
+    uint32_t il_tile, il_parts, il_part, pad2;     // interleaved tiles (il_parts <= 1: contiguous)
 };
 
 struct RtsTraceArgs {
@@ -125,7 +126,7 @@ struct RtsPinned {
     RtsTargetMotion motion[256];
     RtsTargetDev td[256];
     double rcs[256];
-    double gsum[5 * RTS_PIN_GROUPS]; uint64_t gkey[RTS_PIN_GROUPS]; uint32_t gmin[RTS_PIN_GROUPS];
+    double gsum[5 * RTS_PIN_GROUPS]; uint64_t gkey[RTS_PIN_GROUPS]; uint64_t grow[RTS_PIN_GROUPS]; uint32_t gmin[RTS_PIN_GROUPS];
 };
 
 template <typename T> struct DevBuf {
@@ -175,7 +176,7 @@ struct RtsContext {
     DevBuf<PerRayData> d_all_rays; DevBuf<int32_t> d_all_paths; DevBuf<double> d_all_angles;
     // aggregation
     DevBuf<uint64_t> d_akeys, d_akeys_sorted; DevBuf<uint32_t> d_aidx, d_aidx_sorted; DevBuf<uint32_t> d_ghead, d_gid;
-    DevBuf<double> d_gsum; DevBuf<uint32_t> d_gmin; DevBuf<uint64_t> d_gkey; DevBuf<uint32_t> d_gcount;
+    DevBuf<double> d_gsum; DevBuf<uint32_t> d_gmin; DevBuf<uint64_t> d_gkey; DevBuf<uint32_t> d_gcount; DevBuf<uint64_t> d_grow;
     DevBuf<double> d_delay, d_phase; DevBuf<int32_t> d_pathmatch; DevBuf<double> d_rcs;
     std::vector<RtsGroup> groups; bool agg_valid = false; uint64_t recv_index_base = 0;
     RtsCubeParams cube_params; double* cube = nullptr; DevBuf<double> d_cube_own; bool cube_set = false;
@@ -193,7 +194,7 @@ int rts_post_finalise(RtsContext* c, const double* rcs_host, double wl, double g
 int rts_aggregate_device(RtsContext* c, int32_t max_path, int32_t max_rx, const int32_t* d_paths, uint64_t R, uint32_t D,
                          double cspeed, double carrier, uint64_t base, PerRayData* d_rays, double* d_delay,
                          double* d_phase, int32_t* d_pm, std::vector<RtsGroup>* groups, double* d_npath,
-                         double* d_power_sum, double* d_doppler_sum, int32_t pm_init);
+                         double* d_power_sum, double* d_doppler_sum, int32_t pm_init, const uint64_t* d_rows);
 void rts_set_error(const char* fmt, ...);
 // RTS_DEBUG_SYNC=1: synchronise after every stage and name it on stderr, so that a device
 // fault is attributed to the kernel that caused it

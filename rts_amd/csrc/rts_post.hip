@@ -70,7 +70,7 @@ __global__ void k_expand(const RtsTraceArgs a, const RtsEndRecord* __restrict__ 
         o.power = r.power; o.doppler = r.doppler; o.received = r.received;
     }
     rays[j] = o;
-    if (slots) slots[j] = a.ray_first + slot + (uint64_t)chain * ((uint64_t)a.W * a.W * a.W);
+    if (slots) slots[j] = rts_global_index(*a.lc, slot) + (uint64_t)chain * ((uint64_t)a.W * a.W * a.W);
     // path row: dbuf_targ_intersect[row][col], -1 default (ray_tracer.cpp:854-857, normal_shader.cu:140-146, 221-239)
     for (uint32_t col = 0; col < D; col++) {
         int code = 0;
@@ -310,7 +310,8 @@ __global__ void __launch_bounds__(64) k_agg_span(const uint32_t* __restrict__ gs
 }
 
 __global__ void k_agg_groupinfo(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ idx_sorted, const uint64_t* __restrict__ keys_sorted,
-                                const uint32_t* __restrict__ gid_incl, uint32_t R, uint32_t* __restrict__ gmin, uint64_t* __restrict__ gkey, uint32_t* __restrict__ g_out)
+                                const uint32_t* __restrict__ gid_incl, uint32_t R, uint32_t* __restrict__ gmin, uint64_t* __restrict__ gkey, uint32_t* __restrict__ g_out,
+                                const uint64_t* __restrict__ rows, uint64_t* __restrict__ grow)
 {
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t G = gid_incl[R - 1];
@@ -318,6 +319,7 @@ __global__ void k_agg_groupinfo(const uint32_t* __restrict__ gstart, const uint3
     if (g >= G) return;
     gmin[g] = idx_sorted[gstart[g]];          // stable sort: first element of the run has the smallest ray index
     gkey[g] = keys_sorted[gstart[g]];
+    if (rows) grow[g] = rows[gmin[g]];        // its global buffer row (order-isomorphic to the received index, comparable across ranks)
 }
 
 // Per-receiver totals for the direct-ray rule (aggregation.cu:56): groups are sorted by key with the
@@ -382,7 +384,7 @@ __global__ void k_agg_scatter(PerRayData* __restrict__ rays, const uint32_t* __r
 int rts_aggregate_device(RtsContext* c, int32_t max_path, int32_t max_rx, const int32_t* d_paths, uint64_t R64, uint32_t D,
                          double cspeed, double carrier, uint64_t base, PerRayData* d_rays, double* d_delay,
                          double* d_phase, int32_t* d_pm, std::vector<RtsGroup>* groups, double* d_npath,
-                         double* d_power_sum, double* d_doppler_sum, int32_t pm_init)
+                         double* d_power_sum, double* d_doppler_sum, int32_t pm_init, const uint64_t* d_rows)
 {
     if (groups) groups->clear();
     if (R64 == 0) return RTS_OK;
@@ -402,7 +404,7 @@ int rts_aggregate_device(RtsContext* c, int32_t max_path, int32_t max_rx, const 
     RTS_HIP(c->d_akeys.reserve(R)); RTS_HIP(c->d_akeys_sorted.reserve(R)); RTS_HIP(c->d_aidx.reserve(R)); RTS_HIP(c->d_aidx_sorted.reserve(R));
     RTS_HIP(c->d_ghead.reserve(R)); RTS_HIP(c->d_gid.reserve(R));
     RTS_HIP(c->d_gcount.reserve((size_t)R + 4)); RTS_HIP(c->d_gsum.reserve(5*((size_t)R + 2*(size_t)ntiles) + 16));
-    RTS_HIP(c->d_gmin.reserve(R)); RTS_HIP(c->d_gkey.reserve(R));
+    RTS_HIP(c->d_gmin.reserve(R)); RTS_HIP(c->d_gkey.reserve(R)); if (d_rows) RTS_HIP(c->d_grow.reserve(R));
     RTS_HIP(c->d_rcs.reserve(5*(size_t)n_rx_tab + n_rx_tab + 8));
     uint32_t* gstart = c->d_gcount.p;                 // [<= R + 1]
     uint32_t* d_G = c->d_gcount.p + (size_t)R + 2;    // group count, device resident
@@ -420,7 +422,7 @@ int rts_aggregate_device(RtsContext* c, int32_t max_path, int32_t max_rx, const 
     k_agg_starts<<<blocks_for(R, 256), 256, 0, st>>>(c->d_ghead.p, c->d_gid.p, gstart, R);
     k_agg_tiles<<<ntiles, AGG_TILE, 0, st>>>(d_rays, c->d_aidx_sorted.p, c->d_gid.p, gstart, R, cspeed, carrier, gsum, tile_first, tile_last);
     k_agg_span<<<ntiles, 64, 0, st>>>(gstart, c->d_gid.p, R, tile_first, tile_last, gsum);
-    k_agg_groupinfo<<<blocks_for(R, 256), 256, 0, st>>>(gstart, c->d_aidx_sorted.p, c->d_akeys_sorted.p, c->d_gid.p, R, c->d_gmin.p, c->d_gkey.p, d_G);
+    k_agg_groupinfo<<<blocks_for(R, 256), 256, 0, st>>>(gstart, c->d_aidx_sorted.p, c->d_akeys_sorted.p, c->d_gid.p, R, c->d_gmin.p, c->d_gkey.p, d_G, d_rows, d_rows ? c->d_grow.p : nullptr);
     k_agg_rxtot<<<n_rx_tab, 64, 0, st>>>(c->d_gkey.p, gsum, c->d_gmin.p, d_G, shift, d_rxtot, d_rxmin);
     k_agg_scatter<<<blocks_for(R, 256), 256, 0, st>>>(d_rays, c->d_aidx_sorted.p, c->d_gid.p, gsum, c->d_gmin.p, d_rxtot, d_rxmin, n_rx_tab, R,
                                                        (int64_t)base, d_npath, d_power_sum, d_doppler_sum, d_delay, d_phase, d_pm, pm_init, pm_init == INT32_MIN ? 1 : 0);
@@ -433,11 +435,14 @@ int rts_aggregate_device(RtsContext* c, int32_t max_path, int32_t max_rx, const 
     RTS_HIP(hipMemcpyAsync(pin->gsum, gsum, sizeof(double)*5*spec, hipMemcpyDeviceToHost, st));
     RTS_HIP(hipMemcpyAsync(pin->gmin, c->d_gmin.p, sizeof(uint32_t)*spec, hipMemcpyDeviceToHost, st));
     RTS_HIP(hipMemcpyAsync(pin->gkey, c->d_gkey.p, sizeof(uint64_t)*spec, hipMemcpyDeviceToHost, st));
+    if (d_rows) RTS_HIP(hipMemcpyAsync(pin->grow, c->d_grow.p, sizeof(uint64_t)*spec, hipMemcpyDeviceToHost, st));
     RTS_HIP(hipStreamSynchronize(st));
     const uint32_t G = pin->G;
     const double* h_gsum = pin->gsum; const uint32_t* h_gmin = pin->gmin; const uint64_t* h_gkey = pin->gkey;
+    const uint64_t* h_grow = pin->grow; std::vector<uint64_t> v_grow;
     std::vector<double> v_gsum; std::vector<uint32_t> v_gmin; std::vector<uint64_t> v_gkey;
     if (G > spec) {
+        if (d_rows) { v_grow.resize(G); RTS_HIP(hipMemcpy(v_grow.data(), c->d_grow.p, sizeof(uint64_t)*G, hipMemcpyDeviceToHost)); h_grow = v_grow.data(); }
         v_gsum.resize(5*(size_t)G); v_gmin.resize(G); v_gkey.resize(G);
         RTS_HIP(hipMemcpy(v_gsum.data(), gsum, sizeof(double)*5*G, hipMemcpyDeviceToHost));
         RTS_HIP(hipMemcpy(v_gmin.data(), c->d_gmin.p, sizeof(uint32_t)*G, hipMemcpyDeviceToHost));
@@ -456,7 +461,7 @@ int rts_aggregate_device(RtsContext* c, int32_t max_path, int32_t max_rx, const 
             gr.path[k] = v; if (v >= 0) all_neg = false;
         }
         gr.direct = all_neg ? 1u : 0u;
-        gr.min_ray = base + h_gmin[g];
+        gr.min_ray = d_rows ? h_grow[g] : base + h_gmin[g];
         gr.n = h_gsum[5*(size_t)g]; gr.sum_sqrt_power = h_gsum[5*(size_t)g + 1]; gr.sum_delay = h_gsum[5*(size_t)g + 2];
         gr.sum_phase = h_gsum[5*(size_t)g + 3]; gr.sum_doppler = h_gsum[5*(size_t)g + 4];
     }

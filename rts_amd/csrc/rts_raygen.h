@@ -5,10 +5,18 @@
 #pragma once
 #include "rts_internal.h"
 
+// global launch index of local slot `slot` (contiguous range, or interleaved tiles of the range)
+__device__ __forceinline__ uint64_t rts_global_index(const RtsLaunchConsts& a, uint32_t slot)
+{
+    if (a.il_parts <= 1) return a.ray_first + slot;
+    const uint32_t j = slot / a.il_tile, r = slot - j * a.il_tile;
+    return a.ray_first + ((uint64_t)j * a.il_parts + a.il_part) * a.il_tile + r;
+}
+
 __device__ __forceinline__ dvec3 rts_primary_dir(const RtsLaunchConsts& a, uint32_t slot)
 {
     if (a.W == 1) return mk3(a.w1x, a.w1y, a.w1z);                       // ray_tracer.cu:160-161
-    const uint64_t g = a.ray_first + slot;                                // rayIndex = z*W*W + y*W + x  :151
+    const uint64_t g = rts_global_index(a, slot);                         // rayIndex = z*W*W + y*W + x  :151
     const uint32_t lx = (uint32_t)(g % a.W), ly = (uint32_t)((g / a.W) % a.W), lz = (uint32_t)(g / ((uint64_t)a.W * a.W));
     dvec3 v = mk3(a.bsx + a.stx * (double)lx, a.bsy + a.sty * (double)ly, a.bsz + a.stz * (double)lz);   // :167-169
     v = unit3(v);                                                         // :170

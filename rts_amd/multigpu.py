@@ -70,30 +70,43 @@ def aggregate_sharded(tracer, cspeed, carrier, dist, torch):
 
 
 # ------------------------------------------------------------------------------- CPI-level (pulse x ray) sharding
-# A coherent processing interval is K independent pulses (ray_tracer.cpp:843) of W^3 launch indices
-# each.  The K * W^3 (pulse, launch index) pairs are split into N contiguous ranges: a rank owns
-# whole pulses plus at most two partial ones at the ends of its range.  Compared with splitting every
-# pulse N ways this keeps the load balanced for any K, rebuilds the LBVH only for the pulses a
-# rank touches, and needs ONE exchange per CPI (the group tables of all pulse parts) instead of one
-# per pulse -- the tables are a few hundred bytes, so the exchange is latency bound and batching it
-# is what matters on xGMI.  K = 1 degenerates to plain ray sharding of one pulse.
+# A coherent processing interval is K independent pulses (ray_tracer.cpp:843) of W^3 launch indices each.
+# Whole pulses are dealt out first (K // N per rank: no replicated LBVH build, no imbalance); each of the K % N
+# left-over pulses is shared by a group of consecutive ranks that split its launch indices into INTERLEAVED
+# tiles (rays that hit cluster in launch-index space, so contiguous sub-ranges would leave most of the group
+# idle).  K = 1 is plain interleaved ray sharding of one pulse over all ranks.  The per-(receiver, path) group
+# tables of all parts are exchanged ONCE per interval -- they are a few hundred bytes, so the exchange is
+# latency bound and batching it is what matters on xGMI.
+IL_TILE = 4096
+
+
 def plan_cpi(total_rays, n_pulses, rank, world):
-    """[(pulse, ray_first, ray_count)] owned by `rank`"""
-    lo = total_rays * n_pulses * rank // world
-    hi = total_rays * n_pulses * (rank + 1) // world
-    out = []
-    k = lo // total_rays
-    while lo < hi:
-        end = min(hi, (k + 1) * total_rays)
-        out.append((k, lo - k * total_rays, end - lo))
-        lo = end; k += 1
+    """[(pulse, ray_first, ray_count, interleave)] owned by `rank`; interleave = None or (tile, parts, part)"""
+    base = n_pulses // world
+    out = [(rank * base + i, 0, total_rays, None) for i in range(base)]
+    left = n_pulses - base * world
+    if left:
+        i = rank * left // world                                   # the left-over pulse this rank helps with
+        group = [r for r in range(world) if r * left // world == i]
+        il = (IL_TILE, len(group), group.index(rank)) if len(group) > 1 else None
+        out.append((base * world + i, 0, total_rays, il))
     return out
 
 
+def part_ray_count(total_rays, interleave):
+    if interleave is None:
+        return total_rays
+    tile, parts, part = interleave
+    stride = tile * parts
+    full, rem = divmod(total_rays, stride)
+    return full * tile + max(0, min(rem - part * tile, tile))
+
+
 def exchange_parts(parts, dist, torch):
-    """parts: [dict(pulse, ray_first, n_recv, groups)] of this rank -> the same list for ALL ranks.
+    """parts: [dict(pulse, groups)] of this rank -> the same list for ALL ranks.  Group tables must be keyed by
+    global buffer rows (rts_aggregate(..., RTS_BASE_USE_ROWS)) so that they merge with a plain min.
     One all-gather of sizes + one all-gather of payload (meta int64 rows followed by the group records)."""
-    meta = np.array([[p["pulse"], p["ray_first"], p["n_recv"], len(p["groups"])] for p in parts], np.int64).reshape(-1, 4)
+    meta = np.array([[p["pulse"], len(p["groups"])] for p in parts], np.int64).reshape(-1, 2)
     groups = np.concatenate([np.ascontiguousarray(p["groups"], GROUP_DTYPE) for p in parts]) if parts else np.zeros(0, GROUP_DTYPE)
     payload = np.concatenate([meta.view(np.uint8).reshape(-1), groups.view(np.uint8).reshape(-1)])
     if dist is None:
@@ -104,7 +117,7 @@ def exchange_parts(parts, dist, torch):
         szs = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
         dist.all_gather(szs, sz)
         sizes = [(int(x[0]), int(x[1])) for x in szs]
-        cap = max(max(m * 32 + g * GROUP_DTYPE.itemsize for m, g in sizes), 8)
+        cap = max(max(m * 16 + g * GROUP_DTYPE.itemsize for m, g in sizes), 8)
         buf = np.zeros(cap, np.uint8); buf[:len(payload)] = payload
         mine = torch.from_numpy(buf).to(dev)
         outs = [torch.empty_like(mine) for _ in range(world)]
@@ -112,29 +125,23 @@ def exchange_parts(parts, dist, torch):
         blobs = [o.cpu().numpy() for o in outs]
     allp = []
     for blob, (m, g) in zip(blobs, sizes):
-        mt = blob[:m * 32].view(np.int64).reshape(m, 4)
-        gr = blob[m * 32:m * 32 + g * GROUP_DTYPE.itemsize].view(GROUP_DTYPE)
+        mt = blob[:m * 16].view(np.int64).reshape(m, 2)
+        gr = blob[m * 16:m * 16 + g * GROUP_DTYPE.itemsize].view(GROUP_DTYPE)
         off = 0
         for row in mt:
-            allp.append(dict(pulse=int(row[0]), ray_first=int(row[1]), n_recv=int(row[2]), groups=gr[off:off + int(row[3])].copy()))
-            off += int(row[3])
+            allp.append(dict(pulse=int(row[0]), groups=gr[off:off + int(row[1])].copy()))
+            off += int(row[1])
     return allp
 
 
 def merge_cpi(all_parts, depth):
-    """all parts of all ranks -> {pulse: (responses, merged groups)}.  Received-list indices are made
-    global per pulse: parts in ascending ray_first, each offset by the received counts before it."""
+    """all parts of all ranks -> {pulse: (responses, merged groups)}; response.ray = global buffer row of the
+    representative ray (same order as the reference's received-list index)"""
     by_pulse = {}
     for p in all_parts:
-        by_pulse.setdefault(p["pulse"], []).append(p)
+        by_pulse.setdefault(p["pulse"], []).append(p["groups"])
     out = {}
-    for k, ps in by_pulse.items():
-        ps.sort(key=lambda p: p["ray_first"])
-        base = 0; tabs = []
-        for p in ps:
-            g = p["groups"].copy()
-            g["min_ray"] += base
-            tabs.append(g); base += p["n_recv"]
+    for k, tabs in by_pulse.items():
         allg = np.concatenate(tabs) if tabs else np.zeros(0, GROUP_DTYPE)
         out[k] = merge_and_respond(allg, depth)
     return out

@@ -33,7 +33,7 @@ def gpu_trace(api, spec, tr=None, motion=None, **kw):
     if own:
         tr = gpu_tracer(api, spec, keep_all=True)
     tx = spec["tx"]
-    st = tr.trace(tx["origin"], tx["span"], tx["dir"], motion if motion is not None else spec["motion"], **kw)
+    st = tr.trace(tx["origin"], tx["span"], tx["dir"], motion if motion is not None else spec["motion"], **kw)   # kw: ray_first, ray_count, interleave
     return tr, st
 
 

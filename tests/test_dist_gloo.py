@@ -73,6 +73,14 @@ def test_two_rank_sharded_pulse(tmp_path, world, oracle):
         assert int(x["merged"]["n"].sum()) == len(rx)
 
 
+def _tile_indices(total, interleave):
+    if interleave is None:
+        return np.arange(total, dtype=np.int64)
+    tile, parts, part = interleave
+    idx = np.arange(total, dtype=np.int64)
+    return idx[(idx // tile) % parts == part]
+
+
 def _cpi_worker(rank, world, port, out_dir, n_pulses):
     sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -81,25 +89,31 @@ def _cpi_worker(rank, world, port, out_dir, n_pulses):
     from rts_amd import scenes, multigpu
     import helpers as H
     from test_host_logic import numpy_group_table
+    multigpu.IL_TILE = 64                                       # small tiles so that the 1728-index test pulse really interleaves
     spec = scenes.config_multi(W=12)
     total = spec["W"] ** 3
     wl = spec["c"] / spec["carrier"]
     parts = []
-    for (k, first, count) in multigpu.plan_cpi(total, n_pulses, rank, world):
+    for (k, first, count, il) in multigpu.plan_cpi(total, n_pulses, rank, world):
         mo = [dict(position=tuple(np.add(m["position"], (0.3 * k, 0.0, 0.1 * k))), velocity=m["velocity"]) for m in spec["motion"]]
-        o = H.oracle_trace(O, spec, motion=mo, ray_first=first, ray_stride=1, n_rays=count)
-        rx, rxi, slots = O.filter_finalise(o["results"], o["path"], [1.0] * 3, wl, 1.0, 1.0, spec["carrier"], spec["c"])
-        parts.append(dict(pulse=k, ray_first=first, n_recv=len(rx), groups=numpy_group_table(rx, rxi, spec["c"], spec["carrier"], base=0)))
+        o = H.oracle_trace(O, spec, motion=mo)                  # whole pulse, then keep this part's launch indices (stand-in for the device)
+        mine = _tile_indices(total, il)
+        assert len(mine) == multigpu.part_ray_count(total, il)
+        rx, rxi, slots = O.filter_finalise(o["results"][mine], o["path"][mine], [1.0] * 3, wl, 1.0, 1.0, spec["carrier"], spec["c"])
+        g = numpy_group_table(rx, rxi, spec["c"], spec["carrier"], base=0)
+        rows = mine[slots.astype(np.int64)]                     # global buffer rows of this part's received rays
+        g["min_ray"] = rows[g["min_ray"].astype(np.int64)]      # row-keyed, as rts_aggregate(..., RTS_BASE_USE_ROWS) produces
+        parts.append(dict(pulse=k, groups=g))
     allp = multigpu.exchange_parts(parts, dist, torch)
     merged = multigpu.merge_cpi(allp, spec["max_refl"])
     np.savez(os.path.join(out_dir, "cpi_rank%d.npz" % rank), pulses=np.array(sorted(merged)), **{"resp%d" % k: merged[k][0] for k in merged})
     dist.barrier(); dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_pulses", [(2, 3), (3, 2), (2, 1)])
+@pytest.mark.parametrize("world,n_pulses", [(2, 3), (3, 2), (2, 1), (3, 4)])
 def test_cpi_sharding(tmp_path, world, n_pulses, oracle):
-    """pulse x ray sharding of a CPI: ranks own whole and partial pulses, ONE exchange, per-pulse responses
-    identical to the literal single-process pipeline (global received-list indices included)"""
+    """pulse x ray sharding of a CPI: whole pulses per rank, left-over pulses in interleaved tiles within rank groups,
+    ONE exchange; per-pulse responses identical to the literal single-process pipeline"""
     mp.spawn(_cpi_worker, args=(world, _free_port(), str(tmp_path), n_pulses), nprocs=world, join=True)
     sys.path.insert(0, HERE)
     from rts_amd import scenes
@@ -116,7 +130,7 @@ def test_cpi_sharding(tmp_path, world, n_pulses, oracle):
         for x in outs:
             assert list(x["pulses"]) == list(range(n_pulses))
             resp = x["resp%d" % k]
-            assert np.array_equal(resp["ray"].astype(np.int64), uniq.astype(np.int64))
+            assert np.array_equal(resp["ray"].astype(np.int64), slots[uniq].astype(np.int64))     # representative ray, as a buffer row
             np.testing.assert_allclose(resp["power"], lit["results"]["power"][uniq], rtol=1e-12)
             np.testing.assert_allclose(resp["delay"], lit["delay"][uniq], rtol=1e-12)
 
@@ -124,16 +138,19 @@ def test_cpi_sharding(tmp_path, world, n_pulses, oracle):
 def test_plan_cpi_covers_exactly():
     from rts_amd import multigpu
     for total in (1000, 216 ** 3):
-        for K, N in [(1, 8), (8, 8), (5, 3), (20, 8), (3, 1), (1, 1)]:
-            allp = [multigpu.plan_cpi(total, K, r, N) for r in range(N)]
-            cover = sorted(x for ps in allp for x in ps)
-            pos = 0
-            for k, f, c in cover:
-                assert k * total + f == pos and c > 0 and f + c <= total
-                pos += c
-            assert pos == total * K
-            loads = [sum(c for _, _, c in ps) for ps in allp]
-            assert max(loads) - min(loads) <= 1
+        for K, N in [(1, 8), (8, 8), (5, 3), (20, 8), (3, 1), (1, 1), (5, 8), (9, 4)]:
+            cover = {}
+            for r in range(N):
+                for (k, first, count, il) in multigpu.plan_cpi(total, K, r, N):
+                    assert first == 0 and count == total
+                    cover.setdefault(k, []).append(il)
+            assert sorted(cover) == list(range(K))
+            for k, ils in cover.items():
+                if ils == [None]:
+                    continue
+                parts = ils[0][1]
+                assert sorted(il[2] for il in ils) == list(range(parts)) and all(il[1] == parts for il in ils)
+                assert sum(multigpu.part_ray_count(total, il) for il in ils) == total
 
 
 def test_shard_ranges_cover_exactly():

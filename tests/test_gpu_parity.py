@@ -497,3 +497,41 @@ def test_api_errors(rts, scenes):
     with pytest.raises(_lib.RtsError):
         tr.aggregated()                                           # nothing aggregated yet
     tr.close()
+
+
+def test_interleaved_parts_equal_whole(rts, oracle, scenes):
+    """interleaved-tile sharding (RtsPulse.interleave_*): the parts' received sets, merged by buffer row, are the whole
+    launch; row-keyed group tables of the parts merge into the literal aggregation of the whole pulse"""
+    from rts_amd import _lib, multigpu
+    spec = scenes.config_multi(W=20)
+    n = spec["W"] ** 3
+    wl = spec["c"] / spec["carrier"]
+    tr = H.gpu_tracer(rts, spec)
+    H.gpu_trace(rts, spec, tr=tr)
+    whole = tr.received()
+    tr.finalise_uniform(None, wl, 1.0, 1.0, spec["carrier"], spec["c"])
+    g_whole = tr.aggregate(spec["c"], spec["carrier"], _lib.RTS_BASE_USE_ROWS)
+    for tile, parts in [(64, 3), (1000, 2), (4096, 5)]:
+        recs, tabs = [], []
+        for part in range(parts):
+            _, st = H.gpu_trace(rts, spec, tr=tr, interleave=(tile, parts, part))
+            assert st["rays"] == multigpu.part_ray_count(n, (tile, parts, part))
+            recs.append(tr.received())
+            tr.finalise_uniform(None, wl, 1.0, 1.0, spec["carrier"], spec["c"])
+            tabs.append(tr.aggregate(spec["c"], spec["carrier"], _lib.RTS_BASE_USE_ROWS))
+        slots = np.concatenate([r["slots"] for r in recs]); order = np.argsort(slots, kind="stable")
+        assert np.array_equal(slots[order], whole["slots"])
+        H.assert_prd_equal(np.concatenate([r["results"] for r in recs])[order], whole["results"], "interleaved parts")
+        assert np.array_equal(np.concatenate([r["path"] for r in recs])[order], whole["path"])
+        merged = rts.merge_groups(np.concatenate(tabs), spec["max_refl"])
+        assert np.array_equal(merged["min_ray"], g_whole["min_ray"]) and np.array_equal(merged["n"], g_whole["n"])
+        np.testing.assert_allclose(merged["sum_sqrt_power"], g_whole["sum_sqrt_power"], rtol=1e-12)
+    # row-keyed responses vs the oracle: the representative is the same ray, named by its buffer row
+    o = H.oracle_trace(oracle, spec)
+    rx, rxi, oslots = oracle.filter_finalise(o["results"], o["path"], [1.0] * 3, wl, 1.0, 1.0, spec["carrier"], spec["c"])
+    lit = oracle.aggregate_literal(rx, rxi, spec["c"], spec["carrier"], n)
+    uniq = oracle.unique_paths(lit["pathMatch"])
+    resp = rts.groups_to_responses(g_whole)
+    assert np.array_equal(resp["ray"].astype(np.int64), oslots[uniq].astype(np.int64))
+    np.testing.assert_allclose(resp["power"], lit["results"]["power"][uniq], rtol=1e-11)
+    tr.close()
