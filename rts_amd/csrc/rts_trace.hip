@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(RTS_BLOCK) k_trace(const RtsTraceArgs a)
                         }
                     }
                 }
-                if (end == false) {                                                            // Earth sphere :438-476
+                if (end == false && rayLength > 0) {                                           // Earth sphere :438-476 (both roots require rayLength > 0, :464)
                     const double d_earthRadius = 6378136;
                     const double A = (dir.x)*(dir.x) + (dir.y)*(dir.y) + (dir.z)*(dir.z);
                     const double B = 2*(prev.x*dir.x + prev.y*dir.y + prev.z*dir.z);
