@@ -64,6 +64,7 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     hipDeviceProp_t prop; e = hipGetDeviceProperties(&prop, p->device);
     if (e != hipSuccess) { delete c; rts_set_error("hipGetDeviceProperties: %s", hipGetErrorString(e)); return RTS_ERR_HIP; }
     c->n_cu = prop.multiProcessorCount;
+    { const char* e = getenv("RTS_PT"); if (e) c->pt_mode = (e[0] != '0'); }      // RTS_PT=1: persistent-wave kernel with lane refill (A/B)
     *out = c;
     return RTS_OK;
 }
@@ -299,7 +300,8 @@ extern "C" int rts_trace_pulse(RtsHandle c, const RtsPulse* p)
     // ---- trace
     RTS_HIP(hipEventRecord(c->ev[2], st));
     RTS_STAGE(c, "pre-trace");
-    int rc = rts_trace_launch(c, a, count_trav); if (rc != RTS_OK) return rc;
+    int rc = (c->pt_mode && !keep_all && a.max_refr == 0) ? rts_trace_launch_pt(c, a, count_trav) : rts_trace_launch(c, a, count_trav);
+    if (rc != RTS_OK) return rc;
     RTS_STAGE(c, "k_trace");
     RTS_HIP(hipEventRecord(c->ev[3], st));
     unsigned long long* cnt = c->pin->cnt;

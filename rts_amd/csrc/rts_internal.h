@@ -167,7 +167,7 @@ struct RtsContext {
     uint64_t ray_first = 0; uint32_t n_rays = 0;
     DevBuf<RtsEndRecord> d_recv, d_all; DevBuf<unsigned long long> d_counters; DevBuf<float> d_dir_hist;
     DevBuf<int32_t> d_hit_prim; DevBuf<float> d_hit_t; DevBuf<int32_t> d_stack_ovf; DevBuf<RtsChildState> d_child;
-    DevBuf<uint64_t> d_rk64, d_rk64_sorted;
+    DevBuf<uint64_t> d_rk64, d_rk64_sorted; int pt_mode = 0;
     RtsTraceArgs last_args; RtsLaunchConsts last_lc; DevBuf<RtsLaunchConsts> d_lc;
     // received set (ordered, expanded)
     uint64_t n_recv = 0;
@@ -187,6 +187,7 @@ struct RtsContext {
 // implemented in the .hip units
 int rts_bvh_build(RtsContext* c);
 int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a, bool count_traversal);
+int rts_trace_launch_pt(RtsContext* c, const RtsTraceArgs& a, bool count_traversal);
 int rts_post_order_and_expand(RtsContext* c);
 int rts_post_expand_all(RtsContext* c);
 int rts_cube_accumulate_device(RtsContext* c, uint32_t pulse_index, double cspeed, double carrier);

@@ -535,3 +535,19 @@ def test_interleaved_parts_equal_whole(rts, oracle, scenes):
     assert np.array_equal(resp["ray"].astype(np.int64), oslots[uniq].astype(np.int64))
     np.testing.assert_allclose(resp["power"], lit["results"]["power"][uniq], rtol=1e-11)
     tr.close()
+
+
+def test_persistent_wave_kernel_identical(rts, oracle, scenes, monkeypatch):
+    """RTS_PT=1 selects k_trace_pt (persistent waves, lane refill by ballot compaction): a different schedule of the same
+    per-ray arithmetic, so the received set must be bit-identical to the default kernel's and to the oracle's"""
+    spec = scenes.config3(W=40, detail=0.1, rx_radius=300.0)
+    tr0 = H.gpu_tracer(rts, spec); H.gpu_trace(rts, spec, tr=tr0); a = tr0.received(); s0 = tr0.stats(); tr0.close()
+    monkeypatch.setenv("RTS_PT", "1")
+    tr1 = H.gpu_tracer(rts, spec); H.gpu_trace(rts, spec, tr=tr1); b = tr1.received(); s1 = tr1.stats(); tr1.close()
+    assert s0["segments"] == s1["segments"] and s0["shaded"] == s1["shaded"] and s0["received"] == s1["received"] > 0
+    H.assert_prd_equal(a["results"], b["results"], "persistent-wave kernel")
+    assert np.array_equal(a["slots"], b["slots"]) and np.array_equal(a["path"], b["path"])
+    np.testing.assert_array_equal(a["rcs_angle"], b["rcs_angle"])
+    o = H.oracle_trace(oracle, spec, use_bvh=True, threads=4, debug=False)
+    idx = np.nonzero(o["results"]["received"] >= 0)[0]
+    H.assert_prd_equal(o["results"][idx], b["results"], "persistent-wave kernel vs oracle")
