@@ -184,7 +184,10 @@ def main():
         sc = trc.trace(tx["origin"], tx["span"], tx["dir"], pulse_motion(spec, args.warmup))
         trc.close()
         V = sc["node_visits"] / max(sc["segments"], 1); T = sc["tri_tests"] / max(sc["segments"], 1); Hh = sc["shaded"] / max(sc["segments"], 1)
-        bytes_per_seg = 288.0 + 64.0 * V + 72.0 * T + 96.0 * Hh           # SURVEY.md section 8(d), figure (B)
+        # SURVEY.md section 8(d), figure (B), with this build's record sizes: 288 B of ray state per segment, 128 B per
+        # BVH4 node visit (SURVEY assumed 64-B BVH2 nodes; V is counted in BVH4 nodes), 80 B per triangle test (leaf record),
+        # 96 B per shaded hit (3 normals + velocity)
+        bytes_per_seg = 288.0 + 128.0 * V + 80.0 * T + 96.0 * Hh
         seg_per_launch = seg / launches                                    # rank 0's launches
         ms_launch = ms_trace / launches
         achieved = bytes_per_seg * seg_per_launch / (ms_launch * 1e-3) / 1e9 if ms_launch > 0 else 0.0

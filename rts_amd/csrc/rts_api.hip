@@ -78,7 +78,7 @@ extern "C" int rts_destroy(RtsHandle c)
     c->d_verts_local.release(); c->d_normals_local.release(); c->d_verts_world.release(); c->d_normals_world.release();
     c->d_motion.release(); c->d_targets.release(); c->d_prim_box.release(); c->d_node_box.release(); c->d_keys.release(); c->d_keys_sorted.release();
     c->d_vals.release(); c->d_vals_sorted.release(); c->d_bounds.release(); c->d_parent.release(); c->d_leaf_parent.release(); c->d_flags.release();
-    c->d_nodes.release(); c->d_leaves.release(); c->d_sort_tmp.release(); c->d_rx.release(); c->d_recv.release(); c->d_all.release();
+    c->d_nodes.release(); c->d_nodes4.release(); c->d_leaves.release(); c->d_sort_tmp.release(); c->d_rx.release(); c->d_recv.release(); c->d_all.release();
     c->d_counters.release(); c->d_lc.release(); c->d_dir_hist.release(); c->d_child.release(); c->d_rk64.release(); c->d_rk64_sorted.release(); c->d_hit_prim.release(); c->d_hit_t.release(); c->d_stack_ovf.release();
     c->d_rk.release(); c->d_rk_sorted.release(); c->d_ri.release(); c->d_ri_sorted.release(); c->d_rx_rays.release(); c->d_rx_paths.release();
     c->d_rx_angles.release(); c->d_rx_slots.release(); c->d_all_rays.release(); c->d_all_paths.release(); c->d_all_angles.release();
@@ -291,7 +291,7 @@ extern "C" int rts_trace_pulse(RtsHandle c, const RtsPulse* p)
         RTS_HIP(hipMemsetAsync(c->d_hit_t.p, 0, sizeof(float) * (size_t)n * (c->params.max_refl + 1), st));
     }
     RTS_HIP(hipMemsetAsync(c->d_counters.p, 0, sizeof(unsigned long long) * 16, st));
-    a.nodes = c->d_nodes.p; a.leaves = c->d_leaves.p; a.tri_nidx = c->d_tri_nidx.p; a.normals = c->d_normals_world.p;
+    a.nodes = c->d_nodes.p; a.nodes4 = c->d_nodes4.p; a.leaves = c->d_leaves.p; a.tri_nidx = c->d_tri_nidx.p; a.normals = c->d_normals_world.p;
     a.targets = c->d_targets.p; a.rx = c->d_rx.p;
     a.recv_records = c->d_recv.p; a.all_records = c->d_all.p; a.counters = c->d_counters.p; a.dir_hist = c->d_dir_hist.p;
     a.hit_prim = c->d_hit_prim.p; a.hit_t = c->d_hit_t.p; a.stack_ovf = c->d_stack_ovf.p; a.child = c->d_child.p;

@@ -254,6 +254,31 @@ __global__ void __launch_bounds__(RF_THREADS) k_refit(const float* __restrict__ 
     }
 }
 
+// BVH2 -> BVH4 collapse: record i holds, for BVH2 node i, the children of its internal children (boxes taken from
+// the children's own records) and its leaf children as they are.  Only the records reachable from the root through
+// these links are ever visited; the others cost nothing but their 128 bytes.
+__global__ void k_collapse4(const RtsNode* __restrict__ nodes, RtsNode4* __restrict__ nodes4, int n_nodes)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const RtsNode nd = nodes[i];
+    RtsNode4 o;
+    for (int k = 0; k < 4; k++) { o.lox[k] = o.loy[k] = o.loz[k] = 3.0e38f; o.hix[k] = o.hiy[k] = o.hiz[k] = -3.0e38f; o.child[k] = 0x7fffffff; o.pad[k] = 0; }
+    int m = 0;
+    auto put = [&](int c, float lx, float ly, float lz, float hx, float hy, float hz) {
+        o.lox[m] = lx; o.loy[m] = ly; o.loz[m] = lz; o.hix[m] = hx; o.hiy[m] = hy; o.hiz[m] = hz; o.child[m] = c; m++;
+    };
+    auto expand = [&](int c, float lx, float ly, float lz, float hx, float hy, float hz) {
+        if (c < 0) { put(c, lx, ly, lz, hx, hy, hz); return; }
+        const RtsNode ch = nodes[c];
+        put(ch.c0, ch.lo0x, ch.lo0y, ch.lo0z, ch.hi0x, ch.hi0y, ch.hi0z);
+        put(ch.c1, ch.lo1x, ch.lo1y, ch.lo1z, ch.hi1x, ch.hi1y, ch.hi1z);
+    };
+    expand(nd.c0, nd.lo0x, nd.lo0y, nd.lo0z, nd.hi0x, nd.hi0y, nd.hi0z);
+    if (!(nd.lo1x > nd.hi1x && nd.c1 == nd.c0)) expand(nd.c1, nd.lo1x, nd.lo1y, nd.lo1z, nd.hi1x, nd.hi1y, nd.hi1z);   // (single-leaf scene: second slot is a dummy)
+    nodes4[i] = o;
+}
+
 // a scene with a single primitive: one node whose second child is an empty box
 __global__ void k_single_leaf(const float* __restrict__ prim_box, RtsNode* nodes)
 {
@@ -278,7 +303,7 @@ int rts_bvh_build(RtsContext* c)
     RTS_HIP(c->d_prim_box.reserve(6*(size_t)n)); RTS_HIP(c->d_node_box.reserve(6*(size_t)n));
     RTS_HIP(c->d_keys.reserve(n)); RTS_HIP(c->d_keys_sorted.reserve(n)); RTS_HIP(c->d_vals.reserve(n)); RTS_HIP(c->d_vals_sorted.reserve(n));
     RTS_HIP(c->d_bounds.reserve(8)); RTS_HIP(c->d_parent.reserve(n)); RTS_HIP(c->d_leaf_parent.reserve(n)); RTS_HIP(c->d_flags.reserve(n));
-    RTS_HIP(c->d_nodes.reserve(n)); RTS_HIP(c->d_leaves.reserve(n));
+    RTS_HIP(c->d_nodes.reserve(n)); RTS_HIP(c->d_nodes4.reserve(n)); RTS_HIP(c->d_leaves.reserve(n));
     static const uint32_t init_bounds[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
     RTS_HIP(hipMemcpyAsync(c->d_bounds.p, init_bounds, sizeof(init_bounds), hipMemcpyHostToDevice, st));
     k_prim_boxes<<<blocks_for(n, 256), 256, 0, st>>>(c->d_tri_vidx.p, c->d_verts_world.p, c->d_prim_box.p, c->d_bounds.p, n);
@@ -297,6 +322,7 @@ int rts_bvh_build(RtsContext* c)
         k_refit<<<blocks_for(n, RF_CHUNK), RF_THREADS, 0, st>>>(c->d_prim_box.p, c->d_vals_sorted.p, c->d_nodes.p, c->d_parent.p, c->d_leaf_parent.p, (const int2*)c->d_node_box.p, c->d_flags.p, (int)n);
         c->n_nodes = n - 1;
     }
+    k_collapse4<<<blocks_for(c->n_nodes, 256), 256, 0, st>>>(c->d_nodes.p, c->d_nodes4.p, (int)c->n_nodes);
     RTS_HIP(hipGetLastError());
     return RTS_OK;
 }

@@ -19,6 +19,16 @@ struct __attribute__((aligned(64))) RtsNode {
 };
 static_assert(sizeof(RtsNode) == 64, "node size");
 
+// BVH4 node, 128 B, collapsed from the BVH2 (a node's children are its grandchildren, or a child itself when that
+// child is a leaf): half the dependent fetch round-trips per ray.  SoA over the four children so that one
+// dwordx4 load brings the same plane of all four boxes.  Unused slots: empty box (never hit).
+struct __attribute__((aligned(128))) RtsNode4 {
+    float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4];
+    int32_t child[4];               // >= 0 -> BVH2 node index (its RtsNode4 record), < 0 -> ~leaf index
+    int32_t pad[4];
+};
+static_assert(sizeof(RtsNode4) == 128, "node4 size");
+
 // Leaf record, 80 B, in Morton (leaf) order: the three f64 vertices the f64 intersection
 // test needs, pre-gathered (the reference gathers through dbuf_triangles ->
 // dbuf_triVertices per test, triangle_mesh.cu:147-154), plus the global primitive id.
@@ -92,6 +102,7 @@ struct RtsTraceArgs {
     RtsChildState* child;           // [2][grid threads] (refraction only)
     // scene
     const RtsNode* nodes;
+    const RtsNode4* nodes4;
     const RtsLeafTri* leaves;
     const uint32_t* tri_nidx;       // [n_prims][3] indices into normals
     const double* normals;          // world-space normals [.][3]
@@ -159,7 +170,7 @@ struct RtsContext {
     // BVH
     DevBuf<float> d_prim_box, d_node_box; DevBuf<uint64_t> d_keys, d_keys_sorted; DevBuf<uint32_t> d_vals, d_vals_sorted;
     DevBuf<uint32_t> d_bounds; DevBuf<int32_t> d_parent, d_leaf_parent; DevBuf<uint32_t> d_flags;
-    DevBuf<RtsNode> d_nodes; DevBuf<RtsLeafTri> d_leaves; DevBuf<char> d_sort_tmp;
+    DevBuf<RtsNode> d_nodes; DevBuf<RtsNode4> d_nodes4; DevBuf<RtsLeafTri> d_leaves; DevBuf<char> d_sort_tmp;
     uint32_t n_nodes = 0;
     // receivers
     DevBuf<RtsRxDev> d_rx; uint32_t n_rx = 0;

@@ -105,30 +105,37 @@ __global__ void __launch_bounds__(RTS_BLOCK) k_trace(const RtsTraceArgs a)
                 while (node != SENTINEL) {
                     if (++steps > (1u << 24)) { hard_overflow = true; break; }   // malformed tree guard: every wave must drain
                     if (node >= 0) {
-                        const float4* np = reinterpret_cast<const float4*>(a.nodes + node);
-                        const float4 q0 = np[0], q1 = np[1], q2 = np[2];
-                        const int4 q3 = reinterpret_cast<const int4*>(np)[3];
+                        // BVH4 node: six dwordx4 planes (lo/hi x,y,z of the four children) + the four child ids
+                        const float4* np = reinterpret_cast<const float4*>(a.nodes4 + node);
+                        const float4 LX = np[0], LY = np[1], LZ = np[2], HX = np[3], HY = np[4], HZ = np[5];
+                        const int4 CH = reinterpret_cast<const int4*>(np)[6];
                         if (COUNT) n_nodes++;
-                        // child 0: lo = (q0.x, q0.y, q0.z), hi = (q0.w, q1.x, q1.y); child 1: lo = (q1.z, q1.w, q2.x), hi = (q2.y, q2.z, q2.w)
-                        float tn0, tf0, tn1, tf1;
-                        tn0 = ((spx ? q0.x : q0.w) - oNx) * iNx; tf0 = ((spx ? q0.w : q0.x) - oFx) * iFx;
-                        tn0 = fmaxf(tn0, ((spy ? q0.y : q1.x) - oNy) * iNy); tf0 = fminf(tf0, ((spy ? q1.x : q0.y) - oFy) * iFy);
-                        tn0 = fmaxf(tn0, ((spz ? q0.z : q1.y) - oNz) * iNz); tf0 = fminf(tf0, ((spz ? q1.y : q0.z) - oFz) * iFz);
-                        tn1 = ((spx ? q1.z : q2.y) - oNx) * iNx; tf1 = ((spx ? q2.y : q1.z) - oFx) * iFx;
-                        tn1 = fmaxf(tn1, ((spy ? q1.w : q2.z) - oNy) * iNy); tf1 = fminf(tf1, ((spy ? q2.z : q1.w) - oFy) * iFy);
-                        tn1 = fmaxf(tn1, ((spz ? q2.x : q2.w) - oNz) * iNz); tf1 = fminf(tf1, ((spz ? q2.w : q2.x) - oFz) * iFz);
-                        const bool h0 = fmaxf(tn0, 0.0f) <= fminf(tf0, t_prune);
-                        const bool h1 = fmaxf(tn1, 0.0f) <= fminf(tf1, t_prune);
-                        if (h0 && h1) {
-                            const bool swap = tn1 < tn0;
-                            const int nearc = swap ? q3.y : q3.x, farc = swap ? q3.x : q3.y;
-                            if (sp < RTS_STACK_LDS) s_stack[sp * RTS_BLOCK + tid] = farc;
-                            else if (sp < RTS_STACK_LDS + RTS_STACK_OVF) { a.stack_ovf[(size_t)(sp - RTS_STACK_LDS) * a.total_threads + gtid] = farc; n_spill++; }
-                            else hard_overflow = true;
-                            if (sp < RTS_STACK_LDS + RTS_STACK_OVF) sp++;
-                            node = nearc;
-                        } else if (h0) node = q3.x;
-                        else if (h1) node = q3.y;
+                        const float4 NX = spx ? LX : HX, FX = spx ? HX : LX, NY = spy ? LY : HY, FY = spy ? HY : LY, NZ = spz ? LZ : HZ, FZ = spz ? HZ : LZ;
+#define RTS_SLAB4(k) fmaxf(fmaxf(fmaxf((NX.k - oNx) * iNx, (NY.k - oNy) * iNy), (NZ.k - oNz) * iNz), 0.0f)
+#define RTS_SLABF4(k) fminf(fminf(fminf((FX.k - oFx) * iFx, (FY.k - oFy) * iFy), (FZ.k - oFz) * iFz), t_prune)
+                        float d0 = RTS_SLAB4(x), d1 = RTS_SLAB4(y), d2 = RTS_SLAB4(z), d3 = RTS_SLAB4(w);
+                        const float INF = __builtin_inff();
+                        if (!(d0 <= RTS_SLABF4(x))) d0 = INF;
+                        if (!(d1 <= RTS_SLABF4(y))) d1 = INF;
+                        if (!(d2 <= RTS_SLABF4(z))) d2 = INF;
+                        if (!(d3 <= RTS_SLABF4(w))) d3 = INF;
+#undef RTS_SLAB4
+#undef RTS_SLABF4
+                        int c0 = CH.x, c1 = CH.y, c2 = CH.z, c3 = CH.w;
+                        // sort the four (distance, child) pairs ascending (5 compare-exchanges); misses carry +inf
+#define RTS_CSWAP(da, ca, db, cb) { const bool sw = db < da; const float td = sw ? db : da; const int tc = sw ? cb : ca; db = sw ? da : db; cb = sw ? ca : cb; da = td; ca = tc; }
+                        RTS_CSWAP(d0, c0, d1, c1) RTS_CSWAP(d2, c2, d3, c3) RTS_CSWAP(d0, c0, d2, c2) RTS_CSWAP(d1, c1, d3, c3) RTS_CSWAP(d1, c1, d2, c2)
+#undef RTS_CSWAP
+                        // continue with the nearest, push the others farthest first
+#define RTS_PUSH(cv) { if (sp < RTS_STACK_LDS) s_stack[sp * RTS_BLOCK + tid] = (cv); \
+                       else if (sp < RTS_STACK_LDS + RTS_STACK_OVF) { a.stack_ovf[(size_t)(sp - RTS_STACK_LDS) * a.total_threads + gtid] = (cv); n_spill++; } \
+                       else hard_overflow = true; \
+                       if (sp < RTS_STACK_LDS + RTS_STACK_OVF) sp++; }
+                        if (d3 < INF) RTS_PUSH(c3)
+                        if (d2 < INF) RTS_PUSH(c2)
+                        if (d1 < INF) RTS_PUSH(c1)
+#undef RTS_PUSH
+                        if (d0 < INF) node = c0;
                         else {
                             if (sp == 0) node = SENTINEL;
                             else { sp--; node = (sp < RTS_STACK_LDS) ? s_stack[sp * RTS_BLOCK + tid] : a.stack_ovf[(size_t)(sp - RTS_STACK_LDS) * a.total_threads + gtid]; }
