@@ -75,7 +75,7 @@ static_assert(sizeof(RtsChildState) == 128, "child state size");
 
 #define RTS_BLOCK 256
 #define RTS_STACK_LDS 24            // traversal stack entries kept in LDS per lane
-#define RTS_STACK_OVF 80            // further entries spilled to global memory (rare)
+#define RTS_STACK_OVF 128           // further entries spilled to global memory (rare); BVH4 pushes up to 3 per level
 
 // Launch constants of ray_generation (hoisted trig, ray_tracer.cu:155-203).  Device resident and
 // read through a pointer: keeping these 30 doubles as by-value kernel arguments pinned ~60
