@@ -13,7 +13,10 @@ pulse, so the LBVH is rebuilt on the device inside the timed region, as the refe
 its acceleration structure every pulse), trace of the pulse's W^3 launch indices, ordering +
 expansion of the received rays, finalisation and group-by aggregation into the pulse's
 responses.  A "ray" in Mrays/s is one traced segment (one rtTrace of the reference: primary or
-bounce).
+bounce).  Pulses are independent, so each GPU keeps two of them in flight (--inflight, two linked handles): the
+trace kernels run back to back on one stream while the LBVH rebuild of the next pulse and the ordering /
+finalisation / aggregation of the previous one run beside them on the handles' own streams.  All of that is inside
+the timed region; ms_per_step is wall time / pulses.
 
 Scaling is strong: the K timed pulses form one coherent processing interval whose K * W^3
 (pulse, launch index) pairs are dealt to the N ranks (rts_amd/multigpu.py: whole pulses first; each of the K % N
@@ -82,10 +85,11 @@ def cpu_baseline(spec, seconds_target=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--width", type=int, default=216, help="W (launch indices per pulse = W^3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=2, help="pulses in flight per GPU (linked handles); 1 = strictly sequential pulses")
     ap.add_argument("--config", default="c3", choices=["c2", "c3"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks")
     args = ap.parse_args()
@@ -117,29 +121,48 @@ def main():
     W = spec["W"]; total = W ** 3
     tx = spec["tx"]; wl = spec["c"] / spec["carrier"]
 
-    tr = api.Tracer(W, spec["max_refl"], 0, spec["smooth"], device=local_rank)
-    tr.set_scene(spec["meshes"]); tr.set_receivers(spec["rx"])
+    # --inflight handles hold the same scene and take the pulses in turn (rts_link_handles): their trace kernels run back
+    # to back, the LBVH rebuild of the next pulse and the ordering/aggregation of the previous one overlap with them
+    trs = []
+    for _ in range(max(args.inflight, 1)):
+        t = api.Tracer(W, spec["max_refl"], 0, spec["smooth"], device=local_rank)
+        t.set_scene(spec["meshes"]); t.set_receivers(spec["rx"])
+        if trs:
+            trs[0].link(t)
+        trs.append(t)
+    tr = trs[0]
 
     # complex return cube [rx][pulse][range bin] (derived product; the dense buffer that is all-reduced over RCCL)
     n_bins = 1024; r0 = 2.0 * abs(tx["origin"][0])
     cube_t0 = (r0 - 150.0) / spec["c"]; cube_dt = 300.0 / spec["c"] / n_bins
     cube = torch.zeros((len(spec["rx"]), max(args.steps, args.warmup, 1), n_bins), dtype=torch.complex128, device="cuda")
-    tr.cube_attach(cube.shape[0], cube.shape[1], n_bins, cube_t0, cube_dt, device_ptr=cube.data_ptr())
+    for t in trs:                                              # every pulse owns one row of the cube, so the handles can share it
+        t.cube_attach(cube.shape[0], cube.shape[1], n_bins, cube_t0, cube_dt, device_ptr=cube.data_ptr())
 
     def run_cpi(k0, n_pulses):
         """pulses k0 .. k0+n_pulses-1 as one coherent processing interval, sharded over the ranks"""
         parts = []; acc = dict(segments=0, shaded=0, received=0, ms_scene=0.0, ms_trace=0.0, ms_post=0.0, launches=0)
         cube.zero_(); torch.cuda.synchronize()
-        for (k, first, count, il) in multigpu.plan_cpi(total, n_pulses, rank, world):
-            tr.trace(tx["origin"], tx["span"], tx["dir"], pulse_motion(spec, k0 + k), ray_first=first, ray_count=count, want_stats=False, interleave=il)
-            tr.finalise_uniform(None, wl, 1.0, 1.0, spec["carrier"], spec["c"])
-            tr.cube_accumulate(k, spec["c"], spec["carrier"])
-            groups = tr.aggregate(spec["c"], spec["carrier"], rts_amd._lib.RTS_BASE_USE_ROWS)
-            st = tr.stats()                                   # stream already drained by the aggregation's table fetch
+        def finish(t, k):
+            t.trace_end()
+            t.finalise_uniform(None, wl, 1.0, 1.0, spec["carrier"], spec["c"])
+            t.cube_accumulate(k, spec["c"], spec["carrier"])
+            groups = t.aggregate(spec["c"], spec["carrier"], rts_amd._lib.RTS_BASE_USE_ROWS)
+            st = t.stats()                                    # stream already drained by the aggregation's table fetch
             parts.append(dict(pulse=k, groups=groups))
             acc["segments"] += st["segments"]; acc["shaded"] += st["shaded"]; acc["received"] += st["received"]
             acc["ms_scene"] += st["ms_scene"]; acc["ms_trace"] += st["ms_trace"]; acc["ms_post"] += st["ms_compact"] + st["ms_aggregate"]
             acc["launches"] += 1
+
+        pending = []
+        for i, (k, first, count, il) in enumerate(multigpu.plan_cpi(total, n_pulses, rank, world)):
+            t = trs[i % len(trs)]
+            t.trace_begin(tx["origin"], tx["span"], tx["dir"], pulse_motion(spec, k0 + k), ray_first=first, ray_count=count, interleave=il)
+            pending.append((t, k))
+            if len(pending) == len(trs):                      # the oldest pulse in flight is completed while the newer ones run
+                finish(*pending.pop(0))
+        while pending:
+            finish(*pending.pop(0))
         allp = multigpu.exchange_parts(parts, dist, torch)    # ONE exchange per CPI (RCCL all-gather), inside the timed region
         resp = multigpu.merge_cpi(allp, spec["max_refl"])
         if dist is not None:                                  # dense per-receiver return buffers: sum over the ranks
@@ -206,7 +229,7 @@ def main():
                                    % (spec["name"], len(spec["rx"]), W, total, spec["max_refl"]),
                        "rays_per_pulse": total, "segments_per_pulse": seg_all / args.steps, "received_per_pulse": received_all / args.steps,
                        "primary_Mrays_per_s": total * args.steps / dt / 1e6, "return_cube": "complex128 [%d rx][%d pulses][%d bins], all-reduced once per interval" % (cube.shape[0], args.steps, n_bins), "sharding": "%d-pulse interval over %d ranks: whole pulses, left-over pulses in interleaved 4096-index tiles; one group-table all-gather + one cube all-reduce per interval" % (args.steps, world),
-                       "stage_ms_per_launch_rank0": {"scene+lbvh": ms_scene / launches, "trace": ms_launch, "order+finalise+aggregate": ms_post / launches}},
+                       "pulses_in_flight": len(trs), "stage_ms_per_launch_rank0": {"scene+lbvh": ms_scene / launches, "trace": ms_launch, "order+finalise+aggregate": ms_post / launches}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": bytes_per_seg * seg_per_launch, "kernel": "k_trace", "bytes_per_segment": bytes_per_seg,
                          "nodes_per_segment": V, "tri_tests_per_segment": T, "shaded_per_segment": Hh,
@@ -217,7 +240,8 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    tr.close()
+    for t in trs:
+        t.close()
     if dist is not None:
         dist.barrier(); dist.destroy_process_group()
 

@@ -76,7 +76,7 @@ HostMesh build_target_mesh(Target* targ) {
 //   Vec3 (x,y,z), SVec3 (constructible from Vec3; .length, .azimuth, .elevation), Params (static
 //   GetRTSVariables/c/start_time/cw_sample_rate/interpolate_smooth).
 template <class Tr>
-void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlocks, int device = 0, RtsStats* last_stats = nullptr)
+void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlocks, int device = 0, RtsStats* last_stats = nullptr, unsigned in_flight = 2)
 {
     using Vec3 = typename Tr::Vec3; using SVec3 = typename Tr::SVec3;
     const auto rts_vars = Tr::Params::GetRTSVariables();                       // ray_tracer.cpp:600-605
@@ -90,9 +90,13 @@ void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlo
     auto& transmitters = world->transmitters; auto& receivers = world->receivers; auto& targets = world->targets;
     const uint32_t rxsize = (uint32_t)receivers.size(), targsize = (uint32_t)targets.size();
 
-    RtsHandle h = nullptr;
-    check(rts_create(&params, &h), "rts_create");
-    struct Guard { RtsHandle h; ~Guard() { rts_destroy(h); } } guard{h};
+    // Two handles hold the same scene and take the pulses in turn (rts_link_handles): while the host finishes pulse k
+    // (read-back, RCS/gain loop, aggregation, responses) the device already traces pulse k+1.  Results and the order
+    // of every side effect (AddResponse) are those of the sequential loop; in_flight = 1 restores it literally.
+    const unsigned n_handles = in_flight > 1 ? 2u : 1u;
+    struct Handles { RtsHandle h[2] = {nullptr, nullptr}; ~Handles() { rts_destroy(h[0]); rts_destroy(h[1]); } } hs;
+    for (unsigned i = 0; i < n_handles; i++) check(rts_create(&params, &hs.h[i]), "rts_create");
+    if (n_handles == 2) check(rts_link_handles(hs.h[0], hs.h[1]), "rts_link_handles");
 
     // scene: once (the reference regenerates identical meshes every pulse)
     std::vector<HostMesh> host(targsize); std::vector<RtsMesh> meshes(targsize);
@@ -103,7 +107,7 @@ void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlo
         meshes[t].n_normals = (uint32_t)(host[t].normals.size() / 3); meshes[t].reserved = 0;
         meshes[t].refl_coeff = targets[t]->GetReflCoeff(); meshes[t].refr_index = targets[t]->GetRefrIndex();
     }
-    check(rts_set_scene(h, meshes.data(), targsize), "rts_set_scene");
+    for (unsigned i = 0; i < n_handles; i++) check(rts_set_scene(hs.h[i], meshes.data(), targsize), "rts_set_scene");
 
     for (size_t tx_i = 0; tx_i < transmitters.size(); tx_i++) {                // ray_tracer.cpp:806
         auto* trans = transmitters[tx_i];
@@ -115,11 +119,12 @@ void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlo
         const auto txSpan = trans->GetTxSpan();
         for (uint32_t j = 0; j < rxsize; j++)                                  // side effect kept: once per transmitter (:829)
             receivers[j]->SetNoiseTemperature(wave->GetTemp() + receivers[j]->GetNoiseTemperature());
+        const Vec3 trpos = trans->GetPosition(0);                              // Tx position frozen at t = 0 (:881)
 
-        for (unsigned k = 0; k < pulseCount; k++) {                            // :843
+        // ---- everything of pulse k up to the launch (:843-1165), left in flight on handle h; returns the pulse time
+        auto begin_pulse = [&](unsigned k, RtsHandle h) -> double {
             trans->GetPulse(signal, k);
             const double time_t = signal->time;
-            const Vec3 trpos = trans->GetPosition(0);                          // Tx position frozen at t = 0 (:881)
             const auto txrot = trans->GetRotation(time_t);
             RtsPulse pulse{};
             pulse.ray_origin[0] = trpos.x; pulse.ray_origin[1] = trpos.y; pulse.ray_origin[2] = trpos.z;
@@ -149,11 +154,17 @@ void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlo
                 }
             }
             pulse.motion = motion.data();
-            check(rts_trace_pulse(h, &pulse), "rts_trace_pulse");               // replaces :1126-1165
+            check(rts_trace_pulse_begin(h, &pulse), "rts_trace_pulse_begin");   // replaces :1126-1165
+            return time_t;
+        };
+
+        // ---- read-back, finalisation, aggregation and responses of the pulse in flight on handle h (:1180-1321)
+        auto finish_pulse = [&](RtsHandle h, double time_t) {
+            check(rts_trace_pulse_end(h), "rts_trace_pulse_end");
             if (last_stats) rts_get_stats(h, last_stats);
 
             uint64_t R = 0; check(rts_received_count(h, &R), "rts_received_count");
-            if (R == 0) continue;
+            if (R == 0) return;
             std::vector<PerRayData> rx_results(R); std::vector<int> rx_intersects((size_t)R * D); std::vector<double> rcs_angle((size_t)R * D * 2);
             check(rts_get_received(h, rx_results.data(), rx_intersects.data(), rcs_angle.data(), nullptr, R), "rts_get_received");
 
@@ -198,7 +209,15 @@ void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlo
                 response->AddInterpPoint(point);
                 receivers[rx]->AddResponse(response);
             }
+        };
+
+        double t_of[2] = {0, 0};
+        for (unsigned k = 0; k < pulseCount; k++) {                            // :843, software-pipelined by one pulse
+            t_of[k % n_handles] = begin_pulse(k, hs.h[k % n_handles]);
+            if (n_handles == 1) finish_pulse(hs.h[0], t_of[0]);
+            else if (k > 0) finish_pulse(hs.h[(k - 1) % 2], t_of[(k - 1) % 2]);
         }
+        if (n_handles == 2 && pulseCount > 0) finish_pulse(hs.h[(pulseCount - 1) % 2], t_of[(pulseCount - 1) % 2]);
     }
 }
 

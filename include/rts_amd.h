@@ -159,6 +159,20 @@ int rts_set_receivers(RtsHandle h, const RtsReceiverSphere* rx, uint32_t n_rx); 
  * leaves the received rays on the device, ordered by ascending launch index (the order of the
  * host scan at ray_tracer.cpp:1190).  Blocking. */
 int rts_trace_pulse(RtsHandle h, const RtsPulse* pulse);
+
+/* Pulse pipelining.  The reference runs its pulses strictly one after the other (the loop at ray_tracer.cpp:843:
+ * acceleration rebuild -> rtContextLaunch3D -> host read-back -> aggregation, each blocking).  Pulses are independent,
+ * so a caller may keep two (or more) handles holding the same scene, link them once, and alternate pulses between them:
+ *     rts_trace_pulse_begin(hB, pulse k+1);   // enqueued, returns at once
+ *     rts_trace_pulse_end(hA);                // pulse k: wait for its trace, order + expand its received rays
+ *     ... rts_finalise_uniform / rts_cube_accumulate / rts_aggregate on hA ...
+ * rts_trace_pulse == begin + end.  Trace kernels of linked handles execute one at a time in begin order (each has the
+ * whole GPU, so rts_get_stats().ms_trace stays a single-kernel time); the LBVH rebuild of the next pulse and the
+ * ordering / finalisation / aggregation of the previous one overlap with them on the handles' own HIP streams.
+ * Entry points that read a pulse's results end a begun pulse implicitly.  One host thread per link group. */
+int rts_trace_pulse_begin(RtsHandle h, const RtsPulse* pulse);
+int rts_trace_pulse_end(RtsHandle h);
+int rts_link_handles(RtsHandle a, RtsHandle b);               /* same device; groups grow by linking a member to a new handle */
 int rts_get_stats(RtsHandle h, RtsStats* out);
 
 /* Received rays of the last pulse (ray_tracer.cpp:1186-1257 before the gain/RCS update):

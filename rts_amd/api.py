@@ -130,6 +130,21 @@ class Tracer:
 
     def trace(self, origin, tx_span, tx_dir, motion=None, ray_first=0, ray_count=0, want_stats=True, interleave=None):
         """motion: list of dict(position, velocity[, rotation(9)]) per target, or None to keep placement."""
+        check(L.lib().rts_trace_pulse(self.h, C.byref(self._pulse(origin, tx_span, tx_dir, motion, ray_first, ray_count, interleave))))
+        return self.stats() if want_stats else None     # reading the stage timers drains the stream
+
+    def trace_begin(self, origin, tx_span, tx_dir, motion=None, ray_first=0, ray_count=0, interleave=None):
+        """enqueue a pulse (rts_trace_pulse_begin); trace_end() -- or any accessor -- completes it"""
+        check(L.lib().rts_trace_pulse_begin(self.h, C.byref(self._pulse(origin, tx_span, tx_dir, motion, ray_first, ray_count, interleave))))
+
+    def trace_end(self):
+        check(L.lib().rts_trace_pulse_end(self.h))
+
+    def link(self, other):
+        """rts_link_handles: trace kernels of linked tracers run one at a time, everything else overlaps"""
+        check(L.lib().rts_link_handles(self.h, other.h))
+
+    def _pulse(self, origin, tx_span, tx_dir, motion, ray_first, ray_count, interleave):
         p = L.RtsPulse()
         p.ray_origin[:] = list(origin); p.tx_span[:] = list(tx_span); p.tx_dir[:] = list(tx_dir)
         p.ray_first = ray_first; p.ray_count = ray_count
@@ -145,8 +160,7 @@ class Tracer:
                     marr[i].rotation[:] = list(np.asarray(rot, np.float64).reshape(9)); marr[i].has_rotation = 1
             p.motion = C.cast(marr, C.POINTER(L.RtsTargetMotion))
             self._keep = [marr]
-        check(L.lib().rts_trace_pulse(self.h, C.byref(p)))
-        return self.stats() if want_stats else None     # reading the stage timers drains the stream
+        return p
 
     def stats(self):
         s = L.RtsStats()

@@ -26,6 +26,7 @@ int rts_debug_stage(RtsContext* c, const char* name)
     if (!on) return RTS_OK;
     fprintf(stderr, "[rts] stage %s ... ", name); fflush(stderr);
     hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->tstream);
     if (e != hipSuccess) { fprintf(stderr, "FAILED: %s\n", hipGetErrorString(e)); rts_set_error("stage %s: %s", name, hipGetErrorString(e)); return RTS_ERR_HIP; }
     fprintf(stderr, "ok\n"); fflush(stderr);
     return RTS_OK;
@@ -55,9 +56,17 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     RtsContext* c = new RtsContext();
     c->params = *p; c->params.max_refr = refr; c->depth = refr + p->max_refl; c->device = p->device;
     memset(&c->stats, 0, sizeof(c->stats));
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    // two streams of different priority (=> different hardware queues): the long trace kernel on the low one, the many
+    // short build/ordering/aggregation kernels on the high one so that they slot in while a trace kernel is running
+    int prio_low = 0, prio_high = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+    hipError_t e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_high);
     if (e != hipSuccess) { delete c; rts_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return RTS_ERR_HIP; }
-    for (int i = 0; i < 8; i++) { e = hipEventCreate(&c->ev[i]); if (e != hipSuccess) { delete c; rts_set_error("hipEventCreate: %s", hipGetErrorString(e)); return RTS_ERR_HIP; } }
+    c->gate = new RtsGate(); c->gate->refs = 1; c->gate->device = p->device;
+    e = hipStreamCreateWithPriority(&c->gate->tstream, hipStreamNonBlocking, prio_low);
+    if (e != hipSuccess) { delete c->gate; (void)hipStreamDestroy(c->stream); delete c; rts_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return RTS_ERR_HIP; }
+    c->tstream = c->gate->tstream;
+    for (int i = 0; i < 9; i++) { e = hipEventCreate(&c->ev[i]); if (e != hipSuccess) { delete c; rts_set_error("hipEventCreate: %s", hipGetErrorString(e)); return RTS_ERR_HIP; } }
     e = hipHostMalloc((void**)&c->pin, sizeof(RtsPinned), hipHostMallocDefault);
     if (e != hipSuccess) { delete c; rts_set_error("hipHostMalloc: %s", hipGetErrorString(e)); return RTS_ERR_HIP; }
     memset(c->pin, 0, sizeof(RtsPinned));
@@ -85,19 +94,40 @@ extern "C" int rts_destroy(RtsHandle c)
     c->d_akeys.release(); c->d_akeys_sorted.release(); c->d_aidx.release(); c->d_aidx_sorted.release(); c->d_ghead.release(); c->d_gid.release();
     c->d_gsum.release(); c->d_gmin.release(); c->d_gkey.release(); c->d_grow.release(); c->d_gcount.release(); c->d_delay.release(); c->d_phase.release();
     c->d_pathmatch.release(); c->d_rcs.release(); c->d_rcsval.release(); c->d_cube_own.release();
+    (void)hipStreamSynchronize(c->tstream);
+    if (--c->gate->refs == 0) { (void)hipStreamDestroy(c->gate->tstream); delete c->gate; }
     if (c->pin) (void)hipHostFree(c->pin);
-    for (int i = 0; i < 8; i++) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 9; i++) (void)hipEventDestroy(c->ev[i]);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return RTS_OK;
 }
 
 #define CHECK_HANDLE(c) do { if (!(c)) { rts_set_error("null handle"); return RTS_ERR_INVALID; } RTS_HIP(hipSetDevice((c)->device)); } while (0)
+// entry points that consume a pulse's results complete a pulse that was begun but not yet ended
+#define CHECK_CLOSED(c) do { if ((c)->pulse_open) { int rc_ = rts_trace_pulse_end(c); if (rc_ != RTS_OK) return rc_; } } while (0)
+
+extern "C" int rts_link_handles(RtsHandle a, RtsHandle b)
+{
+    if (!a || !b || a == b) { rts_set_error("rts_link_handles: needs two distinct handles"); return RTS_ERR_INVALID; }
+    if (a->device != b->device) { rts_set_error("rts_link_handles: handles live on different devices (%d, %d)", a->device, b->device); return RTS_ERR_INVALID; }
+    if (a->gate == b->gate) return RTS_OK;
+    if (a->gate->refs > 1 && b->gate->refs > 1) { rts_set_error("rts_link_handles: both handles already belong to (different) groups"); return RTS_ERR_INVALID; }
+    if (a->pulse_open || b->pulse_open) { rts_set_error("rts_link_handles: a pulse is in flight"); return RTS_ERR_INVALID; }
+    RtsContext* joiner = b->gate->refs == 1 ? b : a;     // the handle that is still alone adopts the other's trace stream
+    RtsContext* host = joiner == b ? a : b;
+    RTS_HIP(hipSetDevice(a->device));
+    RTS_HIP(hipStreamSynchronize(joiner->tstream));
+    (void)hipStreamDestroy(joiner->gate->tstream); delete joiner->gate;
+    joiner->gate = host->gate; joiner->gate->refs++; joiner->tstream = joiner->gate->tstream;
+    return RTS_OK;
+}
 
 // ------------------------------------------------------------------------------------- scene
 extern "C" int rts_set_scene(RtsHandle c, const RtsMesh* meshes, uint32_t n_targets)
 {
     CHECK_HANDLE(c);
+    CHECK_CLOSED(c);
     if (n_targets && !meshes) { rts_set_error("rts_set_scene: null meshes"); return RTS_ERR_INVALID; }
     if (n_targets > 254) { rts_set_error("rts_set_scene: more than 254 targets"); return RTS_ERR_UNSUPPORTED; }
     std::vector<RtsMeshHost> mh(n_targets);
@@ -150,6 +180,7 @@ extern "C" int rts_set_scene(RtsHandle c, const RtsMesh* meshes, uint32_t n_targ
 extern "C" int rts_set_receivers(RtsHandle c, const RtsReceiverSphere* rx, uint32_t n_rx)
 {
     CHECK_HANDLE(c);
+    CHECK_CLOSED(c);
     if (n_rx && !rx) { rts_set_error("rts_set_receivers: null array"); return RTS_ERR_INVALID; }
     if (n_rx > 65535) { rts_set_error("rts_set_receivers: more than 65535 receivers"); return RTS_ERR_UNSUPPORTED; }
     std::vector<RtsRxDev> h(n_rx);
@@ -206,8 +237,16 @@ static void fill_launch_constants(RtsLaunchConsts& a, const RtsPulse& p, uint32_
 // ------------------------------------------------------------------------------------- launch
 extern "C" int rts_trace_pulse(RtsHandle c, const RtsPulse* p)
 {
+    int rc = rts_trace_pulse_begin(c, p);
+    return rc != RTS_OK ? rc : rts_trace_pulse_end(c);
+}
+
+// Everything of a pulse up to and including the trace kernel, left in flight on the handle's stream.
+extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
+{
     CHECK_HANDLE(c);
     if (!p) { rts_set_error("rts_trace_pulse: null pulse"); return RTS_ERR_INVALID; }
+    if (c->pulse_open) { rts_set_error("rts_trace_pulse_begin: the previous pulse of this handle was begun but not ended"); return RTS_ERR_INVALID; }
     const uint32_t W = c->params.width;
     const uint64_t total = (uint64_t)W * W * W;
     uint64_t first = p->ray_first, count = p->ray_count ? p->ray_count : (total > first ? total - first : 0);
@@ -298,21 +337,37 @@ extern "C" int rts_trace_pulse(RtsHandle c, const RtsPulse* p)
     c->last_args = a;
 
     // ---- trace
-    RTS_HIP(hipEventRecord(c->ev[2], st));
     RTS_STAGE(c, "pre-trace");
+    RTS_HIP(hipEventRecord(c->ev[8], st));                       // scene + per-pulse buffers of this handle are ready
+    RTS_HIP(hipStreamWaitEvent(c->tstream, c->ev[8], 0));
+    RTS_HIP(hipEventRecord(c->ev[2], c->tstream));
     int rc = (c->pt_mode && !keep_all && a.max_refr == 0) ? rts_trace_launch_pt(c, a, count_trav) : rts_trace_launch(c, a, count_trav);
     if (rc != RTS_OK) return rc;
     RTS_STAGE(c, "k_trace");
-    RTS_HIP(hipEventRecord(c->ev[3], st));
+    RTS_HIP(hipEventRecord(c->ev[3], c->tstream));
+    RTS_HIP(hipStreamWaitEvent(st, c->ev[3], 0));                // everything later on this handle's stream follows its trace
+    RTS_HIP(hipMemcpyAsync(c->pin->cnt, c->d_counters.p, sizeof(unsigned long long) * 8, hipMemcpyDeviceToHost, st));
+    c->pulse_open = true;
+    return RTS_OK;
+}
+
+// Waits for the pulse begun on this handle, then orders + expands its received rays (left in flight).
+extern "C" int rts_trace_pulse_end(RtsHandle c)
+{
+    CHECK_HANDLE(c);
+    if (!c->pulse_open) { rts_set_error("rts_trace_pulse_end: no pulse in flight on this handle"); return RTS_ERR_INVALID; }
+    c->pulse_open = false;
+    hipStream_t st = c->stream;
+    const bool keep_all = (c->params.flags & RTS_FLAG_KEEP_ALL_RAYS) != 0;
+    const uint32_t n = c->n_rays;
     unsigned long long* cnt = c->pin->cnt;
-    RTS_HIP(hipMemcpyAsync(cnt, c->d_counters.p, sizeof(unsigned long long) * 8, hipMemcpyDeviceToHost, st));
     RTS_HIP(hipStreamSynchronize(st));              // the one host sync of the launch: the received count sizes what follows
     if (cnt[6]) { rts_set_error("rts_trace_pulse: traversal stack overflow / malformed BVH guard tripped on %llu waves", cnt[6]); return RTS_ERR_HIP; }
     c->n_recv = cnt[0];
 
     // ---- order + expand the received rays (and the keep-all buffers); left in flight on the stream
     RTS_HIP(hipEventRecord(c->ev[4], st));
-    rc = rts_post_order_and_expand(c); if (rc != RTS_OK) return rc;
+    int rc = rts_post_order_and_expand(c); if (rc != RTS_OK) return rc;
     if (keep_all) { rc = rts_post_expand_all(c); if (rc != RTS_OK) return rc; }
     RTS_HIP(hipEventRecord(c->ev[5], st));
 
@@ -327,6 +382,7 @@ extern "C" int rts_trace_pulse(RtsHandle c, const RtsPulse* p)
 extern "C" int rts_get_stats(RtsHandle c, RtsStats* out)
 {
     if (!c || !out) { rts_set_error("rts_get_stats: null argument"); return RTS_ERR_INVALID; }
+    CHECK_CLOSED(c);
     if (c->stats_pending) {                          // stage timers are resolved lazily: reading them drains the stream
         RTS_HIP(hipSetDevice(c->device));
         RTS_HIP(hipStreamSynchronize(c->stream));
@@ -344,12 +400,14 @@ extern "C" int rts_get_stats(RtsHandle c, RtsStats* out)
 extern "C" int rts_received_count(RtsHandle c, uint64_t* count)
 {
     if (!c || !count) { rts_set_error("rts_received_count: null argument"); return RTS_ERR_INVALID; }
+    CHECK_CLOSED(c);
     *count = c->n_recv; return RTS_OK;
 }
 
 extern "C" int rts_get_received(RtsHandle c, PerRayData* rays, int32_t* paths, double* rcs_angles, uint64_t* slots, uint64_t capacity)
 {
     CHECK_HANDLE(c);
+    CHECK_CLOSED(c);
     const uint64_t R = c->n_recv; const uint32_t D = c->depth;
     if (capacity < R) { rts_set_error("rts_get_received: capacity %llu < %llu received rays", (unsigned long long)capacity, (unsigned long long)R); return RTS_ERR_CAPACITY; }
     if (R == 0) return RTS_OK;
@@ -364,6 +422,7 @@ extern "C" int rts_get_received(RtsHandle c, PerRayData* rays, int32_t* paths, d
 extern "C" int rts_get_all_rays(RtsHandle c, PerRayData* results, int32_t* targ_intersect, double* rcs_angle, int32_t* hit_prim, float* hit_t, uint64_t capacity)
 {
     CHECK_HANDLE(c);
+    CHECK_CLOSED(c);
     if (!(c->params.flags & RTS_FLAG_KEEP_ALL_RAYS)) { rts_set_error("rts_get_all_rays: handle was not created with RTS_FLAG_KEEP_ALL_RAYS"); return RTS_ERR_INVALID; }
     const uint64_t n1 = c->n_rays, n = n1 * c->last_args.rows; const uint32_t D = c->depth, H = c->params.max_refl + 1;
     if (capacity < n) { rts_set_error("rts_get_all_rays: capacity too small (%llu rows)", (unsigned long long)n); return RTS_ERR_CAPACITY; }
@@ -381,6 +440,7 @@ extern "C" int rts_get_all_rays(RtsHandle c, PerRayData* results, int32_t* targ_
 extern "C" int rts_finalise_uniform(RtsHandle c, const double* rcs_per_target, double wavelength, double gt, double gr, double carrier, double cspeed)
 {
     CHECK_HANDLE(c);
+    CHECK_CLOSED(c);
     std::vector<double> ones;
     if (!rcs_per_target) { ones.assign(c->meshes.size() + 1, 1.0); rcs_per_target = ones.data(); }
     RTS_HIP(hipEventRecord(c->ev[6], c->stream));
@@ -394,6 +454,7 @@ extern "C" int rts_finalise_uniform(RtsHandle c, const double* rcs_per_target, d
 extern "C" int rts_aggregate(RtsHandle c, double cspeed, double carrier, uint64_t recv_index_base)
 {
     CHECK_HANDLE(c);
+    CHECK_CLOSED(c);
     const uint64_t R = c->n_recv;
     c->groups.clear(); c->recv_index_base = recv_index_base;
     if (R == 0) { c->agg_valid = true; return RTS_OK; }
@@ -460,6 +521,7 @@ extern "C" int rts_cube_attach(RtsHandle c, const RtsCubeParams* p, void* device
 extern "C" int rts_cube_accumulate(RtsHandle c, uint32_t pulse_index, double cspeed, double carrier)
 {
     CHECK_HANDLE(c);
+    CHECK_CLOSED(c);
     if (!c->cube_set) { rts_set_error("rts_cube_accumulate: call rts_cube_attach first"); return RTS_ERR_INVALID; }
     if (pulse_index >= c->cube_params.n_pulses) { rts_set_error("rts_cube_accumulate: pulse %u >= %u", pulse_index, c->cube_params.n_pulses); return RTS_ERR_INVALID; }
     return rts_cube_accumulate_device(c, pulse_index, cspeed, carrier);

@@ -153,12 +153,18 @@ template <typename T> struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// Handles joined by rts_link_handles share one trace stream: their trace kernels execute one after the other, in the
+// order the pulses were begun; the rest of each pulse (scene placement + LBVH build before, ordering / finalise /
+// aggregation after) runs on the handle's own (high-priority) stream and overlaps with the other handles' trace kernels.
+struct RtsGate { hipStream_t tstream = nullptr; int refs = 0; int device = 0; };
+
 struct RtsContext {
     RtsParams params;
     uint32_t depth;                 // D = max_refr + max_refl
     int device;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[8];
+    hipStream_t stream = nullptr;       // scene placement, LBVH build, ordering, finalise, aggregation (high priority: short kernels)
+    hipStream_t tstream = nullptr;      // trace kernels (the link group's, see RtsGate)
+    hipEvent_t ev[9];
     // scene (static part)
     std::vector<RtsMeshHost> meshes;
     uint32_t n_prims = 0, n_verts = 0, n_normals = 0;
@@ -193,6 +199,7 @@ struct RtsContext {
     RtsCubeParams cube_params; double* cube = nullptr; DevBuf<double> d_cube_own; bool cube_set = false;
     RtsPinned* pin = nullptr; DevBuf<double> d_rcsval; int n_cu = 0; bool stats_pending = false; bool agg_timed = false, fin_timed = false;
     RtsStats stats;
+    RtsGate* gate = nullptr; bool pulse_open = false;   // gate: never null after rts_create
 };
 
 // implemented in the .hip units

@@ -372,7 +372,7 @@ int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a, bool count_traversal)
 {
     if (a.n_rays == 0) return RTS_OK;
     const unsigned grid = a.total_threads / RTS_BLOCK;
-    hipStream_t st = c->stream;
+    hipStream_t st = c->tstream;
     const int sel = (a.max_refr ? 4 : 0) | (a.keep_all ? 2 : 0) | (count_traversal ? 1 : 0);
     switch (sel) {
         case 0: k_trace<false, false, false><<<grid, RTS_BLOCK, 0, st>>>(a); break;

@@ -205,8 +205,8 @@ int rts_trace_launch_pt(RtsContext* c, const RtsTraceArgs& a, bool count_travers
 {
     if (a.n_rays == 0) return RTS_OK;
     const unsigned grid = a.total_threads / RTS_BLOCK;
-    if (count_traversal) k_trace_pt<true><<<grid, RTS_BLOCK, 0, c->stream>>>(a);
-    else k_trace_pt<false><<<grid, RTS_BLOCK, 0, c->stream>>>(a);
+    if (count_traversal) k_trace_pt<true><<<grid, RTS_BLOCK, 0, c->tstream>>>(a);
+    else k_trace_pt<false><<<grid, RTS_BLOCK, 0, c->tstream>>>(a);
     RTS_HIP(hipGetLastError());
     return RTS_OK;
 }

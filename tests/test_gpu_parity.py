@@ -350,6 +350,8 @@ def test_adapter_end_to_end(rts, oracle, tmp_path):
     exe = build_adapter_binary(str(tmp_path / "adapter_main"))
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
+    seq = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=300)       # strictly sequential pulses
+    assert seq.returncode == 0 and seq.stdout == out.stdout, "pipelined and sequential pulse loops must emit identical responses"
     got = np.array([[float(x) for x in line.split()] for line in out.stdout.strip().splitlines()])
     # the same scene through the oracle
     c, fc, Ts, W, max_refl = C0, 10e9, 1e-3, 16, 4
@@ -551,3 +553,63 @@ def test_persistent_wave_kernel_identical(rts, oracle, scenes, monkeypatch):
     o = H.oracle_trace(oracle, spec, use_bvh=True, threads=4, debug=False)
     idx = np.nonzero(o["results"]["received"] >= 0)[0]
     H.assert_prd_equal(o["results"][idx], b["results"], "persistent-wave kernel vs oracle")
+
+
+def test_pipelined_pulses_identical(rts, scenes):
+    """rts_trace_pulse_begin/_end over two linked handles (pulse k+1 enqueued before pulse k is finished): every pulse's
+    received set, group table and return-cube row are bit-identical to the strictly sequential single-handle run"""
+    import torch
+    from rts_amd import _lib
+    spec = scenes.config3(W=48, detail=0.3)
+    wl = spec["c"] / spec["carrier"]; tx = spec["tx"]; n_pulses = 5
+
+    def motion(k):
+        return scenes.config5_motion(k, speed=150.0, yaw_rate=20.0)
+
+    def post(t, k):
+        rec = t.received()
+        t.finalise_uniform(None, wl, 1.0, 1.0, spec["carrier"], spec["c"])
+        t.cube_accumulate(k, spec["c"], spec["carrier"])
+        return rec, t.aggregate(spec["c"], spec["carrier"], _lib.RTS_BASE_USE_ROWS)
+
+    r0 = 2.0 * abs(tx["origin"][0]); t0 = (r0 - 150.0) / spec["c"]; dt = 300.0 / spec["c"] / 256
+    cubes = [torch.zeros((len(spec["rx"]), n_pulses, 256), dtype=torch.complex128, device="cuda") for _ in range(2)]
+    seq = H.gpu_tracer(rts, spec)
+    seq.cube_attach(len(spec["rx"]), n_pulses, 256, t0, dt, device_ptr=cubes[0].data_ptr())
+    ref = []
+    for k in range(n_pulses):
+        seq.trace(tx["origin"], tx["span"], tx["dir"], motion(k), want_stats=False)
+        ref.append(post(seq, k))
+    seq.close()
+
+    a, b = H.gpu_tracer(rts, spec), H.gpu_tracer(rts, spec)
+    a.link(b)
+    for t in (a, b):
+        t.cube_attach(len(spec["rx"]), n_pulses, 256, t0, dt, device_ptr=cubes[1].data_ptr())
+    got = [None] * n_pulses; pending = []
+    for k in range(n_pulses):
+        t = (a, b)[k % 2]
+        t.trace_begin(tx["origin"], tx["span"], tx["dir"], motion(k))
+        pending.append((t, k))
+        if len(pending) == 2:
+            tt, kk = pending.pop(0); got[kk] = post(tt, kk)          # received() ends the begun pulse implicitly
+    while pending:
+        tt, kk = pending.pop(0); tt.trace_end(); got[kk] = post(tt, kk)
+    torch.cuda.synchronize()
+    assert sum(len(r[0]["slots"]) for r in ref) > 100
+    for k in range(n_pulses):
+        assert np.array_equal(ref[k][0]["slots"], got[k][0]["slots"])
+        H.assert_prd_equal(ref[k][0]["results"], got[k][0]["results"], "pipelined pulse %d" % k)
+        assert np.array_equal(ref[k][0]["path"], got[k][0]["path"])
+        assert ref[k][1].tobytes() == got[k][1].tobytes()
+    assert torch.equal(torch.view_as_real(cubes[0]), torch.view_as_real(cubes[1]))
+    # protocol errors
+    with pytest.raises(RuntimeError):
+        a.trace_end()                                                # nothing in flight
+    a.trace_begin(tx["origin"], tx["span"], tx["dir"], motion(0))
+    with pytest.raises(RuntimeError):
+        a.trace_begin(tx["origin"], tx["span"], tx["dir"], motion(1))
+    a.trace_end()
+    with pytest.raises(RuntimeError):
+        a.link(a)
+    a.close(); b.close()
