@@ -257,8 +257,12 @@ int rts_rx_sphere(const double* rx_position, double azimuth, double elevation, d
                   double phi_span, RtsReceiverSphere* out);                                          /* :894-918 */
 
 /* ---------------------------------------------------------------- introspection (tests)
- * LBVH of the last pulse: nodes[n_nodes][16] floats-as-stored (64-byte records), leaf_prim[n_prims]. */
-int rts_get_bvh(RtsHandle h, void* nodes64, uint32_t* leaf_prim, uint32_t node_capacity, uint32_t prim_capacity);
+ * The static target-space hierarchy built by rts_set_scene: nodes[RtsStats.n_nodes] as stored (128-byte records: lo x,y,z /
+ * hi x,y,z planes of the four children as 6 x float[4], int32 child[4] (>= 0 node, < 0 ~leaf slot, 0x7fffffff unused),
+ * int32 pad[4]); leaf_prim[*n_leaves] = global primitive id per leaf slot (primitives with a non-finite vertex have
+ * none); roots[n_targets] = root node per target (-1: no geometry).  Any output may be NULL. */
+int rts_get_bvh(RtsHandle h, void* nodes128, uint32_t* leaf_prim, int32_t* roots, uint32_t node_capacity,
+                uint32_t leaf_capacity, uint32_t* n_leaves);
 int rts_self_test_math(RtsHandle h, const float* y, const float* x, float* atan2f_out, const double* a,
                        const double* b, double* div_out, double* sqrt_out, uint32_t n);
 

@@ -137,7 +137,7 @@ def lib():
         "rts_sphere_mesh": [u32, C.c_float, C.c_float, C.c_float, C.c_float, vp, C.POINTER(u32), vp, C.POINTER(u32), vp],
         "rts_file_mesh": [C.c_char_p, C.c_char_p, C.c_float, C.c_float, C.c_float, vp, vp, vp, C.POINTER(u32)],
         "rts_rx_sphere": [vp, dbl, dbl, dbl, dbl, dbl, C.POINTER(RtsReceiverSphere)],
-        "rts_get_bvh": [vp, vp, vp, u32, u32],
+        "rts_get_bvh": [vp, vp, vp, vp, u32, u32, vp],
         "rts_cube_attach": [vp, C.POINTER(RtsCubeParams), vp],
         "rts_cube_accumulate": [vp, u32, dbl, dbl],
         "rts_cube_get": [vp, vp, u64],

@@ -73,7 +73,7 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     hipDeviceProp_t prop; e = hipGetDeviceProperties(&prop, p->device);
     if (e != hipSuccess) { delete c; rts_set_error("hipGetDeviceProperties: %s", hipGetErrorString(e)); return RTS_ERR_HIP; }
     c->n_cu = prop.multiProcessorCount;
-    { const char* e = getenv("RTS_PT"); if (e) c->pt_mode = (e[0] != '0'); }      // RTS_PT=1: persistent-wave kernel with lane refill (A/B)
+    { const char* e = getenv("RTS_STACK_LDS_DEBUG"); if (e) { int v = atoi(e); if (v >= 1 && v <= RTS_STACK_LDS) c->stack_lds = (uint32_t)v; } }   // tests: force the spill path
     *out = c;
     return RTS_OK;
 }
@@ -85,9 +85,8 @@ extern "C" int rts_destroy(RtsHandle c)
     (void)hipStreamSynchronize(c->stream);
     c->d_tri_vidx.release(); c->d_tri_nidx.release(); c->d_vert_targ.release(); c->d_norm_targ.release(); c->d_prim_targ.release();
     c->d_verts_local.release(); c->d_normals_local.release(); c->d_verts_world.release(); c->d_normals_world.release();
-    c->d_motion.release(); c->d_targets.release(); c->d_prim_box.release(); c->d_node_box.release(); c->d_keys.release(); c->d_keys_sorted.release();
-    c->d_vals.release(); c->d_vals_sorted.release(); c->d_bounds.release(); c->d_parent.release(); c->d_leaf_parent.release(); c->d_flags.release();
-    c->d_nodes.release(); c->d_nodes4.release(); c->d_leaves.release(); c->d_sort_tmp.release(); c->d_rx.release(); c->d_recv.release(); c->d_all.release();
+    c->d_motion.release(); c->d_targets.release(); c->d_leaf_prim.release();
+    c->d_nodes4.release(); c->d_leaves.release(); c->d_sort_tmp.release(); c->d_rx.release(); c->d_recv.release(); c->d_all.release();
     c->d_counters.release(); c->d_lc.release(); c->d_dir_hist.release(); c->d_child.release(); c->d_rk64.release(); c->d_rk64_sorted.release(); c->d_hit_prim.release(); c->d_hit_t.release(); c->d_stack_ovf.release();
     c->d_rk.release(); c->d_rk_sorted.release(); c->d_ri.release(); c->d_ri_sorted.release(); c->d_rx_rays.release(); c->d_rx_paths.release();
     c->d_rx_angles.release(); c->d_rx_slots.release(); c->d_all_rays.release(); c->d_all_paths.release(); c->d_all_angles.release();
@@ -163,7 +162,20 @@ extern "C" int rts_set_scene(RtsHandle c, const RtsMesh* meshes, uint32_t n_targ
         for (uint32_t i = 0; i < m.n_vertices; i++) { vtarg[(size_t)h.vert_base + i] = t; for (int k = 0; k < 3; k++) verts[3*((size_t)h.vert_base + i) + k] = m.vertices[3*(size_t)i + k]; }
         for (uint32_t i = 0; i < m.n_normals; i++) { ntarg[(size_t)h.normal_base + i] = t; for (int k = 0; k < 3; k++) normals[3*((size_t)h.normal_base + i) + k] = m.normals[3*(size_t)i + k]; }
     }
+    // static target-space hierarchy, one per mesh (rts_sah.cpp); leaf slots name GLOBAL primitive ids
+    std::vector<RtsNode4> nodes4; std::vector<uint32_t> leaf_prim; std::vector<RtsBlasInfo> blas(n_targets);
+    nodes4.reserve(nt / 2 + 4); leaf_prim.reserve(nt);
+    for (uint32_t t = 0; t < n_targets; t++) {
+        const RtsMesh& m = meshes[t];
+        const size_t leaf0 = leaf_prim.size();
+        int rc = rts_sah_build(m.vertices, m.triangles, m.n_triangles, nodes4, leaf_prim, blas[t]); if (rc != RTS_OK) return rc;
+        for (size_t i = leaf0; i < leaf_prim.size(); i++) leaf_prim[i] += mh[t].tri_base;
+    }
     RTS_HIP(hipStreamSynchronize(c->stream));
+    RTS_HIP(c->d_nodes4.reserve(nodes4.size() + 1)); RTS_HIP(c->d_leaf_prim.reserve(leaf_prim.size() + 1)); RTS_HIP(c->d_leaves.reserve(leaf_prim.size() + 1));
+    if (!nodes4.empty()) RTS_HIP(hipMemcpy(c->d_nodes4.p, nodes4.data(), sizeof(RtsNode4)*nodes4.size(), hipMemcpyHostToDevice));
+    if (!leaf_prim.empty()) RTS_HIP(hipMemcpy(c->d_leaf_prim.p, leaf_prim.data(), sizeof(uint32_t)*leaf_prim.size(), hipMemcpyHostToDevice));
+    c->blas = blas; c->n_nodes = (uint32_t)nodes4.size(); c->n_leaves = (uint32_t)leaf_prim.size();
     RTS_HIP(c->d_tri_vidx.reserve(3*nt + 1)); RTS_HIP(c->d_tri_nidx.reserve(3*nt + 1)); RTS_HIP(c->d_vert_targ.reserve(nv + 1)); RTS_HIP(c->d_norm_targ.reserve(nn + 1));
     RTS_HIP(c->d_prim_targ.reserve(nt + 1)); RTS_HIP(c->d_verts_local.reserve(3*nv + 1)); RTS_HIP(c->d_normals_local.reserve(3*nn + 1));
     RTS_HIP(c->d_verts_world.reserve(3*nv + 1)); RTS_HIP(c->d_normals_world.reserve(3*nn + 1));
@@ -234,6 +246,41 @@ static void fill_launch_constants(RtsLaunchConsts& a, const RtsPulse& p, uint32_
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) a.rot1[3*i + j] = Rot1[i][j];
 }
 
+// Per-target placement constants of a pulse: inverse rotation, world bounds of the placed hierarchy, error slack.
+static int fill_target_placement(const RtsContext* c, uint32_t t, RtsTargetDev& td)
+{
+    const RtsTargetMotion& m = c->motion[t]; const RtsBlasInfo& b = c->blas[t];
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (m.has_rotation) for (int k = 0; k < 9; k++) R[k] = m.rotation[k];
+    for (int k = 0; k < 9; k++) if (!std::isfinite(R[k])) { rts_set_error("rts_trace_pulse: target %u has a non-finite rotation", t); return RTS_ERR_INVALID; }
+    // the hierarchy is rigid: R must be a rotation up to rounding (the reference's are products of float-trig
+    // axis rotations, ray_tracer.cpp:95-118, orthonormal to ~1e-7)
+    double dev = 0;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        double g = 0; for (int k = 0; k < 3; k++) g += R[3*k + i] * R[3*k + j];
+        dev = std::max(dev, std::fabs(g - (i == j ? 1.0 : 0.0)));
+    }
+    if (!(dev < 1e-3)) { rts_set_error("rts_trace_pulse: target %u: rotation is not orthonormal (|R^T R - I| = %.3g); only rigid placements are supported", t, dev); return RTS_ERR_UNSUPPORTED; }
+    const double det = R[0]*(R[4]*R[8] - R[5]*R[7]) - R[1]*(R[3]*R[8] - R[5]*R[6]) + R[2]*(R[3]*R[7] - R[4]*R[6]);
+    const double id = 1.0 / det;
+    td.rinv[0] = (R[4]*R[8] - R[5]*R[7]) * id; td.rinv[1] = (R[2]*R[7] - R[1]*R[8]) * id; td.rinv[2] = (R[1]*R[5] - R[2]*R[4]) * id;
+    td.rinv[3] = (R[5]*R[6] - R[3]*R[8]) * id; td.rinv[4] = (R[0]*R[8] - R[2]*R[6]) * id; td.rinv[5] = (R[2]*R[3] - R[0]*R[5]) * id;
+    td.rinv[6] = (R[3]*R[7] - R[4]*R[6]) * id; td.rinv[7] = (R[1]*R[6] - R[0]*R[7]) * id; td.rinv[8] = (R[0]*R[4] - R[1]*R[3]) * id;
+    td.px = m.position[0]; td.py = m.position[1]; td.pz = m.position[2];
+    td.root = b.root;
+    // bounding sphere of the placed hierarchy: image of the local box centre, half diagonal stretched by the
+    // rotation's deviation from orthonormality, padded by 1e-6 of the world scale
+    double cl[3], half2 = 0, wc[3], wmax = 0;
+    for (int i = 0; i < 3; i++) { cl[i] = 0.5 * b.lo[i] + 0.5 * b.hi[i]; const double h = 0.5 * (b.hi[i] - b.lo[i]); half2 += h * h; }
+    for (int i = 0; i < 3; i++) { wc[i] = R[3*i]*cl[0] + R[3*i + 1]*cl[1] + R[3*i + 2]*cl[2] + m.position[i]; wmax = std::max(wmax, std::fabs(wc[i])); }
+    double rad = std::sqrt(half2) * (1.0 + 2.0 * dev); wmax += rad;
+    rad = rad * (1.0 + 1e-6) + wmax * 1e-6 + 1e-30;
+    td.cx = wc[0]; td.cy = wc[1]; td.cz = wc[2]; td.r2 = rad * rad;
+    td.ew = (float)(wmax * 4.0e-9) + 1.0e-30f;
+    if (b.root < 0 || !std::isfinite(td.cx + td.cy + td.cz + td.r2)) td.root = -1;
+    return RTS_OK;
+}
+
 // ------------------------------------------------------------------------------------- launch
 extern "C" int rts_trace_pulse(RtsHandle c, const RtsPulse* p)
 {
@@ -282,14 +329,15 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
         for (uint32_t t = 0; t < n_targets; t++) {
             td[t].reflCoeff = c->meshes[t].refl_coeff; td[t].vx = c->motion[t].velocity[0]; td[t].vy = c->motion[t].velocity[1]; td[t].vz = c->motion[t].velocity[2];
             td[t].tri_base = c->meshes[t].tri_base; td[t].perface_normals = c->meshes[t].perface ? 1u : 0u; td[t].refrIndex = c->meshes[t].refr_index;
+            int rc = fill_target_placement(c, t, td[t]); if (rc != RTS_OK) { c->bvh_valid = false; c->motion_valid = false; return rc; }
             c->pin->motion[t] = c->motion[t];
         }
         if (n_targets) {
             RTS_HIP(hipMemcpyAsync(c->d_motion.p, c->pin->motion, sizeof(RtsTargetMotion)*n_targets, hipMemcpyHostToDevice, st));
             RTS_HIP(hipMemcpyAsync(c->d_targets.p, td, sizeof(RtsTargetDev)*n_targets, hipMemcpyHostToDevice, st));
         }
-        int rc = rts_bvh_build(c); if (rc != RTS_OK) return rc;
-        RTS_STAGE(c, "bvh_build");
+        int rc = rts_scene_place(c); if (rc != RTS_OK) return rc;
+        RTS_STAGE(c, "scene_place");
         c->bvh_valid = true; c->stats.bvh_rebuilt = 1;
     }
     RTS_HIP(hipEventRecord(c->ev[1], st));
@@ -330,7 +378,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
         RTS_HIP(hipMemsetAsync(c->d_hit_t.p, 0, sizeof(float) * (size_t)n * (c->params.max_refl + 1), st));
     }
     RTS_HIP(hipMemsetAsync(c->d_counters.p, 0, sizeof(unsigned long long) * 16, st));
-    a.nodes = c->d_nodes.p; a.nodes4 = c->d_nodes4.p; a.leaves = c->d_leaves.p; a.tri_nidx = c->d_tri_nidx.p; a.normals = c->d_normals_world.p;
+    a.nodes4 = c->d_nodes4.p; a.stack_lds = c->stack_lds; a.leaves = c->d_leaves.p; a.tri_nidx = c->d_tri_nidx.p; a.normals = c->d_normals_world.p;
     a.targets = c->d_targets.p; a.rx = c->d_rx.p;
     a.recv_records = c->d_recv.p; a.all_records = c->d_all.p; a.counters = c->d_counters.p; a.dir_hist = c->d_dir_hist.p;
     a.hit_prim = c->d_hit_prim.p; a.hit_t = c->d_hit_t.p; a.stack_ovf = c->d_stack_ovf.p; a.child = c->d_child.p;
@@ -341,7 +389,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     RTS_HIP(hipEventRecord(c->ev[8], st));                       // scene + per-pulse buffers of this handle are ready
     RTS_HIP(hipStreamWaitEvent(c->tstream, c->ev[8], 0));
     RTS_HIP(hipEventRecord(c->ev[2], c->tstream));
-    int rc = (c->pt_mode && !keep_all && a.max_refr == 0) ? rts_trace_launch_pt(c, a, count_trav) : rts_trace_launch(c, a, count_trav);
+    int rc = rts_trace_launch(c, a, count_trav);
     if (rc != RTS_OK) return rc;
     RTS_STAGE(c, "k_trace");
     RTS_HIP(hipEventRecord(c->ev[3], c->tstream));
@@ -663,14 +711,15 @@ void kernel_wrapper(PerRayData* h_rx_results_arr, int* h_rx_intersects_arr, unsi
 }
 
 // ------------------------------------------------------------------------------------- introspection
-extern "C" int rts_get_bvh(RtsHandle c, void* nodes64, uint32_t* leaf_prim, uint32_t node_capacity, uint32_t prim_capacity)
+extern "C" int rts_get_bvh(RtsHandle c, void* nodes128, uint32_t* leaf_prim, int32_t* roots, uint32_t node_capacity, uint32_t leaf_capacity, uint32_t* n_leaves)
 {
     CHECK_HANDLE(c);
-    if (!c->bvh_valid) { rts_set_error("rts_get_bvh: no BVH built yet"); return RTS_ERR_INVALID; }
-    if (node_capacity < c->n_nodes || prim_capacity < c->n_prims) { rts_set_error("rts_get_bvh: capacity too small"); return RTS_ERR_CAPACITY; }
+    if (n_leaves) *n_leaves = c->n_leaves;
+    if (node_capacity < c->n_nodes || leaf_capacity < c->n_leaves) { rts_set_error("rts_get_bvh: capacity too small (%u nodes, %u leaves)", c->n_nodes, c->n_leaves); return RTS_ERR_CAPACITY; }
     RTS_HIP(hipStreamSynchronize(c->stream));
-    if (nodes64 && c->n_nodes) RTS_HIP(hipMemcpy(nodes64, c->d_nodes.p, sizeof(RtsNode)*c->n_nodes, hipMemcpyDeviceToHost));
-    if (leaf_prim && c->n_prims) RTS_HIP(hipMemcpy(leaf_prim, c->d_vals_sorted.p, sizeof(uint32_t)*c->n_prims, hipMemcpyDeviceToHost));
+    if (nodes128 && c->n_nodes) RTS_HIP(hipMemcpy(nodes128, c->d_nodes4.p, sizeof(RtsNode4)*c->n_nodes, hipMemcpyDeviceToHost));
+    if (leaf_prim && c->n_leaves) RTS_HIP(hipMemcpy(leaf_prim, c->d_leaf_prim.p, sizeof(uint32_t)*c->n_leaves, hipMemcpyDeviceToHost));
+    if (roots) for (size_t t = 0; t < c->blas.size(); t++) roots[t] = c->blas[t].root;
     return RTS_OK;
 }
 

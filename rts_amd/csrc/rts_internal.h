@@ -8,29 +8,18 @@
 #include "rts_device_math.h"
 
 // ----------------------------------------------------------------------------- HBM layout
-// BVH2 node, 64 B = one half cache line, fetched as 4 x dwordx4 by the lane that visits it.
-// A node stores the (padded, f32) boxes of its two children, so one fetch decides both.
-struct __attribute__((aligned(64))) RtsNode {
-    float lo0x, lo0y, lo0z, hi0x;   // q0
-    float hi0y, hi0z, lo1x, lo1y;   // q1
-    float lo1z, hi1x, hi1y, hi1z;   // q2
-    int32_t c0, c1;                 // q3: child >= 0 -> node index, < 0 -> ~leaf index
-    int32_t pad0, pad1;
-};
-static_assert(sizeof(RtsNode) == 64, "node size");
-
-// BVH4 node, 128 B, collapsed from the BVH2 (a node's children are its grandchildren, or a child itself when that
-// child is a leaf): half the dependent fetch round-trips per ray.  SoA over the four children so that one
-// dwordx4 load brings the same plane of all four boxes.  Unused slots: empty box (never hit).
+// BVH4 node, 128 B = one cache line, of the static target-space hierarchy (rts_sah.cpp): half the dependent fetch
+// round-trips of a binary tree per ray.  SoA over the four children so that one dwordx4 load brings the same plane of
+// all four (padded, f32, TARGET-SPACE) boxes.  Unused slots: empty box (never hit).
 struct __attribute__((aligned(128))) RtsNode4 {
     float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4];
-    int32_t child[4];               // >= 0 -> BVH2 node index (its RtsNode4 record), < 0 -> ~leaf index
+    int32_t child[4];               // >= 0 -> node index, < 0 -> ~leaf slot, 0x7fffffff -> unused
     int32_t pad[4];
 };
 static_assert(sizeof(RtsNode4) == 128, "node4 size");
 
-// Leaf record, 80 B, in Morton (leaf) order: the three f64 vertices the f64 intersection
-// test needs, pre-gathered (the reference gathers through dbuf_triangles ->
+// Leaf record, 80 B, in the hierarchy's (depth-first) leaf order, refreshed every pulse: the three f64 WORLD-space
+// vertices the f64 intersection test needs, pre-gathered (the reference gathers through dbuf_triangles ->
 // dbuf_triVertices per test, triangle_mesh.cu:147-154), plus the global primitive id.
 struct __attribute__((aligned(16))) RtsLeafTri {
     double p0x, p0y, p0z, p1x, p1y, p1z, p2x, p2y, p2z;
@@ -45,7 +34,17 @@ struct RtsTargetDev {               // per target, per pulse
     double vx, vy, vz;              // dbuf_targ_vel[targ]
     uint32_t tri_base;              // first global primitive id
     uint32_t perface_normals;       // triangle_mesh.cu:178 (normals.size() > vertices.size())
+    // placement of the target's static hierarchy for this pulse: local = rinv * (world - pos)
+    double rinv[9];                 // inverse of the pulse's rotation (identity when the target does not rotate)
+    double px, py, pz;
+    double cx, cy, cz, r2;          // bounding sphere of the placed target (world space, radius^2, padded)
+    float ew;                       // extra origin slack of the target-space slab test [m]: covers the rounding of the world
+                                    // vertices, of the exact test and of the world -> target mapping (~1e-12 of the world scale)
+    int32_t root;                   // root node of the target's hierarchy, < 0: no (finite) geometry
 };
+
+// One mesh's slice of the static hierarchy (host side).
+struct RtsBlasInfo { int32_t root; uint32_t n_nodes, n_leaves, depth; double lo[3], hi[3], max_abs; };
 
 struct RtsRxDev { double cx, cy, cz, radius, minTheta, maxTheta, minPhi, maxPhi; };
 
@@ -75,7 +74,7 @@ static_assert(sizeof(RtsChildState) == 128, "child state size");
 
 #define RTS_BLOCK 256
 #define RTS_STACK_LDS 24            // traversal stack entries kept in LDS per lane
-#define RTS_STACK_OVF 128           // further entries spilled to global memory (rare); BVH4 pushes up to 3 per level
+#define RTS_STACK_OVF 128           // further entries spilled to global memory (rare); a BVH4 node pushes up to 3 entries
 
 // Launch constants of ray_generation (hoisted trig, ray_tracer.cu:155-203).  Device resident and
 // read through a pointer: keeping these 30 doubles as by-value kernel arguments pinned ~60
@@ -101,7 +100,6 @@ struct RtsTraceArgs {
     uint32_t max_refr, rows;        // 0 or 2; output rows per launch index (1 or max_refl + 3)
     RtsChildState* child;           // [2][grid threads] (refraction only)
     // scene
-    const RtsNode* nodes;
     const RtsNode4* nodes4;
     const RtsLeafTri* leaves;
     const uint32_t* tri_nidx;       // [n_prims][3] indices into normals
@@ -117,6 +115,7 @@ struct RtsTraceArgs {
     float* hit_t;                   // [n_rays][max_refl+1] (keep_all)
     int32_t* stack_ovf;             // [RTS_STACK_OVF][grid threads]
     uint32_t total_threads;
+    uint32_t stack_lds;             // LDS stack entries in use (RTS_STACK_LDS; smaller only to exercise the spill path in tests)
 };
 
 // ----------------------------------------------------------------------------- host context
@@ -170,21 +169,19 @@ struct RtsContext {
     uint32_t n_prims = 0, n_verts = 0, n_normals = 0;
     DevBuf<uint32_t> d_tri_vidx, d_tri_nidx, d_vert_targ, d_norm_targ, d_prim_targ;
     DevBuf<double> d_verts_local, d_normals_local, d_verts_world, d_normals_world;
-    std::vector<RtsTargetMotion> motion; bool motion_valid = false; bool bvh_valid = false;
+    std::vector<RtsTargetMotion> motion; bool motion_valid = false; bool bvh_valid = false;   // bvh_valid: scene placed for `motion`
     DevBuf<RtsTargetMotion> d_motion;
     DevBuf<RtsTargetDev> d_targets;
-    // BVH
-    DevBuf<float> d_prim_box, d_node_box; DevBuf<uint64_t> d_keys, d_keys_sorted; DevBuf<uint32_t> d_vals, d_vals_sorted;
-    DevBuf<uint32_t> d_bounds; DevBuf<int32_t> d_parent, d_leaf_parent; DevBuf<uint32_t> d_flags;
-    DevBuf<RtsNode> d_nodes; DevBuf<RtsNode4> d_nodes4; DevBuf<RtsLeafTri> d_leaves; DevBuf<char> d_sort_tmp;
-    uint32_t n_nodes = 0;
+    // hierarchy: static nodes + leaf order (set_scene), leaf records refreshed per pulse
+    std::vector<RtsBlasInfo> blas; uint32_t n_nodes = 0, n_leaves = 0; uint32_t stack_lds = RTS_STACK_LDS;
+    DevBuf<RtsNode4> d_nodes4; DevBuf<uint32_t> d_leaf_prim; DevBuf<RtsLeafTri> d_leaves; DevBuf<char> d_sort_tmp;
     // receivers
     DevBuf<RtsRxDev> d_rx; uint32_t n_rx = 0;
     // per pulse
     uint64_t ray_first = 0; uint32_t n_rays = 0;
     DevBuf<RtsEndRecord> d_recv, d_all; DevBuf<unsigned long long> d_counters; DevBuf<float> d_dir_hist;
     DevBuf<int32_t> d_hit_prim; DevBuf<float> d_hit_t; DevBuf<int32_t> d_stack_ovf; DevBuf<RtsChildState> d_child;
-    DevBuf<uint64_t> d_rk64, d_rk64_sorted; int pt_mode = 0;
+    DevBuf<uint64_t> d_rk64, d_rk64_sorted;
     RtsTraceArgs last_args; RtsLaunchConsts last_lc; DevBuf<RtsLaunchConsts> d_lc;
     // received set (ordered, expanded)
     uint64_t n_recv = 0;
@@ -203,9 +200,9 @@ struct RtsContext {
 };
 
 // implemented in the .hip units
-int rts_bvh_build(RtsContext* c);
+int rts_sah_build(const double* verts, const uint32_t* tris, uint32_t n_tris, std::vector<RtsNode4>& nodes, std::vector<uint32_t>& leaf_prim, RtsBlasInfo& out);
+int rts_scene_place(RtsContext* c);
 int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a, bool count_traversal);
-int rts_trace_launch_pt(RtsContext* c, const RtsTraceArgs& a, bool count_traversal);
 int rts_post_order_and_expand(RtsContext* c);
 int rts_post_expand_all(RtsContext* c);
 int rts_cube_accumulate_device(RtsContext* c, uint32_t pulse_index, double cspeed, double carrier);

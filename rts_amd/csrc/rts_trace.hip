@@ -1,4 +1,4 @@
-// rts_trace.hip -- the hot kernel: ray generation, LBVH traversal with the f64 triangle
+// rts_trace.hip -- the hot kernel: ray generation, BVH4 traversal (target space) with the f64 triangle
 // test, reflection shading and receiver capture, for one launch (one pulse).
 //
 // Replaces the OptiX programs of the reference:
@@ -22,6 +22,31 @@
 #include "rts_raygen.h"
 #include "rts_ray_ops.h"
 
+// Conservative f32 slab test of a ray against padded f32 boxes (the traversal only has to be CONSERVATIVE with respect
+// to the f64 triangle test; the boxes are padded f32 already, rts_sah.cpp).  Error budget:
+//   o32 = fl32(o), |o - o32| <= 2^-24 |o|;  E = 3e-7 * max|o| (+ extra) covers that and the rounding of o32 +- E;
+//   near planes are measured from the origin pushed E TOWARDS them, far planes from the origin pushed E AWAY, so
+//   every per-axis interval contains the exact one; the f32 roundings of d, of 1/d, of the subtraction and of the
+//   product (5 x 2^-24 = 3e-7 relative) are covered by scaling the near reciprocal by (1 - 6e-7) and the far one by
+//   (1 + 6e-7).  Signs follow 1/d so that a zero direction component (1/d = +-inf) gives (-inf, +inf) when the
+//   origin is inside the slab (NaN products are dropped by fmaxf/fminf, which widens the interval).
+struct RtsSlabRay { float oNx, oFx, oNy, oFy, oNz, oFz, iNx, iFx, iNy, iFy, iNz, iFz; bool spx, spy, spz; };
+__device__ __forceinline__ RtsSlabRay rts_slab_setup(const dvec3& o, const dvec3& d, float extra)
+{
+    RtsSlabRay r;
+    const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
+    const float Eo = fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) * 3.0e-7f + extra + 1.0e-30f;
+    const float ivx = 1.0f / (float)d.x, ivy = 1.0f / (float)d.y, ivz = 1.0f / (float)d.z;
+    r.spx = !(ivx < 0.0f); r.spy = !(ivy < 0.0f); r.spz = !(ivz < 0.0f);
+    r.oNx = ox + (r.spx ? Eo : -Eo); r.oFx = ox - (r.spx ? Eo : -Eo);
+    r.oNy = oy + (r.spy ? Eo : -Eo); r.oFy = oy - (r.spy ? Eo : -Eo);
+    r.oNz = oz + (r.spz ? Eo : -Eo); r.oFz = oz - (r.spz ? Eo : -Eo);
+    r.iNx = ivx * 0.9999994f; r.iFx = ivx * 1.0000006f;
+    r.iNy = ivy * 0.9999994f; r.iFy = ivy * 1.0000006f;
+    r.iNz = ivz * 0.9999994f; r.iFz = ivz * 1.0000006f;
+    return r;
+}
+
 // KEEP_ALL is a template parameter, not a run-time flag: hipcc (ROCm 7.2) lowered the uniform
 // `if (a.keep_all)` to a per-lane v_cmp mask computed under the divergent exec of the bounce loop
 // and re-used it at the write-back under a different exec, so lanes that were inactive at the
@@ -33,7 +58,7 @@
 // The reference recurses depth first; the chains are independent once spawned (the payload is copied,
 // :191), so they are traced one after the other and the spawned state is parked in global memory.
 template <bool COUNT, bool KEEP_ALL, bool REFR>
-__global__ void __launch_bounds__(RTS_BLOCK) k_trace(const RtsTraceArgs a)
+__global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTraceArgs a)
 {
     __shared__ int32_t s_stack[RTS_STACK_LDS * RTS_BLOCK];
     const uint32_t tid = threadIdx.x;
@@ -74,86 +99,91 @@ __global__ void __launch_bounds__(RTS_BLOCK) k_trace(const RtsTraceArgs a)
         bool chain_start = true;               // first segment of this chain: incident epsilon, f32 direction rule below
 
         for (;;) {
-            // ------------------------------------------------------------ rtTrace: closest hit over the LBVH
+            // ------------------------------------------------------------ rtTrace: closest hit over the targets' hierarchies
             n_seg++;
             const float tmin = chain_start ? SCENE_EPS : SCENE_EPS_R;          // ray_tracer.cu:209, normal_shader.cu:242,297
             float best_t = RTS_DEFAULT_TMAX;
             int best_leaf = -1; uint32_t best_prim = 0xffffffffu;
             if (a.n_prims > 0) {
-                // f32 slab test with an explicit error budget (the traversal only has to be CONSERVATIVE with
-                // respect to the f64 triangle test; the boxes are padded f32 already, see rts_bvh.hip):
-                //   o32 = fl32(o), |o - o32| <= 2^-24 |o|;  E = 3e-7 * max|o| covers that and the rounding of o32 +- E;
-                //   near planes are measured from the origin pushed E TOWARDS them, far planes from the origin
-                //   pushed E AWAY, so every per-axis interval contains the exact one; the f32 roundings of the
-                //   subtraction, of 1/d and of the product (< 2e-7 relative) are covered by scaling the near
-                //   reciprocal by (1 - 4e-7) and the far one by (1 + 4e-7).  Signs follow 1/d so that a zero
-                //   direction component (1/d = +-inf) gives (-inf, +inf) when the origin is inside the slab.
-                const float Eo = fmaxf(fmaxf(fabsf((float)prev.x), fabsf((float)prev.y)), fabsf((float)prev.z)) * 3.0e-7f + 1.0e-30f;
-                const float ivx = (float)(1.0 / dir.x), ivy = (float)(1.0 / dir.y), ivz = (float)(1.0 / dir.z);
-                const bool spx = !(ivx < 0.0f), spy = !(ivy < 0.0f), spz = !(ivz < 0.0f);
-                const float oNx = (float)prev.x + (spx ? Eo : -Eo), oFx = (float)prev.x - (spx ? Eo : -Eo);
-                const float oNy = (float)prev.y + (spy ? Eo : -Eo), oFy = (float)prev.y - (spy ? Eo : -Eo);
-                const float oNz = (float)prev.z + (spz ? Eo : -Eo), oFz = (float)prev.z - (spz ? Eo : -Eo);
-                const float iNx = ivx * 0.9999996f, iFx = ivx * 1.0000004f;
-                const float iNy = ivy * 0.9999996f, iFy = ivy * 1.0000004f;
-                const float iNz = ivz * 0.9999996f, iFz = ivz * 1.0000004f;
                 float t_prune = RTS_DEFAULT_TMAX;
-                int sp = 0;
-                int node = 0;
-                const int SENTINEL = 0x7fffffff;
                 uint32_t steps = 0;
-                while (node != SENTINEL) {
-                    if (++steps > (1u << 24)) { hard_overflow = true; break; }   // malformed tree guard: every wave must drain
-                    if (node >= 0) {
-                        // BVH4 node: six dwordx4 planes (lo/hi x,y,z of the four children) + the four child ids
-                        const float4* np = reinterpret_cast<const float4*>(a.nodes4 + node);
-                        const float4 LX = np[0], LY = np[1], LZ = np[2], HX = np[3], HY = np[4], HZ = np[5];
-                        const int4 CH = reinterpret_cast<const int4*>(np)[6];
-                        if (COUNT) n_nodes++;
-                        const float4 NX = spx ? LX : HX, FX = spx ? HX : LX, NY = spy ? LY : HY, FY = spy ? HY : LY, NZ = spz ? LZ : HZ, FZ = spz ? HZ : LZ;
+                for (uint32_t targ = 0; targ < a.n_targets; targ++) {
+                    const RtsTargetDev& TG = a.targets[targ];                            // uniform index: scalar loads
+                    if (TG.root < 0) continue;
+                    {   // bounding sphere of the placed target (f64 on the live payload: no registers survive into the walk
+                        // below, an f32 box test here cost a wave of occupancy); radius is padded on the host
+                        const dvec3 q = mk3(TG.cx - prev.x, TG.cy - prev.y, TG.cz - prev.z);
+                        const double qq = q.x*q.x + q.y*q.y + q.z*q.z, b = q.x*dir.x + q.y*dir.y + q.z*dir.z;
+                        if (qq > TG.r2) {                                                 // origin outside the sphere
+                            const double dd = dir.x*dir.x + dir.y*dir.y + dir.z*dir.z;
+                            if (!(b > 0.0) || !(b*b >= (qq - TG.r2) * dd * 0.999999)) continue;   // pointing away, or passing outside
+                        }
+                    }
+                    // the ray in target space: local = rinv * (world - pos); an affine map keeps the ray parameter, so
+                    // slab distances compare directly with the f32 t of the exact (world-space, f64) triangle test
+                    const dvec3 q = mk3(prev.x - TG.px, prev.y - TG.py, prev.z - TG.pz);
+                    const dvec3 ol = mk3(TG.rinv[0]*q.x + TG.rinv[1]*q.y + TG.rinv[2]*q.z, TG.rinv[3]*q.x + TG.rinv[4]*q.y + TG.rinv[5]*q.z, TG.rinv[6]*q.x + TG.rinv[7]*q.y + TG.rinv[8]*q.z);
+                    const dvec3 dl = mk3(TG.rinv[0]*dir.x + TG.rinv[1]*dir.y + TG.rinv[2]*dir.z, TG.rinv[3]*dir.x + TG.rinv[4]*dir.y + TG.rinv[5]*dir.z, TG.rinv[6]*dir.x + TG.rinv[7]*dir.y + TG.rinv[8]*dir.z);
+                    const RtsSlabRay lr = rts_slab_setup(ol, dl, TG.ew);
+                    const float oNx = lr.oNx, oFx = lr.oFx, oNy = lr.oNy, oFy = lr.oFy, oNz = lr.oNz, oFz = lr.oFz;
+                    const float iNx = lr.iNx, iFx = lr.iFx, iNy = lr.iNy, iFy = lr.iFy, iNz = lr.iNz, iFz = lr.iFz;
+                    const bool spx = lr.spx, spy = lr.spy, spz = lr.spz;
+                    int sp = 0;
+                    int node = TG.root;
+                    const int SENTINEL = 0x7fffffff;
+                    while (node != SENTINEL) {
+                        if (++steps > (1u << 24)) { hard_overflow = true; break; }   // malformed tree guard: every wave must drain
+                        if (node >= 0) {
+                            // BVH4 node: six dwordx4 planes (lo/hi x,y,z of the four children) + the four child ids
+                            const float4* np = reinterpret_cast<const float4*>(a.nodes4 + node);
+                            const float4 LX = np[0], LY = np[1], LZ = np[2], HX = np[3], HY = np[4], HZ = np[5];
+                            const int4 CH = reinterpret_cast<const int4*>(np)[6];
+                            if (COUNT) n_nodes++;
+                            const float4 NX = spx ? LX : HX, FX = spx ? HX : LX, NY = spy ? LY : HY, FY = spy ? HY : LY, NZ = spz ? LZ : HZ, FZ = spz ? HZ : LZ;
 #define RTS_SLAB4(k) fmaxf(fmaxf(fmaxf((NX.k - oNx) * iNx, (NY.k - oNy) * iNy), (NZ.k - oNz) * iNz), 0.0f)
 #define RTS_SLABF4(k) fminf(fminf(fminf((FX.k - oFx) * iFx, (FY.k - oFy) * iFy), (FZ.k - oFz) * iFz), t_prune)
-                        float d0 = RTS_SLAB4(x), d1 = RTS_SLAB4(y), d2 = RTS_SLAB4(z), d3 = RTS_SLAB4(w);
-                        const float INF = __builtin_inff();
-                        if (!(d0 <= RTS_SLABF4(x))) d0 = INF;
-                        if (!(d1 <= RTS_SLABF4(y))) d1 = INF;
-                        if (!(d2 <= RTS_SLABF4(z))) d2 = INF;
-                        if (!(d3 <= RTS_SLABF4(w))) d3 = INF;
+                            float d0 = RTS_SLAB4(x), d1 = RTS_SLAB4(y), d2 = RTS_SLAB4(z), d3 = RTS_SLAB4(w);
+                            const float INF = __builtin_inff();
+                            if (!(d0 <= RTS_SLABF4(x))) d0 = INF;
+                            if (!(d1 <= RTS_SLABF4(y))) d1 = INF;
+                            if (!(d2 <= RTS_SLABF4(z))) d2 = INF;
+                            if (!(d3 <= RTS_SLABF4(w))) d3 = INF;
 #undef RTS_SLAB4
 #undef RTS_SLABF4
-                        int c0 = CH.x, c1 = CH.y, c2 = CH.z, c3 = CH.w;
-                        // sort the four (distance, child) pairs ascending (5 compare-exchanges); misses carry +inf
+                            int c0 = CH.x, c1 = CH.y, c2 = CH.z, c3 = CH.w;
+                            // sort the four (distance, child) pairs ascending (5 compare-exchanges); misses carry +inf
 #define RTS_CSWAP(da, ca, db, cb) { const bool sw = db < da; const float td = sw ? db : da; const int tc = sw ? cb : ca; db = sw ? da : db; cb = sw ? ca : cb; da = td; ca = tc; }
-                        RTS_CSWAP(d0, c0, d1, c1) RTS_CSWAP(d2, c2, d3, c3) RTS_CSWAP(d0, c0, d2, c2) RTS_CSWAP(d1, c1, d3, c3) RTS_CSWAP(d1, c1, d2, c2)
+                            RTS_CSWAP(d0, c0, d1, c1) RTS_CSWAP(d2, c2, d3, c3) RTS_CSWAP(d0, c0, d2, c2) RTS_CSWAP(d1, c1, d3, c3) RTS_CSWAP(d1, c1, d2, c2)
 #undef RTS_CSWAP
-                        // continue with the nearest, push the others farthest first
-#define RTS_PUSH(cv) { if (sp < RTS_STACK_LDS) s_stack[sp * RTS_BLOCK + tid] = (cv); \
-                       else if (sp < RTS_STACK_LDS + RTS_STACK_OVF) { a.stack_ovf[(size_t)(sp - RTS_STACK_LDS) * a.total_threads + gtid] = (cv); n_spill++; } \
+                            // continue with the nearest, push the others farthest first
+#define RTS_PUSH(cv) { if (sp < (int)a.stack_lds) s_stack[sp * RTS_BLOCK + tid] = (cv); \
+                       else if (sp < (int)a.stack_lds + RTS_STACK_OVF) { a.stack_ovf[(size_t)(sp - (int)a.stack_lds) * a.total_threads + gtid] = (cv); n_spill++; } \
                        else hard_overflow = true; \
-                       if (sp < RTS_STACK_LDS + RTS_STACK_OVF) sp++; }
-                        if (d3 < INF) RTS_PUSH(c3)
-                        if (d2 < INF) RTS_PUSH(c2)
-                        if (d1 < INF) RTS_PUSH(c1)
+                       if (sp < (int)a.stack_lds + RTS_STACK_OVF) sp++; }
+                            if (d3 < INF) RTS_PUSH(c3)
+                            if (d2 < INF) RTS_PUSH(c2)
+                            if (d1 < INF) RTS_PUSH(c1)
 #undef RTS_PUSH
-                        if (d0 < INF) node = c0;
-                        else {
-                            if (sp == 0) node = SENTINEL;
-                            else { sp--; node = (sp < RTS_STACK_LDS) ? s_stack[sp * RTS_BLOCK + tid] : a.stack_ovf[(size_t)(sp - RTS_STACK_LDS) * a.total_threads + gtid]; }
-                        }
-                    } else {
-                        const int leaf = ~node;
-                        const RtsLeafTri L = a.leaves[leaf];
-                        if (COUNT) n_tris++;
-                        const TriHit h = tri_test(L, prev, dir, tmin, RTS_DEFAULT_TMAX);
-                        if (h.ok) {
-                            const float tf = (float)h.t;                      // rtPotentialIntersection takes float, triangle_mesh.cu:167
-                            if ((tf > tmin) && (tf < best_t || (tf == best_t && L.prim < best_prim))) {
-                                best_t = tf; best_leaf = leaf; best_prim = L.prim;
-                                t_prune = f32_next_up_pos(tf);                 // keep equal-t candidates reachable
+                            if (d0 < INF) node = c0;
+                            else {
+                                if (sp == 0) node = SENTINEL;
+                                else { sp--; node = (sp < (int)a.stack_lds) ? s_stack[sp * RTS_BLOCK + tid] : a.stack_ovf[(size_t)(sp - (int)a.stack_lds) * a.total_threads + gtid]; }
                             }
+                        } else {
+                            const int leaf = ~node;
+                            const RtsLeafTri L = a.leaves[leaf];
+                            if (COUNT) n_tris++;
+                            const TriHit h = tri_test(L, prev, dir, tmin, RTS_DEFAULT_TMAX);
+                            if (h.ok) {
+                                const float tf = (float)h.t;                      // rtPotentialIntersection takes float, triangle_mesh.cu:167
+                                if ((tf > tmin) && (tf < best_t || (tf == best_t && L.prim < best_prim))) {
+                                    best_t = tf; best_leaf = leaf; best_prim = L.prim;
+                                    t_prune = f32_next_up_pos(tf);                 // keep equal-t candidates reachable
+                                }
+                            }
+                            if (sp == 0) node = SENTINEL;
+                            else { sp--; node = (sp < (int)a.stack_lds) ? s_stack[sp * RTS_BLOCK + tid] : a.stack_ovf[(size_t)(sp - (int)a.stack_lds) * a.total_threads + gtid]; }
                         }
-                        if (sp == 0) node = SENTINEL;
-                        else { sp--; node = (sp < RTS_STACK_LDS) ? s_stack[sp * RTS_BLOCK + tid] : a.stack_ovf[(size_t)(sp - RTS_STACK_LDS) * a.total_threads + gtid]; }
                     }
                 }
             }
