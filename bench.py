@@ -8,13 +8,14 @@ Workload (config.workload): BASELINE.json configs[2] -- aircraft-like 100 000-tr
 1 Tx / 4 Rx, W = 216 (10 077 696 launch indices per pulse), maxRefl = 6; the configuration the
 metric ("Mrays/s ... 100k-tri scene") is quoted on.  Synthetic mesh, isotropic antennas, RCS 1.
 
-A step is ONE PULSE end to end: target placement for that pulse (the target moves every
-pulse, so the LBVH is rebuilt on the device inside the timed region, as the reference rebuilds
-its acceleration structure every pulse), trace of the pulse's W^3 launch indices, ordering +
+A step is ONE PULSE end to end: target placement for that pulse (the target moves every pulse: world-space
+vertices, normals and leaf records are re-placed on the device inside the timed region; the hierarchy itself is
+static in target space because the reference's targets are rigid -- the reference instead has OptiX rebuild its
+acceleration structure every pulse), trace of the pulse's W^3 launch indices, ordering +
 expansion of the received rays, finalisation and group-by aggregation into the pulse's
 responses.  A "ray" in Mrays/s is one traced segment (one rtTrace of the reference: primary or
 bounce).  Pulses are independent, so each GPU keeps two of them in flight (--inflight, two linked handles): the
-trace kernels run back to back on one stream while the LBVH rebuild of the next pulse and the ordering /
+trace kernels run back to back on one stream while the scene placement of the next pulse and the ordering /
 finalisation / aggregation of the previous one run beside them on the handles' own streams.  All of that is inside
 the timed region; ms_per_step is wall time / pulses.
 
@@ -122,7 +123,7 @@ def main():
     tx = spec["tx"]; wl = spec["c"] / spec["carrier"]
 
     # --inflight handles hold the same scene and take the pulses in turn (rts_link_handles): their trace kernels run back
-    # to back, the LBVH rebuild of the next pulse and the ordering/aggregation of the previous one overlap with them
+    # to back, the scene placement of the next pulse and the ordering/aggregation of the previous one overlap with them
     trs = []
     for _ in range(max(args.inflight, 1)):
         t = api.Tracer(W, spec["max_refl"], 0, spec["smooth"], device=local_rank)
@@ -225,11 +226,11 @@ def main():
             "value": seg_all / dt / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[2]: %s, 1 Tx / %d Rx, W=%d (%d launch indices/pulse), maxRefl=%d, target moves every pulse (LBVH rebuilt per pulse)"
+            "config": {"workload": "BASELINE.json configs[2]: %s, 1 Tx / %d Rx, W=%d (%d launch indices/pulse), maxRefl=%d, target moves every pulse (re-placed on the device per pulse; static target-space BVH4)"
                                    % (spec["name"], len(spec["rx"]), W, total, spec["max_refl"]),
                        "rays_per_pulse": total, "segments_per_pulse": seg_all / args.steps, "received_per_pulse": received_all / args.steps,
                        "primary_Mrays_per_s": total * args.steps / dt / 1e6, "return_cube": "complex128 [%d rx][%d pulses][%d bins], all-reduced once per interval" % (cube.shape[0], args.steps, n_bins), "sharding": "%d-pulse interval over %d ranks: whole pulses, left-over pulses in interleaved 4096-index tiles; one group-table all-gather + one cube all-reduce per interval" % (args.steps, world),
-                       "pulses_in_flight": len(trs), "stage_ms_per_launch_rank0": {"scene+lbvh": ms_scene / launches, "trace": ms_launch, "order+finalise+aggregate": ms_post / launches}},
+                       "pulses_in_flight": len(trs), "stage_ms_per_launch_rank0": {"scene_placement": ms_scene / launches, "trace": ms_launch, "order+finalise+aggregate": ms_post / launches}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": bytes_per_seg * seg_per_launch, "kernel": "k_trace", "bytes_per_segment": bytes_per_seg,
                          "nodes_per_segment": V, "tri_tests_per_segment": T, "shaded_per_segment": Hh,
