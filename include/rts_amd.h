@@ -1,7 +1,7 @@
 /* rts_amd.h -- C-ABI of the MI355X-native RTS hot path (librts_amd.so).
  *
  * Drop-in boundary for the ray-traced radar return path of ymartin101/RTS:
- *   ray launch -> closest triangle hit (LBVH built on device) -> reflect shading ->
+ *   ray launch -> closest triangle hit (static target-space BVH4, f64 triangle test) -> reflect shading ->
  *   receiver-sphere capture -> host/device finalisation -> per-receiver path aggregation.
  * Each entry point cites the reference interface it replaces (file:line in the reference
  * repository).  Plain pointers and sizes only: no HIP, torch or C++ types.
@@ -77,7 +77,8 @@ typedef struct RtsMesh {
 typedef struct RtsTargetMotion {
     double position[3];
     double velocity[3];
-    double rotation[9];          /* row-major R_total = Rz*Ry*Rx, used only if has_rotation  */
+    double rotation[9];          /* row-major R_total = Rz*Ry*Rx, used only if has_rotation; must be a rotation
+                                  * (|R^T R - I| < 1e-3): the hierarchy is rigid, else RTS_ERR_UNSUPPORTED   */
     int32_t has_rotation;
     int32_t reserved;
 } RtsTargetMotion;
@@ -117,11 +118,11 @@ typedef struct RtsStats {
     uint64_t node_visits;        /* BVH nodes fetched   (RTS_FLAG_COUNT_TRAVERSAL only) */
     uint64_t tri_tests;          /* triangle tests      (RTS_FLAG_COUNT_TRAVERSAL only) */
     uint32_t n_prims, n_nodes;
-    float ms_scene;              /* transform + bounds + LBVH build                     */
+    float ms_scene;              /* per-pulse scene placement (vertices, normals, leaves)*/
     float ms_trace;              /* trace kernel                                        */
     float ms_compact;            /* received-ray ordering + record expansion            */
     float ms_aggregate;          /* finalise + group-by                                 */
-    uint32_t bvh_rebuilt;        /* 1 if the LBVH was rebuilt for this pulse            */
+    uint32_t bvh_rebuilt;        /* 1 if a target moved and the scene was re-placed      */
     uint32_t stack_overflows;    /* traversal stack spills to global memory             */
 } RtsStats;
 
@@ -155,7 +156,7 @@ int rts_set_receivers(RtsHandle h, const RtsReceiverSphere* rx, uint32_t n_rx); 
 
 /* ---------------------------------------------------------------- launch
  * Replaces rtContextValidate/Compile/Launch3D (ray_tracer.cpp:1126-1165): places the targets,
- * (re)builds the LBVH on the device if any target moved, traces ray_count launch indices and
+ * re-places the scene on the device if any target moved (the hierarchy is static), traces ray_count launch indices and
  * leaves the received rays on the device, ordered by ascending launch index (the order of the
  * host scan at ray_tracer.cpp:1190).  Blocking. */
 int rts_trace_pulse(RtsHandle h, const RtsPulse* pulse);
@@ -167,7 +168,7 @@ int rts_trace_pulse(RtsHandle h, const RtsPulse* pulse);
  *     rts_trace_pulse_end(hA);                // pulse k: wait for its trace, order + expand its received rays
  *     ... rts_finalise_uniform / rts_cube_accumulate / rts_aggregate on hA ...
  * rts_trace_pulse == begin + end.  Trace kernels of linked handles execute one at a time in begin order (each has the
- * whole GPU, so rts_get_stats().ms_trace stays a single-kernel time); the LBVH rebuild of the next pulse and the
+ * whole GPU, so rts_get_stats().ms_trace stays a single-kernel time); the scene placement of the next pulse and the
  * ordering / finalisation / aggregation of the previous one overlap with them on the handles' own HIP streams.
  * Entry points that read a pulse's results end a begun pulse implicitly.  One host thread per link group. */
 int rts_trace_pulse_begin(RtsHandle h, const RtsPulse* pulse);

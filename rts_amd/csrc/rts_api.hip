@@ -307,7 +307,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     hipStream_t st = c->stream;
     c->agg_valid = false; c->n_recv = 0;
 
-    // ---- scene placement: rebuild the LBVH only when a target actually moved
+    // ---- scene placement: only when a target actually moved
     RTS_HIP(hipEventRecord(c->ev[0], st));
     bool moved = !c->bvh_valid;
     if (p->motion) {

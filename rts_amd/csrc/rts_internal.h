@@ -153,7 +153,7 @@ template <typename T> struct DevBuf {
 };
 
 // Handles joined by rts_link_handles share one trace stream: their trace kernels execute one after the other, in the
-// order the pulses were begun; the rest of each pulse (scene placement + LBVH build before, ordering / finalise /
+// order the pulses were begun; the rest of each pulse (scene placement before, ordering / finalise /
 // aggregation after) runs on the handle's own (high-priority) stream and overlaps with the other handles' trace kernels.
 struct RtsGate { hipStream_t tstream = nullptr; int refs = 0; int device = 0; };
 
@@ -161,7 +161,7 @@ struct RtsContext {
     RtsParams params;
     uint32_t depth;                 // D = max_refr + max_refl
     int device;
-    hipStream_t stream = nullptr;       // scene placement, LBVH build, ordering, finalise, aggregation (high priority: short kernels)
+    hipStream_t stream = nullptr;       // scene placement, ordering, finalise, aggregation (high priority: short kernels)
     hipStream_t tstream = nullptr;      // trace kernels (the link group's, see RtsGate)
     hipEvent_t ev[9];
     // scene (static part)

@@ -71,7 +71,7 @@ def aggregate_sharded(tracer, cspeed, carrier, dist, torch):
 
 # ------------------------------------------------------------------------------- CPI-level (pulse x ray) sharding
 # A coherent processing interval is K independent pulses (ray_tracer.cpp:843) of W^3 launch indices each.
-# Whole pulses are dealt out first (K // N per rank: no replicated LBVH build, no imbalance); each of the K % N
+# Whole pulses are dealt out first (K // N per rank: no replicated scene placement, no imbalance); each of the K % N
 # left-over pulses is shared by a group of consecutive ranks that split its launch indices into INTERLEAVED
 # tiles (rays that hit cluster in launch-index space, so contiguous sub-ranges would leave most of the group
 # idle).  K = 1 is plain interleaved ray sharding of one pulse over all ranks.  The per-(receiver, path) group

@@ -150,7 +150,7 @@ def test_refraction(rts, oracle, scenes, max_refl, smooth):
 
 
 def test_aircraft_bvh_mode(rts, oracle, scenes):
-    """8 000-triangle airframe, 4 receivers: the device LBVH finds exactly the brute-force closest hits"""
+    """8 000-triangle airframe, 4 receivers: the device hierarchy finds exactly the brute-force closest hits"""
     spec = scenes.config3(W=22, detail=0.08, rx_radius=400.0)
     tr, st, o, g = full_parity(rts, oracle, spec, bvh=True)
     assert (g["hit_prim"][:, 0] >= 0).mean() > 0.1
@@ -170,7 +170,7 @@ def test_rotating_moving_target(rts, oracle, scenes):
         assert st["bvh_rebuilt"] == 1
         H.compare_full(H.oracle_trace(oracle, spec, motion=mo), tr.all_rays(n), n)
     _, st = H.gpu_trace(rts, spec, tr=tr, motion=mo)
-    assert st["bvh_rebuilt"] == 0                                        # unchanged placement: the LBVH is reused
+    assert st["bvh_rebuilt"] == 0                                        # unchanged placement: nothing is re-placed
     tr.close()
 
 
@@ -405,7 +405,7 @@ def test_adapter_end_to_end(rts, oracle, tmp_path):
 
 def test_c4_c5_shapes(rts, oracle, scenes):
     """BASELINE configs[3] and [4] at reduced size: four targets / two transmitters / eight receivers / 8 bounces,
-    and the per-pulse rotating + translating target (LBVH rebuilt every pulse)"""
+    and the per-pulse rotating + translating target (re-placed every pulse)"""
     spec = scenes.config4(W=40, detail=0.1, rx_radius=300.0)
     for tx in spec["tx_list"]:
         spec["tx"] = tx
