@@ -156,7 +156,7 @@ def main():
             acc["launches"] += 1
 
         pending = []
-        for i, (k, first, count, il) in enumerate(multigpu.plan_cpi(total, n_pulses, rank, world)):
+        for i, (k, first, count, il) in enumerate(multigpu.refine_plan(multigpu.plan_cpi(total, n_pulses, rank, world), len(trs))):
             t = trs[i % len(trs)]
             t.trace_begin(tx["origin"], tx["span"], tx["dir"], pulse_motion(spec, k0 + k), ray_first=first, ray_count=count, interleave=il)
             pending.append((t, k))

@@ -87,7 +87,7 @@ extern "C" int rts_destroy(RtsHandle c)
     c->d_verts_local.release(); c->d_normals_local.release(); c->d_verts_world.release(); c->d_normals_world.release();
     c->d_motion.release(); c->d_targets.release(); c->d_leaf_prim.release();
     c->d_nodes4.release(); c->d_leaves.release(); c->d_sort_tmp.release(); c->d_rx.release(); c->d_recv.release(); c->d_all.release();
-    c->d_counters.release(); c->d_lc.release(); c->d_dir_hist.release(); c->d_child.release(); c->d_rk64.release(); c->d_rk64_sorted.release(); c->d_hit_prim.release(); c->d_hit_t.release(); c->d_stack_ovf.release();
+    c->d_counters.release(); c->d_block_counters.release(); c->d_lc.release(); c->d_dir_hist.release(); c->d_child.release(); c->d_rk64.release(); c->d_rk64_sorted.release(); c->d_hit_prim.release(); c->d_hit_t.release(); c->d_stack_ovf.release();
     c->d_rk.release(); c->d_rk_sorted.release(); c->d_ri.release(); c->d_ri_sorted.release(); c->d_rx_rays.release(); c->d_rx_paths.release();
     c->d_rx_angles.release(); c->d_rx_slots.release(); c->d_all_rays.release(); c->d_all_paths.release(); c->d_all_angles.release();
     c->d_akeys.release(); c->d_akeys_sorted.release(); c->d_aidx.release(); c->d_aidx_sorted.release(); c->d_ghead.release(); c->d_gid.release();
@@ -372,6 +372,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     RTS_HIP(c->d_dir_hist.reserve((size_t)(a.max_refr ? 3 * (c->params.max_refl + 1) : std::max<uint32_t>(c->params.max_refl, 1)) * 3 * n + 4));
     if (a.max_refr) RTS_HIP(c->d_child.reserve((size_t)2 * a.total_threads));
     RTS_HIP(c->d_stack_ovf.reserve((size_t)RTS_STACK_OVF * a.total_threads));
+    RTS_HIP(c->d_block_counters.reserve((size_t)grid * 8));
     if (keep_all) {
         RTS_HIP(c->d_all.reserve((size_t)n * chains + 1)); RTS_HIP(c->d_hit_prim.reserve((size_t)n * (c->params.max_refl + 1) + 1)); RTS_HIP(c->d_hit_t.reserve((size_t)n * (c->params.max_refl + 1) + 1));
         rts_fill_i32(st, c->d_hit_prim.p, -2, (size_t)n * (c->params.max_refl + 1));
@@ -380,7 +381,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     RTS_HIP(hipMemsetAsync(c->d_counters.p, 0, sizeof(unsigned long long) * 16, st));
     a.nodes4 = c->d_nodes4.p; a.stack_lds = c->stack_lds; a.leaves = c->d_leaves.p; a.tri_nidx = c->d_tri_nidx.p; a.normals = c->d_normals_world.p;
     a.targets = c->d_targets.p; a.rx = c->d_rx.p;
-    a.recv_records = c->d_recv.p; a.all_records = c->d_all.p; a.counters = c->d_counters.p; a.dir_hist = c->d_dir_hist.p;
+    a.recv_records = c->d_recv.p; a.all_records = c->d_all.p; a.counters = c->d_counters.p; a.block_counters = c->d_block_counters.p; a.dir_hist = c->d_dir_hist.p;
     a.hit_prim = c->d_hit_prim.p; a.hit_t = c->d_hit_t.p; a.stack_ovf = c->d_stack_ovf.p; a.child = c->d_child.p;
     c->last_args = a;
 

@@ -109,7 +109,8 @@ struct RtsTraceArgs {
     // outputs
     RtsEndRecord* recv_records;     // appended (unordered), capacity n_rays
     RtsEndRecord* all_records;      // [n_rays] (keep_all)
-    unsigned long long* counters;   // [0] recv count [1] segments [2] shaded [3] node visits [4] tri tests [5] spills [6] hard overflow
+    unsigned long long* counters;   // [0] recv count (append atomic) [1] segments [2] shaded [3] node visits [4] tri tests [5] spills [6] hard overflow
+    unsigned long long* block_counters;   // [grid][8] per-block partial sums of counters 1..6 (k_sum_counters)
     float* dir_hist;                // [max_refl][3][n_rays] reflected directions (f32)
     int32_t* hit_prim;              // [n_rays][max_refl+1] (keep_all)
     float* hit_t;                   // [n_rays][max_refl+1] (keep_all)
@@ -179,7 +180,7 @@ struct RtsContext {
     DevBuf<RtsRxDev> d_rx; uint32_t n_rx = 0;
     // per pulse
     uint64_t ray_first = 0; uint32_t n_rays = 0;
-    DevBuf<RtsEndRecord> d_recv, d_all; DevBuf<unsigned long long> d_counters; DevBuf<float> d_dir_hist;
+    DevBuf<RtsEndRecord> d_recv, d_all; DevBuf<unsigned long long> d_counters, d_block_counters; DevBuf<float> d_dir_hist;
     DevBuf<int32_t> d_hit_prim; DevBuf<float> d_hit_t; DevBuf<int32_t> d_stack_ovf; DevBuf<RtsChildState> d_child;
     DevBuf<uint64_t> d_rk64, d_rk64_sorted;
     RtsTraceArgs last_args; RtsLaunchConsts last_lc; DevBuf<RtsLaunchConsts> d_lc;

@@ -60,7 +60,7 @@ __device__ __forceinline__ RtsSlabRay rts_slab_setup(const dvec3& o, const dvec3
 template <bool COUNT, bool KEEP_ALL, bool REFR>
 __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTraceArgs a)
 {
-    __shared__ int32_t s_stack[RTS_STACK_LDS * RTS_BLOCK];
+    __shared__ __attribute__((aligned(16))) int32_t s_stack[RTS_STACK_LDS * RTS_BLOCK];
     const uint32_t tid = threadIdx.x;
     const uint32_t gtid = blockIdx.x * RTS_BLOCK + tid;
     const RtsLaunchConsts& lc = *a.lc;
@@ -384,18 +384,44 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
       }   // chain
     }
 
-    // ------------------------------------------------------------------ counters: wave reduce, one atomic per wave
+    // ------------------------------------------------------------------ counters: wave reduce -> block reduce (LDS, the
+    // traversal stack is dead by now) -> one plain store per block; k_sum_counters adds the blocks up.  (One atomic per
+    // wave on the same two addresses -- 32 k same-line L2 atomics -- cost a fixed ~0.35 ms at the tail of every launch.)
     for (int off = 32; off > 0; off >>= 1) {
         n_seg += __shfl_down(n_seg, off); n_shaded += __shfl_down(n_shaded, off);
         if (COUNT) { n_nodes += __shfl_down(n_nodes, off); n_tris += __shfl_down(n_tris, off); }
         n_spill += __shfl_down(n_spill, off);
     }
+    __syncthreads();
+    unsigned long long* s_cnt = reinterpret_cast<unsigned long long*>(s_stack);        // [waves][8]
+    const int wave = tid >> 6;
     if ((tid & 63) == 0) {
-        atomicAdd(&a.counters[1], n_seg); atomicAdd(&a.counters[2], n_shaded);
-        if (COUNT) { atomicAdd(&a.counters[3], n_nodes); atomicAdd(&a.counters[4], n_tris); }
-        if (n_spill) atomicAdd(&a.counters[5], n_spill);
+        s_cnt[wave * 8 + 1] = n_seg; s_cnt[wave * 8 + 2] = n_shaded; s_cnt[wave * 8 + 3] = COUNT ? n_nodes : 0ULL;
+        s_cnt[wave * 8 + 4] = COUNT ? n_tris : 0ULL; s_cnt[wave * 8 + 5] = n_spill;
     }
-    if (hard_overflow) atomicAdd(&a.counters[6], 1ULL);
+    const bool any_overflow = __syncthreads_or(hard_overflow ? 1 : 0) != 0;
+    if (tid >= 1 && tid <= 6) {
+        unsigned long long v = 0;
+        if (tid <= 5) { for (int w = 0; w < RTS_BLOCK / 64; w++) v += s_cnt[w * 8 + tid]; }
+        else v = any_overflow ? 1ULL : 0ULL;
+        a.block_counters[(size_t)blockIdx.x * 8 + tid] = v;
+    }
+}
+
+// counters[1..6] = sum over the blocks of a launch (single block; the launch has at most a few thousand blocks)
+__global__ void k_sum_counters(const unsigned long long* __restrict__ block_counters, unsigned int n_blocks, unsigned long long* __restrict__ counters)
+{
+    __shared__ unsigned long long s[256];
+    const unsigned int k = threadIdx.x & 7u, lane = threadIdx.x >> 3;                   // 32 partial sums per counter
+    unsigned long long v = 0;
+    if (k >= 1 && k <= 6) for (unsigned int b = lane; b < n_blocks; b += 32) v += block_counters[(size_t)b * 8 + k];
+    s[threadIdx.x] = v;
+    __syncthreads();
+    if (threadIdx.x >= 1 && threadIdx.x <= 6) {
+        unsigned long long t = 0;
+        for (unsigned int l = 0; l < 32; l++) t += s[l * 8 + threadIdx.x];
+        counters[threadIdx.x] = t;
+    }
 }
 
 int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a, bool count_traversal)
@@ -414,6 +440,7 @@ int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a, bool count_traversal)
         case 6: k_trace<false, true, true><<<grid, RTS_BLOCK, 0, st>>>(a); break;
         default: k_trace<true, true, true><<<grid, RTS_BLOCK, 0, st>>>(a); break;
     }
+    k_sum_counters<<<1, 256, 0, st>>>(a.block_counters, grid, a.counters);
     RTS_HIP(hipGetLastError());
     return RTS_OK;
 }

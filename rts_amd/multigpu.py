@@ -93,6 +93,21 @@ def plan_cpi(total_rays, n_pulses, rank, world):
     return out
 
 
+def refine_plan(plan, min_items):
+    """split items until the rank owns at least `min_items` of them, so that it can keep that many pulses (or pulse
+    parts) in flight (rts_link_handles): the ordering/aggregation of one part then overlaps the trace of the next.
+    Part p of P (tile T) splits into parts p and p + P of 2P -- every other one of its tiles -- so the refined parts
+    are again interleaved parts of the same pulse and their row-keyed group tables merge like any others."""
+    plan = list(plan)
+    while plan and len(plan) < min_items:
+        k, first, count, il = plan.pop(0)                          # oldest first keeps the pulse order of the plan
+        tile, parts, part = il if il is not None else (IL_TILE, 1, 0)
+        if part_ray_count(count, (tile, 2 * parts, part + parts)) == 0:
+            plan.insert(0, (k, first, count, il)); break           # nothing left to split off
+        plan += [(k, first, count, (tile, 2 * parts, part)), (k, first, count, (tile, 2 * parts, part + parts))]
+    return plan
+
+
 def part_ray_count(total_rays, interleave):
     if interleave is None:
         return total_rays

@@ -161,3 +161,28 @@ def test_shard_ranges_cover_exactly():
             assert r[0][0] == 0 and sum(c for _, c in r) == total
             assert all(r[k][0] + r[k][1] == r[k + 1][0] for k in range(world - 1))
             assert max(c for _, c in r) - min(c for _, c in r) <= 1
+
+
+def test_refine_plan_partitions_the_same_indices():
+    """refine_plan (pulse parts kept in flight on linked handles) only re-partitions what the rank already owned"""
+    from rts_amd import multigpu
+
+    def indices(total, il):
+        idx = np.arange(total)
+        if il is None:
+            return idx
+        tile, parts, part = il
+        return idx[(idx // tile) % parts == part]
+
+    for total in (1000, 40 ** 3, 100000):
+        for K, N, want in [(1, 1, 2), (1, 8, 2), (8, 8, 2), (5, 8, 2), (3, 2, 2), (1, 2, 4), (16, 8, 2)]:
+            for r in range(N):
+                plan = multigpu.plan_cpi(total, K, r, N)
+                fine = multigpu.refine_plan(plan, want)
+                assert len(fine) >= min(want, len(plan)) and [p[0] for p in fine] == sorted(p[0] for p in fine)
+                for k in {p[0] for p in plan}:
+                    a = np.sort(np.concatenate([indices(total, il) for (kk, _, _, il) in plan if kk == k]))
+                    b = np.sort(np.concatenate([indices(total, il) for (kk, _, _, il) in fine if kk == k]))
+                    assert np.array_equal(a, b)
+                for (k, first, count, il) in fine:
+                    assert multigpu.part_ray_count(count, il) == len(indices(total, il))
