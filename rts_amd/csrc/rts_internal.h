@@ -116,6 +116,9 @@ struct RtsTraceArgs {
     float* hit_t;                   // [n_rays][max_refl+1] (keep_all)
     int32_t* stack_ovf;             // [RTS_STACK_OVF][grid threads]
     uint32_t total_threads;
+    const uint32_t* tile_order;     // [tiles] tile ids in descending order of their cost in the handle's previous launch (null: identity)
+    uint32_t* tile_cost;            // [tiles] out: max over the tile's waves of its duration (shader clocks >> 6, + 1)
+    unsigned long long* timeline;   // debug (RTS_TIMELINE, counting build): [grid][2] block start/end ticks, then [tiles] tile durations (100 MHz)
     uint32_t stack_lds;             // LDS stack entries in use (RTS_STACK_LDS; smaller only to exercise the spill path in tests)
 };
 
@@ -180,7 +183,8 @@ struct RtsContext {
     DevBuf<RtsRxDev> d_rx; uint32_t n_rx = 0;
     // per pulse
     uint64_t ray_first = 0; uint32_t n_rays = 0;
-    DevBuf<RtsEndRecord> d_recv, d_all; DevBuf<unsigned long long> d_counters, d_block_counters; DevBuf<float> d_dir_hist;
+    DevBuf<RtsEndRecord> d_recv, d_all; DevBuf<unsigned long long> d_counters, d_block_counters, d_timeline;
+    DevBuf<uint32_t> d_tile_cost, d_tile_key, d_tile_key_sorted, d_tile_id, d_tile_order; bool tile_hist_valid = false; uint64_t tile_hist_sig[4] = {0, 0, 0, 0}; DevBuf<float> d_dir_hist;
     DevBuf<int32_t> d_hit_prim; DevBuf<float> d_hit_t; DevBuf<int32_t> d_stack_ovf; DevBuf<RtsChildState> d_child;
     DevBuf<uint64_t> d_rk64, d_rk64_sorted;
     RtsTraceArgs last_args; RtsLaunchConsts last_lc; DevBuf<RtsLaunchConsts> d_lc;
@@ -203,6 +207,7 @@ struct RtsContext {
 // implemented in the .hip units
 int rts_sah_build(const double* verts, const uint32_t* tris, uint32_t n_tris, std::vector<RtsNode4>& nodes, std::vector<uint32_t>& leaf_prim, RtsBlasInfo& out);
 int rts_scene_place(RtsContext* c);
+int rts_tile_order_build(RtsContext* c, uint32_t n_tiles);
 int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a, bool count_traversal);
 int rts_post_order_and_expand(RtsContext* c);
 int rts_post_expand_all(RtsContext* c);

@@ -109,6 +109,26 @@ __global__ void k_expand(const RtsTraceArgs a, const RtsEndRecord* __restrict__ 
 __global__ void k_fill_i32(int32_t* p, int32_t v, size_t n) { size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
 int rts_fill_i32(hipStream_t st, int32_t* p, int32_t v, size_t n) { if (n) k_fill_i32<<<blocks_for(n, 256), 256, 0, st>>>(p, v, n); return RTS_OK; }
 
+// --------------------------------------------------------------------------- tile order of the next launch
+// tile ids in descending order of the cost they had in this handle's previous launch (stable: ties keep index order)
+__global__ void k_tile_keys(const uint32_t* __restrict__ cost, uint32_t* __restrict__ key, uint32_t* __restrict__ id, uint32_t n)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { key[i] = ~cost[i]; id[i] = i; }
+}
+
+int rts_tile_order_build(RtsContext* c, uint32_t n_tiles)
+{
+    hipStream_t st = c->stream;
+    RTS_HIP(c->d_tile_key.reserve(n_tiles)); RTS_HIP(c->d_tile_key_sorted.reserve(n_tiles)); RTS_HIP(c->d_tile_id.reserve(n_tiles)); RTS_HIP(c->d_tile_order.reserve(n_tiles));
+    k_tile_keys<<<blocks_for(n_tiles, 256), 256, 0, st>>>(c->d_tile_cost.p, c->d_tile_key.p, c->d_tile_id.p, n_tiles);
+    size_t tmp = 0;
+    RTS_HIP(rocprim::radix_sort_pairs(nullptr, tmp, c->d_tile_key.p, c->d_tile_key_sorted.p, c->d_tile_id.p, c->d_tile_order.p, n_tiles, 0, 32, st));
+    RTS_HIP(c->d_sort_tmp.reserve(tmp));
+    RTS_HIP(rocprim::radix_sort_pairs(c->d_sort_tmp.p, tmp, c->d_tile_key.p, c->d_tile_key_sorted.p, c->d_tile_id.p, c->d_tile_order.p, n_tiles, 0, 32, st));
+    return RTS_OK;
+}
+
 int rts_post_order_and_expand(RtsContext* c)
 {
     const uint32_t R = (uint32_t)c->n_recv, D = c->depth;

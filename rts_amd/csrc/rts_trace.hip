@@ -70,7 +70,25 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
     const uint32_t max_refr = REFR ? 2u : 0u;
     const uint32_t D = a.max_refl + max_refr;
 
-    for (uint32_t slot = gtid; slot < a.n_rays; slot += a.total_threads) {
+    unsigned long long tl_t0 = 0;
+    if (COUNT && a.timeline && (a.n_rays % RTS_BLOCK == 0) && tid == 0) { tl_t0 = wall_clock64(); a.timeline[(size_t)blockIdx.x * 2] = tl_t0; }
+    // Work units are tiles of RTS_BLOCK consecutive launch indices; a block's four waves take the same tiles but never
+    // wait for each other.  Tile durations are extremely skewed (median 7 us, 99.9th percentile 0.7 ms, a handful above
+    // 1 ms where rays cross fans of thin triangles), so an in-order sweep leaves a ~1 ms tail in which a few blocks finish
+    // their slow tiles on an otherwise idle GPU.  Pulses of an interval look alike, so every launch records what each tile
+    // cost (tile_cost, shader clocks >> 6) and the NEXT launch of the handle deals the tiles out in descending order of
+    // that cost, in snake order over the blocks (longest-processing-time-first with no atomics and no barriers):
+    // position p of the order is tile_order[p]; block b takes positions i*G + b on even sweeps i and i*G + G-1-b on odd.
+    const uint32_t n_tiles = (a.n_rays + RTS_BLOCK - 1) / RTS_BLOCK;
+    for (uint32_t sweep = 0, p0 = 0; p0 < n_tiles; sweep++, p0 += gridDim.x) {
+      const uint32_t tpos = p0 + ((sweep & 1u) ? gridDim.x - 1u - blockIdx.x : blockIdx.x);
+      if (tpos >= n_tiles) continue;
+      const uint32_t tile = a.tile_order ? a.tile_order[tpos] : tpos;
+      const uint32_t slot = tile * RTS_BLOCK + tid;
+      const long long tile_t0 = clock64();
+      unsigned long long tl_tile = 0;
+      if (COUNT && a.timeline && (a.n_rays % RTS_BLOCK == 0) && tid == 0) tl_tile = wall_clock64();
+      if (slot < a.n_rays) {
       uint32_t pending = 0;                   // bit k: chain k has been spawned
       uint32_t refr_code0 = 0;                // (target + 1) of chain 0's refraction, for the path prefill of rows >= 3
       for (uint32_t chain = 0; chain < (REFR ? 3u : 1u); chain++) {
@@ -382,7 +400,17 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
             }
         }
       }   // chain
+      }   // slot < n_rays
+      if (a.tile_cost && (tid & 63u) == 0) {           // one relaxed max per wave and tile (distinct addresses)
+          const unsigned long long dt = (unsigned long long)(clock64() - tile_t0) >> 6;
+          atomicMax(&a.tile_cost[tile], (unsigned int)(dt > 0xfffffffeULL ? 0xfffffffeULL : dt) + 1u);
+      }
+      if (COUNT && a.timeline && (a.n_rays % RTS_BLOCK == 0)) {                     // debug timeline (RTS_TIMELINE): per-tile duration as seen by the block's first wave
+          __syncthreads();
+          if (tid == 0) a.timeline[(size_t)gridDim.x * 2 + slot / RTS_BLOCK] = wall_clock64() - tl_tile;
+      }
     }
+    if (COUNT && a.timeline && (a.n_rays % RTS_BLOCK == 0) && tid == 0) a.timeline[(size_t)blockIdx.x * 2 + 1] = wall_clock64();
 
     // ------------------------------------------------------------------ counters: wave reduce -> block reduce (LDS, the
     // traversal stack is dead by now) -> one plain store per block; k_sum_counters adds the blocks up.  (One atomic per

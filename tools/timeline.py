@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Block / tile timeline of one k_trace launch (debug): RTS_TIMELINE=<file> makes the counting build dump, per block,
+its start and end tick (100 MHz wall clock) and, per tile of 256 launch indices, the tile's duration.
+   python tools/timeline.py [c3|c3narrow|c2]"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+out = os.path.join(ROOT, "gpurun_out", "timeline.bin")
+os.makedirs(os.path.dirname(out), exist_ok=True)
+os.environ["RTS_TIMELINE"] = out
+from rts_amd import api, scenes  # noqa: E402
+which = sys.argv[1] if len(sys.argv) > 1 else "c3"
+spec = scenes.config2(rx_radius=200.0) if which == "c2" else scenes.config3()
+if which == "c3narrow":
+    spec["tx"] = dict(spec["tx"], span=(0.004, 0.004, 0.1))
+tr = api.Tracer(spec["W"], spec["max_refl"], 0, spec["smooth"], count_traversal=True)
+tr.set_scene(spec["meshes"]); tr.set_receivers(spec["rx"]); tx = spec["tx"]
+for _ in range(3):
+    st = tr.trace(tx["origin"], tx["span"], tx["dir"], spec["motion"])
+d = np.fromfile(out, np.uint64)
+grid, ntiles = int(d[0]), int(d[1]); blk = d[2:2 + 2 * grid].reshape(grid, 2).astype(np.int64); tile = d[2 + 2 * grid:2 + 2 * grid + ntiles].astype(np.float64) / 100.0   # us
+t0 = blk[:, 0].min(); start = (blk[:, 0] - t0) / 100.0; end = (blk[:, 1] - t0) / 100.0
+print("launch %.3f ms (events), blocks %d tiles %d" % (st["ms_trace"], grid, ntiles))
+print("block start us: pct 0/25/50/75/100 =", np.percentile(start, [0, 25, 50, 75, 100]).round(1))
+print("block end   us: pct 0/25/50/75/100 =", np.percentile(end, [0, 25, 50, 75, 100]).round(1))
+print("block duration us: mean %.1f  pct 50/90/99/100 =" % (end - start).mean(), np.percentile(end - start, [50, 90, 99, 100]).round(1))
+print("tile duration us: mean %.1f  pct 50/90/99/99.9/100 =" % tile.mean(), np.percentile(tile, [50, 90, 99, 99.9, 100]).round(1), " sum %.1f ms" % (tile.sum() / 1e3))
+late = np.argsort(end)[-8:]
+print("last blocks to end:", [(int(b), round(float(start[b]), 1), round(float(end[b]), 1)) for b in late])
+busy = np.zeros(int(end.max() / 50) + 2)
+for s, e in zip(start, end):
+    busy[int(s / 50):int(e / 50) + 1] += 1
+print("resident blocks per 50 us bin:", busy.astype(int).tolist())
+slow = np.argsort(tile)[-10:]
+print("slowest tiles (tile, us):", [(int(t), round(float(tile[t]), 1)) for t in slow])
+hist, edges = np.histogram(tile, bins=[0, 5, 10, 20, 50, 100, 200, 400, 800, 1600, 1e9])
+print("tile duration histogram (us):", list(zip(edges[:-1].astype(int).tolist(), hist.tolist())))
+np.save(os.path.join(ROOT, "gpurun_out", "tile_us.npy"), tile)
