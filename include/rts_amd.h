@@ -261,7 +261,8 @@ int rts_rx_sphere(const double* rx_position, double azimuth, double elevation, d
  * The static target-space hierarchy built by rts_set_scene: nodes[RtsStats.n_nodes] as stored (128-byte records: lo x,y,z /
  * hi x,y,z planes of the four children as 6 x float[4], int32 child[4] (>= 0 node, < 0 ~leaf slot, 0x7fffffff unused),
  * int32 pad[4]); leaf_prim[*n_leaves] = global primitive id per leaf slot (primitives with a non-finite vertex have
- * none); roots[n_targets] = root node per target (-1: no geometry).  Any output may be NULL. */
+ * none; a primitive whose box is mostly empty has several slots, each boxing a part of it -- "split references");
+ * roots[n_targets] = root node per target (-1: no geometry).  Any output may be NULL (sizes: call with NULLs first). */
 int rts_get_bvh(RtsHandle h, void* nodes128, uint32_t* leaf_prim, int32_t* roots, uint32_t node_capacity,
                 uint32_t leaf_capacity, uint32_t* n_leaves);
 int rts_self_test_math(RtsHandle h, const float* y, const float* x, float* atan2f_out, const double* a,

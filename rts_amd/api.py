@@ -223,8 +223,10 @@ class Tracer:
     def bvh(self):
         """static target-space hierarchy: (nodes [n][32] float32 view of the 128-byte records, leaf_prim, roots)"""
         s = self.stats()
-        nodes = np.zeros((max(s["n_nodes"], 1), 32), np.float32); leaf = np.zeros(max(s["n_prims"], 1), np.uint32)
-        roots = np.zeros(max(self.n_targets, 1), np.int32); nl = C.c_uint32(0)
+        nl = C.c_uint32(0)
+        check(L.lib().rts_get_bvh(self.h, None, None, None, 0, 0, C.byref(nl)))        # leaf slots (>= primitives: split references)
+        nodes = np.zeros((max(s["n_nodes"], 1), 32), np.float32); leaf = np.zeros(max(nl.value, 1), np.uint32)
+        roots = np.zeros(max(self.n_targets, 1), np.int32)
         check(L.lib().rts_get_bvh(self.h, ptr(nodes), ptr(leaf), ptr(roots), nodes.shape[0], leaf.shape[0], C.byref(nl)))
         return nodes[:s["n_nodes"]], leaf[:nl.value], roots[:self.n_targets]
 

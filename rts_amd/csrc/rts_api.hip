@@ -163,12 +163,14 @@ extern "C" int rts_set_scene(RtsHandle c, const RtsMesh* meshes, uint32_t n_targ
         for (uint32_t i = 0; i < m.n_normals; i++) { ntarg[(size_t)h.normal_base + i] = t; for (int k = 0; k < 3; k++) normals[3*((size_t)h.normal_base + i) + k] = m.normals[3*(size_t)i + k]; }
     }
     // static target-space hierarchy, one per mesh (rts_sah.cpp); leaf slots name GLOBAL primitive ids
+    double split_budget = 1.0;                          // extra references for triangles whose boxes are mostly empty (rts_sah.cpp)
+    { const char* e = getenv("RTS_SPLIT_BUDGET"); if (e) { const double v = atof(e); if (v >= 0 && v <= 8) split_budget = v; } }
     std::vector<RtsNode4> nodes4; std::vector<uint32_t> leaf_prim; std::vector<RtsBlasInfo> blas(n_targets);
     nodes4.reserve(nt / 2 + 4); leaf_prim.reserve(nt);
     for (uint32_t t = 0; t < n_targets; t++) {
         const RtsMesh& m = meshes[t];
         const size_t leaf0 = leaf_prim.size();
-        int rc = rts_sah_build(m.vertices, m.triangles, m.n_triangles, nodes4, leaf_prim, blas[t]); if (rc != RTS_OK) return rc;
+        int rc = rts_sah_build(m.vertices, m.triangles, m.n_triangles, split_budget, nodes4, leaf_prim, blas[t]); if (rc != RTS_OK) return rc;
         for (size_t i = leaf0; i < leaf_prim.size(); i++) leaf_prim[i] += mh[t].tri_base;
     }
     RTS_HIP(hipStreamSynchronize(c->stream));
@@ -738,7 +740,7 @@ extern "C" int rts_get_bvh(RtsHandle c, void* nodes128, uint32_t* leaf_prim, int
 {
     CHECK_HANDLE(c);
     if (n_leaves) *n_leaves = c->n_leaves;
-    if (node_capacity < c->n_nodes || leaf_capacity < c->n_leaves) { rts_set_error("rts_get_bvh: capacity too small (%u nodes, %u leaves)", c->n_nodes, c->n_leaves); return RTS_ERR_CAPACITY; }
+    if ((nodes128 && node_capacity < c->n_nodes) || (leaf_prim && leaf_capacity < c->n_leaves)) { rts_set_error("rts_get_bvh: capacity too small (%u nodes, %u leaves)", c->n_nodes, c->n_leaves); return RTS_ERR_CAPACITY; }
     RTS_HIP(hipStreamSynchronize(c->stream));
     if (nodes128 && c->n_nodes) RTS_HIP(hipMemcpy(nodes128, c->d_nodes4.p, sizeof(RtsNode4)*c->n_nodes, hipMemcpyDeviceToHost));
     if (leaf_prim && c->n_leaves) RTS_HIP(hipMemcpy(leaf_prim, c->d_leaf_prim.p, sizeof(uint32_t)*c->n_leaves, hipMemcpyDeviceToHost));

@@ -205,7 +205,7 @@ struct RtsContext {
 };
 
 // implemented in the .hip units
-int rts_sah_build(const double* verts, const uint32_t* tris, uint32_t n_tris, std::vector<RtsNode4>& nodes, std::vector<uint32_t>& leaf_prim, RtsBlasInfo& out);
+int rts_sah_build(const double* verts, const uint32_t* tris, uint32_t n_tris, double split_budget, std::vector<RtsNode4>& nodes, std::vector<uint32_t>& leaf_prim, RtsBlasInfo& out);
 int rts_scene_place(RtsContext* c);
 int rts_tile_order_build(RtsContext* c, uint32_t n_tiles);
 int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a, bool count_traversal);

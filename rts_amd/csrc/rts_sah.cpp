@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <queue>
 #include "rts_internal.h"
 
 namespace {
@@ -99,29 +100,137 @@ void put_box(RtsNode4& o, int k, const Box& b)
     if (!ok) { o.lox[k] = o.loy[k] = o.loz[k] = 3.0e38f; o.hix[k] = o.hiy[k] = o.hiz[k] = -3.0e38f; }   // coordinates beyond f32: never hit
 }
 
+// ---- reference splitting (early split clipping).  A triangle whose box is mostly empty -- long, thin and diagonal, like
+// the fans of slivers around the pole of a lat-long tessellated ellipsoid, hundreds of which overlap each other -- is
+// entered into the hierarchy as several references, each the box of the part of the triangle inside one half of the
+// parent reference's box (split at the middle of its longest axis).  Every reference leads to the SAME exact test of the
+// whole triangle, so results cannot change; a ray near such a fan meets tens of boxes instead of hundreds.
+struct Poly { int n; double v[10][3]; };
+
+inline void poly_box(const Poly& p, Box& b) { box_empty(b); for (int i = 0; i < p.n; i++) box_grow_pt(b, p.v[i]); }
+
+// the part of convex polygon p with  sign * (x[axis] - pos) <= 0  (Sutherland-Hodgman against one plane)
+inline void poly_clip(const Poly& p, int axis, double pos, double sign, Poly& out)
+{
+    out.n = 0;
+    for (int i = 0; i < p.n; i++) {
+        const double* a = p.v[i]; const double* b = p.v[(i + 1) % p.n];
+        const double da = sign * (a[axis] - pos), db = sign * (b[axis] - pos);
+        if (da <= 0) { if (out.n < 10) { out.v[out.n][0] = a[0]; out.v[out.n][1] = a[1]; out.v[out.n][2] = a[2]; out.n++; } }
+        if ((da < 0 && db > 0) || (da > 0 && db < 0)) {
+            const double t = da / (da - db);
+            if (out.n < 10) { for (int k = 0; k < 3; k++) out.v[out.n][k] = a[k] + t * (b[k] - a[k]); out.v[out.n][axis] = pos; out.n++; }
+        }
+    }
+}
+
+struct Ref { Poly poly; Box box; uint32_t prim; };
+
+// splits ref r at the middle of its longest axis; returns the surface area saved (<= 0: not worth it)
+inline double ref_split(const Ref& r, Ref& lo, Ref& hi)
+{
+    int ax = 0; double ext = r.box.hi[0] - r.box.lo[0];
+    for (int k = 1; k < 3; k++) if (r.box.hi[k] - r.box.lo[k] > ext) { ext = r.box.hi[k] - r.box.lo[k]; ax = k; }
+    if (!(ext > 0)) return 0.0;
+    const double pos = 0.5 * r.box.lo[ax] + 0.5 * r.box.hi[ax];
+    poly_clip(r.poly, ax, pos, 1.0, lo.poly); poly_clip(r.poly, ax, pos, -1.0, hi.poly);
+    if (lo.poly.n < 3 || hi.poly.n < 3) return 0.0;
+    poly_box(lo.poly, lo.box); poly_box(hi.poly, hi.box);
+    for (int k = 0; k < 3; k++) {                                   // never outside the parent's box (clipping rounds)
+        lo.box.lo[k] = std::max(lo.box.lo[k], r.box.lo[k]); lo.box.hi[k] = std::min(lo.box.hi[k], r.box.hi[k]);
+        hi.box.lo[k] = std::max(hi.box.lo[k], r.box.lo[k]); hi.box.hi[k] = std::min(hi.box.hi[k], r.box.hi[k]);
+    }
+    lo.box.hi[ax] = pos; hi.box.lo[ax] = pos;                       // both halves contain the cut itself
+    lo.prim = hi.prim = r.prim;
+    return box_area(r.box) - (box_area(lo.box) + box_area(hi.box));
+}
+
 }  // namespace
 
 // verts: [n_verts][3] target-space vertices of the mesh; tris: [n_tris][3] indices into verts.
 // Appends the mesh's nodes to `nodes` (child links are indices into that shared array) and its leaf order to
 // `leaf_prim` (LOCAL triangle index per leaf slot; a leaf link is ~slot, slot counted over the shared array).
-int rts_sah_build(const double* verts, const uint32_t* tris, uint32_t n_tris, std::vector<RtsNode4>& nodes, std::vector<uint32_t>& leaf_prim, RtsBlasInfo& out)
+// split_budget: extra references allowed, as a fraction of the triangle count (0: one reference per triangle).
+int rts_sah_build(const double* verts, const uint32_t* tris, uint32_t n_tris, double split_budget, std::vector<RtsNode4>& nodes, std::vector<uint32_t>& leaf_prim, RtsBlasInfo& out)
 {
     out.root = -1; out.n_nodes = 0; out.n_leaves = 0; out.depth = 0;
     for (int k = 0; k < 3; k++) { out.lo[k] = 0; out.hi[k] = 0; }
     out.max_abs = 0;
-    std::vector<Box> pb; std::vector<double> cen; std::vector<uint32_t> prim_of;
-    pb.reserve(n_tris); cen.reserve(3*(size_t)n_tris); prim_of.reserve(n_tris);
+    std::vector<Ref> refs; refs.reserve(n_tris + n_tris / 2);
+    double area_sum = 0;
     for (uint32_t i = 0; i < n_tris; i++) {
-        Box b; box_empty(b); bool finite = true;
+        Ref r; r.poly.n = 3; r.prim = i; bool finite = true;
         for (int k = 0; k < 3; k++) {
             const double* p = verts + 3*(size_t)tris[3*(size_t)i + k];
             finite = finite && std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]);
-            box_grow_pt(b, p);
+            r.poly.v[k][0] = p[0]; r.poly.v[k][1] = p[1]; r.poly.v[k][2] = p[2];
         }
         if (!finite) continue;
-        pb.push_back(b); prim_of.push_back(i);
-        for (int k = 0; k < 3; k++) cen.push_back(0.5 * b.lo[k] + 0.5 * b.hi[k]);
+        poly_box(r.poly, r.box); area_sum += box_area(r.box);
+        refs.push_back(r);
     }
+    if (split_budget > 0 && !refs.empty()) {
+        const size_t n_orig = refs.size();
+        size_t extra = (size_t)(split_budget * (double)n_orig);
+        Ref lo, hi;
+        struct Cand { double gain; uint32_t ref; bool operator<(const Cand& o) const { return gain < o.gain; } };
+        {   // round 0 (half the budget), greedy by box area saved: always split the reference that saves the most; a split
+            // must save a quarter of its reference's area and a little of the mean reference area
+            const double mean_area = area_sum / (double)n_orig;
+            std::priority_queue<Cand> heap;
+            auto consider = [&](uint32_t ri) {
+                const double g = ref_split(refs[ri], lo, hi);
+                if (g > 0.25 * box_area(refs[ri].box) && g > 0.02 * mean_area) heap.push(Cand{g, ri});
+            };
+            for (uint32_t i = 0; i < (uint32_t)refs.size(); i++) consider(i);
+            size_t quota = extra / 2;
+            while (quota > 0 && !heap.empty()) {
+                const Cand c = heap.top(); heap.pop();
+                if (!(ref_split(refs[c.ref], lo, hi) > 0)) continue;
+                refs[c.ref] = lo; refs.push_back(hi); quota--; extra--;
+                consider(c.ref); consider((uint32_t)refs.size() - 1);
+            }
+        }
+        // rounds 1..3 (the rest), aimed at where boxes pile up: area saved says nothing about HOW MANY references cover
+        // the same spot (a ray through the hub of a fan of N slivers tests all N of them, however small they are).  Build
+        // a provisional tree, count for every reference how many reference boxes contain its centre, and split the
+        // references in crowded spots, most crowded and most wasteful first; recount and repeat.
+        for (int round = 0; round < 3 && extra > 0; round++) {
+            const uint32_t nr = (uint32_t)refs.size();
+            std::vector<Box> tb(nr); std::vector<double> tc(3 * (size_t)nr); std::vector<uint32_t> tidx(nr);
+            for (uint32_t i = 0; i < nr; i++) { tb[i] = refs[i].box; tidx[i] = i; for (int k = 0; k < 3; k++) tc[3*(size_t)i + k] = 0.5 * refs[i].box.lo[k] + 0.5 * refs[i].box.hi[k]; }
+            Builder T{tb, tc, tidx, {}};
+            T.nodes.reserve(2 * (size_t)nr);
+            T.build(0, nr);
+            std::priority_queue<Cand> heap;
+            std::vector<int> stack;
+            for (uint32_t i = 0; i < nr; i++) {
+                const double* c = &tc[3*(size_t)i];
+                int count = 0; stack.clear(); stack.push_back(0);
+                while (!stack.empty() && count < 4096) {
+                    const Node2& nd = T.nodes[stack.back()]; stack.pop_back();
+                    if (c[0] < nd.box.lo[0] || c[0] > nd.box.hi[0] || c[1] < nd.box.lo[1] || c[1] > nd.box.hi[1] || c[2] < nd.box.lo[2] || c[2] > nd.box.hi[2]) continue;
+                    if (nd.left < 0) count++; else { stack.push_back(nd.left); stack.push_back(nd.right); }
+                }
+                if (count < 12) continue;                             // a dozen overlapping neighbours is normal on a curved surface
+                const double g = ref_split(refs[i], lo, hi);
+                if (g > 0.10 * box_area(refs[i].box)) heap.push(Cand{(double)count * g / box_area(refs[i].box), i});
+            }
+            if (heap.empty()) break;
+            size_t quota = std::max<size_t>(extra / (size_t)(3 - round), 1);
+            while (quota > 0 && extra > 0 && !heap.empty()) {
+                const Cand c = heap.top(); heap.pop();
+                if (!(ref_split(refs[c.ref], lo, hi) > 0)) continue;
+                refs[c.ref] = lo; refs.push_back(hi); quota--; extra--;
+            }
+        }
+    }
+    std::vector<Box> pb(refs.size()); std::vector<double> cen(3 * refs.size()); std::vector<uint32_t> prim_of(refs.size());
+    for (size_t i = 0; i < refs.size(); i++) {
+        pb[i] = refs[i].box; prim_of[i] = refs[i].prim;
+        for (int k = 0; k < 3; k++) cen[3*i + k] = 0.5 * refs[i].box.lo[k] + 0.5 * refs[i].box.hi[k];
+    }
+    { std::vector<Ref>().swap(refs); }
     const uint32_t n = (uint32_t)pb.size();
     if (n == 0) return RTS_OK;
     std::vector<uint32_t> idx(n); for (uint32_t i = 0; i < n; i++) idx[i] = i;

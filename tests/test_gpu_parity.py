@@ -221,21 +221,26 @@ def test_ragged_shards_equal_whole(rts, scenes):
 
 
 def test_bvh_invariants(rts, scenes):
-    """static target-space BVH4 (rts_sah.cpp): every primitive in exactly one leaf, every node reachable exactly once from
-    its target's root, child boxes nested in the parent's and strictly containing their triangles (local coordinates)"""
+    """static target-space BVH4 (rts_sah.cpp): every node reachable exactly once from its target's root, child boxes nested
+    in the parent's; every primitive has at least one leaf slot, an unsplit primitive's box strictly contains it, and the
+    boxes of a split primitive's references together cover its vertices and its centroid (local coordinates)"""
     spec = scenes.config_multi(W=4)
+    big = scenes.config3(W=4, detail=0.2)                                        # ellipsoids with sliver fans at the poles: these get split
+    spec["meshes"] = spec["meshes"] + big["meshes"]; spec["motion"] = spec["motion"] + big["motion"]
     tr = H.gpu_tracer(rts, spec)
     H.gpu_trace(rts, spec, tr=tr)
     nodes, leaf_prim, roots = tr.bvh()
     nprim = sum(m["tris"].shape[0] for m in spec["meshes"])
-    assert len(leaf_prim) == nprim and sorted(leaf_prim) == list(range(nprim)) and len(roots) == len(spec["meshes"])
+    refs = np.bincount(leaf_prim, minlength=nprim)
+    assert len(leaf_prim) >= nprim and refs.min() >= 1 and len(roots) == len(spec["meshes"])
+    assert refs.max() > 1, "the sliver fans of the ellipsoid mesh are expected to be split"
     child = nodes[:, 24:28].copy().view(np.int32)
     lo = np.stack([nodes[:, 0:4], nodes[:, 4:8], nodes[:, 8:12]], axis=2)        # [node][child][xyz]
     hi = np.stack([nodes[:, 12:16], nodes[:, 16:20], nodes[:, 20:24]], axis=2)
-    lo_p = np.concatenate([m["verts"][m["tris"]].min(axis=1) for m in spec["meshes"]])
-    hi_p = np.concatenate([m["verts"][m["tris"]].max(axis=1) for m in spec["meshes"]])
+    tv = np.concatenate([m["verts"][m["tris"]] for m in spec["meshes"]])         # [prim][3][xyz]
     prim_targ = np.concatenate([np.full(m["tris"].shape[0], i) for i, m in enumerate(spec["meshes"])])
-    seen_nodes = np.zeros(len(nodes), bool); seen_leaves = np.zeros(nprim, bool)
+    seen_nodes = np.zeros(len(nodes), bool); seen_leaves = np.zeros(len(leaf_prim), bool)
+    covered = np.zeros((nprim, 4), bool)                                         # 3 vertices + centroid inside some reference box
     for t, root in enumerate(roots):
         assert root >= 0
         stack = [(int(root), np.full(3, -np.inf), np.full(3, np.inf))]
@@ -254,11 +259,15 @@ def test_bvh_invariants(rts, scenes):
                     leaf = ~c; assert not seen_leaves[leaf]; seen_leaves[leaf] = True
                     p = leaf_prim[leaf]
                     assert prim_targ[p] == t
-                    assert (lo[i, k].astype(np.float64) < lo_p[p]).all() and (hi[i, k].astype(np.float64) > hi_p[p]).all()   # padded outward
+                    pts = np.concatenate([tv[p], tv[p].mean(axis=0, keepdims=True)])
+                    inside = ((pts > lo[i, k].astype(np.float64)) & (pts < hi[i, k].astype(np.float64))).all(axis=1)
+                    covered[p] |= inside
+                    if refs[p] == 1:
+                        assert inside.all()                                    # padded outward
                 else:
                     stack.append((int(c), lo[i, k], hi[i, k]))
             assert used >= 1
-    assert seen_nodes.all() and seen_leaves.all()
+    assert seen_nodes.all() and seen_leaves.all() and covered.all()
     tr.close()
 
 
