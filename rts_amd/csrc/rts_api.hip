@@ -354,7 +354,8 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     c->ray_first = first; c->n_rays = n;
     const bool keep_all = (c->params.flags & RTS_FLAG_KEEP_ALL_RAYS) != 0;
     const bool count_trav = (c->params.flags & RTS_FLAG_COUNT_TRAVERSAL) != 0;
-    uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)n + RTS_BLOCK - 1) / RTS_BLOCK, (uint64_t)c->n_cu * 16);
+    static int grid_mult = 0; if (!grid_mult) { const char* e = getenv("RTS_GRID_MULT"); grid_mult = e ? std::max(1, atoi(e)) : 16; }   // blocks per CU (A/B: 16 is best on C3)
+    uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)n + RTS_BLOCK - 1) / RTS_BLOCK, (uint64_t)c->n_cu * grid_mult);
     if (grid == 0) grid = 1;
     RtsTraceArgs a; memset(&a, 0, sizeof(a));
     RtsLaunchConsts& lc = c->last_lc; memset(&lc, 0, sizeof(lc));
