@@ -87,7 +87,7 @@ extern "C" int rts_destroy(RtsHandle c)
     c->d_verts_local.release(); c->d_normals_local.release(); c->d_verts_world.release(); c->d_normals_world.release();
     c->d_motion.release(); c->d_targets.release(); c->d_leaf_prim.release();
     c->d_nodes4.release(); c->d_leaves.release(); c->d_sort_tmp.release(); c->d_rx.release(); c->d_recv.release(); c->d_all.release();
-    c->d_counters.release(); c->d_block_counters.release(); c->d_timeline.release(); c->d_tile_cost.release(); c->d_tile_key.release(); c->d_tile_key_sorted.release(); c->d_tile_id.release(); c->d_tile_order.release(); c->d_lc.release(); c->d_dir_hist.release(); c->d_child.release(); c->d_rk64.release(); c->d_rk64_sorted.release(); c->d_hit_prim.release(); c->d_hit_t.release(); c->d_stack_ovf.release();
+    c->d_counters.release(); c->d_block_counters.release(); c->d_timeline.release(); c->d_tile_cost.release(); c->d_tile_key.release(); c->d_tile_key_sorted.release(); c->d_tile_id.release(); c->d_tile_order.release(); c->d_tile_hist.release(); c->d_lc.release(); c->d_dir_hist.release(); c->d_child.release(); c->d_rk64.release(); c->d_rk64_sorted.release(); c->d_hit_prim.release(); c->d_hit_t.release(); c->d_stack_ovf.release();
     c->d_rk.release(); c->d_rk_sorted.release(); c->d_ri.release(); c->d_ri_sorted.release(); c->d_rx_rays.release(); c->d_rx_paths.release();
     c->d_rx_angles.release(); c->d_rx_slots.release(); c->d_all_rays.release(); c->d_all_paths.release(); c->d_all_angles.release();
     c->d_akeys.release(); c->d_akeys_sorted.release(); c->d_aidx.release(); c->d_aidx_sorted.release(); c->d_ghead.release(); c->d_gid.release();
@@ -187,7 +187,7 @@ extern "C" int rts_set_scene(RtsHandle c, const RtsMesh* meshes, uint32_t n_targ
     if (nv) { RTS_HIP(hipMemcpy(c->d_vert_targ.p, vtarg.data(), sizeof(uint32_t)*nv, hipMemcpyHostToDevice)); RTS_HIP(hipMemcpy(c->d_verts_local.p, verts.data(), sizeof(double)*3*nv, hipMemcpyHostToDevice)); }
     if (nn) { RTS_HIP(hipMemcpy(c->d_norm_targ.p, ntarg.data(), sizeof(uint32_t)*nn, hipMemcpyHostToDevice)); RTS_HIP(hipMemcpy(c->d_normals_local.p, normals.data(), sizeof(double)*3*nn, hipMemcpyHostToDevice)); }
     c->meshes = mh; c->n_prims = (uint32_t)nt; c->n_verts = (uint32_t)nv; c->n_normals = (uint32_t)nn;
-    c->motion.assign(n_targets, RtsTargetMotion{}); c->motion_valid = false; c->bvh_valid = false; c->tile_hist_valid = false;
+    c->motion.assign(n_targets, RtsTargetMotion{}); c->motion_valid = false; c->bvh_valid = false; c->tile_hist_n = 0; c->tile_hist_any = false; c->tile_cost_pending = false;
     return RTS_OK;
 }
 
@@ -386,17 +386,26 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     a.targets = c->d_targets.p; a.rx = c->d_rx.p;
     a.recv_records = c->d_recv.p; a.all_records = c->d_all.p; a.counters = c->d_counters.p; a.block_counters = c->d_block_counters.p; a.dir_hist = c->d_dir_hist.p;
     a.hit_prim = c->d_hit_prim.p; a.hit_t = c->d_hit_t.p; a.stack_ovf = c->d_stack_ovf.p; a.child = c->d_child.p;
-    {   // longest-tile-first order from the costs this handle measured on its previous launch of the same shape
+    {   // longest-tile-first order from what this handle's earlier launches measured per global tile (rts_post.hip)
         static int lpt = -1; if (lpt < 0) { const char* e = getenv("RTS_TILE_LPT"); lpt = (e && e[0] == '0') ? 0 : 1; }
         const uint32_t n_tiles = (n + RTS_BLOCK - 1) / RTS_BLOCK;
         const uint64_t sig[4] = {n, first, ((uint64_t)il_parts << 32) | il_tile, il_part};
-        if (lpt && n_tiles > grid) {
-            if (c->tile_hist_valid && memcmp(sig, c->tile_hist_sig, sizeof(sig)) == 0) { int rc = rts_tile_order_build(c, n_tiles); if (rc != RTS_OK) return rc; a.tile_order = c->d_tile_order.p; }
+        const bool aligned = first % RTS_BLOCK == 0 && (il_parts <= 1 || il_tile % RTS_BLOCK == 0);
+        const uint32_t n_hist = (uint32_t)((total + RTS_BLOCK - 1) / RTS_BLOCK);
+        if (lpt && aligned && n_tiles > grid) {
+            if (c->tile_hist_n != n_hist) {
+                RTS_HIP(c->d_tile_hist.reserve(n_hist)); RTS_HIP(hipMemsetAsync(c->d_tile_hist.p, 0, sizeof(uint32_t) * n_hist, st));
+                c->tile_hist_n = n_hist; c->tile_hist_any = false; c->tile_cost_pending = false;
+            }
+            if (c->tile_cost_pending || c->tile_hist_any) {
+                int rc = rts_tile_order_build(c, c->tile_cost_sig, c->tile_cost_pending, sig, n_tiles); if (rc != RTS_OK) return rc;
+                a.tile_order = c->d_tile_order.p; c->tile_hist_any = true;
+            }
             RTS_HIP(c->d_tile_cost.reserve(n_tiles));
             RTS_HIP(hipMemsetAsync(c->d_tile_cost.p, 0, sizeof(uint32_t) * n_tiles, st));
             a.tile_cost = c->d_tile_cost.p;
-            c->tile_hist_valid = true; memcpy(c->tile_hist_sig, sig, sizeof(sig));
-        } else c->tile_hist_valid = false;
+            c->tile_cost_pending = true; memcpy(c->tile_cost_sig, sig, sizeof(sig));
+        } else c->tile_cost_pending = false;                        // (costs of an unaligned or single-sweep launch are not recorded)
     }
     const char* tl_path = count_trav ? getenv("RTS_TIMELINE") : nullptr;      // debug: dump the block/tile timeline of this launch
     if (tl_path) { RTS_HIP(c->d_timeline.reserve((size_t)grid * 2 + (n + RTS_BLOCK - 1) / RTS_BLOCK + 1)); RTS_HIP(hipMemsetAsync(c->d_timeline.p, 0, sizeof(unsigned long long) * ((size_t)grid * 2 + (n + RTS_BLOCK - 1) / RTS_BLOCK + 1), st)); a.timeline = c->d_timeline.p; }

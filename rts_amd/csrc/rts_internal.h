@@ -184,7 +184,9 @@ struct RtsContext {
     // per pulse
     uint64_t ray_first = 0; uint32_t n_rays = 0;
     DevBuf<RtsEndRecord> d_recv, d_all; DevBuf<unsigned long long> d_counters, d_block_counters, d_timeline;
-    DevBuf<uint32_t> d_tile_cost, d_tile_key, d_tile_key_sorted, d_tile_id, d_tile_order; bool tile_hist_valid = false; uint64_t tile_hist_sig[4] = {0, 0, 0, 0}; DevBuf<float> d_dir_hist;
+    DevBuf<uint32_t> d_tile_cost, d_tile_key, d_tile_key_sorted, d_tile_id, d_tile_order, d_tile_hist;
+    bool tile_cost_pending = false, tile_hist_any = false; uint64_t tile_cost_sig[4] = {0, 0, 0, 0}; uint32_t tile_hist_n = 0;   // per-global-tile cost history (rts_post.hip)
+    DevBuf<float> d_dir_hist;
     DevBuf<int32_t> d_hit_prim; DevBuf<float> d_hit_t; DevBuf<int32_t> d_stack_ovf; DevBuf<RtsChildState> d_child;
     DevBuf<uint64_t> d_rk64, d_rk64_sorted;
     RtsTraceArgs last_args; RtsLaunchConsts last_lc; DevBuf<RtsLaunchConsts> d_lc;
@@ -207,7 +209,7 @@ struct RtsContext {
 // implemented in the .hip units
 int rts_sah_build(const double* verts, const uint32_t* tris, uint32_t n_tris, double split_budget, std::vector<RtsNode4>& nodes, std::vector<uint32_t>& leaf_prim, RtsBlasInfo& out);
 int rts_scene_place(RtsContext* c);
-int rts_tile_order_build(RtsContext* c, uint32_t n_tiles);
+int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_valid, const uint64_t* cur_sig, uint32_t n_tiles_cur);
 int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a, bool count_traversal);
 int rts_post_order_and_expand(RtsContext* c);
 int rts_post_expand_all(RtsContext* c);

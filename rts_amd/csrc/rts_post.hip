@@ -110,22 +110,60 @@ __global__ void k_fill_i32(int32_t* p, int32_t v, size_t n) { size_t i = (size_t
 int rts_fill_i32(hipStream_t st, int32_t* p, int32_t v, size_t n) { if (n) k_fill_i32<<<blocks_for(n, 256), 256, 0, st>>>(p, v, n); return RTS_OK; }
 
 // --------------------------------------------------------------------------- tile order of the next launch
-// tile ids in descending order of the cost they had in this handle's previous launch (stable: ties keep index order)
-__global__ void k_tile_keys(const uint32_t* __restrict__ cost, uint32_t* __restrict__ key, uint32_t* __restrict__ id, uint32_t n)
+// The handle keeps what every GLOBAL tile (256 consecutive launch indices of the W^3 lattice) cost the last time one of
+// its launches traced it, so the history carries over between launch shapes (whole pulse, contiguous shard, interleaved
+// part): a launch's local tile j is global tile (ray_first + local index of its first ray) / 256.
+struct RtsTileShape { uint64_t first; uint32_t il_tile, il_parts, il_part, n_tiles; };
+
+__device__ __forceinline__ uint32_t tile_global(const RtsTileShape& s, uint32_t j)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { key[i] = ~cost[i]; id[i] = i; }
+    const uint64_t slot = (uint64_t)j * RTS_BLOCK;
+    if (s.il_parts <= 1) return (uint32_t)((s.first + slot) / RTS_BLOCK);
+    const uint64_t t = slot / s.il_tile, r = slot - t * s.il_tile;
+    return (uint32_t)((s.first + (t * s.il_parts + s.il_part) * s.il_tile + r) / RTS_BLOCK);
 }
 
-int rts_tile_order_build(RtsContext* c, uint32_t n_tiles)
+// fold the costs measured by the previous launch into the history
+__global__ void k_tile_merge(const uint32_t* __restrict__ cost, RtsTileShape prev, uint32_t* __restrict__ hist, uint32_t n_hist)
+{
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= prev.n_tiles) return;
+    const uint32_t v = cost[j], g = tile_global(prev, j);
+    if (v && g < n_hist) hist[g] = v;
+}
+
+// sort key of local tile j of the coming launch: ~(estimated cost); a tile never traced yet takes the largest cost known
+// within 16 global tiles of it (expensive regions are contiguous in launch-index space)
+__global__ void k_tile_keys(const uint32_t* __restrict__ hist, uint32_t n_hist, RtsTileShape cur, uint32_t* __restrict__ key, uint32_t* __restrict__ id)
+{
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= cur.n_tiles) return;
+    const uint32_t g = tile_global(cur, j);
+    uint32_t est = g < n_hist ? hist[g] : 0u;
+    if (est == 0) {
+        for (uint32_t d = 1; d <= 16; d++) {
+            if (g >= d && g - d < n_hist) est = max(est, hist[g - d]);
+            if (g + d < n_hist) est = max(est, hist[g + d]);
+        }
+    }
+    key[j] = ~est; id[j] = j;
+}
+
+// prev_valid: d_tile_cost holds the costs of a launch of shape prev_shape that have not been merged yet
+int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_valid, const uint64_t* cur_sig, uint32_t n_tiles_cur)
 {
     hipStream_t st = c->stream;
-    RTS_HIP(c->d_tile_key.reserve(n_tiles)); RTS_HIP(c->d_tile_key_sorted.reserve(n_tiles)); RTS_HIP(c->d_tile_id.reserve(n_tiles)); RTS_HIP(c->d_tile_order.reserve(n_tiles));
-    k_tile_keys<<<blocks_for(n_tiles, 256), 256, 0, st>>>(c->d_tile_cost.p, c->d_tile_key.p, c->d_tile_id.p, n_tiles);
+    const uint32_t n_hist = c->tile_hist_n;
+    auto shape = [](const uint64_t* sig) { RtsTileShape s; s.first = sig[1]; s.il_tile = (uint32_t)(sig[2] & 0xffffffffu); s.il_parts = (uint32_t)(sig[2] >> 32); s.il_part = (uint32_t)sig[3];
+                                          s.n_tiles = (uint32_t)((sig[0] + RTS_BLOCK - 1) / RTS_BLOCK); return s; };
+    if (prev_valid) { const RtsTileShape p = shape(prev_sig); if (p.n_tiles) k_tile_merge<<<blocks_for(p.n_tiles, 256), 256, 0, st>>>(c->d_tile_cost.p, p, c->d_tile_hist.p, n_hist); }
+    RTS_HIP(c->d_tile_key.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_key_sorted.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_id.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_order.reserve(n_tiles_cur));
+    const RtsTileShape cur = shape(cur_sig);
+    k_tile_keys<<<blocks_for(n_tiles_cur, 256), 256, 0, st>>>(c->d_tile_hist.p, n_hist, cur, c->d_tile_key.p, c->d_tile_id.p);
     size_t tmp = 0;
-    RTS_HIP(rocprim::radix_sort_pairs(nullptr, tmp, c->d_tile_key.p, c->d_tile_key_sorted.p, c->d_tile_id.p, c->d_tile_order.p, n_tiles, 0, 32, st));
+    RTS_HIP(rocprim::radix_sort_pairs(nullptr, tmp, c->d_tile_key.p, c->d_tile_key_sorted.p, c->d_tile_id.p, c->d_tile_order.p, n_tiles_cur, 0, 32, st));
     RTS_HIP(c->d_sort_tmp.reserve(tmp));
-    RTS_HIP(rocprim::radix_sort_pairs(c->d_sort_tmp.p, tmp, c->d_tile_key.p, c->d_tile_key_sorted.p, c->d_tile_id.p, c->d_tile_order.p, n_tiles, 0, 32, st));
+    RTS_HIP(rocprim::radix_sort_pairs(c->d_sort_tmp.p, tmp, c->d_tile_key.p, c->d_tile_key_sorted.p, c->d_tile_id.p, c->d_tile_order.p, n_tiles_cur, 0, 32, st));
     return RTS_OK;
 }
 
