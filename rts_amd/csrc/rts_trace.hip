@@ -173,20 +173,31 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
 #define RTS_CSWAP(da, ca, db, cb) { const bool sw = db < da; const float td = sw ? db : da; const int tc = sw ? cb : ca; db = sw ? da : db; cb = sw ? ca : cb; da = td; ca = tc; }
                             RTS_CSWAP(d0, c0, d1, c1) RTS_CSWAP(d2, c2, d3, c3) RTS_CSWAP(d0, c0, d2, c2) RTS_CSWAP(d1, c1, d3, c3) RTS_CSWAP(d1, c1, d2, c2)
 #undef RTS_CSWAP
-                            // continue with the nearest, push the others farthest first
+                            // continue with the nearest, push the others farthest first.  Fast path (wave-uniform test): every
+                            // lane has room for three more entries in the LDS part of the stack -- plain predicated LDS stores;
+                            // otherwise the general path that may spill to the global slab.
 #define RTS_PUSH(cv) { if (sp < (int)a.stack_lds) s_stack[sp * RTS_BLOCK + tid] = (cv); \
                        else if (sp < (int)a.stack_lds + RTS_STACK_OVF) { a.stack_ovf[(size_t)(sp - (int)a.stack_lds) * a.total_threads + gtid] = (cv); n_spill++; } \
                        else hard_overflow = true; \
                        if (sp < (int)a.stack_lds + RTS_STACK_OVF) sp++; }
-                            if (d3 < INF) RTS_PUSH(c3)
-                            if (d2 < INF) RTS_PUSH(c2)
-                            if (d1 < INF) RTS_PUSH(c1)
-#undef RTS_PUSH
-                            if (d0 < INF) node = c0;
-                            else {
-                                if (sp == 0) node = SENTINEL;
-                                else { sp--; node = (sp < (int)a.stack_lds) ? s_stack[sp * RTS_BLOCK + tid] : a.stack_ovf[(size_t)(sp - (int)a.stack_lds) * a.total_threads + gtid]; }
+                            if (__all(sp + 3 <= (int)a.stack_lds)) {
+                                if (d3 < INF) { s_stack[sp * RTS_BLOCK + tid] = c3; sp++; }
+                                if (d2 < INF) { s_stack[sp * RTS_BLOCK + tid] = c2; sp++; }
+                                if (d1 < INF) { s_stack[sp * RTS_BLOCK + tid] = c1; sp++; }
+                                if (d0 < INF) node = c0;
+                                else if (sp == 0) node = SENTINEL;
+                                else { sp--; node = s_stack[sp * RTS_BLOCK + tid]; }
+                            } else {
+                                if (d3 < INF) RTS_PUSH(c3)
+                                if (d2 < INF) RTS_PUSH(c2)
+                                if (d1 < INF) RTS_PUSH(c1)
+                                if (d0 < INF) node = c0;
+                                else {
+                                    if (sp == 0) node = SENTINEL;
+                                    else { sp--; node = (sp < (int)a.stack_lds) ? s_stack[sp * RTS_BLOCK + tid] : a.stack_ovf[(size_t)(sp - (int)a.stack_lds) * a.total_threads + gtid]; }
+                                }
                             }
+#undef RTS_PUSH
                         } else {
                             const int leaf = ~node;
                             const RtsLeafTri L = a.leaves[leaf];
