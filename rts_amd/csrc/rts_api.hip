@@ -87,7 +87,7 @@ extern "C" int rts_destroy(RtsHandle c)
     c->d_verts_local.release(); c->d_normals_local.release(); c->d_verts_world.release(); c->d_normals_world.release();
     c->d_motion.release(); c->d_targets.release(); c->d_leaf_prim.release();
     c->d_nodes4.release(); c->d_leaves.release(); c->d_sort_tmp.release(); c->d_rx.release(); c->d_recv.release(); c->d_all.release();
-    c->d_counters.release(); c->d_block_counters.release(); c->d_timeline.release(); c->d_tile_cost.release(); c->d_tile_key.release(); c->d_tile_key_sorted.release(); c->d_tile_id.release(); c->d_tile_order.release(); c->d_tile_hist.release(); c->d_lc.release(); c->d_dir_hist.release(); c->d_child.release(); c->d_rk64.release(); c->d_rk64_sorted.release(); c->d_hit_prim.release(); c->d_hit_t.release(); c->d_stack_ovf.release();
+    c->d_counters.release(); c->d_block_counters.release(); c->d_timeline.release(); c->d_tile_cost.release(); c->d_tile_key.release(); c->d_tile_key_sorted.release(); c->d_tile_id.release(); c->d_tile_order.release(); c->d_tile_hist.release(); c->d_tile_ctr.release(); c->d_lc.release(); c->d_dir_hist.release(); c->d_child.release(); c->d_rk64.release(); c->d_rk64_sorted.release(); c->d_hit_prim.release(); c->d_hit_t.release(); c->d_stack_ovf.release();
     c->d_rk.release(); c->d_rk_sorted.release(); c->d_ri.release(); c->d_ri_sorted.release(); c->d_rx_rays.release(); c->d_rx_paths.release();
     c->d_rx_angles.release(); c->d_rx_slots.release(); c->d_all_rays.release(); c->d_all_paths.release(); c->d_all_angles.release();
     c->d_akeys.release(); c->d_akeys_sorted.release(); c->d_aidx.release(); c->d_aidx_sorted.release(); c->d_ghead.release(); c->d_gid.release();
@@ -354,7 +354,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     c->ray_first = first; c->n_rays = n;
     const bool keep_all = (c->params.flags & RTS_FLAG_KEEP_ALL_RAYS) != 0;
     const bool count_trav = (c->params.flags & RTS_FLAG_COUNT_TRAVERSAL) != 0;
-    static int grid_mult = 0; if (!grid_mult) { const char* e = getenv("RTS_GRID_MULT"); grid_mult = e ? std::max(1, atoi(e)) : 16; }   // blocks per CU (A/B: 16 is best on C3)
+    static int grid_mult = 0; if (!grid_mult) { const char* e = getenv("RTS_GRID_MULT"); grid_mult = e ? std::max(1, atoi(e)) : 4; }   // blocks per CU: 4 = exactly the resident set (waves draw tiles from a queue)
     uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)n + RTS_BLOCK - 1) / RTS_BLOCK, (uint64_t)c->n_cu * grid_mult);
     if (grid == 0) grid = 1;
     RtsTraceArgs a; memset(&a, 0, sizeof(a));
@@ -388,11 +388,13 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     a.hit_prim = c->d_hit_prim.p; a.hit_t = c->d_hit_t.p; a.stack_ovf = c->d_stack_ovf.p; a.child = c->d_child.p;
     {   // longest-tile-first order from what this handle's earlier launches measured per global tile (rts_post.hip)
         static int lpt = -1; if (lpt < 0) { const char* e = getenv("RTS_TILE_LPT"); lpt = (e && e[0] == '0') ? 0 : 1; }
-        const uint32_t n_tiles = (n + RTS_BLOCK - 1) / RTS_BLOCK;
+        const uint32_t n_tiles = (n + RTS_WTILE - 1) / RTS_WTILE;
         const uint64_t sig[4] = {n, first, ((uint64_t)il_parts << 32) | il_tile, il_part};
-        const bool aligned = first % RTS_BLOCK == 0 && (il_parts <= 1 || il_tile % RTS_BLOCK == 0);
-        const uint32_t n_hist = (uint32_t)((total + RTS_BLOCK - 1) / RTS_BLOCK);
-        if (lpt && aligned && n_tiles > grid) {
+        const bool aligned = first % RTS_WTILE == 0 && (il_parts <= 1 || il_tile % RTS_WTILE == 0);
+        const uint32_t n_hist = (uint32_t)((total + RTS_WTILE - 1) / RTS_WTILE);
+        RTS_HIP(c->d_tile_ctr.reserve(RTS_TILE_CTRS)); RTS_HIP(hipMemsetAsync(c->d_tile_ctr.p, 0, sizeof(uint32_t) * RTS_TILE_CTRS, st));
+        a.tile_ctr = c->d_tile_ctr.p;
+        if (lpt && aligned && n_tiles > grid * (RTS_BLOCK / RTS_WTILE)) {
             if (c->tile_hist_n != n_hist) {
                 RTS_HIP(c->d_tile_hist.reserve(n_hist)); RTS_HIP(hipMemsetAsync(c->d_tile_hist.p, 0, sizeof(uint32_t) * n_hist, st));
                 c->tile_hist_n = n_hist; c->tile_hist_any = false; c->tile_cost_pending = false;
@@ -408,7 +410,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
         } else c->tile_cost_pending = false;                        // (costs of an unaligned or single-sweep launch are not recorded)
     }
     const char* tl_path = count_trav ? getenv("RTS_TIMELINE") : nullptr;      // debug: dump the block/tile timeline of this launch
-    if (tl_path) { RTS_HIP(c->d_timeline.reserve((size_t)grid * 2 + (n + RTS_BLOCK - 1) / RTS_BLOCK + 1)); RTS_HIP(hipMemsetAsync(c->d_timeline.p, 0, sizeof(unsigned long long) * ((size_t)grid * 2 + (n + RTS_BLOCK - 1) / RTS_BLOCK + 1), st)); a.timeline = c->d_timeline.p; }
+    if (tl_path) { RTS_HIP(c->d_timeline.reserve((size_t)grid * 2 + (n + RTS_WTILE - 1) / RTS_WTILE + 1)); RTS_HIP(hipMemsetAsync(c->d_timeline.p, 0, sizeof(unsigned long long) * ((size_t)grid * 2 + (n + RTS_WTILE - 1) / RTS_WTILE + 1), st)); a.timeline = c->d_timeline.p; }
     c->last_args = a;
 
     // ---- trace
@@ -425,9 +427,9 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     c->pulse_open = true;
     if (tl_path) {
         RTS_HIP(hipStreamSynchronize(st));
-        const size_t cnt_tl = (size_t)grid * 2 + (n + RTS_BLOCK - 1) / RTS_BLOCK;
+        const size_t cnt_tl = (size_t)grid * 2 + (n + RTS_WTILE - 1) / RTS_WTILE;
         std::vector<unsigned long long> h(cnt_tl + 2);
-        h[0] = grid; h[1] = (n + RTS_BLOCK - 1) / RTS_BLOCK;
+        h[0] = grid; h[1] = (n + RTS_WTILE - 1) / RTS_WTILE;
         RTS_HIP(hipMemcpy(h.data() + 2, c->d_timeline.p, sizeof(unsigned long long) * cnt_tl, hipMemcpyDeviceToHost));
         if (FILE* f = fopen(tl_path, "wb")) { fwrite(h.data(), sizeof(unsigned long long), h.size(), f); fclose(f); }
     }

@@ -73,6 +73,8 @@ struct __attribute__((aligned(16))) RtsChildState {
 static_assert(sizeof(RtsChildState) == 128, "child state size");
 
 #define RTS_BLOCK 256
+#define RTS_WTILE 64               // work unit of the trace kernel: launch indices per wave tile
+#define RTS_TILE_CTRS 64           // striped draw counters of the tile queue
 #define RTS_STACK_LDS 24            // traversal stack entries kept in LDS per lane
 #define RTS_STACK_OVF 128           // further entries spilled to global memory (rare); a BVH4 node pushes up to 3 entries
 
@@ -116,8 +118,9 @@ struct RtsTraceArgs {
     float* hit_t;                   // [n_rays][max_refl+1] (keep_all)
     int32_t* stack_ovf;             // [RTS_STACK_OVF][grid threads]
     uint32_t total_threads;
-    const uint32_t* tile_order;     // [tiles] tile ids in descending order of their cost in the handle's previous launch (null: identity)
-    uint32_t* tile_cost;            // [tiles] out: max over the tile's waves of its duration (shader clocks >> 6, + 1)
+    const uint32_t* tile_order;     // [wave tiles] tile ids in descending order of the cost last seen by the handle (null: identity)
+    uint32_t* tile_cost;            // [wave tiles] out: duration of the tile (shader clocks >> 6, + 1)
+    uint32_t* tile_ctr;             // [RTS_TILE_CTRS] draw counters, zero at launch
     unsigned long long* timeline;   // debug (RTS_TIMELINE, counting build): [grid][2] block start/end ticks, then [tiles] tile durations (100 MHz)
     uint32_t stack_lds;             // LDS stack entries in use (RTS_STACK_LDS; smaller only to exercise the spill path in tests)
 };
@@ -184,7 +187,7 @@ struct RtsContext {
     // per pulse
     uint64_t ray_first = 0; uint32_t n_rays = 0;
     DevBuf<RtsEndRecord> d_recv, d_all; DevBuf<unsigned long long> d_counters, d_block_counters, d_timeline;
-    DevBuf<uint32_t> d_tile_cost, d_tile_key, d_tile_key_sorted, d_tile_id, d_tile_order, d_tile_hist;
+    DevBuf<uint32_t> d_tile_cost, d_tile_key, d_tile_key_sorted, d_tile_id, d_tile_order, d_tile_hist, d_tile_ctr;
     bool tile_cost_pending = false, tile_hist_any = false; uint64_t tile_cost_sig[4] = {0, 0, 0, 0}; uint32_t tile_hist_n = 0;   // per-global-tile cost history (rts_post.hip)
     DevBuf<float> d_dir_hist;
     DevBuf<int32_t> d_hit_prim; DevBuf<float> d_hit_t; DevBuf<int32_t> d_stack_ovf; DevBuf<RtsChildState> d_child;

@@ -110,17 +110,17 @@ __global__ void k_fill_i32(int32_t* p, int32_t v, size_t n) { size_t i = (size_t
 int rts_fill_i32(hipStream_t st, int32_t* p, int32_t v, size_t n) { if (n) k_fill_i32<<<blocks_for(n, 256), 256, 0, st>>>(p, v, n); return RTS_OK; }
 
 // --------------------------------------------------------------------------- tile order of the next launch
-// The handle keeps what every GLOBAL tile (256 consecutive launch indices of the W^3 lattice) cost the last time one of
+// The handle keeps what every GLOBAL wave tile (64 consecutive launch indices of the W^3 lattice) cost the last time one of
 // its launches traced it, so the history carries over between launch shapes (whole pulse, contiguous shard, interleaved
-// part): a launch's local tile j is global tile (ray_first + local index of its first ray) / 256.
+// part): a launch's local tile j is global tile (ray_first + local index of its first ray) / 64.
 struct RtsTileShape { uint64_t first; uint32_t il_tile, il_parts, il_part, n_tiles; };
 
 __device__ __forceinline__ uint32_t tile_global(const RtsTileShape& s, uint32_t j)
 {
-    const uint64_t slot = (uint64_t)j * RTS_BLOCK;
-    if (s.il_parts <= 1) return (uint32_t)((s.first + slot) / RTS_BLOCK);
+    const uint64_t slot = (uint64_t)j * RTS_WTILE;
+    if (s.il_parts <= 1) return (uint32_t)((s.first + slot) / RTS_WTILE);
     const uint64_t t = slot / s.il_tile, r = slot - t * s.il_tile;
-    return (uint32_t)((s.first + (t * s.il_parts + s.il_part) * s.il_tile + r) / RTS_BLOCK);
+    return (uint32_t)((s.first + (t * s.il_parts + s.il_part) * s.il_tile + r) / RTS_WTILE);
 }
 
 // fold the costs measured by the previous launch into the history
@@ -155,7 +155,7 @@ int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_vali
     hipStream_t st = c->stream;
     const uint32_t n_hist = c->tile_hist_n;
     auto shape = [](const uint64_t* sig) { RtsTileShape s; s.first = sig[1]; s.il_tile = (uint32_t)(sig[2] & 0xffffffffu); s.il_parts = (uint32_t)(sig[2] >> 32); s.il_part = (uint32_t)sig[3];
-                                          s.n_tiles = (uint32_t)((sig[0] + RTS_BLOCK - 1) / RTS_BLOCK); return s; };
+                                          s.n_tiles = (uint32_t)((sig[0] + RTS_WTILE - 1) / RTS_WTILE); return s; };
     if (prev_valid) { const RtsTileShape p = shape(prev_sig); if (p.n_tiles) k_tile_merge<<<blocks_for(p.n_tiles, 256), 256, 0, st>>>(c->d_tile_cost.p, p, c->d_tile_hist.p, n_hist); }
     RTS_HIP(c->d_tile_key.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_key_sorted.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_id.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_order.reserve(n_tiles_cur));
     const RtsTileShape cur = shape(cur_sig);

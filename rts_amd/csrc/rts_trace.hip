@@ -71,23 +71,39 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
     const uint32_t D = a.max_refl + max_refr;
 
     unsigned long long tl_t0 = 0;
-    if (COUNT && a.timeline && (a.n_rays % RTS_BLOCK == 0) && tid == 0) { tl_t0 = wall_clock64(); a.timeline[(size_t)blockIdx.x * 2] = tl_t0; }
-    // Work units are tiles of RTS_BLOCK consecutive launch indices; a block's four waves take the same tiles but never
-    // wait for each other.  Tile durations are extremely skewed (median 7 us, 99.9th percentile 0.7 ms, a handful above
-    // 1 ms where rays cross fans of thin triangles), so an in-order sweep leaves a ~1 ms tail in which a few blocks finish
-    // their slow tiles on an otherwise idle GPU.  Pulses of an interval look alike, so every launch records what each tile
-    // cost (tile_cost, shader clocks >> 6) and the NEXT launch of the handle deals the tiles out in descending order of
-    // that cost, in snake order over the blocks (longest-processing-time-first with no atomics and no barriers):
-    // position p of the order is tile_order[p]; block b takes positions i*G + b on even sweeps i and i*G + G-1-b on odd.
-    const uint32_t n_tiles = (a.n_rays + RTS_BLOCK - 1) / RTS_BLOCK;
-    for (uint32_t sweep = 0, p0 = 0; p0 < n_tiles; sweep++, p0 += gridDim.x) {
-      const uint32_t tpos = p0 + ((sweep & 1u) ? gridDim.x - 1u - blockIdx.x : blockIdx.x);
-      if (tpos >= n_tiles) continue;
+    if (COUNT && a.timeline && tid == 0) { tl_t0 = wall_clock64(); a.timeline[(size_t)blockIdx.x * 2] = tl_t0; }
+    // Work units are WAVE TILES of 64 consecutive launch indices, taken by the waves one at a time from RTS_TILE_CTRS
+    // striped counters: wave w draws k = atomicAdd(ctr[w % C]) and traces position k*C + (w % C) of the tile order.  Tile
+    // durations are extremely skewed (median ~7 us: every ray misses; 99.9th percentile ~0.5 ms; a handful near 1 ms where
+    // rays cross fans of thin triangles), so an in-order sweep left a ~1 ms tail in which a few waves finished their slow
+    // tiles on an otherwise idle GPU.  Pulses of an interval look alike, so every launch records what each tile cost
+    // (tile_cost, shader clocks >> 6) and the next launches of the handle trace the tiles in descending order of the cost
+    // last seen (tile_order, built by rts_tile_order_build): longest-processing-time-first list scheduling.  Striping the
+    // counter keeps same-address atomics (~10 ns each) off the critical path: 157 k fetches over 64 addresses.
+    const uint32_t n_tiles = (a.n_rays + 63u) / 64u;
+    const uint32_t lane = tid & 63u;
+    const uint32_t stripe = (blockIdx.x * (RTS_BLOCK / 64u) + (tid >> 6)) % RTS_TILE_CTRS;
+    // Draw schedule of a stripe (positions k*C + stripe, k = 0, 1, ...): the first quarter -- the expensive end of the
+    // order -- one tile per draw, the cheap rest four tiles per draw (a miss-only tile is ~7 us of work, a draw ~2 us of
+    // latency).  The next draw is issued before the current tiles are traced, so its latency hides behind them.
+    const uint32_t per_stripe = (n_tiles + RTS_TILE_CTRS - 1u) / RTS_TILE_CTRS;
+    const uint32_t single_draws = per_stripe >= 1024u ? per_stripe / 4u : per_stripe;      // (short queues: one tile per draw throughout)
+    uint32_t draw_next = 0;
+    if (lane == 0) draw_next = atomicAdd(&a.tile_ctr[stripe], 1u);
+    for (;;) {
+      const uint32_t draw = __builtin_amdgcn_readfirstlane(draw_next);
+      const uint32_t k0 = draw < single_draws ? draw : single_draws + 4u * (draw - single_draws);
+      const uint32_t kn = draw < single_draws ? 1u : 4u;
+      if (k0 >= per_stripe) break;
+      if (lane == 0) draw_next = atomicAdd(&a.tile_ctr[stripe], 1u);
+     for (uint32_t kb = 0; kb < kn; kb++) {
+      const uint64_t tpos64 = (uint64_t)(k0 + kb) * RTS_TILE_CTRS + stripe;
+      if (tpos64 >= n_tiles) break;
+      const uint32_t tpos = (uint32_t)tpos64;
       const uint32_t tile = a.tile_order ? a.tile_order[tpos] : tpos;
-      const uint32_t slot = tile * RTS_BLOCK + tid;
+      const uint32_t slot = tile * 64u + lane;
       const long long tile_t0 = clock64();
-      unsigned long long tl_tile = 0;
-      if (COUNT && a.timeline && (a.n_rays % RTS_BLOCK == 0) && tid == 0) tl_tile = wall_clock64();
+      const unsigned long long tl_tile = (COUNT && a.timeline && lane == 0) ? wall_clock64() : 0ULL;
       if (slot < a.n_rays) {
       uint32_t pending = 0;                   // bit k: chain k has been spawned
       uint32_t refr_code0 = 0;                // (target + 1) of chain 0's refraction, for the path prefill of rows >= 3
@@ -412,16 +428,14 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
         }
       }   // chain
       }   // slot < n_rays
-      if (a.tile_cost && (tid & 63u) == 0) {           // one relaxed max per wave and tile (distinct addresses)
+      if (lane == 0) {
           const unsigned long long dt = (unsigned long long)(clock64() - tile_t0) >> 6;
-          atomicMax(&a.tile_cost[tile], (unsigned int)(dt > 0xfffffffeULL ? 0xfffffffeULL : dt) + 1u);
+          if (a.tile_cost) a.tile_cost[tile] = (unsigned int)(dt > 0xfffffffeULL ? 0xfffffffeULL : dt) + 1u;
+          if (COUNT && a.timeline) a.timeline[(size_t)gridDim.x * 2 + tile] = wall_clock64() - tl_tile;       // debug timeline (RTS_TIMELINE)
       }
-      if (COUNT && a.timeline && (a.n_rays % RTS_BLOCK == 0)) {                     // debug timeline (RTS_TIMELINE): per-tile duration as seen by the block's first wave
-          __syncthreads();
-          if (tid == 0) a.timeline[(size_t)gridDim.x * 2 + slot / RTS_BLOCK] = wall_clock64() - tl_tile;
-      }
+     }   // tiles of the draw
     }
-    if (COUNT && a.timeline && (a.n_rays % RTS_BLOCK == 0) && tid == 0) a.timeline[(size_t)blockIdx.x * 2 + 1] = wall_clock64();
+    if (COUNT && a.timeline && tid == 0) a.timeline[(size_t)blockIdx.x * 2 + 1] = wall_clock64();
 
     // ------------------------------------------------------------------ counters: wave reduce -> block reduce (LDS, the
     // traversal stack is dead by now) -> one plain store per block; k_sum_counters adds the blocks up.  (One atomic per

@@ -21,7 +21,7 @@ for _ in range(3):
 d = np.fromfile(out, np.uint64)
 grid, ntiles = int(d[0]), int(d[1]); blk = d[2:2 + 2 * grid].reshape(grid, 2).astype(np.int64); tile = d[2 + 2 * grid:2 + 2 * grid + ntiles].astype(np.float64) / 100.0   # us
 t0 = blk[:, 0].min(); start = (blk[:, 0] - t0) / 100.0; end = (blk[:, 1] - t0) / 100.0
-print("launch %.3f ms (events), blocks %d tiles %d" % (st["ms_trace"], grid, ntiles))
+print("launch %.3f ms (events), blocks %d wave tiles %d" % (st["ms_trace"], grid, ntiles))
 print("block start us: pct 0/25/50/75/100 =", np.percentile(start, [0, 25, 50, 75, 100]).round(1))
 print("block end   us: pct 0/25/50/75/100 =", np.percentile(end, [0, 25, 50, 75, 100]).round(1))
 print("block duration us: mean %.1f  pct 50/90/99/100 =" % (end - start).mean(), np.percentile(end - start, [50, 90, 99, 100]).round(1))
