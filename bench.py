@@ -14,10 +14,11 @@ static in target space because the reference's targets are rigid -- the referenc
 acceleration structure every pulse), trace of the pulse's W^3 launch indices, ordering +
 expansion of the received rays, finalisation and group-by aggregation into the pulse's
 responses.  A "ray" in Mrays/s is one traced segment (one rtTrace of the reference: primary or
-bounce).  Pulses are independent, so each GPU keeps two of them in flight (--inflight, two linked handles): the
-trace kernels run back to back on one stream while the scene placement of the next pulse and the ordering /
-finalisation / aggregation of the previous one run beside them on the handles' own streams.  All of that is inside
-the timed region; ms_per_step is wall time / pulses.
+bounce).  Pulses are independent, so each GPU keeps three of them in flight (--inflight handles, each with its own
+streams): while one pulse's trace kernel finishes its last slow tiles the next handle's trace blocks already fill the
+freed CUs, and the scene placement / ordering / finalisation / aggregation of the neighbouring pulses run beside them.
+All of that is inside the timed region; ms_per_step is wall time / pulses.  roofline.kernel_ms_avg is the mean
+duration of a trace kernel as it ran, i.e. overlapped with its neighbours.
 
 Scaling is strong: the K timed pulses form one coherent processing interval whose K * W^3
 (pulse, launch index) pairs are dealt to the N ranks (rts_amd/multigpu.py: whole pulses first; each of the K % N
@@ -89,7 +90,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--width", type=int, default=216, help="W (launch indices per pulse = W^3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=2, help="pulses in flight per GPU (linked handles); 1 = strictly sequential pulses")
+    ap.add_argument("--link", action="store_true", help="rts_link_handles: the handles' trace kernels run strictly one at a time (clean single-kernel timings, ~20 %% slower)")
+    ap.add_argument("--inflight", type=int, default=3, help="pulses in flight per GPU (linked handles); 1 = strictly sequential pulses")
     ap.add_argument("--config", default="c3", choices=["c2", "c3"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks")
     args = ap.parse_args()
@@ -121,13 +123,14 @@ def main():
     W = spec["W"]; total = W ** 3
     tx = spec["tx"]; wl = spec["c"] / spec["carrier"]
 
-    # --inflight handles hold the same scene and take the pulses in turn (rts_link_handles): their trace kernels run back
-    # to back, the scene placement of the next pulse and the ordering/aggregation of the previous one overlap with them
+    # --inflight handles hold the same scene and take the pulses in turn: the scene placement of the next pulse and the
+    # ordering/aggregation of the previous one overlap with the trace kernels, and the tail of one trace kernel (a few slow
+    # tiles) is filled by the blocks of the next handle's (--link serialises the trace kernels instead)
     trs = []
     for _ in range(max(args.inflight, 1)):
         t = api.Tracer(W, spec["max_refl"], 0, spec["smooth"], device=local_rank)
         t.set_scene(spec["meshes"]); t.set_receivers(spec["rx"])
-        if trs:
+        if trs and args.link:
             trs[0].link(t)
         trs.append(t)
     tr = trs[0]

@@ -90,13 +90,12 @@ void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlo
     auto& transmitters = world->transmitters; auto& receivers = world->receivers; auto& targets = world->targets;
     const uint32_t rxsize = (uint32_t)receivers.size(), targsize = (uint32_t)targets.size();
 
-    // Two handles hold the same scene and take the pulses in turn (rts_link_handles): while the host finishes pulse k
-    // (read-back, RCS/gain loop, aggregation, responses) the device already traces pulse k+1.  Results and the order
-    // of every side effect (AddResponse) are those of the sequential loop; in_flight = 1 restores it literally.
+    // Two handles hold the same scene and take the pulses in turn: while the host finishes pulse k (read-back, RCS/gain
+    // loop, aggregation, responses) the device already traces pulse k+1.  Results and the order of every side effect
+    // (AddResponse) are those of the sequential loop; in_flight = 1 restores it literally.
     const unsigned n_handles = in_flight > 1 ? 2u : 1u;
     struct Handles { RtsHandle h[2] = {nullptr, nullptr}; ~Handles() { rts_destroy(h[0]); rts_destroy(h[1]); } } hs;
     for (unsigned i = 0; i < n_handles; i++) check(rts_create(&params, &hs.h[i]), "rts_create");
-    if (n_handles == 2) check(rts_link_handles(hs.h[0], hs.h[1]), "rts_link_handles");
 
     // scene: once (the reference regenerates identical meshes every pulse)
     std::vector<HostMesh> host(targsize); std::vector<RtsMesh> meshes(targsize);

@@ -170,6 +170,8 @@ int rts_trace_pulse(RtsHandle h, const RtsPulse* pulse);
  * rts_trace_pulse == begin + end.  Trace kernels of linked handles execute one at a time in begin order (each has the
  * whole GPU, so rts_get_stats().ms_trace stays a single-kernel time); the scene placement of the next pulse and the
  * ordering / finalisation / aggregation of the previous one overlap with them on the handles' own HIP streams.
+ * Linking is optional: un-linked handles also overlap their trace kernels (the tail of one launch -- a few slow tiles --
+ * is filled by the next handle's blocks), which is faster; linking trades that for strictly serial, cleanly timed kernels.
  * Entry points that read a pulse's results end a begun pulse implicitly.  One host thread per link group. */
 int rts_trace_pulse_begin(RtsHandle h, const RtsPulse* pulse);
 int rts_trace_pulse_end(RtsHandle h);

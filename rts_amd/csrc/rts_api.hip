@@ -355,7 +355,10 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     const bool keep_all = (c->params.flags & RTS_FLAG_KEEP_ALL_RAYS) != 0;
     const bool count_trav = (c->params.flags & RTS_FLAG_COUNT_TRAVERSAL) != 0;
     static int grid_mult = 0; if (!grid_mult) { const char* e = getenv("RTS_GRID_MULT"); grid_mult = e ? std::max(1, atoi(e)) : 4; }   // blocks per CU: 4 = exactly the resident set (waves draw tiles from a queue)
-    uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)n + RTS_BLOCK - 1) / RTS_BLOCK, (uint64_t)c->n_cu * grid_mult);
+    static int grid_spare = -1; if (grid_spare < 0) { const char* e = getenv("RTS_GRID_SPARE"); grid_spare = e ? std::max(0, atoi(e)) : 64; }
+    // the trace kernel's blocks are persistent and four of them fill a CU's register file: leave a few block slots free so
+    // that the short kernels of the neighbouring pulses (other streams) are not locked out for the whole launch
+    uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)n + RTS_BLOCK - 1) / RTS_BLOCK, (uint64_t)std::max<int>(c->n_cu * grid_mult - grid_spare, c->n_cu));
     if (grid == 0) grid = 1;
     RtsTraceArgs a; memset(&a, 0, sizeof(a));
     RtsLaunchConsts& lc = c->last_lc; memset(&lc, 0, sizeof(lc));
