@@ -15,7 +15,7 @@
 // Closest hit = smallest f32 t; equal f32 t resolved to the lowest global primitive id
 // (OptiX keeps whichever it met first; order there is unknowable).
 //
-// Structure: one lane per launch index, grid-stride over the shard; each lane iterates its
+// Structure: one lane per launch index, persistent waves drawing 64-index tiles from a queue; each lane iterates its
 // bounces (the reference recurses through rtTrace).  The traversal stack lives in LDS
 // (entry-major, lane-minor: conflict free), spilling to a global slab when deeper.
 #include "rts_internal.h"
