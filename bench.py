@@ -166,14 +166,18 @@ def main():
                 finish(*pending.pop(0))
         while pending:
             finish(*pending.pop(0))
+        t_a = time.perf_counter()
         allp = multigpu.exchange_parts(parts, dist, torch)    # ONE exchange per CPI (RCCL all-gather), inside the timed region
+        t_b = time.perf_counter()
         resp = multigpu.merge_cpi(allp, spec["max_refl"])
+        t_c = time.perf_counter()
         if dist is not None:                                  # dense per-receiver return buffers: sum over the ranks
             if args.backend == "nccl":
                 dist.all_reduce(torch.view_as_real(cube), op=dist.ReduceOp.SUM)
             else:
                 cc = torch.view_as_real(cube).cpu(); dist.all_reduce(cc, op=dist.ReduceOp.SUM); cube.copy_(torch.view_as_complex(cc))
         acc["range_doppler_peak"] = float(torch.fft.fft(cube[:, :n_pulses], dim=1).abs().max().item()) if n_pulses > 0 else 0.0
+        acc["tail_ms"] = dict(exchange=(t_b - t_a) * 1e3, merge=(t_c - t_b) * 1e3, cube_reduce_fft=(time.perf_counter() - t_c) * 1e3)
         return acc, resp
 
     def sync():
@@ -232,7 +236,7 @@ def main():
                                    % (spec["name"], len(spec["rx"]), W, total, spec["max_refl"]),
                        "rays_per_pulse": total, "segments_per_pulse": seg_all / args.steps, "received_per_pulse": received_all / args.steps,
                        "primary_Mrays_per_s": total * args.steps / dt / 1e6, "return_cube": "complex128 [%d rx][%d pulses][%d bins], all-reduced once per interval" % (cube.shape[0], args.steps, n_bins), "sharding": "%d-pulse interval over %d ranks: whole pulses, left-over pulses in interleaved 4096-index tiles; one group-table all-gather + one cube all-reduce per interval" % (args.steps, world),
-                       "pulses_in_flight": len(trs), "stage_ms_per_launch_rank0": {"scene_placement": ms_scene / launches, "trace": ms_launch, "order+finalise+aggregate": ms_post / launches}},
+                       "pulses_in_flight": len(trs), "interval_tail_ms_rank0": acc["tail_ms"], "stage_ms_per_launch_rank0": {"scene_placement": ms_scene / launches, "trace": ms_launch, "order+finalise+aggregate": ms_post / launches}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": bytes_per_seg * seg_per_launch, "kernel": "k_trace", "bytes_per_segment": bytes_per_seg,
                          "nodes_per_segment": V, "tri_tests_per_segment": T, "shaded_per_segment": Hh,

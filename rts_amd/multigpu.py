@@ -121,6 +121,8 @@ def exchange_parts(parts, dist, torch):
     """parts: [dict(pulse, groups)] of this rank -> the same list for ALL ranks.  Group tables must be keyed by
     global buffer rows (rts_aggregate(..., RTS_BASE_USE_ROWS)) so that they merge with a plain min.
     One all-gather of sizes + one all-gather of payload (meta int64 rows followed by the group records)."""
+    if dist is None:
+        return [dict(pulse=int(p["pulse"]), groups=np.ascontiguousarray(p["groups"], GROUP_DTYPE)) for p in parts]
     meta = np.array([[p["pulse"], len(p["groups"])] for p in parts], np.int64).reshape(-1, 2)
     groups = np.concatenate([np.ascontiguousarray(p["groups"], GROUP_DTYPE) for p in parts]) if parts else np.zeros(0, GROUP_DTYPE)
     payload = np.concatenate([meta.view(np.uint8).reshape(-1), groups.view(np.uint8).reshape(-1)])
@@ -157,6 +159,8 @@ def merge_cpi(all_parts, depth):
         by_pulse.setdefault(p["pulse"], []).append(p["groups"])
     out = {}
     for k, tabs in by_pulse.items():
-        allg = np.concatenate(tabs) if tabs else np.zeros(0, GROUP_DTYPE)
-        out[k] = merge_and_respond(allg, depth)
+        if len(tabs) == 1:                                   # a pulse traced whole by one rank: its table is already merged
+            out[k] = (api.groups_to_responses(tabs[0]), tabs[0])
+        else:
+            out[k] = merge_and_respond(np.concatenate(tabs), depth)
     return out
