@@ -86,8 +86,8 @@ def cpu_baseline(spec, seconds_target=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--width", type=int, default=216, help="W (launch indices per pulse = W^3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--link", action="store_true", help="rts_link_handles: the handles' trace kernels run strictly one at a time (clean single-kernel timings, ~20 %% slower)")
