@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <map>
+#include <thread>
 #include "rts_internal.h"
 
 static thread_local char g_err[1024] = "";
@@ -166,12 +167,24 @@ extern "C" int rts_set_scene(RtsHandle c, const RtsMesh* meshes, uint32_t n_targ
     double split_budget = 1.0;                          // extra references for triangles whose boxes are mostly empty (rts_sah.cpp)
     { const char* e = getenv("RTS_SPLIT_BUDGET"); if (e) { const double v = atof(e); if (v >= 0 && v <= 8) split_budget = v; } }
     std::vector<RtsNode4> nodes4; std::vector<uint32_t> leaf_prim; std::vector<RtsBlasInfo> blas(n_targets);
-    nodes4.reserve(nt / 2 + 4); leaf_prim.reserve(nt);
-    for (uint32_t t = 0; t < n_targets; t++) {
-        const RtsMesh& m = meshes[t];
-        const size_t leaf0 = leaf_prim.size();
-        int rc = rts_sah_build(m.vertices, m.triangles, m.n_triangles, split_budget, nodes4, leaf_prim, blas[t]); if (rc != RTS_OK) return rc;
-        for (size_t i = leaf0; i < leaf_prim.size(); i++) leaf_prim[i] += mh[t].tri_base;
+    {   // the meshes are independent: one host thread each (at most 16 at a time), results concatenated in target order
+        std::vector<std::vector<RtsNode4>> pn(n_targets); std::vector<std::vector<uint32_t>> pl(n_targets); std::vector<int> prc(n_targets, RTS_OK);
+        for (uint32_t t0 = 0; t0 < n_targets; t0 += 16) {
+            std::vector<std::thread> pool;
+            for (uint32_t t = t0; t < std::min(n_targets, t0 + 16); t++)
+                pool.emplace_back([&, t]() { prc[t] = rts_sah_build(meshes[t].vertices, meshes[t].triangles, meshes[t].n_triangles, split_budget, pn[t], pl[t], blas[t]); });
+            for (auto& th : pool) th.join();
+        }
+        for (uint32_t t = 0; t < n_targets; t++) {
+            if (prc[t] != RTS_OK) return prc[t];
+            const int32_t node_base = (int32_t)nodes4.size(), leaf_base = (int32_t)leaf_prim.size();
+            for (RtsNode4 nd : pn[t]) {
+                for (int k = 0; k < 4; k++) { int32_t& ch = nd.child[k]; if (ch == 0x7fffffff) continue; if (ch >= 0) ch += node_base; else ch = ~(~ch + leaf_base); }
+                nodes4.push_back(nd);
+            }
+            for (uint32_t lp : pl[t]) leaf_prim.push_back(lp + mh[t].tri_base);
+            if (blas[t].root >= 0) blas[t].root += node_base;
+        }
     }
     RTS_HIP(hipStreamSynchronize(c->stream));
     RTS_HIP(c->d_nodes4.reserve(nodes4.size() + 1)); RTS_HIP(c->d_leaf_prim.reserve(leaf_prim.size() + 1)); RTS_HIP(c->d_leaves.reserve(leaf_prim.size() + 1));
