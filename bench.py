@@ -130,6 +130,7 @@ def main():
     for _ in range(max(args.inflight, 1)):
         t = api.Tracer(W, spec["max_refl"], 0, spec["smooth"], device=local_rank)
         t.set_scene(spec["meshes"]); t.set_receivers(spec["rx"])
+        t.reserve(0)                                          # set-up, not warm-up: device buffers exist before the first pulse
         if trs and args.link:
             trs[0].link(t)
         trs.append(t)
@@ -146,6 +147,7 @@ def main():
         """pulses k0 .. k0+n_pulses-1 as one coherent processing interval, sharded over the ranks"""
         parts = []; acc = dict(segments=0, shaded=0, received=0, ms_scene=0.0, ms_trace=0.0, ms_post=0.0, launches=0)
         cube.zero_(); torch.cuda.synchronize()
+        t_cpi = time.perf_counter()
         def finish(t, k):
             t.trace_end()
             t.finalise_uniform(None, wl, 1.0, 1.0, spec["carrier"], spec["c"])
@@ -156,6 +158,8 @@ def main():
             acc["segments"] += st["segments"]; acc["shaded"] += st["shaded"]; acc["received"] += st["received"]
             acc["ms_scene"] += st["ms_scene"]; acc["ms_trace"] += st["ms_trace"]; acc["ms_post"] += st["ms_compact"] + st["ms_aggregate"]
             acc["launches"] += 1
+            if os.environ.get("BENCH_DEBUG"):
+                print("pulse %d done at %.3f ms: scene %.3f trace %.3f compact %.3f agg %.3f" % (k, (time.perf_counter() - t_cpi) * 1e3, st["ms_scene"], st["ms_trace"], st["ms_compact"], st["ms_aggregate"]), file=sys.stderr)
 
         pending = []
         for i, (k, first, count, il) in enumerate(multigpu.refine_plan(multigpu.plan_cpi(total, n_pulses, rank, world), len(trs))):

@@ -173,6 +173,9 @@ int rts_trace_pulse(RtsHandle h, const RtsPulse* pulse);
  * Linking is optional: un-linked handles also overlap their trace kernels (the tail of one launch -- a few slow tiles --
  * is filled by the next handle's blocks), which is faster; linking trades that for strictly serial, cleanly timed kernels.
  * Entry points that read a pulse's results end a begun pulse implicitly.  One host thread per link group. */
+/* Optional: allocate (and touch) the device buffers of launches of up to n_rays launch indices now (0 = W^3) instead of
+ * inside the first rts_trace_pulse; keeps multi-GB allocations out of a timed or latency-critical region. */
+int rts_reserve(RtsHandle h, uint64_t n_rays);
 int rts_trace_pulse_begin(RtsHandle h, const RtsPulse* pulse);
 int rts_trace_pulse_end(RtsHandle h);
 int rts_link_handles(RtsHandle a, RtsHandle b);               /* same device; groups grow by linking a member to a new handle */

@@ -133,6 +133,10 @@ class Tracer:
         check(L.lib().rts_trace_pulse(self.h, C.byref(self._pulse(origin, tx_span, tx_dir, motion, ray_first, ray_count, interleave))))
         return self.stats() if want_stats else None     # reading the stage timers drains the stream
 
+    def reserve(self, n_rays=0):
+        """rts_reserve: allocate the per-launch device buffers now (0 = W^3 launch indices)"""
+        check(L.lib().rts_reserve(self.h, n_rays))
+
     def trace_begin(self, origin, tx_span, tx_dir, motion=None, ray_first=0, ray_count=0, interleave=None):
         """enqueue a pulse (rts_trace_pulse_begin); trace_end() -- or any accessor -- completes it"""
         check(L.lib().rts_trace_pulse_begin(self.h, C.byref(self._pulse(origin, tx_span, tx_dir, motion, ray_first, ray_count, interleave))))

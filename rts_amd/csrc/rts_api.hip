@@ -296,6 +296,37 @@ static int fill_target_placement(const RtsContext* c, uint32_t t, RtsTargetDev& 
     return RTS_OK;
 }
 
+// Device buffers of a launch of up to n launch indices (grown, never shrunk).  Also the first touch of the big slabs:
+// doing it before the first pulse keeps multi-GB hipMalloc calls out of a caller's timed or latency-critical region.
+extern "C" int rts_reserve(RtsHandle c, uint64_t n_rays)
+{
+    CHECK_HANDLE(c);
+    const uint64_t W3 = (uint64_t)c->params.width * c->params.width * c->params.width;
+    const uint64_t n = std::min<uint64_t>(n_rays ? n_rays : W3, W3);
+    const uint32_t chains = c->params.max_refr ? 3u : 1u;
+    if (n * chains > 0xfffffff0ULL) { rts_set_error("rts_reserve: rays x chains exceeds 2^32"); return RTS_ERR_UNSUPPORTED; }
+    const size_t threads = (size_t)c->n_cu * 64 * RTS_BLOCK;             // upper bound of any launch's grid
+    const uint32_t H = c->params.max_refl + 1;
+    RTS_HIP(c->d_recv.reserve((size_t)n * chains + 1)); RTS_HIP(c->d_counters.reserve(16)); RTS_HIP(c->d_lc.reserve(1));
+    RTS_HIP(c->d_dir_hist.reserve((size_t)(c->params.max_refr ? 3 * H : std::max<uint32_t>(c->params.max_refl, 1)) * 3 * n + 4));
+    if (c->params.max_refr) RTS_HIP(c->d_child.reserve(2 * threads));
+    RTS_HIP(c->d_stack_ovf.reserve((size_t)RTS_STACK_OVF * (size_t)c->n_cu * 4 * RTS_BLOCK));
+    RTS_HIP(c->d_block_counters.reserve((size_t)c->n_cu * 64 * 8));
+    const size_t n_tiles = (size_t)((n + RTS_WTILE - 1) / RTS_WTILE), n_hist = (size_t)((W3 + RTS_WTILE - 1) / RTS_WTILE);
+    RTS_HIP(c->d_tile_ctr.reserve(RTS_TILE_CTRS)); RTS_HIP(c->d_tile_cost.reserve(n_tiles)); RTS_HIP(c->d_tile_key.reserve(n_tiles)); RTS_HIP(c->d_tile_key_sorted.reserve(n_tiles));
+    RTS_HIP(c->d_tile_id.reserve(n_tiles)); RTS_HIP(c->d_tile_order.reserve(n_tiles));
+    if (c->tile_hist_n != (uint32_t)n_hist) {
+        RTS_HIP(c->d_tile_hist.reserve(n_hist)); RTS_HIP(hipMemsetAsync(c->d_tile_hist.p, 0, sizeof(uint32_t) * n_hist, c->stream));
+        c->tile_hist_n = (uint32_t)n_hist; c->tile_hist_any = false; c->tile_cost_pending = false;
+    }
+    if (c->params.flags & RTS_FLAG_KEEP_ALL_RAYS) { RTS_HIP(c->d_all.reserve((size_t)n * chains + 1)); RTS_HIP(c->d_hit_prim.reserve((size_t)n * H + 1)); RTS_HIP(c->d_hit_t.reserve((size_t)n * H + 1)); }
+    // touch the two slabs the trace kernel writes sparsely, so that their pages exist before the first launch
+    RTS_HIP(hipMemsetAsync(c->d_recv.p, 0, sizeof(RtsEndRecord) * ((size_t)n * chains + 1), c->stream));
+    RTS_HIP(hipMemsetAsync(c->d_dir_hist.p, 0, sizeof(float) * c->d_dir_hist.cap, c->stream));
+    RTS_HIP(hipStreamSynchronize(c->stream));
+    return RTS_OK;
+}
+
 // ------------------------------------------------------------------------------------- launch
 extern "C" int rts_trace_pulse(RtsHandle c, const RtsPulse* p)
 {

@@ -150,8 +150,12 @@ template <typename T> struct DevBuf {
     T* p = nullptr; size_t cap = 0;
     hipError_t reserve(size_t n) {
         if (n <= cap) return hipSuccess;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        // hipFree is a device-wide synchronisation (it stalls the other handles' launches): grow geometrically, and give
+        // the many small buffers sized by a pulse's received-ray count room to begin with
         size_t want = n + n / 8 + 16;
+        if (want < 2 * cap) want = 2 * cap;
+        if (want < 65536) want = 65536;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
         hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
         if (e == hipSuccess) cap = want;
         return e;

@@ -100,7 +100,9 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
       const uint64_t tpos64 = (uint64_t)(k0 + kb) * RTS_TILE_CTRS + stripe;
       if (tpos64 >= n_tiles) break;
       const uint32_t tpos = (uint32_t)tpos64;
-      const uint32_t tile = a.tile_order ? a.tile_order[tpos] : tpos;
+      // no history yet (first launch of the handle): centre-out over the launch range -- the beam is normally centred on
+      // the targets, so the expensive tiles sit in the middle of the lattice and should be started first
+      const uint32_t tile = a.tile_order ? a.tile_order[tpos] : ((tpos & 1u) ? (n_tiles - 1u) / 2u + (tpos + 1u) / 2u : (n_tiles - 1u) / 2u - tpos / 2u);
       const uint32_t slot = tile * 64u + lane;
       const long long tile_t0 = clock64();
       const unsigned long long tl_tile = (COUNT && a.timeline && lane == 0) ? wall_clock64() : 0ULL;
