@@ -154,7 +154,7 @@ template <typename T> struct DevBuf {
         // the many small buffers sized by a pulse's received-ray count room to begin with
         size_t want = n + n / 8 + 16;
         if (want < 2 * cap) want = 2 * cap;
-        if (want < 65536) want = 65536;
+        if (sizeof(T) <= 144 && want < 65536) want = 65536;
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
         hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
         if (e == hipSuccess) cap = want;
