@@ -42,6 +42,9 @@ PRI = 1.0e-3                   # pulse repetition interval of the synthetic CPI
 
 
 def pulse_motion(spec, k):
+    """target placement of pulse k; the config's interval is n_pulses long (C3: 256 pulses = 51 m of flight), longer runs
+    repeat it so that the workload does not drift out of the beam"""
+    k = k % max(int(spec.get("n_pulses", 256)), 1)
     out = []
     for m in spec["motion"]:
         v = np.asarray(m["velocity"], np.float64); p0 = np.asarray(m["position"], np.float64)
@@ -86,7 +89,7 @@ def cpu_baseline(spec, seconds_target=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--width", type=int, default=216, help="W (launch indices per pulse = W^3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
