@@ -690,3 +690,37 @@ def test_tile_schedule_does_not_change_results(rts, scenes, monkeypatch):
     H.assert_prd_equal(a["results"], d["results"], "fresh handle")
     assert np.array_equal(a["slots"], d["slots"])
     tr2.close()
+
+
+def test_c4_full_size_sampled_parity(rts, oracle, scenes):
+    """BASELINE configs[3] at full size (4 airframes, 999 824 triangles, W = 465: 100 544 625 launch indices, 8 bounces,
+    8 receivers): segment accounting + every 1999th launch index through the oracle (BVH mode); the received subset
+    must match record for record, and two interleaved parts must add up to the whole"""
+    spec = scenes.config4()
+    spec["rx"] = [dict(r, radius=max(r["radius"], 400.0)) for r in spec["rx"]]        # wide capture spheres: enough received rays to compare
+    tx = spec["tx_list"][0] if "tx_list" in spec else spec["tx"]
+    spec["tx"] = tx
+    n = spec["W"] ** 3
+    tr = H.gpu_tracer(rts, spec)
+    _, st = H.gpu_trace(rts, spec, tr=tr)
+    whole = tr.received()
+    R = st["received"]
+    assert st["rays"] == n and st["segments"] == n + st["shaded"] and R == len(whole["slots"]) and R > 200
+    assert (np.diff(whole["slots"].astype(np.int64)) > 0).all()
+    stride = 1999; m = n // stride
+    o = H.oracle_trace(oracle, spec, ray_first=11, ray_stride=stride, n_rays=m, use_bvh=True, threads=8, debug=False)
+    samp = 11 + stride * np.arange(m, dtype=np.int64)
+    o_idx = np.nonzero(o["results"]["received"] >= 0)[0]
+    slots = whole["slots"].astype(np.int64)
+    pos_c = np.minimum(np.searchsorted(slots, samp), R - 1)
+    is_recv = slots[pos_c] == samp
+    assert len(o_idx) > 0 and np.array_equal(np.nonzero(is_recv)[0], o_idx)
+    H.assert_prd_equal(o["results"][o_idx], whole["results"][pos_c[is_recv]], "C4 sampled received records")
+    assert np.array_equal(o["path"][o_idx], whole["path"][pos_c[is_recv]])
+    parts = []
+    for part in range(2):
+        H.gpu_trace(rts, spec, tr=tr, interleave=(4096, 2, part)); parts.append(tr.received())
+    ps = np.concatenate([p["slots"] for p in parts]); order = np.argsort(ps, kind="stable")
+    assert np.array_equal(ps[order], whole["slots"])
+    H.assert_prd_equal(np.concatenate([p["results"] for p in parts])[order], whole["results"], "C4 interleaved halves")
+    tr.close()
