@@ -724,3 +724,34 @@ def test_c4_full_size_sampled_parity(rts, oracle, scenes):
     assert np.array_equal(ps[order], whole["slots"])
     H.assert_prd_equal(np.concatenate([p["results"] for p in parts])[order], whole["results"], "C4 interleaved halves")
     tr.close()
+
+
+def test_c5_full_size_moving_target_sampled_parity(rts, oracle, scenes):
+    """BASELINE configs[4] at full size (the 100 000-triangle airframe translating 200 m/s and yawing 1 rad/s, W = 216):
+    three pulses spread over the interval on ONE handle (static hierarchy, re-placed per pulse; tile order learnt from
+    the previous pulse); every 499th launch index of each pulse through the oracle with that pulse's world-space mesh"""
+    spec = scenes.config5(rx_radius=300.0)
+    n = spec["W"] ** 3
+    tr = H.gpu_tracer(rts, spec)
+    total_recv = 0
+    for k in (0, 37, 90):
+        motion = spec["motion_fn"](k)
+        _, st = H.gpu_trace(rts, spec, tr=tr, motion=motion)
+        g = tr.received(); R = st["received"]
+        assert st["rays"] == n and st["segments"] == n + st["shaded"] and st["bvh_rebuilt"] == 1
+        stride = 499; m = n // stride
+        o = H.oracle_trace(oracle, spec, motion=motion, ray_first=3, ray_stride=stride, n_rays=m, use_bvh=True, threads=8, debug=False)
+        samp = 3 + stride * np.arange(m, dtype=np.int64)
+        o_idx = np.nonzero(o["results"]["received"] >= 0)[0]
+        slots = g["slots"].astype(np.int64)
+        if R == 0:
+            assert len(o_idx) == 0
+            continue
+        pos_c = np.minimum(np.searchsorted(slots, samp), R - 1)
+        is_recv = slots[pos_c] == samp
+        assert np.array_equal(np.nonzero(is_recv)[0], o_idx)
+        H.assert_prd_equal(o["results"][o_idx], g["results"][pos_c[is_recv]], "C5 pulse %d sampled received records" % k)
+        assert np.array_equal(o["path"][o_idx], g["path"][pos_c[is_recv]])
+        total_recv += len(o_idx)
+    assert total_recv > 20
+    tr.close()
