@@ -755,3 +755,47 @@ def test_c5_full_size_moving_target_sampled_parity(rts, oracle, scenes):
         total_recv += len(o_idx)
     assert total_recv > 20
     tr.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_triangle_soups_brute_force(rts, oracle, scenes, seed):
+    """fuzz of the hierarchy builder (SAH, split references) and of the conservative walk: random triangle soups with
+    mixed scales, long diagonal slivers, fans around a shared vertex, coincident and degenerate triangles, two targets
+    (one rotated and displaced) -- every output row of every launch index against the oracle's BRUTE-FORCE closest hit"""
+    rng = np.random.default_rng(seed)
+
+    def soup(n_reg, n_sliver, n_fan, centre):
+        tris = []
+        for _ in range(n_reg):                                         # ordinary triangles of mixed size
+            c = rng.normal(0, 6.0, 3); s = 10 ** rng.uniform(-1.5, 0.7)
+            tris.append(c + rng.normal(0, s, (3, 3)))
+        for _ in range(n_sliver):                                      # long thin diagonal slivers
+            a = rng.normal(0, 6.0, 3); d = rng.normal(0, 1, 3); d /= np.linalg.norm(d)
+            L = rng.uniform(5, 25); w = rng.normal(0, 1, 3) * 10 ** rng.uniform(-4, -1.5)
+            tris.append(np.stack([a, a + L * d, a + 0.5 * L * d + w]))
+        hub = rng.normal(0, 3.0, 3)                                    # a fan of thin wedges around one vertex
+        ang = np.sort(rng.uniform(0, 2 * np.pi, n_fan + 1)); rad = rng.uniform(2, 8)
+        e1 = np.array([0.0, 1.0, 0.2]); e2 = np.array([0.1, -0.2, 1.0])
+        for i in range(n_fan):
+            tris.append(np.stack([hub, hub + rad * (np.cos(ang[i]) * e1 + np.sin(ang[i]) * e2), hub + rad * (np.cos(ang[i + 1]) * e1 + np.sin(ang[i + 1]) * e2)]))
+        tris.append(tris[0].copy())                                    # an exact duplicate (tie on t: lowest primitive id wins)
+        p = rng.normal(0, 5.0, 3); tris.append(np.stack([p, p, p + 1.0]))   # degenerate (zero area)
+        v = np.concatenate(tris).astype(np.float64) + np.asarray(centre, np.float64)
+        t = np.arange(len(v), dtype=np.uint32).reshape(-1, 3)
+        nrm = np.repeat(np.cross(v[1::3] - v[0::3], v[2::3] - v[0::3]) + 1e-30, 3, axis=0)
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        return dict(tris=t, verts=v, normals=nrm, refl_coeff=0.8, refr_index=1.0)
+
+    from rts_amd import api as A
+    spec = scenes.config1()
+    spec.update(W=14, max_refl=3, smooth=bool(seed % 2),
+                meshes=[soup(120, 40, 60, (0, 0, 0)), soup(60, 20, 30, (4.0, -3.0, 2.0))],
+                motion=[dict(position=(0.0, 0.0, 0.0), velocity=(5.0, 0.0, 0.0)),
+                        dict(position=(12.0, 7.0, -4.0), velocity=(0.0, -3.0, 1.0), rotation=A.rotation_matrix(0.4 * seed, -0.3, 0.9))])
+    spec["tx"] = dict(origin=(-300.0, 2.0, 1.0), span=(0.16, 0.14, 0.08), dir=(0.0, 0.0))
+    spec["rx"] = [A.rx_sphere((-300.0, 2.0, 1.0), 0.0, 0.0, 120.0, 2.6, 2.6), A.rx_sphere((-100.0, 200.0, 30.0), -1.1, -0.1, 150.0, 2.6, 2.6)]
+    tr, st, o, g = full_parity(rts, oracle, spec)
+    assert st["shaded"] > 200
+    nodes, leaf_prim, roots = tr.bvh()
+    assert np.bincount(leaf_prim).max() > 1                            # the slivers and wedges were split
+    tr.close()
