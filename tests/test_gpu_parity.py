@@ -757,8 +757,8 @@ def test_c5_full_size_moving_target_sampled_parity(rts, oracle, scenes):
     tr.close()
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4])
-def test_random_triangle_soups_brute_force(rts, oracle, scenes, seed):
+@pytest.mark.parametrize("seed,refr,far", [(1, 0, False), (2, 0, False), (3, 1, False), (4, 0, True), (5, 1, True)])
+def test_random_triangle_soups_brute_force(rts, oracle, scenes, seed, refr, far):
     """fuzz of the hierarchy builder (SAH, split references) and of the conservative walk: random triangle soups with
     mixed scales, long diagonal slivers, fans around a shared vertex, coincident and degenerate triangles, two targets
     (one rotated and displaced) -- every output row of every launch index against the oracle's BRUTE-FORCE closest hit"""
@@ -787,13 +787,16 @@ def test_random_triangle_soups_brute_force(rts, oracle, scenes, seed):
         return dict(tris=t, verts=v, normals=nrm, refl_coeff=0.8, refr_index=1.0)
 
     from rts_amd import api as A
+    off = np.array([41234.5, -30987.25, 20011.125]) if far else np.zeros(3)      # the whole scene far from the origin
     spec = scenes.config1()
-    spec.update(W=14, max_refl=3, smooth=bool(seed % 2),
-                meshes=[soup(120, 40, 60, (0, 0, 0)), soup(60, 20, 30, (4.0, -3.0, 2.0))],
-                motion=[dict(position=(0.0, 0.0, 0.0), velocity=(5.0, 0.0, 0.0)),
-                        dict(position=(12.0, 7.0, -4.0), velocity=(0.0, -3.0, 1.0), rotation=A.rotation_matrix(0.4 * seed, -0.3, 0.9))])
-    spec["tx"] = dict(origin=(-300.0, 2.0, 1.0), span=(0.16, 0.14, 0.08), dir=(0.0, 0.0))
-    spec["rx"] = [A.rx_sphere((-300.0, 2.0, 1.0), 0.0, 0.0, 120.0, 2.6, 2.6), A.rx_sphere((-100.0, 200.0, 30.0), -1.1, -0.1, 150.0, 2.6, 2.6)]
+    m0, m1 = soup(120, 40, 60, (0, 0, 0)), soup(60, 20, 30, (4.0, -3.0, 2.0))
+    if refr:
+        m0["refr_index"] = 1.4; m1["refr_index"] = 1.2; spec["max_refr"] = 1
+    spec.update(W=14 if not refr else 10, max_refl=3, smooth=bool(seed % 2), meshes=[m0, m1],
+                motion=[dict(position=tuple(off), velocity=(5.0, 0.0, 0.0)),
+                        dict(position=tuple(off + (12.0, 7.0, -4.0)), velocity=(0.0, -3.0, 1.0), rotation=A.rotation_matrix(0.4 * seed, -0.3, 0.9))])
+    spec["tx"] = dict(origin=tuple(off + (-300.0, 2.0, 1.0)), span=(0.16, 0.14, 0.08), dir=(0.0, 0.0))
+    spec["rx"] = [A.rx_sphere(tuple(off + (-300.0, 2.0, 1.0)), 0.0, 0.0, 120.0, 2.6, 2.6), A.rx_sphere(tuple(off + (-100.0, 200.0, 30.0)), -1.1, -0.1, 150.0, 2.6, 2.6)]
     tr, st, o, g = full_parity(rts, oracle, spec)
     assert st["shaded"] > 200
     nodes, leaf_prim, roots = tr.bvh()
