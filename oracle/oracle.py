@@ -76,6 +76,8 @@ def lib():
                                            [C.c_void_p] * 6
         L.orc_unique_paths.restype = C.c_uint
         L.orc_unique_paths.argtypes = [C.c_void_p, C.c_uint, C.c_void_p]
+        L.orc_coverage.restype = C.c_uint
+        L.orc_coverage.argtypes = [C.c_void_p, C.c_int]
         L.orc_sizeof_prd.restype = C.c_uint32
         assert L.orc_sizeof_prd() == PRD_DTYPE.itemsize
         _lib = L
@@ -218,3 +220,16 @@ def atan2f(y, x):
 
 def libm_atan2f(y, x):
     return lib().orc_libm_atan2f(float(np.float32(y)), float(np.float32(x)))
+
+
+COVERAGE_NAMES = ["phi_low", "phi_high", "win_minphi", "win_maxphi", "capture_region1", "capture_region2", "both_roots",
+                  "second_root_only", "recapture", "recapture_reflected", "direct_capture", "earth_tested", "earth_root0",
+                  "earth_root1", "earth_both", "earth_miss"]
+
+
+def coverage(reset=True):
+    """branch coverage of the miss program (ray_tracer.cu:260-478) since the last reset: dict name -> count"""
+    out = np.zeros(len(COVERAGE_NAMES), np.uint64)
+    n = lib().orc_coverage(_p(out), 1 if reset else 0)
+    assert n == len(COVERAGE_NAMES)
+    return {k: int(v) for k, v in zip(COVERAGE_NAMES, out)}

@@ -40,6 +40,7 @@
 // =====================================================================================
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -372,6 +373,28 @@ static inline d2 cart_to_sph(d3 in) {                       // normal_shader.cu:
     d2 sph; sph.x = std::atan2(in.y, in.x); sph.y = std::atan2(in.z, std::sqrt(in.x*in.x + in.y*in.y)); return sph;
 }
 
+// Branch coverage of the miss program (observers only: they never feed back into the arithmetic).  Tests use them to
+// prove that a scene really drives the oracle through the branch it claims to cover (orc_coverage).
+enum { COV_PHI_LOW = 0,       // :332-335  phi < -pi/2 correction taken
+       COV_PHI_HIGH,          // :337-340  phi > +pi/2 correction taken
+       COV_WIN_MINPHI,        // :354-360  window crosses -pi/2 (second region built from minPhi)
+       COV_WIN_MAXPHI,        // :362-368  window crosses +pi/2 (second region built from maxPhi)
+       COV_CAPTURE_REGION1,   // :374      captured by the first (theta, phi) region
+       COV_CAPTURE_REGION2,   // :375      captured ONLY by the second region
+       COV_BOTH_ROOTS,        // :378-381  both roots captured, nearest chosen
+       COV_SECOND_ROOT_ONLY,  //           only root 1 captured (root 0 invalid or outside the window)
+       COV_RECAPTURE,         // :272,393-426 quirk 4: a ray already received is captured again by a later receiver
+       COV_RECAPTURE_REFLECTED, //         ... and it is a reflected ray, so power is multiplied a second time (:419-425)
+       COV_DIRECT_CAPTURE,    // :410-417
+       COV_EARTH_TESTED,      // :438      Earth block entered (prd.end == false)
+       COV_EARTH_ROOT0,       // :462-471  t0 >= 0 && rayLength > 0
+       COV_EARTH_ROOT1,       //           t1 >= 0 && rayLength > 0
+       COV_EARTH_BOTH,        //           both roots added to rayLength (quirk 6)
+       COV_EARTH_MISS,        //           discriminant <= 0 or no valid root
+       COV_N };
+static std::atomic<unsigned long long> g_cov[COV_N];
+#define COV(k) g_cov[k].fetch_add(1ULL, std::memory_order_relaxed)
+
 // ------------------------------------------------------------------ ray_tracer.cu:260-478  miss program
 static void miss_program(OTraceCtx& cx, PerRayData& prd)
 {
@@ -409,8 +432,8 @@ static void miss_program(OTraceCtx& cx, PerRayData& prd)
                         double phi = orc_atan2f_cr((float)(endPoint.z - c.z), (float)std::sqrt(((endPoint.y - c.y) *
                                             (endPoint.y - c.y)) + ((endPoint.x - c.x) *
                                             (endPoint.x - c.x))));
-                        if ((phi < -M_PI/2)) { theta += M_PI; phi = -M_PI - phi; }
-                        if ((phi > M_PI/2)) { theta += M_PI; phi = M_PI - phi; }
+                        if ((phi < -M_PI/2)) { theta += M_PI; phi = -M_PI - phi; COV(COV_PHI_LOW); }
+                        if ((phi > M_PI/2)) { theta += M_PI; phi = M_PI - phi; COV(COV_PHI_HIGH); }
                         double d_maxTheta1 = sc.maxTheta[Rx_i];
                         double d_minTheta1 = sc.minTheta[Rx_i];
                         double d_maxTheta2 = d_maxTheta1;
@@ -421,21 +444,23 @@ static void miss_program(OTraceCtx& cx, PerRayData& prd)
                         double d_minPhi2 = d_minPhi1;
                         if ((d_minPhi1 < -M_PI/2)) {
                             d_maxTheta2 += M_PI; d_minTheta2 += M_PI;
-                            d_maxPhi2 = -M_PI - d_minPhi1; d_minPhi2 = -M_PI/2; d_minPhi1 = -M_PI/2;
+                            d_maxPhi2 = -M_PI - d_minPhi1; d_minPhi2 = -M_PI/2; d_minPhi1 = -M_PI/2; COV(COV_WIN_MINPHI);
                         }
                         if ((d_maxPhi1 > M_PI/2)) {
                             d_maxTheta2 += M_PI; d_minTheta2 += M_PI;
-                            d_minPhi2 = M_PI - d_maxPhi1; d_maxPhi2 = M_PI/2; d_maxPhi1 = M_PI/2;
+                            d_minPhi2 = M_PI - d_maxPhi1; d_maxPhi2 = M_PI/2; d_maxPhi1 = M_PI/2; COV(COV_WIN_MAXPHI);
                         }
                         if (((angle_in_range(theta, d_minTheta1, d_maxTheta1)) && (angle_in_range(phi, d_minPhi1, d_maxPhi1))) ||
                             ((angle_in_range(theta, d_minTheta2, d_maxTheta2)) && (angle_in_range(phi, d_minPhi2, d_maxPhi2))))
                         {
-                            if (received_root == 2) received_root = i;
-                            else if (t[received_root] > t[i]) received_root = i;
+                            if ((angle_in_range(theta, d_minTheta1, d_maxTheta1)) && (angle_in_range(phi, d_minPhi1, d_maxPhi1))) COV(COV_CAPTURE_REGION1); else COV(COV_CAPTURE_REGION2);
+                            if (received_root == 2) { received_root = i; if (i == 1) COV(COV_SECOND_ROOT_ONLY); }
+                            else { COV(COV_BOTH_ROOTS); if (t[received_root] > t[i]) received_root = i; }
                         }
                     }
                 }
                 if (received_root < 2) {
+                    if (prd.received >= 0) { COV(COV_RECAPTURE); if (!((prd.reflDepth == 0) && (prd.refrDepth == 0))) COV(COV_RECAPTURE_REFLECTED); }
                     prd.end = true;
                     unsigned int i = received_root;
                     d3 endPoint;
@@ -447,6 +472,7 @@ static void miss_program(OTraceCtx& cx, PerRayData& prd)
                         RxRange = endPoint - d_rayOrigin;
                         if (lengthd3(RxRange) >= SCENE_EPS) {
                             prd.power = 1/(4*M_PI*4*M_PI*(magsquared3(RxRange)));
+                            COV(COV_DIRECT_CAPTURE);
                             prd.doppler = 0;
                             prd.rayLength += t[i];
                             prd.received = Rx_i;
@@ -470,14 +496,18 @@ static void miss_program(OTraceCtx& cx, PerRayData& prd)
         double C = (prd.prevHitPoint).x*(prd.prevHitPoint).x + (prd.prevHitPoint).y*(prd.prevHitPoint).y + (prd.prevHitPoint).z*(prd.prevHitPoint).z - d_earthRadius*d_earthRadius;
         double discriminant = B*B - 4*A*C;
         double t[2] = {0, 0};
+        COV(COV_EARTH_TESTED);
+        int n_roots = 0;
         if (discriminant > 0.f) {
             discriminant = std::sqrt(discriminant);
             t[0] = (-B - discriminant)/(2*A);
             t[1] = (-B + discriminant)/(2*A);
             for (int i = 0; i < 2; i++) {
-                if ((t[i] >= 0) && (prd.rayLength > 0)) { prd.end = true; prd.rayLength += t[i]; }
+                if ((t[i] >= 0) && (prd.rayLength > 0)) { prd.end = true; prd.rayLength += t[i]; n_roots++; COV(i == 0 ? COV_EARTH_ROOT0 : COV_EARTH_ROOT1); }
             }
         }
+        if (n_roots == 2) COV(COV_EARTH_BOTH);
+        if (n_roots == 0) COV(COV_EARTH_MISS);
     }
 }
 
@@ -681,6 +711,13 @@ static void ray_generation(OTraceCtx& cx, uint64_t localIndex, unsigned lx, unsi
 //                                   extern "C" API (ctypes)
 // =====================================================================================
 extern "C" {
+
+// branch coverage of the miss program since the last reset (see the COV_* list above); out[COV_N]
+unsigned int orc_coverage(unsigned long long* out, int reset)
+{
+    for (int k = 0; k < COV_N; k++) { if (out) out[k] = g_cov[k].load(); if (reset) g_cov[k].store(0); }
+    return COV_N;
+}
 
 void* orc_scene_create() { return new OScene(); }
 void orc_scene_destroy(void* s) { delete (OScene*)s; }

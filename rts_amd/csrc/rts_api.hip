@@ -291,7 +291,15 @@ static int fill_target_placement(const RtsContext* c, uint32_t t, RtsTargetDev& 
     double rad = std::sqrt(half2) * (1.0 + 2.0 * dev); wmax += rad;
     rad = rad * (1.0 + 1e-6) + wmax * 1e-6 + 1e-30;
     td.cx = wc[0]; td.cy = wc[1]; td.cz = wc[2]; td.r2 = rad * rad;
-    td.ew = (float)(wmax * 4.0e-9) + 1.0e-30f;
+    // Extra origin slack of the target-space slab test.  What it has to cover is the one error that scales with the WORLD
+    // coordinates: the exact test runs on vw = fl(fl(R v) + p), which is off the ideal R v + p by <= 2^-53 |vw| per
+    // coordinate (one rounding of the final sum; the partial sums live at target scale), i.e. <= sqrt(3) 2^-53 wmax along a
+    // target axis = 1.2e-9 m at Earth-centred coordinates (6.4e6 m).  Everything else -- the mapping R^-1 (o - p), o - p
+    // itself (Sterbenz-exact or correctly rounded), the f32 narrowing of the mapped origin -- is relative to |o - p| and
+    // is inside the 3e-7 |o'| of rts_slab_setup.  2^-49 wmax is that bound times 9.  (Round 1 used 4e-9 wmax: harmless
+    // near the origin, but 2.6 cm on every slab plane of a mesh of 10-30 cm triangles at 6.4e6 m.)
+    static const double ew_rel = []() { const char* e = getenv("RTS_EW_REL"); const double v = e ? atof(e) : 0.0; return v > 0 ? v : 1.7763568394002505e-15; }();
+    td.ew = (float)(wmax * ew_rel) + 1.0e-30f;
     if (b.root < 0 || !std::isfinite(td.cx + td.cy + td.cz + td.r2)) td.root = -1;
     return RTS_OK;
 }

@@ -209,3 +209,73 @@ def world_vertices(mesh, motion):
         v = rotate(v); n = rotate(n)
     p = np.asarray(motion["position"], np.float64)
     return v + p[None, :], n
+
+
+# ------------------------------------------------------------------------------- receiver-capture branch scenes
+def rx_window(centre, radius, theta, phi):
+    """a capture sphere given directly by its buffers (ray_tracer.cu:33-38): centre, radius, (minTheta, maxTheta), (minPhi, maxPhi)"""
+    return dict(centre=np.array(centre, np.float64), radius=float(radius), minTheta=float(theta[0]), maxTheta=float(theta[1]),
+                minPhi=float(phi[0]), maxPhi=float(phi[1]))
+
+
+def config_miss_branches(W=20, max_refl=4):
+    """The three-target scene with six capture spheres chosen so that one launch drives the miss program
+    (ray_tracer.cu:260-478) through the branches the BASELINE scenes never reach:
+      rx0 / rx1  windows that cross phi = +pi/2 / -pi/2 (second (theta, phi) region, :354-368), above / below the targets;
+      rx2 / rx3  two overlapping spheres with wide windows in the path of the direct AND the reflected rays: no `break`
+                 in the receiver loop (:272), so a ray is captured twice, power multiplied twice, last receiver wins (quirk 4);
+      rx4        a sphere beside the targets crossed along chords: both roots inside the window, nearest wins (:378-381);
+      rx5        a sphere in the beam whose window admits the EXIT point only, and only through the second region."""
+    s = config_multi(W=W, max_refl=max_refl)
+    s["name"] = "miss-branches"
+    s["tx"] = dict(origin=(-200.0, 0.0, 0.0), span=(0.12, 0.10, 0.05), dir=(0.0, 0.0))
+    s["rx"] = [
+        rx_window((-30.0, 0.0, 40.0), 30.0, (-1.5, 1.5), (0.5, 2.6)),
+        rx_window((-30.0, 0.0, -40.0), 30.0, (-1.5, 1.5), (-2.6, -0.5)),
+        rx_window((-70.0, 0.0, 0.0), 30.0, (-1.5, 1.5), (-1.5, 1.5)),
+        rx_window((-90.0, 5.0, 5.0), 40.0, (-1.5, 1.5), (-1.5, 1.5)),
+        rx_window((0.0, 70.0, 0.0), 45.0, (-math.pi / 2 - 1.5, -math.pi / 2 + 1.5), (-1.5, 1.5)),
+        rx_window((-150.0, -20.0, -20.0), 30.0, (math.pi + 0.3, math.pi + 1.3), (0.5, 2.6)),
+    ]
+    return s
+
+
+def config_pole(up=True):
+    """Direct rays straight up (down) through a capture sphere exactly above (below) the transmitter: the end points sit
+    on the sphere's poles, where atan2f returns the f32 nearest to pi/2 -- which is LARGER than the f64 pi/2 -- so the
+    phi correction of ray_tracer.cu:332-340 fires (it is dead code anywhere else: phi comes from atan2f(z, +sqrt))."""
+    sgn = 1.0 if up else -1.0
+    return dict(name="pole-%s" % ("up" if up else "down"), W=3, max_refl=1, smooth=True, n_pulses=1,
+                meshes=[dict(zip(("verts", "tris", "normals"), plate_mesh(2.0)), refl_coeff=0.9, refr_index=1.0)],
+                motion=_static_motion(1, [(500.0, 0.0, 0.0)], [(0.0, 0.0, 0.0)]),
+                tx=dict(origin=(10.0, 20.0, 30.0), span=(1.0e-9, 1.0e-9, 0.0), dir=(0.3, sgn * math.pi / 2)),
+                rx=[rx_window((10.0, 20.0, 30.0 + sgn * 100.0), 20.0, (0.3 - 1.5, 0.3 + 1.5), (sgn * math.pi / 2 - 0.6, sgn * math.pi / 2 + 0.6)),
+                    rx_window((10.0, 20.0, 30.0 + sgn * 200.0), 20.0, (0.3 + math.pi - 1.5, 0.3 + math.pi + 1.5), (-sgn * math.pi / 2 - 0.6, -sgn * math.pi / 2 + 0.6))],
+                carrier=FC, c=C0)
+
+
+# ------------------------------------------------------------------------------- Earth-centred placement
+EARTH_RADIUS = 6378136.0          # ray_tracer.cu:447
+
+
+def translate(spec, offset):
+    """the same scene with transmitter, receivers and targets moved by `offset` (np.float64[3]).  The Earth sphere of
+    ray_tracer.cu:447-476 is centred on the world origin, so a real SOARS scene lives at |x| >= 6.378e6 m: every scene
+    above sits INSIDE that sphere (each non-received ray takes the t1 >= 0 root only); translated to Earth-centred
+    coordinates rays pointing down take both roots, rays pointing up none."""
+    off = np.asarray(offset, np.float64)
+    s = dict(spec)
+    s["name"] = spec["name"] + "@ecef"
+    s["tx"] = dict(spec["tx"], origin=tuple(np.asarray(spec["tx"]["origin"], np.float64) + off))
+    if "tx_list" in spec:
+        s["tx_list"] = [dict(t, origin=tuple(np.asarray(t["origin"], np.float64) + off)) for t in spec["tx_list"]]
+    s["rx"] = [dict(r, centre=np.asarray(r["centre"], np.float64) + off) for r in spec["rx"]]
+    s["motion"] = [dict(m, position=tuple(np.asarray(m["position"], np.float64) + off)) for m in spec["motion"]]
+    return s
+
+
+def ecef_offset(height=10.0e3, lat=0.0, lon=0.0):
+    """a point `height` metres above the reference's Earth sphere; lat = lon = 0 puts it on the +x axis; the default of the
+    bench configuration is the north pole (0, 0, R + h), with the C3 beam (along +x) then grazing horizontally"""
+    r = EARTH_RADIUS + height
+    return np.array([r * math.cos(lat) * math.cos(lon), r * math.cos(lat) * math.sin(lon), r * math.sin(lat)], np.float64)

@@ -490,11 +490,17 @@ def test_file_mesh_on_device(rts, oracle, scenes, tmp_path):
     for f, a in ((vf, tri_v), (nf, tri_n)):
         with open(f, "w") as fh:
             for row in a:
-                fh.write("%.17g %.17g %.17g, %.17g %.17g %.17g, %.17g %.17g %.17g,\\n" % tuple(row))
+                fh.write("%.17g %.17g %.17g, %.17g %.17g %.17g, %.17g %.17g %.17g,\n" % tuple(row))
     v, t, n = rts.file_mesh(str(vf), str(nf), 0.3, -0.2, 0.1)
+    assert t.shape[0] == tri_v.shape[0] == 320 and v.shape == (960, 3) and n.shape == (960, 3)     # an empty mesh must not pass
+    ov, ot, on = oracle.file_mesh(str(vf), str(nf), 0.3, -0.2, 0.1)
+    assert np.array_equal(v, ov) and np.array_equal(t, ot) and np.array_equal(n, on)
     spec = scenes.config_multi(W=14)
     spec["meshes"][0] = dict(tris=t, verts=v, normals=n, refl_coeff=0.9, refr_index=1.0)
-    full_parity(rts, oracle, spec)[0].close()
+    tr, st, o, g = full_parity(rts, oracle, spec)
+    hit0 = (o["hit_prim"] >= 0) & (o["hit_prim"] < 320)
+    assert hit0.sum() > 20 and st["shaded"] > 0, "the file mesh must actually be hit"
+    tr.close()
 
 
 def test_api_errors(rts, scenes):

@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """node visits / triangle tests per segment of the bench scenes (counting build of the trace kernel)"""
-import os, sys
+import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rts_amd import api, scenes
-for name, spec in (("c3", scenes.config3()), ("c2", scenes.config2(rx_radius=200.0)), ("c3narrow", dict(scenes.config3(), tx=dict(scenes.config3()["tx"], span=(0.004, 0.004, 0.1))))):
+narrow = dict(scenes.config3(), tx=dict(scenes.config3()["tx"], span=(0.004, 0.004, 0.1)))
+ecef = scenes.ecef_offset(lat=math.pi / 2)
+for name, spec in (("c3", scenes.config3()), ("c2", scenes.config2(rx_radius=200.0)), ("c3narrow", narrow),
+                   ("c3ecef", scenes.translate(scenes.config3(), ecef)), ("c3narrowecef", scenes.translate(narrow, ecef))):
     tr = api.Tracer(spec["W"], spec["max_refl"], 0, spec["smooth"], count_traversal=True)
     tr.set_scene(spec["meshes"]); tr.set_receivers(spec["rx"])
     tx = spec["tx"]

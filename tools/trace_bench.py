@@ -3,6 +3,7 @@
 bench scenes and prints a checksum of the received set, so that a kernel change that alters any
 result bit is caught immediately.   python tools/trace_bench.py [c2|c3|c3s] [reps]"""
 import hashlib
+import math
 import os
 import sys
 
@@ -17,12 +18,14 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 spec = {"c2": lambda: scenes.config2(rx_radius=200.0), "c3": lambda: scenes.config3(rx_radius=50.0),
         "c3s": lambda: scenes.config3(W=100, rx_radius=50.0), "c3nomesh": lambda: scenes.config3(rx_radius=50.0),
         "c3norx": lambda: scenes.config3(rx_radius=50.0), "c3narrow": lambda: scenes.config3(rx_radius=50.0),
+        "c3ecef": lambda: scenes.translate(scenes.config3(rx_radius=50.0), scenes.ecef_offset(lat=math.pi / 2)),
+        "c3narrowecef": lambda: scenes.translate(scenes.config3(rx_radius=50.0), scenes.ecef_offset(lat=math.pi / 2)),
         "c4s": lambda: scenes.config4(W=232), "c4": lambda: scenes.config4(), "c5": lambda: scenes.config5()}[which]()
 if which == "c3nomesh":
     spec["meshes"] = []
 if which == "c3norx":
     spec["rx"] = []
-if which == "c3narrow":          # beam squeezed onto the fuselage: nearly every ray hits
+if which in ("c3narrow", "c3narrowecef"):          # beam squeezed onto the fuselage: nearly every ray hits
     spec["tx"] = dict(spec["tx"], span=(0.004, 0.004, 0.1))
 tr = api.Tracer(spec["W"], spec["max_refl"], 0, spec["smooth"])
 tr.set_scene(spec["meshes"]); tr.set_receivers(spec["rx"])
