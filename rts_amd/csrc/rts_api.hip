@@ -465,7 +465,8 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
         } else c->tile_cost_pending = false;                        // (costs of an unaligned or single-sweep launch are not recorded)
     }
     const char* tl_path = count_trav ? getenv("RTS_TIMELINE") : nullptr;      // debug: dump the block/tile timeline of this launch
-    if (tl_path) { RTS_HIP(c->d_timeline.reserve((size_t)grid * 2 + (n + RTS_WTILE - 1) / RTS_WTILE + 1)); RTS_HIP(hipMemsetAsync(c->d_timeline.p, 0, sizeof(unsigned long long) * ((size_t)grid * 2 + (n + RTS_WTILE - 1) / RTS_WTILE + 1), st)); a.timeline = c->d_timeline.p; }
+    const size_t cnt_tl = (size_t)grid * 2 + 2 * (size_t)((n + RTS_WTILE - 1) / RTS_WTILE);          // [grid][2] block ticks, [tiles] durations, [tiles] start ticks
+    if (tl_path) { RTS_HIP(c->d_timeline.reserve(cnt_tl + 1)); RTS_HIP(hipMemsetAsync(c->d_timeline.p, 0, sizeof(unsigned long long) * (cnt_tl + 1), st)); a.timeline = c->d_timeline.p; }
     c->last_args = a;
 
     // ---- trace
@@ -482,7 +483,6 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     c->pulse_open = true;
     if (tl_path) {
         RTS_HIP(hipStreamSynchronize(st));
-        const size_t cnt_tl = (size_t)grid * 2 + (n + RTS_WTILE - 1) / RTS_WTILE;
         std::vector<unsigned long long> h(cnt_tl + 2);
         h[0] = grid; h[1] = (n + RTS_WTILE - 1) / RTS_WTILE;
         RTS_HIP(hipMemcpy(h.data() + 2, c->d_timeline.p, sizeof(unsigned long long) * cnt_tl, hipMemcpyDeviceToHost));

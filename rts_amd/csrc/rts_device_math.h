@@ -101,18 +101,10 @@ RTS_HD double rts_atan_unit(double x) {
     s = 1.0/5.0 - r2 * s;
     s = 1.0/3.0 - r2 * s;
     s = 1.0 - r2 * s;
-    double base;
-    switch (k) {
-        case 0: base = 0.0; break;
-        case 1: base = 0.12435499454676143503; break;
-        case 2: base = 0.24497866312686415417; break;
-        case 3: base = 0.35877067027057222040; break;
-        case 4: base = 0.46364760900080611621; break;
-        case 5: base = 0.55859931534356243597; break;
-        case 6: base = 0.64350110879328438680; break;
-        case 7: base = 0.71882999962162450542; break;
-        default: base = 0.78539816339744830962; break;
-    }
+    // atan(k/8), k = 0..8 (a table, not a switch: the switch became a tree of branches with its constants in scratch)
+    static const double atan_k8[9] = { 0.0, 0.12435499454676143503, 0.24497866312686415417, 0.35877067027057222040, 0.46364760900080611621,
+                                       0.55859931534356243597, 0.64350110879328438680, 0.71882999962162450542, 0.78539816339744830962 };
+    const double base = atan_k8[k < 0 ? 0 : (k > 8 ? 8 : k)];
     return base + r * s;
 }
 RTS_HD double rts_atan2_f64(double y, double x) {

@@ -97,7 +97,7 @@ void put_box(RtsNode4& o, int k, const Box& b)
     o.lox[k] = f32_dn(b.lo[0] - pad); o.loy[k] = f32_dn(b.lo[1] - pad); o.loz[k] = f32_dn(b.lo[2] - pad);
     o.hix[k] = f32_upw(b.hi[0] + pad); o.hiy[k] = f32_upw(b.hi[1] + pad); o.hiz[k] = f32_upw(b.hi[2] + pad);
     const bool ok = std::isfinite(o.lox[k]) && std::isfinite(o.loy[k]) && std::isfinite(o.loz[k]) && std::isfinite(o.hix[k]) && std::isfinite(o.hiy[k]) && std::isfinite(o.hiz[k]);
-    if (!ok) { o.lox[k] = o.loy[k] = o.loz[k] = 3.0e38f; o.hix[k] = o.hiy[k] = o.hiz[k] = -3.0e38f; }   // coordinates beyond f32: never hit
+    if (!ok) { o.lox[k] = o.loy[k] = o.loz[k] = 3.0e38f; o.hix[k] = o.hiy[k] = o.hiz[k] = 3.0e38f; }   // coordinates beyond f32: never hit (see new_node)
 }
 
 // ---- reference splitting (early split clipping).  A triangle whose box is mostly empty -- long, thin and diagonal, like
@@ -243,7 +243,10 @@ int rts_sah_build(const double* verts, const uint32_t* tris, uint32_t n_tris, do
     const int32_t node_base = (int32_t)nodes.size();
     struct Item { int n2; int32_t n4; int depth; };
     std::vector<Item> stack;
-    auto new_node = [&]() { RtsNode4 o; for (int k = 0; k < 4; k++) { o.lox[k] = o.loy[k] = o.loz[k] = 3.0e38f; o.hix[k] = o.hiy[k] = o.hiz[k] = -3.0e38f; o.child[k] = 0x7fffffff; o.pad[k] = 0; }
+    // unused slots: the degenerate box lo = hi = 3e38 in every axis.  The traversal takes min / max of the two plane
+    // parameters of an axis (rts_trace.hip), so an INVERTED box would read as a valid one; a point at 3e38 gives entry = exit
+    // = +-inf (or 3e38 |1/d|), which fails entry <= min(exit, t_prune) for every ray.
+    auto new_node = [&]() { RtsNode4 o; for (int k = 0; k < 4; k++) { o.lox[k] = o.loy[k] = o.loz[k] = 3.0e38f; o.hix[k] = o.hiy[k] = o.hiz[k] = 3.0e38f; o.child[k] = 0x7fffffff; o.pad[k] = 0; }
                             nodes.push_back(o); return (int32_t)nodes.size() - 1; };
     const int32_t root4 = new_node();
     stack.push_back(Item{0, root4, 1});

@@ -23,28 +23,74 @@
 #include "rts_ray_ops.h"
 
 // Conservative f32 slab test of a ray against padded f32 boxes (the traversal only has to be CONSERVATIVE with respect
-// to the f64 triangle test; the boxes are padded f32 already, rts_sah.cpp).  Error budget:
-//   o32 = fl32(o), |o - o32| <= 2^-24 |o|;  E = 3e-7 * max|o| (+ extra) covers that and the rounding of o32 +- E;
-//   near planes are measured from the origin pushed E TOWARDS them, far planes from the origin pushed E AWAY, so
-//   every per-axis interval contains the exact one; the f32 roundings of d, of 1/d, of the subtraction and of the
-//   product (5 x 2^-24 = 3e-7 relative) are covered by scaling the near reciprocal by (1 - 6e-7) and the far one by
-//   (1 + 6e-7).  Signs follow 1/d so that a zero direction component (1/d = +-inf) gives (-inf, +inf) when the
-//   origin is inside the slab (NaN products are dropped by fmaxf/fminf, which widens the interval).
-struct RtsSlabRay { float oNx, oFx, oNy, oFy, oNz, oFz, iNx, iFx, iNy, iFy, iNz, iFz; bool spx, spy, spz; };
+// to the f64 triangle test; the boxes are padded f32 already, rts_sah.cpp).  Per axis the ray parameter at a box plane P is
+//     t(P) = (P - o) / d  =  fma(P, i, c),   i = 1/d,  c = -o i
+// -- ONE instruction per plane, with per-ray constants (i, c) that already carry the whole error budget, chosen by the role
+// the plane plays for this ray (d > 0: the box's low plane is the entry plane, its high plane the exit plane; d < 0 the
+// other way round), so the per-node code needs no sign selects: it evaluates tL = fma(lo, iL, cL), tH = fma(hi, iH, cH)
+// and takes min / max.  Error budget (f32, eps = 2^-24):
+//   o32 = fl32(o): |o - o32| <= eps |o|; c = fl(o' i') with o' = o32 -+ E: its rounding, eps |o' i'|, is a shift of the
+//   origin by eps |o'|; the f64 hit point that has to lie inside the box is off the ideal target-space point by `extra`
+//   (world-scale rounding of the placed vertices, RtsTargetDev::ew).  E = 4.5e-7 max|o| + extra covers all three (2.7 eps
+//   would do) and the rounding of o32 -+ E itself.
+//   The roundings of fl32(d), of 1/d, of i' = i (1 -+ 6e-7) and of the fma result are <= 4 eps = 2.4e-7 relative to t: the
+//   entry reciprocal is scaled by (1 - 6e-7), the exit one by (1 + 6e-7).  (Where that shrinks a NEGATIVE entry value
+//   towards zero the clamp max(., 0) of the caller makes it irrelevant; an exit value that comes out negative belongs to
+//   a box behind the origin, E included.)
+//   d = 0 (or |1/d| beyond 1e30, where o i could overflow): the axis is dropped (entry -inf, exit +inf) -- conservative.
+struct RtsSlabRay { float iLx, cLx, iHx, cHx, iLy, cLy, iHy, cHy, iLz, cLz, iHz, cHz; };
+__device__ __forceinline__ void rts_slab_axis(float o, float d, float E, float& iL, float& cL, float& iH, float& cH)
+{
+    const float iv = 1.0f / d;
+    const bool pos = !(iv < 0.0f);
+    const float oN = o + (pos ? E : -E), oF = o - (pos ? E : -E);          // entry origin pushed towards the entry plane, exit origin away
+    const float iN = iv * 0.9999994f, iF = iv * 1.0000006f;
+    const float cN = -(oN * iN), cF = -(oF * iF);
+    const bool drop = !(fabsf(iv) < 1.0e30f);                               // d == 0, denormal d, NaN
+    const float NINF = -__builtin_inff(), PINF = __builtin_inff();
+    // the low plane is the entry plane when d > 0
+    iL = drop ? 0.0f : (pos ? iN : iF); cL = drop ? NINF : (pos ? cN : cF);
+    iH = drop ? 0.0f : (pos ? iF : iN); cH = drop ? PINF : (pos ? cF : cN);
+}
 __device__ __forceinline__ RtsSlabRay rts_slab_setup(const dvec3& o, const dvec3& d, float extra)
 {
     RtsSlabRay r;
     const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
-    const float Eo = fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) * 3.0e-7f + extra + 1.0e-30f;
-    const float ivx = 1.0f / (float)d.x, ivy = 1.0f / (float)d.y, ivz = 1.0f / (float)d.z;
-    r.spx = !(ivx < 0.0f); r.spy = !(ivy < 0.0f); r.spz = !(ivz < 0.0f);
-    r.oNx = ox + (r.spx ? Eo : -Eo); r.oFx = ox - (r.spx ? Eo : -Eo);
-    r.oNy = oy + (r.spy ? Eo : -Eo); r.oFy = oy - (r.spy ? Eo : -Eo);
-    r.oNz = oz + (r.spz ? Eo : -Eo); r.oFz = oz - (r.spz ? Eo : -Eo);
-    r.iNx = ivx * 0.9999994f; r.iFx = ivx * 1.0000006f;
-    r.iNy = ivy * 0.9999994f; r.iFy = ivy * 1.0000006f;
-    r.iNz = ivz * 0.9999994f; r.iFz = ivz * 1.0000006f;
+    const float E = fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) * 4.5e-7f + extra + 1.0e-30f;
+    rts_slab_axis(ox, (float)d.x, E, r.iLx, r.cLx, r.iHx, r.cHx);
+    rts_slab_axis(oy, (float)d.y, E, r.iLy, r.cLy, r.iHy, r.cHy);
+    rts_slab_axis(oz, (float)d.z, E, r.iLz, r.cLz, r.iHz, r.cHz);
     return r;
+}
+
+// The record fetch of a traversal step as explicit instructions.  Written as plain loads ahead of the node / leaf branches
+// the compiler sinks them into the branches again -- narrowed to the dwords each branch uses (17 global_load_dword) and, being
+// in an if / else, issued one branch after the other: two dependent memory round trips per step.  Here: five (seven) dwordx4
+// loads from one per-lane base, then ONE wait; `seven` is wave-divergent (lanes at leaves need 80 bytes, lanes at nodes 112).
+typedef unsigned int rts_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void rts_fetch_record(const void* p, bool seven, rts_u32x4& q0, rts_u32x4& q1, rts_u32x4& q2, rts_u32x4& q3,
+                                                 rts_u32x4& q4, rts_u32x4& q5, rts_u32x4& q6)
+{
+    asm volatile("global_load_dwordx4 %0, %5, off\n\t"
+                 "global_load_dwordx4 %1, %5, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %5, off offset:32\n\t"
+                 "global_load_dwordx4 %3, %5, off offset:48\n\t"
+                 "global_load_dwordx4 %4, %5, off offset:64"
+                 : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4) : "v"(p) : "memory");
+    if (seven) asm volatile("global_load_dwordx4 %0, %2, off offset:80\n\t"
+                            "global_load_dwordx4 %1, %2, off offset:96"
+                            : "+&v"(q5), "+&v"(q6) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void rts_fetch_wait(rts_u32x4& q0, rts_u32x4& q1, rts_u32x4& q2, rts_u32x4& q3, rts_u32x4& q4, rts_u32x4& q5, rts_u32x4& q6)
+{
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(q6) : : "memory");
+}
+
+// The stack entry below the top when it may live in the global spill slab (rare; kept out of line so that the common LDS
+// read stays a ds_read).
+__device__ __attribute__((noinline)) int rts_stack_below_spilled(int from_lds, int sp, int lds_cap, const int32_t* ovf, uint32_t total_threads, uint32_t gtid)
+{
+    return (sp - 1 < lds_cap) ? from_lds : ovf[(size_t)(sp - 1 - lds_cap) * total_threads + gtid];
 }
 
 // KEEP_ALL is a template parameter, not a run-time flag: hipcc (ROCm 7.2) lowered the uniform
@@ -161,64 +207,81 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
                     const dvec3 ol = mk3(TG.rinv[0]*q.x + TG.rinv[1]*q.y + TG.rinv[2]*q.z, TG.rinv[3]*q.x + TG.rinv[4]*q.y + TG.rinv[5]*q.z, TG.rinv[6]*q.x + TG.rinv[7]*q.y + TG.rinv[8]*q.z);
                     const dvec3 dl = mk3(TG.rinv[0]*dir.x + TG.rinv[1]*dir.y + TG.rinv[2]*dir.z, TG.rinv[3]*dir.x + TG.rinv[4]*dir.y + TG.rinv[5]*dir.z, TG.rinv[6]*dir.x + TG.rinv[7]*dir.y + TG.rinv[8]*dir.z);
                     const RtsSlabRay lr = rts_slab_setup(ol, dl, TG.ew);
-                    const float oNx = lr.oNx, oFx = lr.oFx, oNy = lr.oNy, oFy = lr.oFy, oNz = lr.oNz, oFz = lr.oFz;
-                    const float iNx = lr.iNx, iFx = lr.iFx, iNy = lr.iNy, iFy = lr.iFy, iNz = lr.iNz, iFz = lr.iFz;
-                    const bool spx = lr.spx, spy = lr.spy, spz = lr.spz;
-                    int sp = 0;
-                    int node = TG.root;
+                    // Traversal stack: entry e of lane `tid` lives at s_stack[e * RTS_BLOCK + tid] for e < stack_lds and in the
+                    // global slab above that.  Entry 0 holds a sentinel, so "pop" never needs an emptiness test and the walk
+                    // ends when the sentinel comes off.  The common step is branch free: the entry a lane falls back to
+                    // (`below`) is read at the top of the step, beside the step's global loads; children are stored
+                    // unconditionally at the top of the stack and the stack pointer advances by the hit predicate.
                     const int SENTINEL = 0x7fffffff;
+                    const int lds_cap = (int)a.stack_lds;
+                    s_stack[tid] = SENTINEL;
+                    int sp = 1;
+                    int node = TG.root;
                     while (node != SENTINEL) {
                         if (++steps > (1u << 24)) { hard_overflow = true; break; }   // malformed tree guard: every wave must drain
-                        if (node >= 0) {
+                        const bool deep = __any(sp + 4 > lds_cap);                  // wave-uniform: some lane is about to leave the LDS part
+                        int below = s_stack[min(sp - 1, lds_cap - 1) * RTS_BLOCK + tid];      // (always an LDS read: a second, global source here made the compiler fold both into one FLAT load)
+                        if (deep) below = rts_stack_below_spilled(below, sp, lds_cap, a.stack_ovf, a.total_threads, gtid);
+                        // One fetch for both kinds of step: a lane at a node needs its 112-byte record (six planes + child ids),
+                        // a lane at a leaf its 80-byte record -- the same five (seven) dwordx4 loads from a per-lane base,
+                        // issued together at the top of the step, so a wave whose lanes are at nodes AND at leaves waits for
+                        // ONE memory round trip (as if / else bodies the leaf loads could only be issued after the node body).
+                        const bool at_node = node >= 0;
+                        const void* rp = at_node ? static_cast<const void*>(a.nodes4 + node) : static_cast<const void*>(a.leaves + ~node);
+                        rts_u32x4 q0, q1, q2, q3, q4, q5, q6;
+                        asm volatile("; q5, q6: defined for the lanes at nodes only" : "=v"(q5), "=v"(q6));      // (no instruction: spares eight v_mov of zeros per step)
+                        rts_fetch_record(rp, at_node, q0, q1, q2, q3, q4, q5, q6);
+                        rts_fetch_wait(q0, q1, q2, q3, q4, q5, q6);
+                        if (at_node) {
                             // BVH4 node: six dwordx4 planes (lo/hi x,y,z of the four children) + the four child ids
-                            const float4* np = reinterpret_cast<const float4*>(a.nodes4 + node);
-                            const float4 LX = np[0], LY = np[1], LZ = np[2], HX = np[3], HY = np[4], HZ = np[5];
-                            const int4 CH = reinterpret_cast<const int4*>(np)[6];
+                            // (by value through __uint_as_float: __builtin_bit_cast applied to an ext-vector ELEMENT reads element 0)
+#define RTS_F4(q) make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w))
+                            const float4 LX = RTS_F4(q0), LY = RTS_F4(q1), LZ = RTS_F4(q2), HX = RTS_F4(q3), HY = RTS_F4(q4), HZ = RTS_F4(q5);
+#undef RTS_F4
+                            const int4 CH = make_int4((int)q6.x, (int)q6.y, (int)q6.z, (int)q6.w);
                             if (COUNT) n_nodes++;
-                            const float4 NX = spx ? LX : HX, FX = spx ? HX : LX, NY = spy ? LY : HY, FY = spy ? HY : LY, NZ = spz ? LZ : HZ, FZ = spz ? HZ : LZ;
-#define RTS_SLAB4(k) fmaxf(fmaxf(fmaxf((NX.k - oNx) * iNx, (NY.k - oNy) * iNy), (NZ.k - oNz) * iNz), 0.0f)
-#define RTS_SLABF4(k) fminf(fminf(fminf((FX.k - oFx) * iFx, (FY.k - oFy) * iFy), (FZ.k - oFz) * iFz), t_prune)
-                            float d0 = RTS_SLAB4(x), d1 = RTS_SLAB4(y), d2 = RTS_SLAB4(z), d3 = RTS_SLAB4(w);
                             const float INF = __builtin_inff();
-                            if (!(d0 <= RTS_SLABF4(x))) d0 = INF;
-                            if (!(d1 <= RTS_SLABF4(y))) d1 = INF;
-                            if (!(d2 <= RTS_SLABF4(z))) d2 = INF;
-                            if (!(d3 <= RTS_SLABF4(w))) d3 = INF;
-#undef RTS_SLAB4
-#undef RTS_SLABF4
+#define RTS_CHILD(k, dk) float dk; { \
+                                const float ax = __builtin_fmaf(LX.k, lr.iLx, lr.cLx), bx = __builtin_fmaf(HX.k, lr.iHx, lr.cHx); \
+                                const float ay = __builtin_fmaf(LY.k, lr.iLy, lr.cLy), by = __builtin_fmaf(HY.k, lr.iHy, lr.cHy); \
+                                const float az = __builtin_fmaf(LZ.k, lr.iLz, lr.cLz), bz = __builtin_fmaf(HZ.k, lr.iHz, lr.cHz); \
+                                const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f)); \
+                                const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), t_prune)); \
+                                dk = (tn <= tf) ? tn : INF; }
+                            RTS_CHILD(x, d0) RTS_CHILD(y, d1) RTS_CHILD(z, d2) RTS_CHILD(w, d3)
+#undef RTS_CHILD
                             int c0 = CH.x, c1 = CH.y, c2 = CH.z, c3 = CH.w;
                             // sort the four (distance, child) pairs ascending (5 compare-exchanges); misses carry +inf
 #define RTS_CSWAP(da, ca, db, cb) { const bool sw = db < da; const float td = sw ? db : da; const int tc = sw ? cb : ca; db = sw ? da : db; cb = sw ? ca : cb; da = td; ca = tc; }
                             RTS_CSWAP(d0, c0, d1, c1) RTS_CSWAP(d2, c2, d3, c3) RTS_CSWAP(d0, c0, d2, c2) RTS_CSWAP(d1, c1, d3, c3) RTS_CSWAP(d1, c1, d2, c2)
 #undef RTS_CSWAP
-                            // continue with the nearest, push the others farthest first.  Fast path (wave-uniform test): every
-                            // lane has room for three more entries in the LDS part of the stack -- plain predicated LDS stores;
-                            // otherwise the general path that may spill to the global slab.
-#define RTS_PUSH(cv) { if (sp < (int)a.stack_lds) s_stack[sp * RTS_BLOCK + tid] = (cv); \
-                       else if (sp < (int)a.stack_lds + RTS_STACK_OVF) { a.stack_ovf[(size_t)(sp - (int)a.stack_lds) * a.total_threads + gtid] = (cv); n_spill++; } \
-                       else hard_overflow = true; \
-                       if (sp < (int)a.stack_lds + RTS_STACK_OVF) sp++; }
-                            if (__all(sp + 3 <= (int)a.stack_lds)) {
-                                if (d3 < INF) { s_stack[sp * RTS_BLOCK + tid] = c3; sp++; }
-                                if (d2 < INF) { s_stack[sp * RTS_BLOCK + tid] = c2; sp++; }
-                                if (d1 < INF) { s_stack[sp * RTS_BLOCK + tid] = c1; sp++; }
-                                if (d0 < INF) node = c0;
-                                else if (sp == 0) node = SENTINEL;
-                                else { sp--; node = s_stack[sp * RTS_BLOCK + tid]; }
+                            // continue with the nearest, push the others farthest first
+                            if (!deep) {
+                                s_stack[sp * RTS_BLOCK + tid] = c3; sp += (d3 < INF) ? 1 : 0;
+                                s_stack[sp * RTS_BLOCK + tid] = c2; sp += (d2 < INF) ? 1 : 0;
+                                s_stack[sp * RTS_BLOCK + tid] = c1; sp += (d1 < INF) ? 1 : 0;
+                                const bool go = d0 < INF;                         // nothing hit: nothing was pushed either, `below` is the top
+                                node = go ? c0 : below; sp -= go ? 0 : 1;
                             } else {
+#define RTS_PUSH(cv) { if (sp < lds_cap) s_stack[sp * RTS_BLOCK + tid] = (cv); \
+                       else if (sp < lds_cap + RTS_STACK_OVF) { a.stack_ovf[(size_t)(sp - lds_cap) * a.total_threads + gtid] = (cv); n_spill++; } \
+                       else hard_overflow = true; \
+                       if (sp < lds_cap + RTS_STACK_OVF) sp++; }
                                 if (d3 < INF) RTS_PUSH(c3)
                                 if (d2 < INF) RTS_PUSH(c2)
                                 if (d1 < INF) RTS_PUSH(c1)
-                                if (d0 < INF) node = c0;
-                                else {
-                                    if (sp == 0) node = SENTINEL;
-                                    else { sp--; node = (sp < (int)a.stack_lds) ? s_stack[sp * RTS_BLOCK + tid] : a.stack_ovf[(size_t)(sp - (int)a.stack_lds) * a.total_threads + gtid]; }
-                                }
-                            }
 #undef RTS_PUSH
+                                if (d0 < INF) node = c0;
+                                else { node = below; sp--; }
+                            }
                         } else {
                             const int leaf = ~node;
-                            const RtsLeafTri L = a.leaves[leaf];
+                            RtsLeafTri L;
+#define RTS_D(lo, hi) __hiloint2double((int)(hi), (int)(lo))
+                            L.p0x = RTS_D(q0.x, q0.y); L.p0y = RTS_D(q0.z, q0.w); L.p0z = RTS_D(q1.x, q1.y); L.p1x = RTS_D(q1.z, q1.w);
+                            L.p1y = RTS_D(q2.x, q2.y); L.p1z = RTS_D(q2.z, q2.w); L.p2x = RTS_D(q3.x, q3.y); L.p2y = RTS_D(q3.z, q3.w);
+                            L.p2z = RTS_D(q4.x, q4.y); L.prim = q4.z; L.targ = q4.w;
+#undef RTS_D
                             if (COUNT) n_tris++;
                             const TriHit h = tri_test(L, prev, dir, tmin, RTS_DEFAULT_TMAX);
                             if (h.ok) {
@@ -228,8 +291,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
                                     t_prune = f32_next_up_pos(tf);                 // keep equal-t candidates reachable
                                 }
                             }
-                            if (sp == 0) node = SENTINEL;
-                            else { sp--; node = (sp < (int)a.stack_lds) ? s_stack[sp * RTS_BLOCK + tid] : a.stack_ovf[(size_t)(sp - (int)a.stack_lds) * a.total_threads + gtid]; }
+                            node = below; sp--;
                         }
                     }
                 }
@@ -433,7 +495,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
       if (lane == 0) {
           const unsigned long long dt = (unsigned long long)(clock64() - tile_t0) >> 6;
           if (a.tile_cost) a.tile_cost[tile] = (unsigned int)(dt > 0xfffffffeULL ? 0xfffffffeULL : dt) + 1u;
-          if (COUNT && a.timeline) a.timeline[(size_t)gridDim.x * 2 + tile] = wall_clock64() - tl_tile;       // debug timeline (RTS_TIMELINE)
+          if (COUNT && a.timeline) { a.timeline[(size_t)gridDim.x * 2 + tile] = wall_clock64() - tl_tile; a.timeline[(size_t)gridDim.x * 2 + n_tiles + tile] = tl_tile; }   // debug timeline (RTS_TIMELINE): duration, start tick
       }
      }   // tiles of the draw
     }

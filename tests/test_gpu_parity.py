@@ -251,7 +251,7 @@ def test_bvh_invariants(rts, scenes):
             for k in range(4):
                 c = child[i, k]
                 if c == 0x7fffffff:
-                    assert (lo[i, k] > hi[i, k]).all()                        # unused slot: empty box
+                    assert (lo[i, k] == hi[i, k]).all() and (lo[i, k] > 1e38).all()    # unused slot: a point at 3e38, unreachable
                     continue
                 used += 1
                 assert (lo[i, k] >= plo).all() and (hi[i, k] <= phi).all()     # nested in the parent's box

@@ -20,6 +20,7 @@ for _ in range(3):
     st = tr.trace(tx["origin"], tx["span"], tx["dir"], spec["motion"])
 d = np.fromfile(out, np.uint64)
 grid, ntiles = int(d[0]), int(d[1]); blk = d[2:2 + 2 * grid].reshape(grid, 2).astype(np.int64); tile = d[2 + 2 * grid:2 + 2 * grid + ntiles].astype(np.float64) / 100.0   # us
+tstart = d[2 + 2 * grid + ntiles:2 + 2 * grid + 2 * ntiles].astype(np.int64)
 t0 = blk[:, 0].min(); start = (blk[:, 0] - t0) / 100.0; end = (blk[:, 1] - t0) / 100.0
 print("launch %.3f ms (events), blocks %d wave tiles %d" % (st["ms_trace"], grid, ntiles))
 print("block start us: pct 0/25/50/75/100 =", np.percentile(start, [0, 25, 50, 75, 100]).round(1))
@@ -32,8 +33,12 @@ busy = np.zeros(int(end.max() / 50) + 2)
 for s, e in zip(start, end):
     busy[int(s / 50):int(e / 50) + 1] += 1
 print("resident blocks per 50 us bin:", busy.astype(int).tolist())
-slow = np.argsort(tile)[-10:]
-print("slowest tiles (tile, us):", [(int(t), round(float(tile[t]), 1)) for t in slow])
+slow = np.argsort(tile)[-16:][::-1]
+print("slowest tiles (tile, start us, duration us, end us):", [(int(t), round(float(tstart[t] - t0) / 100.0, 1), round(float(tile[t]), 1), round(float(tstart[t] - t0) / 100.0 + float(tile[t]), 1)) for t in slow])
+srt = np.sort(tile)[::-1]
+print("sorted tile durations us: top 1/4/16/64/256/1024 =", [round(float(srt[k]), 1) for k in (0, 3, 15, 63, 255, 1023) if k < len(srt)], " balanced bound %.1f us" % (tile.sum() / (grid * 4)))
+tend = (tstart - t0) / 100.0 + tile
+print("last tiles to end (tile, start, dur, end):", [(int(t), round(float(tstart[t] - t0) / 100.0, 1), round(float(tile[t]), 1), round(float(tend[t]), 1)) for t in np.argsort(tend)[-8:][::-1]])
 hist, edges = np.histogram(tile, bins=[0, 5, 10, 20, 50, 100, 200, 400, 800, 1600, 1e9])
 print("tile duration histogram (us):", list(zip(edges[:-1].astype(int).tolist(), hist.tolist())))
 np.save(os.path.join(ROOT, "gpurun_out", "tile_us.npy"), tile)
