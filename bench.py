@@ -4,30 +4,37 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (config.workload): BASELINE.json configs[2] -- aircraft-like 100 000-triangle mesh,
-1 Tx / 4 Rx, W = 216 (10 077 696 launch indices per pulse), maxRefl = 6; the configuration the
-metric ("Mrays/s ... 100k-tri scene") is quoted on.  Synthetic mesh, isotropic antennas, RCS 1.
+Workload (config.workload): BASELINE.json configs[2] -- aircraft-like 100 000-triangle mesh, 1 Tx / 4 Rx, W = 216
+(10 077 696 launch indices per pulse), maxRefl = 6; the configuration the metric ("Mrays/s ... 100k-tri scene") is quoted
+on.  Synthetic mesh, isotropic antennas, RCS 1.  --config c3ecef is the same scene at Earth-centred coordinates
+(10 km above the reference's Earth sphere: |position| = 6.388e6 m, the Earth test of ray_tracer.cu:438-476 live),
+--config c2 / c2file the 20 480-triangle icosphere / the 10 000-triangle file-mesh sphere of configs[1].
 
-A step is ONE PULSE end to end: target placement for that pulse (the target moves every pulse: world-space
-vertices, normals and leaf records are re-placed on the device inside the timed region; the hierarchy itself is
-static in target space because the reference's targets are rigid -- the reference instead has OptiX rebuild its
-acceleration structure every pulse), trace of the pulse's W^3 launch indices, ordering +
-expansion of the received rays, finalisation and group-by aggregation into the pulse's
-responses.  A "ray" in Mrays/s is one traced segment (one rtTrace of the reference: primary or
-bounce).  Pulses are independent, so each GPU keeps three of them in flight (--inflight handles, each with its own
-streams): while one pulse's trace kernel finishes its last slow tiles the next handle's trace blocks already fill the
-freed CUs, and the scene placement / ordering / finalisation / aggregation of the neighbouring pulses run beside them.
-All of that is inside the timed region; ms_per_step is wall time / pulses.  roofline.kernel_ms_avg is the mean
-duration of a trace kernel as it ran, i.e. overlapped with its neighbours.
+A step is ONE PULSE end to end: target placement for that pulse (the target moves every pulse: world-space vertices,
+normals and leaf records are re-placed on the device inside the timed region; the hierarchy itself is static in target
+space because the reference's targets are rigid -- the reference has OptiX rebuild its acceleration structure every
+pulse), trace of the pulse's W^3 launch indices, ordering + expansion of the received rays, finalisation and group-by
+aggregation into the pulse's responses.  A "ray" in Mrays/s is one traced segment (one rtTrace of the reference: primary
+or bounce).  Pulses are independent, so each GPU keeps --inflight of them in flight on as many handles.  All of that is
+inside the timed region; ms_per_step is wall time / pulses.
 
-Scaling is strong: the K timed pulses form one coherent processing interval whose K * W^3
-(pulse, launch index) pairs are dealt to the N ranks (rts_amd/multigpu.py: whole pulses first; each of the K % N
-left-over pulses is shared by a group of ranks in interleaved 4096-index tiles; K = 1 is plain ray sharding).  The per-(receiver,
-path) group tables of all pulse parts are exchanged ONCE, at the end of the timed region and inside
-it, by an all-gather over RCCL, and merged into the per-pulse responses on every rank.
+Sharding over N ranks (--shard): "pulses" (default) deals the K pulses of the interval to the ranks whole, left-over
+pulses in interleaved tiles (rts_plan_cpi); "rays" splits EVERY pulse over all ranks in interleaved 4096-index tiles.
+Either way the per-(receiver, path) group tables are exchanged once per interval (one all-gather over RCCL) and the
+complex return cube is summed once (one all-reduce), both inside the timed region.
+
+roofline: the trace kernel moves ~100 MB of HBM per launch against >10 GB of cache-served traversal bytes, so HBM is not
+its bound (reported as secondary fields).  What binds is instruction issue: `bound` names the busier of the two per-CU
+pipes measured with rocprofv3 counters on this binary and workload (profiles/<tag>_pmc_<workload>.json, produced by
+tools/pmc_collect.sh + tools/pmc_derive.py): VALU issue (4 cycles of one of 1024 SIMDs per wave instruction) and the
+vector-memory return path (texture-data unit busy cycles, one per CU).  `achieved` scales the profile's per-segment
+figure by this run's segments and divides by this run's kernel time, `peak` is the unit count at the 2.4 GHz maximum
+clock, so frac <= 1 by construction.  The kernel time used is the SERIAL one (one trace kernel alone on the GPU, HIP
+events on its stream, measured after the timed region); the timed region itself overlaps kernels of --inflight pulses.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -38,7 +45,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+PEAK_CLOCK_HZ = 2.4e9          # max shader clock (MI355X_MICROARCH.md)
+N_SIMD, N_CU = 1024, 256
 PRI = 1.0e-3                   # pulse repetition interval of the synthetic CPI
+PMC_TAG = "r02c"               # profiles/<tag>_pmc_<workload>.json: counters of the committed kernel
 
 
 def pulse_motion(spec, k):
@@ -52,14 +62,25 @@ def pulse_motion(spec, k):
     return out
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(spec, seconds_target=12.0):
-    """The CPU restatement (oracle, BVH mode, all host threads) timed on whole pulses of the same
-    workload, repeated until ~seconds_target of CPU work.  kind = "port": the reference has no CPU
+    """The CPU restatement (oracle, BVH mode, every hardware thread, -O3 -march=native build made on this machine) timed on
+    whole pulses of the same workload, repeated until ~seconds_target of CPU work.  kind = "port": the reference has no CPU
     path and cannot be built here."""
+    os.environ["RTS_ORACLE_NATIVE"] = "1"
     from oracle import oracle as O
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import helpers as H
-    threads = min(os.cpu_count() or 1, 64)
+    threads = os.cpu_count() or 1
     sc = H.oracle_scene(O, spec, pulse_motion(spec, 0))
     tx = spec["tx"]; W = spec["W"]; total = W ** 3
     n = 20000
@@ -68,22 +89,34 @@ def cpu_baseline(spec, seconds_target=12.0):
     t0 = time.time()
     r = sc.trace(tx["origin"], tx["span"], tx["dir"], W, spec["max_refl"], 0, spec["smooth"], ray_first=0, ray_stride=total // n, n_rays=n, **kw)
     rate = r["counters"]["segments"] / max(time.time() - t0, 1e-3)
-    seg = 0; rays = 0; t0 = time.time(); reps = 0
+    seg = 0; t0 = time.time(); reps = 0
     per_pulse = max(r["counters"]["segments"] * total / n, 1)
     if per_pulse / rate <= seconds_target:                 # whole pulses, repeated until ~seconds_target of CPU work
+        best = None
         while time.time() - t0 < seconds_target and reps < 256:
+            t1 = time.time()
             r = sc.trace(tx["origin"], tx["span"], tx["dir"], W, spec["max_refl"], 0, spec["smooth"], ray_first=0, ray_stride=1, n_rays=total, **kw)
-            seg += r["counters"]["segments"]; rays += total; reps += 1
-        what = "%d whole pulses (%d launch indices each)" % (reps, total)
+            d1 = time.time() - t1
+            seg += r["counters"]["segments"]; reps += 1
+            best = d1 if best is None else min(best, d1)
+        what = "%d whole pulses (%d launch indices each), best pulse %.1f ms" % (reps, total, best * 1e3)
     else:                                                  # a strided sample of one pulse
         stride = max(int(per_pulse / (rate * seconds_target)), 1)
         m = total // stride
         r = sc.trace(tx["origin"], tx["span"], tx["dir"], W, spec["max_refl"], 0, spec["smooth"], ray_first=0, ray_stride=stride, n_rays=m, **kw)
-        seg = r["counters"]["segments"]; rays = m
+        seg = r["counters"]["segments"]
         what = "every %d-th of the %d launch indices of one pulse" % (stride, total)
     dt = time.time() - t0
-    return dict(value=seg / dt / 1e6, unit="Mrays/s", cores=threads, kind="port",
-                sample="%s: %d segments in %.1f s, oracle BVH mode, %d threads" % (what, seg, dt, threads))
+    return dict(value=seg / dt / 1e6, unit="Mrays/s", cores=threads, kind="port", cpu=cpu_model(),
+                sample="%s: %d segments in %.1f s; oracle/rts_oracle.cpp in BVH mode, g++ -O3 -march=native -ffp-contract=off, %d threads on %s"
+                       % (what, seg, dt, threads, cpu_model()))
+
+
+def load_pmc(workload):
+    p = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (PMC_TAG, workload))
+    if not os.path.exists(p):
+        return None, None
+    return json.load(open(p)), os.path.relpath(p, ROOT)
 
 
 def main():
@@ -91,11 +124,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--width", type=int, default=216, help="W (launch indices per pulse = W^3)")
+    ap.add_argument("--width", type=int, default=0, help="W (launch indices per pulse = W^3); 0 = the config's own")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--link", action="store_true", help="rts_link_handles: the handles' trace kernels run strictly one at a time (clean single-kernel timings, ~20 %% slower)")
-    ap.add_argument("--inflight", type=int, default=3, help="pulses in flight per GPU (linked handles); 1 = strictly sequential pulses")
-    ap.add_argument("--config", default="c3", choices=["c2", "c3"])
+    ap.add_argument("--link", action="store_true", help="rts_link_handles: the handles' trace kernels run strictly one at a time")
+    ap.add_argument("--inflight", type=int, default=3, help="pulses in flight per GPU; 1 = strictly sequential pulses")
+    ap.add_argument("--config", default="c3", choices=["c2", "c2file", "c3", "c3ecef"])
+    ap.add_argument("--shard", default="pulses", choices=["pulses", "rays"], help="N > 1: deal whole pulses to the ranks, or split every pulse over all ranks (interleaved tiles)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks")
     args = ap.parse_args()
 
@@ -121,36 +155,55 @@ def main():
 
     import rts_amd
     from rts_amd import api, scenes, multigpu
-    rts_amd.build()
-    spec = scenes.config3(W=args.width) if args.config == "c3" else scenes.config2(W=args.width if args.width != 216 else 100)
+    rts_amd._lib.require_built()                                  # never builds (see _lib.require_built)
+    if args.config == "c3":
+        spec = scenes.config3(W=args.width or 216)
+    elif args.config == "c3ecef":
+        spec = scenes.translate(scenes.config3(W=args.width or 216), scenes.ecef_offset(lat=math.pi / 2))
+    elif args.config == "c2":
+        spec = scenes.config2(W=args.width or 100)
+    else:
+        spec = scenes.config2_file(W=args.width or 100)
     W = spec["W"]; total = W ** 3
     tx = spec["tx"]; wl = spec["c"] / spec["carrier"]
 
-    # --inflight handles hold the same scene and take the pulses in turn: the scene placement of the next pulse and the
-    # ordering/aggregation of the previous one overlap with the trace kernels, and the tail of one trace kernel (a few slow
-    # tiles) is filled by the blocks of the next handle's (--link serialises the trace kernels instead)
+    # --inflight handles take the pulses in turn; they SHARE one copy of the immutable scene (hierarchy built once)
     trs = []
-    for _ in range(max(args.inflight, 1)):
+    t_scene0 = time.perf_counter()
+    for i in range(max(args.inflight, 1)):
         t = api.Tracer(W, spec["max_refl"], 0, spec["smooth"], device=local_rank)
-        t.set_scene(spec["meshes"]); t.set_receivers(spec["rx"])
+        if i == 0:
+            t.set_scene(spec["meshes"])
+        else:
+            t.share_scene(trs[0])
+        t.set_receivers(spec["rx"])
         t.reserve(0)                                          # set-up, not warm-up: device buffers exist before the first pulse
         if trs and args.link:
             trs[0].link(t)
         trs.append(t)
-    tr = trs[0]
+    scene_setup_s = time.perf_counter() - t_scene0
 
     # complex return cube [rx][pulse][range bin] (derived product; the dense buffer that is all-reduced over RCCL)
-    n_bins = 1024; r0 = 2.0 * abs(tx["origin"][0])
+    n_bins = 1024
+    r0 = 2.0 * float(np.linalg.norm(np.asarray(tx["origin"], np.float64) - np.asarray(spec["motion"][0]["position"], np.float64)))
     cube_t0 = (r0 - 150.0) / spec["c"]; cube_dt = 300.0 / spec["c"] / n_bins
     cube = torch.zeros((len(spec["rx"]), max(args.steps, args.warmup, 1), n_bins), dtype=torch.complex128, device="cuda")
     for t in trs:                                              # every pulse owns one row of the cube, so the handles can share it
         t.cube_attach(cube.shape[0], cube.shape[1], n_bins, cube_t0, cube_dt, device_ptr=cube.data_ptr())
+
+    def plan(n_pulses):
+        if args.shard == "rays" and world > 1:
+            p = multigpu.plan_rays(total, n_pulses, rank, world)
+        else:
+            p = multigpu.plan_cpi(total, n_pulses, rank, world)
+        return multigpu.refine_plan(p, len(trs))
 
     def run_cpi(k0, n_pulses):
         """pulses k0 .. k0+n_pulses-1 as one coherent processing interval, sharded over the ranks"""
         parts = []; acc = dict(segments=0, shaded=0, received=0, ms_scene=0.0, ms_trace=0.0, ms_post=0.0, launches=0)
         cube.zero_(); torch.cuda.synchronize()
         t_cpi = time.perf_counter()
+
         def finish(t, k):
             t.trace_end()
             t.finalise_uniform(None, wl, 1.0, 1.0, spec["carrier"], spec["c"])
@@ -165,7 +218,7 @@ def main():
                 print("pulse %d done at %.3f ms: scene %.3f trace %.3f compact %.3f agg %.3f" % (k, (time.perf_counter() - t_cpi) * 1e3, st["ms_scene"], st["ms_trace"], st["ms_compact"], st["ms_aggregate"]), file=sys.stderr)
 
         pending = []
-        for i, (k, first, count, il) in enumerate(multigpu.refine_plan(multigpu.plan_cpi(total, n_pulses, rank, world), len(trs))):
+        for i, (k, first, count, il) in enumerate(plan(n_pulses)):
             t = trs[i % len(trs)]
             t.trace_begin(tx["origin"], tx["span"], tx["dir"], pulse_motion(spec, k0 + k), ray_first=first, ray_count=count, interleave=il)
             pending.append((t, k))
@@ -215,41 +268,95 @@ def main():
         seg_all, shaded_all, received_all = seg, shaded, received
 
     if rank == 0:
-        # traversal counts for the roofline accounting: one untimed pulse of the counting build
+        # ---- un-timed measurements behind the roofline block (rank 0, after the timed region)
+        # (1) the SERIAL trace kernel: whole pulses one after the other on one handle; HIP events on the kernel's own stream
+        ser = []
+        for k in range(12):
+            st = trs[0].trace(tx["origin"], tx["span"], tx["dir"], pulse_motion(spec, args.warmup + k))
+            if k >= 2:
+                ser.append((st["ms_trace"], st["segments"]))
+        ms_serial = float(np.mean([s[0] for s in ser])); seg_serial = float(np.mean([s[1] for s in ser]))
+        # (2) traversal counts and the primary hit fraction: one pulse of the counting build, one pulse with maxRefl = 1
+        #     (every primary hit then spawns exactly one more segment, so hit fraction = (segments - rays) / rays)
         trc = api.Tracer(W, spec["max_refl"], 0, spec["smooth"], device=local_rank, count_traversal=True)
-        trc.set_scene(spec["meshes"]); trc.set_receivers(spec["rx"])
+        trc.share_scene(trs[0]); trc.set_receivers(spec["rx"])
         sc = trc.trace(tx["origin"], tx["span"], tx["dir"], pulse_motion(spec, args.warmup))
         trc.close()
+        tr1 = api.Tracer(W, 1, 0, spec["smooth"], device=local_rank)
+        tr1.share_scene(trs[0]); tr1.set_receivers(spec["rx"])
+        s1 = tr1.trace(tx["origin"], tx["span"], tx["dir"], pulse_motion(spec, args.warmup))
+        tr1.close()
+        hit_fraction = (s1["segments"] - s1["rays"]) / max(s1["rays"], 1)
         V = sc["node_visits"] / max(sc["segments"], 1); T = sc["tri_tests"] / max(sc["segments"], 1); Hh = sc["shaded"] / max(sc["segments"], 1)
-        # SURVEY.md section 8(d), figure (B), with this build's record sizes: 288 B of ray state per segment, 128 B per
-        # BVH4 node visit (SURVEY assumed 64-B BVH2 nodes; V is counted in BVH4 nodes), 80 B per triangle test (leaf record),
-        # 96 B per shaded hit (3 normals + velocity)
+        # (3) dense control: the beam squeezed onto the fuselage, (nearly) every launch index hits and bounces
+        dense = None
+        if args.config in ("c3", "c3ecef"):
+            dtx = dict(tx, span=(0.004, 0.004, 0.1)); dn = []
+            for k in range(5):
+                st = trs[0].trace(dtx["origin"], dtx["span"], dtx["dir"], pulse_motion(spec, args.warmup + k))
+                if k >= 1:
+                    dn.append((st["ms_trace"], st["segments"]))
+            dense = dict(Gseg_per_s=float(np.mean([s[1] for s in dn]) / np.mean([s[0] for s in dn]) / 1e6),
+                         kernel_ms=float(np.mean([s[0] for s in dn])), segments=float(np.mean([s[1] for s in dn])),
+                         what="same scene, beam span 0.004 x 0.004 rad: every launch index hits the airframe")
+
+        # ---- roofline from the committed counters of this binary on this workload
+        pmc, pmc_src = load_pmc(args.config if args.config != "c3ecef" else "c3")
+        pmc_ok = pmc is not None and W == 216 and world == 1 and args.config in ("c3", "c3ecef")
+        roof = {"kernel": "k_trace", "kernel_ms_serial": ms_serial, "segments_per_launch": seg_serial,
+                "kernel_ms_overlapped_avg": ms_trace / launches, "gpu_ms_per_launch_timed_region": dt / args.steps * 1e3,
+                "hit_fraction": hit_fraction, "nodes_per_segment": V, "tri_tests_per_segment": T, "shaded_per_segment": Hh,
+                "dense_control": dense, "counters_source": pmc_src if pmc_ok else None}
+        # SURVEY.md section 8(d), figure (B): 288 B of ray state per segment, 128 B per BVH4 node visit, 80 B per triangle test
+        # (leaf record), 96 B per shaded hit -- cache-served bytes; as a fraction of the HBM peak it is a yardstick of
+        # traversal rate only and may exceed 1 (secondary field, labelled)
         bytes_per_seg = 288.0 + 128.0 * V + 80.0 * T + 96.0 * Hh
-        seg_per_launch = seg / launches                                    # rank 0's launches
-        ms_launch = ms_trace / launches
-        achieved = bytes_per_seg * seg_per_launch / (ms_launch * 1e-3) / 1e9 if ms_launch > 0 else 0.0
-        # HBM traffic cannot be read live (PMC needs rocprofv3 passes of their own): taken from the committed profile of
-        # THIS workload (profiles/r01_pmc_k_trace.json), null for any other configuration
-        traffic = None; traffic_src = None
-        pj = os.path.join(ROOT, "profiles", "r01_pmc_k_trace.json")
-        if args.config == "c3" and W == 216 and world == 1 and os.path.exists(pj):
-            traffic = json.load(open(pj))["hbm_bytes_per_launch"]; traffic_src = "profiles/r01_pmc_k_trace.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+        alg = bytes_per_seg * seg_serial
+        roof["secondary_hbm_yardstick"] = {"algorithmic_bytes_per_launch": alg, "bytes_per_segment": bytes_per_seg,
+                                           "GBps_if_it_were_hbm": alg / (ms_serial * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (ms_serial * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                           "note": "cache-served bytes priced as if they came from HBM (SURVEY 8d figure B): NOT a bound, the 20 MB scene lives in L1/L2"}
+        if pmc_ok:
+            d = pmc["derived"]; pl = pmc["per_launch"]
+            seg_prof = float(pmc.get("segments_per_launch") or seg_serial)
+            scale = seg_serial / seg_prof                           # this run's launch vs the profiled one (same workload: ~1)
+            t_s = ms_serial * 1e-3
+            valu = d["valu_wave_insts"] * scale                     # VALU wave instructions per launch
+            td = d["td_busy_cycles"] * scale                        # busy cycles of the 256 texture-data units per launch
+            f_valu = valu * 4.0 / (N_SIMD * PEAK_CLOCK_HZ * t_s)
+            f_td = td / (N_CU * PEAK_CLOCK_HZ * t_s)
+            hbm = d.get("hbm_bytes_per_launch")
+            if f_valu >= f_td:
+                roof.update(bound="valu_issue", achieved=valu / t_s / 1e9, peak=N_SIMD * PEAK_CLOCK_HZ / 4.0 / 1e9, unit="Gwave-inst/s", frac=f_valu)
+            else:
+                roof.update(bound="vmem_issue", achieved=td / t_s / 1e9, peak=N_CU * PEAK_CLOCK_HZ / 1e9, unit="G TD-busy-cycles/s", frac=f_td)
+            t_w = dt / args.steps                                   # GPU time per launch in the timed region (kernels of --inflight pulses overlap)
+            roof.update(valu_issue_frac=f_valu, vmem_return_path_frac=f_td,
+                        timed_region={"valu_issue_frac": valu * 4.0 / (N_SIMD * PEAK_CLOCK_HZ * t_w), "vmem_return_path_frac": td / (N_CU * PEAK_CLOCK_HZ * t_w),
+                                      "note": "the same per-launch counters over wall time / launches of the timed region: up to --inflight trace kernels share the chip, so a launch costs less wall time than the serial kernel (kernel_ms_serial x launches > ms_per_step x steps is expected unless --link / --inflight 1)"},
+                        in_profile={"valu_busy": d.get("valu_busy"), "td_busy": d.get("td_busy"), "ta_busy": d.get("ta_busy"), "l1_hit_rate": d.get("l1_hit_rate"),
+                                    "l2_hit_rate": d.get("l2_hit_rate"), "waves_per_simd_avg": d.get("waves_per_simd_avg"), "active_lanes_per_valu_inst": d.get("active_lanes_per_valu_inst"),
+                                    "note": "utilisations formed inside the profiled passes (busy cycles over GRBM_GUI_ACTIVE of the same dispatches)"},
+                        traffic=hbm, traffic_source="%s: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of this binary on this workload; static, not re-measured by this run" % pmc_src,
+                        hbm_GBps_measured=(hbm / t_s / 1e9) if hbm else None, hbm_frac_of_peak=(hbm / t_s / 1e9 / HBM_PEAK_GBS) if hbm else None,
+                        note="bound = the busier of VALU issue and the vector-memory return path; HBM carries ~1 % of its peak (hbm_frac_of_peak) -- the scene is cache resident, the kernel is issue bound (DESIGN.md section 5)")
+        else:
+            roof.update(bound="valu_issue", achieved=None, peak=N_SIMD * PEAK_CLOCK_HZ / 4.0 / 1e9, unit="Gwave-inst/s", frac=None, traffic=None,
+                        note="no committed counter profile for this configuration (profiles/%s_pmc_*.json cover c3 at W = 216 on one GPU)" % PMC_TAG)
         out = {
             "metric": "Mrays/s (primary+bounces) & ms/pulse, 100k-tri scene",
             "value": seg_all / dt / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[2]: %s, 1 Tx / %d Rx, W=%d (%d launch indices/pulse), maxRefl=%d, target moves every pulse (re-placed on the device per pulse; static target-space BVH4)"
-                                   % (spec["name"], len(spec["rx"]), W, total, spec["max_refl"]),
+            "config": {"workload": "BASELINE.json configs[%d]%s: %s, 1 Tx / %d Rx, W=%d (%d launch indices/pulse), maxRefl=%d, target moves every pulse (re-placed on the device per pulse; static target-space BVH4)"
+                                   % (2 if args.config.startswith("c3") else 1, " at Earth-centred coordinates" if args.config == "c3ecef" else "", spec["name"], len(spec["rx"]), W, total, spec["max_refl"]),
                        "rays_per_pulse": total, "segments_per_pulse": seg_all / args.steps, "received_per_pulse": received_all / args.steps,
-                       "primary_Mrays_per_s": total * args.steps / dt / 1e6, "return_cube": "complex128 [%d rx][%d pulses][%d bins], all-reduced once per interval" % (cube.shape[0], args.steps, n_bins), "sharding": "%d-pulse interval over %d ranks: whole pulses, left-over pulses in interleaved 4096-index tiles; one group-table all-gather + one cube all-reduce per interval" % (args.steps, world),
-                       "pulses_in_flight": len(trs), "interval_tail_ms_rank0": acc["tail_ms"], "stage_ms_per_launch_rank0": {"scene_placement": ms_scene / launches, "trace": ms_launch, "order+finalise+aggregate": ms_post / launches}},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": bytes_per_seg * seg_per_launch, "kernel": "k_trace", "bytes_per_segment": bytes_per_seg,
-                         "nodes_per_segment": V, "tri_tests_per_segment": T, "shaded_per_segment": Hh,
-                         "kernel_ms_avg": ms_launch, "segments_per_launch": seg_per_launch,
-                         "hbm_GBps_measured": (traffic / (ms_launch * 1e-3) / 1e9) if (traffic and ms_launch > 0) else None,
-                         "note": "achieved counts the ALGORITHMIC bytes of SURVEY 8d (288 B ray state + 128 B per BVH4 node visit + 80 B per triangle test + 96 B per shaded hit); the 20 MB scene is served from L1/L2 (traffic = measured HBM bytes per launch), so frac measures traversal rate against the agreed yardstick and can exceed 1 -- the kernel is latency/issue bound, not bandwidth bound (DESIGN.md section 5)"},
+                       "hit_fraction": hit_fraction, "primary_Mrays_per_s": total * args.steps / dt / 1e6,
+                       "return_cube": "complex128 [%d rx][%d pulses][%d bins], all-reduced once per interval" % (cube.shape[0], args.steps, n_bins),
+                       "sharding": ("%d-pulse interval over %d ranks, --shard %s: " % (args.steps, world, args.shard)) + ("every pulse split over all ranks in interleaved 4096-index tiles" if args.shard == "rays" else "whole pulses, left-over pulses in interleaved 4096-index tiles") + "; one group-table all-gather + one cube all-reduce per interval",
+                       "pulses_in_flight": len(trs), "linked": bool(args.link), "scene_setup_s": scene_setup_s,
+                       "interval_tail_ms_rank0": acc["tail_ms"],
+                       "stage_ms_per_launch_rank0": {"scene_placement": ms_scene / launches, "trace": ms_trace / launches, "order+finalise+aggregate": ms_post / launches}},
+            "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(spec)

@@ -53,6 +53,10 @@ typedef struct RtsParams {
 #define RTS_FLAG_KEEP_ALL_RAYS 1u /* also keep the full per-ray output buffers of the reference
                                      (dbuf_results / dbuf_targ_intersect / dbuf_rcs_angle for EVERY
                                      launch index) plus the per-segment hit trace -- parity/debug */
+#define RTS_FLAG_DEVICE_BUILD 4u  /* rts_set_scene builds the hierarchy ON THE DEVICE (LBVH: Morton codes, radix sort, Karras
+                                     hierarchy, bottom-up boxes, 4-wide collapse) instead of the host SAH builder: set-up in
+                                     milliseconds, traversal a little slower; same node format, same results (the f64 triangle
+                                     test alone decides hits).  The environment variable RTS_BUILDER=device|host overrides. */
 #define RTS_FLAG_COUNT_TRAVERSAL 2u /* run the counting build of the trace kernel (node visits and
                                      triangle tests per segment, for the roofline accounting)        */
 
@@ -153,6 +157,21 @@ int rts_device_count(int* n);
 /* ---------------------------------------------------------------- scene */
 int rts_set_scene(RtsHandle h, const RtsMesh* meshes, uint32_t n_targets);          /* ray_tracer.cpp:1020-1117 */
 int rts_set_receivers(RtsHandle h, const RtsReceiverSphere* rx, uint32_t n_rx);     /* ray_tracer.cpp:670-715,894-925 */
+/* Several handles on one device (pulses in flight, rts_trace_pulse_begin/_end) can SHARE the immutable part of a scene:
+ * dst gives up its own and reads src's meshes, hierarchy and leaf order (reference counted; the hierarchy is built once,
+ * by the rts_set_scene of the handle that owns it).  Each handle still places, traces and post-processes into its own
+ * per-pulse buffers.  A later rts_set_scene on any of the handles gives that handle a fresh scene of its own. */
+int rts_share_scene(RtsHandle dst, RtsHandle src);
+typedef struct RtsSceneInfo {
+    uint32_t n_targets, n_prims, n_nodes, n_leaves;
+    uint32_t handles_sharing;    /* handles that point at this scene                                         */
+    uint32_t builder;            /* 0: host SAH (rts_sah.cpp), 1: device LBVH (rts_lbvh.hip)                 */
+    double build_ms;             /* wall time of the hierarchy build inside rts_set_scene                    */
+    uint64_t shared_device_bytes;/* device memory of the shared, immutable part                              */
+    uint64_t handle_device_bytes;/* device memory of this handle's placement of it (leaf records, world-space
+                                    vertices and normals); per-launch buffers (rts_reserve) not included       */
+} RtsSceneInfo;
+int rts_scene_info(RtsHandle h, RtsSceneInfo* out);
 
 /* ---------------------------------------------------------------- launch
  * Replaces rtContextValidate/Compile/Launch3D (ray_tracer.cpp:1126-1165): places the targets,

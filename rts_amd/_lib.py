@@ -17,6 +17,7 @@ CSRC = os.path.join(_HERE, "csrc")
 RTS_OK, RTS_ERR_INVALID, RTS_ERR_NO_DEVICE, RTS_ERR_HIP, RTS_ERR_UNSUPPORTED, RTS_ERR_CAPACITY, RTS_ERR_IO = range(7)
 RTS_FLAG_KEEP_ALL_RAYS = 1
 RTS_FLAG_COUNT_TRAVERSAL = 2
+RTS_FLAG_DEVICE_BUILD = 4
 RTS_MAX_DEPTH = 16
 RTS_BASE_USE_ROWS = 0xffffffffffffffff
 
@@ -62,6 +63,12 @@ class RtsCubeParams(C.Structure):
                 ("t0", C.c_double), ("dt", C.c_double)]
 
 
+class RtsSceneInfo(C.Structure):
+    _fields_ = [("n_targets", C.c_uint32), ("n_prims", C.c_uint32), ("n_nodes", C.c_uint32), ("n_leaves", C.c_uint32),
+                ("handles_sharing", C.c_uint32), ("builder", C.c_uint32), ("build_ms", C.c_double),
+                ("shared_device_bytes", C.c_uint64), ("handle_device_bytes", C.c_uint64)]
+
+
 class RtsStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("segments", C.c_uint64), ("shaded", C.c_uint64), ("received", C.c_uint64),
                 ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64), ("n_prims", C.c_uint32), ("n_nodes", C.c_uint32),
@@ -77,12 +84,25 @@ GROUP_DTYPE = np.dtype([("rx", "<i4"), ("direct", "<u4"), ("path", "<i4", (RTS_M
 assert RESPONSE_DTYPE.itemsize == 48 and GROUP_DTYPE.itemsize == 120
 
 
-def build(force=False, verbose=False):
-    """Compile librts_amd.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+def is_stale():
+    """True if librts_amd.so is missing or older than one of its sources"""
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + \
            [os.path.join(_HERE, "..", "include", f) for f in ("rts_amd.h", "rts_prd.h")]
     newest = max(os.path.getmtime(s) for s in srcs if not s.endswith(".o"))
-    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest:
+    return not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest
+
+
+def require_built():
+    """bench.py and the timed tools never build: under `rocprofv3 -- python bench.py` a make -> sh -> hipcc chain would be
+    an exec from a process whose GPU the profiler's preload has already initialised.  Build beforehand
+    (__graft_entry__.build() or make -C rts_amd/csrc)."""
+    if not os.path.exists(LIB_PATH):
+        raise SystemExit("librts_amd.so is not built: run `python __graft_entry__.py` (or make -C rts_amd/csrc) first")
+
+
+def build(force=False, verbose=False):
+    """Compile librts_amd.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    if force or is_stale():
         cmd = ["make", "-C", CSRC, "-j", "5"] + ([] if verbose else ["-s"])
         subprocess.check_call(cmd)
     return LIB_PATH
@@ -91,7 +111,7 @@ def build(force=False, verbose=False):
 _lib = None
 
 # every symbol include/rts_amd.h declares
-EXPORTS = ["rts_create", "rts_destroy", "rts_last_error", "rts_device_count", "rts_set_scene", "rts_set_receivers",
+EXPORTS = ["rts_create", "rts_destroy", "rts_last_error", "rts_device_count", "rts_set_scene", "rts_share_scene", "rts_scene_info", "rts_set_receivers",
            "rts_trace_pulse", "rts_reserve", "rts_trace_pulse_begin", "rts_trace_pulse_end", "rts_link_handles", "rts_get_stats", "rts_received_count", "rts_get_received", "rts_get_all_rays",
            "rts_finalise_uniform", "rts_aggregate", "rts_group_count", "rts_get_groups", "rts_get_aggregated",
            "rts_merge_groups", "rts_groups_to_responses", "rts_kernel_wrapper", "rts_vertex_rotation",
@@ -114,6 +134,8 @@ def lib():
         "rts_destroy": [vp],
         "rts_device_count": [C.POINTER(C.c_int)],
         "rts_set_scene": [vp, C.POINTER(RtsMesh), u32],
+        "rts_share_scene": [vp, vp],
+        "rts_scene_info": [vp, C.POINTER(RtsSceneInfo)],
         "rts_set_receivers": [vp, C.POINTER(RtsReceiverSphere), u32],
         "rts_trace_pulse": [vp, C.POINTER(RtsPulse)],
         "rts_reserve": [vp, u64],

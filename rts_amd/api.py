@@ -89,9 +89,10 @@ def device_count():
 class Tracer:
     """One RtsHandle: scene + receivers + per-pulse launch on one GPU."""
 
-    def __init__(self, width, max_refl, max_refr=0, smooth=True, device=0, keep_all=False, count_traversal=False):
+    def __init__(self, width, max_refl, max_refr=0, smooth=True, device=0, keep_all=False, count_traversal=False, device_build=False):
         p = L.RtsParams(width, max_refl, max_refr, 1 if smooth else 0, device,
-                        (L.RTS_FLAG_KEEP_ALL_RAYS if keep_all else 0) | (L.RTS_FLAG_COUNT_TRAVERSAL if count_traversal else 0))
+                        (L.RTS_FLAG_KEEP_ALL_RAYS if keep_all else 0) | (L.RTS_FLAG_COUNT_TRAVERSAL if count_traversal else 0) |
+                        (L.RTS_FLAG_DEVICE_BUILD if device_build else 0))
         self.h = C.c_void_p()
         check(L.lib().rts_create(C.byref(p), C.byref(self.h)))
         self.width = width; self.max_refl = max_refl; self.depth = max_refl + (2 if max_refr else 0)
@@ -120,6 +121,16 @@ class Tracer:
                                float(m.get("refl_coeff", 1.0)), float(m.get("refr_index", 1.0)))
         check(L.lib().rts_set_scene(self.h, arr, len(meshes)))
         self.n_targets = len(meshes)
+
+    def share_scene(self, other):
+        """rts_share_scene: use `other`'s immutable scene (meshes, hierarchy, leaf order) instead of an own copy"""
+        check(L.lib().rts_share_scene(self.h, other.h))
+        self.n_targets = other.n_targets
+
+    def scene_info(self):
+        s = L.RtsSceneInfo()
+        check(L.lib().rts_scene_info(self.h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in L.RtsSceneInfo._fields_}
 
     def set_receivers(self, spheres):
         arr = (L.RtsReceiverSphere * max(len(spheres), 1))()

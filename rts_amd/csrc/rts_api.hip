@@ -10,6 +10,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <thread>
 #include "rts_internal.h"
@@ -19,6 +20,7 @@ void rts_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vsnpri
 extern "C" const char* rts_last_error(void) { return g_err; }
 
 extern int rts_fill_i32(hipStream_t st, int32_t* p, int32_t v, size_t n);
+static int rts_attach_scene(RtsContext* c);
 
 int rts_debug_stage(RtsContext* c, const char* name)
 {
@@ -56,6 +58,7 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     RTS_HIP(hipSetDevice(p->device));
     RtsContext* c = new RtsContext();
     c->params = *p; c->params.max_refr = refr; c->depth = refr + p->max_refl; c->device = p->device;
+    c->scene = new RtsScene(); c->scene->device = p->device;
     memset(&c->stats, 0, sizeof(c->stats));
     // two streams of different priority (=> different hardware queues): the long trace kernel on the low one, the many
     // short build/ordering/aggregation kernels on the high one so that they slot in while a trace kernel is running
@@ -84,10 +87,11 @@ extern "C" int rts_destroy(RtsHandle c)
     if (!c) return RTS_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    c->d_tri_vidx.release(); c->d_tri_nidx.release(); c->d_vert_targ.release(); c->d_norm_targ.release(); c->d_prim_targ.release();
-    c->d_verts_local.release(); c->d_normals_local.release(); c->d_verts_world.release(); c->d_normals_world.release();
-    c->d_motion.release(); c->d_targets.release(); c->d_leaf_prim.release();
-    c->d_nodes4.release(); c->d_leaves.release(); c->d_sort_tmp.release(); c->d_rx.release(); c->d_recv.release(); c->d_all.release();
+    if (c->scene && --c->scene->refs == 0) { c->scene->release(); delete c->scene; }
+    c->scene = nullptr;
+    c->d_verts_world.release(); c->d_normals_world.release();
+    c->d_motion.release(); c->d_targets.release();
+    c->d_leaves.release(); c->d_sort_tmp.release(); c->d_rx.release(); c->d_recv.release(); c->d_all.release();
     c->d_counters.release(); c->d_block_counters.release(); c->d_timeline.release(); c->d_tile_cost.release(); c->d_tile_key.release(); c->d_tile_key_sorted.release(); c->d_tile_id.release(); c->d_tile_order.release(); c->d_tile_hist.release(); c->d_tile_ctr.release(); c->d_lc.release(); c->d_dir_hist.release(); c->d_child.release(); c->d_rk64.release(); c->d_rk64_sorted.release(); c->d_hit_prim.release(); c->d_hit_t.release(); c->d_stack_ovf.release();
     c->d_rk.release(); c->d_rk_sorted.release(); c->d_ri.release(); c->d_ri_sorted.release(); c->d_rx_rays.release(); c->d_rx_paths.release();
     c->d_rx_angles.release(); c->d_rx_slots.release(); c->d_all_rays.release(); c->d_all_paths.release(); c->d_all_angles.release();
@@ -163,44 +167,103 @@ extern "C" int rts_set_scene(RtsHandle c, const RtsMesh* meshes, uint32_t n_targ
         for (uint32_t i = 0; i < m.n_vertices; i++) { vtarg[(size_t)h.vert_base + i] = t; for (int k = 0; k < 3; k++) verts[3*((size_t)h.vert_base + i) + k] = m.vertices[3*(size_t)i + k]; }
         for (uint32_t i = 0; i < m.n_normals; i++) { ntarg[(size_t)h.normal_base + i] = t; for (int k = 0; k < 3; k++) normals[3*((size_t)h.normal_base + i) + k] = m.normals[3*(size_t)i + k]; }
     }
-    // static target-space hierarchy, one per mesh (rts_sah.cpp); leaf slots name GLOBAL primitive ids
-    double split_budget = 1.0;                          // extra references for triangles whose boxes are mostly empty (rts_sah.cpp)
-    { const char* e = getenv("RTS_SPLIT_BUDGET"); if (e) { const double v = atof(e); if (v >= 0 && v <= 8) split_budget = v; } }
-    std::vector<RtsNode4> nodes4; std::vector<uint32_t> leaf_prim; std::vector<RtsBlasInfo> blas(n_targets);
-    {   // the meshes are independent: one host thread each (at most 16 at a time), results concatenated in target order
-        std::vector<std::vector<RtsNode4>> pn(n_targets); std::vector<std::vector<uint32_t>> pl(n_targets); std::vector<int> prc(n_targets, RTS_OK);
-        for (uint32_t t0 = 0; t0 < n_targets; t0 += 16) {
-            std::vector<std::thread> pool;
-            for (uint32_t t = t0; t < std::min(n_targets, t0 + 16); t++)
-                pool.emplace_back([&, t]() { prc[t] = rts_sah_build(meshes[t].vertices, meshes[t].triangles, meshes[t].n_triangles, split_budget, pn[t], pl[t], blas[t]); });
-            for (auto& th : pool) th.join();
-        }
-        for (uint32_t t = 0; t < n_targets; t++) {
-            if (prc[t] != RTS_OK) return prc[t];
-            const int32_t node_base = (int32_t)nodes4.size(), leaf_base = (int32_t)leaf_prim.size();
-            for (RtsNode4 nd : pn[t]) {
-                for (int k = 0; k < 4; k++) { int32_t& ch = nd.child[k]; if (ch == 0x7fffffff) continue; if (ch >= 0) ch += node_base; else ch = ~(~ch + leaf_base); }
-                nodes4.push_back(nd);
-            }
-            for (uint32_t lp : pl[t]) leaf_prim.push_back(lp + mh[t].tri_base);
-            if (blas[t].root >= 0) blas[t].root += node_base;
-        }
-    }
+    // ---- the new scene object (swapped in at the end; every failure path below leaves the handle's old scene alone)
+    struct SceneGuard { RtsScene* s; ~SceneGuard() { if (s) { s->release(); delete s; } } } guard{new RtsScene()};
+    RtsScene* ns = guard.s; ns->device = c->device;
     RTS_HIP(hipStreamSynchronize(c->stream));
-    RTS_HIP(c->d_nodes4.reserve(nodes4.size() + 1)); RTS_HIP(c->d_leaf_prim.reserve(leaf_prim.size() + 1)); RTS_HIP(c->d_leaves.reserve(leaf_prim.size() + 1));
-    if (!nodes4.empty()) RTS_HIP(hipMemcpy(c->d_nodes4.p, nodes4.data(), sizeof(RtsNode4)*nodes4.size(), hipMemcpyHostToDevice));
-    if (!leaf_prim.empty()) RTS_HIP(hipMemcpy(c->d_leaf_prim.p, leaf_prim.data(), sizeof(uint32_t)*leaf_prim.size(), hipMemcpyHostToDevice));
-    c->blas = blas; c->n_nodes = (uint32_t)nodes4.size(); c->n_leaves = (uint32_t)leaf_prim.size();
-    RTS_HIP(c->d_tri_vidx.reserve(3*nt + 1)); RTS_HIP(c->d_tri_nidx.reserve(3*nt + 1)); RTS_HIP(c->d_vert_targ.reserve(nv + 1)); RTS_HIP(c->d_norm_targ.reserve(nn + 1));
-    RTS_HIP(c->d_prim_targ.reserve(nt + 1)); RTS_HIP(c->d_verts_local.reserve(3*nv + 1)); RTS_HIP(c->d_normals_local.reserve(3*nn + 1));
-    RTS_HIP(c->d_verts_world.reserve(3*nv + 1)); RTS_HIP(c->d_normals_world.reserve(3*nn + 1));
+    RTS_HIP(ns->d_tri_vidx.reserve(3*nt + 1)); RTS_HIP(ns->d_tri_nidx.reserve(3*nt + 1)); RTS_HIP(ns->d_vert_targ.reserve(nv + 1)); RTS_HIP(ns->d_norm_targ.reserve(nn + 1));
+    RTS_HIP(ns->d_prim_targ.reserve(nt + 1)); RTS_HIP(ns->d_verts_local.reserve(3*nv + 1)); RTS_HIP(ns->d_normals_local.reserve(3*nn + 1));
+    if (nt) { RTS_HIP(hipMemcpy(ns->d_tri_vidx.p, vidx.data(), sizeof(uint32_t)*3*nt, hipMemcpyHostToDevice)); RTS_HIP(hipMemcpy(ns->d_tri_nidx.p, nidx.data(), sizeof(uint32_t)*3*nt, hipMemcpyHostToDevice));
+              RTS_HIP(hipMemcpy(ns->d_prim_targ.p, ptarg.data(), sizeof(uint32_t)*nt, hipMemcpyHostToDevice)); }
+    if (nv) { RTS_HIP(hipMemcpy(ns->d_vert_targ.p, vtarg.data(), sizeof(uint32_t)*nv, hipMemcpyHostToDevice)); RTS_HIP(hipMemcpy(ns->d_verts_local.p, verts.data(), sizeof(double)*3*nv, hipMemcpyHostToDevice)); }
+    if (nn) { RTS_HIP(hipMemcpy(ns->d_norm_targ.p, ntarg.data(), sizeof(uint32_t)*nn, hipMemcpyHostToDevice)); RTS_HIP(hipMemcpy(ns->d_normals_local.p, normals.data(), sizeof(double)*3*nn, hipMemcpyHostToDevice)); }
+    ns->meshes = mh; ns->n_prims = (uint32_t)nt; ns->n_verts = (uint32_t)nv; ns->n_normals = (uint32_t)nn;
+
+    // ---- static target-space hierarchy, one per mesh; leaf slots name GLOBAL primitive ids.  Two builders, same node format:
+    //   host   (default) binned SAH with split references, one host thread per mesh (rts_sah.cpp): best traversal cost
+    //   device RTS_BUILDER=device / RtsParams.flags & RTS_FLAG_DEVICE_BUILD: LBVH built on the GPU (rts_lbvh.hip): set-up in milliseconds
+    const auto t_build0 = std::chrono::steady_clock::now();
+    bool device_build = (c->params.flags & RTS_FLAG_DEVICE_BUILD) != 0;
+    { const char* e = getenv("RTS_BUILDER"); if (e) device_build = (strcmp(e, "device") == 0); }
+    if (device_build) {
+        int rc = rts_lbvh_build_device(c, ns, vidx, mh); if (rc != RTS_OK) return rc;
+        ns->builder = 1;
+    } else {
+        double split_budget = 1.0;                          // extra references for triangles whose boxes are mostly empty (rts_sah.cpp)
+        { const char* e = getenv("RTS_SPLIT_BUDGET"); if (e) { const double v = atof(e); if (v >= 0 && v <= 8) split_budget = v; } }
+        std::vector<RtsNode4> nodes4; std::vector<uint32_t> leaf_prim; std::vector<RtsBlasInfo> blas(n_targets);
+        {   // the meshes are independent: one host thread each (at most 16 at a time), results concatenated in target order
+            std::vector<std::vector<RtsNode4>> pn(n_targets); std::vector<std::vector<uint32_t>> pl(n_targets); std::vector<int> prc(n_targets, RTS_OK);
+            for (uint32_t t0 = 0; t0 < n_targets; t0 += 16) {
+                std::vector<std::thread> pool;
+                for (uint32_t t = t0; t < std::min(n_targets, t0 + 16); t++)
+                    pool.emplace_back([&, t]() { prc[t] = rts_sah_build(meshes[t].vertices, meshes[t].triangles, meshes[t].n_triangles, split_budget, pn[t], pl[t], blas[t]); });
+                for (auto& th : pool) th.join();
+            }
+            for (uint32_t t = 0; t < n_targets; t++) {
+                if (prc[t] != RTS_OK) return prc[t];
+                const int32_t node_base = (int32_t)nodes4.size(), leaf_base = (int32_t)leaf_prim.size();
+                for (RtsNode4 nd : pn[t]) {
+                    for (int k = 0; k < 4; k++) { int32_t& ch = nd.child[k]; if (ch == 0x7fffffff) continue; if (ch >= 0) ch += node_base; else ch = ~(~ch + leaf_base); }
+                    nodes4.push_back(nd);
+                }
+                for (uint32_t lp : pl[t]) leaf_prim.push_back(lp + mh[t].tri_base);
+                if (blas[t].root >= 0) blas[t].root += node_base;
+            }
+        }
+        RTS_HIP(ns->d_nodes4.reserve(nodes4.size() + 1)); RTS_HIP(ns->d_leaf_prim.reserve(leaf_prim.size() + 1));
+        if (!nodes4.empty()) RTS_HIP(hipMemcpy(ns->d_nodes4.p, nodes4.data(), sizeof(RtsNode4)*nodes4.size(), hipMemcpyHostToDevice));
+        if (!leaf_prim.empty()) RTS_HIP(hipMemcpy(ns->d_leaf_prim.p, leaf_prim.data(), sizeof(uint32_t)*leaf_prim.size(), hipMemcpyHostToDevice));
+        ns->blas = blas; ns->n_nodes = (uint32_t)nodes4.size(); ns->n_leaves = (uint32_t)leaf_prim.size();
+        ns->builder = 0;
+    }
+    ns->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build0).count();
+
+    // ---- swap it in
+    if (--c->scene->refs == 0) { c->scene->release(); delete c->scene; }
+    c->scene = ns; guard.s = nullptr;
+    return rts_attach_scene(c);
+}
+
+// Per-handle buffers sized by the scene the handle now points at; placement and tile history start afresh.
+static int rts_attach_scene(RtsContext* c)
+{
+    const RtsScene* sc = c->scene; const uint32_t n_targets = (uint32_t)sc->meshes.size();
+    RTS_HIP(c->d_leaves.reserve((size_t)sc->n_leaves + 1));
+    RTS_HIP(c->d_verts_world.reserve(3*(size_t)sc->n_verts + 1)); RTS_HIP(c->d_normals_world.reserve(3*(size_t)sc->n_normals + 1));
     RTS_HIP(c->d_motion.reserve(n_targets + 1)); RTS_HIP(c->d_targets.reserve(n_targets + 1));
-    if (nt) { RTS_HIP(hipMemcpy(c->d_tri_vidx.p, vidx.data(), sizeof(uint32_t)*3*nt, hipMemcpyHostToDevice)); RTS_HIP(hipMemcpy(c->d_tri_nidx.p, nidx.data(), sizeof(uint32_t)*3*nt, hipMemcpyHostToDevice));
-              RTS_HIP(hipMemcpy(c->d_prim_targ.p, ptarg.data(), sizeof(uint32_t)*nt, hipMemcpyHostToDevice)); }
-    if (nv) { RTS_HIP(hipMemcpy(c->d_vert_targ.p, vtarg.data(), sizeof(uint32_t)*nv, hipMemcpyHostToDevice)); RTS_HIP(hipMemcpy(c->d_verts_local.p, verts.data(), sizeof(double)*3*nv, hipMemcpyHostToDevice)); }
-    if (nn) { RTS_HIP(hipMemcpy(c->d_norm_targ.p, ntarg.data(), sizeof(uint32_t)*nn, hipMemcpyHostToDevice)); RTS_HIP(hipMemcpy(c->d_normals_local.p, normals.data(), sizeof(double)*3*nn, hipMemcpyHostToDevice)); }
-    c->meshes = mh; c->n_prims = (uint32_t)nt; c->n_verts = (uint32_t)nv; c->n_normals = (uint32_t)nn;
     c->motion.assign(n_targets, RtsTargetMotion{}); c->motion_valid = false; c->bvh_valid = false; c->tile_hist_n = 0; c->tile_hist_any = false; c->tile_cost_pending = false;
+    return RTS_OK;
+}
+
+// rts_share_scene: dst drops its own scene and uses src's (same device): the meshes, the hierarchy and its leaf order then
+// exist once however many handles keep pulses in flight, and the hierarchy is built once.
+extern "C" int rts_share_scene(RtsHandle dst, RtsHandle src)
+{
+    if (!dst || !src || dst == src) { rts_set_error("rts_share_scene: needs two distinct handles"); return RTS_ERR_INVALID; }
+    if (dst->device != src->device) { rts_set_error("rts_share_scene: handles live on different devices (%d, %d)", dst->device, src->device); return RTS_ERR_INVALID; }
+    if (dst->params.interpolate_smooth && !src->params.interpolate_smooth) {
+        for (const RtsMeshHost& m : src->scene->meshes) if (m.n_tris && m.n_normals == 0) { rts_set_error("rts_share_scene: the scene has a mesh without normals but the receiving handle interpolates normals"); return RTS_ERR_INVALID; }
+    }
+    RtsContext* c = dst;
+    CHECK_HANDLE(c);
+    CHECK_CLOSED(c);
+    RTS_HIP(hipStreamSynchronize(c->stream));
+    if (dst->scene == src->scene) return RTS_OK;
+    if (--dst->scene->refs == 0) { dst->scene->release(); delete dst->scene; }
+    dst->scene = src->scene; dst->scene->refs++;
+    return rts_attach_scene(dst);
+}
+
+extern "C" int rts_scene_info(RtsHandle c, RtsSceneInfo* out)
+{
+    if (!c || !out) { rts_set_error("rts_scene_info: null argument"); return RTS_ERR_INVALID; }
+    const RtsScene* sc = c->scene;
+    memset(out, 0, sizeof(*out));
+    out->n_targets = (uint32_t)sc->meshes.size(); out->n_prims = sc->n_prims; out->n_nodes = sc->n_nodes; out->n_leaves = sc->n_leaves;
+    out->handles_sharing = (uint32_t)sc->refs; out->builder = sc->builder; out->build_ms = sc->build_ms;
+    out->shared_device_bytes = sc->device_bytes();
+    out->handle_device_bytes = c->d_leaves.cap * sizeof(RtsLeafTri) + c->d_verts_world.cap * 8 + c->d_normals_world.cap * 8 + c->d_motion.cap * sizeof(RtsTargetMotion) + c->d_targets.cap * sizeof(RtsTargetDev);
     return RTS_OK;
 }
 
@@ -264,7 +327,7 @@ static void fill_launch_constants(RtsLaunchConsts& a, const RtsPulse& p, uint32_
 // Per-target placement constants of a pulse: inverse rotation, world bounds of the placed hierarchy, error slack.
 static int fill_target_placement(const RtsContext* c, uint32_t t, RtsTargetDev& td)
 {
-    const RtsTargetMotion& m = c->motion[t]; const RtsBlasInfo& b = c->blas[t];
+    const RtsTargetMotion& m = c->motion[t]; const RtsBlasInfo& b = c->scene->blas[t];
     double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     if (m.has_rotation) for (int k = 0; k < 9; k++) R[k] = m.rotation[k];
     for (int k = 0; k < 9; k++) if (!std::isfinite(R[k])) { rts_set_error("rts_trace_pulse: target %u has a non-finite rotation", t); return RTS_ERR_INVALID; }
@@ -357,7 +420,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
         if (il_tile == 0 || il_part >= il_parts) { rts_set_error("rts_trace_pulse: bad interleave (tile %u, part %u of %u)", il_tile, il_part, il_parts); return RTS_ERR_INVALID; }
     }
     if (first > total || count > total - first) { rts_set_error("rts_trace_pulse: ray range [%llu, +%llu) outside W^3 = %llu", (unsigned long long)first, (unsigned long long)count, (unsigned long long)total); return RTS_ERR_INVALID; }
-    const uint32_t n_targets = (uint32_t)c->meshes.size();
+    const uint32_t n_targets = (uint32_t)c->scene->meshes.size();
     hipStream_t st = c->stream;
     c->agg_valid = false; c->n_recv = 0;
 
@@ -381,8 +444,8 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
         // completion the host already waited for (received-count readback)
         RtsTargetDev* td = c->pin->td;
         for (uint32_t t = 0; t < n_targets; t++) {
-            td[t].reflCoeff = c->meshes[t].refl_coeff; td[t].vx = c->motion[t].velocity[0]; td[t].vy = c->motion[t].velocity[1]; td[t].vz = c->motion[t].velocity[2];
-            td[t].tri_base = c->meshes[t].tri_base; td[t].perface_normals = c->meshes[t].perface ? 1u : 0u; td[t].refrIndex = c->meshes[t].refr_index;
+            td[t].reflCoeff = c->scene->meshes[t].refl_coeff; td[t].vx = c->motion[t].velocity[0]; td[t].vy = c->motion[t].velocity[1]; td[t].vz = c->motion[t].velocity[2];
+            td[t].tri_base = c->scene->meshes[t].tri_base; td[t].perface_normals = c->scene->meshes[t].perface ? 1u : 0u; td[t].refrIndex = c->scene->meshes[t].refr_index;
             int rc = fill_target_placement(c, t, td[t]); if (rc != RTS_OK) { c->bvh_valid = false; c->motion_valid = false; return rc; }
             c->pin->motion[t] = c->motion[t];
         }
@@ -421,7 +484,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     RTS_HIP(hipMemcpyAsync(c->d_lc.p, &c->pin->lc, sizeof(lc), hipMemcpyHostToDevice, st));
     a.lc = c->d_lc.p;
     a.ray_first = first; a.n_rays = n; a.W = W; a.max_refl = c->params.max_refl; a.smooth = c->params.interpolate_smooth ? 1u : 0u;
-    a.n_prims = c->n_prims; a.n_targets = n_targets; a.n_rx = c->n_rx; a.keep_all = keep_all ? 1u : 0u;
+    a.n_prims = c->scene->n_prims; a.n_targets = n_targets; a.n_rx = c->n_rx; a.keep_all = keep_all ? 1u : 0u;
     a.max_refr = c->params.max_refr; a.rows = a.max_refr ? c->params.max_refl + 3 : 1;
     const uint32_t chains = a.max_refr ? 3u : 1u;
     if ((uint64_t)n * chains > 0xfffffff0ULL) { rts_set_error("rts_trace_pulse: rays x chains exceeds 2^32"); return RTS_ERR_UNSUPPORTED; }
@@ -437,7 +500,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
         RTS_HIP(hipMemsetAsync(c->d_hit_t.p, 0, sizeof(float) * (size_t)n * (c->params.max_refl + 1), st));
     }
     RTS_HIP(hipMemsetAsync(c->d_counters.p, 0, sizeof(unsigned long long) * 16, st));
-    a.nodes4 = c->d_nodes4.p; a.stack_lds = c->stack_lds; a.leaves = c->d_leaves.p; a.tri_nidx = c->d_tri_nidx.p; a.normals = c->d_normals_world.p;
+    a.nodes4 = c->scene->d_nodes4.p; a.stack_lds = c->stack_lds; a.leaves = c->d_leaves.p; a.tri_nidx = c->scene->d_tri_nidx.p; a.normals = c->d_normals_world.p;
     a.targets = c->d_targets.p; a.rx = c->d_rx.p;
     a.recv_records = c->d_recv.p; a.all_records = c->d_all.p; a.counters = c->d_counters.p; a.block_counters = c->d_block_counters.p; a.dir_hist = c->d_dir_hist.p;
     a.hit_prim = c->d_hit_prim.p; a.hit_t = c->d_hit_t.p; a.stack_ovf = c->d_stack_ovf.p; a.child = c->d_child.p;
@@ -513,7 +576,7 @@ extern "C" int rts_trace_pulse_end(RtsHandle c)
 
     RtsStats& s = c->stats;
     s.rays = n; s.segments = cnt[1]; s.shaded = cnt[2]; s.received = cnt[0]; s.node_visits = cnt[3]; s.tri_tests = cnt[4]; s.stack_overflows = (uint32_t)cnt[5];
-    s.n_prims = c->n_prims; s.n_nodes = c->n_nodes;
+    s.n_prims = c->scene->n_prims; s.n_nodes = c->scene->n_nodes;
     s.ms_scene = s.ms_trace = s.ms_compact = s.ms_aggregate = 0;
     c->stats_pending = true; c->agg_timed = false; c->fin_timed = false;
     return RTS_OK;
@@ -582,7 +645,7 @@ extern "C" int rts_finalise_uniform(RtsHandle c, const double* rcs_per_target, d
     CHECK_HANDLE(c);
     CHECK_CLOSED(c);
     std::vector<double> ones;
-    if (!rcs_per_target) { ones.assign(c->meshes.size() + 1, 1.0); rcs_per_target = ones.data(); }
+    if (!rcs_per_target) { ones.assign(c->scene->meshes.size() + 1, 1.0); rcs_per_target = ones.data(); }
     RTS_HIP(hipEventRecord(c->ev[6], c->stream));
     int rc = rts_post_finalise(c, rcs_per_target, wavelength, gt, gr, carrier, cspeed); if (rc != RTS_OK) return rc;
     RTS_HIP(hipEventRecord(c->ev[7], c->stream));
@@ -602,7 +665,7 @@ extern "C" int rts_aggregate(RtsHandle c, double cspeed, double carrier, uint64_
     if (!c->fin_timed) RTS_HIP(hipEventRecord(c->ev[6], c->stream));
     RTS_HIP(hipMemsetAsync(c->d_delay.p, 0, sizeof(double)*R, c->stream));
     RTS_HIP(hipMemsetAsync(c->d_phase.p, 0, sizeof(double)*R, c->stream));
-    const int32_t max_path = (int32_t)c->meshes.size() - 1, max_rx = c->n_rx ? (int32_t)c->n_rx - 1 : 0;
+    const int32_t max_path = (int32_t)c->scene->meshes.size() - 1, max_rx = c->n_rx ? (int32_t)c->n_rx - 1 : 0;
     const bool use_rows = recv_index_base == RTS_BASE_USE_ROWS;
     int rc = rts_aggregate_device(c, max_path, max_rx, c->d_rx_paths.p, R, c->depth, cspeed, carrier, use_rows ? 0 : recv_index_base, c->d_rx_rays.p,
                                   c->d_delay.p, c->d_phase.p, c->d_pathmatch.p, &c->groups, nullptr, nullptr, nullptr, INT32_MAX, use_rows ? c->d_rx_slots.p : nullptr);
@@ -806,12 +869,12 @@ void kernel_wrapper(PerRayData* h_rx_results_arr, int* h_rx_intersects_arr, unsi
 extern "C" int rts_get_bvh(RtsHandle c, void* nodes128, uint32_t* leaf_prim, int32_t* roots, uint32_t node_capacity, uint32_t leaf_capacity, uint32_t* n_leaves)
 {
     CHECK_HANDLE(c);
-    if (n_leaves) *n_leaves = c->n_leaves;
-    if ((nodes128 && node_capacity < c->n_nodes) || (leaf_prim && leaf_capacity < c->n_leaves)) { rts_set_error("rts_get_bvh: capacity too small (%u nodes, %u leaves)", c->n_nodes, c->n_leaves); return RTS_ERR_CAPACITY; }
+    if (n_leaves) *n_leaves = c->scene->n_leaves;
+    if ((nodes128 && node_capacity < c->scene->n_nodes) || (leaf_prim && leaf_capacity < c->scene->n_leaves)) { rts_set_error("rts_get_bvh: capacity too small (%u nodes, %u leaves)", c->scene->n_nodes, c->scene->n_leaves); return RTS_ERR_CAPACITY; }
     RTS_HIP(hipStreamSynchronize(c->stream));
-    if (nodes128 && c->n_nodes) RTS_HIP(hipMemcpy(nodes128, c->d_nodes4.p, sizeof(RtsNode4)*c->n_nodes, hipMemcpyDeviceToHost));
-    if (leaf_prim && c->n_leaves) RTS_HIP(hipMemcpy(leaf_prim, c->d_leaf_prim.p, sizeof(uint32_t)*c->n_leaves, hipMemcpyDeviceToHost));
-    if (roots) for (size_t t = 0; t < c->blas.size(); t++) roots[t] = c->blas[t].root;
+    if (nodes128 && c->scene->n_nodes) RTS_HIP(hipMemcpy(nodes128, c->scene->d_nodes4.p, sizeof(RtsNode4)*c->scene->n_nodes, hipMemcpyDeviceToHost));
+    if (leaf_prim && c->scene->n_leaves) RTS_HIP(hipMemcpy(leaf_prim, c->scene->d_leaf_prim.p, sizeof(uint32_t)*c->scene->n_leaves, hipMemcpyDeviceToHost));
+    if (roots) for (size_t t = 0; t < c->scene->blas.size(); t++) roots[t] = c->scene->blas[t].root;
     return RTS_OK;
 }
 

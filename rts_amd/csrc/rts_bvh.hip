@@ -54,9 +54,9 @@ static inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n 
 int rts_scene_place(RtsContext* c)
 {
     hipStream_t st = c->stream;
-    if (c->n_verts) k_place<<<blocks_for(c->n_verts, 256), 256, 0, st>>>(c->d_verts_local.p, c->d_verts_world.p, c->d_vert_targ.p, c->d_motion.p, c->n_verts, 1);
-    if (c->n_normals) k_place<<<blocks_for(c->n_normals, 256), 256, 0, st>>>(c->d_normals_local.p, c->d_normals_world.p, c->d_norm_targ.p, c->d_motion.p, c->n_normals, 0);
-    if (c->n_leaves) k_leaves<<<blocks_for(c->n_leaves, 256), 256, 0, st>>>(c->d_leaf_prim.p, c->d_tri_vidx.p, c->d_verts_world.p, c->d_prim_targ.p, c->d_leaves.p, c->n_leaves);
+    if (c->scene->n_verts) k_place<<<blocks_for(c->scene->n_verts, 256), 256, 0, st>>>(c->scene->d_verts_local.p, c->d_verts_world.p, c->scene->d_vert_targ.p, c->d_motion.p, c->scene->n_verts, 1);
+    if (c->scene->n_normals) k_place<<<blocks_for(c->scene->n_normals, 256), 256, 0, st>>>(c->scene->d_normals_local.p, c->d_normals_world.p, c->scene->d_norm_targ.p, c->d_motion.p, c->scene->n_normals, 0);
+    if (c->scene->n_leaves) k_leaves<<<blocks_for(c->scene->n_leaves, 256), 256, 0, st>>>(c->scene->d_leaf_prim.p, c->scene->d_tri_vidx.p, c->d_verts_world.p, c->scene->d_prim_targ.p, c->d_leaves.p, c->scene->n_leaves);
     RTS_HIP(hipGetLastError());
     return RTS_OK;
 }

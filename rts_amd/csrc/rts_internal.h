@@ -168,6 +168,26 @@ template <typename T> struct DevBuf {
 // aggregation after) runs on the handle's own (high-priority) stream and overlaps with the other handles' trace kernels.
 struct RtsGate { hipStream_t tstream = nullptr; int refs = 0; int device = 0; };
 
+// The immutable part of a scene -- meshes in their own frames, the static target-space hierarchy and its leaf order -- lives
+// ONCE per device and is shared (reference counted) by every handle that was given it with rts_share_scene: handles that keep
+// several pulses in flight place, trace and post-process into their own per-pulse buffers but read the same nodes.
+struct RtsScene {
+    int refs = 1; int device = 0;
+    std::vector<RtsMeshHost> meshes;
+    uint32_t n_prims = 0, n_verts = 0, n_normals = 0;
+    DevBuf<uint32_t> d_tri_vidx, d_tri_nidx, d_vert_targ, d_norm_targ, d_prim_targ;
+    DevBuf<double> d_verts_local, d_normals_local;
+    std::vector<RtsBlasInfo> blas; uint32_t n_nodes = 0, n_leaves = 0;
+    DevBuf<RtsNode4> d_nodes4; DevBuf<uint32_t> d_leaf_prim;
+    double build_ms = 0; uint32_t builder = 0;     // how long the hierarchy build took, and where it ran (0 host SAH, 1 device LBVH)
+    size_t device_bytes() const {
+        return d_tri_vidx.cap * 4 + d_tri_nidx.cap * 4 + d_vert_targ.cap * 4 + d_norm_targ.cap * 4 + d_prim_targ.cap * 4 + d_verts_local.cap * 8 +
+               d_normals_local.cap * 8 + d_nodes4.cap * sizeof(RtsNode4) + d_leaf_prim.cap * 4;
+    }
+    void release() { d_tri_vidx.release(); d_tri_nidx.release(); d_vert_targ.release(); d_norm_targ.release(); d_prim_targ.release();
+                     d_verts_local.release(); d_normals_local.release(); d_nodes4.release(); d_leaf_prim.release(); }
+};
+
 struct RtsContext {
     RtsParams params;
     uint32_t depth;                 // D = max_refr + max_refl
@@ -175,17 +195,15 @@ struct RtsContext {
     hipStream_t stream = nullptr;       // scene placement, ordering, finalise, aggregation (high priority: short kernels)
     hipStream_t tstream = nullptr;      // trace kernels (the link group's, see RtsGate)
     hipEvent_t ev[9];
-    // scene (static part)
-    std::vector<RtsMeshHost> meshes;
-    uint32_t n_prims = 0, n_verts = 0, n_normals = 0;
-    DevBuf<uint32_t> d_tri_vidx, d_tri_nidx, d_vert_targ, d_norm_targ, d_prim_targ;
-    DevBuf<double> d_verts_local, d_normals_local, d_verts_world, d_normals_world;
+    // scene: the shared static part, and this handle's placement of it
+    RtsScene* scene = nullptr;          // never null after rts_create
+    DevBuf<double> d_verts_world, d_normals_world;
     std::vector<RtsTargetMotion> motion; bool motion_valid = false; bool bvh_valid = false;   // bvh_valid: scene placed for `motion`
     DevBuf<RtsTargetMotion> d_motion;
     DevBuf<RtsTargetDev> d_targets;
     // hierarchy: static nodes + leaf order (set_scene), leaf records refreshed per pulse
-    std::vector<RtsBlasInfo> blas; uint32_t n_nodes = 0, n_leaves = 0; uint32_t stack_lds = RTS_STACK_LDS;
-    DevBuf<RtsNode4> d_nodes4; DevBuf<uint32_t> d_leaf_prim; DevBuf<RtsLeafTri> d_leaves; DevBuf<char> d_sort_tmp;
+    uint32_t stack_lds = RTS_STACK_LDS;
+    DevBuf<RtsLeafTri> d_leaves; DevBuf<char> d_sort_tmp;
     // receivers
     DevBuf<RtsRxDev> d_rx; uint32_t n_rx = 0;
     // per pulse
@@ -215,6 +233,7 @@ struct RtsContext {
 
 // implemented in the .hip units
 int rts_sah_build(const double* verts, const uint32_t* tris, uint32_t n_tris, double split_budget, std::vector<RtsNode4>& nodes, std::vector<uint32_t>& leaf_prim, RtsBlasInfo& out);
+int rts_lbvh_build_device(RtsContext* c, RtsScene* ns, const std::vector<uint32_t>& vidx, const std::vector<RtsMeshHost>& mh);
 int rts_scene_place(RtsContext* c);
 int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_valid, const uint64_t* cur_sig, uint32_t n_tiles_cur);
 int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a, bool count_traversal);

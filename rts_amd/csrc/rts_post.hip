@@ -229,7 +229,7 @@ int rts_post_finalise(RtsContext* c, const double* rcs_host, double wl, double g
 {
     const uint32_t R = (uint32_t)c->n_recv;
     if (R == 0) return RTS_OK;
-    const uint32_t nt = (uint32_t)c->meshes.size();
+    const uint32_t nt = (uint32_t)c->scene->meshes.size();
     RTS_HIP(c->d_rcsval.reserve(nt + 1));
     for (uint32_t t = 0; t < nt && t < 256; t++) c->pin->rcs[t] = rcs_host[t];
     if (nt) RTS_HIP(hipMemcpyAsync(c->d_rcsval.p, c->pin->rcs, sizeof(double)*nt, hipMemcpyHostToDevice, c->stream));

@@ -93,6 +93,13 @@ def plan_cpi(total_rays, n_pulses, rank, world):
     return out
 
 
+def plan_rays(total_rays, n_pulses, rank, world):
+    """ray sharding: EVERY pulse of the interval is split over all ranks in interleaved tiles ("ray-sharding is
+    the one to report"); the work per rank does not depend on how n_pulses divides by the number of ranks"""
+    il = (IL_TILE, world, rank) if world > 1 else None
+    return [(k, 0, total_rays, il) for k in range(n_pulses)]
+
+
 def refine_plan(plan, min_items):
     """split items until the rank owns at least `min_items` of them, so that it can keep that many pulses (or pulse
     parts) in flight (rts_link_handles): the ordering/aggregation of one part then overlaps the trace of the next.

@@ -279,3 +279,26 @@ def ecef_offset(height=10.0e3, lat=0.0, lon=0.0):
     bench configuration is the north pole (0, 0, R + h), with the C3 beam (along +x) then grazing horizontally"""
     r = EARTH_RADIUS + height
     return np.array([r * math.cos(lat) * math.cos(lon), r * math.cos(lat) * math.sin(lon), r * math.sin(lat)], np.float64)
+
+
+def config2_file(W=100, rx_radius=50.0, n_tris=10000):
+    """C2 as BASELINE.json words it ("sphere mesh 10k tris"): an icosphere has 20 * 4^n triangles (5 120 or 20 480), so the
+    10 000-triangle sphere is a lat-long tessellation written in the reference's mesh file format ("x y z, x y z, x y z," per
+    triangle, one file of vertices and one of per-vertex normals, ray_tracer.cpp:429-504) and loaded through rts_file_mesh:
+    unshared vertices, 3 * n_tris of them."""
+    import os
+    import tempfile
+    nv = 51; nu = n_tris // (2 * (nv - 1))
+    v, t, n = _ellipsoid(nu, nv, (5.0, 5.0, 5.0))
+    assert t.shape[0] == n_tris, (t.shape, n_tris)
+    d = tempfile.mkdtemp(prefix="rts_c2file_")
+    vf, nf = os.path.join(d, "sphere_v.txt"), os.path.join(d, "sphere_n.txt")
+    for path, arr in ((vf, v[t].reshape(-1, 9)), (nf, n[t].reshape(-1, 9))):
+        with open(path, "w") as fh:
+            for row in arr:
+                fh.write("%.17g %.17g %.17g, %.17g %.17g %.17g, %.17g %.17g %.17g,\n" % tuple(row))
+    fv, ft, fn = api.file_mesh(vf, nf, 0.0, 0.0, 0.0)
+    s = config2(subdiv=1, W=W, rx_radius=rx_radius)
+    s["name"] = "C2-filemesh-%dtri" % ft.shape[0]
+    s["meshes"] = [dict(tris=ft, verts=fv, normals=fn, refl_coeff=0.9, refr_index=1.0)]
+    return s

@@ -233,7 +233,13 @@ def test_bvh_invariants(rts, scenes):
     nprim = sum(m["tris"].shape[0] for m in spec["meshes"])
     refs = np.bincount(leaf_prim, minlength=nprim)
     assert len(leaf_prim) >= nprim and refs.min() >= 1 and len(roots) == len(spec["meshes"])
-    assert refs.max() > 1, "the sliver fans of the ellipsoid mesh are expected to be split"
+    info = tr.scene_info()
+    host_sah = info["builder"] == 0            # RTS_BUILDER=device: LBVH, no split references, records of opened BVH2 nodes are unreachable
+    assert info["n_nodes"] == len(nodes) and info["n_leaves"] == len(leaf_prim) and info["n_targets"] == len(roots)
+    if host_sah:
+        assert refs.max() > 1, "the sliver fans of the ellipsoid mesh are expected to be split"
+    else:
+        assert refs.max() == 1
     child = nodes[:, 24:28].copy().view(np.int32)
     lo = np.stack([nodes[:, 0:4], nodes[:, 4:8], nodes[:, 8:12]], axis=2)        # [node][child][xyz]
     hi = np.stack([nodes[:, 12:16], nodes[:, 16:20], nodes[:, 20:24]], axis=2)
@@ -267,8 +273,65 @@ def test_bvh_invariants(rts, scenes):
                 else:
                     stack.append((int(c), lo[i, k], hi[i, k]))
             assert used >= 1
-    assert seen_nodes.all() and seen_leaves.all() and covered.all()
+    assert seen_leaves.all() and covered.all()
+    assert seen_nodes.all() or not host_sah
     tr.close()
+
+
+def test_device_builder_gives_the_same_rays(rts, oracle, scenes):
+    """RTS_FLAG_DEVICE_BUILD: the hierarchy is built on the GPU (LBVH, rts_lbvh.hip) instead of the host SAH builder.  A
+    different tree, the same results bit for bit: the exact f64 test alone decides hits.  Also: a mesh with non-finite
+    vertices (those triangles get no leaf), a single-triangle mesh, an empty mesh; and the build is the fast one."""
+    spec = scenes.config_multi(W=18)
+    one = dict(tris=np.array([[0, 1, 2]], np.uint32), verts=np.array([[3.0, -2, -2], [3.0, 2, -2], [3.2, 0, 2.5]]), normals=np.array([[-1.0, 0, 0]] * 3), refl_coeff=0.6, refr_index=1.0)
+    bad = dict(spec["meshes"][1]); bv = bad["verts"].copy(); bv[0, 1] = np.nan; bad["verts"] = bv
+    empty = dict(tris=np.zeros((0, 3), np.uint32), verts=np.zeros((0, 3)), normals=np.zeros((1, 3)), refl_coeff=0.9, refr_index=1.0)
+    spec["meshes"] = spec["meshes"] + [one, bad, empty]
+    spec["motion"] = spec["motion"] + [dict(position=(-6.0, 1.0, 0.5), velocity=(0.0, 0.0, 0.0)), dict(position=(4.0, -12.0, 3.0), velocity=(1.0, 0.0, 0.0)), dict(position=(0.0, 0.0, 0.0), velocity=(0.0, 0.0, 0.0))]
+    n = spec["W"] ** 3
+    res = {}
+    for dev in (False, True):
+        tr = rts.Tracer(spec["W"], spec["max_refl"], 0, spec["smooth"], keep_all=True, device_build=dev)
+        tr.set_scene(spec["meshes"]); tr.set_receivers(spec["rx"])
+        _, st = H.gpu_trace(rts, spec, tr=tr)
+        info = tr.scene_info()
+        if "RTS_BUILDER" not in os.environ:
+            assert info["builder"] == (1 if dev else 0)
+        res[dev] = (tr.all_rays(n), st, info)
+        tr.close()
+    a, b = res[False][0], res[True][0]
+    assert np.array_equal(a["hit_prim"], b["hit_prim"]) and np.array_equal(a["hit_t"].view(np.uint32), b["hit_t"].view(np.uint32))
+    H.assert_prd_equal(a["results"], b["results"], "device-built hierarchy")
+    assert np.array_equal(a["path"], b["path"])
+    assert res[False][1]["segments"] == res[True][1]["segments"] and res[True][1]["shaded"] > 100
+    o = H.oracle_trace(oracle, spec)
+    H.compare_full(o, b, n)
+
+
+def test_shared_scene_between_handles(rts, scenes):
+    """rts_share_scene: handles that keep pulses in flight read ONE copy of the meshes and the hierarchy; results are those
+    of handles with scenes of their own, and the shared part outlives the handle that built it"""
+    spec = scenes.config3(W=40, detail=0.1, rx_radius=300.0)
+    own = H.gpu_tracer(rts, spec)
+    _, st0 = H.gpu_trace(rts, spec, tr=own); ref = own.received()
+    a = H.gpu_tracer(rts, spec)
+    b = rts.Tracer(spec["W"], spec["max_refl"], 0, spec["smooth"]); b.share_scene(a); b.set_receivers(spec["rx"])
+    c = rts.Tracer(spec["W"], spec["max_refl"], 0, spec["smooth"]); c.share_scene(b); c.set_receivers(spec["rx"])
+    ia, ib = a.scene_info(), b.scene_info()
+    assert ia["handles_sharing"] == ib["handles_sharing"] == 3 and own.scene_info()["handles_sharing"] == 1
+    assert ia["shared_device_bytes"] == ib["shared_device_bytes"] > 0 and ib["handle_device_bytes"] > 0
+    assert ib["build_ms"] == ia["build_ms"]                                    # built once
+    a.close()                                                                    # the builder goes away first
+    for t in (b, c):
+        _, st = H.gpu_trace(rts, spec, tr=t); got = t.received()
+        assert st["segments"] == st0["segments"]
+        H.assert_prd_equal(ref["results"], got["results"], "shared scene")
+        assert np.array_equal(ref["slots"], got["slots"])
+    assert b.scene_info()["handles_sharing"] == 2
+    # a handle that sets a scene of its own leaves the group
+    c.set_scene(spec["meshes"]); assert c.scene_info()["handles_sharing"] == 1 and b.scene_info()["handles_sharing"] == 1
+    _, st = H.gpu_trace(rts, spec, tr=c); H.assert_prd_equal(ref["results"], c.received()["results"], "own scene again")
+    own.close(); b.close(); c.close()
 
 
 @pytest.mark.parametrize("seed,R,D,n_rx,n_targ", [(1, 50, 3, 2, 2), (2, 3000, 4, 4, 3), (3, 700, 1, 1, 1), (4, 5000, 6, 3, 1), (5, 1, 2, 1, 1)])
@@ -806,5 +869,6 @@ def test_random_triangle_soups_brute_force(rts, oracle, scenes, seed, refr, far)
     tr, st, o, g = full_parity(rts, oracle, spec)
     assert st["shaded"] > 200
     nodes, leaf_prim, roots = tr.bvh()
-    assert np.bincount(leaf_prim).max() > 1                            # the slivers and wedges were split
+    if tr.scene_info()["builder"] == 0:
+        assert np.bincount(leaf_prim).max() > 1                        # host SAH builder: the slivers and wedges were split
     tr.close()

@@ -62,6 +62,10 @@ def main():
     un = os.path.join(src, "unprofiled.log")
     if os.path.exists(un):
         out["unprofiled_line"] = open(un).read().strip().splitlines()[-1]
+        import re
+        m = re.search(r"segs (\d+)", out["unprofiled_line"])
+        if m:
+            out["segments_per_launch"] = int(m.group(1))
     P = out["passes"]; L = out["per_launch"]
     d = {}
 
