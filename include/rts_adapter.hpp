@@ -16,7 +16,9 @@
 //   * errors throw std::runtime_error(rts_last_error()) instead of exit(1);
 //   * meshes are built once per target and placed on the device per pulse (the reference
 //     rebuilds and re-uploads them every pulse, ray_tracer.cpp:963-1117);
-//   * the four wall-clock printf timers are replaced by RtsStats (rts_get_stats).
+//   * the four wall-clock printf timers are replaced by RtsStats (rts_get_stats);
+//   * pulses (or, RunOptions::shard_rays, the rays of every pulse) are spread over all visible GPUs; responses and their
+//     order are those of the sequential single-GPU loop.
 #ifndef RTS_ADAPTER_HPP
 #define RTS_ADAPTER_HPP
 
@@ -71,31 +73,48 @@ HostMesh build_target_mesh(Target* targ) {
     return m;
 }
 
+// How the pulses of a run are spread over the GPUs of the machine (the reference is single-GPU).
+struct RunOptions {
+    std::vector<int> devices;      // HIP device ordinals, one SET of handles each; empty = every visible device.  An ordinal may
+                                   // repeat: two handle sets on one GPU (that is how the multi-device path is tested on one GPU)
+    unsigned in_flight = 2;        // pulses in flight per handle set (1: no software pipelining)
+    bool shard_rays = false;       // false: whole pulses are dealt to the handle sets in turn (pulses are independent,
+                                   //        ray_tracer.cpp:843); true: EVERY pulse is split over all handle sets in interleaved
+                                   //        tiles (rays are independent, ray_tracer.cu:227-253) and its received rays merged
+                                   //        on the host in launch-index order -- the way to use N GPUs for ONE pulse
+    RtsStats* last_stats = nullptr;
+};
+
 // Traits: the simulator types the driver touches.
 //   World, Transmitter, Receiver, Target, TransmitterPulse, RadarSignal, Response, InterpPoint,
 //   Vec3 (x,y,z), SVec3 (constructible from Vec3; .length, .azimuth, .elevation), Params (static
 //   GetRTSVariables/c/start_time/cw_sample_rate/interpolate_smooth).
 template <class Tr>
-void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlocks, int device = 0, RtsStats* last_stats = nullptr, unsigned in_flight = 2)
+void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlocks, const RunOptions& opt)
 {
     using Vec3 = typename Tr::Vec3; using SVec3 = typename Tr::SVec3;
     const auto rts_vars = Tr::Params::GetRTSVariables();                       // ray_tracer.cpp:600-605
     RtsParams params{};
     params.width = rts_vars.x; params.max_refl = rts_vars.y; params.max_refr = rts_vars.z > 0 ? 2u : 0u;
-    params.interpolate_smooth = Tr::Params::interpolate_smooth() ? 1u : 0u; params.device = device; params.flags = 0;
+    params.interpolate_smooth = Tr::Params::interpolate_smooth() ? 1u : 0u; params.flags = 0;
     const unsigned D = params.max_refr + params.max_refl;
-    const uint64_t rayTotal = (uint64_t)params.width * params.width * params.width * (params.max_refr ? params.max_refl + 3 : 1);
+    const uint64_t launchTotal = (uint64_t)params.width * params.width * params.width;
+    const uint64_t rayTotal = launchTotal * (params.max_refr ? params.max_refl + 3 : 1);
     const double cspeed = Tr::Params::c(), sim_starttime = Tr::Params::start_time(), sample_time = 1.0 / Tr::Params::cw_sample_rate();
 
     auto& transmitters = world->transmitters; auto& receivers = world->receivers; auto& targets = world->targets;
     const uint32_t rxsize = (uint32_t)receivers.size(), targsize = (uint32_t)targets.size();
 
-    // Two handles hold the same scene and take the pulses in turn: while the host finishes pulse k (read-back, RCS/gain
-    // loop, aggregation, responses) the device already traces pulse k+1.  Results and the order of every side effect
-    // (AddResponse) are those of the sequential loop; in_flight = 1 restores it literally.
-    const unsigned n_handles = in_flight > 1 ? 2u : 1u;
-    struct Handles { RtsHandle h[2] = {nullptr, nullptr}; ~Handles() { rts_destroy(h[0]); rts_destroy(h[1]); } } hs;
-    for (unsigned i = 0; i < n_handles; i++) check(rts_create(&params, &hs.h[i]), "rts_create");
+    // ---- handle sets: S sets (one per entry of opt.devices) x F slots (pulses in flight per set).  Slot 0 of a set owns the
+    // set's scene, the other slots share it (rts_share_scene: one hierarchy per set, built once).
+    std::vector<int> devices = opt.devices;
+    if (devices.empty()) { int n = 0; check(rts_device_count(&n), "rts_device_count"); for (int i = 0; i < n; i++) devices.push_back(i); }
+    if (devices.empty()) throw std::runtime_error("rts_adapter: no HIP device");
+    const unsigned S = (unsigned)devices.size(), F = opt.in_flight > 1 ? opt.in_flight : 1u;
+    struct Handles { std::vector<RtsHandle> h; ~Handles() { for (RtsHandle x : h) rts_destroy(x); } } hs;
+    hs.h.assign((size_t)S * F, nullptr);
+    auto H = [&](unsigned set, unsigned slot) -> RtsHandle& { return hs.h[(size_t)slot * S + set]; };
+    for (unsigned f = 0; f < F; f++) for (unsigned s = 0; s < S; s++) { params.device = devices[s]; check(rts_create(&params, &H(s, f)), "rts_create"); }
 
     // scene: once (the reference regenerates identical meshes every pulse)
     std::vector<HostMesh> host(targsize); std::vector<RtsMesh> meshes(targsize);
@@ -106,7 +125,10 @@ void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlo
         meshes[t].n_normals = (uint32_t)(host[t].normals.size() / 3); meshes[t].reserved = 0;
         meshes[t].refl_coeff = targets[t]->GetReflCoeff(); meshes[t].refr_index = targets[t]->GetRefrIndex();
     }
-    for (unsigned i = 0; i < n_handles; i++) check(rts_set_scene(hs.h[i], meshes.data(), targsize), "rts_set_scene");
+    for (unsigned s = 0; s < S; s++) {
+        check(rts_set_scene(H(s, 0), meshes.data(), targsize), "rts_set_scene");
+        for (unsigned f = 1; f < F; f++) check(rts_share_scene(H(s, f), H(s, 0)), "rts_share_scene");
+    }
 
     for (size_t tx_i = 0; tx_i < transmitters.size(); tx_i++) {                // ray_tracer.cpp:806
         auto* trans = transmitters[tx_i];
@@ -120,8 +142,9 @@ void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlo
             receivers[j]->SetNoiseTemperature(wave->GetTemp() + receivers[j]->GetNoiseTemperature());
         const Vec3 trpos = trans->GetPosition(0);                              // Tx position frozen at t = 0 (:881)
 
-        // ---- everything of pulse k up to the launch (:843-1165), left in flight on handle h; returns the pulse time
-        auto begin_pulse = [&](unsigned k, RtsHandle h) -> double {
+        // ---- everything of pulse k up to the launch (:843-1165), left in flight on handle h; item: the part of the pulse's
+        // launch indices this handle traces.  Returns the pulse time.
+        auto begin_pulse = [&](unsigned k, RtsHandle h, const RtsPlanItem& item) -> double {
             trans->GetPulse(signal, k);
             const double time_t = signal->time;
             const auto txrot = trans->GetRotation(time_t);
@@ -129,6 +152,8 @@ void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlo
             pulse.ray_origin[0] = trpos.x; pulse.ray_origin[1] = trpos.y; pulse.ray_origin[2] = trpos.z;
             pulse.tx_span[0] = txSpan.x; pulse.tx_span[1] = txSpan.y; pulse.tx_span[2] = txSpan.z;
             pulse.tx_dir[0] = txrot.azimuth; pulse.tx_dir[1] = txrot.elevation;
+            pulse.ray_first = item.ray_first; pulse.ray_count = item.ray_count;
+            pulse.interleave_tile = item.interleave_tile; pulse.interleave_parts = item.interleave_parts; pulse.interleave_part = item.interleave_part;
 
             std::vector<RtsReceiverSphere> spheres(rxsize);                    // :894-918
             for (uint32_t j = 0; j < rxsize; j++) {
@@ -157,15 +182,37 @@ void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlo
             return time_t;
         };
 
-        // ---- read-back, finalisation, aggregation and responses of the pulse in flight on handle h (:1180-1321)
-        auto finish_pulse = [&](RtsHandle h, double time_t) {
-            check(rts_trace_pulse_end(h), "rts_trace_pulse_end");
-            if (last_stats) rts_get_stats(h, last_stats);
-
-            uint64_t R = 0; check(rts_received_count(h, &R), "rts_received_count");
+        // ---- read-back, finalisation, aggregation and responses of one pulse whose launch indices were traced by the handles
+        // `parts` (one handle: a whole pulse; several: interleaved parts, merged here in launch-index order) (:1180-1321)
+        auto finish_pulse = [&](const std::vector<RtsHandle>& parts, double time_t) {
+            uint64_t R = 0; std::vector<uint64_t> Rp(parts.size(), 0);
+            for (size_t q = 0; q < parts.size(); q++) {
+                check(rts_trace_pulse_end(parts[q]), "rts_trace_pulse_end");
+                check(rts_received_count(parts[q], &Rp[q]), "rts_received_count"); R += Rp[q];
+            }
+            if (opt.last_stats) rts_get_stats(parts[0], opt.last_stats);
             if (R == 0) return;
+            if (R > 0x7ffffffeULL) throw std::runtime_error("rts_adapter: more than 2^31 received rays in one pulse");
             std::vector<PerRayData> rx_results(R); std::vector<int> rx_intersects((size_t)R * D); std::vector<double> rcs_angle((size_t)R * D * 2);
-            check(rts_get_received(h, rx_results.data(), rx_intersects.data(), rcs_angle.data(), nullptr, R), "rts_get_received");
+            if (parts.size() == 1) {
+                check(rts_get_received(parts[0], rx_results.data(), rx_intersects.data(), rcs_angle.data(), nullptr, R), "rts_get_received");
+            } else {        // every part's list ascends in launch index (slot): merge the lists into one ascending list
+                std::vector<PerRayData> rr(R); std::vector<int> ri((size_t)R * D); std::vector<double> ra((size_t)R * D * 2); std::vector<uint64_t> slots(R);
+                uint64_t off = 0;
+                for (size_t q = 0; q < parts.size(); q++) {
+                    if (Rp[q]) check(rts_get_received(parts[q], rr.data() + off, ri.data() + off * D, ra.data() + off * D * 2, slots.data() + off, Rp[q]), "rts_get_received");
+                    off += Rp[q];
+                }
+                std::vector<uint64_t> order(R); for (uint64_t i = 0; i < R; i++) order[i] = i;
+                // rows of one launch index (refraction: chains k W^3 apart) come from the same part; (slot mod W^3, slot) keeps
+                // the reference's order, which is the buffer-row order = ascending slot
+                std::stable_sort(order.begin(), order.end(), [&](uint64_t x, uint64_t y) { return slots[x] < slots[y]; });
+                for (uint64_t i = 0; i < R; i++) {
+                    const uint64_t j = order[i];
+                    rx_results[i] = rr[j];
+                    for (unsigned d = 0; d < D; d++) { rx_intersects[(size_t)i * D + d] = ri[(size_t)j * D + d]; rcs_angle[((size_t)i * D + d) * 2] = ra[((size_t)j * D + d) * 2]; rcs_angle[((size_t)i * D + d) * 2 + 1] = ra[((size_t)j * D + d) * 2 + 1]; }
+                }
+            }
 
             const Vec3 origin = trpos;
             for (uint64_t i = 0; i < R; i++) {                                 // :1198-1256 for the received rays
@@ -195,12 +242,15 @@ void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlo
 
             std::vector<double> npath(R, 0), power(R, 0), doppler(R, 0), delay(R, 0), phase(R, 0);      // :1266-1271
             std::vector<int> pathMatch(R, (int)std::min<uint64_t>(rayTotal + 1, 0x7fffffffULL));
-            rs::kernel_wrapper(rx_results.data(), rx_intersects.data(), (unsigned)R, D, MaxThreads, MaxBlocks, cspeed, carrier,
-                               npath.data(), power.data(), doppler.data(), delay.data(), phase.data(), pathMatch.data());
+            // rs::kernel_wrapper's arithmetic (aggregation.cu:103-184) on the device and stream of the handle that traced the
+            // pulse; a failure is an exception here (the reference exit(1)s, aggregation.cu:17-27), never a silent skip
+            check(rts_kernel_wrapper_on(parts[0], rx_results.data(), rx_intersects.data(), (unsigned)R, D, MaxThreads, MaxBlocks, cspeed, carrier,
+                                        npath.data(), power.data(), doppler.data(), delay.data(), phase.data(), pathMatch.data()), "rs::kernel_wrapper");
 
             std::vector<int> uniq(pathMatch);                                  // :1290-1292
             std::sort(uniq.begin(), uniq.end()); uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
             for (int i : uniq) {                                               // :1301-1321
+                if (i < 0 || (uint64_t)i >= R) throw std::runtime_error("rts_adapter: aggregation returned a representative ray outside the received list");
                 const int rx = rx_results[i].received;
                 typename Tr::InterpPoint point(rx_results[i].power, time_t + delay[i], delay[i], rx_results[i].doppler, phase[i],
                                                receivers[rx]->GetNoiseTemperature());
@@ -210,14 +260,38 @@ void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlo
             }
         };
 
-        double t_of[2] = {0, 0};
-        for (unsigned k = 0; k < pulseCount; k++) {                            // :843, software-pipelined by one pulse
-            t_of[k % n_handles] = begin_pulse(k, hs.h[k % n_handles]);
-            if (n_handles == 1) finish_pulse(hs.h[0], t_of[0]);
-            else if (k > 0) finish_pulse(hs.h[(k - 1) % 2], t_of[(k - 1) % 2]);
+        // ---- the pulse loop (:843), software-pipelined.  Pulses are FINISHED strictly in pulse order, so every side effect
+        // (AddResponse) happens in the order of the sequential loop whatever the number of handle sets and slots.
+        struct InFlight { std::vector<RtsHandle> parts; double time_t; };
+        std::vector<InFlight> fly; size_t done = 0;                            // fly[k] for pulse k; finished up to `done`
+        const unsigned lanes = opt.shard_rays ? F : S * F;                     // pulses in flight
+        for (unsigned k = 0; k < pulseCount; k++) {
+            InFlight fl;
+            if (opt.shard_rays && S > 1) {                                     // every handle set takes its interleaved part of pulse k
+                const unsigned f = k % F;
+                for (unsigned s = 0; s < S; s++) {
+                    RtsPlanItem item{}; uint32_t n_items = 0;
+                    check(rts_plan_cpi(launchTotal, 1, s, S, RTS_SHARD_RAYS, 0, &item, 1, &n_items), "rts_plan_cpi");
+                    fl.time_t = begin_pulse(k, H(s, f), item); fl.parts.push_back(H(s, f));
+                }
+            } else {                                                           // whole pulse on the next (set, slot) in turn
+                const unsigned w = k % (S * F);
+                RtsPlanItem item{}; item.ray_first = 0; item.ray_count = launchTotal;
+                fl.time_t = begin_pulse(k, H(w % S, w / S), item); fl.parts.push_back(H(w % S, w / S));
+            }
+            fly.push_back(fl);
+            if (fly.size() - done >= lanes) { finish_pulse(fly[done].parts, fly[done].time_t); done++; }
         }
-        if (n_handles == 2 && pulseCount > 0) finish_pulse(hs.h[(pulseCount - 1) % 2], t_of[(pulseCount - 1) % 2]);
+        while (done < fly.size()) { finish_pulse(fly[done].parts, fly[done].time_t); done++; }
     }
+}
+
+// single handle set on one device (the signature of round 1)
+template <class Tr>
+void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlocks, int device = 0, RtsStats* last_stats = nullptr, unsigned in_flight = 2)
+{
+    RunOptions opt; opt.devices = {device}; opt.in_flight = in_flight; opt.last_stats = last_stats;
+    run<Tr>(world, MaxThreads, MaxBlocks, opt);
 }
 
 }  // namespace rts_amd
@@ -230,7 +304,8 @@ struct SoarsTraits {
     using InterpPoint = rs::InterpPoint; using Vec3 = rs::Vec3; using SVec3 = rs::SVec3; using Params = rs::rsParameters;
 };
 }
-namespace rs { inline void RTS(World* world, unsigned int MaxThreads, unsigned int MaxBlocks) { rts_amd::run<rts_amd::SoarsTraits>(world, MaxThreads, MaxBlocks); } }
+// every visible GPU, whole pulses dealt to them in turn (RunOptions{}); SOARS' call site is unchanged
+namespace rs { inline void RTS(World* world, unsigned int MaxThreads, unsigned int MaxBlocks) { rts_amd::run<rts_amd::SoarsTraits>(world, MaxThreads, MaxBlocks, rts_amd::RunOptions{}); } }
 #endif
 
 #endif  // RTS_ADAPTER_HPP

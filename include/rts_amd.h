@@ -228,7 +228,11 @@ int rts_finalise_uniform(RtsHandle h, const double* rcs_per_target, double wavel
  * recv_index_base offsets the received-list indices (multi-GPU with contiguous ranges: number of received
  * rays on lower ranks).  RTS_BASE_USE_ROWS makes RtsGroup.min_ray the GLOBAL BUFFER ROW (launch index + k W^3)
  * of the group's first ray instead: rows order rays exactly as received-list indices do, and they are comparable
- * across ranks whatever the sharding (interleaved tiles). */
+ * across ranks whatever the sharding (interleaved tiles).
+ * Key-width limit: rays are grouped by a packed (receiver, path) key of
+ *     D x ceil(log2(targets + 1)) + ceil(log2(receivers)) <= 64 bits,   D = max_refl + max_refr
+ * (C3: 6 x 1 + 2; C4: 8 x 3 + 3; e.g. D = 8 allows 127 targets, D = 16 seven).  rts_set_scene / rts_set_receivers refuse a
+ * configuration beyond it with RTS_ERR_UNSUPPORTED, rts_kernel_wrapper refuses such data. */
 #define RTS_BASE_USE_ROWS 0xffffffffffffffffULL
 int rts_aggregate(RtsHandle h, double cspeed, double carrier, uint64_t recv_index_base);
 int rts_group_count(RtsHandle h, uint32_t* count);
@@ -259,6 +263,36 @@ int rts_cube_attach(RtsHandle h, const RtsCubeParams* params, void* device_ptr);
 int rts_cube_accumulate(RtsHandle h, uint32_t pulse_index, double cspeed, double carrier);
 int rts_cube_get(RtsHandle h, double* host_out, uint64_t capacity_doubles);
 
+/* ---------------------------------------------------------------- several GPUs (not in the reference: it is single-GPU)
+ * Rays are independent (each launch index writes only its own rows, ray_tracer.cu:227-253) and so are pulses
+ * (ray_tracer.cpp:843).  rts_plan_cpi deals the n_pulses x total_rays (pulse, launch index) pairs of one coherent
+ * processing interval to `world` workers -- one handle set per GPU, in one process (rts_adapter.hpp) or one process per
+ * GPU (bench.py) -- and returns worker `rank`'s share as RtsPulse-ready items:
+ *   RTS_SHARD_PULSES  n_pulses / world whole pulses per worker; each of the n_pulses % world left-over pulses is shared by a
+ *                     group of consecutive workers in interleaved tiles (RtsPulse.interleave_*)
+ *   RTS_SHARD_RAYS    every pulse is split over all workers in interleaved tiles (work per worker independent of how
+ *                     n_pulses divides by world)
+ * min_items > 1 splits items further (part p of P -> parts p and p + P of 2 P) until the worker owns that many, so that
+ * it can keep min_items pulses (or parts) in flight.  Parts of one pulse are merged again through their group tables
+ * (rts_aggregate with RTS_BASE_USE_ROWS, rts_merge_groups) or through their received sets ordered by RtsResponse.ray /
+ * slots.  Pure host code. */
+typedef struct RtsPlanItem {
+    uint32_t pulse;
+    uint32_t interleave_tile, interleave_parts, interleave_part;   /* parts <= 1: the whole range */
+    uint64_t ray_first, ray_count;
+} RtsPlanItem;
+#define RTS_SHARD_PULSES 0u
+#define RTS_SHARD_RAYS 1u
+#define RTS_PLAN_TILE 4096u      /* launch indices per interleaved tile */
+int rts_plan_cpi(uint64_t total_rays, uint32_t n_pulses, uint32_t rank, uint32_t world, uint32_t mode, uint32_t min_items,
+                 RtsPlanItem* out, uint32_t capacity, uint32_t* n_out);
+/* Sum of the complex return cubes of several handles (same RtsCubeParams; one handle per GPU, or several per GPU), left in
+ * EVERY handle's cube: the "RCCL reduce over the per-receiver return buffers" of a multi-GPU interval when all GPUs belong
+ * to one process.  transport 0: RCCL (ncclCommInitAll + ncclAllReduce, loaded on first use) when the handles sit on
+ * distinct devices and librccl can be loaded, otherwise peer copies; 1: RCCL or fail; 2: peer copies (hipMemcpyPeer +
+ * add, in handle order -- bit-reproducible). */
+int rts_cube_reduce(RtsHandle* handles, uint32_t n_handles, int transport);
+
 /* ---------------------------------------------------------------- the reference's inner C-like boundary
  * Same argument list and in/out behaviour as rs::kernel_wrapper (aggregation.cuh:19-22,
  * aggregation.cu:103-184); the C++ symbol rs::kernel_wrapper is exported by the library too
@@ -267,6 +301,13 @@ int rts_kernel_wrapper(struct PerRayData* h_rx_results_arr, int* h_rx_intersects
                        unsigned int depthTotal, unsigned int MaxThreads, unsigned int MaxBlocks, double cspeed,
                        double carrier, double* h_npath_arr, double* h_power_arr, double* h_doppler_arr,
                        double* h_delay_arr, double* h_phase_arr, int* h_pathMatch);
+/* The same on the device and stream of a handle (NULL: a process-wide context of the calling thread's current device, one
+ * per device, which is what rts_kernel_wrapper and rs::kernel_wrapper use).  The handle's own received set is overwritten.
+ * rs::kernel_wrapper (void in the reference, which exit(1)s on error) throws std::runtime_error on failure. */
+int rts_kernel_wrapper_on(RtsHandle h, struct PerRayData* h_rx_results_arr, int* h_rx_intersects_arr, unsigned int receivedRays,
+                          unsigned int depthTotal, unsigned int MaxThreads, unsigned int MaxBlocks, double cspeed,
+                          double carrier, double* h_npath_arr, double* h_power_arr, double* h_doppler_arr,
+                          double* h_delay_arr, double* h_phase_arr, int* h_pathMatch);
 
 /* ---------------------------------------------------------------- host scene helpers (ray_tracer.cpp:85-504, 894-918)
  * Two-call pattern for the variable-size builders: pass NULL outputs to obtain the sizes. */

@@ -63,6 +63,14 @@ class RtsCubeParams(C.Structure):
                 ("t0", C.c_double), ("dt", C.c_double)]
 
 
+class RtsPlanItem(C.Structure):
+    _fields_ = [("pulse", C.c_uint32), ("interleave_tile", C.c_uint32), ("interleave_parts", C.c_uint32), ("interleave_part", C.c_uint32),
+                ("ray_first", C.c_uint64), ("ray_count", C.c_uint64)]
+
+
+RTS_SHARD_PULSES, RTS_SHARD_RAYS = 0, 1
+
+
 class RtsSceneInfo(C.Structure):
     _fields_ = [("n_targets", C.c_uint32), ("n_prims", C.c_uint32), ("n_nodes", C.c_uint32), ("n_leaves", C.c_uint32),
                 ("handles_sharing", C.c_uint32), ("builder", C.c_uint32), ("build_ms", C.c_double),
@@ -116,7 +124,7 @@ EXPORTS = ["rts_create", "rts_destroy", "rts_last_error", "rts_device_count", "r
            "rts_finalise_uniform", "rts_aggregate", "rts_group_count", "rts_get_groups", "rts_get_aggregated",
            "rts_merge_groups", "rts_groups_to_responses", "rts_kernel_wrapper", "rts_vertex_rotation",
            "rts_rotation_matrix", "rts_rect_mesh", "rts_sphere_mesh", "rts_file_mesh", "rts_rx_sphere", "rts_get_bvh",
-           "rts_self_test_math", "rts_cube_attach", "rts_cube_accumulate", "rts_cube_get"]
+           "rts_self_test_math", "rts_cube_attach", "rts_cube_accumulate", "rts_cube_get", "rts_plan_cpi", "rts_cube_reduce", "rts_kernel_wrapper_on"]
 
 
 def lib():
@@ -154,6 +162,7 @@ def lib():
         "rts_merge_groups": [vp, u32, u32, vp, C.POINTER(u32)],
         "rts_groups_to_responses": [vp, u32, vp, u32, C.POINTER(u32)],
         "rts_kernel_wrapper": [vp, vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, dbl, dbl, vp, vp, vp, vp, vp, vp],
+        "rts_kernel_wrapper_on": [vp, vp, vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, dbl, dbl, vp, vp, vp, vp, vp, vp],
         "rts_vertex_rotation": [vp, u32, C.c_float, C.c_float, C.c_float],
         "rts_rotation_matrix": [C.c_float, C.c_float, C.c_float, vp],
         "rts_rect_mesh": [C.c_float] * 6 + [vp, vp, vp],
@@ -164,6 +173,8 @@ def lib():
         "rts_cube_attach": [vp, C.POINTER(RtsCubeParams), vp],
         "rts_cube_accumulate": [vp, u32, dbl, dbl],
         "rts_cube_get": [vp, vp, u64],
+        "rts_plan_cpi": [u64, u32, u32, u32, u32, u32, vp, u32, C.POINTER(u32)],
+        "rts_cube_reduce": [vp, u32, C.c_int],
         "rts_self_test_math": [vp, vp, vp, vp, vp, vp, vp, vp, u32],
     }
     for name, args in sig.items():

@@ -9,9 +9,13 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <dlfcn.h>
 #include <algorithm>
 #include <chrono>
 #include <map>
+#include <mutex>
+#include <stdexcept>
+#include <string>
 #include <thread>
 #include "rts_internal.h"
 
@@ -127,11 +131,28 @@ extern "C" int rts_link_handles(RtsHandle a, RtsHandle b)
     return RTS_OK;
 }
 
+// The aggregation groups received rays by a packed (receiver, path) key of D x ceil(log2(targets + 1)) + ceil(log2(receivers))
+// bits, which has to fit 64 (rts_post.hip).  Configurations beyond that are refused HERE, when the scene or the receivers are
+// set, not in the middle of a pulse loop.
+static int check_key_width(uint32_t depth, uint32_t n_targets, uint32_t n_rx, const char* who)
+{
+    uint32_t B = 1; while (((uint64_t)1 << B) < (uint64_t)n_targets + 1) B++;
+    uint32_t RXB = 1; while (((uint64_t)1 << RXB) < (uint64_t)std::max<uint32_t>(n_rx, 1)) RXB++;
+    if (depth == 0) B = 0;
+    if ((uint64_t)depth * B + RXB > 64) {
+        rts_set_error("%s: %u targets x depth %u (max_refl + max_refr) with %u receivers needs a %u-bit (receiver, path) aggregation key; the limit is 64 bits (see rts_amd.h, rts_aggregate)",
+                      who, n_targets, depth, n_rx, depth * B + RXB);
+        return RTS_ERR_UNSUPPORTED;
+    }
+    return RTS_OK;
+}
+
 // ------------------------------------------------------------------------------------- scene
 extern "C" int rts_set_scene(RtsHandle c, const RtsMesh* meshes, uint32_t n_targets)
 {
     CHECK_HANDLE(c);
     CHECK_CLOSED(c);
+    { int rc = check_key_width(c->depth, n_targets, c->n_rx, "rts_set_scene"); if (rc != RTS_OK) return rc; }
     if (n_targets && !meshes) { rts_set_error("rts_set_scene: null meshes"); return RTS_ERR_INVALID; }
     if (n_targets > 254) { rts_set_error("rts_set_scene: more than 254 targets"); return RTS_ERR_UNSUPPORTED; }
     std::vector<RtsMeshHost> mh(n_targets);
@@ -273,6 +294,7 @@ extern "C" int rts_set_receivers(RtsHandle c, const RtsReceiverSphere* rx, uint3
     CHECK_CLOSED(c);
     if (n_rx && !rx) { rts_set_error("rts_set_receivers: null array"); return RTS_ERR_INVALID; }
     if (n_rx > 65535) { rts_set_error("rts_set_receivers: more than 65535 receivers"); return RTS_ERR_UNSUPPORTED; }
+    { int rc = check_key_width(c->depth, (uint32_t)c->scene->meshes.size(), n_rx, "rts_set_receivers"); if (rc != RTS_OK) return rc; }
     std::vector<RtsRxDev> h(n_rx);
     for (uint32_t i = 0; i < n_rx; i++) {
         const RtsReceiverSphere& r = rx[i];
@@ -741,6 +763,127 @@ extern "C" int rts_cube_get(RtsHandle c, double* host_out, uint64_t capacity_dou
     return RTS_OK;
 }
 
+// ------------------------------------------------------------------------------------- several GPUs: the plan of an interval
+static uint64_t plan_part_count(uint64_t total, uint32_t tile, uint32_t parts, uint32_t part)
+{
+    if (parts <= 1) return total;
+    const uint64_t stride = (uint64_t)tile * parts, full = total / stride, rem = total % stride, lo = (uint64_t)part * tile;
+    return full * tile + (rem > lo ? std::min<uint64_t>(rem - lo, tile) : 0);
+}
+
+extern "C" int rts_plan_cpi(uint64_t total_rays, uint32_t n_pulses, uint32_t rank, uint32_t world, uint32_t mode, uint32_t min_items,
+                            RtsPlanItem* out, uint32_t capacity, uint32_t* n_out)
+{
+    if (!n_out || world == 0 || rank >= world || mode > RTS_SHARD_RAYS) { rts_set_error("rts_plan_cpi: bad argument (rank %u of %u, mode %u)", rank, world, mode); return RTS_ERR_INVALID; }
+    std::vector<RtsPlanItem> plan;
+    auto item = [&](uint32_t pulse, uint32_t parts, uint32_t part) { RtsPlanItem it; memset(&it, 0, sizeof(it)); it.pulse = pulse; it.ray_first = 0; it.ray_count = total_rays;
+                                                                     if (parts > 1) { it.interleave_tile = RTS_PLAN_TILE; it.interleave_parts = parts; it.interleave_part = part; } return it; };
+    if (mode == RTS_SHARD_RAYS) {
+        for (uint32_t k = 0; k < n_pulses; k++) plan.push_back(item(k, world, rank));
+    } else {
+        const uint32_t base = n_pulses / world, left = n_pulses - base * world;
+        for (uint32_t i = 0; i < base; i++) plan.push_back(item(rank * base + i, 1, 0));
+        if (left) {                                      // the left-over pulse this worker helps with, and who else does
+            const uint32_t mine = (uint32_t)((uint64_t)rank * left / world);
+            uint32_t group = 0, index = 0;
+            for (uint32_t r = 0; r < world; r++) if ((uint32_t)((uint64_t)r * left / world) == mine) { if (r == rank) index = group; group++; }
+            plan.push_back(item(base * world + mine, group, index));
+        }
+    }
+    // refinement: the oldest item is split in two (every other one of its tiles each) until there are min_items
+    while (!plan.empty() && plan.size() < min_items) {
+        const RtsPlanItem it = plan.front();
+        const uint32_t parts = it.interleave_parts > 1 ? it.interleave_parts : 1u, part = it.interleave_parts > 1 ? it.interleave_part : 0u;
+        if (parts > 0x3fffffffu || plan_part_count(it.ray_count, RTS_PLAN_TILE, 2 * parts, part + parts) == 0) break;      // nothing left to split off
+        plan.erase(plan.begin());
+        plan.push_back(item(it.pulse, 2 * parts, part)); plan.push_back(item(it.pulse, 2 * parts, part + parts));
+    }
+    *n_out = (uint32_t)plan.size();
+    if (out) { if (capacity < plan.size()) { rts_set_error("rts_plan_cpi: capacity %u < %zu items", capacity, plan.size()); return RTS_ERR_CAPACITY; }
+               if (!plan.empty()) memcpy(out, plan.data(), sizeof(RtsPlanItem) * plan.size()); }
+    return RTS_OK;
+}
+
+// ------------------------------------------------------------------------------------- several GPUs: sum of the return cubes
+// RCCL is loaded on first use (dlopen): librts_amd.so has no link-time dependency on it, and a process that already holds
+// a copy (torch.distributed) shares that one.
+namespace {
+typedef struct ncclComm* rccl_comm_t;
+struct RcclApi {
+    void* lib = nullptr; bool tried = false;
+    int (*CommInitAll)(rccl_comm_t*, int, const int*) = nullptr;
+    int (*CommDestroy)(rccl_comm_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr; int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool load() {
+        if (tried) return lib != nullptr;
+        tried = true;
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char* n : names) { lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
+        if (!lib) return false;
+        CommInitAll = (int (*)(rccl_comm_t*, int, const int*))dlsym(lib, "ncclCommInitAll");
+        CommDestroy = (int (*)(rccl_comm_t))dlsym(lib, "ncclCommDestroy");
+        AllReduce = (int (*)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t))dlsym(lib, "ncclAllReduce");
+        GroupStart = (int (*)())dlsym(lib, "ncclGroupStart"); GroupEnd = (int (*)())dlsym(lib, "ncclGroupEnd");
+        GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
+        if (!CommInitAll || !CommDestroy || !AllReduce || !GroupStart || !GroupEnd) { dlclose(lib); lib = nullptr; }
+        return lib != nullptr;
+    }
+};
+RcclApi g_rccl;
+__global__ void k_add_f64(double* __restrict__ dst, const double* __restrict__ src, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+}  // namespace
+
+extern "C" int rts_cube_reduce(RtsHandle* hs, uint32_t n, int transport)
+{
+    if (!hs || n == 0) { rts_set_error("rts_cube_reduce: no handles"); return RTS_ERR_INVALID; }
+    for (uint32_t i = 0; i < n; i++) {
+        if (!hs[i] || !hs[i]->cube_set) { rts_set_error("rts_cube_reduce: handle %u has no cube (rts_cube_attach)", i); return RTS_ERR_INVALID; }
+        const RtsCubeParams &a = hs[0]->cube_params, &b = hs[i]->cube_params;
+        if (a.n_rx != b.n_rx || a.n_pulses != b.n_pulses || a.n_bins != b.n_bins) { rts_set_error("rts_cube_reduce: handle %u has a cube of another shape", i); return RTS_ERR_INVALID; }
+        for (uint32_t j = 0; j < i; j++) if (hs[j]->cube == hs[i]->cube) { rts_set_error("rts_cube_reduce: handles %u and %u share one cube buffer (nothing to add)", j, i); return RTS_ERR_INVALID; }
+    }
+    const size_t doubles = 2 * (size_t)hs[0]->cube_params.n_rx * hs[0]->cube_params.n_pulses * hs[0]->cube_params.n_bins;
+    for (uint32_t i = 0; i < n; i++) { RtsContext* c = hs[i]; CHECK_CLOSED(c); RTS_HIP(hipSetDevice(c->device)); RTS_HIP(hipStreamSynchronize(c->stream)); }
+    if (n == 1) return RTS_OK;
+    bool distinct = true;
+    for (uint32_t i = 0; i < n; i++) for (uint32_t j = 0; j < i; j++) if (hs[i]->device == hs[j]->device) distinct = false;
+    if (transport != 2 && distinct && g_rccl.load()) {
+        // one communicator per device, all in this process; one all-reduce (sum, f64) on each handle's stream inside a group
+        std::vector<rccl_comm_t> comms(n, nullptr); std::vector<int> devs(n);
+        for (uint32_t i = 0; i < n; i++) devs[i] = hs[i]->device;
+        int rc = g_rccl.CommInitAll(comms.data(), (int)n, devs.data());
+        if (rc == 0) {
+            rc = g_rccl.GroupStart();
+            for (uint32_t i = 0; i < n && rc == 0; i++) { (void)hipSetDevice(hs[i]->device); rc = g_rccl.AllReduce(hs[i]->cube, hs[i]->cube, doubles, 8 /* ncclFloat64 */, 0 /* ncclSum */, comms[i], hs[i]->stream); }
+            const int rc2 = g_rccl.GroupEnd(); if (rc == 0) rc = rc2;
+            for (uint32_t i = 0; i < n; i++) { (void)hipSetDevice(hs[i]->device); (void)hipStreamSynchronize(hs[i]->stream); }
+            for (uint32_t i = 0; i < n; i++) if (comms[i]) (void)g_rccl.CommDestroy(comms[i]);
+            if (rc == 0) return RTS_OK;
+        }
+        if (transport == 1) { rts_set_error("rts_cube_reduce: RCCL failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"); return RTS_ERR_HIP; }
+        // fall through to peer copies
+    } else if (transport == 1) { rts_set_error("rts_cube_reduce: RCCL requested but %s", distinct ? "librccl could not be loaded" : "two handles share a device"); return RTS_ERR_UNSUPPORTED; }
+    // peer copies: everything is added into handle 0's cube in handle order (bit-reproducible), then copied back out
+    RtsContext* c0 = hs[0];
+    RTS_HIP(hipSetDevice(c0->device));
+    DevBuf<double> tmp; RTS_HIP(tmp.reserve(doubles));
+    struct FreeTmp { DevBuf<double>& t; ~FreeTmp() { t.release(); } } ft{tmp};
+    for (uint32_t i = 1; i < n; i++) {
+        RTS_HIP(hipMemcpyPeerAsync(tmp.p, c0->device, hs[i]->cube, hs[i]->device, sizeof(double) * doubles, c0->stream));
+        k_add_f64<<<(unsigned)((doubles + 255) / 256), 256, 0, c0->stream>>>(c0->cube, tmp.p, doubles);
+        RTS_HIP(hipGetLastError());
+    }
+    RTS_HIP(hipStreamSynchronize(c0->stream));
+    for (uint32_t i = 1; i < n; i++) RTS_HIP(hipMemcpyPeer(hs[i]->cube, hs[i]->device, c0->cube, c0->device, sizeof(double) * doubles));
+    return RTS_OK;
+}
+
 // ------------------------------------------------------------------------------------- host-side group algebra
 // Merge partial group tables (one per GPU): same (rx, path) => sums add, min_ray takes the minimum.
 // Groups are combined in input order, output sorted by (rx, path) so the result does not depend
@@ -808,22 +951,37 @@ extern "C" int rts_groups_to_responses(const RtsGroup* groups, uint32_t n_groups
 }
 
 // ------------------------------------------------------------------------------------- rs::kernel_wrapper
-static RtsContext* g_wrapper_ctx = nullptr;
+// Contexts of the handle-less entry points, one per device (the device current on the calling thread at the call), created on
+// first use and kept for the life of the process.
+static std::map<int, RtsContext*> g_wrapper_ctx;
+static std::mutex g_wrapper_mutex;
 
-extern "C" int rts_kernel_wrapper(PerRayData* h_rx_results_arr, int* h_rx_intersects_arr, unsigned int receivedRays,
-                                  unsigned int depthTotal, unsigned int MaxThreads, unsigned int MaxBlocks, double cspeed,
-                                  double carrier, double* h_npath_arr, double* h_power_arr, double* h_doppler_arr,
-                                  double* h_delay_arr, double* h_phase_arr, int* h_pathMatch)
+static int wrapper_context(RtsContext** out)
+{
+    int cur = 0; if (hipGetDevice(&cur) != hipSuccess) cur = 0;
+    std::lock_guard<std::mutex> lock(g_wrapper_mutex);
+    auto it = g_wrapper_ctx.find(cur);
+    if (it == g_wrapper_ctx.end()) {
+        RtsParams p; memset(&p, 0, sizeof(p)); p.width = 1; p.max_refl = 1; p.device = cur;
+        RtsContext* c = nullptr;
+        int rc = rts_create(&p, &c); if (rc != RTS_OK) return rc;
+        it = g_wrapper_ctx.emplace(cur, c).first;
+    }
+    *out = it->second;
+    return RTS_OK;
+}
+
+extern "C" int rts_kernel_wrapper_on(RtsHandle h, PerRayData* h_rx_results_arr, int* h_rx_intersects_arr, unsigned int receivedRays,
+                                     unsigned int depthTotal, unsigned int MaxThreads, unsigned int MaxBlocks, double cspeed,
+                                     double carrier, double* h_npath_arr, double* h_power_arr, double* h_doppler_arr,
+                                     double* h_delay_arr, double* h_phase_arr, int* h_pathMatch)
 {
     (void)MaxThreads; (void)MaxBlocks;   // launch shapes are chosen by the library (aggregation.cu:142-160 picks them from these)
     if (receivedRays == 0) return RTS_OK;
     if (!h_rx_results_arr || (depthTotal && !h_rx_intersects_arr) || !h_delay_arr || !h_phase_arr || !h_pathMatch) { rts_set_error("rts_kernel_wrapper: null array"); return RTS_ERR_INVALID; }
-    if (!g_wrapper_ctx) {
-        RtsParams p; memset(&p, 0, sizeof(p)); p.width = 1; p.max_refl = 1;
-        int cur = 0; if (hipGetDevice(&cur) == hipSuccess) p.device = cur;
-        int rc = rts_create(&p, &g_wrapper_ctx); if (rc != RTS_OK) return rc;
-    }
-    RtsContext* c = g_wrapper_ctx;
+    RtsContext* c = h;
+    if (!c) { int rc = wrapper_context(&c); if (rc != RTS_OK) return rc; }
+    else { CHECK_CLOSED(c); c->agg_valid = false; c->n_recv = 0; }      // the handle's own received set is overwritten
     RTS_HIP(hipSetDevice(c->device));
     const size_t R = receivedRays, D = depthTotal;
     RTS_HIP(c->d_rx_rays.reserve(R)); RTS_HIP(c->d_rx_paths.reserve(R*D + 1)); RTS_HIP(c->d_delay.reserve(R)); RTS_HIP(c->d_phase.reserve(R)); RTS_HIP(c->d_pathmatch.reserve(R));
@@ -853,7 +1011,18 @@ extern "C" int rts_kernel_wrapper(PerRayData* h_rx_results_arr, int* h_rx_inters
     return RTS_OK;
 }
 
-// the C++ symbol the reference's caller links against (aggregation.cuh:19-22)
+extern "C" int rts_kernel_wrapper(PerRayData* h_rx_results_arr, int* h_rx_intersects_arr, unsigned int receivedRays,
+                                  unsigned int depthTotal, unsigned int MaxThreads, unsigned int MaxBlocks, double cspeed,
+                                  double carrier, double* h_npath_arr, double* h_power_arr, double* h_doppler_arr,
+                                  double* h_delay_arr, double* h_phase_arr, int* h_pathMatch)
+{
+    return rts_kernel_wrapper_on(nullptr, h_rx_results_arr, h_rx_intersects_arr, receivedRays, depthTotal, MaxThreads, MaxBlocks, cspeed, carrier,
+                                 h_npath_arr, h_power_arr, h_doppler_arr, h_delay_arr, h_phase_arr, h_pathMatch);
+}
+
+// the C++ symbol the reference's caller links against (aggregation.cuh:19-22).  The reference prints and exit(1)s on a CUDA
+// error (aggregation.cu:17-27); a library must not end the process, and carrying on with un-aggregated arrays would be worse:
+// a failure is a C++ exception.
 namespace rs {
 void kernel_wrapper(PerRayData* h_rx_results_arr, int* h_rx_intersects_arr, unsigned int receivedRays, unsigned int depthTotal,
                     unsigned int MaxThreads, unsigned int MaxBlocks, double cspeed, double carrier, double* h_npath_arr,
@@ -861,7 +1030,7 @@ void kernel_wrapper(PerRayData* h_rx_results_arr, int* h_rx_intersects_arr, unsi
 {
     int rc = rts_kernel_wrapper(h_rx_results_arr, h_rx_intersects_arr, receivedRays, depthTotal, MaxThreads, MaxBlocks, cspeed, carrier,
                                 h_npath_arr, h_power_arr, h_doppler_arr, h_delay_arr, h_phase_arr, h_pathMatch);
-    if (rc != RTS_OK) fprintf(stderr, "rs::kernel_wrapper: %s\n", rts_last_error());   // the reference prints and exit(1)s (aggregation.cu:17-27)
+    if (rc != RTS_OK) throw std::runtime_error(std::string("rs::kernel_wrapper: ") + rts_last_error());
 }
 }
 

@@ -77,34 +77,37 @@ def aggregate_sharded(tracer, cspeed, carrier, dist, torch):
 # idle).  K = 1 is plain interleaved ray sharding of one pulse over all ranks.  The per-(receiver, path) group
 # tables of all parts are exchanged ONCE per interval -- they are a few hundred bytes, so the exchange is
 # latency bound and batching it is what matters on xGMI.
-IL_TILE = 4096
+IL_TILE = 4096                # == RTS_PLAN_TILE
 
 
-def plan_cpi(total_rays, n_pulses, rank, world):
-    """[(pulse, ray_first, ray_count, interleave)] owned by `rank`; interleave = None or (tile, parts, part)"""
-    base = n_pulses // world
-    out = [(rank * base + i, 0, total_rays, None) for i in range(base)]
-    left = n_pulses - base * world
-    if left:
-        i = rank * left // world                                   # the left-over pulse this rank helps with
-        group = [r for r in range(world) if r * left // world == i]
-        il = (IL_TILE, len(group), group.index(rank)) if len(group) > 1 else None
-        out.append((base * world + i, 0, total_rays, il))
-    return out
+def _plan(total_rays, n_pulses, rank, world, mode, min_items):
+    """the plan lives in the library (rts_plan_cpi, also used by the C++ adapter); items as (pulse, first, count, interleave)"""
+    import ctypes as C
+    from . import _lib as L
+    n = C.c_uint32(0)
+    L.check(L.lib().rts_plan_cpi(total_rays, n_pulses, rank, world, mode, min_items, None, 0, C.byref(n)))
+    arr = (L.RtsPlanItem * max(n.value, 1))()
+    L.check(L.lib().rts_plan_cpi(total_rays, n_pulses, rank, world, mode, min_items, arr, n.value, C.byref(n)))
+    return [(int(it.pulse), int(it.ray_first), int(it.ray_count),
+             (int(it.interleave_tile), int(it.interleave_parts), int(it.interleave_part)) if it.interleave_parts > 1 else None) for it in arr[:n.value]]
 
 
-def plan_rays(total_rays, n_pulses, rank, world):
+def plan_cpi(total_rays, n_pulses, rank, world, min_items=0):
+    """[(pulse, ray_first, ray_count, interleave)] owned by `rank`; interleave = None or (tile, parts, part): whole pulses
+    first, left-over pulses shared by groups of ranks in interleaved tiles"""
+    return _plan(total_rays, n_pulses, rank, world, 0, min_items)
+
+
+def plan_rays(total_rays, n_pulses, rank, world, min_items=0):
     """ray sharding: EVERY pulse of the interval is split over all ranks in interleaved tiles ("ray-sharding is
     the one to report"); the work per rank does not depend on how n_pulses divides by the number of ranks"""
-    il = (IL_TILE, world, rank) if world > 1 else None
-    return [(k, 0, total_rays, il) for k in range(n_pulses)]
+    return _plan(total_rays, n_pulses, rank, world, 1, min_items)
 
 
 def refine_plan(plan, min_items):
     """split items until the rank owns at least `min_items` of them, so that it can keep that many pulses (or pulse
-    parts) in flight (rts_link_handles): the ordering/aggregation of one part then overlaps the trace of the next.
-    Part p of P (tile T) splits into parts p and p + P of 2P -- every other one of its tiles -- so the refined parts
-    are again interleaved parts of the same pulse and their row-keyed group tables merge like any others."""
+    parts) in flight: part p of P (tile T) splits into parts p and p + P of 2P -- every other one of its tiles.  (Same
+    rule as rts_plan_cpi's min_items; kept for plans assembled by hand.)"""
     plan = list(plan)
     while plan and len(plan) < min_items:
         k, first, count, il = plan.pop(0)                          # oldest first keeps the pulse order of the plan

@@ -1,9 +1,13 @@
 // adapter_main.cpp -- drives include/rts_adapter.hpp (the rs::RTS replacement) over the mock World and
 // prints every emitted response, one per line:  pulse-time rx power delay doppler phase
 // The scene mirrors rts_amd.scenes.config_multi(W=16) with moving targets over 3 pulses.
-// argv[1] (optional): pulses in flight (default 2 = software-pipelined over two linked handles; 1 = sequential).
+// argv[1] (optional): pulses in flight per handle set (default 2; 1 = sequential)
+// argv[2] (optional): number of handle SETS, all on device 0 (default 1) -- the multi-device path of the adapter on one GPU
+// argv[3] (optional): "rays" = every pulse split over all handle sets (interleaved tiles), default whole pulses per set
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
+#include <string>
 #include "mock_soars.hpp"
 #include "rts_adapter.hpp"
 
@@ -23,7 +27,12 @@ int main(int argc, char** argv)
     p.shape = "rect"; p.w = 0.2f; p.h = 14.0f; p.d = 14.0f; p.rot0 = YPR{0.6, 0, 0}; p.p0 = Vec3(9, -7, 0); p.vel = Vec3(0, 0, 3); p.refl = 0.7;
     w.transmitters = {&tx}; w.receivers = {&r0, &r1}; w.targets = {&s, &b, &p};
     RtsStats st{};
-    try { rts_amd::run<mock::Traits>(&w, 1024, 65535, 0, &st, argc > 1 ? (unsigned)atoi(argv[1]) : 2u); }
+    rts_amd::RunOptions opt;
+    opt.in_flight = argc > 1 ? (unsigned)atoi(argv[1]) : 2u;
+    opt.devices.assign(argc > 2 ? (size_t)std::max(1, atoi(argv[2])) : 1u, 0);
+    opt.shard_rays = argc > 3 && std::string(argv[3]) == "rays";
+    opt.last_stats = &st;
+    try { rts_amd::run<mock::Traits>(&w, 1024, 65535, opt); }
     catch (const std::exception& e) { fprintf(stderr, "adapter failed: %s\n", e.what()); return 2; }
     for (size_t j = 0; j < w.receivers.size(); j++)
         for (auto* resp : w.receivers[j]->responses)

@@ -1,0 +1,3 @@
+// MOCK: see rsworld.cuh in this directory
+#pragma once
+#include "rsworld.cuh"

@@ -436,6 +436,12 @@ def test_adapter_end_to_end(rts, oracle, tmp_path):
     assert out.returncode == 0, out.stderr
     seq = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=300)       # strictly sequential pulses
     assert seq.returncode == 0 and seq.stdout == out.stdout, "pipelined and sequential pulse loops must emit identical responses"
+    # the multi-device path on one GPU: several handle sets on device 0 -- whole pulses dealt to the sets in turn, and every
+    # pulse split over the sets in interleaved tiles (received rays merged on the host): byte-identical output
+    for argv in (["2", "2"], ["1", "3"], ["2", "2", "rays"], ["1", "3", "rays"], ["3", "2", "rays"]):
+        multi = subprocess.run([exe] + argv, capture_output=True, text=True, timeout=300)
+        assert multi.returncode == 0, multi.stderr
+        assert multi.stdout == out.stdout, "handle sets %r must emit the responses of the single-set run" % (argv,)
     got = np.array([[float(x) for x in line.split()] for line in out.stdout.strip().splitlines()])
     # the same scene through the oracle
     c, fc, Ts, W, max_refl = C0, 10e9, 1e-3, 16, 4
@@ -564,6 +570,58 @@ def test_file_mesh_on_device(rts, oracle, scenes, tmp_path):
     hit0 = (o["hit_prim"] >= 0) & (o["hit_prim"] < 320)
     assert hit0.sum() > 20 and st["shaded"] > 0, "the file mesh must actually be hit"
     tr.close()
+
+
+def test_key_width_is_refused_at_set_up(rts, scenes):
+    """the (receiver, path) aggregation key has to fit 64 bits: a configuration beyond that is refused when the scene or the
+    receivers are set (RTS_ERR_UNSUPPORTED), not discovered by the aggregation in the middle of a pulse loop"""
+    from rts_amd import _lib
+    v, t, n = scenes.plate_mesh(1.0)
+    mesh = dict(tris=t, verts=v, normals=n, refl_coeff=0.9, refr_index=1.0)
+    tr = rts.Tracer(4, 16)                                            # D = 16: 3 bits per path entry, i.e. at most 7 targets
+    tr.set_scene([mesh] * 7)
+    with pytest.raises(_lib.RtsError) as e:
+        tr.set_scene([mesh] * 8)
+    assert e.value.code == _lib.RTS_ERR_UNSUPPORTED and "64" in str(e.value)
+    tr.close()
+    tr = rts.Tracer(4, 8)                                             # D = 8 with 100 targets: 8 x 7 = 56 bits + receivers
+    tr.set_scene([mesh] * 100)
+    rx = scenes.config1()["rx"][0]
+    tr.set_receivers([rx] * 256)                                      # 8 bits: 64 in all
+    with pytest.raises(_lib.RtsError) as e:
+        tr.set_receivers([rx] * 257)
+    assert e.value.code == _lib.RTS_ERR_UNSUPPORTED
+    tr.close()
+
+
+def test_cube_reduce_between_handles(rts, scenes):
+    """rts_cube_reduce: the complex return cubes of several handles of ONE process summed into every one of them (peer-copy
+    transport; the RCCL transport needs distinct devices)"""
+    import ctypes as C
+    from rts_amd import _lib
+    spec = scenes.config_multi(W=16)
+    wl = spec["c"] / spec["carrier"]; tx = spec["tx"]
+    r0 = 2.0 * abs(tx["origin"][0]); t0 = (r0 - 150.0) / spec["c"]; dt = 300.0 / spec["c"] / 64
+    trs = []
+    for part in range(3):
+        t = H.gpu_tracer(rts, spec); t.cube_attach(len(spec["rx"]), 2, 64, t0, dt)
+        t.trace(tx["origin"], tx["span"], tx["dir"], spec["motion"], interleave=(64, 3, part), want_stats=False)
+        t.finalise_uniform(None, wl, 1.0, 1.0, spec["carrier"], spec["c"]); t.cube_accumulate(1, spec["c"], spec["carrier"])
+        trs.append(t)
+    parts = [t.cube() for t in trs]
+    whole = H.gpu_tracer(rts, spec); whole.cube_attach(len(spec["rx"]), 2, 64, t0, dt)
+    whole.trace(tx["origin"], tx["span"], tx["dir"], spec["motion"], want_stats=False)
+    whole.finalise_uniform(None, wl, 1.0, 1.0, spec["carrier"], spec["c"]); whole.cube_accumulate(1, spec["c"], spec["carrier"])
+    arr = (C.c_void_p * 3)(*[t.h for t in trs])
+    _lib.check(_lib.lib().rts_cube_reduce(arr, 3, 0))
+    want = parts[0] + parts[1] + parts[2]
+    for t in trs:
+        assert np.array_equal(t.cube(), want)                       # handle order: bit-reproducible
+    assert np.abs(want).max() > 0
+    np.testing.assert_allclose(want, whole.cube(), rtol=1e-9, atol=1e-30)     # f64 atomics of the whole pulse add in another order
+    assert _lib.lib().rts_cube_reduce(arr, 3, 1) == _lib.RTS_ERR_UNSUPPORTED  # RCCL demanded, but the handles share a device
+    for t in trs + [whole]:
+        t.close()
 
 
 def test_api_errors(rts, scenes):

@@ -206,3 +206,36 @@ def test_adapter_header_compiles_and_links(rts, tmp_path):
     compiler against the C-ABI and resolves rs::kernel_wrapper from librts_amd.so"""
     exe = build_adapter_binary(str(tmp_path / "adapter_main"))
     assert os.path.exists(exe)
+
+
+def test_soars_traits_branch_compiles_and_links(rts, tmp_path):
+    """the RTS_ADAPTER_WITH_SOARS branch of rts_adapter.hpp (rts_amd::SoarsTraits, rs::RTS with the reference's signature,
+    ray_tracer.cpp:512) parses, type-checks and links against header-only stand-ins that carry the SOARS class and method
+    NAMES of ray_tracer.cpp:50-60 (tests/adapter/soars_stub/: a mock, SOARS itself is not in the reference repository)"""
+    import subprocess
+    exe = str(tmp_path / "soars_glue")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tests", "adapter", "soars_stub"),
+                           os.path.join(ROOT, "tests", "adapter", "soars_glue.cpp"), "-L", os.path.join(ROOT, "rts_amd"), "-lrts_amd",
+                           "-Wl,-rpath," + os.path.join(ROOT, "rts_amd"), "-o", exe])
+    assert subprocess.run([exe], timeout=60).returncode == 0
+
+
+def test_plan_cpi_in_the_library(rts):
+    """rts_plan_cpi (the plan the C++ adapter and bench.py share): ray mode gives every rank its interleaved part of every
+    pulse; min_items refines to that many items without changing what the rank owns; bad arguments are refused"""
+    from rts_amd import multigpu, _lib
+    total = 216 ** 3
+    for world in (1, 2, 5, 8):
+        for rank in range(world):
+            p = multigpu.plan_rays(total, 3, rank, world)
+            assert [k for k, _, _, _ in p] == [0, 1, 2]
+            assert all(il == ((multigpu.IL_TILE, world, rank) if world > 1 else None) for _, _, _, il in p)
+        cover = sum(multigpu.part_ray_count(total, il) for r in range(world) for (_, _, _, il) in multigpu.plan_rays(total, 1, r, world))
+        assert cover == total
+    for K, N, want in ((20, 8, 3), (1, 4, 3), (7, 3, 4)):
+        for r in range(N):
+            coarse = multigpu.plan_cpi(total, K, r, N); fine = multigpu.plan_cpi(total, K, r, N, min_items=want)
+            assert fine == multigpu.refine_plan(coarse, want)
+            assert sum(multigpu.part_ray_count(c, il) for _, _, c, il in fine) == sum(multigpu.part_ray_count(c, il) for _, _, c, il in coarse)
+    with pytest.raises(_lib.RtsError):
+        multigpu.plan_cpi(total, 4, 3, 3)                            # rank >= world
