@@ -84,7 +84,7 @@ def cpu_baseline(spec, seconds_target=12.0):
     sc = H.oracle_scene(O, spec, pulse_motion(spec, 0))
     tx = spec["tx"]; W = spec["W"]; total = W ** 3
     n = 20000
-    kw = dict(use_bvh=True, threads=threads, debug=False)
+    kw = dict(use_bvh=True, threads=threads, debug=False, reuse_buffers=True)
     sc.trace(tx["origin"], tx["span"], tx["dir"], W, spec["max_refl"], 0, spec["smooth"], ray_first=0, ray_stride=total // n, n_rays=n, **kw)   # builds the BVH
     t0 = time.time()
     r = sc.trace(tx["origin"], tx["span"], tx["dir"], W, spec["max_refl"], 0, spec["smooth"], ray_first=0, ray_stride=total // n, n_rays=n, **kw)

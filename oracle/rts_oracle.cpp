@@ -761,16 +761,20 @@ int orc_trace(void* s, const OPulse* p, uint64_t ray_first, uint64_t ray_stride,
     if (use_bvh && !sc->bvhBuilt) bvh_build(*sc);
     const unsigned D = p->maxRefr + p->maxRefl;
     const uint64_t rows = (uint64_t)orc_rows_per_ray(p->maxRefl, p->maxRefr) * n_rays;
-    // host pre-fill: ray_tracer.cpp:854-868 and ray_tracer.cu:227-240
-    for (uint64_t i = 0; i < rows; i++) {
-        PerRayData& o = results[i]; memset(&o, 0, sizeof(o));
-        o.refrIndex.x = 1; o.refrIndex.y = 1; o.received = -1; o.end = false;
-    }
-    for (uint64_t i = 0; i < rows*D; i++) { targ_intersect[i] = -1; rcs_angle[2*i] = -1000000; rcs_angle[2*i+1] = -1000000; }
     const unsigned hitCols = p->maxRefl + 1;
-    if (hit_prim) for (uint64_t i = 0; i < n_rays*hitCols; i++) { hit_prim[i] = -2; hit_t[i] = 0.0f; }
     if (n_threads < 1) n_threads = 1;
+    // host pre-fill: ray_tracer.cpp:854-868 and ray_tracer.cu:227-240 (done by the workers, chunk by chunk, so that a
+    // many-thread run is not dominated by one thread touching gigabytes of output)
+    auto prefill = [&](uint64_t r0, uint64_t r1) {
+        for (uint64_t i = r0; i < r1; i++) {
+            PerRayData& o = results[i]; memset(&o, 0, sizeof(o));
+            o.refrIndex.x = 1; o.refrIndex.y = 1; o.received = -1; o.end = false;
+        }
+        for (uint64_t i = r0*D; i < r1*D; i++) { targ_intersect[i] = -1; rcs_angle[2*i] = -1000000; rcs_angle[2*i+1] = -1000000; }
+    };
     std::vector<OTraceCtx> ctxs(n_threads);
+    const uint64_t CHUNK = 2048;                                   // launch indices per work unit, handed out dynamically:
+    std::atomic<uint64_t> next_fill(0), next_ray(0), filled(0);    // rays that hit cluster in launch-index space
     auto worker = [&](int tid) {
         OTraceCtx& cx = ctxs[tid];
         cx.sc = sc; cx.p = p; cx.d_maxReflDepth = p->maxRefl + 1; cx.d_maxRefrDepth = p->maxRefr; cx.depthTotal = D;
@@ -778,11 +782,22 @@ int orc_trace(void* s, const OPulse* p, uint64_t ray_first, uint64_t ray_stride,
         cx.hit_prim = hit_prim; cx.hit_t = hit_t; cx.hitCols = hitCols;
         cx.nodeVisits = cx.triTests = cx.segments = cx.shaded = 0;
         const uint64_t W = p->width;
-        uint64_t lo = n_rays * tid / n_threads, hi = n_rays * (tid + 1) / n_threads;
-        for (uint64_t k = lo; k < hi; k++) {
-            uint64_t g = ray_first + k*ray_stride;                         // rayIndex = z*W*W + y*W + x  (ray_tracer.cu:151)
-            unsigned lx = (unsigned)(g % W), ly = (unsigned)((g / W) % W), lz = (unsigned)(g / (W*W));
-            ray_generation(cx, k, lx, ly, lz);
+        for (;;) {                                                 // phase 1: pre-fill every output row
+            const uint64_t r0 = next_fill.fetch_add(CHUNK); if (r0 >= rows) break;
+            const uint64_t r1 = std::min(rows, r0 + CHUNK);
+            prefill(r0, r1);
+            if (hit_prim) for (uint64_t i = r0; i < std::min(r1, n_rays); i++) for (unsigned c = 0; c < hitCols; c++) { hit_prim[i*hitCols + c] = -2; hit_t[i*hitCols + c] = 0.0f; }
+            filled.fetch_add(r1 - r0);
+        }
+        while (filled.load() < rows) std::this_thread::yield();    // a refracted child writes rows of other chunks: all rows first
+        for (;;) {                                                 // phase 2: trace
+            const uint64_t lo = next_ray.fetch_add(CHUNK); if (lo >= n_rays) break;
+            const uint64_t hi = std::min(n_rays, lo + CHUNK);
+            for (uint64_t k = lo; k < hi; k++) {
+                uint64_t g = ray_first + k*ray_stride;                         // rayIndex = z*W*W + y*W + x  (ray_tracer.cu:151)
+                unsigned lx = (unsigned)(g % W), ly = (unsigned)((g / W) % W), lz = (unsigned)(g / (W*W));
+                ray_generation(cx, k, lx, ly, lz);
+            }
         }
     };
     if (n_threads == 1) worker(0);
