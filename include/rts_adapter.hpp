@@ -271,7 +271,7 @@ void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlo
                 const unsigned f = k % F;
                 for (unsigned s = 0; s < S; s++) {
                     RtsPlanItem item{}; uint32_t n_items = 0;
-                    check(rts_plan_cpi(launchTotal, 1, s, S, RTS_SHARD_RAYS, 0, &item, 1, &n_items), "rts_plan_cpi");
+                    check(rts_plan_cpi(launchTotal, 1, s, S, RTS_SHARD_RAYS, 0, 0, &item, 1, &n_items), "rts_plan_cpi");
                     fl.time_t = begin_pulse(k, H(s, f), item); fl.parts.push_back(H(s, f));
                 }
             } else {                                                           // whole pulse on the next (set, slot) in turn

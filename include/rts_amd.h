@@ -283,9 +283,10 @@ typedef struct RtsPlanItem {
 } RtsPlanItem;
 #define RTS_SHARD_PULSES 0u
 #define RTS_SHARD_RAYS 1u
-#define RTS_PLAN_TILE 4096u      /* launch indices per interleaved tile */
+#define RTS_PLAN_TILE 4096u      /* default launch indices per interleaved tile (a multiple of 64 keeps the tile-cost history) */
 int rts_plan_cpi(uint64_t total_rays, uint32_t n_pulses, uint32_t rank, uint32_t world, uint32_t mode, uint32_t min_items,
-                 RtsPlanItem* out, uint32_t capacity, uint32_t* n_out);
+                 uint32_t tile /* launch indices per interleaved tile; 0 = RTS_PLAN_TILE */, RtsPlanItem* out, uint32_t capacity,
+                 uint32_t* n_out);
 /* Sum of the complex return cubes of several handles (same RtsCubeParams; one handle per GPU, or several per GPU), left in
  * EVERY handle's cube: the "RCCL reduce over the per-receiver return buffers" of a multi-GPU interval when all GPUs belong
  * to one process.  transport 0: RCCL (ncclCommInitAll + ncclAllReduce, loaded on first use) when the handles sit on

@@ -173,7 +173,7 @@ def lib():
         "rts_cube_attach": [vp, C.POINTER(RtsCubeParams), vp],
         "rts_cube_accumulate": [vp, u32, dbl, dbl],
         "rts_cube_get": [vp, vp, u64],
-        "rts_plan_cpi": [u64, u32, u32, u32, u32, u32, vp, u32, C.POINTER(u32)],
+        "rts_plan_cpi": [u64, u32, u32, u32, u32, u32, u32, vp, u32, C.POINTER(u32)],
         "rts_cube_reduce": [vp, u32, C.c_int],
         "rts_self_test_math": [vp, vp, vp, vp, vp, vp, vp, vp, u32],
     }

@@ -81,6 +81,11 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     hipDeviceProp_t prop; e = hipGetDeviceProperties(&prop, p->device);
     if (e != hipSuccess) { delete c; rts_set_error("hipGetDeviceProperties: %s", hipGetErrorString(e)); return RTS_ERR_HIP; }
     c->n_cu = prop.multiProcessorCount;
+    // experiment / test knobs, read ONCE PER HANDLE at creation (never per process: two handles of one process may differ)
+    { const char* e = getenv("RTS_GRID_MULT"); if (e) c->grid_mult = std::max(1, atoi(e)); }
+    { const char* e = getenv("RTS_GRID_SPARE"); if (e) c->grid_spare = std::max(0, atoi(e)); }
+    { const char* e = getenv("RTS_TILE_LPT"); if (e && e[0] == '0') c->tile_lpt = false; }
+    { const char* e = getenv("RTS_EW_REL"); if (e) { const double v = atof(e); if (v > 0) c->ew_rel = v; } }
     { const char* e = getenv("RTS_STACK_LDS_DEBUG"); if (e) { int v = atoi(e); if (v >= 1 && v <= RTS_STACK_LDS) c->stack_lds = (uint32_t)v; } }   // tests: force the spill path
     *out = c;
     return RTS_OK;
@@ -383,8 +388,7 @@ static int fill_target_placement(const RtsContext* c, uint32_t t, RtsTargetDev& 
     // itself (Sterbenz-exact or correctly rounded), the f32 narrowing of the mapped origin -- is relative to |o - p| and
     // is inside the 3e-7 |o'| of rts_slab_setup.  2^-49 wmax is that bound times 9.  (Round 1 used 4e-9 wmax: harmless
     // near the origin, but 2.6 cm on every slab plane of a mesh of 10-30 cm triangles at 6.4e6 m.)
-    static const double ew_rel = []() { const char* e = getenv("RTS_EW_REL"); const double v = e ? atof(e) : 0.0; return v > 0 ? v : 1.7763568394002505e-15; }();
-    td.ew = (float)(wmax * ew_rel) + 1.0e-30f;
+    td.ew = (float)(wmax * c->ew_rel) + 1.0e-30f;
     if (b.root < 0 || !std::isfinite(td.cx + td.cy + td.cz + td.r2)) td.root = -1;
     return RTS_OK;
 }
@@ -491,8 +495,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     c->ray_first = first; c->n_rays = n;
     const bool keep_all = (c->params.flags & RTS_FLAG_KEEP_ALL_RAYS) != 0;
     const bool count_trav = (c->params.flags & RTS_FLAG_COUNT_TRAVERSAL) != 0;
-    static int grid_mult = 0; if (!grid_mult) { const char* e = getenv("RTS_GRID_MULT"); grid_mult = e ? std::max(1, atoi(e)) : 4; }   // blocks per CU: 4 = exactly the resident set (waves draw tiles from a queue)
-    static int grid_spare = -1; if (grid_spare < 0) { const char* e = getenv("RTS_GRID_SPARE"); grid_spare = e ? std::max(0, atoi(e)) : 64; }
+    const int grid_mult = c->grid_mult, grid_spare = c->grid_spare;   // blocks per CU: 4 = exactly the resident set (waves draw tiles from a queue); block slots left free
     // the trace kernel's blocks are persistent and four of them fill a CU's register file: leave a few block slots free so
     // that the short kernels of the neighbouring pulses (other streams) are not locked out for the whole launch
     uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)n + RTS_BLOCK - 1) / RTS_BLOCK, (uint64_t)std::max<int>(c->n_cu * grid_mult - grid_spare, c->n_cu));
@@ -527,7 +530,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     a.recv_records = c->d_recv.p; a.all_records = c->d_all.p; a.counters = c->d_counters.p; a.block_counters = c->d_block_counters.p; a.dir_hist = c->d_dir_hist.p;
     a.hit_prim = c->d_hit_prim.p; a.hit_t = c->d_hit_t.p; a.stack_ovf = c->d_stack_ovf.p; a.child = c->d_child.p;
     {   // longest-tile-first order from what this handle's earlier launches measured per global tile (rts_post.hip)
-        static int lpt = -1; if (lpt < 0) { const char* e = getenv("RTS_TILE_LPT"); lpt = (e && e[0] == '0') ? 0 : 1; }
+        const int lpt = c->tile_lpt ? 1 : 0;
         const uint32_t n_tiles = (n + RTS_WTILE - 1) / RTS_WTILE;
         const uint64_t sig[4] = {n, first, ((uint64_t)il_parts << 32) | il_tile, il_part};
         const bool aligned = first % RTS_WTILE == 0 && (il_parts <= 1 || il_tile % RTS_WTILE == 0);
@@ -772,12 +775,13 @@ static uint64_t plan_part_count(uint64_t total, uint32_t tile, uint32_t parts, u
 }
 
 extern "C" int rts_plan_cpi(uint64_t total_rays, uint32_t n_pulses, uint32_t rank, uint32_t world, uint32_t mode, uint32_t min_items,
-                            RtsPlanItem* out, uint32_t capacity, uint32_t* n_out)
+                            uint32_t tile, RtsPlanItem* out, uint32_t capacity, uint32_t* n_out)
 {
+    if (tile == 0) tile = RTS_PLAN_TILE;
     if (!n_out || world == 0 || rank >= world || mode > RTS_SHARD_RAYS) { rts_set_error("rts_plan_cpi: bad argument (rank %u of %u, mode %u)", rank, world, mode); return RTS_ERR_INVALID; }
     std::vector<RtsPlanItem> plan;
     auto item = [&](uint32_t pulse, uint32_t parts, uint32_t part) { RtsPlanItem it; memset(&it, 0, sizeof(it)); it.pulse = pulse; it.ray_first = 0; it.ray_count = total_rays;
-                                                                     if (parts > 1) { it.interleave_tile = RTS_PLAN_TILE; it.interleave_parts = parts; it.interleave_part = part; } return it; };
+                                                                     if (parts > 1) { it.interleave_tile = tile; it.interleave_parts = parts; it.interleave_part = part; } return it; };
     if (mode == RTS_SHARD_RAYS) {
         for (uint32_t k = 0; k < n_pulses; k++) plan.push_back(item(k, world, rank));
     } else {
@@ -794,7 +798,7 @@ extern "C" int rts_plan_cpi(uint64_t total_rays, uint32_t n_pulses, uint32_t ran
     while (!plan.empty() && plan.size() < min_items) {
         const RtsPlanItem it = plan.front();
         const uint32_t parts = it.interleave_parts > 1 ? it.interleave_parts : 1u, part = it.interleave_parts > 1 ? it.interleave_part : 0u;
-        if (parts > 0x3fffffffu || plan_part_count(it.ray_count, RTS_PLAN_TILE, 2 * parts, part + parts) == 0) break;      // nothing left to split off
+        if (parts > 0x3fffffffu || plan_part_count(it.ray_count, tile, 2 * parts, part + parts) == 0) break;      // nothing left to split off
         plan.erase(plan.begin());
         plan.push_back(item(it.pulse, 2 * parts, part)); plan.push_back(item(it.pulse, 2 * parts, part + parts));
     }

@@ -85,9 +85,9 @@ def _plan(total_rays, n_pulses, rank, world, mode, min_items):
     import ctypes as C
     from . import _lib as L
     n = C.c_uint32(0)
-    L.check(L.lib().rts_plan_cpi(total_rays, n_pulses, rank, world, mode, min_items, None, 0, C.byref(n)))
+    L.check(L.lib().rts_plan_cpi(total_rays, n_pulses, rank, world, mode, min_items, IL_TILE, None, 0, C.byref(n)))
     arr = (L.RtsPlanItem * max(n.value, 1))()
-    L.check(L.lib().rts_plan_cpi(total_rays, n_pulses, rank, world, mode, min_items, arr, n.value, C.byref(n)))
+    L.check(L.lib().rts_plan_cpi(total_rays, n_pulses, rank, world, mode, min_items, IL_TILE, arr, n.value, C.byref(n)))
     return [(int(it.pulse), int(it.ray_first), int(it.ray_count),
              (int(it.interleave_tile), int(it.interleave_parts), int(it.interleave_part)) if it.interleave_parts > 1 else None) for it in arr[:n.value]]
 

@@ -81,7 +81,7 @@ def _tile_indices(total, interleave):
     return idx[(idx // tile) % parts == part]
 
 
-def _cpi_worker(rank, world, port, out_dir, n_pulses):
+def _cpi_worker(rank, world, port, out_dir, n_pulses, shard="pulses"):
     sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -94,7 +94,7 @@ def _cpi_worker(rank, world, port, out_dir, n_pulses):
     total = spec["W"] ** 3
     wl = spec["c"] / spec["carrier"]
     parts = []
-    for (k, first, count, il) in multigpu.plan_cpi(total, n_pulses, rank, world):
+    for (k, first, count, il) in (multigpu.plan_rays if shard == "rays" else multigpu.plan_cpi)(total, n_pulses, rank, world):
         mo = [dict(position=tuple(np.add(m["position"], (0.3 * k, 0.0, 0.1 * k))), velocity=m["velocity"]) for m in spec["motion"]]
         o = H.oracle_trace(O, spec, motion=mo)                  # whole pulse, then keep this part's launch indices (stand-in for the device)
         mine = _tile_indices(total, il)
@@ -110,11 +110,12 @@ def _cpi_worker(rank, world, port, out_dir, n_pulses):
     dist.barrier(); dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_pulses", [(2, 3), (3, 2), (2, 1), (3, 4)])
-def test_cpi_sharding(tmp_path, world, n_pulses, oracle):
-    """pulse x ray sharding of a CPI: whole pulses per rank, left-over pulses in interleaved tiles within rank groups,
-    ONE exchange; per-pulse responses identical to the literal single-process pipeline"""
-    mp.spawn(_cpi_worker, args=(world, _free_port(), str(tmp_path), n_pulses), nprocs=world, join=True)
+@pytest.mark.parametrize("world,n_pulses,shard", [(2, 3, "pulses"), (3, 2, "pulses"), (2, 1, "pulses"), (3, 4, "pulses"), (2, 2, "rays"), (3, 3, "rays")])
+def test_cpi_sharding(tmp_path, world, n_pulses, shard, oracle):
+    """pulse x ray sharding of a CPI: whole pulses per rank, left-over pulses in interleaved tiles within rank groups -- or
+    (bench.py --shard rays) EVERY pulse split over all ranks in interleaved tiles --, ONE exchange; per-pulse responses
+    identical to the literal single-process pipeline"""
+    mp.spawn(_cpi_worker, args=(world, _free_port(), str(tmp_path), n_pulses, shard), nprocs=world, join=True)
     sys.path.insert(0, HERE)
     from rts_amd import scenes
     import helpers as H

@@ -811,7 +811,7 @@ def test_tile_schedule_does_not_change_results(rts, scenes, monkeypatch):
     H.assert_prd_equal(a["results"], c["results"], "after a different launch shape")
     tr.close()
     monkeypatch.setenv("RTS_TILE_LPT", "0")
-    # (the switch is read once per process: this handle may or may not honour it, the results must not care)
+    # (read per handle at creation: this handle runs without the cost ordering)
     tr2 = H.gpu_tracer(rts, spec)
     _, d = snapshot(tr2)
     H.assert_prd_equal(a["results"], d["results"], "fresh handle")
