@@ -181,6 +181,7 @@ struct OTraceCtx {
     // debug trace (oracle-only outputs): per launch ray, per segment of the REFLECTION chain
     int* hit_prim; float* hit_t; unsigned hitCols;
     uint64_t nodeVisits, triTests, segments, shaded;
+    unsigned long long cov[24] = {0};   // branch coverage of the miss program, private to the worker (COV_* below)
 };
 
 // ------------------------------------------------------------------ triangle_mesh.cu:121-137
@@ -392,8 +393,9 @@ enum { COV_PHI_LOW = 0,       // :332-335  phi < -pi/2 correction taken
        COV_EARTH_BOTH,        //           both roots added to rayLength (quirk 6)
        COV_EARTH_MISS,        //           discriminant <= 0 or no valid root
        COV_N };
-static std::atomic<unsigned long long> g_cov[COV_N];
-#define COV(k) g_cov[k].fetch_add(1ULL, std::memory_order_relaxed)
+static_assert(COV_N <= 24, "OTraceCtx::cov is too small");
+static std::atomic<unsigned long long> g_cov[COV_N];            // totals since the last reset; the workers count privately
+#define COV(k) (cx.cov[k]++)                                      // (a shared atomic per ray made 256 threads crawl) and add up once
 
 // ------------------------------------------------------------------ ray_tracer.cu:260-478  miss program
 static void miss_program(OTraceCtx& cx, PerRayData& prd)
@@ -802,6 +804,7 @@ int orc_trace(void* s, const OPulse* p, uint64_t ray_first, uint64_t ray_stride,
     };
     if (n_threads == 1) worker(0);
     else { std::vector<std::thread> th; for (int t = 0; t < n_threads; t++) th.emplace_back(worker, t); for (auto& t : th) t.join(); }
+    for (auto& c : ctxs) for (int k = 0; k < COV_N; k++) if (c.cov[k]) g_cov[k].fetch_add(c.cov[k], std::memory_order_relaxed);
     if (counters) { counters[0] = counters[1] = counters[2] = counters[3] = 0;
         for (auto& c : ctxs) { counters[0] += c.nodeVisits; counters[1] += c.triTests; counters[2] += c.segments; counters[3] += c.shaded; } }
     return 0;

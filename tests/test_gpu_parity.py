@@ -884,6 +884,31 @@ def test_c5_full_size_moving_target_sampled_parity(rts, oracle, scenes):
     tr.close()
 
 
+@pytest.mark.parametrize("variant", ["icosphere", "file10k"])
+def test_c2_full_size_sampled_parity(rts, oracle, scenes, variant):
+    """BASELINE configs[1] at full size -- W = 100 (1 000 000 launch indices), 4 bounces, on the n = 5 icosphere (20 480
+    triangles) and on the 10 000-triangle sphere loaded through rts_file_mesh (unshared vertices, the "10k tris" of the config's
+    wording): every launch index's segment accounting plus every 97th launch index through the oracle (BVH mode)"""
+    spec = scenes.config2(rx_radius=200.0) if variant == "icosphere" else scenes.config2_file(rx_radius=200.0)
+    n = spec["W"] ** 3
+    assert n == 1000000 and spec["meshes"][0]["tris"].shape[0] == (20480 if variant == "icosphere" else 10000)
+    tr = H.gpu_tracer(rts, spec)
+    _, st = H.gpu_trace(rts, spec, tr=tr)
+    g = tr.received(); R = st["received"]
+    assert st["rays"] == n and st["segments"] == n + st["shaded"] and R > 1000
+    stride = 97; m = n // stride
+    o = H.oracle_trace(oracle, spec, ray_first=5, ray_stride=stride, n_rays=m, use_bvh=True, threads=8, debug=False)
+    samp = 5 + stride * np.arange(m, dtype=np.int64)
+    o_idx = np.nonzero(o["results"]["received"] >= 0)[0]
+    slots = g["slots"].astype(np.int64)
+    pos_c = np.minimum(np.searchsorted(slots, samp), R - 1)
+    is_recv = slots[pos_c] == samp
+    assert np.array_equal(np.nonzero(is_recv)[0], o_idx) and len(o_idx) > 20
+    H.assert_prd_equal(o["results"][o_idx], g["results"][pos_c[is_recv]], "C2 %s sampled received records" % variant)
+    assert np.array_equal(o["path"][o_idx], g["path"][pos_c[is_recv]])
+    tr.close()
+
+
 @pytest.mark.parametrize("seed,refr,far", [(1, 0, False), (2, 0, False), (3, 1, False), (4, 0, True), (5, 1, True)])
 def test_random_triangle_soups_brute_force(rts, oracle, scenes, seed, refr, far):
     """fuzz of the hierarchy builder (SAH, split references) and of the conservative walk: random triangle soups with
