@@ -76,6 +76,7 @@ static_assert(sizeof(RtsChildState) == 128, "child state size");
 #define RTS_WTILE 64               // work unit of the trace kernel: launch indices per wave tile
 #define RTS_TILE_CTRS 64           // striped draw counters of the tile queue
 #define RTS_STACK_LDS 24            // traversal stack entries kept in LDS per lane
+#define RTS_RX_LDS 16               // receivers whose capture spheres the trace kernel keeps in LDS (the rest are read from memory)
 #define RTS_STACK_OVF 128           // further entries spilled to global memory (rare); a BVH4 node pushes up to 3 entries
 
 // Launch constants of ray_generation (hoisted trig, ray_tracer.cu:155-203).  Device resident and

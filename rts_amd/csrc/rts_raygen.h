@@ -16,8 +16,10 @@ __device__ __forceinline__ uint64_t rts_global_index(const RtsLaunchConsts& a, u
 __device__ __forceinline__ dvec3 rts_primary_dir(const RtsLaunchConsts& a, uint32_t slot)
 {
     if (a.W == 1) return mk3(a.w1x, a.w1y, a.w1z);                       // ray_tracer.cu:160-161
-    const uint64_t g = rts_global_index(a, slot);                         // rayIndex = z*W*W + y*W + x  :151
-    const uint32_t lx = (uint32_t)(g % a.W), ly = (uint32_t)((g / a.W) % a.W), lz = (uint32_t)(g / ((uint64_t)a.W * a.W));
+    // rayIndex = z*W*W + y*W + x (:151), an unsigned int in the reference and < 2^32 here (rts_create): two 32-bit
+    // divisions.  (As 64-bit % and / this was ~450 instructions per launch index -- a sixth of the whole C3 kernel.)
+    const uint32_t g = (uint32_t)rts_global_index(a, slot);
+    const uint32_t q = g / a.W, lx = g - q * a.W, lz = q / a.W, ly = q - lz * a.W;
     dvec3 v = mk3(a.bsx + a.stx * (double)lx, a.bsy + a.sty * (double)ly, a.bsz + a.stz * (double)lz);   // :167-169
     v = unit3(v);                                                         // :170
     dvec3 r;                                                              // rotated = 0; rotated += Rot*v  :178-182

@@ -109,7 +109,22 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
     __shared__ __attribute__((aligned(16))) int32_t s_stack[RTS_STACK_LDS * RTS_BLOCK];
     const uint32_t tid = threadIdx.x;
     const uint32_t gtid = blockIdx.x * RTS_BLOCK + tid;
-    const RtsLaunchConsts& lc = *a.lc;
+    // Launch constants and the first RTS_RX_LDS receivers are copied into LDS once per (persistent) block.  Read through their
+    // device pointers they are wave-wide BROADCAST loads on the vector memory path -- which returns 64 x 16 bytes per dwordx4
+    // whether the lanes' addresses differ or not -- and they are re-issued for every tile and every missing segment (the
+    // fetch asm clobbers memory, so nothing read through a pointer stays in registers): on a launch that hits nothing they
+    // alone kept the return path 87 % busy (5.3 M loads, counters of tools/trace_bench.py c3nomesh).
+    __shared__ __attribute__((aligned(16))) RtsLaunchConsts s_lc;
+    __shared__ __attribute__((aligned(16))) RtsRxDev s_rx[RTS_RX_LDS];
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.lc); uint32_t* dst = reinterpret_cast<uint32_t*>(&s_lc);
+        for (uint32_t i = threadIdx.x; i < sizeof(RtsLaunchConsts) / 4; i += RTS_BLOCK) dst[i] = src[i];
+        const uint32_t n_rx_lds = a.n_rx < RTS_RX_LDS ? a.n_rx : RTS_RX_LDS;
+        const uint32_t* rsrc = reinterpret_cast<const uint32_t*>(a.rx); uint32_t* rdst = reinterpret_cast<uint32_t*>(s_rx);
+        for (uint32_t i = threadIdx.x; i < n_rx_lds * (sizeof(RtsRxDev) / 4); i += RTS_BLOCK) rdst[i] = rsrc[i];
+    }
+    __syncthreads();
+    const RtsLaunchConsts& lc = s_lc;
     const dvec3 origin = mk3(lc.ox, lc.oy, lc.oz);
     unsigned long long n_seg = 0, n_shaded = 0, n_nodes = 0, n_tris = 0, n_spill = 0;
     bool hard_overflow = false;
@@ -306,7 +321,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
                 // -------------------------------------------------------- miss, ray_tracer.cu:260-478
                 if (end == false) {
                     for (uint32_t Rx_i = 0; Rx_i < a.n_rx; Rx_i++) {
-                        const RtsRxDev rx = a.rx[Rx_i];
+                        const RtsRxDev rx = Rx_i < RTS_RX_LDS ? s_rx[Rx_i] : a.rx[Rx_i];
                         double t[2] = {0, 0};
                         const double A = (dir.x)*(dir.x) + (dir.y)*(dir.y) + (dir.z)*(dir.z);
                         const double B = 2*(((prev.x - rx.cx)*dir.x) + ((prev.y - rx.cy)*dir.y) + ((prev.z - rx.cz)*dir.z));

@@ -22,7 +22,7 @@ spec = {"c2": lambda: scenes.config2(rx_radius=200.0), "c3": lambda: scenes.conf
         "c3narrowecef": lambda: scenes.translate(scenes.config3(rx_radius=50.0), scenes.ecef_offset(lat=math.pi / 2)),
         "c4s": lambda: scenes.config4(W=232), "c4": lambda: scenes.config4(), "c5": lambda: scenes.config5()}[which]()
 if which == "c3nomesh":
-    spec["meshes"] = []
+    spec["meshes"] = []; spec["motion"] = []
 if which == "c3norx":
     spec["rx"] = []
 if which in ("c3narrow", "c3narrowecef"):          # beam squeezed onto the fuselage: nearly every ray hits
