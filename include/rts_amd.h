@@ -229,10 +229,9 @@ int rts_finalise_uniform(RtsHandle h, const double* rcs_per_target, double wavel
  * rays on lower ranks).  RTS_BASE_USE_ROWS makes RtsGroup.min_ray the GLOBAL BUFFER ROW (launch index + k W^3)
  * of the group's first ray instead: rows order rays exactly as received-list indices do, and they are comparable
  * across ranks whatever the sharding (interleaved tiles).
- * Key-width limit: rays are grouped by a packed (receiver, path) key of
- *     D x ceil(log2(targets + 1)) + ceil(log2(receivers)) <= 64 bits,   D = max_refl + max_refr
- * (C3: 6 x 1 + 2; C4: 8 x 3 + 3; e.g. D = 8 allows 127 targets, D = 16 seven).  rts_set_scene / rts_set_receivers refuse a
- * configuration beyond it with RTS_ERR_UNSUPPORTED, rts_kernel_wrapper refuses such data. */
+ * Rays are grouped by a packed (receiver, path) key of D x ceil(log2(targets + 1)) + ceil(log2(receivers)) bits,
+ * D = max_refl + max_refr: one 64-bit radix sort when that fits 64 bits (every BASELINE configuration: C3 6 x 1 + 2,
+ * C4 8 x 3 + 3), two or three stable passes over 64-bit words otherwise (e.g. 16 bounces in a scene of 100 targets: 115 bits). */
 #define RTS_BASE_USE_ROWS 0xffffffffffffffffULL
 int rts_aggregate(RtsHandle h, double cspeed, double carrier, uint64_t recv_index_base);
 int rts_group_count(RtsHandle h, uint32_t* count);

@@ -105,7 +105,7 @@ extern "C" int rts_destroy(RtsHandle c)
     c->d_rk.release(); c->d_rk_sorted.release(); c->d_ri.release(); c->d_ri_sorted.release(); c->d_rx_rays.release(); c->d_rx_paths.release();
     c->d_rx_angles.release(); c->d_rx_slots.release(); c->d_all_rays.release(); c->d_all_paths.release(); c->d_all_angles.release();
     c->d_akeys.release(); c->d_akeys_sorted.release(); c->d_aidx.release(); c->d_aidx_sorted.release(); c->d_ghead.release(); c->d_gid.release();
-    c->d_gsum.release(); c->d_gmin.release(); c->d_gkey.release(); c->d_grow.release(); c->d_gcount.release(); c->d_delay.release(); c->d_phase.release();
+    c->d_gsum.release(); c->d_gmin.release(); c->d_gkey.release(); c->d_gpath.release(); c->d_grow.release(); c->d_gcount.release(); c->d_delay.release(); c->d_phase.release();
     c->d_pathmatch.release(); c->d_rcs.release(); c->d_rcsval.release(); c->d_cube_own.release();
     (void)hipStreamSynchronize(c->tstream);
     if (--c->gate->refs == 0) { (void)hipStreamDestroy(c->gate->tstream); delete c->gate; }
@@ -137,15 +137,15 @@ extern "C" int rts_link_handles(RtsHandle a, RtsHandle b)
 }
 
 // The aggregation groups received rays by a packed (receiver, path) key of D x ceil(log2(targets + 1)) + ceil(log2(receivers))
-// bits, which has to fit 64 (rts_post.hip).  Configurations beyond that are refused HERE, when the scene or the receivers are
-// set, not in the middle of a pulse loop.
+// bits: one 64-bit sort when it fits, two or three stable passes when it does not (rts_post.hip: wide keys).  A configuration
+// beyond 256 bits would be refused HERE, when the scene or the receivers are set, not in the middle of a pulse loop.
 static int check_key_width(uint32_t depth, uint32_t n_targets, uint32_t n_rx, const char* who)
 {
     uint32_t B = 1; while (((uint64_t)1 << B) < (uint64_t)n_targets + 1) B++;
     uint32_t RXB = 1; while (((uint64_t)1 << RXB) < (uint64_t)std::max<uint32_t>(n_rx, 1)) RXB++;
     if (depth == 0) B = 0;
-    if ((uint64_t)depth * B + RXB > 64) {
-        rts_set_error("%s: %u targets x depth %u (max_refl + max_refr) with %u receivers needs a %u-bit (receiver, path) aggregation key; the limit is 64 bits (see rts_amd.h, rts_aggregate)",
+    if ((uint64_t)depth * B + RXB > 256) {            // (cannot happen within the other limits: 16 x 8 + 16 = 144 bits)
+        rts_set_error("%s: %u targets x depth %u (max_refl + max_refr) with %u receivers needs a %u-bit (receiver, path) aggregation key; the limit is 256 bits",
                       who, n_targets, depth, n_rx, depth * B + RXB);
         return RTS_ERR_UNSUPPORTED;
     }

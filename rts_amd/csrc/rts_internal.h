@@ -224,7 +224,7 @@ struct RtsContext {
     DevBuf<PerRayData> d_all_rays; DevBuf<int32_t> d_all_paths; DevBuf<double> d_all_angles;
     // aggregation
     DevBuf<uint64_t> d_akeys, d_akeys_sorted; DevBuf<uint32_t> d_aidx, d_aidx_sorted; DevBuf<uint32_t> d_ghead, d_gid;
-    DevBuf<double> d_gsum; DevBuf<uint32_t> d_gmin; DevBuf<uint64_t> d_gkey; DevBuf<uint32_t> d_gcount; DevBuf<uint64_t> d_grow;
+    DevBuf<double> d_gsum; DevBuf<uint32_t> d_gmin; DevBuf<uint64_t> d_gkey; DevBuf<uint32_t> d_gcount; DevBuf<uint64_t> d_grow; DevBuf<int32_t> d_gpath;
     DevBuf<double> d_delay, d_phase; DevBuf<int32_t> d_pathmatch; DevBuf<double> d_rcs;
     std::vector<RtsGroup> groups; bool agg_valid = false; uint64_t recv_index_base = 0;
     RtsCubeParams cube_params; double* cube = nullptr; DevBuf<double> d_cube_own; bool cube_set = false;

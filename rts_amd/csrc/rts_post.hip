@@ -281,6 +281,52 @@ __global__ void k_agg_keys(const PerRayData* __restrict__ rays, const int32_t* _
     keys[i] = k; idx[i] = i;
 }
 
+// Wide keys (D*B + RXB > 64 bits, e.g. 16 bounces in a scene of 100 targets): the same key as a 128- or 192-bit integer,
+// sorted by least-significant-word-first passes of the stable 64-bit radix sort.  Word w of the key of ray idx[j]:
+__global__ void k_agg_keys_wide(const PerRayData* __restrict__ rays, const int32_t* __restrict__ paths, const uint32_t* __restrict__ idx_in, uint32_t R,
+                                uint32_t D, uint32_t B, uint32_t w, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx_out)
+{
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= R) return;
+    const uint32_t i = idx_in ? idx_in[j] : j;
+    uint64_t words[4] = {0, 0, 0, 0};
+    auto put = [&](uint64_t v, uint32_t pos) {
+        const uint32_t wd = pos >> 6, off = pos & 63u;
+        if (wd < 4) words[wd] |= v << off;
+        if (off && wd + 1 < 4) words[wd + 1] |= v >> (64u - off);
+    };
+    for (uint32_t c = 0; c < D; c++) put((uint64_t)(uint32_t)(paths[(size_t)i*D + c] + 1), c * B);
+    put((uint64_t)(uint32_t)rays[i].received, D * B);
+    keys[j] = words[w]; idx_out[j] = i;
+}
+
+// head flags of the sorted order from the rays themselves (same receiver and identical path row: aggregation.cu:46-53), and
+// a 64-bit surrogate key that keeps what the later stages read from a key: the receiver, in the top 32 bits
+__global__ void k_agg_heads_wide(const PerRayData* __restrict__ rays, const int32_t* __restrict__ paths, const uint32_t* __restrict__ idx_sorted, uint32_t R,
+                                 uint32_t D, uint32_t* __restrict__ head, uint64_t* __restrict__ keys_sorted)
+{
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= R) return;
+    const uint32_t i = idx_sorted[j];
+    bool h = (j == 0);
+    if (!h) {
+        const uint32_t p = idx_sorted[j - 1];
+        h = rays[i].received != rays[p].received;
+        for (uint32_t c = 0; c < D && !h; c++) h = paths[(size_t)i*D + c] != paths[(size_t)p*D + c];
+    }
+    head[j] = h ? 1u : 0u;
+    keys_sorted[j] = (uint64_t)(uint32_t)rays[i].received << 32;
+}
+
+// path rows of the groups' first rays (wide keys: the host cannot decode the path from a 64-bit key)
+__global__ void k_agg_gather_paths(const int32_t* __restrict__ paths, const uint32_t* __restrict__ gmin, const uint32_t* __restrict__ g_count, uint32_t D,
+                                   int32_t* __restrict__ gpath)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= *g_count) return;
+    for (uint32_t c = 0; c < D; c++) gpath[(size_t)g*D + c] = paths[(size_t)gmin[g]*D + c];
+}
+
 __global__ void k_agg_heads(const uint64_t* __restrict__ keys, uint32_t* __restrict__ head, uint32_t R)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -452,11 +498,13 @@ int rts_aggregate_device(RtsContext* c, int32_t max_path, int32_t max_rx, const 
     uint32_t B = 1; while (((uint64_t)1 << B) < (uint64_t)(max_path + 2)) B++;
     uint32_t RXB = 1; while (((uint64_t)1 << RXB) < (uint64_t)(max_rx + 1)) RXB++;
     if (D == 0) B = 0;
-    if ((uint64_t)D * B + RXB > 64 || D > RTS_MAX_DEPTH) {
-        rts_set_error("aggregate: (receiver, path) key needs %u x %u + %u bits > 64 or depth > %d", D, B, RXB, RTS_MAX_DEPTH);
+    if (D > RTS_MAX_DEPTH || (uint64_t)D * B + RXB > 256) {
+        rts_set_error("aggregate: depth %u > %d or a (receiver, path) key of %u x %u + %u bits > 256", D, RTS_MAX_DEPTH, D, B, RXB);
         return RTS_ERR_UNSUPPORTED;
     }
-    const uint32_t key_bits = D * B + RXB, shift = D * B;
+    const uint32_t key_bits = D * B + RXB;
+    const bool wide = key_bits > 64;                  // multi-word key: least-significant-word-first passes of the stable sort
+    const uint32_t shift = wide ? 32u : D * B;        // where the receiver sits in the 64-bit (surrogate) key of the sorted order
     const uint32_t n_rx_tab = (uint32_t)max_rx + 1;
     const uint32_t ntiles = blocks_for(R, AGG_TILE);
     RTS_HIP(c->d_akeys.reserve(R)); RTS_HIP(c->d_akeys_sorted.reserve(R)); RTS_HIP(c->d_aidx.reserve(R)); RTS_HIP(c->d_aidx_sorted.reserve(R));
@@ -468,12 +516,28 @@ int rts_aggregate_device(RtsContext* c, int32_t max_path, int32_t max_rx, const 
     uint32_t* d_G = c->d_gcount.p + (size_t)R + 2;    // group count, device resident
     double* gsum = c->d_gsum.p; double* tile_first = gsum + 5*(size_t)R; double* tile_last = tile_first + 5*(size_t)ntiles;
     double* d_rxtot = c->d_rcs.p; uint32_t* d_rxmin = (uint32_t*)(c->d_rcs.p + 5*(size_t)n_rx_tab);
-    k_agg_keys<<<blocks_for(R, 256), 256, 0, st>>>(d_rays, d_paths, R, D, B, c->d_akeys.p, c->d_aidx.p);
     size_t tmp = 0;
-    RTS_HIP(rocprim::radix_sort_pairs(nullptr, tmp, c->d_akeys.p, c->d_akeys_sorted.p, c->d_aidx.p, c->d_aidx_sorted.p, R, 0, key_bits, st));
-    RTS_HIP(c->d_sort_tmp.reserve(tmp));
-    RTS_HIP(rocprim::radix_sort_pairs(c->d_sort_tmp.p, tmp, c->d_akeys.p, c->d_akeys_sorted.p, c->d_aidx.p, c->d_aidx_sorted.p, R, 0, key_bits, st));
-    k_agg_heads<<<blocks_for(R, 256), 256, 0, st>>>(c->d_akeys_sorted.p, c->d_ghead.p, R);
+    if (!wide) {
+        k_agg_keys<<<blocks_for(R, 256), 256, 0, st>>>(d_rays, d_paths, R, D, B, c->d_akeys.p, c->d_aidx.p);
+        RTS_HIP(rocprim::radix_sort_pairs(nullptr, tmp, c->d_akeys.p, c->d_akeys_sorted.p, c->d_aidx.p, c->d_aidx_sorted.p, R, 0, key_bits, st));
+        RTS_HIP(c->d_sort_tmp.reserve(tmp));
+        RTS_HIP(rocprim::radix_sort_pairs(c->d_sort_tmp.p, tmp, c->d_akeys.p, c->d_akeys_sorted.p, c->d_aidx.p, c->d_aidx_sorted.p, R, 0, key_bits, st));
+        k_agg_heads<<<blocks_for(R, 256), 256, 0, st>>>(c->d_akeys_sorted.p, c->d_ghead.p, R);
+    } else {
+        const uint32_t n_words = (key_bits + 63u) / 64u;
+        RTS_HIP(rocprim::radix_sort_pairs(nullptr, tmp, c->d_akeys.p, c->d_akeys_sorted.p, c->d_aidx.p, c->d_aidx_sorted.p, R, 0, 64, st));
+        RTS_HIP(c->d_sort_tmp.reserve(tmp));
+        RTS_HIP(c->d_gid.reserve(R));                  // (free until the scan: the order handed from one pass to the next)
+        for (uint32_t w = 0; w < n_words; w++) {
+            // keys of word w in the order left by the passes so far (pass 0: ray order), then a stable sort by that word
+            k_agg_keys_wide<<<blocks_for(R, 256), 256, 0, st>>>(d_rays, d_paths, w == 0 ? nullptr : c->d_gid.p, R, D, B, w, c->d_akeys.p, c->d_aidx.p);
+            const uint32_t bits = std::min(64u, key_bits - 64u * w);
+            size_t t2 = tmp;
+            RTS_HIP(rocprim::radix_sort_pairs(c->d_sort_tmp.p, t2, c->d_akeys.p, c->d_akeys_sorted.p, c->d_aidx.p, c->d_aidx_sorted.p, R, 0, bits, st));
+            if (w + 1 < n_words) RTS_HIP(hipMemcpyAsync(c->d_gid.p, c->d_aidx_sorted.p, sizeof(uint32_t) * R, hipMemcpyDeviceToDevice, st));
+        }
+        k_agg_heads_wide<<<blocks_for(R, 256), 256, 0, st>>>(d_rays, d_paths, c->d_aidx_sorted.p, R, D, c->d_ghead.p, c->d_akeys_sorted.p);
+    }
     RTS_HIP(rocprim::inclusive_scan(nullptr, tmp, c->d_ghead.p, c->d_gid.p, R, rocprim::plus<uint32_t>(), st));
     RTS_HIP(c->d_sort_tmp.reserve(tmp));
     RTS_HIP(rocprim::inclusive_scan(c->d_sort_tmp.p, tmp, c->d_ghead.p, c->d_gid.p, R, rocprim::plus<uint32_t>(), st));
@@ -486,6 +550,11 @@ int rts_aggregate_device(RtsContext* c, int32_t max_path, int32_t max_rx, const 
                                                        (int64_t)base, d_npath, d_power_sum, d_doppler_sum, d_delay, d_phase, d_pm, pm_init, pm_init == INT32_MIN ? 1 : 0);
     RTS_HIP(hipGetLastError());
     if (!groups) { RTS_HIP(hipStreamSynchronize(st)); return RTS_OK; }
+    if (wide) {                                        // the groups' path rows, for the host copy of the table
+        RTS_HIP(c->d_gpath.reserve((size_t)R * D + 1));
+        k_agg_gather_paths<<<blocks_for(R, 256), 256, 0, st>>>(d_paths, c->d_gmin.p, d_G, D, c->d_gpath.p);
+        RTS_HIP(hipGetLastError());
+    }
     // group table to the host: count + the first AGG_SPEC groups speculatively in one batch (pinned), rest on demand
     RtsPinned* pin = c->pin;
     const uint32_t spec = std::min<uint32_t>(R, RTS_PIN_GROUPS);
@@ -508,6 +577,8 @@ int rts_aggregate_device(RtsContext* c, int32_t max_path, int32_t max_rx, const 
         h_gsum = v_gsum.data(); h_gmin = v_gmin.data(); h_gkey = v_gkey.data();
     }
     const uint64_t pmask = (shift >= 64) ? ~0ULL : (((uint64_t)1 << shift) - 1);
+    std::vector<int32_t> v_gpath;
+    if (wide && G) { v_gpath.resize((size_t)G * D); RTS_HIP(hipMemcpy(v_gpath.data(), c->d_gpath.p, sizeof(int32_t) * (size_t)G * D, hipMemcpyDeviceToHost)); }
     groups->resize(G);
     for (uint32_t g = 0; g < G; g++) {
         RtsGroup& gr = (*groups)[g]; memset(&gr, 0, sizeof(gr));
@@ -515,7 +586,7 @@ int rts_aggregate_device(RtsContext* c, int32_t max_path, int32_t max_rx, const 
         bool all_neg = true;
         for (uint32_t k = 0; k < RTS_MAX_DEPTH; k++) {
             int v = -1;
-            if (k < D) v = (int)(((h_gkey[g] & pmask) >> (k*B)) & (((uint64_t)1 << B) - 1)) - 1;
+            if (k < D) v = wide ? v_gpath[(size_t)g * D + k] : (int)(((h_gkey[g] & pmask) >> (k*B)) & (((uint64_t)1 << B) - 1)) - 1;
             gr.path[k] = v; if (v >= 0) all_neg = false;
         }
         gr.direct = all_neg ? 1u : 0u;

@@ -334,9 +334,11 @@ def test_shared_scene_between_handles(rts, scenes):
     own.close(); b.close(); c.close()
 
 
-@pytest.mark.parametrize("seed,R,D,n_rx,n_targ", [(1, 50, 3, 2, 2), (2, 3000, 4, 4, 3), (3, 700, 1, 1, 1), (4, 5000, 6, 3, 1), (5, 1, 2, 1, 1)])
+@pytest.mark.parametrize("seed,R,D,n_rx,n_targ", [(1, 50, 3, 2, 2), (2, 3000, 4, 4, 3), (3, 700, 1, 1, 1), (4, 5000, 6, 3, 1), (5, 1, 2, 1, 1),
+                                                   (6, 2500, 16, 5, 100), (7, 1500, 16, 300, 250), (8, 900, 9, 2, 200)])
 def test_kernel_wrapper_equals_literal(rts, oracle, seed, R, D, n_rx, n_targ):
-    """rs::kernel_wrapper drop-in (aggregation.cuh:19-22): same in/out arrays as the O(R^2) myKernel1/2"""
+    """rs::kernel_wrapper drop-in (aggregation.cuh:19-22): same in/out arrays as the O(R^2) myKernel1/2.  Seeds 6-8 need a
+    (receiver, path) key of 115 / 137 / 73 bits: the multi-word (wide key) path of the group-by"""
     rng = np.random.default_rng(seed)
     a, paths = random_received_set(oracle, rng, R, D, n_rx, n_targ)
     fc = 10e9
@@ -572,25 +574,34 @@ def test_file_mesh_on_device(rts, oracle, scenes, tmp_path):
     tr.close()
 
 
-def test_key_width_is_refused_at_set_up(rts, scenes):
-    """the (receiver, path) aggregation key has to fit 64 bits: a configuration beyond that is refused when the scene or the
-    receivers are set (RTS_ERR_UNSUPPORTED), not discovered by the aggregation in the middle of a pulse loop"""
-    from rts_amd import _lib
-    v, t, n = scenes.plate_mesh(1.0)
-    mesh = dict(tris=t, verts=v, normals=n, refl_coeff=0.9, refr_index=1.0)
-    tr = rts.Tracer(4, 16)                                            # D = 16: 3 bits per path entry, i.e. at most 7 targets
-    tr.set_scene([mesh] * 7)
-    with pytest.raises(_lib.RtsError) as e:
-        tr.set_scene([mesh] * 8)
-    assert e.value.code == _lib.RTS_ERR_UNSUPPORTED and "64" in str(e.value)
-    tr.close()
-    tr = rts.Tracer(4, 8)                                             # D = 8 with 100 targets: 8 x 7 = 56 bits + receivers
-    tr.set_scene([mesh] * 100)
-    rx = scenes.config1()["rx"][0]
-    tr.set_receivers([rx] * 256)                                      # 8 bits: 64 in all
-    with pytest.raises(_lib.RtsError) as e:
-        tr.set_receivers([rx] * 257)
-    assert e.value.code == _lib.RTS_ERR_UNSUPPORTED
+def test_wide_aggregation_keys_on_a_traced_scene(rts, oracle, scenes):
+    """16 bounces among 9 targets: 16 x 4 + 1 = 65 key bits, one more than a 64-bit sort holds.  The device group table and
+    the responses derived from it equal the literal O(R^2) aggregation of the oracle's rays"""
+    spec = scenes.config_multi(W=16, max_refl=16)
+    extra = []
+    for k in range(6):
+        v, t, n = scenes.plate_mesh(3.0 + k)
+        extra.append(dict(tris=t, verts=v, normals=n, refl_coeff=0.85, refr_index=1.0))
+    spec["meshes"] = spec["meshes"] + extra
+    spec["motion"] = spec["motion"] + [dict(position=(6.0 + 3.0 * k, 12.0 - 5.0 * k, -3.0 + k), velocity=(0.0, 1.0 * k, 0.0)) for k in range(6)]
+    n = spec["W"] ** 3; wl = spec["c"] / spec["carrier"]
+    tr, st, o, g = full_parity(rts, oracle, spec)
+    tr.finalise_uniform(None, wl, 1.0, 1.0, spec["carrier"], spec["c"])
+    groups = tr.aggregate(spec["c"], spec["carrier"])
+    ag = tr.aggregated()
+    rx, rxi, _ = oracle.filter_finalise(o["results"], o["path"], [1.0] * 9, wl, 1.0, 1.0, spec["carrier"], spec["c"])
+    lit = oracle.aggregate_literal(rx, rxi, spec["c"], spec["carrier"], n)
+    assert np.array_equal(ag["pathMatch"], lit["pathMatch"])
+    np.testing.assert_allclose(ag["results"]["power"], lit["results"]["power"], rtol=1e-11)
+    np.testing.assert_allclose(ag["delay"], lit["delay"], rtol=1e-12)
+    uniq = oracle.unique_paths(lit["pathMatch"])
+    resp = rts.groups_to_responses(groups)
+    assert np.array_equal(resp["ray"].astype(np.int64), uniq.astype(np.int64)) and len(uniq) > 3
+    # the host copy of the table carries the groups' paths (decoded from the rays, not from a 64-bit key)
+    first = {int(gr["min_ray"]): gr for gr in groups}
+    for u in uniq[:50]:
+        if int(u) in first and not first[int(u)]["direct"]:
+            assert np.array_equal(first[int(u)]["path"][:16], rxi[u])
     tr.close()
 
 
