@@ -116,6 +116,14 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
     // alone kept the return path 87 % busy (5.3 M loads, counters of tools/trace_bench.py c3nomesh).
     __shared__ __attribute__((aligned(16))) RtsLaunchConsts s_lc;
     __shared__ __attribute__((aligned(16))) RtsRxDev s_rx[RTS_RX_LDS];
+    // Payload that the traversal loop does not touch lives in LDS, entry-major like the stack (lane `tid` owns element
+    // k * RTS_BLOCK + tid: conflict-free 8-byte accesses): the first hit point, the two path words and the per-lane
+    // counters -- 13 dwords per lane that the register allocator otherwise carried through the walk (128-VGPR budget at
+    // four waves per SIMD) by spilling to scratch.  They are touched per SHADED hit and at write-back only.
+    __shared__ __attribute__((aligned(16))) double s_first[3 * RTS_BLOCK];
+    __shared__ __attribute__((aligned(16))) unsigned long long s_path[2 * RTS_BLOCK];
+    __shared__ uint32_t s_n[3 * RTS_BLOCK];                      // segments, shaded hits, stack entries spilled (per lane)
+    s_n[threadIdx.x] = 0; s_n[RTS_BLOCK + threadIdx.x] = 0; s_n[2 * RTS_BLOCK + threadIdx.x] = 0;
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(a.lc); uint32_t* dst = reinterpret_cast<uint32_t*>(&s_lc);
         for (uint32_t i = threadIdx.x; i < sizeof(RtsLaunchConsts) / 4; i += RTS_BLOCK) dst[i] = src[i];
@@ -126,7 +134,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
     __syncthreads();
     const RtsLaunchConsts& lc = s_lc;
     const dvec3 origin = mk3(lc.ox, lc.oy, lc.oz);
-    unsigned long long n_seg = 0, n_shaded = 0, n_nodes = 0, n_tris = 0, n_spill = 0;
+    unsigned long long n_nodes = 0, n_tris = 0;                  // counting build only
     bool hard_overflow = false;
     const uint32_t max_refr = REFR ? 2u : 0u;
     const uint32_t D = a.max_refl + max_refr;
@@ -143,7 +151,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
     // counter keeps same-address atomics (~10 ns each) off the critical path: 157 k fetches over 64 addresses.
     const uint32_t n_tiles = (a.n_rays + 63u) / 64u;
     const uint32_t lane = tid & 63u;
-    const uint32_t stripe = (blockIdx.x * (RTS_BLOCK / 64u) + (tid >> 6)) % RTS_TILE_CTRS;
+    const uint32_t stripe = __builtin_amdgcn_readfirstlane((blockIdx.x * (RTS_BLOCK / 64u) + (tid >> 6)) % RTS_TILE_CTRS);   // wave-uniform: the queue arithmetic below stays scalar
     // Draw schedule of a stripe (positions k*C + stripe, k = 0, 1, ...): the first quarter -- the expensive end of the
     // order -- one tile per draw, the cheap rest four tiles per draw (a miss-only tile is ~7 us of work, a draw ~2 us of
     // latency).  The next draw is issued before the current tiles are traced, so its latency hides behind them.
@@ -171,33 +179,37 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
       uint32_t pending = 0;                   // bit k: chain k has been spawned
       uint32_t refr_code0 = 0;                // (target + 1) of chain 0's refraction, for the path prefill of rows >= 3
       for (uint32_t chain = 0; chain < (REFR ? 3u : 1u); chain++) {
-        dvec3 dir, prev, first;
+        dvec3 dir, prev;
         double rayLength, power, doppler, refx = 1, refy = 1;
         uint32_t reflDepth = 0, refrDepth = 0;
         int received = -1;
         bool end = false;
-        uint64_t path_lo = 0, path_hi = 0;
         if (chain == 0) {
             // ------------------------------------------------------------ ray_generation + payload, ray_tracer.cu:144-224
             dir = rts_primary_dir(lc, slot);
-            prev = origin; first = mk3(0.0, 0.0, 0.0);
+            prev = origin;
+            s_first[tid] = 0.0; s_first[RTS_BLOCK + tid] = 0.0; s_first[2 * RTS_BLOCK + tid] = 0.0;
+            s_path[tid] = 0ULL; s_path[RTS_BLOCK + tid] = 0ULL;
             rayLength = 0; power = 0; doppler = 0;
         } else {
             if (!REFR || !(pending & (1u << chain))) continue;
             const RtsChildState cs = a.child[(size_t)(chain - 1) * a.total_threads + gtid];
             dir = mk3((double)cs.dx, (double)cs.dy, (double)cs.dz);          // prd_refr.rayDirection = widened f32 refract() result (:252)
-            prev = mk3(cs.prevx, cs.prevy, cs.prevz); first = mk3(cs.firstx, cs.firsty, cs.firstz);
+            prev = mk3(cs.prevx, cs.prevy, cs.prevz);
+            s_first[tid] = cs.firstx; s_first[RTS_BLOCK + tid] = cs.firsty; s_first[2 * RTS_BLOCK + tid] = cs.firstz;
             rayLength = cs.rayLength; power = cs.power; doppler = cs.doppler; refx = cs.refx; refy = cs.refy;
             refrDepth = cs.refrDepth; end = cs.end != 0;
             // path prefill by the FIRST refraction (:221-239): row W^3 gets every column, row 2 W^3 columns 0..1
             const uint64_t code = cs.refr_code;
+            uint64_t path_lo = 0, path_hi = 0;
             for (uint32_t col = 0; col < (chain == 1 ? D : 2u); col++) { if (col < 8) path_lo |= code << (8 * col); else path_hi |= code << (8 * (col - 8)); }
+            s_path[tid] = path_lo; s_path[RTS_BLOCK + tid] = path_hi;
         }
         bool chain_start = true;               // first segment of this chain: incident epsilon, f32 direction rule below
 
         for (;;) {
             // ------------------------------------------------------------ rtTrace: closest hit over the targets' hierarchies
-            n_seg++;
+            atomicAdd(&s_n[tid], 1u);                                          // (ds_add_u32, no return)
             const float tmin = chain_start ? SCENE_EPS : SCENE_EPS_R;          // ray_tracer.cu:209, normal_shader.cu:242,297
             float best_t = RTS_DEFAULT_TMAX;
             int best_leaf = -1; uint32_t best_prim = 0xffffffffu;
@@ -279,7 +291,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
                                 node = go ? c0 : below; sp -= go ? 0 : 1;
                             } else {
 #define RTS_PUSH(cv) { if (sp < lds_cap) s_stack[sp * RTS_BLOCK + tid] = (cv); \
-                       else if (sp < lds_cap + RTS_STACK_OVF) { a.stack_ovf[(size_t)(sp - lds_cap) * a.total_threads + gtid] = (cv); n_spill++; } \
+                       else if (sp < lds_cap + RTS_STACK_OVF) { a.stack_ovf[(size_t)(sp - lds_cap) * a.total_threads + gtid] = (cv); atomicAdd(&s_n[2 * RTS_BLOCK + tid], 1u); } \
                        else hard_overflow = true; \
                        if (sp < lds_cap + RTS_STACK_OVF) sp++; }
                                 if (d3 < INF) RTS_PUSH(c3)
@@ -292,11 +304,11 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
                         } else {
                             const int leaf = ~node;
                             RtsLeafTri L;
-#define RTS_D(lo, hi) __hiloint2double((int)(hi), (int)(lo))
-                            L.p0x = RTS_D(q0.x, q0.y); L.p0y = RTS_D(q0.z, q0.w); L.p0z = RTS_D(q1.x, q1.y); L.p1x = RTS_D(q1.z, q1.w);
-                            L.p1y = RTS_D(q2.x, q2.y); L.p1z = RTS_D(q2.z, q2.w); L.p2x = RTS_D(q3.x, q3.y); L.p2y = RTS_D(q3.z, q3.w);
-                            L.p2z = RTS_D(q4.x, q4.y); L.prim = q4.z; L.targ = q4.w;
-#undef RTS_D
+#define RTS_F64(lo, hi) __hiloint2double((int)(hi), (int)(lo))
+                            L.p0x = RTS_F64(q0.x, q0.y); L.p0y = RTS_F64(q0.z, q0.w); L.p0z = RTS_F64(q1.x, q1.y); L.p1x = RTS_F64(q1.z, q1.w);
+                            L.p1y = RTS_F64(q2.x, q2.y); L.p1z = RTS_F64(q2.z, q2.w); L.p2x = RTS_F64(q3.x, q3.y); L.p2y = RTS_F64(q3.z, q3.w);
+                            L.p2z = RTS_F64(q4.x, q4.y); L.prim = q4.z; L.targ = q4.w;
+#undef RTS_F64
                             if (COUNT) n_tris++;
                             const TriHit h = tri_test(L, prev, dir, tmin, RTS_DEFAULT_TMAX);
                             if (h.ok) {
@@ -395,23 +407,24 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
 
             // ------------------------------------------------------------ closest_hit, normal_shader.cu:128-340
             if (!((end == false) && ((refrDepth < max_refr) || (reflDepth < a.max_refl)))) break;   // gate :134 ; absorbed hit leaves the payload untouched
-            n_shaded++;
+            atomicAdd(&s_n[RTS_BLOCK + tid], 1u);
             const RtsLeafTri L = a.leaves[best_leaf];
             const RtsTargetDev T = a.targets[L.targ];
             if (refrDepth != 1) {                                              // path column (:140-146)
                 const uint32_t col = reflDepth + refrDepth;
                 if (col < D) {
                     const uint64_t code = (uint64_t)(L.targ + 1);
-                    if (col < 8) path_lo = (path_lo & ~(0xffULL << (8 * col))) | (code << (8 * col));
-                    else path_hi = (path_hi & ~(0xffULL << (8 * (col - 8)))) | (code << (8 * (col - 8)));
+                    unsigned long long* pw = &s_path[(col < 8 ? 0 : RTS_BLOCK) + tid];
+                    const uint32_t sh = 8 * (col & 7u);
+                    *pw = (*pw & ~(0xffULL << sh)) | (code << sh);
                 }
             }
             const float hit_t = best_t;
             const dvec3 hitPoint = mk3(prev.x + (double)hit_t*dir.x, prev.y + (double)hit_t*dir.y, prev.z + (double)hit_t*dir.z);   // :149-152
             rayLength += hit_t;                                                // :153
             if ((reflDepth == 0) && (refrDepth == 0)) {                        // :159-166
-                first = hitPoint;
-                const dvec3 TxRange = sub3(first, origin);
+                s_first[tid] = hitPoint.x; s_first[RTS_BLOCK + tid] = hitPoint.y; s_first[2 * RTS_BLOCK + tid] = hitPoint.z;
+                const dvec3 TxRange = sub3(hitPoint, origin);
                 if (len3(TxRange) >= SCENE_EPS) power = 1/((magsq3(TxRange))*4*RTS_PI);
                 else end = true;
             } else {                                                           // :167-173
@@ -451,7 +464,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
                     fvec3 rd;
                     if (refract3f(rd, dirf, nf, ratio)) {                      // :212
                         RtsChildState cs;
-                        cs.prevx = prev.x; cs.prevy = prev.y; cs.prevz = prev.z; cs.firstx = first.x; cs.firsty = first.y; cs.firstz = first.z;
+                        cs.prevx = prev.x; cs.prevy = prev.y; cs.prevz = prev.z; cs.firstx = s_first[tid]; cs.firsty = s_first[RTS_BLOCK + tid]; cs.firstz = s_first[2 * RTS_BLOCK + tid];
                         cs.rayLength = rayLength; cs.refx = rrefx; cs.refy = rrefy; cs.end = end ? 1u : 0u;
                         double cpower = power;
                         if ((reflDepth + 1) < (a.max_refl + 1)) cpower *= (1 - fabs(T.reflCoeff));   // :245-246
@@ -462,7 +475,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
                         const dvec3 k1 = unit3(nd3);
                         cs.doppler = doppler + dot3(mk3(T.vx, T.vy, T.vz), sub3(k1, k0));
                         cs.dx = rd.x; cs.dy = rd.y; cs.dz = rd.z;
-                        cs.refr_code = (chain == 0) ? (L.targ + 1) : (uint32_t)((path_lo) & 0xff);   // prefill code travels with the first refraction only
+                        cs.refr_code = (chain == 0) ? (L.targ + 1) : (uint32_t)(s_path[tid] & 0xff);   // prefill code travels with the first refraction only
                         if (chain == 0) refr_code0 = L.targ + 1;
                         a.child[(size_t)chain * a.total_threads + gtid] = cs;
                         pending |= 1u << (chain + 1);
@@ -495,8 +508,8 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
             RtsEndRecord r;
             r.rayLength = rayLength; r.power = power; r.doppler = doppler;
             r.prevx = prev.x; r.prevy = prev.y; r.prevz = prev.z;
-            r.firstx = first.x; r.firsty = first.y; r.firstz = first.z;
-            r.path_lo = path_lo; r.path_hi = path_hi; r.slot = slot; r.received = received; r.reflDepth = reflDepth;
+            r.firstx = s_first[tid]; r.firsty = s_first[RTS_BLOCK + tid]; r.firstz = s_first[2 * RTS_BLOCK + tid];
+            r.path_lo = s_path[tid]; r.path_hi = s_path[RTS_BLOCK + tid]; r.slot = slot; r.received = received; r.reflDepth = reflDepth;
             r.pad = chain | (refrDepth << 2) | ((chain == 0 ? refr_code0 : 0u) << 8) | ((pending & 6u) << 15);   // chain, refrDepth, prefill code, spawned children
             if (KEEP_ALL) a.all_records[(size_t)chain * a.n_rays + slot] = r;
             if (recv) {
@@ -519,6 +532,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
     // ------------------------------------------------------------------ counters: wave reduce -> block reduce (LDS, the
     // traversal stack is dead by now) -> one plain store per block; k_sum_counters adds the blocks up.  (One atomic per
     // wave on the same two addresses -- 32 k same-line L2 atomics -- cost a fixed ~0.35 ms at the tail of every launch.)
+    unsigned long long n_seg = s_n[tid], n_shaded = s_n[RTS_BLOCK + tid], n_spill = s_n[2 * RTS_BLOCK + tid];
     for (int off = 32; off > 0; off >>= 1) {
         n_seg += __shfl_down(n_seg, off); n_shaded += __shfl_down(n_shaded, off);
         if (COUNT) { n_nodes += __shfl_down(n_nodes, off); n_tris += __shfl_down(n_tris, off); }
