@@ -75,6 +75,7 @@ static_assert(sizeof(RtsChildState) == 128, "child state size");
 #define RTS_BLOCK 256
 #define RTS_WTILE 64               // work unit of the trace kernel: launch indices per wave tile
 #define RTS_TILE_CTRS 64           // striped draw counters of the tile queue
+#define RTS_TILE_CTR_STRIDE 32     // ... one per 128-byte line: same-LINE atomics serialise in L2 (~10 ns each) whatever their address
 #define RTS_STACK_LDS 24            // traversal stack entries kept in LDS per lane
 #define RTS_RX_LDS 16               // receivers whose capture spheres the trace kernel keeps in LDS (the rest are read from memory)
 #define RTS_STACK_OVF 128           // further entries spilled to global memory (rare); a BVH4 node pushes up to 3 entries
@@ -121,7 +122,7 @@ struct RtsTraceArgs {
     uint32_t total_threads;
     const uint32_t* tile_order;     // [wave tiles] tile ids in descending order of the cost last seen by the handle (null: identity)
     uint32_t* tile_cost;            // [wave tiles] out: duration of the tile (shader clocks >> 6, + 1)
-    uint32_t* tile_ctr;             // [RTS_TILE_CTRS] draw counters, zero at launch
+    uint32_t* tile_ctr;             // [RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE] draw counters (element s * STRIDE), zero at launch
     unsigned long long* timeline;   // debug (RTS_TIMELINE, counting build): [grid][2] block start/end ticks, then [tiles] tile durations (100 MHz)
     uint32_t stack_lds;             // LDS stack entries in use (RTS_STACK_LDS; smaller only to exercise the spill path in tests)
 };

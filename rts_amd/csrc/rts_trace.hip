@@ -158,13 +158,13 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
     const uint32_t per_stripe = (n_tiles + RTS_TILE_CTRS - 1u) / RTS_TILE_CTRS;
     const uint32_t single_draws = per_stripe >= 1024u ? per_stripe / 4u : per_stripe;      // (short queues: one tile per draw throughout)
     uint32_t draw_next = 0;
-    if (lane == 0) draw_next = atomicAdd(&a.tile_ctr[stripe], 1u);
+    if (lane == 0) draw_next = atomicAdd(&a.tile_ctr[stripe * RTS_TILE_CTR_STRIDE], 1u);
     for (;;) {
       const uint32_t draw = __builtin_amdgcn_readfirstlane(draw_next);
       const uint32_t k0 = draw < single_draws ? draw : single_draws + 4u * (draw - single_draws);
       const uint32_t kn = draw < single_draws ? 1u : 4u;
       if (k0 >= per_stripe) break;
-      if (lane == 0) draw_next = atomicAdd(&a.tile_ctr[stripe], 1u);
+      if (lane == 0) draw_next = atomicAdd(&a.tile_ctr[stripe * RTS_TILE_CTR_STRIDE], 1u);
      for (uint32_t kb = 0; kb < kn; kb++) {
       const uint64_t tpos64 = (uint64_t)(k0 + kb) * RTS_TILE_CTRS + stripe;
       if (tpos64 >= n_tiles) break;
