@@ -57,6 +57,11 @@ typedef struct RtsParams {
                                      hierarchy, bottom-up boxes, 4-wide collapse) instead of the host SAH builder: set-up in
                                      milliseconds, traversal a little slower; same node format, same results (the f64 triangle
                                      test alone decides hits).  The environment variable RTS_BUILDER=device|host overrides. */
+#define RTS_FLAG_NO_PREFILTER 8u   /* primary rays skip the conservative f32 pre-filter (direction mask over the placed triangles +
+                                     widened receiver spheres) that lets rays which can meet nothing bypass the exact ray
+                                     generation and the walk.  Results are identical either way (tested); the filter also switches
+                                     itself off while more than half of a handle's launch indices hit.  RTS_PRIMARY_MASK=0 does the
+                                     same from the environment. */
 #define RTS_FLAG_COUNT_TRAVERSAL 2u /* run the counting build of the trace kernel (node visits and
                                      triangle tests per segment, for the roofline accounting)        */
 

@@ -18,6 +18,7 @@
 #include <string>
 #include <thread>
 #include "rts_internal.h"
+#include "rts_raygen.h"
 
 static thread_local char g_err[1024] = "";
 void rts_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap); }
@@ -81,6 +82,8 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     hipDeviceProp_t prop; e = hipGetDeviceProperties(&prop, p->device);
     if (e != hipSuccess) { delete c; rts_set_error("hipGetDeviceProperties: %s", hipGetErrorString(e)); return RTS_ERR_HIP; }
     c->n_cu = prop.multiProcessorCount;
+    { const char* e = getenv("RTS_PRIMARY_MASK"); if (e && e[0] == '0') c->use_pmask = false; }            // experiments / tests: no primary-ray pre-filter
+    if (p->flags & RTS_FLAG_NO_PREFILTER) c->use_pmask = false;
     // experiment / test knobs, read ONCE PER HANDLE at creation (never per process: two handles of one process may differ)
     { const char* e = getenv("RTS_GRID_MULT"); if (e) c->grid_mult = std::max(1, atoi(e)); }
     { const char* e = getenv("RTS_GRID_SPARE"); if (e) c->grid_spare = std::max(0, atoi(e)); }
@@ -101,7 +104,7 @@ extern "C" int rts_destroy(RtsHandle c)
     c->d_verts_world.release(); c->d_normals_world.release();
     c->d_motion.release(); c->d_targets.release();
     c->d_leaves.release(); c->d_sort_tmp.release(); c->d_rx.release(); c->d_recv.release(); c->d_all.release();
-    c->d_counters.release(); c->d_block_counters.release(); c->d_timeline.release(); c->d_tile_cost.release(); c->d_tile_key.release(); c->d_tile_key_sorted.release(); c->d_tile_id.release(); c->d_tile_order.release(); c->d_tile_hist.release(); c->d_tile_ctr.release(); c->d_lc.release(); c->d_dir_hist.release(); c->d_child.release(); c->d_rk64.release(); c->d_rk64_sorted.release(); c->d_hit_prim.release(); c->d_hit_t.release(); c->d_stack_ovf.release();
+    c->d_counters.release(); c->d_block_counters.release(); c->d_timeline.release(); c->d_tile_cost.release(); c->d_tile_key.release(); c->d_tile_key_sorted.release(); c->d_tile_id.release(); c->d_tile_order.release(); c->d_tile_hist.release(); c->d_tile_ctr.release(); c->d_lc.release(); c->d_dir_hist.release(); c->d_pmask.release(); c->d_child.release(); c->d_rk64.release(); c->d_rk64_sorted.release(); c->d_hit_prim.release(); c->d_hit_t.release(); c->d_stack_ovf.release();
     c->d_rk.release(); c->d_rk_sorted.release(); c->d_ri.release(); c->d_ri_sorted.release(); c->d_rx_rays.release(); c->d_rx_paths.release();
     c->d_rx_angles.release(); c->d_rx_slots.release(); c->d_all_rays.release(); c->d_all_paths.release(); c->d_all_angles.release();
     c->d_akeys.release(); c->d_akeys_sorted.release(); c->d_aidx.release(); c->d_aidx_sorted.release(); c->d_ghead.release(); c->d_gid.release();
@@ -351,6 +354,40 @@ static void fill_launch_constants(RtsLaunchConsts& a, const RtsPulse& p, uint32_
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) a.rot1[3*i + j] = Rot1[i][j];
 }
 
+// Frame and extent of the primary-ray mask (RtsMaskFrame): b = direction of the beam's middle, (u, v) an orthonormal complement;
+// the directions of a launch are the central projection of the (convex) lattice box, so the perspective coordinates of its
+// eight corners bound those of every ray.
+static void fill_mask_frame(RtsLaunchConsts& a, bool enable)
+{
+    RtsMaskFrame& f = a.mask; memset(&f, 0, sizeof(f));
+    if (!enable || a.W < 2) return;
+    dvec3 c[8]; dvec3 sum = mk3(0, 0, 0);
+    for (int k = 0; k < 8; k++) {
+        c[k] = rts_lattice_dir(a, (k & 1) ? a.W - 1 : 0, (k & 2) ? a.W - 1 : 0, (k & 4) ? a.W - 1 : 0);
+        const double n = len3(c[k]); if (!(n > 0) || !std::isfinite(n)) return;
+        c[k] = mk3(c[k].x / n, c[k].y / n, c[k].z / n); sum = add3(sum, c[k]);
+    }
+    const double sn = len3(sum); if (!(sn > 1e-6)) return;
+    const dvec3 b = mk3(sum.x / sn, sum.y / sn, sum.z / sn);
+    dvec3 ref = std::fabs(b.z) < 0.9 ? mk3(0, 0, 1) : mk3(1, 0, 0);
+    dvec3 u = cross3(ref, b); const double un = len3(u); u = mk3(u.x / un, u.y / un, u.z / un);
+    const dvec3 v = cross3(b, u);
+    double u0 = 1e300, u1 = -1e300, v0 = 1e300, v1 = -1e300;
+    for (int k = 0; k < 8; k++) {
+        const double w = dot3(c[k], b); if (!(w > 0.5)) return;                  // beam wider than ~120 degrees: no mask
+        const double uu = dot3(c[k], u) / w, vv = dot3(c[k], v) / w;
+        u0 = std::min(u0, uu); u1 = std::max(u1, uu); v0 = std::min(v0, vv); v1 = std::max(v1, vv);
+    }
+    const double du = std::max(u1 - u0, 1e-9), dv = std::max(v1 - v0, 1e-9);
+    u0 -= 0.002 * du; u1 += 0.002 * du; v0 -= 0.002 * dv; v1 += 0.002 * dv;   // rays exactly on the rim stay inside the bitmap
+    f.bx = (float)b.x; f.by = (float)b.y; f.bz = (float)b.z; f.ux = (float)u.x; f.uy = (float)u.y; f.uz = (float)u.z; f.vx = (float)v.x; f.vy = (float)v.y; f.vz = (float)v.z;
+    const double n_fit = std::floor(std::min(u1 - u0, v1 - v0) / RTS_MASK_MIN_CELL);
+    if (!(n_fit >= 32.0)) return;                                                // beam narrower than 32 cells of the minimum size: no mask
+    const uint32_t n = (uint32_t)std::min<double>(RTS_MASK_N, n_fit) & ~31u;     // whole 32-bit words per row
+    f.u0 = (float)u0; f.v0 = (float)v0; f.inv_du = (float)(n / (u1 - u0)); f.inv_dv = (float)(n / (v1 - v0));
+    f.n = n;
+}
+
 // Per-target placement constants of a pulse: inverse rotation, world bounds of the placed hierarchy, error slack.
 static int fill_target_placement(const RtsContext* c, uint32_t t, RtsTargetDev& td)
 {
@@ -504,6 +541,11 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     RtsLaunchConsts& lc = c->last_lc; memset(&lc, 0, sizeof(lc));
     fill_launch_constants(lc, *p, W);
     lc.ray_first = first; lc.W = W; lc.il_tile = il_tile; lc.il_parts = il_parts; lc.il_part = il_part;
+    const bool pre_filter = c->use_pmask && !c->pre_dense;           // (a launch where most rays hit pays for the filter and skips nothing)
+    fill_mask_frame(lc, pre_filter && c->scene->n_prims > 0);
+    for (int k = 0; k < 3; k++) { lc.f_bs[k] = (float)(&lc.bsx)[k]; lc.f_st[k] = (float)(&lc.stx)[k]; }
+    for (int k = 0; k < 9; k++) { lc.f_rot[k] = (float)lc.rot[k]; lc.f_rot1[k] = (float)lc.rot1[k]; }
+    { int rc = rts_primary_mask_build(c, lc); if (rc != RTS_OK) return rc; }
     RTS_HIP(c->d_lc.reserve(1));
     c->pin->lc = lc;
     RTS_HIP(hipMemcpyAsync(c->d_lc.p, &c->pin->lc, sizeof(lc), hipMemcpyHostToDevice, st));
@@ -525,6 +567,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
         RTS_HIP(hipMemsetAsync(c->d_hit_t.p, 0, sizeof(float) * (size_t)n * (c->params.max_refl + 1), st));
     }
     RTS_HIP(hipMemsetAsync(c->d_counters.p, 0, sizeof(unsigned long long) * 16, st));
+    a.pmask = lc.mask.n ? c->d_pmask.p : nullptr; a.pre_filter = pre_filter ? 1u : 0u;
     a.nodes4 = c->scene->d_nodes4.p; a.stack_lds = c->stack_lds; a.leaves = c->d_leaves.p; a.tri_nidx = c->scene->d_tri_nidx.p; a.normals = c->d_normals_world.p;
     a.targets = c->d_targets.p; a.rx = c->d_rx.p;
     a.recv_records = c->d_recv.p; a.all_records = c->d_all.p; a.counters = c->d_counters.p; a.block_counters = c->d_block_counters.p; a.dir_hist = c->d_dir_hist.p;
@@ -602,6 +645,7 @@ extern "C" int rts_trace_pulse_end(RtsHandle c)
     RtsStats& s = c->stats;
     s.rays = n; s.segments = cnt[1]; s.shaded = cnt[2]; s.received = cnt[0]; s.node_visits = cnt[3]; s.tri_tests = cnt[4]; s.stack_overflows = (uint32_t)cnt[5];
     s.n_prims = c->scene->n_prims; s.n_nodes = c->scene->n_nodes;
+    c->pre_dense = 2 * s.shaded > (uint64_t)n;                      // next launch of this handle: pre-filter only if most launch indices hit nothing
     s.ms_scene = s.ms_trace = s.ms_compact = s.ms_aggregate = 0;
     c->stats_pending = true; c->agg_timed = false; c->fin_timed = false;
     return RTS_OK;

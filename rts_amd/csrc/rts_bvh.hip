@@ -49,7 +49,56 @@ __global__ void k_leaves(const uint32_t* __restrict__ leaf_prim, const uint32_t*
     leaves[i] = L;
 }
 
+// --------------------------------------------------------------------------- primary-ray mask (see RtsMaskFrame)
+__global__ void k_primary_mask(const uint32_t* __restrict__ tri_vidx, const double* __restrict__ verts, uint32_t n_prims, double ox, double oy, double oz,
+                               RtsMaskFrame f, uint32_t* __restrict__ mask)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_prims) return;
+    uint32_t* flag = mask + (size_t)f.n * f.n / 32u;
+    double u[3], v[3]; bool finite = true, front = true;
+    for (int k = 0; k < 3; k++) {
+        const uint32_t a = tri_vidx[3*(size_t)i + k];
+        const double px = verts[3*(size_t)a] - ox, py = verts[3*(size_t)a + 1] - oy, pz = verts[3*(size_t)a + 2] - oz;
+        finite = finite && isfinite(px) && isfinite(py) && isfinite(pz);
+        const double w = px * (double)f.bx + py * (double)f.by + pz * (double)f.bz;
+        const double r = sqrt(px*px + py*py + pz*pz);
+        front = front && (w > 1.0e-3 * r);                          // well in front of the transmitter (within ~89.94 degrees of the boresight)
+        u[k] = (px * (double)f.ux + py * (double)f.uy + pz * (double)f.uz) / w;
+        v[k] = (px * (double)f.vx + py * (double)f.vy + pz * (double)f.vz) / w;
+    }
+    if (!finite) return;                                            // never hit (no leaf either)
+    if (!front) { atomicExch(flag, 1u); return; }                   // its projection is not a triangle: no mask for this pulse
+    const double fu0 = (fmin(fmin(u[0], u[1]), u[2]) - (double)f.u0) * (double)f.inv_du, fu1 = (fmax(fmax(u[0], u[1]), u[2]) - (double)f.u0) * (double)f.inv_du;
+    const double fv0 = (fmin(fmin(v[0], v[1]), v[2]) - (double)f.v0) * (double)f.inv_dv, fv1 = (fmax(fmax(v[0], v[1]), v[2]) - (double)f.v0) * (double)f.inv_dv;
+    const double nn = (double)f.n;
+    if (fu1 < -1.0 || fv1 < -1.0 || fu0 > nn || fv0 > nn) return;  // outside the beam
+    const int iu0 = (int)fmax(floor(fu0) - 1.0, 0.0), iu1 = (int)fmin(floor(fu1) + 1.0, nn - 1.0);
+    const int iv0 = (int)fmax(floor(fv0) - 1.0, 0.0), iv1 = (int)fmin(floor(fv1) + 1.0, nn - 1.0);
+    if ((long long)(iu1 - iu0 + 1) * (long long)(iv1 - iv0 + 1) > RTS_MASK_MAX_CELLS) { atomicExch(flag, 1u); return; }
+    for (int iv = iv0; iv <= iv1; iv++) {
+        for (int w0 = iu0 >> 5; w0 <= (iu1 >> 5); w0++) {           // one atomic per touched word of the row
+            const int lo = max(iu0, w0 << 5) & 31, hi = min(iu1, (w0 << 5) + 31) & 31;
+            const uint32_t bits = (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+            atomicOr(&mask[((size_t)iv * f.n >> 5) + (size_t)w0], bits);
+        }
+    }
+}
+
 static inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+
+int rts_primary_mask_build(RtsContext* c, const RtsLaunchConsts& lc)
+{
+    const RtsMaskFrame& f = lc.mask;
+    if (f.n == 0 || c->scene->n_prims == 0) return RTS_OK;
+    hipStream_t st = c->stream;
+    const size_t words = (size_t)f.n * f.n / 32u + 1u;
+    RTS_HIP(c->d_pmask.reserve(words));
+    RTS_HIP(hipMemsetAsync(c->d_pmask.p, 0, sizeof(uint32_t) * words, st));
+    k_primary_mask<<<blocks_for(c->scene->n_prims, 256), 256, 0, st>>>(c->scene->d_tri_vidx.p, c->d_verts_world.p, c->scene->n_prims, lc.ox, lc.oy, lc.oz, f, c->d_pmask.p);
+    RTS_HIP(hipGetLastError());
+    return RTS_OK;
+}
 
 int rts_scene_place(RtsContext* c)
 {

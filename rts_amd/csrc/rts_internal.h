@@ -83,6 +83,29 @@ static_assert(sizeof(RtsChildState) == 128, "child state size");
 // Launch constants of ray_generation (hoisted trig, ray_tracer.cu:155-203).  Device resident and
 // read through a pointer: keeping these 30 doubles as by-value kernel arguments pinned ~60
 // SGPRs for the whole kernel (SGPR spills to VGPR lanes).
+// Primary-ray pre-filter and mask.  A primary ray that meets no triangle and no receiver sphere leaves NO trace in any output
+// (not even with RTS_FLAG_KEEP_ALL_RAYS: its record is the initial payload, whatever its direction), and on C3 that is 84 % of
+// the launch indices.  For those the exact f64 ray generation (two normalisations: a square root and three divisions each),
+// the bounding-sphere tests, the target mapping, the root visits and the receiver quadratics buy nothing.  The trace kernel
+// therefore first forms the direction in f32 (good to ~2e-6 rad) and asks two CONSERVATIVE questions -- is any triangle's
+// projection near this direction (the mask below), can the ray come within a widened radius of a receiver sphere -- and only
+// a ray that may hit something gets the exact treatment (everything a ray can be observed through is still computed exactly
+// as before: the pre-filter can only say "certainly nothing").
+// The mask: all primary rays of a launch start at the transmitter, so which of them CAN meet a triangle is a question
+// about their direction alone.  Per pulse every placed triangle marks the cells of a 2-D bitmap over the beam -- perspective
+// coordinates (p.u / p.b, p.v / p.b) of p = vertex - origin in a frame (b, u, v) around the boresight -- that the bounding
+// rectangle of its projection touches (k_primary_mask, rts_bvh.hip); a primary ray whose own cell is clear skips the targets
+// altogether (bounding spheres, target mapping, slab set-up, root visits: about half the instructions of a launch index that
+// hits nothing -- 84 % of them on C3).  Conservative: a ray that hits a triangle has its direction inside the triangle's
+// projection, hence inside the rectangle; the rectangle is widened by a cell, the ray's f32 coordinates are good to 1e-6 of the
+// extent.  Disabled for the pulse (n = 0 / flag set) when a vertex is not in front of the transmitter, when a single triangle
+// would cover more than RTS_MASK_MAX_CELLS cells, for W = 1 and for beams wider than ~120 degrees.  Cells are never finer than
+// RTS_MASK_MIN_CELL (tangent units = radians): the f32 direction of the pre-filter must stay inside the one-cell margin.
+#define RTS_MASK_MIN_CELL 1.0e-5
+#define RTS_MASK_N 1024u
+#define RTS_MASK_MAX_CELLS 4096
+struct RtsMaskFrame { float bx, by, bz, ux, uy, uz, vx, vy, vz; float u0, v0, inv_du, inv_dv; uint32_t n, pad0, pad1; };
+
 struct RtsLaunchConsts {
     double ox, oy, oz;              // d_rayOrigin
     double bsx, bsy, bsz;           // beamStart
@@ -93,7 +116,11 @@ struct RtsLaunchConsts {
     uint64_t ray_first;
     uint32_t W, pad;
     uint32_t il_tile, il_parts, il_part, pad2;     // interleaved tiles (il_parts <= 1: contiguous)
+    RtsMaskFrame mask;              // primary-ray mask frame (n = 0: no mask this launch)
+    // f32 copies for the primary-ray PRE-FILTER (rts_trace.hip): beamStart, lattice step, Rot, Rot1
+    float f_bs[3], f_st[3], f_rot[9], f_rot1[9];
 };
+static_assert(sizeof(RtsLaunchConsts) % 8 == 0, "launch constants are copied to LDS dword by dword");
 
 struct RtsTraceArgs {
     const RtsLaunchConsts* lc;      // device copy of the launch constants
@@ -124,6 +151,8 @@ struct RtsTraceArgs {
     uint32_t* tile_cost;            // [wave tiles] out: duration of the tile (shader clocks >> 6, + 1)
     uint32_t* tile_ctr;             // [RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE] draw counters (element s * STRIDE), zero at launch
     unsigned long long* timeline;   // debug (RTS_TIMELINE, counting build): [grid][2] block start/end ticks, then [tiles] tile durations (100 MHz)
+    uint32_t pre_filter;            // 1: primary rays go through the f32 pre-filter (needs the mask when there is geometry)
+    const uint32_t* pmask;          // primary-ray mask: RTS_MASK_N^2 bits, then one word != 0 if the mask is void for this pulse (null: none)
     uint32_t stack_lds;             // LDS stack entries in use (RTS_STACK_LDS; smaller only to exercise the spill path in tests)
 };
 
@@ -214,7 +243,7 @@ struct RtsContext {
     DevBuf<RtsEndRecord> d_recv, d_all; DevBuf<unsigned long long> d_counters, d_block_counters, d_timeline;
     DevBuf<uint32_t> d_tile_cost, d_tile_key, d_tile_key_sorted, d_tile_id, d_tile_order, d_tile_hist, d_tile_ctr;
     bool tile_cost_pending = false, tile_hist_any = false; uint64_t tile_cost_sig[4] = {0, 0, 0, 0}; uint32_t tile_hist_n = 0;   // per-global-tile cost history (rts_post.hip)
-    DevBuf<float> d_dir_hist;
+    DevBuf<float> d_dir_hist; DevBuf<uint32_t> d_pmask; bool use_pmask = true, pre_dense = false;
     DevBuf<int32_t> d_hit_prim; DevBuf<float> d_hit_t; DevBuf<int32_t> d_stack_ovf; DevBuf<RtsChildState> d_child;
     DevBuf<uint64_t> d_rk64, d_rk64_sorted;
     RtsTraceArgs last_args; RtsLaunchConsts last_lc; DevBuf<RtsLaunchConsts> d_lc;
@@ -238,6 +267,7 @@ struct RtsContext {
 int rts_sah_build(const double* verts, const uint32_t* tris, uint32_t n_tris, double split_budget, std::vector<RtsNode4>& nodes, std::vector<uint32_t>& leaf_prim, RtsBlasInfo& out);
 int rts_lbvh_build_device(RtsContext* c, RtsScene* ns, const std::vector<uint32_t>& vidx, const std::vector<RtsMeshHost>& mh);
 int rts_scene_place(RtsContext* c);
+int rts_primary_mask_build(RtsContext* c, const RtsLaunchConsts& lc);
 int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_valid, const uint64_t* cur_sig, uint32_t n_tiles_cur);
 int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a, bool count_traversal);
 int rts_post_order_and_expand(RtsContext* c);

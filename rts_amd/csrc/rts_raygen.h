@@ -13,13 +13,10 @@ __device__ __forceinline__ uint64_t rts_global_index(const RtsLaunchConsts& a, u
     return a.ray_first + ((uint64_t)j * a.il_parts + a.il_part) * a.il_tile + r;
 }
 
-__device__ __forceinline__ dvec3 rts_primary_dir(const RtsLaunchConsts& a, uint32_t slot)
+// direction of lattice point (lx, ly, lz); host + device: the host uses it for the extent of the primary-ray mask
+RTS_HD dvec3 rts_lattice_dir(const RtsLaunchConsts& a, uint32_t lx, uint32_t ly, uint32_t lz)
 {
     if (a.W == 1) return mk3(a.w1x, a.w1y, a.w1z);                       // ray_tracer.cu:160-161
-    // rayIndex = z*W*W + y*W + x (:151), an unsigned int in the reference and < 2^32 here (rts_create): two 32-bit
-    // divisions.  (As 64-bit % and / this was ~450 instructions per launch index -- a sixth of the whole C3 kernel.)
-    const uint32_t g = (uint32_t)rts_global_index(a, slot);
-    const uint32_t q = g / a.W, lx = g - q * a.W, lz = q / a.W, ly = q - lz * a.W;
     dvec3 v = mk3(a.bsx + a.stx * (double)lx, a.bsy + a.sty * (double)ly, a.bsz + a.stz * (double)lz);   // :167-169
     v = unit3(v);                                                         // :170
     dvec3 r;                                                              // rotated = 0; rotated += Rot*v  :178-182
@@ -32,4 +29,19 @@ __device__ __forceinline__ dvec3 rts_primary_dir(const RtsLaunchConsts& a, uint3
     dir.y = 0.0 + (a.rot1[3]*v.x + a.rot1[4]*v.y + a.rot1[5]*v.z);
     dir.z = 0.0 + (a.rot1[6]*v.x + a.rot1[7]*v.y + a.rot1[8]*v.z);
     return dir;
+}
+
+// launch index -> lattice coordinates.  rayIndex = z*W*W + y*W + x (:151), an unsigned int in the reference and < 2^32 here
+// (rts_create): two 32-bit divisions.
+__device__ __forceinline__ void rts_lattice_coords(const RtsLaunchConsts& a, uint32_t slot, uint32_t& lx, uint32_t& ly, uint32_t& lz)
+{
+    const uint32_t g = (uint32_t)rts_global_index(a, slot);
+    const uint32_t q = g / a.W; lx = g - q * a.W; lz = q / a.W; ly = q - lz * a.W;
+}
+
+__device__ __forceinline__ dvec3 rts_primary_dir(const RtsLaunchConsts& a, uint32_t slot)
+{
+    if (a.W == 1) return mk3(a.w1x, a.w1y, a.w1z);
+    uint32_t lx, ly, lz; rts_lattice_coords(a, slot, lx, ly, lz);
+    return rts_lattice_dir(a, lx, ly, lz);
 }

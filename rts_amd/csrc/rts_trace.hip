@@ -134,8 +134,24 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
     __syncthreads();
     const RtsLaunchConsts& lc = s_lc;
     const dvec3 origin = mk3(lc.ox, lc.oy, lc.oz);
+    // pre-filter constants of the receivers, for rays that start at the transmitter: q = centre - origin (f64, then f32),
+    // |q|, |q|^2 and the widened radius^2.  Widening: the f32 direction is good to ~2e-6 rad and the f32 discriminant
+    // b^2 - (|q|^2 - r^2) |d|^2 to ~1e-6 |q|^2; r'^2 = r^2 (1 + 1e-3) + 1e-5 |q|^2 + 1e-6 covers both ten times over.
+    __shared__ float s_rxp[RTS_RX_LDS][6];
+    if (tid < RTS_RX_LDS && tid < a.n_rx) {
+        const RtsRxDev r = s_rx[tid];
+        const double qx = r.cx - lc.ox, qy = r.cy - lc.oy, qz = r.cz - lc.oz, qq = qx*qx + qy*qy + qz*qz;
+        s_rxp[tid][0] = (float)qx; s_rxp[tid][1] = (float)qy; s_rxp[tid][2] = (float)qz; s_rxp[tid][3] = (float)qq * 1.000001f;
+        s_rxp[tid][4] = (float)(r.radius * r.radius * 1.001 + 1.0e-5 * qq + 1.0e-6);
+        s_rxp[tid][5] = (float)sqrt(qq);
+    }
+    __syncthreads();
     unsigned long long n_nodes = 0, n_tris = 0;                  // counting build only
     bool hard_overflow = false;
+    const bool mask_on = a.pmask != nullptr && lc.mask.n != 0 && a.pmask[(size_t)lc.mask.n * lc.mask.n / 32u] == 0u;     // (uniform) not voided by k_primary_mask
+    // the pre-filter can only pay if it can clear a ray of the targets: with geometry but no valid mask every primary needs
+    // its exact direction anyway
+    const bool pre_on = lc.W > 1 && a.n_rx <= RTS_RX_LDS && (mask_on || a.n_prims == 0) && a.pre_filter;
     const uint32_t max_refr = REFR ? 2u : 0u;
     const uint32_t D = a.max_refl + max_refr;
 
@@ -184,9 +200,37 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
         uint32_t reflDepth = 0, refrDepth = 0;
         int received = -1;
         bool end = false;
+        bool may_target = a.n_prims > 0, may_rx = a.n_rx > 0;   // (primary ray: what the pre-filter could not exclude)
         if (chain == 0) {
             // ------------------------------------------------------------ ray_generation + payload, ray_tracer.cu:144-224
-            dir = rts_primary_dir(lc, slot);
+            if (pre_on) {
+                // ray_generation in f32 (same tree, f32 constants): lattice point, normalise, Rot, normalise, Rot1
+                uint32_t lx, ly, lz; rts_lattice_coords(lc, slot, lx, ly, lz);
+                float vx = __builtin_fmaf(lc.f_st[0], (float)lx, lc.f_bs[0]), vy = __builtin_fmaf(lc.f_st[1], (float)ly, lc.f_bs[1]), vz = __builtin_fmaf(lc.f_st[2], (float)lz, lc.f_bs[2]);
+                float inv = __frsqrt_rn(vx*vx + vy*vy + vz*vz); vx *= inv; vy *= inv; vz *= inv;
+                float rx_ = lc.f_rot[0]*vx + lc.f_rot[1]*vy + lc.f_rot[2]*vz, ry_ = lc.f_rot[3]*vx + lc.f_rot[4]*vy + lc.f_rot[5]*vz, rz_ = lc.f_rot[6]*vx + lc.f_rot[7]*vy + lc.f_rot[8]*vz;
+                inv = __frsqrt_rn(rx_*rx_ + ry_*ry_ + rz_*rz_); rx_ *= inv; ry_ *= inv; rz_ *= inv;
+                const float dx = lc.f_rot1[0]*rx_ + lc.f_rot1[1]*ry_ + lc.f_rot1[2]*rz_, dy = lc.f_rot1[3]*rx_ + lc.f_rot1[4]*ry_ + lc.f_rot1[5]*rz_, dz = lc.f_rot1[6]*rx_ + lc.f_rot1[7]*ry_ + lc.f_rot1[8]*rz_;
+                if (mask_on) {                                       // is any triangle's projection near this direction? (RtsMaskFrame)
+                    const RtsMaskFrame& mf = lc.mask;
+                    const float w = dx * mf.bx + dy * mf.by + dz * mf.bz;
+                    const float fu = ((dx * mf.ux + dy * mf.uy + dz * mf.uz) / w - mf.u0) * mf.inv_du, fv = ((dx * mf.vx + dy * mf.vy + dz * mf.vz) / w - mf.v0) * mf.inv_dv;
+                    if (w > 0.0f && fu >= 0.0f && fv >= 0.0f && fu < (float)mf.n && fv < (float)mf.n) {
+                        const uint32_t cell = (uint32_t)fv * mf.n + (uint32_t)fu;
+                        may_target = ((a.pmask[cell >> 5] >> (cell & 31u)) & 1u) != 0u;
+                    }
+                }
+                may_rx = false;
+                const float dd = dx*dx + dy*dy + dz*dz;
+                for (uint32_t Rx_i = 0; Rx_i < a.n_rx; Rx_i++) {    // can the ray come within the widened radius of this receiver's sphere?
+                    const float qx = s_rxp[Rx_i][0], qy = s_rxp[Rx_i][1], qz = s_rxp[Rx_i][2], qq = s_rxp[Rx_i][3], r2w = s_rxp[Rx_i][4], qn = s_rxp[Rx_i][5];
+                    const float b = qx*dx + qy*dy + qz*dz;
+                    const bool inside = qq <= r2w * 1.01f;
+                    const bool ahead = b > -1.0e-3f * qn && (b*b - (qq - r2w) * dd) >= 0.0f;
+                    may_rx = may_rx || inside || ahead;
+                }
+            }
+            dir = (may_target || may_rx) ? rts_primary_dir(lc, slot) : mk3(0.0, 0.0, 0.0);
             prev = origin;
             s_first[tid] = 0.0; s_first[RTS_BLOCK + tid] = 0.0; s_first[2 * RTS_BLOCK + tid] = 0.0;
             s_path[tid] = 0ULL; s_path[RTS_BLOCK + tid] = 0ULL;
@@ -213,7 +257,9 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
             const float tmin = chain_start ? SCENE_EPS : SCENE_EPS_R;          // ray_tracer.cu:209, normal_shader.cu:242,297
             float best_t = RTS_DEFAULT_TMAX;
             int best_leaf = -1; uint32_t best_prim = 0xffffffffu;
-            if (a.n_prims > 0) {
+            const bool primary = chain == 0 && chain_start;
+            const bool may_hit = primary ? may_target : a.n_prims > 0;
+            if (may_hit) {
                 float t_prune = RTS_DEFAULT_TMAX;
                 uint32_t steps = 0;
                 for (uint32_t targ = 0; targ < a.n_targets; targ++) {
@@ -331,7 +377,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
 
             if (best_leaf < 0) {
                 // -------------------------------------------------------- miss, ray_tracer.cu:260-478
-                if (end == false) {
+                if (end == false && (!primary || may_rx)) {
                     for (uint32_t Rx_i = 0; Rx_i < a.n_rx; Rx_i++) {
                         const RtsRxDev rx = Rx_i < RTS_RX_LDS ? s_rx[Rx_i] : a.rx[Rx_i];
                         double t[2] = {0, 0};

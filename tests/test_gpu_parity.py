@@ -966,3 +966,73 @@ def test_random_triangle_soups_brute_force(rts, oracle, scenes, seed, refr, far)
     if tr.scene_info()["builder"] == 0:
         assert np.bincount(leaf_prim).max() > 1                        # host SAH builder: the slivers and wedges were split
     tr.close()
+
+
+def _all_equal(a, b, what):
+    H.assert_prd_equal(a["results"], b["results"], what)
+    for k in ("path", "rcs_angle", "hit_prim"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg="%s: %s" % (what, k))
+    assert np.array_equal(a["hit_t"].view(np.uint32), b["hit_t"].view(np.uint32)), what
+
+
+def test_primary_prefilter_is_invisible(rts, scenes):
+    """the f32 pre-filter of primary rays (direction mask over the placed triangles + widened receiver spheres,
+    rts_internal.h) may only ever say "this ray certainly meets nothing": every output buffer -- all launch indices, the
+    per-segment hit trace, the received set and its order -- must be the same bits with the filter on and off
+    (RTS_FLAG_NO_PREFILTER), wherever the scene sits, whatever the beam looks like; and it must really be switched on where
+    it can be (fewer node visits), and off where its frame does not exist"""
+    import math
+    ecef = scenes.ecef_offset(lat=math.pi / 2)
+    c3 = scenes.config3(W=56, detail=0.3, rx_radius=300.0)
+    behind = scenes.config_multi(W=16)                                     # a target partly BEHIND the transmitter: mask void
+    behind["tx"] = dict(behind["tx"], origin=(2.0, 0.5, 0.3), span=(2.4, 2.4, 0.1))
+    inside = scenes.config_multi(W=16)                                     # transmitter INSIDE a capture sphere
+    inside["rx"] = list(inside["rx"]) + [scenes.rx_window(tuple(np.add(inside["tx"]["origin"], (1.0, 2.0, -1.0))), 25.0, (-3.2, 3.2), (-1.6, 1.6))]
+    narrow = dict(c3, tx=dict(c3["tx"], span=(2.0e-4, 2.0e-4, 0.1)))      # beam narrower than 32 minimum cells: no mask
+    wide = dict(scenes.config_multi(W=16)); wide["tx"] = dict(wide["tx"], span=(2.9, 2.9, 0.1))   # > 120 degrees: no mask
+    c5 = scenes.config5(W=40, detail=0.3)
+    cases = [("c3", c3, c3["motion"], True), ("c3 ecef", scenes.translate(c3, ecef), None, True), ("miss branches", scenes.config_miss_branches(), None, None),
+             ("pole", scenes.config_pole(True), None, None), ("target behind tx", behind, None, None), ("tx inside rx", inside, None, None),
+             ("narrow beam", narrow, None, False), ("wide beam", wide, None, False), ("refraction", scenes.config_multi(W=12, max_refl=2), None, None),
+             ("c5 pulse 7", c5, c5["motion_fn"](7), True)]
+    for name, spec, motion, engaged in cases:
+        if name == "refraction":
+            spec = dict(spec, max_refr=1)
+            spec["meshes"] = [dict(m, refl_coeff=0.6, refr_index=1.5) for m in spec["meshes"]]
+            spec["rx"] = spec["rx"] + [scenes._rx_at((200.0, 0.0, 0.0), (0, 0, 0), 90.0, 2.6)]
+        motion = motion if motion is not None else spec["motion"]
+        n = spec["W"] ** 3
+        out = {}
+        for on in (True, False):
+            tr = H.gpu_tracer(rts, spec, keep_all=True, count_traversal=True, pre_filter=on)
+            for rep in range(2):                                            # (second launch: cost-ordered tiles, adaptive switch settled)
+                _, st = H.gpu_trace(rts, spec, tr=tr, motion=motion)
+            out[on] = (tr.all_rays(n), tr.received(), st)
+            tr.close()
+        (a, ra, sa), (b, rb, sb) = out[True], out[False]
+        _all_equal(a, b, name)
+        assert np.array_equal(ra["slots"], rb["slots"]) and np.array_equal(ra["path"], rb["path"]), name
+        H.assert_prd_equal(ra["results"], rb["results"], name + " (received)")
+        assert (sa["segments"], sa["shaded"], sa["received"], sa["tri_tests"]) == (sb["segments"], sb["shaded"], sb["received"], sb["tri_tests"]), name
+        if engaged is True:
+            assert sa["node_visits"] < sb["node_visits"], (name, sa["node_visits"], sb["node_visits"])
+        elif engaged is False:
+            assert sa["node_visits"] == sb["node_visits"], name
+
+
+def test_primary_prefilter_switches_off_when_most_rays_hit(rts, scenes):
+    """a handle whose last launch shaded more hits than half its launch indices runs the next one without the filter
+    (it would cost every ray and skip none) -- seen through the node visits of the counting build; results unchanged"""
+    c3 = scenes.config3(W=48, detail=0.3, rx_radius=300.0)
+    dense = dict(c3, tx=dict(c3["tx"], span=(0.004, 0.004, 0.1)))
+    tr = H.gpu_tracer(rts, dense, keep_all=True, count_traversal=True)
+    _, s1 = H.gpu_trace(rts, dense, tr=tr); a = tr.all_rays(dense["W"] ** 3)
+    assert 2 * s1["shaded"] > dense["W"] ** 3
+    _, s2 = H.gpu_trace(rts, dense, tr=tr); b = tr.all_rays(dense["W"] ** 3)
+    _all_equal(a, b, "dense, filter off")
+    assert s2["node_visits"] >= s1["node_visits"] and s2["segments"] == s1["segments"]
+    # back on a sparse launch of the same handle: first launch still unfiltered, second filtered
+    tx = c3["tx"]
+    st = [tr.trace(tx["origin"], tx["span"], tx["dir"], c3["motion"]) for _ in range(3)]
+    assert st[0]["node_visits"] > st[1]["node_visits"] == st[2]["node_visits"] and st[0]["segments"] == st[2]["segments"]
+    tr.close()
