@@ -180,7 +180,10 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
       const uint32_t k0 = draw < single_draws ? draw : single_draws + 4u * (draw - single_draws);
       const uint32_t kn = draw < single_draws ? 1u : 4u;
       if (k0 >= per_stripe) break;
-      if (lane == 0) draw_next = atomicAdd(&a.tile_ctr[stripe * RTS_TILE_CTR_STRIDE], 1u);
+      // (only in the cheap part of the order: a draw made before an EXPENSIVE tile would reserve the stripe's next most
+      // expensive tile for as long as this one takes -- the launch then ends with that tile, traced alone)
+      const bool ahead = draw >= single_draws;
+      if (ahead && lane == 0) draw_next = atomicAdd(&a.tile_ctr[stripe * RTS_TILE_CTR_STRIDE], 1u);
      for (uint32_t kb = 0; kb < kn; kb++) {
       const uint64_t tpos64 = (uint64_t)(k0 + kb) * RTS_TILE_CTRS + stripe;
       if (tpos64 >= n_tiles) break;
@@ -572,6 +575,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
           if (COUNT && a.timeline) { a.timeline[(size_t)gridDim.x * 2 + tile] = wall_clock64() - tl_tile; a.timeline[(size_t)gridDim.x * 2 + n_tiles + tile] = tl_tile; }   // debug timeline (RTS_TIMELINE): duration, start tick
       }
      }   // tiles of the draw
+      if (!ahead && lane == 0) draw_next = atomicAdd(&a.tile_ctr[stripe * RTS_TILE_CTR_STRIDE], 1u);
     }
     if (COUNT && a.timeline && tid == 0) a.timeline[(size_t)blockIdx.x * 2 + 1] = wall_clock64();
 
