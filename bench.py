@@ -48,7 +48,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~
 PEAK_CLOCK_HZ = 2.4e9          # max shader clock (MI355X_MICROARCH.md)
 N_SIMD, N_CU = 1024, 256
 PRI = 1.0e-3                   # pulse repetition interval of the synthetic CPI
-PMC_TAG = "r02c"               # profiles/<tag>_pmc_<workload>.json: counters of the committed kernel
+PMC_TAG = "r02d"               # profiles/<tag>_pmc_<workload>.json: counters of the committed kernel
 
 
 def pulse_motion(spec, k):
@@ -322,24 +322,24 @@ def main():
             scale = seg_serial / seg_prof                           # this run's launch vs the profiled one (same workload: ~1)
             t_s = ms_serial * 1e-3
             valu = d["valu_wave_insts"] * scale                     # VALU wave instructions per launch
-            td = d["td_busy_cycles"] * scale                        # busy cycles of the 256 texture-data units per launch
+            td = d["vmem_rd_wave_insts"] * 16.0 * scale             # data cycles of the 256 L1 -> register return paths per launch: 16 clk (64 x 16 B at 64 B/clk) per wave-wide load, counted (SQ_INSTS_VMEM_RD); TD_TD_BUSY is not used: it counts cycles with requests outstanding (0.85 on an empty launch)
             f_valu = valu * 4.0 / (N_SIMD * PEAK_CLOCK_HZ * t_s)
             f_td = td / (N_CU * PEAK_CLOCK_HZ * t_s)
             hbm = d.get("hbm_bytes_per_launch")
             if f_valu >= f_td:
                 roof.update(bound="valu_issue", achieved=valu / t_s / 1e9, peak=N_SIMD * PEAK_CLOCK_HZ / 4.0 / 1e9, unit="Gwave-inst/s", frac=f_valu)
             else:
-                roof.update(bound="vmem_issue", achieved=td / t_s / 1e9, peak=N_CU * PEAK_CLOCK_HZ / 1e9, unit="G TD-busy-cycles/s", frac=f_td)
+                roof.update(bound="vmem_issue", achieved=td / t_s / 1e9, peak=N_CU * PEAK_CLOCK_HZ / 1e9, unit="G return-path data cycles/s", frac=f_td)
             t_w = dt / args.steps                                   # GPU time per launch in the timed region (kernels of --inflight pulses overlap)
             roof.update(valu_issue_frac=f_valu, vmem_return_path_frac=f_td,
                         timed_region={"valu_issue_frac": valu * 4.0 / (N_SIMD * PEAK_CLOCK_HZ * t_w), "vmem_return_path_frac": td / (N_CU * PEAK_CLOCK_HZ * t_w),
                                       "note": "the same per-launch counters over wall time / launches of the timed region: up to --inflight trace kernels share the chip, so a launch costs less wall time than the serial kernel (kernel_ms_serial x launches > ms_per_step x steps is expected unless --link / --inflight 1)"},
-                        in_profile={"valu_busy": d.get("valu_busy"), "td_busy": d.get("td_busy"), "ta_busy": d.get("ta_busy"), "l1_hit_rate": d.get("l1_hit_rate"),
+                        in_profile={"valu_busy": d.get("valu_busy"), "vmem_return_frac_from_counts": d.get("vmem_return_frac_from_counts"), "td_cycles_with_requests_frac": d.get("td_busy"), "ta_busy": d.get("ta_busy"), "l1_hit_rate": d.get("l1_hit_rate"),
                                     "l2_hit_rate": d.get("l2_hit_rate"), "waves_per_simd_avg": d.get("waves_per_simd_avg"), "active_lanes_per_valu_inst": d.get("active_lanes_per_valu_inst"),
                                     "note": "utilisations formed inside the profiled passes (busy cycles over GRBM_GUI_ACTIVE of the same dispatches)"},
                         traffic=hbm, traffic_source="%s: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of this binary on this workload; static, not re-measured by this run" % pmc_src,
                         hbm_GBps_measured=(hbm / t_s / 1e9) if hbm else None, hbm_frac_of_peak=(hbm / t_s / 1e9 / HBM_PEAK_GBS) if hbm else None,
-                        note="bound = the busier of VALU issue and the vector-memory return path; HBM carries ~1 % of its peak (hbm_frac_of_peak) -- the scene is cache resident, the kernel is issue bound (DESIGN.md section 5)")
+                        note="bound = the busier of VALU issue (4 clk of one of 1024 SIMDs per VALU wave-instruction) and the vector-memory return path (16 clk of one of 256 CUs per wave-wide load), both from instruction COUNTS of the profiled launch over this run's serial kernel time at the 2.4 GHz peak clock; HBM carries ~1 % of its peak (hbm_frac_of_peak) -- the scene is cache resident, the kernel is issue bound (DESIGN.md section 5)")
         else:
             roof.update(bound="valu_issue", achieved=None, peak=N_SIMD * PEAK_CLOCK_HZ / 4.0 / 1e9, unit="Gwave-inst/s", frac=None, traffic=None,
                         note="no committed counter profile for this configuration (profiles/%s_pmc_*.json cover c3 at W = 216 on one GPU)" % PMC_TAG)

@@ -88,6 +88,10 @@ def main():
         # 4 cycles of one SIMD per VALU wave-instruction (f32 and f64 alike on gfx950: FP64 vector = FP32 non-packed rate)
         if "kernel_cycles" in d:
             d["valu_issue_frac_from_counts"] = L["SQ_INSTS_VALU"] * 4.0 / (N_SIMD * d["kernel_cycles"])
+            # vector-memory return path, from COUNTS: a wave-wide dwordx4 load returns 64 x 16 B = 1024 B through the CU's
+            # 64 B/clk L1 -> register path = 16 clk whatever the addresses; nearly every read of this kernel is one (the
+            # record fetch); priced at 16 clk each this is an upper bound of the data cycles
+            d["vmem_return_frac_from_counts"] = L.get("SQ_INSTS_VMEM_RD", 0.0) * 16.0 / (N_CU * d["kernel_cycles"])
     if "SQ_INSTS_VALU_ADD_F64" in L:
         d["f64_wave_insts"] = sum(L.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
     if "TA_TA_BUSY_sum" in L and cyc("TA_TA_BUSY_sum"):
@@ -95,6 +99,8 @@ def main():
     if "TD_TD_BUSY_sum" in L and cyc("TD_TD_BUSY_sum"):
         d["td_busy"] = L["TD_TD_BUSY_sum"] / (N_CU * cyc("TD_TD_BUSY_sum"))
         d["td_busy_cycles"] = L["TD_TD_BUSY_sum"]
+        # NOT a utilisation of the return path: TD_TD_BUSY counts cycles with a request in the unit -- an (almost) empty launch
+        # (tools/trace_bench.py c3empty: 1.4 M vector-memory instructions, 0.38 ms) shows 0.85 -- use vmem_return_frac_from_counts
     if "TCP_TOTAL_CACHE_ACCESSES_sum" in L:
         d["l1_line_accesses"] = L["TCP_TOTAL_CACHE_ACCESSES_sum"]
         if "TCP_TCC_READ_REQ_sum" in L:
