@@ -535,7 +535,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     const int grid_mult = c->grid_mult, grid_spare = c->grid_spare;   // blocks per CU: 4 = exactly the resident set (waves draw tiles from a queue); block slots left free
     // the trace kernel's blocks are persistent and four of them fill a CU's register file: leave a few block slots free so
     // that the short kernels of the neighbouring pulses (other streams) are not locked out for the whole launch
-    uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)n + RTS_BLOCK - 1) / RTS_BLOCK, (uint64_t)std::max<int>(c->n_cu * grid_mult - grid_spare, c->n_cu));
+    uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)n + RTS_BLOCK - 1) / RTS_BLOCK, (uint64_t)std::max<int>(c->n_cu * grid_mult - grid_spare * c->n_cu / 256, c->n_cu));   // (grid_spare: block slots per 256 CUs; 160 measured best with three pulses in flight: 0.709 vs 0.735 ms/pulse at 64)
     if (grid == 0) grid = 1;
     RtsTraceArgs a; memset(&a, 0, sizeof(a));
     RtsLaunchConsts& lc = c->last_lc; memset(&lc, 0, sizeof(lc));

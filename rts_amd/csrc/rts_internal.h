@@ -234,7 +234,7 @@ struct RtsContext {
     DevBuf<RtsTargetDev> d_targets;
     // hierarchy: static nodes + leaf order (set_scene), leaf records refreshed per pulse
     uint32_t stack_lds = RTS_STACK_LDS;
-    int grid_mult = 4, grid_spare = 64; bool tile_lpt = true; double ew_rel = 1.7763568394002505e-15;   // per-handle knobs (rts_create reads RTS_GRID_MULT / RTS_GRID_SPARE / RTS_TILE_LPT / RTS_EW_REL)
+    int grid_mult = 4, grid_spare = 160; bool tile_lpt = true; double ew_rel = 1.7763568394002505e-15;   // per-handle knobs (rts_create reads RTS_GRID_MULT / RTS_GRID_SPARE / RTS_TILE_LPT / RTS_EW_REL)
     DevBuf<RtsLeafTri> d_leaves; DevBuf<char> d_sort_tmp;
     // receivers
     DevBuf<RtsRxDev> d_rx; uint32_t n_rx = 0;
