@@ -19,6 +19,7 @@
 #include <thread>
 #include "rts_internal.h"
 #include "rts_raygen.h"
+#include <atomic>
 
 static thread_local char g_err[1024] = "";
 void rts_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap); }
@@ -86,7 +87,7 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     if (p->flags & RTS_FLAG_NO_PREFILTER) c->use_pmask = false;
     // experiment / test knobs, read ONCE PER HANDLE at creation (never per process: two handles of one process may differ)
     { const char* e = getenv("RTS_GRID_MULT"); if (e) c->grid_mult = std::max(1, atoi(e)); }
-    { const char* e = getenv("RTS_GRID_SPARE"); if (e) c->grid_spare = std::max(0, atoi(e)); }
+    { const char* e = getenv("RTS_GRID_SPARE"); if (e) { c->grid_spare = std::max(0, atoi(e)); c->grid_spare_forced = true; } }
     { const char* e = getenv("RTS_TILE_LPT"); if (e && e[0] == '0') c->tile_lpt = false; }
     { const char* e = getenv("RTS_EW_REL"); if (e) { const double v = atof(e); if (v > 0) c->ew_rel = v; } }
     { const char* e = getenv("RTS_STACK_LDS_DEBUG"); if (e) { int v = atoi(e); if (v >= 1 && v <= RTS_STACK_LDS) c->stack_lds = (uint32_t)v; } }   // tests: force the spill path
@@ -94,11 +95,16 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     return RTS_OK;
 }
 
+// pulses begun and not yet ended, per device: a trace launch that will share the GPU with another pulse's kernels leaves block
+// slots free for them (RtsContext::grid_spare), a lone pulse takes the whole chip
+static std::atomic<int> g_open_pulses[64];
+
 extern "C" int rts_destroy(RtsHandle c)
 {
     if (!c) return RTS_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->pulse_open) { c->pulse_open = false; g_open_pulses[c->device & 63]--; }
     if (c->scene && --c->scene->refs == 0) { c->scene->release(); delete c->scene; }
     c->scene = nullptr;
     c->d_verts_world.release(); c->d_normals_world.release();
@@ -532,7 +538,8 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     c->ray_first = first; c->n_rays = n;
     const bool keep_all = (c->params.flags & RTS_FLAG_KEEP_ALL_RAYS) != 0;
     const bool count_trav = (c->params.flags & RTS_FLAG_COUNT_TRAVERSAL) != 0;
-    const int grid_mult = c->grid_mult, grid_spare = c->grid_spare;   // blocks per CU: 4 = exactly the resident set (waves draw tiles from a queue); block slots left free
+    const bool shared_gpu = c->grid_spare_forced || g_open_pulses[c->device & 63].load() > 0;
+    const int grid_mult = c->grid_mult, grid_spare = shared_gpu ? c->grid_spare : 0;   // blocks per CU: 4 = exactly the resident set (waves draw tiles from a queue); block slots left free
     // the trace kernel's blocks are persistent and four of them fill a CU's register file: leave a few block slots free so
     // that the short kernels of the neighbouring pulses (other streams) are not locked out for the whole launch
     uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)n + RTS_BLOCK - 1) / RTS_BLOCK, (uint64_t)std::max<int>(c->n_cu * grid_mult - grid_spare * c->n_cu / 256, c->n_cu));   // (grid_spare: block slots per 256 CUs; 160 measured best with three pulses in flight: 0.709 vs 0.735 ms/pulse at 64)
@@ -611,7 +618,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     RTS_HIP(hipEventRecord(c->ev[3], c->tstream));
     RTS_HIP(hipStreamWaitEvent(st, c->ev[3], 0));                // everything later on this handle's stream follows its trace
     RTS_HIP(hipMemcpyAsync(c->pin->cnt, c->d_counters.p, sizeof(unsigned long long) * 8, hipMemcpyDeviceToHost, st));
-    c->pulse_open = true;
+    c->pulse_open = true; g_open_pulses[c->device & 63]++;
     if (tl_path) {
         RTS_HIP(hipStreamSynchronize(st));
         std::vector<unsigned long long> h(cnt_tl + 2);
@@ -627,7 +634,7 @@ extern "C" int rts_trace_pulse_end(RtsHandle c)
 {
     CHECK_HANDLE(c);
     if (!c->pulse_open) { rts_set_error("rts_trace_pulse_end: no pulse in flight on this handle"); return RTS_ERR_INVALID; }
-    c->pulse_open = false;
+    c->pulse_open = false; g_open_pulses[c->device & 63]--;
     hipStream_t st = c->stream;
     const bool keep_all = (c->params.flags & RTS_FLAG_KEEP_ALL_RAYS) != 0;
     const uint32_t n = c->n_rays;

@@ -74,7 +74,9 @@ static_assert(sizeof(RtsChildState) == 128, "child state size");
 
 #define RTS_BLOCK 256
 #define RTS_WTILE 64               // work unit of the trace kernel: launch indices per wave tile
+#ifndef RTS_TILE_CTRS
 #define RTS_TILE_CTRS 64           // striped draw counters of the tile queue
+#endif
 #define RTS_TILE_CTR_STRIDE 32     // ... one per 128-byte line: same-LINE atomics serialise in L2 (~10 ns each) whatever their address
 #define RTS_STACK_LDS 24            // traversal stack entries kept in LDS per lane
 #define RTS_RX_LDS 16               // receivers whose capture spheres the trace kernel keeps in LDS (the rest are read from memory)
@@ -234,7 +236,7 @@ struct RtsContext {
     DevBuf<RtsTargetDev> d_targets;
     // hierarchy: static nodes + leaf order (set_scene), leaf records refreshed per pulse
     uint32_t stack_lds = RTS_STACK_LDS;
-    int grid_mult = 4, grid_spare = 160; bool tile_lpt = true; double ew_rel = 1.7763568394002505e-15;   // per-handle knobs (rts_create reads RTS_GRID_MULT / RTS_GRID_SPARE / RTS_TILE_LPT / RTS_EW_REL)
+    int grid_mult = 4, grid_spare = 160; bool grid_spare_forced = false; bool tile_lpt = true; double ew_rel = 1.7763568394002505e-15;   // per-handle knobs (rts_create reads RTS_GRID_MULT / RTS_GRID_SPARE / RTS_TILE_LPT / RTS_EW_REL)
     DevBuf<RtsLeafTri> d_leaves; DevBuf<char> d_sort_tmp;
     // receivers
     DevBuf<RtsRxDev> d_rx; uint32_t n_rx = 0;
