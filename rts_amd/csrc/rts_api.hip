@@ -224,7 +224,7 @@ extern "C" int rts_set_scene(RtsHandle c, const RtsMesh* meshes, uint32_t n_targ
         int rc = rts_lbvh_build_device(c, ns, vidx, mh); if (rc != RTS_OK) return rc;
         ns->builder = 1;
     } else {
-        double split_budget = 1.0;                          // extra references for triangles whose boxes are mostly empty (rts_sah.cpp)
+        double split_budget = 2.0;                          // extra references for triangles whose boxes are mostly empty (rts_sah.cpp)
         { const char* e = getenv("RTS_SPLIT_BUDGET"); if (e) { const double v = atof(e); if (v >= 0 && v <= 8) split_budget = v; } }
         std::vector<RtsNode4> nodes4; std::vector<uint32_t> leaf_prim; std::vector<RtsBlasInfo> blas(n_targets);
         {   // the meshes are independent: one host thread each (at most 16 at a time), results concatenated in target order

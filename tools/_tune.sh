@@ -1,4 +1,7 @@
 cd $GRAFT_REPO_ROOT
-run() { python3 bench.py --no-cpu-baseline --steps 64 "$@" 2>/dev/null | tail -1 | python3 -c "import json,sys; j=json.loads(sys.stdin.read()); print(round(j['value']), round(j['ms_per_step'],4), round(j['roofline']['kernel_ms_serial'],3), round(j['roofline']['dense_control']['kernel_ms'],3))"; }
-for v in before after before after; do if [ $v = before ]; then echo "$v $(RTS_AMD_LIB=variants/librts_before.so run)" >> gpurun_out/tune.log; else echo "$v $(run)" >> gpurun_out/tune.log; fi; done
+for b in 1 2 3 4 6; do
+  echo "budget $b: $(RTS_SPLIT_BUDGET=$b python3 tools/count_stats.py 2>/dev/null | grep -E '^c3 |^c3narrow ' | tr '\n' '|')" >> gpurun_out/tune.log
+  echo "   c3 $(RTS_SPLIT_BUDGET=$b python3 tools/trace_bench.py c3 12 | tail -1 | cut -c30-140)" >> gpurun_out/tune.log
+  echo "   dense $(RTS_SPLIT_BUDGET=$b python3 tools/trace_bench.py c3narrow 8 | tail -1 | cut -c30-140)" >> gpurun_out/tune.log
+done
 cat gpurun_out/tune.log
