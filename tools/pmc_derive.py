@@ -46,6 +46,7 @@ def main():
         files = glob.glob(os.path.join(pdir, "**", "*_counter_collection.csv"), recursive=True)
         if not files:
             continue
+        files.sort(key=os.path.getmtime, reverse=True)          # (a re-collected tag: gpurun merges new files beside the old ones)
         rows, m = kernel_rows(files[0])
         if len(rows) < 2:
             continue
