@@ -93,6 +93,92 @@ __device__ __attribute__((noinline)) int rts_stack_below_spilled(int from_lds, i
     return (sp - 1 < lds_cap) ? from_lds : ovf[(size_t)(sp - 1 - lds_cap) * total_threads + gtid];
 }
 
+// One step of the walk for the lanes that hold a node or a leaf (`node` != the sentinel): fetch the record, test the four
+// child boxes / the triangle, update the stack and the closest hit.  Shared by the per-lane walk of k_trace and by the
+// cooperative walk that finishes a straggler's traversal with all 64 lanes (below).
+#define RTS_STACK_SENTINEL 0x7fffffff
+template <bool COUNT>
+__device__ __forceinline__ void rts_walk_step(const RtsTraceArgs& a, int32_t* s_stack, uint32_t tid, uint32_t gtid, int lds_cap, uint32_t* n_spill_lds,
+                                              int& node, int& sp, const RtsSlabRay& lr, const dvec3& prev, const dvec3& dir, float tmin,
+                                              float& best_t, int& best_leaf, uint32_t& best_prim, float& t_prune,
+                                              unsigned long long& n_nodes, unsigned long long& n_tris, bool& hard_overflow)
+{
+    const bool deep = __any(sp + 4 > lds_cap);                  // wave-uniform: some lane is about to leave the LDS part
+    int below = s_stack[min(sp - 1, lds_cap - 1) * RTS_BLOCK + tid];      // (always an LDS read: a second, global source here made the compiler fold both into one FLAT load)
+    if (deep) below = rts_stack_below_spilled(below, sp, lds_cap, a.stack_ovf, a.total_threads, gtid);
+    // One fetch for both kinds of step: a lane at a node needs its 112-byte record (six planes + child ids),
+    // a lane at a leaf its 80-byte record -- the same five (seven) dwordx4 loads from a per-lane base,
+    // issued together at the top of the step, so a wave whose lanes are at nodes AND at leaves waits for
+    // ONE memory round trip (as if / else bodies the leaf loads could only be issued after the node body).
+    const bool at_node = node >= 0;
+    const void* rp = at_node ? static_cast<const void*>(a.nodes4 + node) : static_cast<const void*>(a.leaves + ~node);
+    rts_u32x4 q0, q1, q2, q3, q4, q5, q6;
+    asm volatile("; q5, q6: defined for the lanes at nodes only" : "=v"(q5), "=v"(q6));      // (no instruction: spares eight v_mov of zeros per step)
+    rts_fetch_record(rp, at_node, q0, q1, q2, q3, q4, q5, q6);
+    rts_fetch_wait(q0, q1, q2, q3, q4, q5, q6);
+    if (at_node) {
+        // BVH4 node: six dwordx4 planes (lo/hi x,y,z of the four children) + the four child ids
+        // (by value through __uint_as_float: __builtin_bit_cast applied to an ext-vector ELEMENT reads element 0)
+#define RTS_F4(q) make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w))
+        const float4 LX = RTS_F4(q0), LY = RTS_F4(q1), LZ = RTS_F4(q2), HX = RTS_F4(q3), HY = RTS_F4(q4), HZ = RTS_F4(q5);
+#undef RTS_F4
+        const int4 CH = make_int4((int)q6.x, (int)q6.y, (int)q6.z, (int)q6.w);
+        if (COUNT) n_nodes++;
+        const float INF = __builtin_inff();
+#define RTS_CHILD(k, dk) float dk; { \
+            const float ax = __builtin_fmaf(LX.k, lr.iLx, lr.cLx), bx = __builtin_fmaf(HX.k, lr.iHx, lr.cHx); \
+            const float ay = __builtin_fmaf(LY.k, lr.iLy, lr.cLy), by = __builtin_fmaf(HY.k, lr.iHy, lr.cHy); \
+            const float az = __builtin_fmaf(LZ.k, lr.iLz, lr.cLz), bz = __builtin_fmaf(HZ.k, lr.iHz, lr.cHz); \
+            const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f)); \
+            const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), t_prune)); \
+            dk = (tn <= tf) ? tn : INF; }
+        RTS_CHILD(x, d0) RTS_CHILD(y, d1) RTS_CHILD(z, d2) RTS_CHILD(w, d3)
+#undef RTS_CHILD
+        int c0 = CH.x, c1 = CH.y, c2 = CH.z, c3 = CH.w;
+        // sort the four (distance, child) pairs ascending (5 compare-exchanges); misses carry +inf
+#define RTS_CSWAP(da, ca, db, cb) { const bool sw = db < da; const float td = sw ? db : da; const int tc = sw ? cb : ca; db = sw ? da : db; cb = sw ? ca : cb; da = td; ca = tc; }
+        RTS_CSWAP(d0, c0, d1, c1) RTS_CSWAP(d2, c2, d3, c3) RTS_CSWAP(d0, c0, d2, c2) RTS_CSWAP(d1, c1, d3, c3) RTS_CSWAP(d1, c1, d2, c2)
+#undef RTS_CSWAP
+        // continue with the nearest, push the others farthest first
+        if (!deep) {
+            s_stack[sp * RTS_BLOCK + tid] = c3; sp += (d3 < INF) ? 1 : 0;
+            s_stack[sp * RTS_BLOCK + tid] = c2; sp += (d2 < INF) ? 1 : 0;
+            s_stack[sp * RTS_BLOCK + tid] = c1; sp += (d1 < INF) ? 1 : 0;
+            const bool go = d0 < INF;                         // nothing hit: nothing was pushed either, `below` is the top
+            node = go ? c0 : below; sp -= go ? 0 : 1;
+        } else {
+#define RTS_PUSH(cv) { if (sp < lds_cap) s_stack[sp * RTS_BLOCK + tid] = (cv); \
+                       else if (sp < lds_cap + RTS_STACK_OVF) { a.stack_ovf[(size_t)(sp - lds_cap) * a.total_threads + gtid] = (cv); atomicAdd(n_spill_lds, 1u); } \
+                       else hard_overflow = true; \
+                       if (sp < lds_cap + RTS_STACK_OVF) sp++; }
+            if (d3 < INF) RTS_PUSH(c3)
+            if (d2 < INF) RTS_PUSH(c2)
+            if (d1 < INF) RTS_PUSH(c1)
+#undef RTS_PUSH
+            if (d0 < INF) node = c0;
+            else { node = below; sp--; }
+        }
+    } else {
+        const int leaf = ~node;
+        RtsLeafTri L;
+#define RTS_F64(lo, hi) __hiloint2double((int)(hi), (int)(lo))
+        L.p0x = RTS_F64(q0.x, q0.y); L.p0y = RTS_F64(q0.z, q0.w); L.p0z = RTS_F64(q1.x, q1.y); L.p1x = RTS_F64(q1.z, q1.w);
+        L.p1y = RTS_F64(q2.x, q2.y); L.p1z = RTS_F64(q2.z, q2.w); L.p2x = RTS_F64(q3.x, q3.y); L.p2y = RTS_F64(q3.z, q3.w);
+        L.p2z = RTS_F64(q4.x, q4.y); L.prim = q4.z; L.targ = q4.w;
+#undef RTS_F64
+        if (COUNT) n_tris++;
+        const TriHit h = tri_test(L, prev, dir, tmin, RTS_DEFAULT_TMAX);
+        if (h.ok) {
+            const float tf = (float)h.t;                      // rtPotentialIntersection takes float, triangle_mesh.cu:167
+            if ((tf > tmin) && (tf < best_t || (tf == best_t && L.prim < best_prim))) {
+                best_t = tf; best_leaf = leaf; best_prim = L.prim;
+                t_prune = f32_next_up_pos(tf);                 // keep equal-t candidates reachable
+            }
+        }
+        node = below; sp--;
+    }
+}
+
 // KEEP_ALL is a template parameter, not a run-time flag: hipcc (ROCm 7.2) lowered the uniform
 // `if (a.keep_all)` to a per-lane v_cmp mask computed under the divergent exec of the bounce loop
 // and re-used it at the write-back under a different exec, so lanes that were inactive at the
@@ -288,87 +374,15 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
                     // ends when the sentinel comes off.  The common step is branch free: the entry a lane falls back to
                     // (`below`) is read at the top of the step, beside the step's global loads; children are stored
                     // unconditionally at the top of the stack and the stack pointer advances by the hit predicate.
-                    const int SENTINEL = 0x7fffffff;
+                    const int SENTINEL = RTS_STACK_SENTINEL;
                     const int lds_cap = (int)a.stack_lds;
                     s_stack[tid] = SENTINEL;
                     int sp = 1;
                     int node = TG.root;
                     while (node != SENTINEL) {
                         if (++steps > (1u << 24)) { hard_overflow = true; break; }   // malformed tree guard: every wave must drain
-                        const bool deep = __any(sp + 4 > lds_cap);                  // wave-uniform: some lane is about to leave the LDS part
-                        int below = s_stack[min(sp - 1, lds_cap - 1) * RTS_BLOCK + tid];      // (always an LDS read: a second, global source here made the compiler fold both into one FLAT load)
-                        if (deep) below = rts_stack_below_spilled(below, sp, lds_cap, a.stack_ovf, a.total_threads, gtid);
-                        // One fetch for both kinds of step: a lane at a node needs its 112-byte record (six planes + child ids),
-                        // a lane at a leaf its 80-byte record -- the same five (seven) dwordx4 loads from a per-lane base,
-                        // issued together at the top of the step, so a wave whose lanes are at nodes AND at leaves waits for
-                        // ONE memory round trip (as if / else bodies the leaf loads could only be issued after the node body).
-                        const bool at_node = node >= 0;
-                        const void* rp = at_node ? static_cast<const void*>(a.nodes4 + node) : static_cast<const void*>(a.leaves + ~node);
-                        rts_u32x4 q0, q1, q2, q3, q4, q5, q6;
-                        asm volatile("; q5, q6: defined for the lanes at nodes only" : "=v"(q5), "=v"(q6));      // (no instruction: spares eight v_mov of zeros per step)
-                        rts_fetch_record(rp, at_node, q0, q1, q2, q3, q4, q5, q6);
-                        rts_fetch_wait(q0, q1, q2, q3, q4, q5, q6);
-                        if (at_node) {
-                            // BVH4 node: six dwordx4 planes (lo/hi x,y,z of the four children) + the four child ids
-                            // (by value through __uint_as_float: __builtin_bit_cast applied to an ext-vector ELEMENT reads element 0)
-#define RTS_F4(q) make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w))
-                            const float4 LX = RTS_F4(q0), LY = RTS_F4(q1), LZ = RTS_F4(q2), HX = RTS_F4(q3), HY = RTS_F4(q4), HZ = RTS_F4(q5);
-#undef RTS_F4
-                            const int4 CH = make_int4((int)q6.x, (int)q6.y, (int)q6.z, (int)q6.w);
-                            if (COUNT) n_nodes++;
-                            const float INF = __builtin_inff();
-#define RTS_CHILD(k, dk) float dk; { \
-                                const float ax = __builtin_fmaf(LX.k, lr.iLx, lr.cLx), bx = __builtin_fmaf(HX.k, lr.iHx, lr.cHx); \
-                                const float ay = __builtin_fmaf(LY.k, lr.iLy, lr.cLy), by = __builtin_fmaf(HY.k, lr.iHy, lr.cHy); \
-                                const float az = __builtin_fmaf(LZ.k, lr.iLz, lr.cLz), bz = __builtin_fmaf(HZ.k, lr.iHz, lr.cHz); \
-                                const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f)); \
-                                const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), t_prune)); \
-                                dk = (tn <= tf) ? tn : INF; }
-                            RTS_CHILD(x, d0) RTS_CHILD(y, d1) RTS_CHILD(z, d2) RTS_CHILD(w, d3)
-#undef RTS_CHILD
-                            int c0 = CH.x, c1 = CH.y, c2 = CH.z, c3 = CH.w;
-                            // sort the four (distance, child) pairs ascending (5 compare-exchanges); misses carry +inf
-#define RTS_CSWAP(da, ca, db, cb) { const bool sw = db < da; const float td = sw ? db : da; const int tc = sw ? cb : ca; db = sw ? da : db; cb = sw ? ca : cb; da = td; ca = tc; }
-                            RTS_CSWAP(d0, c0, d1, c1) RTS_CSWAP(d2, c2, d3, c3) RTS_CSWAP(d0, c0, d2, c2) RTS_CSWAP(d1, c1, d3, c3) RTS_CSWAP(d1, c1, d2, c2)
-#undef RTS_CSWAP
-                            // continue with the nearest, push the others farthest first
-                            if (!deep) {
-                                s_stack[sp * RTS_BLOCK + tid] = c3; sp += (d3 < INF) ? 1 : 0;
-                                s_stack[sp * RTS_BLOCK + tid] = c2; sp += (d2 < INF) ? 1 : 0;
-                                s_stack[sp * RTS_BLOCK + tid] = c1; sp += (d1 < INF) ? 1 : 0;
-                                const bool go = d0 < INF;                         // nothing hit: nothing was pushed either, `below` is the top
-                                node = go ? c0 : below; sp -= go ? 0 : 1;
-                            } else {
-#define RTS_PUSH(cv) { if (sp < lds_cap) s_stack[sp * RTS_BLOCK + tid] = (cv); \
-                       else if (sp < lds_cap + RTS_STACK_OVF) { a.stack_ovf[(size_t)(sp - lds_cap) * a.total_threads + gtid] = (cv); atomicAdd(&s_n[2 * RTS_BLOCK + tid], 1u); } \
-                       else hard_overflow = true; \
-                       if (sp < lds_cap + RTS_STACK_OVF) sp++; }
-                                if (d3 < INF) RTS_PUSH(c3)
-                                if (d2 < INF) RTS_PUSH(c2)
-                                if (d1 < INF) RTS_PUSH(c1)
-#undef RTS_PUSH
-                                if (d0 < INF) node = c0;
-                                else { node = below; sp--; }
-                            }
-                        } else {
-                            const int leaf = ~node;
-                            RtsLeafTri L;
-#define RTS_F64(lo, hi) __hiloint2double((int)(hi), (int)(lo))
-                            L.p0x = RTS_F64(q0.x, q0.y); L.p0y = RTS_F64(q0.z, q0.w); L.p0z = RTS_F64(q1.x, q1.y); L.p1x = RTS_F64(q1.z, q1.w);
-                            L.p1y = RTS_F64(q2.x, q2.y); L.p1z = RTS_F64(q2.z, q2.w); L.p2x = RTS_F64(q3.x, q3.y); L.p2y = RTS_F64(q3.z, q3.w);
-                            L.p2z = RTS_F64(q4.x, q4.y); L.prim = q4.z; L.targ = q4.w;
-#undef RTS_F64
-                            if (COUNT) n_tris++;
-                            const TriHit h = tri_test(L, prev, dir, tmin, RTS_DEFAULT_TMAX);
-                            if (h.ok) {
-                                const float tf = (float)h.t;                      // rtPotentialIntersection takes float, triangle_mesh.cu:167
-                                if ((tf > tmin) && (tf < best_t || (tf == best_t && L.prim < best_prim))) {
-                                    best_t = tf; best_leaf = leaf; best_prim = L.prim;
-                                    t_prune = f32_next_up_pos(tf);                 // keep equal-t candidates reachable
-                                }
-                            }
-                            node = below; sp--;
-                        }
+                        rts_walk_step<COUNT>(a, s_stack, tid, gtid, lds_cap, &s_n[2 * RTS_BLOCK + tid], node, sp, lr, prev, dir, tmin, best_t, best_leaf, best_prim, t_prune,
+                                             n_nodes, n_tris, hard_overflow);
                     }
                 }
             }
