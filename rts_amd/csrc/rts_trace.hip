@@ -101,7 +101,7 @@ template <bool COUNT>
 __device__ __forceinline__ void rts_walk_step(const RtsTraceArgs& a, int32_t* s_stack, uint32_t tid, uint32_t gtid, int lds_cap, uint32_t* n_spill_lds,
                                               int& node, int& sp, const RtsSlabRay& lr, const dvec3& prev, const dvec3& dir, float tmin,
                                               float& best_t, int& best_leaf, uint32_t& best_prim, float& t_prune,
-                                              unsigned long long& n_nodes, unsigned long long& n_tris, bool& hard_overflow)
+                                              uint32_t& n_nodes, uint32_t& n_tris, bool& hard_overflow)
 {
     const bool deep = __any(sp + 4 > lds_cap);                  // wave-uniform: some lane is about to leave the LDS part
     int below = s_stack[min(sp - 1, lds_cap - 1) * RTS_BLOCK + tid];      // (always an LDS read: a second, global source here made the compiler fold both into one FLAT load)
@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
         s_rxp[tid][5] = (float)sqrt(qq);
     }
     __syncthreads();
-    unsigned long long n_nodes = 0, n_tris = 0;                  // counting build only
+    uint32_t n_nodes = 0, n_tris = 0;                            // counting build only (per lane and launch: far below 2^32)
     bool hard_overflow = false;
     const bool mask_on = a.pmask != nullptr && lc.mask.n != 0 && a.pmask[(size_t)lc.mask.n * lc.mask.n / 32u] == 0u;     // (uniform) not voided by k_primary_mask
     // the pre-filter can only pay if it can clear a ray of the targets: with geometry but no valid mask every primary needs
@@ -259,17 +259,23 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
     // latency).  The next draw is issued before the current tiles are traced, so its latency hides behind them.
     const uint32_t per_stripe = (n_tiles + RTS_TILE_CTRS - 1u) / RTS_TILE_CTRS;
     const uint32_t single_draws = per_stripe >= 1024u ? per_stripe / 4u : per_stripe;      // (short queues: one tile per draw throughout)
+    // The pending draw is held in a register of lane 0 (so that its latency hides behind the tiles traced meanwhile) -- except
+    // in the counting builds, which are short of registers: there the allocator spilled it to scratch, stored under
+    // EXEC = lane 0 and reloaded at the loop top, and launches then lost whole tiles' worth of counters from run to run
+    // (the reload overtaking the store is the suspicion; product builds have no scratch at all, tests/test_host_logic.py checks).
+    __shared__ uint32_t s_draw[RTS_BLOCK / 64];
     uint32_t draw_next = 0;
-    if (lane == 0) draw_next = atomicAdd(&a.tile_ctr[stripe * RTS_TILE_CTR_STRIDE], 1u);
+#define RTS_DRAW() { const uint32_t dv_ = atomicAdd(&a.tile_ctr[stripe * RTS_TILE_CTR_STRIDE], 1u); if (COUNT) s_draw[tid >> 6] = dv_; else draw_next = dv_; }
+    if (lane == 0) RTS_DRAW()
     for (;;) {
-      const uint32_t draw = __builtin_amdgcn_readfirstlane(draw_next);
+      const uint32_t draw = __builtin_amdgcn_readfirstlane(COUNT ? s_draw[tid >> 6] : draw_next);
       const uint32_t k0 = draw < single_draws ? draw : single_draws + 4u * (draw - single_draws);
       const uint32_t kn = draw < single_draws ? 1u : 4u;
       if (k0 >= per_stripe) break;
       // (only in the cheap part of the order: a draw made before an EXPENSIVE tile would reserve the stripe's next most
       // expensive tile for as long as this one takes -- the launch then ends with that tile, traced alone)
       const bool ahead = draw >= single_draws;
-      if (ahead && lane == 0) draw_next = atomicAdd(&a.tile_ctr[stripe * RTS_TILE_CTR_STRIDE], 1u);
+      if (ahead && lane == 0) RTS_DRAW()
      for (uint32_t kb = 0; kb < kn; kb++) {
       const uint64_t tpos64 = (uint64_t)(k0 + kb) * RTS_TILE_CTRS + stripe;
       if (tpos64 >= n_tiles) break;
@@ -589,25 +595,25 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
           if (COUNT && a.timeline) { a.timeline[(size_t)gridDim.x * 2 + tile] = wall_clock64() - tl_tile; a.timeline[(size_t)gridDim.x * 2 + n_tiles + tile] = tl_tile; }   // debug timeline (RTS_TIMELINE): duration, start tick
       }
      }   // tiles of the draw
-      if (!ahead && lane == 0) draw_next = atomicAdd(&a.tile_ctr[stripe * RTS_TILE_CTR_STRIDE], 1u);
+      if (!ahead && lane == 0) RTS_DRAW()
     }
     if (COUNT && a.timeline && tid == 0) a.timeline[(size_t)blockIdx.x * 2 + 1] = wall_clock64();
 
     // ------------------------------------------------------------------ counters: wave reduce -> block reduce (LDS, the
     // traversal stack is dead by now) -> one plain store per block; k_sum_counters adds the blocks up.  (One atomic per
     // wave on the same two addresses -- 32 k same-line L2 atomics -- cost a fixed ~0.35 ms at the tail of every launch.)
-    unsigned long long n_seg = s_n[tid], n_shaded = s_n[RTS_BLOCK + tid], n_spill = s_n[2 * RTS_BLOCK + tid];
+    unsigned long long n_seg = s_n[tid], n_shaded = s_n[RTS_BLOCK + tid], n_spill = s_n[2 * RTS_BLOCK + tid], n_nodes_w = n_nodes, n_tris_w = n_tris;
     for (int off = 32; off > 0; off >>= 1) {
         n_seg += __shfl_down(n_seg, off); n_shaded += __shfl_down(n_shaded, off);
-        if (COUNT) { n_nodes += __shfl_down(n_nodes, off); n_tris += __shfl_down(n_tris, off); }
+        if (COUNT) { n_nodes_w += __shfl_down(n_nodes_w, off); n_tris_w += __shfl_down(n_tris_w, off); }
         n_spill += __shfl_down(n_spill, off);
     }
     __syncthreads();
     unsigned long long* s_cnt = reinterpret_cast<unsigned long long*>(s_stack);        // [waves][8]
     const int wave = tid >> 6;
     if ((tid & 63) == 0) {
-        s_cnt[wave * 8 + 1] = n_seg; s_cnt[wave * 8 + 2] = n_shaded; s_cnt[wave * 8 + 3] = COUNT ? n_nodes : 0ULL;
-        s_cnt[wave * 8 + 4] = COUNT ? n_tris : 0ULL; s_cnt[wave * 8 + 5] = n_spill;
+        s_cnt[wave * 8 + 1] = n_seg; s_cnt[wave * 8 + 2] = n_shaded; s_cnt[wave * 8 + 3] = COUNT ? n_nodes_w : 0ULL;
+        s_cnt[wave * 8 + 4] = COUNT ? n_tris_w : 0ULL; s_cnt[wave * 8 + 5] = n_spill;
     }
     const bool any_overflow = __syncthreads_or(hard_overflow ? 1 : 0) != 0;
     if (tid >= 1 && tid <= 6) {

@@ -239,3 +239,30 @@ def test_plan_cpi_in_the_library(rts):
             assert sum(multigpu.part_ray_count(c, il) for _, _, c, il in fine) == sum(multigpu.part_ray_count(c, il) for _, _, c, il in coarse)
     with pytest.raises(_lib.RtsError):
         multigpu.plan_cpi(total, 4, 3, 3)                            # rank >= world
+
+
+def test_product_trace_kernels_use_no_scratch():
+    """the product instantiations of the trace kernel (COUNT = false) must not spill vector registers: 128 VGPRs at four waves
+    per SIMD is the budget the kernel is written for, and a spilled draw of the tile queue once cost the counting builds whole
+    tiles' worth of counters (rts_trace.hip, RTS_DRAW).  hipcc's own resource remarks, device code only (no GPU needed)."""
+    import re, shutil, subprocess, tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "rts_amd", "csrc", "rts_trace.hip")
+    with tempfile.TemporaryDirectory() as td:
+        r = subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-I" + os.path.join(ROOT, "include"),
+                            "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", os.path.join(td, "t.o")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    blocks = re.split(r"remark: Function Name: ", r.stderr)[1:]
+    seen = 0
+    for b in blocks:
+        name = b.split()[0]
+        if not name.startswith("_Z7k_traceILb0E"):
+            continue
+        seen += 1
+        scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1)); vspill = int(re.search(r"VGPRs Spill: (\d+)", b).group(1))
+        lds = int(re.search(r"LDS Size \[bytes/block\]: (\d+)", b).group(1)); occ = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1))
+        assert scratch == 0 and vspill == 0, (name, scratch, vspill)
+        assert lds * 4 <= 160 * 1024 and occ >= 2, (name, lds, occ)          # four blocks of four waves per CU
+    assert seen == 4
