@@ -220,12 +220,12 @@ extern "C" int rts_set_scene(RtsHandle c, const RtsMesh* meshes, uint32_t n_targ
     const auto t_build0 = std::chrono::steady_clock::now();
     bool device_build = (c->params.flags & RTS_FLAG_DEVICE_BUILD) != 0;
     { const char* e = getenv("RTS_BUILDER"); if (e) device_build = (strcmp(e, "device") == 0); }
+    double split_budget = 2.0;                              // extra references for triangles whose boxes are mostly empty (rts_sah.cpp, rts_lbvh.hip)
+    { const char* e = getenv("RTS_SPLIT_BUDGET"); if (e) { const double v = atof(e); if (v >= 0 && v <= 8) split_budget = v; } }
     if (device_build) {
-        int rc = rts_lbvh_build_device(c, ns, vidx, mh); if (rc != RTS_OK) return rc;
+        int rc = rts_lbvh_build_device(c, ns, vidx, mh, split_budget); if (rc != RTS_OK) return rc;
         ns->builder = 1;
     } else {
-        double split_budget = 2.0;                          // extra references for triangles whose boxes are mostly empty (rts_sah.cpp)
-        { const char* e = getenv("RTS_SPLIT_BUDGET"); if (e) { const double v = atof(e); if (v >= 0 && v <= 8) split_budget = v; } }
         std::vector<RtsNode4> nodes4; std::vector<uint32_t> leaf_prim; std::vector<RtsBlasInfo> blas(n_targets);
         {   // the meshes are independent: one host thread each (at most 16 at a time), results concatenated in target order
             std::vector<std::vector<RtsNode4>> pn(n_targets); std::vector<std::vector<uint32_t>> pl(n_targets); std::vector<int> prc(n_targets, RTS_OK);

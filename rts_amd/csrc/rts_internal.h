@@ -267,7 +267,7 @@ struct RtsContext {
 
 // implemented in the .hip units
 int rts_sah_build(const double* verts, const uint32_t* tris, uint32_t n_tris, double split_budget, std::vector<RtsNode4>& nodes, std::vector<uint32_t>& leaf_prim, RtsBlasInfo& out);
-int rts_lbvh_build_device(RtsContext* c, RtsScene* ns, const std::vector<uint32_t>& vidx, const std::vector<RtsMeshHost>& mh);
+int rts_lbvh_build_device(RtsContext* c, RtsScene* ns, const std::vector<uint32_t>& vidx, const std::vector<RtsMeshHost>& mh, double split_budget);
 int rts_scene_place(RtsContext* c);
 int rts_primary_mask_build(RtsContext* c, const RtsLaunchConsts& lc);
 int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_valid, const uint64_t* cur_sig, uint32_t n_tiles_cur);

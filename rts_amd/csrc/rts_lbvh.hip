@@ -3,16 +3,20 @@
 // The reference has OptiX rebuild its closed-source "Bvh" acceleration on the device every pulse (ray_tracer.cpp:1126-1130);
 // here the hierarchy of a rigid target never changes (rts_sah.cpp), so it is built once per rts_set_scene -- by the host SAH
 // builder (default: best traversal cost, seconds for a million triangles on one core per mesh) or by this file (milliseconds):
-//   prim_boxes : f64 extent of each triangle in TARGET space -> f32 rounded outward + conservative pad (put_box of
+//   references : a triangle whose box is large against the mesh's mean is cut into up to 8 REFERENCES -- slabs across the
+//                longest axis of its box, each with the box of the part of the triangle inside the slab (early split
+//                clipping, the device counterpart of the split references of rts_sah.cpp): k = ceil(sqrt(area / threshold)),
+//                counted, scanned and emitted on the device.  Every reference of a triangle leads to the same exact test.
+//   ref_boxes  : f64 extent of each reference in TARGET space -> f32 rounded outward + conservative pad (put_box of
 //                rts_sah.cpp; the reference's `bound` program, triangle_mesh.cu:204-233, works on world-space boxes)
 //   morton     : 63-bit Morton code of the box centre in the mesh's (cubic) bounds
-//   sort       : rocPRIM radix sort of (code, triangle); triangles with a non-finite vertex sort last and get no leaf
+//   sort       : rocPRIM radix sort of (code, reference); triangles with a non-finite vertex sort last and get no leaf
 //   hierarchy  : Karras 2012 radix tree over the sorted codes, one thread per internal node
 //   refit      : bottom-up child boxes; a 1024-leaf chunk is resolved through LDS counters, the few subtree roots whose
 //                parents span chunks through agent-scope atomics (per-XCD L2s are not coherent)
 //   collapse   : record i = BVH2 node i with its internal children opened -> the 4-wide, 128-byte node format the trace
 //                kernel walks (RtsNode4); records not reachable from the root are never visited
-// Same node format and leaf-order convention as the host builder, no split references; results cannot differ (the f64
+// Same node format and leaf-order convention as the host builder; results cannot differ (the f64
 // triangle test alone decides hits), only the number of nodes and triangles a ray visits.
 #include <cmath>
 #include <cstring>
@@ -32,38 +36,116 @@ static_assert(sizeof(Node2) == 64, "node2 size");
 __device__ __forceinline__ uint32_t f2ord(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __device__ __forceinline__ float ord2f(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
 
+struct TriV { double v[3][3]; bool finite; };
+__device__ __forceinline__ TriV load_tri(const uint32_t* __restrict__ tri_vidx, const double* __restrict__ verts, uint32_t i)
+{
+    TriV t; t.finite = true;
+    for (int k = 0; k < 3; k++) {
+        const uint32_t a = tri_vidx[3*(size_t)i + k];
+        for (int c = 0; c < 3; c++) { t.v[k][c] = verts[3*(size_t)a + c]; t.finite = t.finite && isfinite(t.v[k][c]); }
+    }
+    return t;
+}
+__device__ __forceinline__ void tri_extent(const TriV& t, double lo[3], double hi[3])
+{
+    for (int c = 0; c < 3; c++) { lo[c] = fmin(fmin(t.v[0][c], t.v[1][c]), t.v[2][c]); hi[c] = fmax(fmax(t.v[0][c], t.v[1][c]), t.v[2][c]); }
+}
+// number of references of a triangle: slabs across the longest axis of its box, more for boxes that are large against `a_thr`
+__device__ __forceinline__ uint32_t ref_count(const double lo[3], const double hi[3], double a_thr)
+{
+    const double ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+    const double area = 2.0 * (ex*ey + ey*ez + ex*ez);
+    if (!(a_thr > 0.0) || !(area > a_thr) || !(fmax(fmax(ex, ey), ez) > 0.0)) return 1u;
+    const double k = ceil(sqrt(area / a_thr));
+    return (uint32_t)fmin(fmax(k, 1.0), 8.0);
+}
+
+// pass 0: sum of the box areas of the valid triangles (for the split threshold) and their number
+__global__ void k_tri_area(const uint32_t* __restrict__ tri_vidx, const double* __restrict__ verts, uint32_t n, double* __restrict__ acc)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    double a = 0.0, c = 0.0;
+    if (i < n) {
+        const TriV t = load_tri(tri_vidx, verts, i);
+        if (t.finite) { double lo[3], hi[3]; tri_extent(t, lo, hi); const double ex = hi[0]-lo[0], ey = hi[1]-lo[1], ez = hi[2]-lo[2]; a = 2.0 * (ex*ey + ey*ez + ex*ez); c = 1.0; if (!isfinite(a)) { a = 0.0; c = 0.0; } }
+    }
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); c += __shfl_down(c, off); }
+    if ((threadIdx.x & 63) == 0 && c > 0.0) { atomicAdd(&acc[0], a); atomicAdd(&acc[1], c); }
+}
+// pass 1: references per triangle (an invalid triangle keeps ONE, invalid, reference: it sorts last and gets no leaf)
+__global__ void k_ref_count(const uint32_t* __restrict__ tri_vidx, const double* __restrict__ verts, uint32_t n, double a_thr, uint32_t* __restrict__ cnt, uint32_t* __restrict__ n_valid_refs)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t k = 0, kv = 0;
+    if (i < n) {
+        const TriV t = load_tri(tri_vidx, verts, i);
+        k = 1;
+        if (t.finite) { double lo[3], hi[3]; tri_extent(t, lo, hi); k = ref_count(lo, hi, a_thr); kv = k; }
+        cnt[i] = k;
+    }
+    for (int off = 32; off > 0; off >>= 1) kv += __shfl_down(kv, off);
+    if ((threadIdx.x & 63) == 0 && kv) atomicAdd(n_valid_refs, kv);
+}
+
 // Box = [rd(min - pad), ru(max + pad)] in f32, pad = 2^-22 of the largest coordinate magnitude (rts_sah.cpp: put_box).
 // Invalid (non-finite) triangles get the INVERTED box, neutral under union; they sort last and stay outside the tree.
-__global__ void k_prim_boxes(const uint32_t* __restrict__ tri_vidx, const double* __restrict__ verts, float* __restrict__ prim_box,
-                             uint32_t* __restrict__ bounds, uint32_t n)
+// Reference j of k: the part of the triangle between the planes lo + e j/k and lo + e (j+1)/k across the box's longest axis --
+// its vertices inside the slab and the points where its edges cross the two planes (f64; the pad dwarfs their rounding).
+__global__ void k_ref_boxes(const uint32_t* __restrict__ tri_vidx, const double* __restrict__ verts, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
+                            float* __restrict__ ref_box, uint32_t* __restrict__ ref_tri, uint32_t* __restrict__ bounds, uint32_t n)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    float cx = 0, cy = 0, cz = 0; bool ok = false;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    float mnx = 3.0e38f, mny = 3.0e38f, mnz = 3.0e38f, mxx = -3.0e38f, mxy = -3.0e38f, mxz = -3.0e38f;
     if (i < n) {
-        uint32_t a = tri_vidx[3*i], b = tri_vidx[3*i+1], c = tri_vidx[3*i+2];
-        double ax = verts[3*(size_t)a], ay = verts[3*(size_t)a+1], az = verts[3*(size_t)a+2];
-        double bx = verts[3*(size_t)b], by = verts[3*(size_t)b+1], bz = verts[3*(size_t)b+2];
-        double cx_ = verts[3*(size_t)c], cy_ = verts[3*(size_t)c+1], cz_ = verts[3*(size_t)c+2];
-        double lox = fmin(fmin(ax, bx), cx_), loy = fmin(fmin(ay, by), cy_), loz = fmin(fmin(az, bz), cz_);
-        double hix = fmax(fmax(ax, bx), cx_), hiy = fmax(fmax(ay, by), cy_), hiz = fmax(fmax(az, bz), cz_);
-        bool finite = isfinite(ax) && isfinite(ay) && isfinite(az) && isfinite(bx) && isfinite(by) && isfinite(bz) &&
-                      isfinite(cx_) && isfinite(cy_) && isfinite(cz_);
-        float* o = prim_box + 6*(size_t)i;
-        if (finite) {
-            double s = fmax(fmax(fmax(fabs(lox), fabs(hix)), fmax(fabs(loy), fabs(hiy))), fmax(fabs(loz), fabs(hiz)));
-            double pad = s * 2.384185791015625e-07 + 1e-30;
-            o[0] = f32_down(lox - pad); o[1] = f32_down(loy - pad); o[2] = f32_down(loz - pad);
-            o[3] = f32_up(hix + pad); o[4] = f32_up(hiy + pad); o[5] = f32_up(hiz + pad);
-            cx = (float)((lox + hix) * 0.5); cy = (float)((loy + hiy) * 0.5); cz = (float)((loz + hiz) * 0.5);
-            ok = isfinite(o[0]) && isfinite(o[1]) && isfinite(o[2]) && isfinite(o[3]) && isfinite(o[4]) && isfinite(o[5]);
+        const TriV t = load_tri(tri_vidx, verts, i);
+        const uint32_t k = cnt[i], base = off[i];
+        double tlo[3], thi[3];
+        if (t.finite) tri_extent(t, tlo, thi);
+        int ax = 0;
+        if (t.finite) { const double ex = thi[0]-tlo[0], ey = thi[1]-tlo[1], ez = thi[2]-tlo[2]; ax = (ex >= ey && ex >= ez) ? 0 : (ey >= ez ? 1 : 2); }
+        for (uint32_t j = 0; j < k; j++) {
+            float* o = ref_box + 6*(size_t)(base + j);
+            ref_tri[base + j] = i;
+            bool ok = false;
+            if (t.finite) {
+                double lo[3] = {tlo[0], tlo[1], tlo[2]}, hi[3] = {thi[0], thi[1], thi[2]};
+                if (k > 1) {
+                    const double e = thi[ax] - tlo[ax];
+                    const double s0 = j == 0 ? tlo[ax] : tlo[ax] + e * ((double)j / (double)k), s1 = j + 1 == k ? thi[ax] : tlo[ax] + e * ((double)(j + 1) / (double)k);
+                    double clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                    for (int a = 0; a < 3; a++) {
+                        const double* p = t.v[a]; const double* q = t.v[(a + 1) % 3];
+                        if (p[ax] >= s0 && p[ax] <= s1) for (int c = 0; c < 3; c++) { clo[c] = fmin(clo[c], p[c]); chi[c] = fmax(chi[c], p[c]); }
+                        for (int w = 0; w < 2; w++) {
+                            const double sp = w ? s1 : s0;
+                            if ((p[ax] < sp && q[ax] > sp) || (p[ax] > sp && q[ax] < sp)) {
+                                const double u = (sp - p[ax]) / (q[ax] - p[ax]);
+                                for (int c = 0; c < 3; c++) { const double x = c == ax ? sp : p[c] + u * (q[c] - p[c]); clo[c] = fmin(clo[c], x); chi[c] = fmax(chi[c], x); }
+                            }
+                        }
+                    }
+                    if (clo[0] <= chi[0] && clo[1] <= chi[1] && clo[2] <= chi[2]) {
+                        for (int c = 0; c < 3; c++) { lo[c] = fmax(clo[c], tlo[c]); hi[c] = fmin(chi[c], thi[c]); }
+                    }
+                    lo[ax] = fmax(lo[ax], s0); hi[ax] = fmin(hi[ax], s1);          // (an empty clip -- it cannot happen inside the extent -- keeps the slab of the whole box)
+                    if (!(lo[ax] <= hi[ax])) { lo[ax] = s0; hi[ax] = s1; }
+                }
+                const double s = fmax(fmax(fmax(fabs(lo[0]), fabs(hi[0])), fmax(fabs(lo[1]), fabs(hi[1]))), fmax(fabs(lo[2]), fabs(hi[2])));
+                const double pad = s * 2.384185791015625e-07 + 1e-30;
+                o[0] = f32_down(lo[0] - pad); o[1] = f32_down(lo[1] - pad); o[2] = f32_down(lo[2] - pad);
+                o[3] = f32_up(hi[0] + pad); o[4] = f32_up(hi[1] + pad); o[5] = f32_up(hi[2] + pad);
+                ok = isfinite(o[0]) && isfinite(o[1]) && isfinite(o[2]) && isfinite(o[3]) && isfinite(o[4]) && isfinite(o[5]);
+                if (ok) {
+                    const float cx = (float)((lo[0] + hi[0]) * 0.5), cy = (float)((lo[1] + hi[1]) * 0.5), cz = (float)((lo[2] + hi[2]) * 0.5);
+                    mnx = fminf(mnx, cx); mny = fminf(mny, cy); mnz = fminf(mnz, cz); mxx = fmaxf(mxx, cx); mxy = fmaxf(mxy, cy); mxz = fmaxf(mxz, cz);
+                }
+            }
+            if (!ok) { o[0] = o[1] = o[2] = 3.0e38f; o[3] = o[4] = o[5] = -3.0e38f; }
         }
-        if (!ok) { o[0] = o[1] = o[2] = 3.0e38f; o[3] = o[4] = o[5] = -3.0e38f; }
     }
-    float mnx = ok ? cx : 3.0e38f, mny = ok ? cy : 3.0e38f, mnz = ok ? cz : 3.0e38f;
-    float mxx = ok ? cx : -3.0e38f, mxy = ok ? cy : -3.0e38f, mxz = ok ? cz : -3.0e38f;
-    for (int off = 32; off > 0; off >>= 1) {
-        mnx = fminf(mnx, __shfl_down(mnx, off)); mny = fminf(mny, __shfl_down(mny, off)); mnz = fminf(mnz, __shfl_down(mnz, off));
-        mxx = fmaxf(mxx, __shfl_down(mxx, off)); mxy = fmaxf(mxy, __shfl_down(mxy, off)); mxz = fmaxf(mxz, __shfl_down(mxz, off));
+    for (int off2 = 32; off2 > 0; off2 >>= 1) {
+        mnx = fminf(mnx, __shfl_down(mnx, off2)); mny = fminf(mny, __shfl_down(mny, off2)); mnz = fminf(mnz, __shfl_down(mnz, off2));
+        mxx = fmaxf(mxx, __shfl_down(mxx, off2)); mxy = fmaxf(mxy, __shfl_down(mxy, off2)); mxz = fmaxf(mxz, __shfl_down(mxz, off2));
     }
     __shared__ float s_red[4][6];
     const int wave = threadIdx.x >> 6;
@@ -106,10 +188,10 @@ __global__ void k_morton(const float* __restrict__ prim_box, const uint32_t* __r
 }
 
 // leaf order of the mesh: leaf slot (leaf_base + sorted position) -> GLOBAL primitive id
-__global__ void k_leaf_order(const uint32_t* __restrict__ sorted_prim, uint32_t tri_base, uint32_t* __restrict__ leaf_prim, uint32_t n)
+__global__ void k_leaf_order(const uint32_t* __restrict__ sorted_ref, const uint32_t* __restrict__ ref_tri, uint32_t tri_base, uint32_t* __restrict__ leaf_prim, uint32_t n)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) leaf_prim[i] = tri_base + sorted_prim[i];
+    if (i < n) leaf_prim[i] = tri_base + ref_tri[sorted_ref[i]];
 }
 
 // --------------------------------------------------------------------------- Karras radix tree
@@ -266,56 +348,101 @@ inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 
 
 // vidx: [n_prims][3] GLOBAL vertex indices (host copy of ns->d_tri_vidx); mh: per-mesh slices.  Fills ns->d_nodes4,
 // ns->d_leaf_prim, ns->blas, ns->n_nodes, ns->n_leaves.  Uses the handle's stream; temporaries are freed before returning.
-int rts_lbvh_build_device(RtsContext* c, RtsScene* ns, const std::vector<uint32_t>& vidx, const std::vector<RtsMeshHost>& mh)
+// split_budget: aimed-at extra references per triangle (0: one reference per triangle); the threshold of ref_count is the
+// mesh's mean box area / (1 + budget)^2, i.e. an average triangle gets about 1 + budget references.
+int rts_lbvh_build_device(RtsContext* c, RtsScene* ns, const std::vector<uint32_t>& vidx, const std::vector<RtsMeshHost>& mh, double split_budget)
 {
     hipStream_t st = c->stream;
     const uint32_t n_targets = (uint32_t)mh.size();
     ns->blas.assign(n_targets, RtsBlasInfo{});
-    // host pass: which triangles are finite, the f64 bounds of every mesh (for the per-pulse placement constants)
+    // host pass: the f64 bounds of every mesh over its finite triangles (for the per-pulse placement constants)
     std::vector<double> hv(3 * (size_t)ns->n_verts);
     if (ns->n_verts) RTS_HIP(hipMemcpy(hv.data(), ns->d_verts_local.p, sizeof(double) * hv.size(), hipMemcpyDeviceToHost));
-    std::vector<uint32_t> n_valid(n_targets, 0);
-    uint64_t node_total = 0, leaf_total = 0; uint32_t n_max = 0;
+    uint32_t n_max = 0;
     for (uint32_t t = 0; t < n_targets; t++) {
         RtsBlasInfo& b = ns->blas[t]; b.root = -1; b.depth = 64;
         double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        uint32_t nv = 0;
         for (uint32_t i = 0; i < mh[t].n_tris; i++) {
             bool finite = true;
             for (int k = 0; k < 3; k++) { const double* p = &hv[3 * (size_t)vidx[3 * ((size_t)mh[t].tri_base + i) + k]]; finite = finite && std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]); }
             if (!finite) continue;
-            n_valid[t]++;
+            nv++;
             for (int k = 0; k < 3; k++) { const double* p = &hv[3 * (size_t)vidx[3 * ((size_t)mh[t].tri_base + i) + k]]; for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); } }
         }
-        b.n_leaves = n_valid[t]; b.n_nodes = n_valid[t] == 0 ? 0 : std::max<uint32_t>(n_valid[t] - 1, 1);
-        for (int a = 0; a < 3; a++) { b.lo[a] = n_valid[t] ? lo[a] : 0; b.hi[a] = n_valid[t] ? hi[a] : 0; b.max_abs = std::max(b.max_abs, std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a]))); }
-        node_total += b.n_nodes; leaf_total += b.n_leaves; n_max = std::max(n_max, mh[t].n_tris);
+        for (int a = 0; a < 3; a++) { b.lo[a] = nv ? lo[a] : 0; b.hi[a] = nv ? hi[a] : 0; b.max_abs = std::max(b.max_abs, std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a]))); }
+        n_max = std::max(n_max, mh[t].n_tris);
     }
+    ns->n_nodes = 0; ns->n_leaves = 0;
+    if (n_max == 0) { RTS_HIP(ns->d_nodes4.reserve(1)); RTS_HIP(ns->d_leaf_prim.reserve(1)); return RTS_OK; }
+
+    // ---- pass A: the split threshold of every mesh and its number of references (valid ones first after the sort)
+    DevBuf<double> d_acc; DevBuf<uint32_t> d_cnt, d_off, d_nvr; DevBuf<char> d_scan_tmp;
+    struct FreeA { DevBuf<double>& a; DevBuf<uint32_t>& b; DevBuf<uint32_t>& c1; DevBuf<uint32_t>& d; DevBuf<char>& e; ~FreeA() { a.release(); b.release(); c1.release(); d.release(); e.release(); } } free_a{d_acc, d_cnt, d_off, d_nvr, d_scan_tmp};
+    RTS_HIP(d_acc.reserve(2)); RTS_HIP(d_cnt.reserve(n_max)); RTS_HIP(d_off.reserve(n_max)); RTS_HIP(d_nvr.reserve(1));
+    size_t scan_tmp = 0;
+    RTS_HIP(rocprim::exclusive_scan(nullptr, scan_tmp, d_cnt.p, d_off.p, 0u, n_max, rocprim::plus<uint32_t>(), st));
+    RTS_HIP(d_scan_tmp.reserve(scan_tmp + 16));
+    std::vector<double> a_thr(n_targets, 0.0); std::vector<uint32_t> n_refs(n_targets, 0), n_valid(n_targets, 0);
+    auto count_refs = [&](uint32_t t) -> int {                       // cnt / off of mesh t (deterministic: pass B repeats it)
+        const uint32_t n = mh[t].n_tris;
+        const uint32_t* tv = ns->d_tri_vidx.p + 3 * (size_t)mh[t].tri_base;
+        RTS_HIP(hipMemsetAsync(d_nvr.p, 0, sizeof(uint32_t), st));
+        k_ref_count<<<blocks_for(n, 256), 256, 0, st>>>(tv, ns->d_verts_local.p, n, a_thr[t], d_cnt.p, d_nvr.p);
+        size_t tmp_n = scan_tmp;
+        RTS_HIP(rocprim::exclusive_scan(d_scan_tmp.p, tmp_n, d_cnt.p, d_off.p, 0u, n, rocprim::plus<uint32_t>(), st));
+        return RTS_OK;
+    };
+    uint64_t node_total = 0, leaf_total = 0; uint32_t r_max = 0;
+    for (uint32_t t = 0; t < n_targets; t++) {
+        const uint32_t n = mh[t].n_tris;
+        if (n == 0) continue;
+        const uint32_t* tv = ns->d_tri_vidx.p + 3 * (size_t)mh[t].tri_base;
+        RTS_HIP(hipMemsetAsync(d_acc.p, 0, 2 * sizeof(double), st));
+        k_tri_area<<<blocks_for(n, 256), 256, 0, st>>>(tv, ns->d_verts_local.p, n, d_acc.p);
+        double acc[2] = {0, 0};
+        RTS_HIP(hipMemcpyAsync(acc, d_acc.p, sizeof(acc), hipMemcpyDeviceToHost, st)); RTS_HIP(hipStreamSynchronize(st));
+        a_thr[t] = (split_budget > 0 && acc[1] > 0 && acc[0] > 0 && std::isfinite(acc[0])) ? (acc[0] / acc[1]) / ((1.0 + split_budget) * (1.0 + split_budget)) : 0.0;
+        { int rc = count_refs(t); if (rc != RTS_OK) return rc; }
+        uint32_t last[2] = {0, 0}, nvr = 0;
+        RTS_HIP(hipMemcpyAsync(&last[0], d_off.p + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        RTS_HIP(hipMemcpyAsync(&last[1], d_cnt.p + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        RTS_HIP(hipMemcpyAsync(&nvr, d_nvr.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st)); RTS_HIP(hipStreamSynchronize(st));
+        n_refs[t] = last[0] + last[1]; n_valid[t] = nvr;
+        RtsBlasInfo& b = ns->blas[t];
+        b.n_leaves = nvr; b.n_nodes = nvr == 0 ? 0 : std::max<uint32_t>(nvr - 1, 1);
+        node_total += b.n_nodes; leaf_total += b.n_leaves; r_max = std::max(r_max, n_refs[t]);
+    }
+    if (node_total > 0x7ffffff0ULL || leaf_total > 0x7ffffff0ULL) { rts_set_error("rts_set_scene: too many references"); return RTS_ERR_UNSUPPORTED; }
     RTS_HIP(ns->d_nodes4.reserve((size_t)node_total + 1)); RTS_HIP(ns->d_leaf_prim.reserve((size_t)leaf_total + 1));
     ns->n_nodes = (uint32_t)node_total; ns->n_leaves = (uint32_t)leaf_total;
-    if (n_max == 0) return RTS_OK;
-    DevBuf<float> d_prim_box; DevBuf<uint64_t> d_keys, d_keys_sorted; DevBuf<uint32_t> d_vals, d_vals_sorted, d_bounds, d_flags; DevBuf<int32_t> d_parent, d_leaf_parent;
+    if (r_max == 0) return RTS_OK;
+
+    // ---- pass B: boxes, codes, sort, tree, boxes of the tree, 4-wide records -- per mesh, over its references
+    DevBuf<float> d_prim_box; DevBuf<uint64_t> d_keys, d_keys_sorted; DevBuf<uint32_t> d_vals, d_vals_sorted, d_bounds, d_flags, d_ref_tri; DevBuf<int32_t> d_parent, d_leaf_parent;
     DevBuf<Node2> d_nodes2; DevBuf<int2> d_range; DevBuf<char> d_tmp;
-    struct Free { DevBuf<float>& a; DevBuf<uint64_t>& b; DevBuf<uint64_t>& b2; DevBuf<uint32_t>& c1; DevBuf<uint32_t>& c2; DevBuf<uint32_t>& c3; DevBuf<uint32_t>& c4; DevBuf<int32_t>& d1; DevBuf<int32_t>& d2; DevBuf<Node2>& e; DevBuf<int2>& f; DevBuf<char>& g;
-                  ~Free() { a.release(); b.release(); b2.release(); c1.release(); c2.release(); c3.release(); c4.release(); d1.release(); d2.release(); e.release(); f.release(); g.release(); } }
-        free_all{d_prim_box, d_keys, d_keys_sorted, d_vals, d_vals_sorted, d_bounds, d_flags, d_parent, d_leaf_parent, d_nodes2, d_range, d_tmp};
-    RTS_HIP(d_prim_box.reserve(6 * (size_t)n_max)); RTS_HIP(d_keys.reserve(n_max)); RTS_HIP(d_keys_sorted.reserve(n_max)); RTS_HIP(d_vals.reserve(n_max)); RTS_HIP(d_vals_sorted.reserve(n_max));
-    RTS_HIP(d_bounds.reserve(8)); RTS_HIP(d_flags.reserve(n_max)); RTS_HIP(d_parent.reserve(n_max)); RTS_HIP(d_leaf_parent.reserve(n_max)); RTS_HIP(d_nodes2.reserve(n_max)); RTS_HIP(d_range.reserve(n_max));
+    struct Free { DevBuf<float>& a; DevBuf<uint64_t>& b; DevBuf<uint64_t>& b2; DevBuf<uint32_t>& c1; DevBuf<uint32_t>& c2; DevBuf<uint32_t>& c3; DevBuf<uint32_t>& c4; DevBuf<uint32_t>& c5; DevBuf<int32_t>& d1; DevBuf<int32_t>& d2; DevBuf<Node2>& e; DevBuf<int2>& f; DevBuf<char>& g;
+                  ~Free() { a.release(); b.release(); b2.release(); c1.release(); c2.release(); c3.release(); c4.release(); c5.release(); d1.release(); d2.release(); e.release(); f.release(); g.release(); } }
+        free_all{d_prim_box, d_keys, d_keys_sorted, d_vals, d_vals_sorted, d_bounds, d_flags, d_ref_tri, d_parent, d_leaf_parent, d_nodes2, d_range, d_tmp};
+    RTS_HIP(d_prim_box.reserve(6 * (size_t)r_max)); RTS_HIP(d_keys.reserve(r_max)); RTS_HIP(d_keys_sorted.reserve(r_max)); RTS_HIP(d_vals.reserve(r_max)); RTS_HIP(d_vals_sorted.reserve(r_max)); RTS_HIP(d_ref_tri.reserve(r_max));
+    RTS_HIP(d_bounds.reserve(8)); RTS_HIP(d_flags.reserve(r_max)); RTS_HIP(d_parent.reserve(r_max)); RTS_HIP(d_leaf_parent.reserve(r_max)); RTS_HIP(d_nodes2.reserve(r_max)); RTS_HIP(d_range.reserve(r_max));
     size_t tmp = 0;
-    RTS_HIP(rocprim::radix_sort_pairs(nullptr, tmp, d_keys.p, d_keys_sorted.p, d_vals.p, d_vals_sorted.p, n_max, 0, 64, st));
+    RTS_HIP(rocprim::radix_sort_pairs(nullptr, tmp, d_keys.p, d_keys_sorted.p, d_vals.p, d_vals_sorted.p, r_max, 0, 64, st));
     RTS_HIP(d_tmp.reserve(tmp));
     int32_t node_base = 0, leaf_base = 0;
     for (uint32_t t = 0; t < n_targets; t++) {
-        const uint32_t n = mh[t].n_tris, nv = n_valid[t];
+        const uint32_t n = mh[t].n_tris, nr = n_refs[t], nv = n_valid[t];
         RtsBlasInfo& b = ns->blas[t];
         if (nv == 0) continue;
         static const uint32_t init_bounds[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
         RTS_HIP(hipMemcpyAsync(d_bounds.p, init_bounds, sizeof(init_bounds), hipMemcpyHostToDevice, st));
         const uint32_t* tv = ns->d_tri_vidx.p + 3 * (size_t)mh[t].tri_base;
-        k_prim_boxes<<<blocks_for(n, 256), 256, 0, st>>>(tv, ns->d_verts_local.p, d_prim_box.p, d_bounds.p, n);
-        k_morton<<<blocks_for(n, 256), 256, 0, st>>>(d_prim_box.p, d_bounds.p, d_keys.p, d_vals.p, n);
+        { int rc = count_refs(t); if (rc != RTS_OK) return rc; }
+        k_ref_boxes<<<blocks_for(n, 256), 256, 0, st>>>(tv, ns->d_verts_local.p, d_cnt.p, d_off.p, d_prim_box.p, d_ref_tri.p, d_bounds.p, n);
+        k_morton<<<blocks_for(nr, 256), 256, 0, st>>>(d_prim_box.p, d_bounds.p, d_keys.p, d_vals.p, nr);
         size_t tmp_n = tmp;
-        RTS_HIP(rocprim::radix_sort_pairs(d_tmp.p, tmp_n, d_keys.p, d_keys_sorted.p, d_vals.p, d_vals_sorted.p, n, 0, 64, st));
-        k_leaf_order<<<blocks_for(nv, 256), 256, 0, st>>>(d_vals_sorted.p, mh[t].tri_base, ns->d_leaf_prim.p + leaf_base, nv);
+        RTS_HIP(rocprim::radix_sort_pairs(d_tmp.p, tmp_n, d_keys.p, d_keys_sorted.p, d_vals.p, d_vals_sorted.p, nr, 0, 64, st));
+        k_leaf_order<<<blocks_for(nv, 256), 256, 0, st>>>(d_vals_sorted.p, d_ref_tri.p, mh[t].tri_base, ns->d_leaf_prim.p + leaf_base, nv);
         if (nv == 1) {
             k_single_leaf4<<<1, 1, 0, st>>>(d_prim_box.p, d_vals_sorted.p, ns->d_nodes4.p + node_base, leaf_base);
         } else {
