@@ -548,6 +548,16 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     RtsLaunchConsts& lc = c->last_lc; memset(&lc, 0, sizeof(lc));
     fill_launch_constants(lc, *p, W);
     lc.ray_first = first; lc.W = W; lc.il_tile = il_tile; lc.il_parts = il_parts; lc.il_part = il_part;
+    if (W >= 2) {                                                     // branch-free magic number of the division by W (libdivide's u32 scheme)
+        const uint32_t fl = 31u - (uint32_t)__builtin_clz(W);
+        if ((W & (W - 1)) == 0) { lc.w_magic = 0; lc.w_more = fl - 1; }
+        else {
+            const uint64_t k2 = 1ULL << (32 + fl); uint64_t pm = k2 / W; const uint64_t rem = k2 - pm * W;
+            pm += pm; const uint64_t tr = rem + rem;
+            if (tr >= W || tr < rem) pm += 1;
+            lc.w_magic = (uint32_t)(1 + pm); lc.w_more = fl;
+        }
+    }
     const bool pre_filter = c->use_pmask && !c->pre_dense;           // (a launch where most rays hit pays for the filter and skips nothing)
     fill_mask_frame(lc, pre_filter && c->scene->n_prims > 0);
     for (int k = 0; k < 3; k++) { lc.f_bs[k] = (float)(&lc.bsx)[k]; lc.f_st[k] = (float)(&lc.stx)[k]; }

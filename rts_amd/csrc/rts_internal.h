@@ -117,6 +117,7 @@ struct RtsLaunchConsts {
     double w1x, w1y, w1z;           // direction for W == 1
     uint64_t ray_first;
     uint32_t W, pad;
+    uint32_t w_magic, w_more;       // division by W (>= 2) without a divide: q = mulhi(magic, g); ((g - q) >> 1) + q >> more  (fill_launch_constants)
     uint32_t il_tile, il_parts, il_part, pad2;     // interleaved tiles (il_parts <= 1: contiguous)
     RtsMaskFrame mask;              // primary-ray mask frame (n = 0: no mask this launch)
     // f32 copies for the primary-ray PRE-FILTER (rts_trace.hip): beamStart, lattice step, Rot, Rot1

@@ -36,7 +36,12 @@ RTS_HD dvec3 rts_lattice_dir(const RtsLaunchConsts& a, uint32_t lx, uint32_t ly,
 __device__ __forceinline__ void rts_lattice_coords(const RtsLaunchConsts& a, uint32_t slot, uint32_t& lx, uint32_t& ly, uint32_t& lz)
 {
     const uint32_t g = (uint32_t)rts_global_index(a, slot);
-    const uint32_t q = g / a.W; lx = g - q * a.W; lz = q / a.W; ly = q - lz * a.W;
+    // two divisions by the launch constant W: multiply-shift with host-made constants (exact for every 32-bit g; a hardware
+    // u32 division is ~35 VALU instructions, and a launch index that hits nothing has little else to do)
+    const uint32_t m = a.w_magic, s = a.w_more;
+    const uint32_t t0 = __umulhi(m, g), q = (((g - t0) >> 1) + t0) >> s;
+    const uint32_t t1 = __umulhi(m, q); lz = (((q - t1) >> 1) + t1) >> s;
+    lx = g - q * a.W; ly = q - lz * a.W;
 }
 
 __device__ __forceinline__ dvec3 rts_primary_dir(const RtsLaunchConsts& a, uint32_t slot)
