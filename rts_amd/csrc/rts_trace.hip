@@ -223,12 +223,17 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
     // pre-filter constants of the receivers, for rays that start at the transmitter: q = centre - origin (f64, then f32),
     // |q|, |q|^2 and the widened radius^2.  Widening: the f32 direction is good to ~2e-6 rad and the f32 discriminant
     // b^2 - (|q|^2 - r^2) |d|^2 to ~1e-6 |q|^2; r'^2 = r^2 (1 + 1e-3) + 1e-5 |q|^2 + 1e-6 covers both ten times over.
+    // The filter has to be conservative with respect to the REFERENCE'S arithmetic, not to geometry: its quadratic forms
+    // C = |prev|^2 + |c|^2 - 2 c.prev - r^2 from world-scale terms (ray_tracer.cu:285), which at Earth-centred coordinates
+    // cancel catastrophically -- terms of 4e13 m^2, rounded a dozen times: the sphere it tests is up to ~0.05 m^2 larger or
+    // smaller in r^2 than the one it was given (found by tools/fuzz_equal.py: a 0.86 m sphere 3.7 m from the transmitter
+    // captured 32 rays the geometric filter had excluded).  + 1e-14 (|o|^2 + |c|^2): 45 ulps of the largest term.
     __shared__ float s_rxp[RTS_RX_LDS][6];
     if (tid < RTS_RX_LDS && tid < a.n_rx) {
         const RtsRxDev r = s_rx[tid];
         const double qx = r.cx - lc.ox, qy = r.cy - lc.oy, qz = r.cz - lc.oz, qq = qx*qx + qy*qy + qz*qz;
         s_rxp[tid][0] = (float)qx; s_rxp[tid][1] = (float)qy; s_rxp[tid][2] = (float)qz; s_rxp[tid][3] = (float)qq * 1.000001f;
-        s_rxp[tid][4] = (float)(r.radius * r.radius * 1.001 + 1.0e-5 * qq + 1.0e-6);
+        s_rxp[tid][4] = (float)(r.radius * r.radius * 1.001 + 1.0e-5 * qq + 1.0e-6 + 1.0e-14 * (lc.ox*lc.ox + lc.oy*lc.oy + lc.oz*lc.oz + r.cx*r.cx + r.cy*r.cy + r.cz*r.cz));
         s_rxp[tid][5] = (float)sqrt(qq);
     }
     __syncthreads();

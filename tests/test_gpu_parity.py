@@ -1012,7 +1012,7 @@ def test_primary_prefilter_is_invisible(rts, scenes):
         _all_equal(a, b, name)
         assert np.array_equal(ra["slots"], rb["slots"]) and np.array_equal(ra["path"], rb["path"]), name
         H.assert_prd_equal(ra["results"], rb["results"], name + " (received)")
-        assert (sa["segments"], sa["shaded"], sa["received"], sa["tri_tests"]) == (sb["segments"], sb["shaded"], sb["received"], sb["tri_tests"]), name
+        assert (sa["segments"], sa["shaded"], sa["received"]) == (sb["segments"], sb["shaded"], sb["received"]) and sa["tri_tests"] <= sb["tri_tests"], name
         if engaged is True:
             assert sa["node_visits"] < sb["node_visits"], (name, sa["node_visits"], sb["node_visits"])
         elif engaged is False:
@@ -1035,3 +1035,18 @@ def test_primary_prefilter_switches_off_when_most_rays_hit(rts, scenes):
     st = [tr.trace(tx["origin"], tx["span"], tx["dir"], c3["motion"]) for _ in range(3)]
     assert st[0]["node_visits"] > st[1]["node_visits"] == st[2]["node_visits"] and st[0]["segments"] == st[2]["segments"]
     tr.close()
+
+
+def test_differential_fuzz_seeds(rts):
+    """tools/fuzz_equal.py on a few seeds (random soups / beams / receivers near the origin, far away and at Earth-centred
+    coordinates): host and device trees, with and without slab references, with and without the primary-ray pre-filter
+    must produce the same bits.  Seed 12661 is the scene that showed the receiver pre-filter must be conservative with
+    respect to the REFERENCE'S cancelling quadratic, not to geometry (a 0.86 m sphere 3.7 m from a transmitter at 6.4e6 m)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_equal as F
+    for seed in (12661, 7, 1234, 20011, 20500, 31337):
+        spec, place, aim = F.random_scene(seed)
+        a = F.run(spec); b = F.run(spec, pre_filter=False); c = F.run(spec, device_build=True)
+        F.same(a, b, "seed %d: pre-filter on / off" % seed)
+        F.same(a, c, "seed %d: host / device tree" % seed)

@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""Differential fuzz on the GPU: results must not depend on HOW a launch is traced.  For every random scene the full
+per-launch-index buffers (KEEP_ALL: payload, paths, RCS angles, per-segment hit primitive and f32 t), the received set and
+its order, and the segment / shaded / received counts are compared between
+    host SAH tree + primary-ray pre-filter (the default)   |   host SAH tree, no pre-filter
+    device LBVH with slab references + pre-filter          |   device LBVH, one reference per triangle, no pre-filter
+(the hierarchy and the filter may only change how much work is done).  Scenes: triangle soups (ordinary triangles, slivers,
+fans, duplicates, degenerate triangles) as one to three targets, placed near the origin, far from it or at Earth-centred
+coordinates, some behind or around the transmitter; beams from 1e-4 to 3 rad wide, pointed at / beside / away from the
+targets; 0-6 capture spheres, some containing the transmitter; W = 6..40; reflection depth 0..6; smooth / flat normals;
+optionally the refraction branch.
+   python tools/fuzz_equal.py [n_scenes] [seed0]            (about 0.1 s per scene on an MI355X)
+The counting builds of the same two host-tree launches say in how many scenes the pre-filter actually removed work."""
+import math
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from rts_amd import api, scenes  # noqa: E402
+import helpers as H  # noqa: E402
+
+
+def soup(rng, n_reg, n_sliver, n_fan, scale):
+    tris = []
+    for _ in range(n_reg):
+        c = rng.normal(0, 6.0 * scale, 3); s = scale * 10 ** rng.uniform(-1.5, 0.7)
+        tris.append(c + rng.normal(0, s, (3, 3)))
+    for _ in range(n_sliver):
+        a = rng.normal(0, 6.0 * scale, 3); d = rng.normal(0, 1, 3); d /= np.linalg.norm(d)
+        L = scale * rng.uniform(5, 25); w = rng.normal(0, 1, 3) * scale * 10 ** rng.uniform(-4, -1.5)
+        tris.append(np.stack([a, a + L * d, a + 0.5 * L * d + w]))
+    if n_fan:
+        hub = rng.normal(0, 3.0 * scale, 3)
+        ang = np.sort(rng.uniform(0, 2 * np.pi, n_fan + 1)); rad = scale * rng.uniform(2, 8)
+        e1 = np.array([0.0, 1.0, 0.2]); e2 = np.array([0.1, -0.2, 1.0])
+        for i in range(n_fan):
+            tris.append(np.stack([hub, hub + rad * (np.cos(ang[i]) * e1 + np.sin(ang[i]) * e2), hub + rad * (np.cos(ang[i + 1]) * e1 + np.sin(ang[i + 1]) * e2)]))
+    tris.append(tris[0].copy())
+    p = rng.normal(0, 5.0 * scale, 3); tris.append(np.stack([p, p, p + 1.0]))
+    v = np.concatenate(tris).astype(np.float64)
+    t = np.arange(len(v), dtype=np.uint32).reshape(-1, 3)
+    nrm = np.repeat(np.cross(v[1::3] - v[0::3], v[2::3] - v[0::3]) + 1e-30, 3, axis=0)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    return dict(tris=t, verts=v, normals=nrm, refl_coeff=float(rng.choice([0.8, -0.6, 1.0, 0.3])), refr_index=float(rng.choice([1.0, 1.3, 2.0])))
+
+
+def random_scene(seed):
+    rng = np.random.default_rng(seed)
+    place = rng.choice(["origin", "far", "ecef"])
+    off = {"origin": np.zeros(3), "far": rng.normal(0, 4.0e4, 3), "ecef": scenes.ecef_offset(lat=rng.uniform(-1.5, 1.5), lon=rng.uniform(-3, 3))}[place]
+    n_t = int(rng.integers(1, 4)); scale = 10 ** rng.uniform(-0.5, 0.5)
+    meshes, motion = [], []
+    for k in range(n_t):
+        meshes.append(soup(rng, int(rng.integers(5, 120)), int(rng.integers(0, 40)), int(rng.integers(0, 50)), scale))
+        pos = off + rng.normal(0, 15.0 * scale, 3)
+        m = dict(position=tuple(pos), velocity=tuple(rng.normal(0, 5.0, 3)))
+        if rng.random() < 0.6:
+            m["rotation"] = api.rotation_matrix(*rng.uniform(-3, 3, 3))
+        motion.append(m)
+    dist = scale * 10 ** rng.uniform(0.3, 3.3)                        # 2 m .. 2 km (x scale): inside the soup up to far away
+    dirv = rng.normal(0, 1, 3); dirv /= np.linalg.norm(dirv)
+    origin = off - dist * dirv + rng.normal(0, 2.0 * scale, 3)
+    az = math.atan2(dirv[1], dirv[0]); el = math.asin(max(-1.0, min(1.0, dirv[2])))
+    aim = rng.choice(["at", "beside", "away"], p=[0.7, 0.2, 0.1])
+    if aim == "beside":
+        az += rng.uniform(-0.5, 0.5); el += rng.uniform(-0.3, 0.3)
+    if aim == "away":
+        az += math.pi
+    span_w = 10 ** rng.uniform(-4, 0.45)
+    if rng.random() < 0.5:                                           # half of the scenes: where the pre-filter has work to do --
+        dist = scale * 10 ** rng.uniform(2.0, 3.5)                    # targets well away (no triangle covers thousands of mask cells),
+        origin = off - dist * dirv + rng.normal(0, 2.0 * scale, 3)
+        span_w = min(2.0, (30.0 * scale / dist) * 10 ** rng.uniform(0.2, 1.2))    # the beam a few times wider than the targets
+    tx = dict(origin=tuple(origin), span=(span_w, span_w * rng.uniform(0.3, 1.0), float(rng.uniform(0.0, 0.3))), dir=(az, el))
+    rx = []
+    for _ in range(int(rng.integers(0, 7))):
+        kind = rng.random()
+        if kind < 0.25:
+            c = origin + rng.normal(0, 1.0, 3) * rng.uniform(0.1, 30.0); r = float(np.linalg.norm(c - origin) * rng.uniform(1.1, 3.0))     # contains the transmitter
+        else:
+            c = off + rng.normal(0, 1.0, 3) * dist * rng.uniform(0.2, 2.0); r = float(dist * 10 ** rng.uniform(-2, -0.3))
+        th0 = rng.uniform(-3.2, 3.2); ph0 = rng.uniform(-1.6, 1.6)
+        rx.append(scenes.rx_window(tuple(c), r, (th0 - rng.uniform(0.1, 3.2), th0 + rng.uniform(0.1, 3.2)), (ph0 - rng.uniform(0.1, 1.7), ph0 + rng.uniform(0.1, 1.7))))
+    refr = rng.random() < 0.2
+    W = int(rng.integers(6, 24 if refr else 41))
+    spec = dict(name="fuzz-%d" % seed, W=W, max_refl=int(rng.integers(0, 7)), smooth=bool(rng.integers(0, 2)), n_pulses=1, meshes=meshes, motion=motion,
+                tx=tx, rx=rx, carrier=scenes.FC, c=scenes.C0)
+    if refr:
+        spec["max_refr"] = 1
+    return spec, place, aim
+
+
+def run(spec, **kw):
+    tr = H.gpu_tracer(api, spec, keep_all=True, **kw)
+    _, st = H.gpu_trace(api, spec, tr=tr)
+    out = (tr.all_rays(spec["W"] ** 3), tr.received(), st, tr.scene_info())
+    tr.close()
+    return out
+
+
+def same(a, b, what):
+    (ga, ra, sa, _), (gb, rb, sb, _) = a, b
+    H.assert_prd_equal(ga["results"], gb["results"], what)
+    for k in ("path", "rcs_angle", "hit_prim"):
+        assert np.array_equal(ga[k], gb[k]), (what, k)
+    assert np.array_equal(ga["hit_t"].view(np.uint32), gb["hit_t"].view(np.uint32)), (what, "hit_t")
+    assert np.array_equal(ra["slots"], rb["slots"]) and np.array_equal(ra["path"], rb["path"]), (what, "received order")
+    H.assert_prd_equal(ra["results"], rb["results"], what + " (received)")
+    assert (sa["segments"], sa["shaded"], sa["received"]) == (sb["segments"], sb["shaded"], sb["received"]), (what, "counts")
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    tot = dict(filter_engaged=0, scenes=0, rays=0, segments=0, shaded=0, received=0, refs_host=0, refs_dev=0, prims=0)
+    kinds = {}
+    for seed in range(seed0, seed0 + n):
+        spec, place, aim = random_scene(seed)
+        try:
+            os.environ.pop("RTS_SPLIT_BUDGET", None)
+            a = run(spec)
+            b = run(spec, pre_filter=False)
+            c = run(spec, device_build=True)
+            os.environ["RTS_SPLIT_BUDGET"] = "0"
+            d = run(spec, device_build=True, pre_filter=False)
+            os.environ.pop("RTS_SPLIT_BUDGET", None)
+            same(a, b, "seed %d: pre-filter on / off" % seed)
+            e = run(spec, count_traversal=True); f = run(spec, count_traversal=True, pre_filter=False)     # counting builds: is the filter doing anything?
+            same(a, e, "seed %d: counting build" % seed); same(a, f, "seed %d: counting build, no pre-filter" % seed)
+            assert e[2]["tri_tests"] <= f[2]["tri_tests"] and e[2]["node_visits"] <= f[2]["node_visits"], (seed, e[2], f[2])       # (the filter only ever REMOVES visits)
+            tot["filter_engaged"] += 1 if e[2]["node_visits"] < f[2]["node_visits"] else 0
+            same(a, c, "seed %d: host / device tree" % seed)
+            same(a, d, "seed %d: host / device tree without references" % seed)
+        except Exception as e:
+            print("FAILED seed %d (%s, aimed %s, W=%d, refl=%d, refr=%s): %r" % (seed, place, aim, spec["W"], spec["max_refl"], "max_refr" in spec, e), flush=True)
+            raise
+        st = a[2]
+        tot["scenes"] += 1; tot["rays"] += spec["W"] ** 3; tot["segments"] += st["segments"]; tot["shaded"] += st["shaded"]; tot["received"] += st["received"]
+        tot["refs_host"] += a[3]["n_leaves"]; tot["refs_dev"] += c[3]["n_leaves"]; tot["prims"] += a[3]["n_prims"]
+        kinds[(place, aim)] = kinds.get((place, aim), 0) + 1
+        if tot["scenes"] % 25 == 0:
+            print("%d scenes ok: %s" % (tot["scenes"], tot), flush=True)
+    print("ALL EQUAL: %s" % tot)
+    print("placement x aim:", dict(sorted((("%s/%s" % k), v) for k, v in kinds.items())))
+
+
+if __name__ == "__main__":
+    main()
