@@ -82,6 +82,13 @@ struct Ray { f3 origin; f3 direction; float tmin; float tmax; };
 
 // ------------------------------------------------------------------ small vector helpers
 // ray_tracer.cu:72-122, normal_shader.cu:48-115, triangle_mesh.cu:39-94
+// libm's sin and cos, ONE call per function: GCC merges sin(x) and cos(x) of the same argument into a single sincos(x)
+// (also through libstdc++'s __builtin_sinf / __builtin_cosf, which -fno-builtin-* does not reach), and glibc's sincos does
+// not promise the bits of its separate sin and cos.  The product's host code (clang) calls them separately; so does this.
+static __attribute__((noinline)) double orc_sin(double x) { return sin(x); }
+static __attribute__((noinline)) double orc_cos(double x) { return cos(x); }
+static __attribute__((noinline)) float orc_sinf(float x) { return sinf(x); }
+static __attribute__((noinline)) float orc_cosf(float x) { return cosf(x); }
 static inline d3 to_double3(double x, double y, double z) { d3 o; o.x = x; o.y = y; o.z = z; return o; }
 static inline d3 operator+(d3 a, d3 b) { return to_double3(a.x + b.x, a.y + b.y, a.z + b.z); }
 static inline d3 operator-(d3 a, d3 b) { return to_double3(a.x - b.x, a.y - b.y, a.z - b.z); }
@@ -368,7 +375,7 @@ static bool angle_in_range(double testAngle, double a, double b)
     return std::fabs(a - b) < M_PI;
 }
 static inline d3 sph_to_cart(double azi, double ele) {      // ray_tracer.cu:132-139
-    d3 cart; cart.x = std::cos(azi)*std::cos(ele); cart.y = std::sin(azi)*std::cos(ele); cart.z = std::sin(ele); return cart;
+    d3 cart; cart.x = orc_cos(azi)*orc_cos(ele); cart.y = orc_sin(azi)*orc_cos(ele); cart.z = orc_sin(ele); return cart;
 }
 static inline d2 cart_to_sph(d3 in) {                       // normal_shader.cu:118-124
     d2 sph; sph.x = std::atan2(in.y, in.x); sph.y = std::atan2(in.z, std::sqrt(in.x*in.x + in.y*in.y)); return sph;
@@ -668,8 +675,8 @@ static void ray_generation(OTraceCtx& cx, uint64_t localIndex, unsigned lx, unsi
         rayDir_d3.y = beamStart.y + ((beamEnd.y - beamStart.y)/(d_width - 1)) * (ly);
         rayDir_d3.z = beamStart.z + ((beamEnd.z - beamStart.z)/(d_width - 1)) * (lz);
         rayDir_d3 = normalised3(rayDir_d3);
-        double Rot[3][3] = {{std::cos(d_txDir.x), -std::sin(d_txDir.x), 0},
-                            {std::sin(d_txDir.x), std::cos(d_txDir.x), 0},
+        double Rot[3][3] = {{orc_cos(d_txDir.x), -orc_sin(d_txDir.x), 0},
+                            {orc_sin(d_txDir.x), orc_cos(d_txDir.x), 0},
                             {0, 0, 1}};
         d3 rotated; rotated.x = 0; rotated.y = 0; rotated.z = 0;
         rotated.x += Rot[0][0]*rayDir_d3.x + Rot[0][1]*rayDir_d3.y + Rot[0][2]*rayDir_d3.z;
@@ -681,9 +688,9 @@ static void ray_generation(OTraceCtx& cx, uint64_t localIndex, unsigned lx, unsi
         rotated.y += Rot[1][1];
         rotated.z += Rot[2][1];
         d3 orth_vec = normalised3(rotated);
-        double Rot1[3][3] = {{std::cos(d_txDir.y) + orth_vec.x*orth_vec.x*(1 - std::cos(d_txDir.y)), orth_vec.x*orth_vec.y*(1 - std::cos(d_txDir.y)) + orth_vec.z*std::sin(d_txDir.y), orth_vec.x*orth_vec.z*(1 - std::cos(d_txDir.y)) - orth_vec.y*std::sin(d_txDir.y)},
-                             {orth_vec.y*orth_vec.x*(1 - std::cos(d_txDir.y)) - orth_vec.z*std::sin(d_txDir.y), std::cos(d_txDir.y) + orth_vec.y*orth_vec.y*(1 - std::cos(d_txDir.y)), orth_vec.y*orth_vec.z*(1 - std::cos(d_txDir.y)) + orth_vec.x*std::sin(d_txDir.y)},
-                             {orth_vec.z*orth_vec.x*(1 - std::cos(d_txDir.y)) + orth_vec.y*std::sin(d_txDir.y), orth_vec.z*orth_vec.y*(1 - std::cos(d_txDir.y)) - orth_vec.x*std::sin(d_txDir.y), std::cos(d_txDir.y) + orth_vec.z*orth_vec.z*(1 - std::cos(d_txDir.y))}};
+        double Rot1[3][3] = {{orc_cos(d_txDir.y) + orth_vec.x*orth_vec.x*(1 - orc_cos(d_txDir.y)), orth_vec.x*orth_vec.y*(1 - orc_cos(d_txDir.y)) + orth_vec.z*orc_sin(d_txDir.y), orth_vec.x*orth_vec.z*(1 - orc_cos(d_txDir.y)) - orth_vec.y*orc_sin(d_txDir.y)},
+                             {orth_vec.y*orth_vec.x*(1 - orc_cos(d_txDir.y)) - orth_vec.z*orc_sin(d_txDir.y), orc_cos(d_txDir.y) + orth_vec.y*orth_vec.y*(1 - orc_cos(d_txDir.y)), orth_vec.y*orth_vec.z*(1 - orc_cos(d_txDir.y)) + orth_vec.x*orc_sin(d_txDir.y)},
+                             {orth_vec.z*orth_vec.x*(1 - orc_cos(d_txDir.y)) + orth_vec.y*orc_sin(d_txDir.y), orth_vec.z*orth_vec.y*(1 - orc_cos(d_txDir.y)) - orth_vec.x*orc_sin(d_txDir.y), orc_cos(d_txDir.y) + orth_vec.z*orth_vec.z*(1 - orc_cos(d_txDir.y))}};
         rotated.x = 0; rotated.y = 0; rotated.z = 0;
         rotated.x += Rot1[0][0]*rayDir_d3.x + Rot1[0][1]*rayDir_d3.y + Rot1[0][2]*rayDir_d3.z;
         rotated.y += Rot1[1][0]*rayDir_d3.x + Rot1[1][1]*rayDir_d3.y + Rot1[1][2]*rayDir_d3.z;
@@ -823,9 +830,9 @@ float orc_libm_atan2f(float y, float x) { return atan2f(y, x); }
 void orc_rx_sphere(const double* repos, double az, double el, double radius, double thetaSpan, double phiSpan, double* out9)
 {
     double h_Rx_azimuth = az, h_Rx_elevation = el;
-    double cx = repos[0] + (radius * cosf(h_Rx_elevation) * cosf(h_Rx_azimuth));
-    double cy = repos[1] + (radius * cosf(h_Rx_elevation) * sinf(h_Rx_azimuth));
-    double cz = repos[2] + (radius * sinf(h_Rx_elevation));
+    double cx = repos[0] + (radius * orc_cosf(h_Rx_elevation) * orc_cosf(h_Rx_azimuth));
+    double cy = repos[1] + (radius * orc_cosf(h_Rx_elevation) * orc_sinf(h_Rx_azimuth));
+    double cz = repos[2] + (radius * orc_sinf(h_Rx_elevation));
     h_Rx_azimuth = atan2f((repos[1] - cy), (repos[0] - cx));
     h_Rx_elevation = atan2f((repos[2] - cz), sqrt((repos[0] - cx)*(repos[0] - cx) + (repos[1] - cy)*(repos[1] - cy)));
     out9[0] = cx; out9[1] = cy; out9[2] = cz; out9[3] = radius;
@@ -848,9 +855,9 @@ static Mat matrix_transpose(Mat M1) {
     return M2;
 }
 static Mat vertex_rotation(Mat vertices, float yaw, float pitch, float roll) {
-    Mat Rx = {{1, 0, 0}, {0, std::cos(roll), -std::sin(roll)}, {0, std::sin(roll), std::cos(roll)}};
-    Mat Ry = {{std::cos(pitch), 0, std::sin(pitch)}, {0, 1, 0}, {-std::sin(pitch), 0, std::cos(pitch)}};
-    Mat Rz = {{std::cos(yaw), -std::sin(yaw), 0}, {std::sin(yaw), std::cos(yaw), 0}, {0, 0, 1}};
+    Mat Rx = {{1, 0, 0}, {0, orc_cosf(roll), -orc_sinf(roll)}, {0, orc_sinf(roll), orc_cosf(roll)}};
+    Mat Ry = {{orc_cosf(pitch), 0, orc_sinf(pitch)}, {0, 1, 0}, {-orc_sinf(pitch), 0, orc_cosf(pitch)}};
+    Mat Rz = {{orc_cosf(yaw), -orc_sinf(yaw), 0}, {orc_sinf(yaw), orc_cosf(yaw), 0}, {0, 0, 1}};
     Mat R_total = matrix_multiply(Rz, matrix_multiply(Ry, Rx));
     if (vertices.empty()) return vertices;
     return matrix_transpose(matrix_multiply(R_total, matrix_transpose(vertices)));

@@ -9,7 +9,8 @@ fans, duplicates, degenerate triangles) as one to three targets, placed near the
 coordinates, some behind or around the transmitter; beams from 1e-4 to 3 rad wide, pointed at / beside / away from the
 targets; 0-6 capture spheres, some containing the transmitter; W = 6..40; reflection depth 0..6; smooth / flat normals;
 optionally the refraction branch.
-   python tools/fuzz_equal.py [n_scenes] [seed0]            (about 0.1 s per scene on an MI355X)
+   python tools/fuzz_equal.py [n_scenes] [seed0] [--oracle]  (about 0.1 s per scene on an MI355X; --oracle adds the comparison of
+                                                              the default launch with the CPU restatement's brute force)
 The counting builds of the same two host-tree launches say in how many scenes the pre-filter actually removed work."""
 import math
 import os
@@ -112,9 +113,20 @@ def same(a, b, what):
     assert (sa["segments"], sa["shaded"], sa["received"]) == (sb["segments"], sb["shaded"], sb["received"]), (what, "counts")
 
 
+def against_oracle(spec, a):
+    """the default GPU launch against the CPU restatement in BRUTE-FORCE mode (every triangle tested for every segment)"""
+    from oracle import oracle as O
+    rows = spec["max_refl"] + 3 if spec.get("max_refr", 0) else 1
+    o = H.oracle_trace(O, spec, use_bvh=False, threads=min(32, os.cpu_count() or 1))
+    H.compare_full(o, a[0], spec["W"] ** 3 * rows)
+    assert a[2]["segments"] == o["counters"]["segments"] and a[2]["shaded"] == o["counters"]["shaded"], (a[2], o["counters"])
+
+
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    args = [x for x in sys.argv[1:] if not x.startswith("--")]
+    with_oracle = "--oracle" in sys.argv                             # also: the default launch against the oracle's brute force (CPU, slower)
+    n = int(args[0]) if len(args) > 0 else 200
+    seed0 = int(args[1]) if len(args) > 1 else 1
     tot = dict(filter_engaged=0, scenes=0, rays=0, segments=0, shaded=0, received=0, refs_host=0, refs_dev=0, prims=0)
     kinds = {}
     for seed in range(seed0, seed0 + n):
@@ -134,6 +146,8 @@ def main():
             tot["filter_engaged"] += 1 if e[2]["node_visits"] < f[2]["node_visits"] else 0
             same(a, c, "seed %d: host / device tree" % seed)
             same(a, d, "seed %d: host / device tree without references" % seed)
+            if with_oracle:
+                against_oracle(spec, a)
         except Exception as e:
             print("FAILED seed %d (%s, aimed %s, W=%d, refl=%d, refr=%s): %r" % (seed, place, aim, spec["W"], spec["max_refl"], "max_refr" in spec, e), flush=True)
             raise
