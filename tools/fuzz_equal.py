@@ -102,6 +102,33 @@ def run(spec, **kw):
     return out
 
 
+def moved(spec, rng):
+    """the same scene one pulse later: every target displaced and turned a little (or a lot)"""
+    sp = dict(spec); sp["motion"] = []
+    big = rng.random() < 0.3
+    for m in spec["motion"]:
+        mm = dict(m); mm["position"] = tuple(np.asarray(m["position"]) + rng.normal(0, 30.0 if big else 0.3, 3))
+        if rng.random() < 0.7:
+            mm["rotation"] = api.rotation_matrix(*rng.uniform(-3, 3, 3)) if big else api.rotation_matrix(*(rng.normal(0, 0.02, 3)))
+        sp["motion"].append(mm)
+    return sp
+
+
+def pulses_on_one_handle(spec, seed):
+    """three pulses on ONE handle (tile-cost history, adaptive pre-filter switch, placement buffers and mask carried from
+    pulse to pulse) against fresh handles without the pre-filter"""
+    rng = np.random.default_rng(seed + 7777777)
+    tr = H.gpu_tracer(api, spec, keep_all=True)
+    sp = spec
+    for k in range(3):
+        _, st = H.gpu_trace(api, sp, tr=tr, motion=sp["motion"])
+        got = (tr.all_rays(spec["W"] ** 3), tr.received(), st, None)
+        if k:
+            same(got, run(sp, pre_filter=False), "seed %d: pulse %d on a used handle" % (seed, k))
+        sp = moved(sp, rng)
+    tr.close()
+
+
 def same(a, b, what):
     (ga, ra, sa, _), (gb, rb, sb, _) = a, b
     H.assert_prd_equal(ga["results"], gb["results"], what)
@@ -148,6 +175,8 @@ def main():
             same(a, d, "seed %d: host / device tree without references" % seed)
             if with_oracle:
                 against_oracle(spec, a)
+            if seed % 4 == 0:
+                pulses_on_one_handle(spec, seed)
         except Exception as e:
             print("FAILED seed %d (%s, aimed %s, W=%d, refl=%d, refr=%s): %r" % (seed, place, aim, spec["W"], spec["max_refl"], "max_refr" in spec, e), flush=True)
             raise
