@@ -48,14 +48,25 @@ def soup(rng, n_reg, n_sliver, n_fan, scale):
     return dict(tris=t, verts=v, normals=nrm, refl_coeff=float(rng.choice([0.8, -0.6, 1.0, 0.3])), refr_index=float(rng.choice([1.0, 1.3, 2.0])))
 
 
-def random_scene(seed):
+def random_scene(seed, version=3):
+    """versions 1, 2: the generator as it was when the regression seeds of tests/test_gpu_parity.py were found (1: as first
+    written; 2: + the scenes biased towards an active pre-filter; 3: + many targets / receivers, NaN vertices, W = 1, deep chains)"""
     rng = np.random.default_rng(seed)
+    v2 = version >= 3; friendly = version >= 2
     place = rng.choice(["origin", "far", "ecef"])
     off = {"origin": np.zeros(3), "far": rng.normal(0, 4.0e4, 3), "ecef": scenes.ecef_offset(lat=rng.uniform(-1.5, 1.5), lon=rng.uniform(-3, 3))}[place]
     n_t = int(rng.integers(1, 4)); scale = 10 ** rng.uniform(-0.5, 0.5)
+    many_targets = v2 and rng.random() < 0.08
+    if many_targets:
+        n_t = int(rng.integers(8, 40))                                # the linear loop over the targets' hierarchies
     meshes, motion = [], []
     for k in range(n_t):
-        meshes.append(soup(rng, int(rng.integers(5, 120)), int(rng.integers(0, 40)), int(rng.integers(0, 50)), scale))
+        if many_targets:
+            meshes.append(soup(rng, int(rng.integers(1, 12)), int(rng.integers(0, 4)), int(rng.integers(0, 5)), scale))
+        else:
+            meshes.append(soup(rng, int(rng.integers(5, 120)), int(rng.integers(0, 40)), int(rng.integers(0, 50)), scale))
+        if v2 and rng.random() < 0.05:                                # a vertex that is not a number: its triangles can never be hit
+            meshes[-1]["verts"][int(rng.integers(0, len(meshes[-1]["verts"])))] = np.nan
         pos = off + rng.normal(0, 15.0 * scale, 3)
         m = dict(position=tuple(pos), velocity=tuple(rng.normal(0, 5.0, 3)))
         if rng.random() < 0.6:
@@ -71,13 +82,13 @@ def random_scene(seed):
     if aim == "away":
         az += math.pi
     span_w = 10 ** rng.uniform(-4, 0.45)
-    if rng.random() < 0.5:                                           # half of the scenes: where the pre-filter has work to do --
+    if friendly and rng.random() < 0.5:                              # half of the scenes: where the pre-filter has work to do --
         dist = scale * 10 ** rng.uniform(2.0, 3.5)                    # targets well away (no triangle covers thousands of mask cells),
         origin = off - dist * dirv + rng.normal(0, 2.0 * scale, 3)
         span_w = min(2.0, (30.0 * scale / dist) * 10 ** rng.uniform(0.2, 1.2))    # the beam a few times wider than the targets
     tx = dict(origin=tuple(origin), span=(span_w, span_w * rng.uniform(0.3, 1.0), float(rng.uniform(0.0, 0.3))), dir=(az, el))
     rx = []
-    for _ in range(int(rng.integers(0, 7))):
+    for _ in range(int(rng.integers(17, 48)) if (v2 and rng.random() < 0.08) else int(rng.integers(0, 7))):      # (> 16 receivers: beyond the LDS copy, no pre-filter)
         kind = rng.random()
         if kind < 0.25:
             c = origin + rng.normal(0, 1.0, 3) * rng.uniform(0.1, 30.0); r = float(np.linalg.norm(c - origin) * rng.uniform(1.1, 3.0))     # contains the transmitter
@@ -87,7 +98,9 @@ def random_scene(seed):
         rx.append(scenes.rx_window(tuple(c), r, (th0 - rng.uniform(0.1, 3.2), th0 + rng.uniform(0.1, 3.2)), (ph0 - rng.uniform(0.1, 1.7), ph0 + rng.uniform(0.1, 1.7))))
     refr = rng.random() < 0.2
     W = int(rng.integers(6, 24 if refr else 41))
-    spec = dict(name="fuzz-%d" % seed, W=W, max_refl=int(rng.integers(0, 7)), smooth=bool(rng.integers(0, 2)), n_pulses=1, meshes=meshes, motion=motion,
+    if v2 and rng.random() < 0.03:
+        W = 1                                                         # the single boresight ray (ray_tracer.cu:160-161)
+    spec = dict(name="fuzz-%d" % seed, W=W, max_refl=int(rng.integers(0, 7)) if (not v2 or rng.random() < 0.9) else int(rng.integers(7, 15)), smooth=bool(rng.integers(0, 2)), n_pulses=1, meshes=meshes, motion=motion,
                 tx=tx, rx=rx, carrier=scenes.FC, c=scenes.C0)
     if refr:
         spec["max_refr"] = 1
