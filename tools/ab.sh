@@ -1,4 +1,4 @@
-# same-box A/B: variants/librts_before.so vs the tree's build.  usage: tools/_ab.sh <tag>
+# same-box A/B: variants/librts_before.so vs the tree's build.  usage: tools/ab.sh <tag>
 cd $GRAFT_REPO_ROOT
 T=${1:-ab}
 for w in c3 c3narrow c3empty c3 c3narrow; do
