@@ -201,6 +201,16 @@ def build_adapter_binary(out_path):
     return out_path
 
 
+def test_adapter_bench_compiles(rts, tmp_path):
+    """tests/adapter/adapter_bench.cpp (the C++ boundary timed end to end) builds against the header and the library"""
+    import subprocess
+    out = str(tmp_path / "adapter_bench")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tests", "adapter"),
+                           os.path.join(ROOT, "tests", "adapter", "adapter_bench.cpp"), "-L", os.path.join(ROOT, "rts_amd"), "-lrts_amd",
+                           "-Wl,-rpath," + os.path.join(ROOT, "rts_amd"), "-o", out])
+    assert os.path.exists(out)
+
+
 def test_adapter_header_compiles_and_links(rts, tmp_path):
     """the rs::RTS replacement (header-only, templated on the simulator's types) builds with a plain host
     compiler against the C-ABI and resolves rs::kernel_wrapper from librts_amd.so"""
