@@ -82,6 +82,8 @@ struct RunOptions {
                                    //        ray_tracer.cpp:843); true: EVERY pulse is split over all handle sets in interleaved
                                    //        tiles (rays are independent, ray_tracer.cu:227-253) and its received rays merged
                                    //        on the host in launch-index order -- the way to use N GPUs for ONE pulse
+    unsigned flags = 0;            // RtsParams.flags of every handle: RTS_FLAG_DEVICE_BUILD builds the hierarchy on the GPU in milliseconds
+                                   // (a CPI of a few hundred pulses is over before the host SAH build of a large scene has paid for itself)
     RtsStats* last_stats = nullptr;
 };
 
@@ -96,7 +98,7 @@ void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlo
     const auto rts_vars = Tr::Params::GetRTSVariables();                       // ray_tracer.cpp:600-605
     RtsParams params{};
     params.width = rts_vars.x; params.max_refl = rts_vars.y; params.max_refr = rts_vars.z > 0 ? 2u : 0u;
-    params.interpolate_smooth = Tr::Params::interpolate_smooth() ? 1u : 0u; params.flags = 0;
+    params.interpolate_smooth = Tr::Params::interpolate_smooth() ? 1u : 0u; params.flags = opt.flags;
     const unsigned D = params.max_refr + params.max_refl;
     const uint64_t launchTotal = (uint64_t)params.width * params.width * params.width;
     const uint64_t rayTotal = launchTotal * (params.max_refr ? params.max_refl + 3 : 1);

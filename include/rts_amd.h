@@ -55,7 +55,7 @@ typedef struct RtsParams {
                                      launch index) plus the per-segment hit trace -- parity/debug */
 #define RTS_FLAG_DEVICE_BUILD 4u  /* rts_set_scene builds the hierarchy ON THE DEVICE (LBVH: slab-split references, Morton codes,
                                      radix sort, Karras hierarchy, bottom-up boxes, 4-wide collapse) instead of the host SAH
-                                     builder: set-up in milliseconds, traversal ~15 % slower; same node format, same results (the f64 triangle
+                                     builder: set-up in milliseconds, traversal 15-40 % slower; same node format, same results (the f64 triangle
                                      test alone decides hits).  The environment variable RTS_BUILDER=device|host overrides. */
 #define RTS_FLAG_NO_PREFILTER 8u   /* primary rays skip the conservative f32 pre-filter (direction mask over the placed triangles +
                                      widened receiver spheres) that lets rays which can meet nothing bypass the exact ray

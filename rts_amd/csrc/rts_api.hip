@@ -220,7 +220,10 @@ extern "C" int rts_set_scene(RtsHandle c, const RtsMesh* meshes, uint32_t n_targ
     const auto t_build0 = std::chrono::steady_clock::now();
     bool device_build = (c->params.flags & RTS_FLAG_DEVICE_BUILD) != 0;
     { const char* e = getenv("RTS_BUILDER"); if (e) device_build = (strcmp(e, "device") == 0); }
-    double split_budget = 2.0;                              // extra references for triangles whose boxes are mostly empty (rts_sah.cpp, rts_lbvh.hip)
+    // extra references for triangles whose boxes are mostly empty (rts_sah.cpp, rts_lbvh.hip).  The host builder spends its budget
+    // where a split saves box area (2 measured best); the device builder's rule looks at box size alone and also cuts well-shaped
+    // triangles: 1 is the better compromise there (C3 0.92 ms against 0.87 at 2, a uniformly tessellated sphere 0.76 against 0.85)
+    double split_budget = device_build ? 1.0 : 2.0;
     { const char* e = getenv("RTS_SPLIT_BUDGET"); if (e) { const double v = atof(e); if (v >= 0 && v <= 8) split_budget = v; } }
     if (device_build) {
         int rc = rts_lbvh_build_device(c, ns, vidx, mh, split_budget); if (rc != RTS_OK) return rc;

@@ -3,7 +3,7 @@
 // icosphere target of 20 * 4^subdivs triangles (6 -> 81 920: the scale of BASELINE configs[2]) that moves every pulse, four
 // receivers, the simulator's RCS / gain callbacks on the host for every received ray, aggregation and Response emission
 // per pulse -- everything rs::RTS does per CPI (ray_tracer.cpp:806-1336).
-//   adapter_bench [W=216] [pulses=64] [in_flight=3] [subdivs=6] [maxRefl=6]
+//   adapter_bench [W=216] [pulses=64] [in_flight=3] [subdivs=6] [maxRefl=6] [device_build=0]
 // prints one JSON line: run times for `pulses` and 4 x `pulses`, the marginal ms per pulse, the set-up per run, Mrays/s.
 #include <chrono>
 #include <cmath>
@@ -32,6 +32,7 @@ int main(int argc, char** argv)
     w.transmitters = {&tx}; w.receivers = {&rx[0], &rx[1], &rx[2], &rx[3]}; w.targets = {&s};
     RtsStats st{};
     rts_amd::RunOptions opt; opt.in_flight = in_flight; opt.devices.assign(1, 0); opt.last_stats = &st;
+    if (argc > 6 && atoi(argv[6])) opt.flags |= RTS_FLAG_DEVICE_BUILD;                                   // [device_build=0]
     // run 0: a few pulses (first launches of a handle: cold caches, tiles in index order); runs 1 and 2: `pulses` and 4 x `pulses`
     // pulses -- every run() sets the scene up again (meshes, hierarchy), as rs::RTS does per call, so the difference of the two
     // gives the marginal cost of a pulse and the rest is the set-up
