@@ -306,29 +306,41 @@ __global__ void __launch_bounds__(RF_THREADS) k_refit(const float* __restrict__ 
     }
 }
 
-// BVH2 -> BVH4: record i holds, for BVH2 node i, the children of its internal children (boxes taken from the children's own
-// records) and its leaf children as they are.  Child links become global: node_base + BVH2 index, ~(leaf_base + position).
-// Unused slots: the degenerate box lo = hi = 3e38 (rts_sah.cpp: new_node).
+// BVH2 -> BVH4: record i holds up to four descendants of BVH2 node i -- its two children, then, while there is room, the
+// INTERNAL one with the largest box opened into ITS two children (greedy by surface area: the child most likely to be hit
+// is the one worth a wider record; a leaf child cannot be opened, so a fixed "open both children" pattern left records
+// near the leaves half empty).  Child links become global: node_base + BVH2 index, ~(leaf_base + position); records of BVH2
+// nodes that no record refers to are never visited.  Unused slots: the degenerate box lo = hi = 3e38 (rts_sah.cpp: new_node).
 __global__ void k_collapse4(const Node2* __restrict__ nodes, RtsNode4* __restrict__ nodes4, int n_nodes, int32_t node_base, int32_t leaf_base)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
-    const Node2 nd = nodes[i];
+    int c[4]; float b[4][6]; int m = 0;
+    auto take = [&](const Node2& nd) {
+        c[m] = nd.c0; b[m][0] = nd.lo0x; b[m][1] = nd.lo0y; b[m][2] = nd.lo0z; b[m][3] = nd.hi0x; b[m][4] = nd.hi0y; b[m][5] = nd.hi0z; m++;
+        c[m] = nd.c1; b[m][0] = nd.lo1x; b[m][1] = nd.lo1y; b[m][2] = nd.lo1z; b[m][3] = nd.hi1x; b[m][4] = nd.hi1y; b[m][5] = nd.hi1z; m++;
+    };
+    take(nodes[i]);
+    while (m < 4) {
+        int best = -1; float best_a = -1.0f;
+        for (int k = 0; k < m; k++) {
+            if (c[k] < 0) continue;                                                     // a leaf
+            const float ex = b[k][3] - b[k][0], ey = b[k][4] - b[k][1], ez = b[k][5] - b[k][2];
+            const float a = ex * ey + ey * ez + ex * ez;
+            if (a > best_a) { best_a = a; best = k; }
+        }
+        if (best < 0) break;
+        const Node2 ch = nodes[c[best]];
+        c[best] = c[m - 1]; for (int q = 0; q < 6; q++) b[best][q] = b[m - 1][q];       // remove it (swap with the last) ...
+        m--;
+        take(ch);                                                                       // ... and append its two children
+    }
     RtsNode4 o;
     for (int k = 0; k < 4; k++) { o.lox[k] = o.loy[k] = o.loz[k] = 3.0e38f; o.hix[k] = o.hiy[k] = o.hiz[k] = 3.0e38f; o.child[k] = 0x7fffffff; o.pad[k] = 0; }
-    int m = 0;
-    auto put = [&](int c, float lx, float ly, float lz, float hx, float hy, float hz) {
-        o.lox[m] = lx; o.loy[m] = ly; o.loz[m] = lz; o.hix[m] = hx; o.hiy[m] = hy; o.hiz[m] = hz;
-        o.child[m] = c >= 0 ? c + node_base : ~(~c + leaf_base); m++;
-    };
-    auto expand = [&](int c, float lx, float ly, float lz, float hx, float hy, float hz) {
-        if (c < 0) { put(c, lx, ly, lz, hx, hy, hz); return; }
-        const Node2 ch = nodes[c];
-        put(ch.c0, ch.lo0x, ch.lo0y, ch.lo0z, ch.hi0x, ch.hi0y, ch.hi0z);
-        put(ch.c1, ch.lo1x, ch.lo1y, ch.lo1z, ch.hi1x, ch.hi1y, ch.hi1z);
-    };
-    expand(nd.c0, nd.lo0x, nd.lo0y, nd.lo0z, nd.hi0x, nd.hi0y, nd.hi0z);
-    expand(nd.c1, nd.lo1x, nd.lo1y, nd.lo1z, nd.hi1x, nd.hi1y, nd.hi1z);
+    for (int k = 0; k < m; k++) {
+        o.lox[k] = b[k][0]; o.loy[k] = b[k][1]; o.loz[k] = b[k][2]; o.hix[k] = b[k][3]; o.hiy[k] = b[k][4]; o.hiz[k] = b[k][5];
+        o.child[k] = c[k] >= 0 ? c[k] + node_base : ~(~c[k] + leaf_base);
+    }
     nodes4[i] = o;
 }
 
