@@ -128,7 +128,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--link", action="store_true", help="rts_link_handles: the handles' trace kernels run strictly one at a time")
     ap.add_argument("--inflight", type=int, default=3, help="pulses in flight per GPU; 1 = strictly sequential pulses")
-    ap.add_argument("--config", default="c3", choices=["c2", "c2file", "c3", "c3ecef"])
+    ap.add_argument("--config", default="c3", choices=["c2", "c2file", "c3", "c3ecef", "c3ico"])
     ap.add_argument("--shard", default="pulses", choices=["pulses", "rays"], help="N > 1: deal whole pulses to the ranks, or split every pulse over all ranks (interleaved tiles)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks")
     args = ap.parse_args()
@@ -160,6 +160,8 @@ def main():
         spec = scenes.config3(W=args.width or 216)
     elif args.config == "c3ecef":
         spec = scenes.translate(scenes.config3(W=args.width or 216), scenes.ecef_offset(lat=math.pi / 2))
+    elif args.config == "c3ico":                                  # the same airframe tessellated without pole fans (secondary line)
+        spec = scenes.config3(W=args.width or 216, ico=True)
     elif args.config == "c2":
         spec = scenes.config2(W=args.width or 100)
     else:
@@ -291,7 +293,7 @@ def main():
         V = sc["node_visits"] / max(sc["segments"], 1); T = sc["tri_tests"] / max(sc["segments"], 1); Hh = sc["shaded"] / max(sc["segments"], 1)
         # (3) dense control: the beam squeezed onto the fuselage, (nearly) every launch index hits and bounces
         dense = None
-        if args.config in ("c3", "c3ecef"):
+        if args.config in ("c3", "c3ecef", "c3ico"):
             dtx = dict(tx, span=(0.004, 0.004, 0.1)); dn = []
             for k in range(5):
                 st = trs[0].trace(dtx["origin"], dtx["span"], dtx["dir"], pulse_motion(spec, args.warmup + k))

@@ -76,6 +76,29 @@ def aircraft_mesh(scale=1.0, detail=1.0):
     return _merge(parts)
 
 
+def _ico_ellipsoid(subdivs, semi, centre=(0, 0, 0)):
+    """ellipsoid from the library's icosphere (20 * 4^subdivs triangles, no poles: every vertex has valence 5 or 6), analytic
+    unit normals"""
+    v, t, _ = api.sphere_mesh(subdivs, 1.0)
+    abc = np.array(semi, np.float64)
+    unit = v / np.linalg.norm(v, axis=1, keepdims=True)
+    nrm = unit / abc
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    return unit * abc + np.array(centre, np.float64), t.astype(np.uint32), nrm
+
+
+def aircraft_mesh_ico(scale=1.0):
+    """the same four ellipsoids as aircraft_mesh, tessellated from icospheres: 81 920 + 3 x 5 120 = 97 280 triangles, and no
+    pole fans (the lat-long ellipsoids of aircraft_mesh end in fans of 100-250 slivers around one vertex, whose boxes all
+    overlap there: the rays through a pole are the slowest tiles of a C3 launch)"""
+    return _merge([
+        _ico_ellipsoid(6, (15.0 * scale, 1.8 * scale, 1.8 * scale)),
+        _ico_ellipsoid(4, (2.5 * scale, 16.0 * scale, 0.35 * scale), centre=(1.0 * scale, 0, -0.3 * scale)),
+        _ico_ellipsoid(4, (1.2 * scale, 5.5 * scale, 0.2 * scale), centre=(-13.0 * scale, 0, 0.4 * scale)),
+        _ico_ellipsoid(4, (1.8 * scale, 0.2 * scale, 3.2 * scale), centre=(-13.0 * scale, 0, 2.5 * scale)),
+    ])
+
+
 def plate_mesh(size):
     """Two-triangle square plate in the local y-z plane facing -x (file_mesh-style unshared vertices)."""
     h = size / 2.0
@@ -119,9 +142,10 @@ def config2(subdiv=5, W=100, rx_radius=50.0):
                 rx=[_rx_at((-1000.0, 0.0, 0.0), (0, 0, 0), rx_radius, math.pi / 2)], carrier=FC, c=C0)
 
 
-def config3(W=216, detail=1.0, rx_radius=50.0, n_rx=4):
-    """C3: aircraft-like mesh, 100 000 triangles, 1 Tx / 4 Rx on a 2 km arc, W = 216, 6 bounces, 256 pulses."""
-    v, t, n = aircraft_mesh(detail=detail)
+def config3(W=216, detail=1.0, rx_radius=50.0, n_rx=4, ico=False):
+    """C3: aircraft-like mesh, 100 000 triangles, 1 Tx / 4 Rx on a 2 km arc, W = 216, 6 bounces, 256 pulses.
+    ico: the pole-free tessellation of the same shape (aircraft_mesh_ico, 97 280 triangles)."""
+    v, t, n = aircraft_mesh_ico() if ico else aircraft_mesh(detail=detail)
     # broadside-ish aspect: ~15 % of the beam's launch indices hit the airframe (stated with every result)
     R = api.rotation_matrix(math.radians(70.0), math.radians(5.0), math.radians(35.0)).reshape(3, 3)
     v = v @ R.T; n = n @ R.T

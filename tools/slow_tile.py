@@ -6,8 +6,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from rts_amd import api, scenes  # noqa: E402
-tiles = [int(x) for x in sys.argv[1:]] or [83452, 82689, 81989]
-spec = scenes.config3()
+args = sys.argv[1:]
+which = args.pop(0) if args and not args[0].isdigit() else "c3"        # python tools/slow_tile.py [c3|c4|c5] [tile ...]
+tiles = [int(x) for x in args] or ([83452, 82689, 81989] if which == "c3" else [786329, 786322])
+spec = scenes.config4() if which == "c4" else scenes.config5() if which == "c5" else scenes.config3()
 tr = api.Tracer(spec["W"], spec["max_refl"], 0, spec["smooth"], count_traversal=True)
 tr.set_scene(spec["meshes"]); tr.set_receivers(spec["rx"]); tx = spec["tx"]
 for t in tiles:

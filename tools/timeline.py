@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Block / tile timeline of one k_trace launch (debug): RTS_TIMELINE=<file> makes the counting build dump, per block,
 its start and end tick (100 MHz wall clock) and, per tile of 256 launch indices, the tile's duration.
-   python tools/timeline.py [c3|c3narrow|c2]"""
+   python tools/timeline.py [c3|c3narrow|c2|c4|c5]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,7 +11,7 @@ os.makedirs(os.path.dirname(out), exist_ok=True)
 os.environ["RTS_TIMELINE"] = out
 from rts_amd import api, scenes  # noqa: E402
 which = sys.argv[1] if len(sys.argv) > 1 else "c3"
-spec = scenes.config2(rx_radius=200.0) if which == "c2" else scenes.config3()
+spec = scenes.config2(rx_radius=200.0) if which == "c2" else scenes.config4() if which == "c4" else scenes.config5() if which == "c5" else scenes.config3()
 if which == "c3narrow":
     spec["tx"] = dict(spec["tx"], span=(0.004, 0.004, 0.1))
 tr = api.Tracer(spec["W"], spec["max_refl"], 0, spec["smooth"], count_traversal=True)

@@ -16,7 +16,7 @@ from rts_amd import api, scenes  # noqa: E402
 which = sys.argv[1] if len(sys.argv) > 1 else "c3"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 spec = {"c2": lambda: scenes.config2(rx_radius=200.0), "c3": lambda: scenes.config3(rx_radius=50.0),
-        "c3s": lambda: scenes.config3(W=100, rx_radius=50.0), "c3nomesh": lambda: scenes.config3(rx_radius=50.0),
+        "c3s": lambda: scenes.config3(W=100, rx_radius=50.0), "c3ico": lambda: scenes.config3(rx_radius=50.0, ico=True), "c3iconarrow": lambda: scenes.config3(rx_radius=50.0, ico=True), "c3nomesh": lambda: scenes.config3(rx_radius=50.0),
         "c3norx": lambda: scenes.config3(rx_radius=50.0), "c3empty": lambda: scenes.config3(rx_radius=50.0), "c3narrow": lambda: scenes.config3(rx_radius=50.0),
         "c3ecef": lambda: scenes.translate(scenes.config3(rx_radius=50.0), scenes.ecef_offset(lat=math.pi / 2)),
         "c3narrowecef": lambda: scenes.translate(scenes.config3(rx_radius=50.0), scenes.ecef_offset(lat=math.pi / 2)),
@@ -27,7 +27,7 @@ if which == "c3empty":
     spec["meshes"] = []; spec["motion"] = []; spec["rx"] = []
 if which == "c3norx":
     spec["rx"] = []
-if which in ("c3narrow", "c3narrowecef"):          # beam squeezed onto the fuselage: nearly every ray hits
+if which in ("c3narrow", "c3narrowecef", "c3iconarrow"):          # beam squeezed onto the fuselage: nearly every ray hits
     spec["tx"] = dict(spec["tx"], span=(0.004, 0.004, 0.1))
 tr = api.Tracer(spec["W"], spec["max_refl"], 0, spec["smooth"])
 tr.set_scene(spec["meshes"]); tr.set_receivers(spec["rx"])
