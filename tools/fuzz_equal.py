@@ -48,7 +48,7 @@ def soup(rng, n_reg, n_sliver, n_fan, scale):
     return dict(tris=t, verts=v, normals=nrm, refl_coeff=float(rng.choice([0.8, -0.6, 1.0, 0.3])), refr_index=float(rng.choice([1.0, 1.3, 2.0])))
 
 
-def random_scene(seed, version=3):
+def random_scene(seed, version=3, big=False):
     """versions 1, 2: the generator as it was when the regression seeds of tests/test_gpu_parity.py were found (1: as first
     written; 2: + the scenes biased towards an active pre-filter; 3: + many targets / receivers, NaN vertices, W = 1, deep chains)"""
     rng = np.random.default_rng(seed)
@@ -64,7 +64,8 @@ def random_scene(seed, version=3):
         if many_targets:
             meshes.append(soup(rng, int(rng.integers(1, 12)), int(rng.integers(0, 4)), int(rng.integers(0, 5)), scale))
         else:
-            meshes.append(soup(rng, int(rng.integers(5, 120)), int(rng.integers(0, 40)), int(rng.integers(0, 50)), scale))
+            k_big = 12 if big else 1                                   # --big: soups of a few thousand triangles
+            meshes.append(soup(rng, int(rng.integers(5, 120)) * k_big, int(rng.integers(0, 40)) * k_big, int(rng.integers(0, 50)) * k_big, scale))
         if v2 and rng.random() < 0.05:                                # a vertex that is not a number: its triangles can never be hit
             meshes[-1]["verts"][int(rng.integers(0, len(meshes[-1]["verts"])))] = np.nan
         pos = off + rng.normal(0, 15.0 * scale, 3)
@@ -98,6 +99,8 @@ def random_scene(seed, version=3):
         rx.append(scenes.rx_window(tuple(c), r, (th0 - rng.uniform(0.1, 3.2), th0 + rng.uniform(0.1, 3.2)), (ph0 - rng.uniform(0.1, 1.7), ph0 + rng.uniform(0.1, 1.7))))
     refr = rng.random() < 0.2
     W = int(rng.integers(6, 24 if refr else 41))
+    if big:
+        W = int(rng.integers(20, 36 if refr else 65))
     if v2 and rng.random() < 0.03:
         W = 1                                                         # the single boresight ray (ray_tracer.cu:160-161)
     spec = dict(name="fuzz-%d" % seed, W=W, max_refl=int(rng.integers(0, 7)) if (not v2 or rng.random() < 0.9) else int(rng.integers(7, 15)), smooth=bool(rng.integers(0, 2)), n_pulses=1, meshes=meshes, motion=motion,
@@ -164,13 +167,14 @@ def against_oracle(spec, a):
 
 def main():
     args = [x for x in sys.argv[1:] if not x.startswith("--")]
+    big = "--big" in sys.argv                                        # thousands of triangles per target, W up to 64
     with_oracle = "--oracle" in sys.argv                             # also: the default launch against the oracle's brute force (CPU, slower)
     n = int(args[0]) if len(args) > 0 else 200
     seed0 = int(args[1]) if len(args) > 1 else 1
     tot = dict(filter_engaged=0, scenes=0, rays=0, segments=0, shaded=0, received=0, refs_host=0, refs_dev=0, prims=0)
     kinds = {}
     for seed in range(seed0, seed0 + n):
-        spec, place, aim = random_scene(seed)
+        spec, place, aim = random_scene(seed, big=big)
         try:
             os.environ.pop("RTS_SPLIT_BUDGET", None)
             a = run(spec)
