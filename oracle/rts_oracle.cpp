@@ -37,6 +37,9 @@
 //        output rows are indexed by the local sample number and the refraction row stride
 //        W^3 (normal_shader.cu:214) becomes the local ray count.  With the full launch the
 //        layout is exactly the reference's.
+//   [D4] sin / cos (ray_generation's launch-constant trigonometry, the mesh and receiver builders) are CUDA device
+//        functions there (bits unknowable); here they are glibc's, called ONE AT A TIME (orc_sin ...): a compiler that
+//        merges sin(x), cos(x) into sincos(x) changes last bits, and the product's host code calls them separately.
 // =====================================================================================
 #include <algorithm>
 #include <array>
