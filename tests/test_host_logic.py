@@ -6,6 +6,7 @@ import ctypes as C
 import math
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -276,3 +277,16 @@ def test_product_trace_kernels_use_no_scratch():
         assert scratch == 0 and vspill == 0, (name, scratch, vspill)
         assert lds * 4 <= 160 * 1024 and occ >= 2, (name, lds, occ)          # four blocks of four waves per CU
     assert seen == 4
+
+
+def test_fuzz_generator_versions_are_frozen(rts):
+    """the regression seeds of test_differential_fuzz_seeds name scenes through tools/fuzz_equal.random_scene(seed, version):
+    the old generator versions must keep producing the scenes the bugs were found in"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_equal as F
+    sp, place, aim = F.random_scene(12661, 1)
+    assert (place, aim, sp["W"], sp["max_refl"], len(sp["rx"])) == ("ecef", "at", 31, 4, 1)
+    assert abs(sp["rx"][0]["radius"] - 0.8559495751013925) < 1e-15 and abs(sp["tx"]["origin"][0] + 868346.5622011841) < 1e-6
+    sp, place, aim = F.random_scene(50301, 2)
+    assert (place, aim, sp["W"], sp["max_refl"], len(sp["rx"])) == ("far", "at", 37, 2, 5)
+    assert sp["tx"]["span"][0] == 1.400077894938366                 # the beam start whose cosine glibc's sincos and cos disagree on
