@@ -453,7 +453,7 @@ extern "C" int rts_reserve(RtsHandle c, uint64_t n_rays)
     RTS_HIP(c->d_recv.reserve((size_t)n * chains + 1)); RTS_HIP(c->d_counters.reserve(16)); RTS_HIP(c->d_lc.reserve(1));
     RTS_HIP(c->d_dir_hist.reserve((size_t)(c->params.max_refr ? 3 * H : std::max<uint32_t>(c->params.max_refl, 1)) * 3 * n + 4));
     if (c->params.max_refr) RTS_HIP(c->d_child.reserve(2 * threads));
-    RTS_HIP(c->d_stack_ovf.reserve((size_t)RTS_STACK_OVF * (size_t)c->n_cu * 4 * RTS_BLOCK));
+    RTS_HIP(c->d_stack_ovf.reserve((size_t)RTS_STACK_OVF * (size_t)c->n_cu * 1024));
     RTS_HIP(c->d_block_counters.reserve((size_t)c->n_cu * 64 * 8));
     const size_t n_tiles = (size_t)((n + RTS_WTILE - 1) / RTS_WTILE), n_hist = (size_t)((W3 + RTS_WTILE - 1) / RTS_WTILE);
     RTS_HIP(c->d_tile_ctr.reserve(RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE)); RTS_HIP(c->d_tile_cost.reserve(n_tiles)); RTS_HIP(c->d_tile_key.reserve(n_tiles)); RTS_HIP(c->d_tile_key_sorted.reserve(n_tiles));
@@ -545,7 +545,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     const int grid_mult = c->grid_mult, grid_spare = shared_gpu ? c->grid_spare : 0;   // blocks per CU: 4 = exactly the resident set (waves draw tiles from a queue); block slots left free
     // the trace kernel's blocks are persistent and four of them fill a CU's register file: leave a few block slots free so
     // that the short kernels of the neighbouring pulses (other streams) are not locked out for the whole launch
-    uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)n + RTS_BLOCK - 1) / RTS_BLOCK, (uint64_t)std::max<int>(c->n_cu * grid_mult - grid_spare * c->n_cu / 256, c->n_cu));   // (grid_spare: block slots per 256 CUs; 160 measured best with three pulses in flight: 0.709 vs 0.735 ms/pulse at 64)
+    uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)n + RTS_BLOCK - 1) / RTS_BLOCK, (uint64_t)std::max<int>((c->n_cu * grid_mult - grid_spare * c->n_cu / 256) * (256 / RTS_BLOCK), c->n_cu));   // (grid_spare: block slots per 256 CUs; 160 measured best with three pulses in flight: 0.709 vs 0.735 ms/pulse at 64)
     if (grid == 0) grid = 1;
     RtsTraceArgs a; memset(&a, 0, sizeof(a));
     RtsLaunchConsts& lc = c->last_lc; memset(&lc, 0, sizeof(lc));

@@ -72,14 +72,20 @@ struct __attribute__((aligned(16))) RtsChildState {
 };
 static_assert(sizeof(RtsChildState) == 128, "child state size");
 
+#ifndef RTS_BLOCK
 #define RTS_BLOCK 256
+#endif
 #define RTS_WTILE 64               // work unit of the trace kernel: launch indices per wave tile
 #ifndef RTS_TILE_CTRS
 #define RTS_TILE_CTRS 64           // striped draw counters of the tile queue
 #endif
 #define RTS_TILE_CTR_STRIDE 32     // ... one per 128-byte line: same-LINE atomics serialise in L2 (~10 ns each) whatever their address
+#ifndef RTS_STACK_LDS
 #define RTS_STACK_LDS 24            // traversal stack entries kept in LDS per lane
+#endif
+#ifndef RTS_RX_LDS
 #define RTS_RX_LDS 16               // receivers whose capture spheres the trace kernel keeps in LDS (the rest are read from memory)
+#endif
 #define RTS_STACK_OVF 128           // further entries spilled to global memory (rare); a BVH4 node pushes up to 3 entries
 
 // Launch constants of ray_generation (hoisted trig, ray_tracer.cu:155-203).  Device resident and
