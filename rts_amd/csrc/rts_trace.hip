@@ -250,18 +250,19 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
     if (COUNT && a.timeline && tid == 0) { tl_t0 = wall_clock64(); a.timeline[(size_t)blockIdx.x * 2] = tl_t0; }
     // Work units are WAVE TILES of 64 consecutive launch indices, taken by the waves one at a time from RTS_TILE_CTRS
     // striped counters: wave w draws k = atomicAdd(ctr[w % C]) and traces position k*C + (w % C) of the tile order.  Tile
-    // durations are extremely skewed (median ~7 us: every ray misses; 99.9th percentile ~0.5 ms; a handful near 1 ms where
-    // rays cross fans of thin triangles), so an in-order sweep left a ~1 ms tail in which a few waves finished their slow
-    // tiles on an otherwise idle GPU.  Pulses of an interval look alike, so every launch records what each tile cost
+    // durations are extremely skewed (median ~2.5 us: every ray misses; 99.9th percentile ~0.3 ms; a handful near 0.9 ms whose
+    // rays bounce six times through a hundred steps each), so an in-order sweep left a ~1 ms tail in which a few waves finished
+    // their slow tiles on an otherwise idle GPU.  Pulses of an interval look alike, so every launch records what each tile cost
     // (tile_cost, shader clocks >> 6) and the next launches of the handle trace the tiles in descending order of the cost
     // last seen (tile_order, built by rts_tile_order_build): longest-processing-time-first list scheduling.  Striping the
-    // counter keeps same-address atomics (~10 ns each) off the critical path: 157 k fetches over 64 addresses.
+    // counter -- ONE 128-byte line per stripe (RTS_TILE_CTR_STRIDE): atomics on one line serialise in L2 at ~10 ns each
+    // whatever their address -- keeps the draws off the critical path: 69 k of them per launch over 64 lines.
     const uint32_t n_tiles = (a.n_rays + 63u) / 64u;
     const uint32_t lane = tid & 63u;
     const uint32_t stripe = __builtin_amdgcn_readfirstlane((blockIdx.x * (RTS_BLOCK / 64u) + (tid >> 6)) % RTS_TILE_CTRS);   // wave-uniform: the queue arithmetic below stays scalar
     // Draw schedule of a stripe (positions k*C + stripe, k = 0, 1, ...): the first quarter -- the expensive end of the
-    // order -- one tile per draw, the cheap rest four tiles per draw (a miss-only tile is ~7 us of work, a draw ~2 us of
-    // latency).  The next draw is issued before the current tiles are traced, so its latency hides behind them.
+    // order -- one tile per draw, the cheap rest four tiles per draw (a miss-only tile is ~2 us of work, and so is a draw's
+    // latency).  In the cheap part the next draw is issued before the current tiles are traced, so its latency hides behind them.
     const uint32_t per_stripe = (n_tiles + RTS_TILE_CTRS - 1u) / RTS_TILE_CTRS;
     const uint32_t single_draws = per_stripe >= 1024u ? per_stripe / 4u : per_stripe;      // (short queues: one tile per draw throughout)
     // The pending draw is held in a register of lane 0 (so that its latency hides behind the tiles traced meanwhile) -- except
