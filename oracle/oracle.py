@@ -40,6 +40,9 @@ class OPulse(C.Structure):
                 ("interpolate_smooth", C.c_uint32)]
 
 
+RCS_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double)
+GAIN_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double)
+
 _lib = None
 
 
@@ -76,6 +79,10 @@ def lib():
         L.orc_filter_finalise.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_double,
                                           C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
                                           C.c_void_p]
+        L.orc_filter_finalise_cb.restype = C.c_uint64
+        L.orc_filter_finalise_cb.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int,
+                                             C.c_double, C.c_double, C.c_double, C.c_double, RCS_FN, GAIN_FN, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_aggregate_literal.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_double, C.c_double] + \
                                            [C.c_void_p] * 6
         L.orc_unique_paths.restype = C.c_uint
@@ -207,6 +214,20 @@ def filter_finalise(results, path, rcs_per_target, wavelength, gt, gr, carrier, 
     rcs = np.ascontiguousarray(rcs_per_target, np.float64)
     R = lib().orc_filter_finalise(_p(np.ascontiguousarray(results)), _p(np.ascontiguousarray(path)), n, D, _p(rcs),
                                   wavelength, gt, gr, carrier, cspeed, _p(rx), _p(rxi), _p(slots))
+    return rx[:R].copy(), rxi[:R].copy(), slots[:R].copy()
+
+
+def filter_finalise_cb(results, path, rcs_angle, origin, rx_positions, tx_index, time_t, wavelength, carrier, cspeed, get_rcs, get_gain):
+    """ray_tracer.cpp:1190-1258 with the simulator's callbacks:
+    get_rcs(targ, az, el, wl) -> float; get_gain(is_rx, index, (vx, vy, vz), rot_time, wl) -> float"""
+    n = results.shape[0]; D = path.shape[1]
+    rx = np.zeros(n, PRD_DTYPE); rxi = np.zeros((n, D), np.int32); slots = np.zeros(n, np.uint64)
+    cb_r = RCS_FN(lambda user, targ, az, el, wl: float(get_rcs(targ, az, el, wl)))
+    cb_g = GAIN_FN(lambda user, is_rx, index, vx, vy, vz, t, wl: float(get_gain(is_rx, index, (vx, vy, vz), t, wl)))
+    o = np.ascontiguousarray(origin, np.float64); rp = np.ascontiguousarray(rx_positions, np.float64)
+    R = lib().orc_filter_finalise_cb(_p(np.ascontiguousarray(results)), _p(np.ascontiguousarray(path)),
+                                     _p(np.ascontiguousarray(rcs_angle, np.float64)), n, D, _p(o), _p(rp), tx_index, time_t,
+                                     wavelength, carrier, cspeed, cb_r, cb_g, None, _p(rx), _p(rxi), _p(slots))
     return rx[:R].copy(), rxi[:R].copy(), slots[:R].copy()
 
 

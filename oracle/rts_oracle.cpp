@@ -1008,6 +1008,56 @@ uint64_t orc_filter_finalise(const PerRayData* results, const int* targ_intersec
     return receivedRays;
 }
 
+// ---------------------------------------------------------------- ray_tracer.cpp:1190-1258 with the simulator's callbacks
+// The same loop with everything the reference asks SOARS for handed over as callbacks, so that tests can give antennas and
+// targets patterns that depend on every argument: transvec / recvvec (:1204-1211; the direct-ray branch uses the Rx
+// position, NOT the end point), GetRCS(rcs_angle.x, rcs_angle.y, Wl) per intersected depth (:1219-1230),
+// GetGain(transvec, trans->GetRotation(time_t), Wl) and GetGain(recvvec, recv->GetRotation(delay + time_t), Wl) (:1233-1235).
+// SVec3 is a SOARS type (absent from the reference): the callbacks get the Cartesian vector the reference constructs it
+// from -- its length is overwritten with 1 (:1217-1218) -- and the time the rotation is asked at.
+typedef double (*orc_rcs_fn)(void* user, int targ, double az, double el, double wl);
+typedef double (*orc_gain_fn)(void* user, int is_rx, int index, double vx, double vy, double vz, double rot_time, double wl);
+uint64_t orc_filter_finalise_cb(const PerRayData* results, const int* targ_intersect, const double* rcs_angle /* [rayTotal][D][2] */,
+                                uint64_t rayTotal, uint32_t D, const double* h_rayOrigin, const double* rx_positions /* [n_rx][3] */,
+                                int tx_index, double time_t, double Wl, double carrier, double cspeed,
+                                orc_rcs_fn get_rcs, orc_gain_fn get_gain, void* user,
+                                PerRayData* rx_results, int* rx_intersects, uint64_t* rx_slots)
+{
+    uint64_t receivedRays = 0;
+    for (uint64_t i = 0; i < rayTotal; i++) {
+        if (results[i].received >= 0) {
+            PerRayData r = results[i];
+            const double* repos = rx_positions + 3*(size_t)r.received;            // GetPosition(0)
+            double transvec[3], recvvec[3];
+            if ((r.reflDepth == 0) && (r.refrDepth == 0)) {
+                for (int k = 0; k < 3; k++) { transvec[k] = h_rayOrigin[k] - repos[k]; recvvec[k] = repos[k] - h_rayOrigin[k]; }
+            } else {
+                transvec[0] = r.firstHitPoint.x - h_rayOrigin[0]; transvec[1] = r.firstHitPoint.y - h_rayOrigin[1]; transvec[2] = r.firstHitPoint.z - h_rayOrigin[2];
+                recvvec[0] = r.prevHitPoint.x - repos[0]; recvvec[1] = r.prevHitPoint.y - repos[1]; recvvec[2] = r.prevHitPoint.z - repos[2];
+            }
+            double delay = (r.rayLength)/cspeed;
+            for (unsigned k = 0; k < D; k++) {
+                uint64_t depth_ray_index = k + i*D;
+                int targ_k = targ_intersect[depth_ray_index];
+                rx_intersects[receivedRays*D + k] = targ_k;
+                if (targ_k >= 0) {
+                    double targRCS = get_rcs(user, targ_k, rcs_angle[2*depth_ray_index], rcs_angle[2*depth_ray_index + 1], Wl);
+                    r.power *= targRCS;
+                }
+            }
+            double Gt = get_gain(user, 0, tx_index, transvec[0], transvec[1], transvec[2], time_t, Wl);
+            double Gr = get_gain(user, 1, r.received, recvvec[0], recvvec[1], recvvec[2], delay + time_t, Wl);
+            r.power *= (Wl*Wl*Gt*Gr);
+            double Vr = r.doppler/2;
+            r.doppler = carrier*(((1 + Vr/cspeed)/(1 - Vr/cspeed)) - 1);
+            rx_results[receivedRays] = r;
+            if (rx_slots) rx_slots[receivedRays] = i;
+            receivedRays++;
+        }
+    }
+    return receivedRays;
+}
+
 // ---------------------------------------------------------------- aggregation.cu:32-97  myKernel1 + myKernel2, literal O(R^2 D)
 void orc_aggregate_literal(PerRayData* results_arr, const int* targ_intersect_arr, unsigned receivedRays, unsigned depthTotal,
                            double cspeed, double carrier, double* npath_arr, double* power_arr, double* doppler_arr,

@@ -24,11 +24,11 @@ int main(int argc, char** argv)
     for (int k = 0; k < 4; k++) {
         const double a = -0.6 + 0.4 * k;
         rx[k].pos = Vec3(-2000.0 * std::cos(a), 2000.0 * std::sin(a), 20.0 * k);
-        rx[k].az = std::atan2(-rx[k].pos.y, -rx[k].pos.x); rx[k].el = std::atan2(-rx[k].pos.z, std::hypot(rx[k].pos.x, rx[k].pos.y));
+        rx[k].ant.az = std::atan2(-rx[k].pos.y, -rx[k].pos.x); rx[k].ant.el = std::atan2(-rx[k].pos.z, std::hypot(rx[k].pos.x, rx[k].pos.y)); rx[k].ant.gk = 0.5;
         rx[k].sphere = D3{50.0, 2.6, 2.6};
     }
     Target s; s.shape = "sphere"; s.subdivs = subdivs; s.radius = 15.0f; s.p0 = Vec3(0, 0, 0); s.vel = Vec3(200, 20, 0); s.refl = 0.9;
-    s.rotating = true; s.rate = YPR{1.0, 0, 0};
+    s.rotating = true; s.rate = YPR{1.0, 0, 0}; s.ra = 0.3; s.rb = 0.1;     // angle-dependent RCS and receive gain: the host callbacks do real work
     w.transmitters = {&tx}; w.receivers = {&rx[0], &rx[1], &rx[2], &rx[3]}; w.targets = {&s};
     RtsStats st{};
     rts_amd::RunOptions opt; opt.in_flight = in_flight; opt.devices.assign(1, 0); opt.last_stats = &st;

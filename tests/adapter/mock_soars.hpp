@@ -1,6 +1,10 @@
 // mock_soars.hpp -- the smallest stand-in for the SOARS/FERS classes that rs::RTS touches
 // (named at ray_tracer.cpp:50-60, absent from the reference repository).  Test scaffolding for
-// include/rts_adapter.hpp: isotropic antennas, constant RCS, linear target motion.
+// include/rts_adapter.hpp.  Antenna gains depend on the look direction AND on the antenna's rotation at the time
+// asked for, rotations change with time (so Gr at `delay + time_t` differs from Gr at `time_t`), the RCS depends on
+// both bistatic angles and on the wavelength: a driver that hands any of ray_tracer.cpp:1204-1247's arguments over
+// wrongly (first / previous hit point, the row of rcs_angle, the time of the rotation) emits different responses.
+// tests/adapter_ref.py restates the same patterns in Python, independently, for the oracle side.
 #pragma once
 #include <cmath>
 #include <string>
@@ -31,14 +35,26 @@ inline double Params::rate_ = 1000.0; inline bool Params::smooth_ = true;
 struct RadarSignal { double carrier = 10e9, temp = 0; double GetCarrier() const { return carrier; } double GetTemp() const { return temp; } };
 struct TransmitterPulse { RadarSignal* wave = nullptr; double time = 0; };
 
+// An antenna: boresight az(t) = az + az_rate t + wob sin(wob_w t), el(t) = el + el_rate t; gain
+//   g0 (1 + gw wl) / (1 + gk ((a.az - r.az)^2 + 2 (a.el - r.el)^2))  * a.length      (length is set to 1 by the driver, :1217-1218)
+// gk = 0, gw = 0: isotropic g0.
+struct Antenna {
+    double az = 0, el = 0, az_rate = 0, el_rate = 0, wob = 0, wob_w = 0, g0 = 1, gk = 0, gw = 0;
+    SVec3 rotation(double t) const { SVec3 r; r.length = 1; r.azimuth = az + az_rate * t + wob * std::sin(wob_w * t); r.elevation = el + el_rate * t; return r; }
+    double gain(const SVec3& a, const SVec3& r, double wl) const {
+        const double da = a.azimuth - r.azimuth, de = a.elevation - r.elevation;
+        return g0 * (1 + gw * wl) / (1 + gk * (da * da + 2 * de * de)) * a.length;
+    }
+};
+
 struct Transmitter {
-    Vec3 pos; double az = 0, el = 0; D3 span{0.1, 0.1, 0.0}; unsigned pulses = 1; double pri = 1e-3; RadarSignal sig;
+    Vec3 pos; Antenna ant; D3 span{0.1, 0.1, 0.0}; unsigned pulses = 1; double pri = 1e-3, t_first = 0; RadarSignal sig;
     unsigned GetPulseCount() const { return pulses; }
-    void GetPulse(TransmitterPulse* p, int k) { p->wave = &sig; p->time = k * pri; }
+    void GetPulse(TransmitterPulse* p, int k) { p->wave = &sig; p->time = t_first + k * pri; }
     D3 GetTxSpan() const { return span; }
     Vec3 GetPosition(double) const { return pos; }
-    SVec3 GetRotation(double) const { SVec3 r; r.length = 1; r.azimuth = az; r.elevation = el; return r; }
-    double GetGain(const SVec3&, const SVec3&, double) const { return 1.0; }
+    SVec3 GetRotation(double t) const { return ant.rotation(t); }
+    double GetGain(const SVec3& a, const SVec3& r, double wl) const { return ant.gain(a, r, wl); }
 };
 
 struct InterpPoint {
@@ -52,20 +68,21 @@ struct Response {
 };
 
 struct Receiver {
-    Vec3 pos; double az = 0, el = 0; D3 sphere{50.0, 1.5, 1.5}; double noise = 290; std::vector<Response*> responses;
+    Vec3 pos; Antenna ant; D3 sphere{50.0, 1.5, 1.5}; double noise = 290; std::vector<Response*> responses;
     double GetNoiseTemperature() const { return noise; }
     void SetNoiseTemperature(double t) { noise = t; }
     D3 GetRxSphere() const { return sphere; }
     Vec3 GetPosition(double) const { return pos; }
-    SVec3 GetRotation(double) const { SVec3 r; r.length = 1; r.azimuth = az; r.elevation = el; return r; }
-    double GetGain(const SVec3&, const SVec3&, double) const { return 1.0; }
+    SVec3 GetRotation(double t) const { return ant.rotation(t); }
+    double GetGain(const SVec3& a, const SVec3& r, double wl) const { return ant.gain(a, r, wl); }
     void AddResponse(Response* r) { responses.push_back(r); }
     ~Receiver() { for (auto* r : responses) delete r; }
 };
 
+// RCS pattern: rcs (1 + ra cos(az) sin(el) + rb cos(2 el) + rw wl)   (ra = rb = rw = 0: constant)
 struct Target {
     std::string shape = "sphere"; Vec3 p0, vel; YPR rot0{0, 0, 0}, rate{0, 0, 0}; bool rotating = false;
-    float w = 1, h = 1, d = 1, radius = 1; unsigned subdivs = 2; std::string vfile, nfile; double refl = 0.9, refr = 1.0, rcs = 1.0;
+    float w = 1, h = 1, d = 1, radius = 1; unsigned subdivs = 2; std::string vfile, nfile; double refl = 0.9, refr = 1.0, rcs = 1.0, ra = 0, rb = 0, rw = 0;
     Vec3 GetPosition(double t) const { return Vec3(p0.x + vel.x * t, p0.y + vel.y * t, p0.z + vel.z * t); }
     YPR GetTargetRotation(double t) const { return YPR{rot0.yaw + rate.yaw * t, rot0.pitch + rate.pitch * t, rot0.roll + rate.roll * t}; }
     std::string GetShape() const { return shape; }
@@ -75,7 +92,7 @@ struct Target {
     bool GetRotating() const { return rotating; }
     double GetReflCoeff() const { return refl; }
     double GetRefrIndex() const { return refr; }
-    double GetRCS(double, double, double) const { return rcs; }
+    double GetRCS(double az, double el, double wl) const { return rcs * (1 + ra * std::cos(az) * std::sin(el) + rb * std::cos(2 * el) + rw * wl); }
 };
 
 struct World { std::vector<Transmitter*> transmitters; std::vector<Receiver*> receivers; std::vector<Target*> targets; };

@@ -426,60 +426,55 @@ def test_traversal_counters(rts, scenes):
     H.assert_prd_equal(r0["results"], r1["results"], "counting build")
 
 
+def _adapter_scenarios(tmp_path):
+    import adapter_ref as AR
+    vf, nf = str(tmp_path / "octa_v.txt"), str(tmp_path / "octa_n.txt")
+    AR.write_octahedron_files(vf, nf, radius=4.0, subdiv=2)
+    return [("base", AR.scenario_base()), ("two_tx", AR.scenario_two_tx()), ("refraction", AR.scenario_refraction()),
+            ("file", AR.scenario_file(vf, nf)), ("ecef", AR.scenario_ecef())]
+
+
 def test_adapter_end_to_end(rts, oracle, tmp_path):
-    """rs::RTS drop-in: include/rts_adapter.hpp driven by a mock SOARS World (3 pulses, moving + rotating targets,
-    2 receivers) emits exactly the responses of the literal pipeline: oracle trace -> host finalise
-    (ray_tracer.cpp:1190-1258) -> O(R^2) aggregation -> unique paths (ray_tracer.cpp:1290-1321)."""
+    """rs::RTS drop-in: include/rts_adapter.hpp driven by a mock SOARS World whose antenna gains depend on the look
+    direction and on the antenna's rotation AT THE TIME ASKED FOR, and whose RCS depends on both bistatic angles and the
+    wavelength, emits exactly the responses of the literal pipeline (tests/adapter_ref.py): oracle trace -> host filter +
+    finalise with the simulator's callbacks (ray_tracer.cpp:1190-1258) -> O(R^2) aggregation -> unique paths (:1290-1321).
+    Scenarios: three moving targets / two receivers; TWO transmitters (noise temperature accumulating per transmitter,
+    :829); refraction (maxRefr clamped to 2, rayTotal = W^3 (maxRefl + 3), :604-626); a "file" target (:983-987); the
+    scene at Earth-centred coordinates."""
     import subprocess
+    import adapter_ref as AR
     from test_host_logic import build_adapter_binary
     exe = build_adapter_binary(str(tmp_path / "adapter_main"))
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stderr
-    seq = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=300)       # strictly sequential pulses
-    assert seq.returncode == 0 and seq.stdout == out.stdout, "pipelined and sequential pulse loops must emit identical responses"
-    # the multi-device path on one GPU: several handle sets on device 0 -- whole pulses dealt to the sets in turn, and every
-    # pulse split over the sets in interleaved tiles (received rays merged on the host): byte-identical output
-    for argv in (["2", "2"], ["1", "3"], ["2", "2", "rays"], ["1", "3", "rays"], ["3", "2", "rays"]):
-        multi = subprocess.run([exe] + argv, capture_output=True, text=True, timeout=300)
-        assert multi.returncode == 0, multi.stderr
-        assert multi.stdout == out.stdout, "handle sets %r must emit the responses of the single-set run" % (argv,)
-    got = np.array([[float(x) for x in line.split()] for line in out.stdout.strip().splitlines()])
-    # the same scene through the oracle
-    c, fc, Ts, W, max_refl = C0, 10e9, 1e-3, 16, 4
-    sv, st_, sn = oracle.sphere_mesh(2, 4.0)
-    bv, bt, bn = oracle.rect_mesh(5.0, 5.0, 5.0, 0.5, 0.2, 0.1)
-    pv, pt, pn = oracle.rect_mesh(0.2, 14.0, 14.0, 0.6, 0.0, 0.0)
-    p0 = np.array([[0, 0, 0], [2, 9, 1], [9, -7, 0]], np.float64); vel = np.array([[10, 0, 0], [0, -5, 0], [0, 0, 3]], np.float64)
-    rxs = [oracle.rx_sphere((-200.0, 0.0, 0.0), 0.0, 0.0, 90.0, 2.6, 2.6),
-           oracle.rx_sphere((-150.0, 130.0, 10.0), math.atan2(-130.0, 150.0), math.atan2(-10.0, math.hypot(150.0, 130.0)), 90.0, 2.6, 2.6)]
-    want = []
-    for k in range(3):
-        t = k * Ts
-        sc = oracle.Scene()
-        for i, (v, tri, nrm, refl) in enumerate([(sv, st_, sn, 0.9), (bv, bt, bn, 0.8), (pv, pt, pn, 0.7)]):
-            pos = p0[i] + vel[i] * t; pos1 = p0[i] + vel[i] * (t + Ts)
-            vv, nn = v, nrm
-            if i == 1 and t > 0.0:                            # rotating target: ypr(t) applied to the t = 0 mesh (ray_tracer.cpp:993-1007)
-                ypr = (np.float32(0.5 + 30.0 * t), np.float32(0.2), np.float32(0.1))
-                vv = oracle.vertex_rotation(v, *ypr); nn = oracle.vertex_rotation(nrm, *ypr)
-            sc.add_mesh(tri, vv + pos, nn, refl, 1.0, (pos1 - pos) / Ts)
-        sc.set_receivers(rxs)
-        o = sc.trace((-200.0, 0.0, 0.0), (0.16, 0.12, 0.05), (0.0, 0.0), W, max_refl)
-        rx, rxi, slots = oracle.filter_finalise(o["results"], o["path"], [1.0, 1.0, 1.0], c / fc, 1.0, 1.0, fc, c)
-        lit = oracle.aggregate_literal(rx, rxi, c, fc, W ** 3)
-        for u in oracle.unique_paths(lit["pathMatch"]):
-            want.append([t, lit["results"]["received"][u], lit["results"]["power"][u], lit["delay"][u], lit["results"]["doppler"][u], lit["phase"][u]])
-    want = np.array(want)
-    assert len(want) > 3
-    key = lambda a: np.lexsort((a[:, 3], a[:, 1], np.round(a[:, 0] * 1e6)))          # order by (pulse, rx, delay)
-    got = got[key(got)]; want = want[key(want)]
-    assert got.shape == want.shape
-    np.testing.assert_allclose(got[:, 0], want[:, 0], atol=1e-12)
-    assert np.array_equal(got[:, 1], want[:, 1])
-    np.testing.assert_allclose(got[:, 2], want[:, 2], rtol=1e-9)                    # power
-    np.testing.assert_allclose(got[:, 3], want[:, 3], rtol=1e-12)                   # delay
-    np.testing.assert_allclose(got[:, 4], want[:, 4], rtol=1e-9, atol=1e-6)         # doppler [Hz]
-    np.testing.assert_allclose(got[:, 5], want[:, 5], rtol=1e-9, atol=1e-9)         # phase
+    for name, sc in _adapter_scenarios(tmp_path):
+        path = str(tmp_path / ("%s.scn" % name))
+        AR.write_scenario(path, sc)
+        out = subprocess.run([exe, path], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, (name, out.stderr)
+        variants = [["1"]] if name != "base" else [["1"], ["2", "2"], ["1", "3"], ["2", "2", "rays"], ["1", "3", "rays"], ["3", "2", "rays"]]
+        if name == "refraction":
+            variants.append(["2", "2", "rays"])                                   # chains k W^3 apart come from the same part
+        for argv in variants:
+            # sequential pulses; several handle sets on device 0 (the multi-device path on one GPU) -- whole pulses dealt to the
+            # sets in turn, and every pulse split over the sets in interleaved tiles: byte-identical output
+            other = subprocess.run([exe, path] + argv, capture_output=True, text=True, timeout=300)
+            assert other.returncode == 0, (name, argv, other.stderr)
+            assert other.stdout == out.stdout, "%s: run %r must emit the responses of the default run" % (name, argv)
+        got, got_noise = AR.parse_adapter_output(out.stdout)
+        want, want_noise = AR.run_reference_flow(oracle, sc)
+        assert len(want) > 3, name
+        AR.assert_responses_close(got, want)
+        assert got_noise == want_noise, name
+        if name == "two_tx":
+            assert set(got[:, 0]) == {0.0, 1.0} and got[got[:, 0] == 1][:, 7].min() > got[got[:, 0] == 0][:, 7].max()
+        if name == "refraction":
+            assert want_noise and len(want) > 3
+    # the comparison is sensitive to every argument of :1204-1247 (tests/test_oracle_kat.py shows it on the oracle side too)
+    sc = AR.scenario_base()
+    got, _ = AR.parse_adapter_output(subprocess.run([exe, str(tmp_path / "base.scn")], capture_output=True, text=True, timeout=300).stdout)
+    for mut in ("swap_hits", "rx_time", "angle_rows"):
+        bad, _ = AR.run_reference_flow(oracle, sc, mutate=mut)
+        assert AR.max_power_deviation(got, bad) > 1e-6, mut
 
 
 def test_c4_c5_shapes(rts, oracle, scenes):

@@ -229,3 +229,67 @@ def test_refraction_rows(oracle):
     assert hit.any()
     child = r["results"][27:54]
     assert (child["refrDepth"][hit] >= 1).all()                  # first refraction child row = index + W^3 (normal_shader.cu:214)
+
+
+def test_finalise_callbacks_closed_form(oracle):
+    """ray_tracer.cpp:1204-1247 in the oracle (orc_filter_finalise_cb): the vectors and times handed to the simulator's
+    callbacks, on a hand-made record set -- direct ray: transvec = origin - repos, recvvec = repos - origin (the Rx
+    POSITION, not the end point); reflected ray: firstHitPoint - origin, prevHitPoint - repos; Gt at time_t, Gr at
+    delay + time_t; RCS by (targ_k, rcs_angle.x, rcs_angle.y, Wl) for every depth with targ_k >= 0"""
+    res = np.zeros(4, oracle.PRD_DTYPE)
+    res["received"] = [-1, 1, 0, -1]
+    res["reflDepth"] = [0, 0, 2, 1]
+    res["rayLength"] = [0.0, 2997.92458, 5995.84916, 1.0]
+    res["power"] = [0.0, 2.0, 3.0, 9.0]
+    res["doppler"] = [0.0, 0.0, 40.0, 1.0]
+    res["firstHitPoint"][2] = (10.0, 20.0, 30.0); res["prevHitPoint"][2] = (-5.0, 6.0, 7.0)
+    path = np.array([[-1, -1], [-1, -1], [1, 0], [0, -1]], np.int32)
+    ang = np.full((4, 2, 2), -1.0e6); ang[2] = [[0.1, 0.2], [0.3, 0.4]]
+    origin = (1.0, 2.0, 3.0); rx_pos = np.array([[100.0, 0.0, 0.0], [0.0, 200.0, 50.0]])
+    calls = []
+
+    def get_rcs(targ, az, el, wl):
+        calls.append(("rcs", targ, az, el, wl)); return 2.0 + targ
+
+    def get_gain(is_rx, index, vec, t, wl):
+        calls.append(("gain", is_rx, index, vec, t, wl)); return 5.0 if is_rx else 7.0
+    c, fc, t0 = 299792458.0, 1.0e9, 0.25
+    wl = c / fc
+    rx, rxi, slots = oracle.filter_finalise_cb(res, path, ang, origin, rx_pos, 3, t0, wl, fc, c, get_rcs, get_gain)
+    assert list(slots) == [1, 2] and np.array_equal(rxi, path[[1, 2]])
+    assert calls[0] == ("gain", 0, 3, (1.0, 2.0 - 200.0, 3.0 - 50.0), t0, wl)                   # direct ray: origin - repos, time_t
+    assert calls[1] == ("gain", 1, 1, (-1.0, 200.0 - 2.0, 50.0 - 3.0), 2997.92458 / c + t0, wl)  # repos - origin, delay + time_t
+    assert calls[2] == ("rcs", 1, 0.1, 0.2, wl) and calls[3] == ("rcs", 0, 0.3, 0.4, wl)
+    assert calls[4] == ("gain", 0, 3, (9.0, 18.0, 27.0), t0, wl)                                 # firstHitPoint - origin
+    assert calls[5] == ("gain", 1, 0, (-105.0, 6.0, 7.0), 5995.84916 / c + t0, wl) and len(calls) == 6   # prevHitPoint - repos
+    assert rx["power"][0] == 2.0 * (wl * wl * 7.0 * 5.0) and rx["power"][1] == 3.0 * 3.0 * 2.0 * (wl * wl * 7.0 * 5.0)
+    vr = 20.0
+    assert rx["doppler"][1] == fc * (((1 + vr / c) / (1 - vr / c)) - 1) and rx["doppler"][0] == 0.0
+
+
+def test_reference_flow_scenarios_and_their_sensitivity(oracle, tmp_path):
+    """tests/adapter_ref.py (rs::RTS's control flow over the oracle, the checker of the C++ adapter's GPU test): every
+    scenario yields responses; the noise temperature accumulates once per transmitter (quirk 15); and each deliberate
+    mistake a driver could make in ray_tracer.cpp:1204-1247 -- first / previous hit point swapped, Gr's rotation taken at
+    time_t instead of delay + time_t, rcs_angle columns shifted -- moves some response's power by far more than the
+    tolerance of the comparison (1e-9)"""
+    import adapter_ref as AR
+    vf, nf = str(tmp_path / "v.txt"), str(tmp_path / "n.txt")
+    assert AR.write_octahedron_files(vf, nf, subdiv=2) == 128
+    sc = AR.scenario_base()
+    good, noise = AR.run_reference_flow(oracle, sc)
+    assert len(good) > 6 and noise == [325.0, 185.0] and set(good[:, 2]) == {0.0, 1.0}
+    assert (good[:, 3] > 0).all() and len(np.unique(good[:, 8])) == 3
+    for mut in ("swap_hits", "rx_time", "angle_rows"):
+        bad, _ = AR.run_reference_flow(oracle, sc, mutate=mut)
+        assert AR.max_power_deviation(bad, good) > 1e-6, mut
+    two, noise2 = AR.run_reference_flow(oracle, AR.scenario_two_tx())
+    assert noise2 == [290.0 + 35.0 + 21.5, 150.0 + 35.0 + 21.5]
+    assert set(two[two[:, 0] == 0][:, 7]) == {325.0, 185.0} and set(two[two[:, 0] == 1][:, 7]) <= {346.5, 206.5} and (two[:, 0] == 1).any()
+    refr, _ = AR.run_reference_flow(oracle, AR.scenario_refraction())
+    fil, _ = AR.run_reference_flow(oracle, AR.scenario_file(vf, nf))
+    ecef, _ = AR.run_reference_flow(oracle, AR.scenario_ecef())
+    assert len(refr) > 10 and set(refr[:, 2]) == {0.0, 1.0, 2.0} and len(fil) > 3 and len(ecef) > 3 and np.isfinite(refr).all()
+    AR.write_scenario(str(tmp_path / "s.scn"), sc)
+    lines = open(str(tmp_path / "s.scn")).read().splitlines()
+    assert [l.split()[0] for l in lines] == ["params", "tx", "rx", "rx", "target", "target", "target"]
