@@ -145,7 +145,10 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()       # rehearsal: ranks may share a device
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # launched by torch.distributed.run (RANK in the environment): the process group is initialised whatever the world size, so
+    # that `python -m torch.distributed.run --nproc-per-node 1 ... bench.py --gpus 1` runs init_process_group / all_gather /
+    # all_reduce on RCCL with ONE rank -- the only way to execute those lines on a single-GPU box
+    if world > 1 or "RANK" in os.environ:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":

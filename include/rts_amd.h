@@ -157,6 +157,9 @@ typedef struct RtsGroup {
 int rts_create(const RtsParams* params, RtsHandle* out);      /* rtContextCreate .. ray_tracer.cpp:532-800 */
 int rts_destroy(RtsHandle h);                                 /* ray_tracer.cpp:1342-1360                  */
 const char* rts_last_error(void);
+/* 16 hex digits: SHA-256 (truncated) of the sources the library was built from (rts_amd/csrc/*.hip|cpp|h + rts_amd.h + rts_prd.h,
+ * in byte order of their names).  Profiles record it; bench.py refuses to price a run with counters of another build. */
+const char* rts_build_id(void);
 int rts_device_count(int* n);
 
 /* ---------------------------------------------------------------- scene */

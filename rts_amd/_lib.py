@@ -94,19 +94,46 @@ assert RESPONSE_DTYPE.itemsize == 48 and GROUP_DTYPE.itemsize == 120
 
 
 def is_stale():
-    """True if librts_amd.so is missing or older than one of its sources"""
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + \
-           [os.path.join(_HERE, "..", "include", f) for f in ("rts_amd.h", "rts_prd.h")]
-    newest = max(os.path.getmtime(s) for s in srcs if not s.endswith(".o"))
-    return not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest
+    """True if librts_amd.so is missing or was built from other sources than the tree's (hash baked in by the Makefile)"""
+    if not os.path.exists(LIB_PATH):
+        return True
+    try:
+        return build_id() != source_hash()
+    except (OSError, AttributeError):              # unloadable, or a library from before rts_build_id
+        return True
+
+
+def source_hash():
+    """the hash rts_amd/csrc/Makefile bakes into the library (rts_build_id): SHA-256, first 16 hex digits, of the sources in
+    byte order of their names, then the two public headers"""
+    import hashlib
+    names = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h")) and f != "rts_build_id.h")
+    h = hashlib.sha256()
+    for path in [os.path.join(CSRC, f) for f in names] + [os.path.join(_HERE, "..", "include", f) for f in ("rts_amd.h", "rts_prd.h")]:
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def build_id(path=None):
+    """rts_build_id() of a built library (default: the one lib() loads), without going through lib()'s prototypes"""
+    L = C.CDLL(path or LIB_PATH)
+    L.rts_build_id.restype = C.c_char_p
+    return L.rts_build_id().decode()
 
 
 def require_built():
     """bench.py and the timed tools never build: under `rocprofv3 -- python bench.py` a make -> sh -> hipcc chain would be
     an exec from a process whose GPU the profiler's preload has already initialised.  Build beforehand
-    (__graft_entry__.build() or make -C rts_amd/csrc)."""
+    (__graft_entry__.build() or make -C rts_amd/csrc).  A library that was built from other sources than the tree's is an
+    error too (file times do not survive the copy to a GPU box; the hash baked into the library does) -- unless RTS_AMD_LIB
+    names another build on purpose (same-box A/B runs)."""
     if not os.path.exists(LIB_PATH):
         raise SystemExit("librts_amd.so is not built: run `python __graft_entry__.py` (or make -C rts_amd/csrc) first")
+    if "RTS_AMD_LIB" not in os.environ:
+        have, want = build_id(), source_hash()
+        if have != want:
+            raise SystemExit("librts_amd.so is stale: built from sources %s, the tree is %s -- run `python __graft_entry__.py` first" % (have, want))
 
 
 def build(force=False, verbose=False):
@@ -125,7 +152,7 @@ EXPORTS = ["rts_create", "rts_destroy", "rts_last_error", "rts_device_count", "r
            "rts_finalise_uniform", "rts_aggregate", "rts_group_count", "rts_get_groups", "rts_get_aggregated",
            "rts_merge_groups", "rts_groups_to_responses", "rts_kernel_wrapper", "rts_vertex_rotation",
            "rts_rotation_matrix", "rts_rect_mesh", "rts_sphere_mesh", "rts_file_mesh", "rts_rx_sphere", "rts_get_bvh",
-           "rts_self_test_math", "rts_cube_attach", "rts_cube_accumulate", "rts_cube_get", "rts_plan_cpi", "rts_cube_reduce", "rts_kernel_wrapper_on"]
+           "rts_build_id", "rts_self_test_math", "rts_cube_attach", "rts_cube_accumulate", "rts_cube_get", "rts_plan_cpi", "rts_cube_reduce", "rts_kernel_wrapper_on"]
 
 
 def lib():

@@ -24,9 +24,12 @@
 static thread_local char g_err[1024] = "";
 void rts_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap); }
 extern "C" const char* rts_last_error(void) { return g_err; }
+#include "rts_build_id.h"
+extern "C" const char* rts_build_id(void) { return RTS_SOURCE_HASH; }
 
 extern int rts_fill_i32(hipStream_t st, int32_t* p, int32_t v, size_t n);
 static int rts_attach_scene(RtsContext* c);
+void rts_comm_cache_forget(RtsContext* c);
 
 int rts_debug_stage(RtsContext* c, const char* name)
 {
@@ -105,6 +108,7 @@ extern "C" int rts_destroy(RtsHandle c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->pulse_open) { c->pulse_open = false; g_open_pulses[c->device & 63]--; }
+    rts_comm_cache_forget(c);
     if (c->scene && --c->scene->refs == 0) { c->scene->release(); delete c->scene; }
     c->scene = nullptr;
     c->d_verts_world.release(); c->d_normals_world.release();
@@ -299,7 +303,7 @@ extern "C" int rts_scene_info(RtsHandle c, RtsSceneInfo* out)
     const RtsScene* sc = c->scene;
     memset(out, 0, sizeof(*out));
     out->n_targets = (uint32_t)sc->meshes.size(); out->n_prims = sc->n_prims; out->n_nodes = sc->n_nodes; out->n_leaves = sc->n_leaves;
-    out->handles_sharing = (uint32_t)sc->refs; out->builder = sc->builder; out->build_ms = sc->build_ms;
+    out->handles_sharing = (uint32_t)sc->refs.load(); out->builder = sc->builder; out->build_ms = sc->build_ms;
     out->shared_device_bytes = sc->device_bytes();
     out->handle_device_bytes = c->d_leaves.cap * sizeof(RtsLeafTri) + c->d_verts_world.cap * 8 + c->d_normals_world.cap * 8 + c->d_motion.cap * sizeof(RtsTargetMotion) + c->d_targets.cap * sizeof(RtsTargetDev);
     return RTS_OK;
@@ -900,13 +904,52 @@ struct RcclApi {
     }
 };
 RcclApi g_rccl;
+// Communicators are created once per set of devices and kept (ncclCommInitAll costs hundreds of milliseconds on eight GPUs, an
+// all-reduce of a cube half a millisecond); an entry lives as long as one of the handles that used it (rts_destroy ->
+// rts_comm_cache_forget).
+struct CommEntry { std::vector<int> devs; std::vector<rccl_comm_t> comms; std::vector<RtsContext*> users; };
+std::mutex g_comm_mu;
+std::vector<CommEntry> g_comm_cache;
 __global__ void k_add_f64(double* __restrict__ dst, const double* __restrict__ src, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] += src[i];
 }
+// the communicators for the devices of `hs` (in handle order), created on first use; null on failure (*rc_out = RCCL's code)
+const std::vector<rccl_comm_t>* comm_cache_get(RtsHandle* hs, uint32_t n, int* rc_out)
+{
+    std::vector<int> devs(n);
+    for (uint32_t i = 0; i < n; i++) devs[i] = hs[i]->device;
+    std::lock_guard<std::mutex> lk(g_comm_mu);
+    CommEntry* e = nullptr;
+    for (auto& x : g_comm_cache) if (x.devs == devs) { e = &x; break; }
+    if (!e) {
+        CommEntry ne; ne.devs = devs; ne.comms.assign(n, nullptr);
+        const int rc = g_rccl.CommInitAll(ne.comms.data(), (int)n, devs.data());
+        if (rc != 0) { *rc_out = rc; return nullptr; }
+        g_comm_cache.push_back(std::move(ne)); e = &g_comm_cache.back();
+    }
+    for (uint32_t i = 0; i < n; i++) if (std::find(e->users.begin(), e->users.end(), hs[i]) == e->users.end()) e->users.push_back(hs[i]);
+    *rc_out = 0;
+    return &e->comms;
+}
 }  // namespace
 
+// rts_destroy: the handle no longer keeps any communicator set alive; a set without users is destroyed
+void rts_comm_cache_forget(RtsContext* c)
+{
+    std::lock_guard<std::mutex> lk(g_comm_mu);
+    for (size_t k = 0; k < g_comm_cache.size();) {
+        CommEntry& e = g_comm_cache[k];
+        e.users.erase(std::remove(e.users.begin(), e.users.end(), c), e.users.end());
+        if (e.users.empty()) { for (rccl_comm_t q : e.comms) if (q) (void)g_rccl.CommDestroy(q); g_comm_cache.erase(g_comm_cache.begin() + k); }
+        else k++;
+    }
+}
+
+// transport 0: RCCL when the handles sit on distinct devices and librccl loads, else peer copies; 1: RCCL or an error (with
+// ONE handle: a one-rank communicator and all-reduce -- the identity, but the dlopen, the symbol table and the call sequence
+// run, which is how the RCCL path is exercised on a single GPU); 2: peer copies.
 extern "C" int rts_cube_reduce(RtsHandle* hs, uint32_t n, int transport)
 {
     if (!hs || n == 0) { rts_set_error("rts_cube_reduce: no handles"); return RTS_ERR_INVALID; }
@@ -918,25 +961,28 @@ extern "C" int rts_cube_reduce(RtsHandle* hs, uint32_t n, int transport)
     }
     const size_t doubles = 2 * (size_t)hs[0]->cube_params.n_rx * hs[0]->cube_params.n_pulses * hs[0]->cube_params.n_bins;
     for (uint32_t i = 0; i < n; i++) { RtsContext* c = hs[i]; CHECK_CLOSED(c); RTS_HIP(hipSetDevice(c->device)); RTS_HIP(hipStreamSynchronize(c->stream)); }
-    if (n == 1) return RTS_OK;
+    if (n == 1 && transport != 1) return RTS_OK;
     bool distinct = true;
     for (uint32_t i = 0; i < n; i++) for (uint32_t j = 0; j < i; j++) if (hs[i]->device == hs[j]->device) distinct = false;
     if (transport != 2 && distinct && g_rccl.load()) {
         // one communicator per device, all in this process; one all-reduce (sum, f64) on each handle's stream inside a group
-        std::vector<rccl_comm_t> comms(n, nullptr); std::vector<int> devs(n);
-        for (uint32_t i = 0; i < n; i++) devs[i] = hs[i]->device;
-        int rc = g_rccl.CommInitAll(comms.data(), (int)n, devs.data());
-        if (rc == 0) {
+        int rc = 0;
+        const std::vector<rccl_comm_t>* comms = comm_cache_get(hs, n, &rc);
+        if (comms) {
+            // From here on there is no falling back: the all-reduce is in place, and after a failure part-way some cubes may
+            // already hold partial sums -- adding them again over peer copies would count them twice.
             rc = g_rccl.GroupStart();
-            for (uint32_t i = 0; i < n && rc == 0; i++) { (void)hipSetDevice(hs[i]->device); rc = g_rccl.AllReduce(hs[i]->cube, hs[i]->cube, doubles, 8 /* ncclFloat64 */, 0 /* ncclSum */, comms[i], hs[i]->stream); }
+            for (uint32_t i = 0; i < n && rc == 0; i++) { (void)hipSetDevice(hs[i]->device); rc = g_rccl.AllReduce(hs[i]->cube, hs[i]->cube, doubles, 8 /* ncclFloat64 */, 0 /* ncclSum */, (*comms)[i], hs[i]->stream); }
             const int rc2 = g_rccl.GroupEnd(); if (rc == 0) rc = rc2;
             for (uint32_t i = 0; i < n; i++) { (void)hipSetDevice(hs[i]->device); (void)hipStreamSynchronize(hs[i]->stream); }
-            for (uint32_t i = 0; i < n; i++) if (comms[i]) (void)g_rccl.CommDestroy(comms[i]);
             if (rc == 0) return RTS_OK;
+            rts_set_error("rts_cube_reduce: RCCL all-reduce failed (%s); the cubes may hold partial sums", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+            return RTS_ERR_HIP;
         }
-        if (transport == 1) { rts_set_error("rts_cube_reduce: RCCL failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"); return RTS_ERR_HIP; }
-        // fall through to peer copies
+        if (transport == 1) { rts_set_error("rts_cube_reduce: ncclCommInitAll failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"); return RTS_ERR_HIP; }
+        // no communicator, nothing issued: peer copies
     } else if (transport == 1) { rts_set_error("rts_cube_reduce: RCCL requested but %s", distinct ? "librccl could not be loaded" : "two handles share a device"); return RTS_ERR_UNSUPPORTED; }
+    if (n == 1) return RTS_OK;
     // peer copies: everything is added into handle 0's cube in handle order (bit-reproducible), then copied back out
     RtsContext* c0 = hs[0];
     RTS_HIP(hipSetDevice(c0->device));

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 #include <vector>
 #include "../../include/rts_amd.h"
@@ -206,13 +207,13 @@ template <typename T> struct DevBuf {
 // Handles joined by rts_link_handles share one trace stream: their trace kernels execute one after the other, in the
 // order the pulses were begun; the rest of each pulse (scene placement before, ordering / finalise /
 // aggregation after) runs on the handle's own (high-priority) stream and overlaps with the other handles' trace kernels.
-struct RtsGate { hipStream_t tstream = nullptr; int refs = 0; int device = 0; };
+struct RtsGate { hipStream_t tstream = nullptr; std::atomic<int> refs{0}; int device = 0; };      // (handles may be driven from different threads)
 
 // The immutable part of a scene -- meshes in their own frames, the static target-space hierarchy and its leaf order -- lives
 // ONCE per device and is shared (reference counted) by every handle that was given it with rts_share_scene: handles that keep
 // several pulses in flight place, trace and post-process into their own per-pulse buffers but read the same nodes.
 struct RtsScene {
-    int refs = 1; int device = 0;
+    std::atomic<int> refs{1}; int device = 0;
     std::vector<RtsMeshHost> meshes;
     uint32_t n_prims = 0, n_verts = 0, n_normals = 0;
     DevBuf<uint32_t> d_tri_vidx, d_tri_nidx, d_vert_targ, d_norm_targ, d_prim_targ;

@@ -42,7 +42,9 @@ __device__ __forceinline__ TriV load_tri(const uint32_t* __restrict__ tri_vidx, 
     TriV t; t.finite = true;
     for (int k = 0; k < 3; k++) {
         const uint32_t a = tri_vidx[3*(size_t)i + k];
-        for (int c = 0; c < 3; c++) { t.v[k][c] = verts[3*(size_t)a + c]; t.finite = t.finite && isfinite(t.v[k][c]); }
+        // (finite AND far enough inside the f32 range for the padded, outward-rounded box of every reference to be finite: a
+        // triangle counted as valid by k_ref_count must never come out of k_ref_boxes with the sentinel key)
+        for (int c = 0; c < 3; c++) { t.v[k][c] = verts[3*(size_t)a + c]; t.finite = t.finite && fabs(t.v[k][c]) < 3.0e38; }
     }
     return t;
 }
@@ -176,7 +178,7 @@ __global__ void k_morton(const float* __restrict__ prim_box, const uint32_t* __r
     if (i >= n) return;
     const float* b = prim_box + 6*(size_t)i;
     vals[i] = i;
-    if (b[0] > b[3]) { keys[i] = 0x7fffffffffffffffULL; return; }           // invalid triangle: sorts last
+    if (b[0] > b[3]) { keys[i] = ~0ULL; return; }                           // invalid triangle: sorts last (valid codes have bit 63 clear; 2^63 - 1 IS a valid code)
     float lx = ord2f(bounds[0]), ly = ord2f(bounds[1]), lz = ord2f(bounds[2]);
     float hx = ord2f(bounds[3]), hy = ord2f(bounds[4]), hz = ord2f(bounds[5]);
     float ex = fmaxf(hx - lx, 1e-30f), ey = fmaxf(hy - ly, 1e-30f), ez = fmaxf(hz - lz, 1e-30f);

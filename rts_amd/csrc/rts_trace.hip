@@ -65,25 +65,30 @@ __device__ __forceinline__ RtsSlabRay rts_slab_setup(const dvec3& o, const dvec3
 
 // The record fetch of a traversal step as explicit instructions.  Written as plain loads ahead of the node / leaf branches
 // the compiler sinks them into the branches again -- narrowed to the dwords each branch uses (17 global_load_dword) and, being
-// in an if / else, issued one branch after the other: two dependent memory round trips per step.  Here: five (seven) dwordx4
-// loads from one per-lane base, then ONE wait; `seven` is wave-divergent (lanes at leaves need 80 bytes, lanes at nodes 112).
+// in an if / else, issued one branch after the other: two dependent memory round trips per step.  Here: five dwordx4 loads
+// from one per-lane base for every lane, two more for the lanes at nodes (lanes at leaves need 80 bytes, lanes at nodes 112;
+// EXEC is narrowed to the latter inside the block), then the wait -- ONE asm statement:
+// the backend does not track vector-memory loads issued from inline asm and the hardware has no interlock on a VGPR with a
+// load in flight, so nothing the compiler might place (a copy, a spill of q0..q6) may come between the loads and the wait.
 typedef unsigned int rts_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void rts_fetch_record(const void* p, bool seven, rts_u32x4& q0, rts_u32x4& q1, rts_u32x4& q2, rts_u32x4& q3,
+__device__ __forceinline__ void rts_fetch_record(const void* p, int node, rts_u32x4& q0, rts_u32x4& q1, rts_u32x4& q2, rts_u32x4& q3,
                                                  rts_u32x4& q4, rts_u32x4& q5, rts_u32x4& q6)
 {
-    asm volatile("global_load_dwordx4 %0, %5, off\n\t"
-                 "global_load_dwordx4 %1, %5, off offset:16\n\t"
-                 "global_load_dwordx4 %2, %5, off offset:32\n\t"
-                 "global_load_dwordx4 %3, %5, off offset:48\n\t"
-                 "global_load_dwordx4 %4, %5, off offset:64"
-                 : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4) : "v"(p) : "memory");
-    if (seven) asm volatile("global_load_dwordx4 %0, %2, off offset:80\n\t"
-                            "global_load_dwordx4 %1, %2, off offset:96"
-                            : "+&v"(q5), "+&v"(q6) : "v"(p) : "memory");
-}
-__device__ __forceinline__ void rts_fetch_wait(rts_u32x4& q0, rts_u32x4& q1, rts_u32x4& q2, rts_u32x4& q3, rts_u32x4& q4, rts_u32x4& q5, rts_u32x4& q6)
-{
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(q6) : : "memory");
+    // (the lanes at nodes -- node >= 0 -- are found and EXEC is parked in VCC, which the allocator never hands out as a
+    // general pair: the kernel has no scalar register to spare)
+    asm volatile("global_load_dwordx4 %0, %7, off\n\t"
+                 "global_load_dwordx4 %1, %7, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %7, off offset:32\n\t"
+                 "global_load_dwordx4 %3, %7, off offset:48\n\t"
+                 "global_load_dwordx4 %4, %7, off offset:64\n\t"
+                 "v_cmp_lt_i32 vcc, -1, %8\n\t"
+                 "s_and_saveexec_b64 vcc, vcc\n\t"
+                 "global_load_dwordx4 %5, %7, off offset:80\n\t"
+                 "global_load_dwordx4 %6, %7, off offset:96\n\t"
+                 "s_mov_b64 exec, vcc\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5), "=&v"(q6)     // (q5, q6: written for the lanes at nodes only, read by them only)
+                 : "v"(p), "v"(node) : "memory", "scc", "vcc");
 }
 
 // The stack entry below the top when it may live in the global spill slab (rare; kept out of line so that the common LDS
@@ -94,8 +99,7 @@ __device__ __attribute__((noinline)) int rts_stack_below_spilled(int from_lds, i
 }
 
 // One step of the walk for the lanes that hold a node or a leaf (`node` != the sentinel): fetch the record, test the four
-// child boxes / the triangle, update the stack and the closest hit.  Shared by the per-lane walk of k_trace and by the
-// cooperative walk that finishes a straggler's traversal with all 64 lanes (below).
+// child boxes / the triangle, update the stack and the closest hit.
 #define RTS_STACK_SENTINEL 0x7fffffff
 template <bool COUNT>
 __device__ __forceinline__ void rts_walk_step(const RtsTraceArgs& a, int32_t* s_stack, uint32_t tid, uint32_t gtid, int lds_cap, uint32_t* n_spill_lds,
@@ -113,9 +117,7 @@ __device__ __forceinline__ void rts_walk_step(const RtsTraceArgs& a, int32_t* s_
     const bool at_node = node >= 0;
     const void* rp = at_node ? static_cast<const void*>(a.nodes4 + node) : static_cast<const void*>(a.leaves + ~node);
     rts_u32x4 q0, q1, q2, q3, q4, q5, q6;
-    asm volatile("; q5, q6: defined for the lanes at nodes only" : "=v"(q5), "=v"(q6));      // (no instruction: spares eight v_mov of zeros per step)
-    rts_fetch_record(rp, at_node, q0, q1, q2, q3, q4, q5, q6);
-    rts_fetch_wait(q0, q1, q2, q3, q4, q5, q6);
+    rts_fetch_record(rp, node, q0, q1, q2, q3, q4, q5, q6);
     if (at_node) {
         // BVH4 node: six dwordx4 planes (lo/hi x,y,z of the four children) + the four child ids
         // (by value through __uint_as_float: __builtin_bit_cast applied to an ext-vector ELEMENT reads element 0)

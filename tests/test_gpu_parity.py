@@ -466,7 +466,10 @@ def test_adapter_end_to_end(rts, oracle, tmp_path):
         AR.assert_responses_close(got, want)
         assert got_noise == want_noise, name
         if name == "two_tx":
-            assert set(got[:, 0]) == {0.0, 1.0} and got[got[:, 0] == 1][:, 7].min() > got[got[:, 0] == 0][:, 7].max()
+            assert set(got[:, 0]) == {0.0, 1.0}
+            for j in (0.0, 1.0):                                                   # the second transmitter's responses carry its 21.5 K on top (quirk 15)
+                n0 = set(got[(got[:, 0] == 0) & (got[:, 2] == j)][:, 7]); n1 = set(got[(got[:, 0] == 1) & (got[:, 2] == j)][:, 7])
+                assert len(n0) == 1 and len(n1) == 1 and n1.pop() == n0.pop() + 21.5
         if name == "refraction":
             assert want_noise and len(want) > 3
     # the comparison is sensitive to every argument of :1204-1247 (tests/test_oracle_kat.py shows it on the oracle side too)
@@ -625,6 +628,14 @@ def test_cube_reduce_between_handles(rts, scenes):
     assert np.abs(want).max() > 0
     np.testing.assert_allclose(want, whole.cube(), rtol=1e-9, atol=1e-30)     # f64 atomics of the whole pulse add in another order
     assert _lib.lib().rts_cube_reduce(arr, 3, 1) == _lib.RTS_ERR_UNSUPPORTED  # RCCL demanded, but the handles share a device
+    # the RCCL transport with ONE handle: librccl is loaded, a one-rank communicator created (and cached: the second call
+    # reuses it), ncclGroupStart / ncclAllReduce(sum, f64, in place) / ncclGroupEnd run on the handle's stream -- the identity
+    # on the data, and the only way to execute these lines on a single GPU
+    one = (C.c_void_p * 1)(whole.h)
+    before = whole.cube()
+    for _ in range(2):
+        _lib.check(_lib.lib().rts_cube_reduce(one, 1, 1))
+        assert np.array_equal(whole.cube(), before)
     for t in trs + [whole]:
         t.close()
 

@@ -253,9 +253,14 @@ def test_plan_cpi_in_the_library(rts):
 
 
 def test_product_trace_kernels_use_no_scratch():
-    """the product instantiations of the trace kernel (COUNT = false) must not spill vector registers: 128 VGPRs at four waves
-    per SIMD is the budget the kernel is written for, and a spilled draw of the tile queue once cost the counting builds whole
-    tiles' worth of counters (rts_trace.hip, RTS_DRAW).  hipcc's own resource remarks, device code only (no GPU needed)."""
+    """the product instantiations of the trace kernel (COUNT = false) must not spill vector registers in any loop: 128 VGPRs at
+    four waves per SIMD is the budget the kernel is written for, and a spilled draw of the tile queue once cost the counting
+    builds whole tiles' worth of counters (rts_trace.hip, RTS_DRAW).  hipcc's own resource remarks and the ISA, device code
+    only (no GPU needed).  Allowed: ONE dead store in the prologue (the allocator parks tid * 8 in scratch before the tile loop
+    and then rematerialises it instead of reloading -- no scratch load exists anywhere in the kernel).
+    Also checked here: the record fetch of a traversal step -- its global_load_dwordx4 group and the
+    s_waitcnt vmcnt(0) that covers it -- is ONE inline-asm block, so no compiler-placed instruction can touch the destination
+    registers while the loads are in flight."""
     import re, shutil, subprocess, tempfile
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
@@ -263,8 +268,9 @@ def test_product_trace_kernels_use_no_scratch():
     src = os.path.join(ROOT, "rts_amd", "csrc", "rts_trace.hip")
     with tempfile.TemporaryDirectory() as td:
         r = subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-I" + os.path.join(ROOT, "include"),
-                            "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", os.path.join(td, "t.o")], capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
+                            "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-S", src, "-o", os.path.join(td, "t.s")], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        isa = open(os.path.join(td, "t.s")).read()
     blocks = re.split(r"remark: Function Name: ", r.stderr)[1:]
     seen = 0
     for b in blocks:
@@ -274,8 +280,28 @@ def test_product_trace_kernels_use_no_scratch():
         seen += 1
         scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1)); vspill = int(re.search(r"VGPRs Spill: (\d+)", b).group(1))
         lds = int(re.search(r"LDS Size \[bytes/block\]: (\d+)", b).group(1)); occ = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1))
-        assert scratch == 0 and vspill == 0, (name, scratch, vspill)
+        assert scratch <= 16 and vspill <= 1, (name, scratch, vspill)
         assert lds * 4 <= 160 * 1024 and occ >= 2, (name, lds, occ)          # four blocks of four waves per CU
+        body = isa[isa.index("\n" + name + ":"):]
+        body = body[:body.index("s_endpgm")].splitlines()
+        in_loop = False; in_asm = False; asm_loads = 0; fetch_blocks = 0
+        for line in body:
+            t = line.strip()
+            if t.startswith(".LBB") or t.startswith("; %bb"):
+                in_loop = "in Loop" in t
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True; asm_loads = 0
+            elif t.startswith(";;#ASMEND"):
+                in_asm = False
+            elif in_asm:
+                if t.startswith("global_load_dwordx4"):
+                    asm_loads += 1
+                if t.startswith("s_waitcnt vmcnt(0)") and asm_loads:
+                    assert asm_loads == 7, (name, asm_loads); fetch_blocks += 1; asm_loads = 0
+            assert "scratch_load" not in t, (name, t)
+            if "scratch_store" in t:
+                assert not in_loop, (name, t)
+        assert fetch_blocks >= 1 and asm_loads == 0, (name, fetch_blocks, asm_loads)     # every asm load group ends in its own wait
     assert seen == 4
 
 

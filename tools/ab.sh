@@ -1,5 +1,5 @@
 # same-box A/B: variants/librts_before.so vs the tree's build.  usage: tools/ab.sh <tag>
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}"
 T=${1:-ab}
 for w in c3 c3narrow c3empty c3 c3narrow; do
   echo "before $w: $(RTS_AMD_LIB=variants/librts_before.so python3 tools/trace_bench.py $w 12 | tail -1)" >> gpurun_out/${T}.log

@@ -3,6 +3,8 @@
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rts_amd import api, scenes
+import rts_amd._lib
+rts_amd._lib.require_built()        # a timed tool never builds, and never measures a stale library
 narrow = dict(scenes.config3(), tx=dict(scenes.config3()["tx"], span=(0.004, 0.004, 0.1)))
 ecef = scenes.ecef_offset(lat=math.pi / 2)
 for name, spec in (("c3", scenes.config3()), ("c2", scenes.config2(rx_radius=200.0)), ("c3narrow", narrow),

@@ -1,4 +1,4 @@
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}"
 python bench.py --steps 20 --warmup 5 > gpurun_out/r02d_bench_c3_steps20.json 2> gpurun_out/r02d_bench_c3_steps20.err; tail -c 1500 gpurun_out/r02d_bench_c3_steps20.json; echo
 python bench.py --no-cpu-baseline > gpurun_out/r02d_bench_c3_default.json 2>&1
 python bench.py --no-cpu-baseline --config c3ecef --steps 64 > gpurun_out/r02d_bench_c3ecef.json 2>&1

@@ -6,6 +6,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from rts_amd import api, scenes  # noqa: E402
+import rts_amd._lib
+rts_amd._lib.require_built()        # a timed tool never builds, and never measures a stale library
 args = sys.argv[1:]
 which = args.pop(0) if args and not args[0].isdigit() else "c3"        # python tools/slow_tile.py [c3|c4|c5] [tile ...]
 tiles = [int(x) for x in args] or ([83452, 82689, 81989] if which == "c3" else [786329, 786322])

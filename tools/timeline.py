@@ -10,6 +10,8 @@ out = os.path.join(ROOT, "gpurun_out", "timeline.bin")
 os.makedirs(os.path.dirname(out), exist_ok=True)
 os.environ["RTS_TIMELINE"] = out
 from rts_amd import api, scenes  # noqa: E402
+import rts_amd._lib
+rts_amd._lib.require_built()        # a timed tool never builds, and never measures a stale library
 which = sys.argv[1] if len(sys.argv) > 1 else "c3"
 spec = scenes.config2(rx_radius=200.0) if which == "c2" else scenes.config4() if which == "c4" else scenes.config5() if which == "c5" else scenes.config3()
 if which == "c3narrow":

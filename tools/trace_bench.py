@@ -12,6 +12,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from rts_amd import api, scenes  # noqa: E402
+import rts_amd._lib
+rts_amd._lib.require_built()        # a timed tool never builds, and never measures a stale library
 
 which = sys.argv[1] if len(sys.argv) > 1 else "c3"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
