@@ -79,6 +79,9 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     e = hipStreamCreateWithPriority(&c->gate->tstream, hipStreamNonBlocking, prio_low);
     if (e != hipSuccess) { delete c->gate; (void)hipStreamDestroy(c->stream); delete c; rts_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return RTS_ERR_HIP; }
     c->tstream = c->gate->tstream;
+    e = hipStreamCreateWithPriority(&c->cstream, hipStreamNonBlocking, prio_low);
+    if (e != hipSuccess) { delete c; rts_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return RTS_ERR_HIP; }
+    for (int i = 0; i < 2; i++) { e = hipEventCreateWithFlags(&c->ev_coop[i], hipEventDisableTiming); if (e != hipSuccess) { delete c; rts_set_error("hipEventCreate: %s", hipGetErrorString(e)); return RTS_ERR_HIP; } }
     for (int i = 0; i < 9; i++) { e = hipEventCreate(&c->ev[i]); if (e != hipSuccess) { delete c; rts_set_error("hipEventCreate: %s", hipGetErrorString(e)); return RTS_ERR_HIP; } }
     e = hipHostMalloc((void**)&c->pin, sizeof(RtsPinned), hipHostMallocDefault);
     if (e != hipSuccess) { delete c; rts_set_error("hipHostMalloc: %s", hipGetErrorString(e)); return RTS_ERR_HIP; }
@@ -92,6 +95,9 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     { const char* e = getenv("RTS_GRID_MULT"); if (e) c->grid_mult = std::max(1, atoi(e)); }
     { const char* e = getenv("RTS_GRID_SPARE"); if (e) { c->grid_spare = std::max(0, atoi(e)); c->grid_spare_forced = true; } }
     { const char* e = getenv("RTS_TILE_LPT"); if (e && e[0] == '0') c->tile_lpt = false; }
+    { const char* e = getenv("RTS_COOP_FRAC"); if (e) { const double v = atof(e); if (v >= 0) c->coop_frac = v; } }                  // 0: no cooperative units; tests: tiny values put every tile at the head
+    { const char* e = getenv("RTS_COOP_FLOOR"); if (e) c->coop_floor = (uint32_t)std::max(0, atoi(e)); }
+    { const char* e = getenv("RTS_COOP_GRID"); if (e) c->coop_grid_max = (uint32_t)std::min(4096, std::max(1, atoi(e))); }
     { const char* e = getenv("RTS_EW_REL"); if (e) { const double v = atof(e); if (v > 0) c->ew_rel = v; } }
     { const char* e = getenv("RTS_STACK_LDS_DEBUG"); if (e) { int v = atoi(e); if (v >= 1 && v <= RTS_STACK_LDS) c->stack_lds = (uint32_t)v; } }   // tests: force the spill path
     *out = c;
@@ -114,7 +120,7 @@ extern "C" int rts_destroy(RtsHandle c)
     c->d_verts_world.release(); c->d_normals_world.release();
     c->d_motion.release(); c->d_targets.release();
     c->d_leaves.release(); c->d_sort_tmp.release(); c->d_rx.release(); c->d_recv.release(); c->d_all.release();
-    c->d_counters.release(); c->d_block_counters.release(); c->d_timeline.release(); c->d_tile_cost.release(); c->d_tile_key.release(); c->d_tile_key_sorted.release(); c->d_tile_id.release(); c->d_tile_order.release(); c->d_tile_hist.release(); c->d_tile_ctr.release(); c->d_lc.release(); c->d_dir_hist.release(); c->d_pmask.release(); c->d_child.release(); c->d_rk64.release(); c->d_rk64_sorted.release(); c->d_hit_prim.release(); c->d_hit_t.release(); c->d_stack_ovf.release();
+    c->d_counters.release(); c->d_block_counters.release(); c->d_timeline.release(); c->d_tile_cost.release(); c->d_tile_key.release(); c->d_tile_key_sorted.release(); c->d_tile_id.release(); c->d_tile_order.release(); c->d_tile_hist.release(); c->d_tile_ctr.release(); c->d_tile_head.release(); c->d_lc.release(); c->d_dir_hist.release(); c->d_pmask.release(); c->d_child.release(); c->d_rk64.release(); c->d_rk64_sorted.release(); c->d_hit_prim.release(); c->d_hit_t.release(); c->d_stack_ovf.release();
     c->d_rk.release(); c->d_rk_sorted.release(); c->d_ri.release(); c->d_ri_sorted.release(); c->d_rx_rays.release(); c->d_rx_paths.release();
     c->d_rx_angles.release(); c->d_rx_slots.release(); c->d_all_rays.release(); c->d_all_paths.release(); c->d_all_angles.release();
     c->d_akeys.release(); c->d_akeys_sorted.release(); c->d_aidx.release(); c->d_aidx_sorted.release(); c->d_ghead.release(); c->d_gid.release();
@@ -124,6 +130,8 @@ extern "C" int rts_destroy(RtsHandle c)
     if (--c->gate->refs == 0) { (void)hipStreamDestroy(c->gate->tstream); delete c->gate; }
     if (c->pin) (void)hipHostFree(c->pin);
     for (int i = 0; i < 9; i++) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 2; i++) (void)hipEventDestroy(c->ev_coop[i]);
+    (void)hipStreamSynchronize(c->cstream); (void)hipStreamDestroy(c->cstream);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return RTS_OK;
@@ -456,11 +464,12 @@ extern "C" int rts_reserve(RtsHandle c, uint64_t n_rays)
     const uint32_t H = c->params.max_refl + 1;
     RTS_HIP(c->d_recv.reserve((size_t)n * chains + 1)); RTS_HIP(c->d_counters.reserve(16)); RTS_HIP(c->d_lc.reserve(1));
     RTS_HIP(c->d_dir_hist.reserve((size_t)(c->params.max_refr ? 3 * H : std::max<uint32_t>(c->params.max_refl, 1)) * 3 * n + 4));
-    if (c->params.max_refr) RTS_HIP(c->d_child.reserve(2 * threads));
-    RTS_HIP(c->d_stack_ovf.reserve((size_t)RTS_STACK_OVF * (size_t)c->n_cu * 1024));
-    RTS_HIP(c->d_block_counters.reserve((size_t)c->n_cu * 64 * 8));
+    const size_t coop_threads = c->coop_frac > 0.0 ? (size_t)c->coop_grid_max * RTS_BLOCK : 0;
+    if (c->params.max_refr) RTS_HIP(c->d_child.reserve(2 * (threads + coop_threads)));
+    RTS_HIP(c->d_stack_ovf.reserve((size_t)RTS_STACK_OVF * ((size_t)c->n_cu * 1024 + coop_threads)));
+    RTS_HIP(c->d_block_counters.reserve(((size_t)c->n_cu * 64 + c->coop_grid_max) * 8));
     const size_t n_tiles = (size_t)((n + RTS_WTILE - 1) / RTS_WTILE), n_hist = (size_t)((W3 + RTS_WTILE - 1) / RTS_WTILE);
-    RTS_HIP(c->d_tile_ctr.reserve(RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE)); RTS_HIP(c->d_tile_cost.reserve(n_tiles)); RTS_HIP(c->d_tile_key.reserve(n_tiles)); RTS_HIP(c->d_tile_key_sorted.reserve(n_tiles));
+    RTS_HIP(c->d_tile_ctr.reserve(2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE)); RTS_HIP(c->d_tile_cost.reserve(n_tiles)); RTS_HIP(c->d_tile_key.reserve(n_tiles)); RTS_HIP(c->d_tile_key_sorted.reserve(n_tiles));
     RTS_HIP(c->d_tile_id.reserve(n_tiles)); RTS_HIP(c->d_tile_order.reserve(n_tiles));
     if (c->tile_hist_n != (uint32_t)n_hist) {
         RTS_HIP(c->d_tile_hist.reserve(n_hist)); RTS_HIP(hipMemsetAsync(c->d_tile_hist.p, 0, sizeof(uint32_t) * n_hist, c->stream));
@@ -580,11 +589,13 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     const uint32_t chains = a.max_refr ? 3u : 1u;
     if ((uint64_t)n * chains > 0xfffffff0ULL) { rts_set_error("rts_trace_pulse: rays x chains exceeds 2^32"); return RTS_ERR_UNSUPPORTED; }
     a.total_threads = grid * RTS_BLOCK;
+    const uint32_t coop_threads = c->coop_frac > 0.0 ? c->coop_grid_max * RTS_BLOCK : 0u;      // the cooperative kernel's rows of the per-thread slabs
+    a.slab_threads = a.total_threads + coop_threads;
     RTS_HIP(c->d_recv.reserve((size_t)n * chains + 1)); RTS_HIP(c->d_counters.reserve(16));
     RTS_HIP(c->d_dir_hist.reserve((size_t)(a.max_refr ? 3 * (c->params.max_refl + 1) : std::max<uint32_t>(c->params.max_refl, 1)) * 3 * n + 4));
-    if (a.max_refr) RTS_HIP(c->d_child.reserve((size_t)2 * a.total_threads));
-    RTS_HIP(c->d_stack_ovf.reserve((size_t)RTS_STACK_OVF * a.total_threads));
-    RTS_HIP(c->d_block_counters.reserve((size_t)grid * 8));
+    if (a.max_refr) RTS_HIP(c->d_child.reserve((size_t)2 * a.slab_threads));
+    RTS_HIP(c->d_stack_ovf.reserve((size_t)RTS_STACK_OVF * a.slab_threads));
+    RTS_HIP(c->d_block_counters.reserve(((size_t)grid + c->coop_grid_max) * 8));
     if (keep_all) {
         RTS_HIP(c->d_all.reserve((size_t)n * chains + 1)); RTS_HIP(c->d_hit_prim.reserve((size_t)n * (c->params.max_refl + 1) + 1)); RTS_HIP(c->d_hit_t.reserve((size_t)n * (c->params.max_refl + 1) + 1));
         rts_fill_i32(st, c->d_hit_prim.p, -2, (size_t)n * (c->params.max_refl + 1));
@@ -602,7 +613,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
         const uint64_t sig[4] = {n, first, ((uint64_t)il_parts << 32) | il_tile, il_part};
         const bool aligned = first % RTS_WTILE == 0 && (il_parts <= 1 || il_tile % RTS_WTILE == 0);
         const uint32_t n_hist = (uint32_t)((total + RTS_WTILE - 1) / RTS_WTILE);
-        RTS_HIP(c->d_tile_ctr.reserve(RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE)); RTS_HIP(hipMemsetAsync(c->d_tile_ctr.p, 0, sizeof(uint32_t) * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE, st));
+        RTS_HIP(c->d_tile_ctr.reserve(2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE)); RTS_HIP(hipMemsetAsync(c->d_tile_ctr.p, 0, sizeof(uint32_t) * 2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE, st));
         a.tile_ctr = c->d_tile_ctr.p;
         if (lpt && aligned && n_tiles > grid * (RTS_BLOCK / RTS_WTILE)) {
             if (c->tile_hist_n != n_hist) {
@@ -610,8 +621,8 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
                 c->tile_hist_n = n_hist; c->tile_hist_any = false; c->tile_cost_pending = false;
             }
             if (c->tile_cost_pending || c->tile_hist_any) {
-                int rc = rts_tile_order_build(c, c->tile_cost_sig, c->tile_cost_pending, sig, n_tiles); if (rc != RTS_OK) return rc;
-                a.tile_order = c->d_tile_order.p; c->tile_hist_any = true;
+                int rc = rts_tile_order_build(c, c->tile_cost_sig, c->tile_cost_pending, sig, n_tiles, grid * (RTS_BLOCK / RTS_WTILE)); if (rc != RTS_OK) return rc;
+                a.tile_order = c->d_tile_order.p; a.tile_head = c->coop_frac > 0.0 ? c->d_tile_head.p : nullptr; c->tile_hist_any = true;
             }
             RTS_HIP(c->d_tile_cost.reserve(n_tiles));
             RTS_HIP(hipMemsetAsync(c->d_tile_cost.p, 0, sizeof(uint32_t) * n_tiles, st));
@@ -629,7 +640,20 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     RTS_HIP(hipEventRecord(c->ev[8], st));                       // scene + per-pulse buffers of this handle are ready
     RTS_HIP(hipStreamWaitEvent(c->tstream, c->ev[8], 0));
     RTS_HIP(hipEventRecord(c->ev[2], c->tstream));
-    int rc = rts_trace_launch(c, a, count_trav);
+    // the cooperative kernel (tiles at the head of the cost order, one launch index per wave): its grid follows the head count
+    // of the handle's previous order build (the count of THIS build is on the device; a grid too small or too large only costs
+    // balance, every unit is drawn from a queue) -- read synchronously the first time
+    // Whether there is a cooperative kernel at all is decided HERE, from that earlier count (both kernels must agree on
+    // who traces the head of the order): no head last time -> none now, and the ordinary kernel traces every tile.
+    unsigned coop_grid = 0;
+    if (a.tile_head) {
+        if (!c->head_hint_valid) { RTS_HIP(hipStreamSynchronize(st)); c->head_hint_valid = true; }
+        const uint64_t units = 64ULL * c->pin->n_head;
+        if (units == 0) a.tile_head = nullptr;
+        else coop_grid = (unsigned)std::min<uint64_t>(c->coop_grid_max, std::max<uint64_t>(16, (units + 3) / 4));
+        c->last_args = a;
+    }
+    int rc = rts_trace_launch(c, a, count_trav, coop_grid);
     if (rc != RTS_OK) return rc;
     RTS_STAGE(c, "k_trace");
     RTS_HIP(hipEventRecord(c->ev[3], c->tstream));

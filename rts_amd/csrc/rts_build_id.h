@@ -1,1 +1,1 @@
-#define RTS_SOURCE_HASH "a1ce3adce15b5d92"
+#define RTS_SOURCE_HASH "232ce2d03e6e1cce"

@@ -156,10 +156,12 @@ struct RtsTraceArgs {
     int32_t* hit_prim;              // [n_rays][max_refl+1] (keep_all)
     float* hit_t;                   // [n_rays][max_refl+1] (keep_all)
     int32_t* stack_ovf;             // [RTS_STACK_OVF][grid threads]
-    uint32_t total_threads;
+    uint32_t total_threads;         // threads of the ordinary kernel's grid
+    uint32_t slab_threads;          // row length of the per-thread slabs (stack_ovf, child): total_threads + the cooperative kernel's threads
     const uint32_t* tile_order;     // [wave tiles] tile ids in descending order of the cost last seen by the handle (null: identity)
     uint32_t* tile_cost;            // [wave tiles] out: duration of the tile (shader clocks >> 6, + 1)
     uint32_t* tile_ctr;             // [RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE] draw counters (element s * STRIDE), zero at launch
+    const uint32_t* tile_head;      // [1] number of tiles at the head of tile_order that are traced as 64 cooperative units (null: none)
     unsigned long long* timeline;   // debug (RTS_TIMELINE, counting build): [grid][2] block start/end ticks, then [tiles] tile durations (100 MHz)
     uint32_t pre_filter;            // 1: primary rays go through the f32 pre-filter (needs the mask when there is geometry)
     const uint32_t* pmask;          // primary-ray mask: RTS_MASK_N^2 bits, then one word != 0 if the mask is void for this pulse (null: none)
@@ -179,6 +181,7 @@ struct RtsMeshHost {
 #define RTS_PIN_GROUPS 4096
 struct RtsPinned {
     RtsLaunchConsts lc;
+    uint32_t n_head, n_head_pad;    // rts_tile_order_build's last count of cooperative tiles (sizes the next cooperative grid)
     unsigned long long cnt[16];
     uint32_t G, pad;
     RtsTargetMotion motion[256];
@@ -235,6 +238,9 @@ struct RtsContext {
     int device;
     hipStream_t stream = nullptr;       // scene placement, ordering, finalise, aggregation (high priority: short kernels)
     hipStream_t tstream = nullptr;      // trace kernels (the link group's, see RtsGate)
+    hipStream_t cstream = nullptr; hipEvent_t ev_coop[2];      // the cooperative trace kernel of a launch runs beside the ordinary one (rts_trace.hip)
+    uint32_t coop_grid_max = 1024;      // most blocks of the cooperative kernel (RTS_COOP_GRID)
+    bool head_hint_valid = false;       // pin->n_head holds the count of an earlier order build
     hipEvent_t ev[9];
     // scene: the shared static part, and this handle's placement of it
     RtsScene* scene = nullptr;          // never null after rts_create
@@ -251,7 +257,9 @@ struct RtsContext {
     // per pulse
     uint64_t ray_first = 0; uint32_t n_rays = 0;
     DevBuf<RtsEndRecord> d_recv, d_all; DevBuf<unsigned long long> d_counters, d_block_counters, d_timeline;
-    DevBuf<uint32_t> d_tile_cost, d_tile_key, d_tile_key_sorted, d_tile_id, d_tile_order, d_tile_hist, d_tile_ctr;
+    DevBuf<uint32_t> d_tile_cost, d_tile_key, d_tile_key_sorted, d_tile_id, d_tile_order, d_tile_hist, d_tile_ctr, d_tile_head;
+    uint32_t coop_floor = 56250;        // ... and more than this many cost units (shader clocks >> 6; 56 250 = 1.5 ms of one wave) (RTS_COOP_FLOOR)
+    double coop_frac = 0.5;            // a tile costing more than this fraction of the launch's balanced time is traced as cooperative units (RTS_COOP_FRAC; 0: never)
     bool tile_cost_pending = false, tile_hist_any = false; uint64_t tile_cost_sig[4] = {0, 0, 0, 0}; uint32_t tile_hist_n = 0;   // per-global-tile cost history (rts_post.hip)
     DevBuf<float> d_dir_hist; DevBuf<uint32_t> d_pmask; bool use_pmask = true, pre_dense = false;
     DevBuf<int32_t> d_hit_prim; DevBuf<float> d_hit_t; DevBuf<int32_t> d_stack_ovf; DevBuf<RtsChildState> d_child;
@@ -278,8 +286,8 @@ int rts_sah_build(const double* verts, const uint32_t* tris, uint32_t n_tris, do
 int rts_lbvh_build_device(RtsContext* c, RtsScene* ns, const std::vector<uint32_t>& vidx, const std::vector<RtsMeshHost>& mh, double split_budget);
 int rts_scene_place(RtsContext* c);
 int rts_primary_mask_build(RtsContext* c, const RtsLaunchConsts& lc);
-int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_valid, const uint64_t* cur_sig, uint32_t n_tiles_cur);
-int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a, bool count_traversal);
+int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_valid, const uint64_t* cur_sig, uint32_t n_tiles_cur, uint32_t resident_waves);
+int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a, bool count_traversal, unsigned coop_grid);
 int rts_post_order_and_expand(RtsContext* c);
 int rts_post_expand_all(RtsContext* c);
 int rts_cube_accumulate_device(RtsContext* c, uint32_t pulse_index, double cspeed, double carrier);

@@ -149,8 +149,32 @@ __global__ void k_tile_keys(const uint32_t* __restrict__ hist, uint32_t n_hist, 
     key[j] = ~est; id[j] = j;
 }
 
+// How many tiles at the head of the (descending) cost order are worth tracing as cooperative units: those whose estimated
+// cost exceeds `frac` of the launch's balanced time (sum of the costs / resident waves) and an absolute floor.  One block;
+// key_sorted = ~cost, ascending.
+__global__ void __launch_bounds__(1024) k_tile_head(const uint32_t* __restrict__ key_sorted, uint32_t n, uint32_t resident_waves, double frac, uint32_t floor_cost, uint32_t max_head,
+                                                    uint32_t* __restrict__ out)
+{
+    __shared__ unsigned long long s_sum[1024]; __shared__ uint32_t s_cnt[1024]; __shared__ uint32_t s_thr;
+    unsigned long long acc = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) acc += (uint32_t)~key_sorted[i];
+    s_sum[threadIdx.x] = acc; __syncthreads();
+    for (uint32_t o = blockDim.x / 2; o > 0; o >>= 1) { if (threadIdx.x < o) s_sum[threadIdx.x] += s_sum[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) {
+        const double balanced = (double)s_sum[0] / (double)(resident_waves ? resident_waves : 1u);
+        double thr = frac * balanced; if (thr < (double)floor_cost) thr = (double)floor_cost; if (thr > 4.0e9) thr = 4.0e9;
+        s_thr = (uint32_t)thr;
+    }
+    __syncthreads();
+    const uint32_t thr = s_thr; uint32_t cnt = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) cnt += ((uint32_t)~key_sorted[i] > thr) ? 1u : 0u;
+    s_cnt[threadIdx.x] = cnt; __syncthreads();
+    for (uint32_t o = blockDim.x / 2; o > 0; o >>= 1) { if (threadIdx.x < o) s_cnt[threadIdx.x] += s_cnt[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) out[0] = frac > 0.0 ? min(s_cnt[0], max_head) : 0u;
+}
+
 // prev_valid: d_tile_cost holds the costs of a launch of shape prev_shape that have not been merged yet
-int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_valid, const uint64_t* cur_sig, uint32_t n_tiles_cur)
+int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_valid, const uint64_t* cur_sig, uint32_t n_tiles_cur, uint32_t resident_waves)
 {
     hipStream_t st = c->stream;
     const uint32_t n_hist = c->tile_hist_n;
@@ -164,6 +188,10 @@ int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_vali
     RTS_HIP(rocprim::radix_sort_pairs(nullptr, tmp, c->d_tile_key.p, c->d_tile_key_sorted.p, c->d_tile_id.p, c->d_tile_order.p, n_tiles_cur, 0, 32, st));
     RTS_HIP(c->d_sort_tmp.reserve(tmp));
     RTS_HIP(rocprim::radix_sort_pairs(c->d_sort_tmp.p, tmp, c->d_tile_key.p, c->d_tile_key_sorted.p, c->d_tile_id.p, c->d_tile_order.p, n_tiles_cur, 0, 32, st));
+    // cooperative head (rts_trace.hip): at most 16 384 tiles
+    RTS_HIP(c->d_tile_head.reserve(1));
+    k_tile_head<<<1, 1024, 0, st>>>(c->d_tile_key_sorted.p, n_tiles_cur, resident_waves, c->coop_frac, c->coop_floor, 16384u, c->d_tile_head.p);
+    RTS_HIP(hipMemcpyAsync(&c->pin->n_head, c->d_tile_head.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));      // read by the NEXT launch's set-up (or after a sync, the first time)
     return RTS_OK;
 }
 

@@ -109,7 +109,7 @@ __device__ __forceinline__ void rts_walk_step(const RtsTraceArgs& a, int32_t* s_
 {
     const bool deep = __any(sp + 4 > lds_cap);                  // wave-uniform: some lane is about to leave the LDS part
     int below = s_stack[min(sp - 1, lds_cap - 1) * RTS_BLOCK + tid];      // (always an LDS read: a second, global source here made the compiler fold both into one FLAT load)
-    if (deep) below = rts_stack_below_spilled(below, sp, lds_cap, a.stack_ovf, a.total_threads, gtid);
+    if (deep) below = rts_stack_below_spilled(below, sp, lds_cap, a.stack_ovf, a.slab_threads, gtid);
     // One fetch for both kinds of step: a lane at a node needs its 112-byte record (six planes + child ids),
     // a lane at a leaf its 80-byte record -- the same five (seven) dwordx4 loads from a per-lane base,
     // issued together at the top of the step, so a wave whose lanes are at nodes AND at leaves waits for
@@ -150,7 +150,7 @@ __device__ __forceinline__ void rts_walk_step(const RtsTraceArgs& a, int32_t* s_
             node = go ? c0 : below; sp -= go ? 0 : 1;
         } else {
 #define RTS_PUSH(cv) { if (sp < lds_cap) s_stack[sp * RTS_BLOCK + tid] = (cv); \
-                       else if (sp < lds_cap + RTS_STACK_OVF) { a.stack_ovf[(size_t)(sp - lds_cap) * a.total_threads + gtid] = (cv); atomicAdd(n_spill_lds, 1u); } \
+                       else if (sp < lds_cap + RTS_STACK_OVF) { a.stack_ovf[(size_t)(sp - lds_cap) * a.slab_threads + gtid] = (cv); atomicAdd(n_spill_lds, 1u); } \
                        else hard_overflow = true; \
                        if (sp < lds_cap + RTS_STACK_OVF) sp++; }
             if (d3 < INF) RTS_PUSH(c3)
@@ -181,120 +181,84 @@ __device__ __forceinline__ void rts_walk_step(const RtsTraceArgs& a, int32_t* s_
     }
 }
 
-// KEEP_ALL is a template parameter, not a run-time flag: hipcc (ROCm 7.2) lowered the uniform
-// `if (a.keep_all)` to a per-lane v_cmp mask computed under the divergent exec of the bounce loop
-// and re-used it at the write-back under a different exec, so lanes that were inactive at the
-// definition stored through the null all_records pointer.
-// REFR builds the refraction branch of closest_hit (normal_shader.cu:191-282): a launch index then owns up
-// to three independent ray chains -- 0: the reflection chain, 1: the ray refracted INTO the first-hit
-// target (spawned by chain 0 at its first hit), 2: the ray refracted back OUT (spawned by chain 1 at its
-// first hit) -- whose results live in rows rayIndex + k*W^3 of the output buffers (:214, :272-279).
-// The reference recurses depth first; the chains are independent once spawned (the payload is copied,
-// :191), so they are traced one after the other and the spawned state is parked in global memory.
-template <bool COUNT, bool KEEP_ALL, bool REFR>
-__global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTraceArgs a)
+// The walk of ONE ray by all 64 lanes of a wave (COOP units).  Every lane runs the ordinary depth-first step (rts_walk_step)
+// on its own LDS stack; a lane without work takes the BOTTOM entry -- the largest open subtree -- of a lane that has one,
+// through a 64-entry exchange row in LDS (giver k writes row[k], taker k reads it; ranks by v_mbcnt over the two ballots).
+// A given entry is overwritten with the sentinel, so its owner's stack simply ends one entry higher.  The prune bound is
+// shared: whenever a lane finds a closer hit the wave takes the minimum of the lanes' bounds.  The winner is the
+// lexicographic minimum of (f32 t bits, global primitive id) over the lanes -- the tie rule of the per-lane walk -- and is
+// broadcast, so every lane leaves with the same closest hit.  Exit: no lane holds a node (a lane only goes idle with an
+// empty stack, and entries are handed over in the iteration they are taken in, so nothing is pending then).
+__device__ __forceinline__ float rts_wave_min_f32(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ unsigned long long rts_wave_min_u64(unsigned long long v) { for (int o = 32; o > 0; o >>= 1) { const unsigned long long w = __shfl_xor(v, o); v = w < v ? w : v; } return v; }
+template <bool COUNT>
+__device__ __forceinline__ void rts_walk_coop(const RtsTraceArgs& a, int32_t* s_stack, int32_t* s_exch, uint32_t tid, uint32_t gtid, uint32_t lane, int lds_cap, uint32_t* n_spill_lds,
+                                              int root, const RtsSlabRay& lr, const dvec3& prev, const dvec3& dir, float tmin,
+                                              float& best_t, int& best_leaf, uint32_t& best_prim, float& t_prune, uint32_t& n_nodes, uint32_t& n_tris, bool& hard_overflow)
 {
-    __shared__ __attribute__((aligned(16))) int32_t s_stack[RTS_STACK_LDS * RTS_BLOCK];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t gtid = blockIdx.x * RTS_BLOCK + tid;
-    // Launch constants and the first RTS_RX_LDS receivers are copied into LDS once per (persistent) block.  Read through their
-    // device pointers they are wave-wide BROADCAST loads on the vector memory path -- which returns 64 x 16 bytes per dwordx4
-    // whether the lanes' addresses differ or not -- and they are re-issued for every tile and every missing segment (the
-    // fetch asm clobbers memory, so nothing read through a pointer stays in registers): on a launch that hits nothing they
-    // alone kept the return path 87 % busy (5.3 M loads, counters of tools/trace_bench.py c3nomesh).
-    __shared__ __attribute__((aligned(16))) RtsLaunchConsts s_lc;
-    __shared__ __attribute__((aligned(16))) RtsRxDev s_rx[RTS_RX_LDS];
-    // Payload that the traversal loop does not touch lives in LDS, entry-major like the stack (lane `tid` owns element
-    // k * RTS_BLOCK + tid: conflict-free 8-byte accesses): the first hit point, the two path words and the per-lane
-    // counters -- 13 dwords per lane that the register allocator otherwise carried through the walk (128-VGPR budget at
-    // four waves per SIMD) by spilling to scratch.  They are touched per SHADED hit and at write-back only.
-    __shared__ __attribute__((aligned(16))) double s_first[3 * RTS_BLOCK];
-    __shared__ __attribute__((aligned(16))) unsigned long long s_path[2 * RTS_BLOCK];
-    __shared__ uint32_t s_n[3 * RTS_BLOCK];                      // segments, shaded hits, stack entries spilled (per lane)
-    s_n[threadIdx.x] = 0; s_n[RTS_BLOCK + threadIdx.x] = 0; s_n[2 * RTS_BLOCK + threadIdx.x] = 0;
-    {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.lc); uint32_t* dst = reinterpret_cast<uint32_t*>(&s_lc);
-        for (uint32_t i = threadIdx.x; i < sizeof(RtsLaunchConsts) / 4; i += RTS_BLOCK) dst[i] = src[i];
-        const uint32_t n_rx_lds = a.n_rx < RTS_RX_LDS ? a.n_rx : RTS_RX_LDS;
-        const uint32_t* rsrc = reinterpret_cast<const uint32_t*>(a.rx); uint32_t* rdst = reinterpret_cast<uint32_t*>(s_rx);
-        for (uint32_t i = threadIdx.x; i < n_rx_lds * (sizeof(RtsRxDev) / 4); i += RTS_BLOCK) rdst[i] = rsrc[i];
-    }
-    __syncthreads();
-    const RtsLaunchConsts& lc = s_lc;
-    const dvec3 origin = mk3(lc.ox, lc.oy, lc.oz);
-    // pre-filter constants of the receivers, for rays that start at the transmitter: q = centre - origin (f64, then f32),
-    // |q|, |q|^2 and the widened radius^2.  Widening: the f32 direction is good to ~2e-6 rad and the f32 discriminant
-    // b^2 - (|q|^2 - r^2) |d|^2 to ~1e-6 |q|^2; r'^2 = r^2 (1 + 1e-3) + 1e-5 |q|^2 + 1e-6 covers both ten times over.
-    // The filter has to be conservative with respect to the REFERENCE'S arithmetic, not to geometry: its quadratic forms
-    // C = |prev|^2 + |c|^2 - 2 c.prev - r^2 from world-scale terms (ray_tracer.cu:285), which at Earth-centred coordinates
-    // cancel catastrophically -- terms of 4e13 m^2, rounded a dozen times: the sphere it tests is up to ~0.05 m^2 larger or
-    // smaller in r^2 than the one it was given (found by tools/fuzz_equal.py: a 0.86 m sphere 3.7 m from the transmitter
-    // captured 32 rays the geometric filter had excluded).  + 1e-14 (|o|^2 + |c|^2): 45 ulps of the largest term.
-    __shared__ float s_rxp[RTS_RX_LDS][6];
-    if (tid < RTS_RX_LDS && tid < a.n_rx) {
-        const RtsRxDev r = s_rx[tid];
-        const double qx = r.cx - lc.ox, qy = r.cy - lc.oy, qz = r.cz - lc.oz, qq = qx*qx + qy*qy + qz*qz;
-        s_rxp[tid][0] = (float)qx; s_rxp[tid][1] = (float)qy; s_rxp[tid][2] = (float)qz; s_rxp[tid][3] = (float)qq * 1.000001f;
-        s_rxp[tid][4] = (float)(r.radius * r.radius * 1.001 + 1.0e-5 * qq + 1.0e-6 + 1.0e-14 * (lc.ox*lc.ox + lc.oy*lc.oy + lc.oz*lc.oz + r.cx*r.cx + r.cy*r.cy + r.cz*r.cz));
-        s_rxp[tid][5] = (float)sqrt(qq);
-    }
-    __syncthreads();
-    uint32_t n_nodes = 0, n_tris = 0;                            // counting build only (per lane and launch: far below 2^32)
-    bool hard_overflow = false;
-    const bool mask_on = a.pmask != nullptr && lc.mask.n != 0 && a.pmask[(size_t)lc.mask.n * lc.mask.n / 32u] == 0u;     // (uniform) not voided by k_primary_mask
-    // the pre-filter can only pay if it can clear a ray of the targets: with geometry but no valid mask every primary needs
-    // its exact direction anyway
-    const bool pre_on = lc.W > 1 && a.n_rx <= RTS_RX_LDS && (mask_on || a.n_prims == 0) && a.pre_filter;
-    const uint32_t max_refr = REFR ? 2u : 0u;
-    const uint32_t D = a.max_refl + max_refr;
-
-    unsigned long long tl_t0 = 0;
-    if (COUNT && a.timeline && tid == 0) { tl_t0 = wall_clock64(); a.timeline[(size_t)blockIdx.x * 2] = tl_t0; }
-    // Work units are WAVE TILES of 64 consecutive launch indices, taken by the waves one at a time from RTS_TILE_CTRS
-    // striped counters: wave w draws k = atomicAdd(ctr[w % C]) and traces position k*C + (w % C) of the tile order.  Tile
-    // durations are extremely skewed (median ~2.5 us: every ray misses; 99.9th percentile ~0.3 ms; a handful near 0.9 ms whose
-    // rays bounce six times through a hundred steps each), so an in-order sweep left a ~1 ms tail in which a few waves finished
-    // their slow tiles on an otherwise idle GPU.  Pulses of an interval look alike, so every launch records what each tile cost
-    // (tile_cost, shader clocks >> 6) and the next launches of the handle trace the tiles in descending order of the cost
-    // last seen (tile_order, built by rts_tile_order_build): longest-processing-time-first list scheduling.  Striping the
-    // counter -- ONE 128-byte line per stripe (RTS_TILE_CTR_STRIDE): atomics on one line serialise in L2 at ~10 ns each
-    // whatever their address -- keeps the draws off the critical path: 69 k of them per launch over 64 lines.
-    const uint32_t n_tiles = (a.n_rays + 63u) / 64u;
-    const uint32_t lane = tid & 63u;
-    const uint32_t stripe = __builtin_amdgcn_readfirstlane((blockIdx.x * (RTS_BLOCK / 64u) + (tid >> 6)) % RTS_TILE_CTRS);   // wave-uniform: the queue arithmetic below stays scalar
-    // Draw schedule of a stripe (positions k*C + stripe, k = 0, 1, ...): the first quarter -- the expensive end of the
-    // order -- one tile per draw, the cheap rest four tiles per draw (a miss-only tile is ~2 us of work, and so is a draw's
-    // latency).  In the cheap part the next draw is issued before the current tiles are traced, so its latency hides behind them.
-    const uint32_t per_stripe = (n_tiles + RTS_TILE_CTRS - 1u) / RTS_TILE_CTRS;
-    const uint32_t single_draws = per_stripe >= 1024u ? per_stripe / 4u : per_stripe;      // (short queues: one tile per draw throughout)
-    // The pending draw is held in a register of lane 0 (so that its latency hides behind the tiles traced meanwhile) -- except
-    // in the counting builds, which are short of registers: there the allocator spilled it to scratch, stored under
-    // EXEC = lane 0 and reloaded at the loop top, and launches then lost whole tiles' worth of counters from run to run
-    // (the reload overtaking the store is the suspicion; product builds have no scratch at all, tests/test_host_logic.py checks).
-    __shared__ uint32_t s_draw[RTS_BLOCK / 64];
-    uint32_t draw_next = 0;
-#define RTS_DRAW() { const uint32_t dv_ = atomicAdd(&a.tile_ctr[stripe * RTS_TILE_CTR_STRIDE], 1u); if (COUNT) s_draw[tid >> 6] = dv_; else draw_next = dv_; }
-    if (lane == 0) RTS_DRAW()
+    const int SENTINEL = RTS_STACK_SENTINEL;
+    volatile int32_t* row = s_exch + (tid & ~63u);
+    s_stack[tid] = SENTINEL;
+    int sp = 1, bot = 1;                                  // pending entries of this lane: [bot, sp)
+    int node = lane == 0 ? root : SENTINEL;
+    uint32_t steps = 0;
     for (;;) {
-      const uint32_t draw = __builtin_amdgcn_readfirstlane(COUNT ? s_draw[tid >> 6] : draw_next);
-      const uint32_t k0 = draw < single_draws ? draw : single_draws + 4u * (draw - single_draws);
-      const uint32_t kn = draw < single_draws ? 1u : 4u;
-      if (k0 >= per_stripe) break;
-      // (only in the cheap part of the order: a draw made before an EXPENSIVE tile would reserve the stripe's next most
-      // expensive tile for as long as this one takes -- the launch then ends with that tile, traced alone)
-      const bool ahead = draw >= single_draws;
-      if (ahead && lane == 0) RTS_DRAW()
-     for (uint32_t kb = 0; kb < kn; kb++) {
-      const uint64_t tpos64 = (uint64_t)(k0 + kb) * RTS_TILE_CTRS + stripe;
-      if (tpos64 >= n_tiles) break;
-      const uint32_t tpos = (uint32_t)tpos64;
-      // no history yet (first launch of the handle): centre-out over the launch range -- the beam is normally centred on
-      // the targets, so the expensive tiles sit in the middle of the lattice and should be started first
-      const uint32_t tile = a.tile_order ? a.tile_order[tpos] : ((tpos & 1u) ? (n_tiles - 1u) / 2u + (tpos + 1u) / 2u : (n_tiles - 1u) / 2u - tpos / 2u);
-      const uint32_t slot = tile * 64u + lane;
-      const long long tile_t0 = clock64();
-      const unsigned long long tl_tile = (COUNT && a.timeline && lane == 0) ? wall_clock64() : 0ULL;
-      if (slot < a.n_rays) {
+        const bool busy = node != SENTINEL;
+        const unsigned long long busy_m = __ballot(busy);
+        if (busy_m == 0ULL) break;
+        if (++steps > (1u << 24)) { hard_overflow = true; break; }                  // malformed tree guard: every wave must drain
+        const unsigned long long idle_m = ~busy_m;                                  // (a COOP unit runs with all 64 lanes)
+        if (idle_m != 0ULL) {
+            const bool can = busy && sp > bot && bot < lds_cap;                     // something pending, and in the LDS part of the stack
+            const unsigned long long can_m = __ballot(can);
+            if (can_m != 0ULL) {
+                const uint32_t n_give = min((uint32_t)__popcll(idle_m), (uint32_t)__popcll(can_m));
+                const uint32_t r_can = __builtin_amdgcn_mbcnt_hi((uint32_t)(can_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)can_m, 0u));
+                const uint32_t r_idle = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
+                if (can && r_can < n_give) { row[r_can] = s_stack[bot * RTS_BLOCK + tid]; s_stack[bot * RTS_BLOCK + tid] = SENTINEL; bot++; }
+                __builtin_amdgcn_wave_barrier();
+                if (!busy && r_idle < n_give) { node = row[r_idle]; sp = 1; bot = 1; }      // (entry 0 of the taker still holds the sentinel)
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        bool improved = false;
+        if (node != SENTINEL) {
+            const float before = t_prune;
+            rts_walk_step<COUNT>(a, s_stack, tid, gtid, lds_cap, n_spill_lds, node, sp, lr, prev, dir, tmin, best_t, best_leaf, best_prim, t_prune, n_nodes, n_tris, hard_overflow);
+            improved = t_prune != before;
+        }
+        if (__any(improved)) t_prune = rts_wave_min_f32(t_prune);
+    }
+    // closest hit over the lanes: smallest f32 t (positive: its bits order like the value), then lowest global primitive id
+    const unsigned long long key = best_leaf >= 0 ? (((unsigned long long)__float_as_uint(best_t) << 32) | best_prim) : ~0ULL;
+    const unsigned long long kmin = rts_wave_min_u64(key);
+    if (kmin != ~0ULL) {
+        const int win = __ffsll((long long)__ballot(key == kmin)) - 1;
+        best_leaf = __shfl(best_leaf, win); best_t = __uint_as_float((uint32_t)(kmin >> 32)); best_prim = (uint32_t)kmin;
+        t_prune = f32_next_up_pos(best_t);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// One work unit of the trace kernel: launch index `slot` through its whole bounce chain (ray generation, closest hit per
+// segment, shading, capture, write-back).  Two instantiations per kernel:
+//   COOP = false : one lane per launch index -- the wave traces 64 consecutive launch indices (a tile), every lane with its
+//                  own `slot` and its own walk;
+//   COOP = true  : ALL 64 lanes of the wave trace the SAME launch index: the ray state is computed redundantly (uniformly)
+//                  by every lane, the WALK is shared out between the lanes (rts_walk_coop), lane 0 alone counts and writes.
+//                  For the tiles at the head of the cost order, whose rays walk thousands of dependent steps (grazing rays
+//                  along a fuselage: ~4 000 steps per segment on BASELINE configs[3]): traced one lane per ray such a tile
+//                  occupies ONE wave for 7-13 ms of a launch whose balanced time is 7.8 ms; as 64 cooperative units it is
+//                  spread over 64 waves that finish each ray in a few hundred wave steps.
+// The two share every expression of the payload arithmetic (same code, same operand order): results are bit-identical.
+struct RtsUnitLds { int32_t* stack; int32_t* exch; double* first; unsigned long long* path; uint32_t* n; const RtsRxDev* rx; const float (*rxp)[6]; };
+template <bool COUNT, bool KEEP_ALL, bool REFR, bool COOP>
+__device__ __forceinline__ void rts_trace_unit(const RtsTraceArgs& a, const RtsLaunchConsts& lc, const RtsUnitLds& L_, const uint32_t tid, const uint32_t gtid, const uint32_t lane,
+                                               const uint32_t slot, const bool pre_on, const bool mask_on, const uint32_t D, const uint32_t max_refr, const dvec3& origin,
+                                               uint32_t& n_nodes, uint32_t& n_tris, bool& hard_overflow)
+{
+      int32_t* const s_stack = L_.stack; int32_t* const s_exch = L_.exch; double* const s_first = L_.first; unsigned long long* const s_path = L_.path; uint32_t* const s_n = L_.n;
+      const RtsRxDev* const s_rx = L_.rx; const float (*const s_rxp)[6] = L_.rxp;
       uint32_t pending = 0;                   // bit k: chain k has been spawned
       uint32_t refr_code0 = 0;                // (target + 1) of chain 0's refraction, for the path prefill of rows >= 3
       for (uint32_t chain = 0; chain < (REFR ? 3u : 1u); chain++) {
@@ -340,7 +304,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
             rayLength = 0; power = 0; doppler = 0;
         } else {
             if (!REFR || !(pending & (1u << chain))) continue;
-            const RtsChildState cs = a.child[(size_t)(chain - 1) * a.total_threads + gtid];
+            const RtsChildState cs = a.child[(size_t)(chain - 1) * a.slab_threads + gtid];
             dir = mk3((double)cs.dx, (double)cs.dy, (double)cs.dz);          // prd_refr.rayDirection = widened f32 refract() result (:252)
             prev = mk3(cs.prevx, cs.prevy, cs.prevz);
             s_first[tid] = cs.firstx; s_first[RTS_BLOCK + tid] = cs.firsty; s_first[2 * RTS_BLOCK + tid] = cs.firstz;
@@ -356,7 +320,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
 
         for (;;) {
             // ------------------------------------------------------------ rtTrace: closest hit over the targets' hierarchies
-            atomicAdd(&s_n[tid], 1u);                                          // (ds_add_u32, no return)
+            if (!COOP || lane == 0) atomicAdd(&s_n[tid], 1u);                   // (ds_add_u32, no return)
             const float tmin = chain_start ? SCENE_EPS : SCENE_EPS_R;          // ray_tracer.cu:209, normal_shader.cu:242,297
             float best_t = RTS_DEFAULT_TMAX;
             int best_leaf = -1; uint32_t best_prim = 0xffffffffu;
@@ -390,17 +354,22 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
                     // unconditionally at the top of the stack and the stack pointer advances by the hit predicate.
                     const int SENTINEL = RTS_STACK_SENTINEL;
                     const int lds_cap = (int)a.stack_lds;
-                    s_stack[tid] = SENTINEL;
-                    int sp = 1;
-                    int node = TG.root;
-                    while (node != SENTINEL) {
-                        if (++steps > (1u << 24)) { hard_overflow = true; break; }   // malformed tree guard: every wave must drain
-                        rts_walk_step<COUNT>(a, s_stack, tid, gtid, lds_cap, &s_n[2 * RTS_BLOCK + tid], node, sp, lr, prev, dir, tmin, best_t, best_leaf, best_prim, t_prune,
+                    if (COOP) {
+                        rts_walk_coop<COUNT>(a, s_stack, s_exch, tid, gtid, lane, lds_cap, &s_n[2 * RTS_BLOCK + tid], TG.root, lr, prev, dir, tmin, best_t, best_leaf, best_prim, t_prune,
                                              n_nodes, n_tris, hard_overflow);
+                    } else {
+                        s_stack[tid] = SENTINEL;
+                        int sp = 1;
+                        int node = TG.root;
+                        while (node != SENTINEL) {
+                            if (++steps > (1u << 24)) { hard_overflow = true; break; }   // malformed tree guard: every wave must drain
+                            rts_walk_step<COUNT>(a, s_stack, tid, gtid, lds_cap, &s_n[2 * RTS_BLOCK + tid], node, sp, lr, prev, dir, tmin, best_t, best_leaf, best_prim, t_prune,
+                                                 n_nodes, n_tris, hard_overflow);
+                        }
                     }
                 }
             }
-            if (KEEP_ALL && chain == 0) {
+            if (KEEP_ALL && chain == 0 && (!COOP || lane == 0)) {
                 const size_t hidx = (size_t)slot * (a.max_refl + 1) + reflDepth;
                 a.hit_prim[hidx] = (best_leaf >= 0) ? (int32_t)best_prim : -1;
                 a.hit_t[hidx] = (best_leaf >= 0) ? best_t : 0.0f;
@@ -484,7 +453,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
 
             // ------------------------------------------------------------ closest_hit, normal_shader.cu:128-340
             if (!((end == false) && ((refrDepth < max_refr) || (reflDepth < a.max_refl)))) break;   // gate :134 ; absorbed hit leaves the payload untouched
-            atomicAdd(&s_n[RTS_BLOCK + tid], 1u);
+            if (!COOP || lane == 0) atomicAdd(&s_n[RTS_BLOCK + tid], 1u);
             const RtsLeafTri L = a.leaves[best_leaf];
             const RtsTargetDev T = a.targets[L.targ];
             if (refrDepth != 1) {                                              // path column (:140-146)
@@ -554,11 +523,11 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
                         cs.dx = rd.x; cs.dy = rd.y; cs.dz = rd.z;
                         cs.refr_code = (chain == 0) ? (L.targ + 1) : (uint32_t)(s_path[tid] & 0xff);   // prefill code travels with the first refraction only
                         if (chain == 0) refr_code0 = L.targ + 1;
-                        a.child[(size_t)chain * a.total_threads + gtid] = cs;
+                        a.child[(size_t)chain * a.slab_threads + gtid] = cs;
                         pending |= 1u << (chain + 1);
                         // direction history plane 0 of the child chain: RCS angle of the refraction event (:259-265)
                         float* dh = a.dir_hist + (size_t)((chain + 1) * (a.max_refl + 1)) * 3 * a.n_rays;
-                        dh[slot] = rd.x; dh[(size_t)a.n_rays + slot] = rd.y; dh[2*(size_t)a.n_rays + slot] = rd.z;
+                        if (!COOP || lane == 0) { dh[slot] = rd.x; dh[(size_t)a.n_rays + slot] = rd.y; dh[2*(size_t)a.n_rays + slot] = rd.z; }
                     }
                 }
             }
@@ -575,13 +544,13 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
             {   // direction history: the RCS angles of received rays are rebuilt from it (:320-326)
                 const size_t plane = REFR ? (size_t)chain * (a.max_refl + 1) + reflDepth : (size_t)(reflDepth - 1);
                 float* dh = a.dir_hist + plane * 3 * a.n_rays;
-                dh[slot] = nd.x; dh[(size_t)a.n_rays + slot] = nd.y; dh[2*(size_t)a.n_rays + slot] = nd.z;
+                if (!COOP || lane == 0) { dh[slot] = nd.x; dh[(size_t)a.n_rays + slot] = nd.y; dh[2*(size_t)a.n_rays + slot] = nd.z; }
             }
         }
 
         // ---------------------------------------------------------------- write-back (ray_tracer.cu:246-253, normal_shader.cu:272-279)
         const bool recv = received >= 0;
-        if (recv || KEEP_ALL) {
+        if ((recv || KEEP_ALL) && (!COOP || lane == 0)) {
             RtsEndRecord r;
             r.rayLength = rayLength; r.power = power; r.doppler = doppler;
             r.prevx = prev.x; r.prevy = prev.y; r.prevz = prev.z;
@@ -596,16 +565,151 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
             }
         }
       }   // chain
+}
+
+// KEEP_ALL is a template parameter, not a run-time flag: hipcc (ROCm 7.2) lowered the uniform
+// `if (a.keep_all)` to a per-lane v_cmp mask computed under the divergent exec of the bounce loop
+// and re-used it at the write-back under a different exec, so lanes that were inactive at the
+// definition stored through the null all_records pointer.
+// REFR builds the refraction branch of closest_hit (normal_shader.cu:191-282): a launch index then owns up
+// to three independent ray chains -- 0: the reflection chain, 1: the ray refracted INTO the first-hit
+// target (spawned by chain 0 at its first hit), 2: the ray refracted back OUT (spawned by chain 1 at its
+// first hit) -- whose results live in rows rayIndex + k*W^3 of the output buffers (:214, :272-279).
+// The reference recurses depth first; the chains are independent once spawned (the payload is copied,
+// :191), so they are traced one after the other and the spawned state is parked in global memory.
+// COOP: the kernel of the cooperative units (launched beside the ordinary one, on its own stream, when the handle has a cost
+// history): it traces the 64 n_head launch indices of the tiles at the head of the cost order, one per wave; the ordinary
+// kernel then starts at position n_head of the order.  A kernel of its own because the shared walk needs ~40 registers more
+// than the 128 the ordinary kernel is held to (four waves per SIMD).
+template <bool COUNT, bool KEEP_ALL, bool REFR, bool COOP>
+__global__ void __launch_bounds__(RTS_BLOCK, (REFR || COOP) ? 2 : 4) k_trace(const RtsTraceArgs a)
+{
+    __shared__ __attribute__((aligned(16))) int32_t s_stack[RTS_STACK_LDS * RTS_BLOCK];
+    const uint32_t tid = threadIdx.x;
+    // (the COOP kernel owns the slabs behind the ordinary kernel's: per-thread spill / child rows, draw counters, block counters)
+    const uint32_t gtid = (COOP ? a.total_threads : 0u) + blockIdx.x * RTS_BLOCK + tid;
+    // Launch constants and the first RTS_RX_LDS receivers are copied into LDS once per (persistent) block.  Read through their
+    // device pointers they are wave-wide BROADCAST loads on the vector memory path -- which returns 64 x 16 bytes per dwordx4
+    // whether the lanes' addresses differ or not -- and they are re-issued for every tile and every missing segment (the
+    // fetch asm clobbers memory, so nothing read through a pointer stays in registers): on a launch that hits nothing they
+    // alone kept the return path 87 % busy (5.3 M loads, counters of tools/trace_bench.py c3nomesh).
+    __shared__ __attribute__((aligned(16))) RtsLaunchConsts s_lc;
+    __shared__ __attribute__((aligned(16))) RtsRxDev s_rx[RTS_RX_LDS];
+    // Payload that the traversal loop does not touch lives in LDS, entry-major like the stack (lane `tid` owns element
+    // k * RTS_BLOCK + tid: conflict-free 8-byte accesses): the first hit point, the two path words and the per-lane
+    // counters -- 13 dwords per lane that the register allocator otherwise carried through the walk (128-VGPR budget at
+    // four waves per SIMD) by spilling to scratch.  They are touched per SHADED hit and at write-back only.
+    __shared__ __attribute__((aligned(16))) double s_first[3 * RTS_BLOCK];
+    __shared__ __attribute__((aligned(16))) unsigned long long s_path[2 * RTS_BLOCK];
+    __shared__ uint32_t s_n[3 * RTS_BLOCK];                      // segments, shaded hits, stack entries spilled (per lane)
+    s_n[threadIdx.x] = 0; s_n[RTS_BLOCK + threadIdx.x] = 0; s_n[2 * RTS_BLOCK + threadIdx.x] = 0;
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.lc); uint32_t* dst = reinterpret_cast<uint32_t*>(&s_lc);
+        for (uint32_t i = threadIdx.x; i < sizeof(RtsLaunchConsts) / 4; i += RTS_BLOCK) dst[i] = src[i];
+        const uint32_t n_rx_lds = a.n_rx < RTS_RX_LDS ? a.n_rx : RTS_RX_LDS;
+        const uint32_t* rsrc = reinterpret_cast<const uint32_t*>(a.rx); uint32_t* rdst = reinterpret_cast<uint32_t*>(s_rx);
+        for (uint32_t i = threadIdx.x; i < n_rx_lds * (sizeof(RtsRxDev) / 4); i += RTS_BLOCK) rdst[i] = rsrc[i];
+    }
+    __syncthreads();
+    const RtsLaunchConsts& lc = s_lc;
+    const dvec3 origin = mk3(lc.ox, lc.oy, lc.oz);
+    // pre-filter constants of the receivers, for rays that start at the transmitter: q = centre - origin (f64, then f32),
+    // |q|, |q|^2 and the widened radius^2.  Widening: the f32 direction is good to ~2e-6 rad and the f32 discriminant
+    // b^2 - (|q|^2 - r^2) |d|^2 to ~1e-6 |q|^2; r'^2 = r^2 (1 + 1e-3) + 1e-5 |q|^2 + 1e-6 covers both ten times over.
+    // The filter has to be conservative with respect to the REFERENCE'S arithmetic, not to geometry: its quadratic forms
+    // C = |prev|^2 + |c|^2 - 2 c.prev - r^2 from world-scale terms (ray_tracer.cu:285), which at Earth-centred coordinates
+    // cancel catastrophically -- terms of 4e13 m^2, rounded a dozen times: the sphere it tests is up to ~0.05 m^2 larger or
+    // smaller in r^2 than the one it was given (found by tools/fuzz_equal.py: a 0.86 m sphere 3.7 m from the transmitter
+    // captured 32 rays the geometric filter had excluded).  + 1e-14 (|o|^2 + |c|^2): 45 ulps of the largest term.
+    __shared__ float s_rxp[RTS_RX_LDS][6];
+    if (tid < RTS_RX_LDS && tid < a.n_rx) {
+        const RtsRxDev r = s_rx[tid];
+        const double qx = r.cx - lc.ox, qy = r.cy - lc.oy, qz = r.cz - lc.oz, qq = qx*qx + qy*qy + qz*qz;
+        s_rxp[tid][0] = (float)qx; s_rxp[tid][1] = (float)qy; s_rxp[tid][2] = (float)qz; s_rxp[tid][3] = (float)qq * 1.000001f;
+        s_rxp[tid][4] = (float)(r.radius * r.radius * 1.001 + 1.0e-5 * qq + 1.0e-6 + 1.0e-14 * (lc.ox*lc.ox + lc.oy*lc.oy + lc.oz*lc.oz + r.cx*r.cx + r.cy*r.cy + r.cz*r.cz));
+        s_rxp[tid][5] = (float)sqrt(qq);
+    }
+    __syncthreads();
+    uint32_t n_nodes = 0, n_tris = 0;                            // counting build only (per lane and launch: far below 2^32)
+    bool hard_overflow = false;
+    const bool mask_on = a.pmask != nullptr && lc.mask.n != 0 && a.pmask[(size_t)lc.mask.n * lc.mask.n / 32u] == 0u;     // (uniform) not voided by k_primary_mask
+    // the pre-filter can only pay if it can clear a ray of the targets: with geometry but no valid mask every primary needs
+    // its exact direction anyway
+    const bool pre_on = lc.W > 1 && a.n_rx <= RTS_RX_LDS && (mask_on || a.n_prims == 0) && a.pre_filter;
+    const uint32_t max_refr = REFR ? 2u : 0u;
+    const uint32_t D = a.max_refl + max_refr;
+
+    unsigned long long tl_t0 = 0;
+    if (COUNT && !COOP && a.timeline && tid == 0) { tl_t0 = wall_clock64(); a.timeline[(size_t)blockIdx.x * 2] = tl_t0; }
+    // Work units are WAVE TILES of 64 consecutive launch indices, taken by the waves one at a time from RTS_TILE_CTRS
+    // striped counters: wave w draws k = atomicAdd(ctr[w % C]) and traces position k*C + (w % C) of the tile order.  Tile
+    // durations are extremely skewed (median ~2.5 us: every ray misses; 99.9th percentile ~0.3 ms; a handful near 0.9 ms whose
+    // rays bounce six times through a hundred steps each), so an in-order sweep left a ~1 ms tail in which a few waves finished
+    // their slow tiles on an otherwise idle GPU.  Pulses of an interval look alike, so every launch records what each tile cost
+    // (tile_cost, shader clocks >> 6) and the next launches of the handle trace the tiles in descending order of the cost
+    // last seen (tile_order, built by rts_tile_order_build): longest-processing-time-first list scheduling.  Striping the
+    // counter -- ONE 128-byte line per stripe (RTS_TILE_CTR_STRIDE): atomics on one line serialise in L2 at ~10 ns each
+    // whatever their address -- keeps the draws off the critical path: 69 k of them per launch over 64 lines.
+    const uint32_t n_tiles = (a.n_rays + 63u) / 64u;
+    const uint32_t lane = tid & 63u;
+    const uint32_t stripe = __builtin_amdgcn_readfirstlane((blockIdx.x * (RTS_BLOCK / 64u) + (tid >> 6)) % RTS_TILE_CTRS);   // wave-uniform: the queue arithmetic below stays scalar
+    // Draw schedule of a stripe (positions k*C + stripe, k = 0, 1, ...): the first quarter -- the expensive end of the
+    // order -- one tile per draw, the cheap rest four tiles per draw (a miss-only tile is ~2 us of work, and so is a draw's
+    // latency).  In the cheap part the next draw is issued before the current tiles are traced, so its latency hides behind them.
+    // COOPERATIVE UNITS: the first n_head tiles of the cost order (rts_tile_order_build: those whose last cost exceeds a
+    // fraction of the launch's balanced time) are traced as 64 units of ONE launch index each, all 64 lanes of a wave walking
+    // that ray's hierarchy together (rts_trace_unit<.., COOP = true>) -- by the COOP kernel, whose unit v is
+    // (tile_order[v / 64], ray v % 64); unit v of the ordinary kernel is tile_order[n_head + v].
+    const uint32_t n_head = (a.tile_head && a.tile_order) ? min(__builtin_amdgcn_readfirstlane(a.tile_head[0]), n_tiles) : 0u;
+    const uint32_t n_units = COOP ? 64u * n_head : n_tiles - n_head;
+    __shared__ int32_t s_exch[COOP ? RTS_BLOCK : 1];             // exchange rows of the cooperative walk (one 64-entry row per wave)
+    const RtsUnitLds ul = {s_stack, s_exch, s_first, s_path, s_n, s_rx, s_rxp};
+    const uint32_t per_stripe = (n_units + RTS_TILE_CTRS - 1u) / RTS_TILE_CTRS;
+    const uint32_t single_draws = per_stripe >= 1024u ? per_stripe / 4u : per_stripe;      // (short queues: one tile per draw throughout)
+    // The pending draw is held in a register of lane 0 (so that its latency hides behind the tiles traced meanwhile) -- except
+    // in the counting builds, which are short of registers: there the allocator spilled it to scratch, stored under
+    // EXEC = lane 0 and reloaded at the loop top, and launches then lost whole tiles' worth of counters from run to run
+    // (the reload overtaking the store is the suspicion; product builds have no scratch at all, tests/test_host_logic.py checks).
+    __shared__ uint32_t s_draw[RTS_BLOCK / 64];
+    uint32_t draw_next = 0;
+#define RTS_DRAW() { const uint32_t dv_ = atomicAdd(&a.tile_ctr[(COOP ? RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE : 0) + stripe * RTS_TILE_CTR_STRIDE], 1u); if (COUNT) s_draw[tid >> 6] = dv_; else draw_next = dv_; }
+    if (lane == 0) RTS_DRAW()
+    for (;;) {
+      const uint32_t draw = __builtin_amdgcn_readfirstlane(COUNT ? s_draw[tid >> 6] : draw_next);
+      const uint32_t k0 = draw < single_draws ? draw : single_draws + 4u * (draw - single_draws);
+      const uint32_t kn = draw < single_draws ? 1u : 4u;
+      if (k0 >= per_stripe) break;
+      // (only in the cheap part of the order: a draw made before an EXPENSIVE tile would reserve the stripe's next most
+      // expensive tile for as long as this one takes -- the launch then ends with that tile, traced alone)
+      const bool ahead = draw >= single_draws;
+      if (ahead && lane == 0) RTS_DRAW()
+     for (uint32_t kb = 0; kb < kn; kb++) {
+      const uint64_t vpos64 = (uint64_t)(k0 + kb) * RTS_TILE_CTRS + stripe;
+      if (vpos64 >= n_units) break;
+      const uint32_t vpos = (uint32_t)vpos64;
+      const bool coop_unit = COOP;
+      const uint32_t tpos = COOP ? (vpos >> 6) : vpos + n_head;
+      // no history yet (first launch of the handle): centre-out over the launch range -- the beam is normally centred on
+      // the targets, so the expensive tiles sit in the middle of the lattice and should be started first
+      const uint32_t tile = a.tile_order ? a.tile_order[tpos] : ((tpos & 1u) ? (n_tiles - 1u) / 2u + (tpos + 1u) / 2u : (n_tiles - 1u) / 2u - tpos / 2u);
+      const uint32_t slot = coop_unit ? tile * 64u + (vpos & 63u) : tile * 64u + lane;
+      const long long tile_t0 = clock64();
+      const unsigned long long tl_tile = (COUNT && a.timeline && lane == 0) ? wall_clock64() : 0ULL;
+      if (slot < a.n_rays) {
+          rts_trace_unit<COUNT, KEEP_ALL, REFR, COOP>(a, lc, ul, tid, gtid, lane, slot, pre_on, mask_on, D, max_refr, origin, n_nodes, n_tris, hard_overflow);
       }   // slot < n_rays
       if (lane == 0) {
           const unsigned long long dt = (unsigned long long)(clock64() - tile_t0) >> 6;
-          if (a.tile_cost) a.tile_cost[tile] = (unsigned int)(dt > 0xfffffffeULL ? 0xfffffffeULL : dt) + 1u;
-          if (COUNT && a.timeline) { a.timeline[(size_t)gridDim.x * 2 + tile] = wall_clock64() - tl_tile; a.timeline[(size_t)gridDim.x * 2 + n_tiles + tile] = tl_tile; }   // debug timeline (RTS_TIMELINE): duration, start tick
+          // (a tile traced as cooperative units costs the SUM of its units' wave time -- at least what it costs one wave -- so
+          // a tile once above the threshold stays above it: no flip-flopping between the two modes from launch to launch)
+          if (a.tile_cost) { if (coop_unit) atomicAdd(&a.tile_cost[tile], (unsigned int)(dt > 0x00fffffeULL ? 0x00fffffeULL : dt) + 1u);
+                             else a.tile_cost[tile] = (unsigned int)(dt > 0xfffffffeULL ? 0xfffffffeULL : dt) + 1u; }
+          if (COUNT && a.timeline && !coop_unit) { a.timeline[(size_t)gridDim.x * 2 + tile] = wall_clock64() - tl_tile; a.timeline[(size_t)gridDim.x * 2 + n_tiles + tile] = tl_tile; }   // debug timeline (RTS_TIMELINE): duration, start tick
       }
      }   // tiles of the draw
       if (!ahead && lane == 0) RTS_DRAW()
     }
-    if (COUNT && a.timeline && tid == 0) a.timeline[(size_t)blockIdx.x * 2 + 1] = wall_clock64();
+    if (COUNT && !COOP && a.timeline && tid == 0) a.timeline[(size_t)blockIdx.x * 2 + 1] = wall_clock64();
 
     // ------------------------------------------------------------------ counters: wave reduce -> block reduce (LDS, the
     // traversal stack is dead by now) -> one plain store per block; k_sum_counters adds the blocks up.  (One atomic per
@@ -628,7 +732,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : 4) k_trace(const RtsTrac
         unsigned long long v = 0;
         if (tid <= 5) { for (int w = 0; w < RTS_BLOCK / 64; w++) v += s_cnt[w * 8 + tid]; }
         else v = any_overflow ? 1ULL : 0ULL;
-        a.block_counters[(size_t)blockIdx.x * 8 + tid] = v;
+        a.block_counters[((size_t)(COOP ? a.total_threads / RTS_BLOCK : 0u) + blockIdx.x) * 8 + tid] = v;
     }
 }
 
@@ -648,23 +752,38 @@ __global__ void k_sum_counters(const unsigned long long* __restrict__ block_coun
     }
 }
 
-int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a, bool count_traversal)
+template <bool COOP>
+static void rts_trace_dispatch(const RtsTraceArgs& a, bool count_traversal, unsigned grid, hipStream_t st)
+{
+    const int sel = (a.max_refr ? 4 : 0) | (a.keep_all ? 2 : 0) | (count_traversal ? 1 : 0);
+    switch (sel) {
+        case 0: k_trace<false, false, false, COOP><<<grid, RTS_BLOCK, 0, st>>>(a); break;
+        case 1: k_trace<true, false, false, COOP><<<grid, RTS_BLOCK, 0, st>>>(a); break;
+        case 2: k_trace<false, true, false, COOP><<<grid, RTS_BLOCK, 0, st>>>(a); break;
+        case 3: k_trace<true, true, false, COOP><<<grid, RTS_BLOCK, 0, st>>>(a); break;
+        case 4: k_trace<false, false, true, COOP><<<grid, RTS_BLOCK, 0, st>>>(a); break;
+        case 5: k_trace<true, false, true, COOP><<<grid, RTS_BLOCK, 0, st>>>(a); break;
+        case 6: k_trace<false, true, true, COOP><<<grid, RTS_BLOCK, 0, st>>>(a); break;
+        default: k_trace<true, true, true, COOP><<<grid, RTS_BLOCK, 0, st>>>(a); break;
+    }
+}
+
+// coop_grid > 0: the cooperative kernel is launched FIRST (it holds the most expensive work of the launch), on the handle's
+// second trace stream, so that the ordinary kernel's blocks fill the chip beside it and behind it.
+int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a, bool count_traversal, unsigned coop_grid)
 {
     if (a.n_rays == 0) return RTS_OK;
     const unsigned grid = a.total_threads / RTS_BLOCK;
     hipStream_t st = c->tstream;
-    const int sel = (a.max_refr ? 4 : 0) | (a.keep_all ? 2 : 0) | (count_traversal ? 1 : 0);
-    switch (sel) {
-        case 0: k_trace<false, false, false><<<grid, RTS_BLOCK, 0, st>>>(a); break;
-        case 1: k_trace<true, false, false><<<grid, RTS_BLOCK, 0, st>>>(a); break;
-        case 2: k_trace<false, true, false><<<grid, RTS_BLOCK, 0, st>>>(a); break;
-        case 3: k_trace<true, true, false><<<grid, RTS_BLOCK, 0, st>>>(a); break;
-        case 4: k_trace<false, false, true><<<grid, RTS_BLOCK, 0, st>>>(a); break;
-        case 5: k_trace<true, false, true><<<grid, RTS_BLOCK, 0, st>>>(a); break;
-        case 6: k_trace<false, true, true><<<grid, RTS_BLOCK, 0, st>>>(a); break;
-        default: k_trace<true, true, true><<<grid, RTS_BLOCK, 0, st>>>(a); break;
+    if (coop_grid) {
+        RTS_HIP(hipEventRecord(c->ev_coop[0], st));
+        RTS_HIP(hipStreamWaitEvent(c->cstream, c->ev_coop[0], 0));
+        rts_trace_dispatch<true>(a, count_traversal, coop_grid, c->cstream);
+        RTS_HIP(hipEventRecord(c->ev_coop[1], c->cstream));
     }
-    k_sum_counters<<<1, 256, 0, st>>>(a.block_counters, grid, a.counters);
+    rts_trace_dispatch<false>(a, count_traversal, grid, st);
+    if (coop_grid) RTS_HIP(hipStreamWaitEvent(st, c->ev_coop[1], 0));
+    k_sum_counters<<<1, 256, 0, st>>>(a.block_counters, grid + coop_grid, a.counters);
     RTS_HIP(hipGetLastError());
     return RTS_OK;
 }

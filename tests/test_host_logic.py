@@ -281,7 +281,12 @@ def test_product_trace_kernels_use_no_scratch():
         scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1)); vspill = int(re.search(r"VGPRs Spill: (\d+)", b).group(1))
         lds = int(re.search(r"LDS Size \[bytes/block\]: (\d+)", b).group(1)); occ = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1))
         assert scratch <= 16 and vspill <= 1, (name, scratch, vspill)
-        assert lds * 4 <= 160 * 1024 and occ >= 2, (name, lds, occ)          # four blocks of four waves per CU
+        coop = name.startswith("_Z7k_traceILb0ELb") and name.split("EEv")[0].endswith("Lb1")      # k_trace<COUNT, KEEP_ALL, REFR, COOP>
+        refr = name[len("_Z7k_traceILb0ELb0ELb"):][:1] == "1" or name[len("_Z7k_traceILb0ELb1ELb"):][:1] == "1"
+        if coop:
+            assert lds * 3 <= 160 * 1024 and occ >= 2, (name, lds, occ)      # the cooperative kernel: three blocks per CU
+        else:
+            assert lds * 4 <= 160 * 1024 and occ >= (2 if refr else 4), (name, lds, occ)      # four blocks of four waves per CU
         body = isa[isa.index("\n" + name + ":"):]
         body = body[:body.index("s_endpgm")].splitlines()
         in_loop = False; in_asm = False; asm_loads = 0; fetch_blocks = 0
@@ -302,7 +307,7 @@ def test_product_trace_kernels_use_no_scratch():
             if "scratch_store" in t:
                 assert not in_loop, (name, t)
         assert fetch_blocks >= 1 and asm_loads == 0, (name, fetch_blocks, asm_loads)     # every asm load group ends in its own wait
-    assert seen == 4
+    assert seen == 8
 
 
 def test_fuzz_generator_versions_are_frozen(rts):

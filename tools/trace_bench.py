@@ -35,14 +35,15 @@ tr = api.Tracer(spec["W"], spec["max_refl"], 0, spec["smooth"])
 tr.set_scene(spec["meshes"]); tr.set_receivers(spec["rx"])
 tx = spec["tx"]
 ms = []
-shard = int(os.environ.get("RTS_SHARD", "1"))                     # trace 1/shard of the launch indices (C4: one GPU's share of 8)
-count = spec["W"] ** 3 // shard
+shard = int(os.environ.get("RTS_SHARD", "1"))                     # trace part 0 of `shard` interleaved parts of the launch (C4: one GPU's share of an 8-way ray split, rts_plan_cpi's 4096-index tiles)
+count = spec["W"] ** 3
+il = (4096, shard, int(os.environ.get("RTS_SHARD_PART", "0"))) if shard > 1 else None
 for k in range(reps + 1):
     if "motion_fn" in spec:
         mo = spec["motion_fn"](k)
     else:
         mo = [dict(position=tuple(np.add(m["position"], (0.2 * k, 0.02 * k, 0.0))), velocity=m["velocity"]) for m in spec["motion"]]
-    st = tr.trace(tx["origin"], tx["span"], tx["dir"], mo, ray_first=0, ray_count=count)
+    st = tr.trace(tx["origin"], tx["span"], tx["dir"], mo, ray_first=0, ray_count=count, interleave=il)
     if k:
         ms.append((st["ms_scene"], st["ms_trace"], st["ms_compact"]))
 rec = tr.received()

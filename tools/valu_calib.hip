@@ -25,7 +25,7 @@
 struct Out { unsigned long long cycles, wall; };
 
 // one kernel per class: T = register type, the instruction text takes %N (destination / accumulator), %16 and %17 (sources)
-#define CALIB_KERNEL(NAME, T, INIT, TEXT, CLOBBER)                                                                           \
+#define CALIB_KERNEL(NAME, T, INIT, TEXT, ...)                                                                               \
 __global__ void __launch_bounds__(1024) NAME(Out* out, int iters, T seed)                                                    \
 {                                                                                                                            \
     extern __shared__ char lds_pin[];                                                                                        \
@@ -35,10 +35,10 @@ __global__ void __launch_bounds__(1024) NAME(Out* out, int iters, T seed)       
     __syncthreads();                                                                                                         \
     const unsigned long long w0 = wall_clock64(); const long long c0 = clock64();                                            \
     for (int it = 0; it < iters; it++) {                                                                                     \
-        asm volatile(R16(TEXT) : OUT16(T) : "v"(a), "v"(b) : CLOBBER);                                                       \
-        asm volatile(R16(TEXT) : OUT16(T) : "v"(a), "v"(b) : CLOBBER);                                                       \
-        asm volatile(R16(TEXT) : OUT16(T) : "v"(a), "v"(b) : CLOBBER);                                                       \
-        asm volatile(R16(TEXT) : OUT16(T) : "v"(a), "v"(b) : CLOBBER);                                                       \
+        asm volatile(R16(TEXT) : OUT16(T) : "v"(a), "v"(b) : __VA_ARGS__);                                                       \
+        asm volatile(R16(TEXT) : OUT16(T) : "v"(a), "v"(b) : __VA_ARGS__);                                                       \
+        asm volatile(R16(TEXT) : OUT16(T) : "v"(a), "v"(b) : __VA_ARGS__);                                                       \
+        asm volatile(R16(TEXT) : OUT16(T) : "v"(a), "v"(b) : __VA_ARGS__);                                                       \
     }                                                                                                                        \
     const long long c1 = clock64(); const unsigned long long w1 = wall_clock64();                                            \
     T s = r[0]; for (int i = 1; i < 16; i++) s = s + r[i];                                                                   \
@@ -60,12 +60,30 @@ __global__ void __launch_bounds__(1024) NAME(Out* out, int iters, T seed)       
 #define T_CVT_F64_F32(n) "v_cvt_f32_f64 %" #n ", %16\n\t"
 #define T_ADD_U32(n) "v_add_u32 %" #n ", %16, %" #n "\n\t"
 #define T_MOV_B32(n) "v_mov_b32 %" #n ", %16\n\t"
-#define T_CNDMASK(n) "v_cndmask_b32 %" #n ", %16, %" #n ", vcc\n\t"
+#define T_CNDMASK(n) "v_cndmask_b32 %" #n ", %16, %" #n ", vcc\n\t"      /* (vcc: whatever the compiler left there) */
 #define T_CMP_F32(n) "v_cmp_lt_f32 vcc, %16, %" #n "\n\t"
 #define T_LSHL_B32(n) "v_lshlrev_b32 %" #n ", 1, %" #n "\n\t"
 #define T_MUL_LO_U32(n) "v_mul_lo_u32 %" #n ", %16, %" #n "\n\t"
 #define T_AND_B32(n) "v_and_b32 %" #n ", %16, %" #n "\n\t"
 #define T_PK_FMA_F32(n) "v_pk_fma_f32 %" #n ", %16, %17, %" #n "\n\t"
+#define T_CNDMASK_S(n) "v_cndmask_b32 %" #n ", %16, %" #n ", s[20:21]\n\t"
+#define T_CMP_S(n) "v_cmp_lt_f32 s[20:21], %16, %" #n "\n\t"
+#define T_MIN_F32(n) "v_min_f32 %" #n ", %16, %" #n "\n\t"
+#define T_MAX3_F32(n) "v_max3_f32 %" #n ", %16, %17, %" #n "\n\t"
+#define T_MIN_U32(n) "v_min_u32 %" #n ", %16, %" #n "\n\t"
+#define T_SUB_U32(n) "v_sub_u32 %" #n ", %16, %" #n "\n\t"
+#define T_OR_B32(n) "v_or_b32 %" #n ", %16, %" #n "\n\t"
+#define T_LSHL_ADD_U32(n) "v_lshl_add_u32 %" #n ", %16, 2, %" #n "\n\t"
+#define T_FMAC_F32(n) "v_fmac_f32 %" #n ", %16, %17\n\t"
+#define T_READLANE(n) "v_readlane_b32 s20, %" #n ", 3\n\t"
+#define T_CVT_F32_F64(n) "v_cvt_f32_f64 v127, %" #n "\n\t"
+#define T_DIV_SCALE_F64(n) "v_div_scale_f64 %" #n ", vcc, %16, %17, %" #n "\n\t"
+#define T_DIV_FMAS_F64(n) "v_div_fmas_f64 %" #n ", %16, %17, %" #n "\n\t"
+#define T_DIV_FIXUP_F64(n) "v_div_fixup_f64 %" #n ", %16, %17, %" #n "\n\t"
+#define T_CMP_F64(n) "v_cmp_lt_f64 vcc, %16, %" #n "\n\t"
+#define T_MOV_B64(n) "v_mov_b64 %" #n ", %16\n\t"
+#define T_LSHL_ADD_U64(n) "v_lshl_add_u64 %" #n ", %16, 3, %" #n "\n\t"
+#define T_MAD_U64_U32(n) "v_mad_u64_u32 %" #n ", vcc, v0, v0, %" #n "\n\t"
 
 CALIB_KERNEL(k_fma_f32, float, 0.5f, T_FMA_F32, "memory")
 CALIB_KERNEL(k_mul_f32, float, 0.5f, T_MUL_F32, "memory")
@@ -85,6 +103,24 @@ CALIB_KERNEL(k_cndmask_b32, unsigned, 3u, T_CNDMASK, "memory")
 CALIB_KERNEL(k_lshl_b32, unsigned, 3u, T_LSHL_B32, "memory")
 CALIB_KERNEL(k_mul_lo_u32, unsigned, 3u, T_MUL_LO_U32, "memory")
 CALIB_KERNEL(k_and_b32, unsigned, 3u, T_AND_B32, "memory")
+CALIB_KERNEL(k_cndmask_sgpr, unsigned, 3u, T_CNDMASK_S, "s20", "s21")
+CALIB_KERNEL(k_cmp_sgpr, float, 0.5f, T_CMP_S, "s20", "s21")
+CALIB_KERNEL(k_min_f32, float, 0.5f, T_MIN_F32, "memory")
+CALIB_KERNEL(k_max3_f32, float, 0.5f, T_MAX3_F32, "memory")
+CALIB_KERNEL(k_min_u32, unsigned, 3u, T_MIN_U32, "memory")
+CALIB_KERNEL(k_sub_u32, unsigned, 3u, T_SUB_U32, "memory")
+CALIB_KERNEL(k_or_b32, unsigned, 3u, T_OR_B32, "memory")
+CALIB_KERNEL(k_lshl_add_u32, unsigned, 3u, T_LSHL_ADD_U32, "memory")
+CALIB_KERNEL(k_fmac_f32, float, 0.5f, T_FMAC_F32, "memory")
+CALIB_KERNEL(k_readlane, unsigned, 3u, T_READLANE, "s20")
+CALIB_KERNEL(k_cvt_f32_f64, double, 0.5, T_CVT_F32_F64, "v127")
+CALIB_KERNEL(k_div_scale_f64, double, 0.5, T_DIV_SCALE_F64, "vcc")
+CALIB_KERNEL(k_div_fmas_f64, double, 0.5, T_DIV_FMAS_F64, "memory")
+CALIB_KERNEL(k_div_fixup_f64, double, 0.5, T_DIV_FIXUP_F64, "memory")
+CALIB_KERNEL(k_cmp_f64, double, 0.5, T_CMP_F64, "vcc")
+CALIB_KERNEL(k_mov_b64, double, 0.5, T_MOV_B64, "memory")
+CALIB_KERNEL(k_lshl_add_u64, unsigned long long, 3ull, T_LSHL_ADD_U64, "memory")
+CALIB_KERNEL(k_mad_u64_u32, unsigned long long, 3ull, T_MAD_U64_U32, "vcc")
 
 template <typename K, typename T>
 static void run(const char* name, K kernel, T seed, int n_cu, int iters, bool last)
@@ -134,7 +170,25 @@ int main(int argc, char** argv)
     run("v_lshlrev_b32", k_lshl_b32, 1u, n_cu, iters, false);
     run("v_mov_b32", k_mov_b32, 1u, n_cu, iters, false);
     run("v_cndmask_b32", k_cndmask_b32, 1u, n_cu, iters, false);
-    run("v_mul_lo_u32", k_mul_lo_u32, 1u, n_cu, iters, true);
+    run("v_mul_lo_u32", k_mul_lo_u32, 1u, n_cu, iters, false);
+    run("v_cndmask_b32_sgpr_mask", k_cndmask_sgpr, 1u, n_cu, iters, false);
+    run("v_cmp_lt_f32_to_sgpr", k_cmp_sgpr, 1.0f, n_cu, iters, false);
+    run("v_min_f32", k_min_f32, 1.0f, n_cu, iters, false);
+    run("v_max3_f32", k_max3_f32, 1.0f, n_cu, iters, false);
+    run("v_min_u32", k_min_u32, 1u, n_cu, iters, false);
+    run("v_sub_u32", k_sub_u32, 1u, n_cu, iters, false);
+    run("v_or_b32", k_or_b32, 1u, n_cu, iters, false);
+    run("v_lshl_add_u32", k_lshl_add_u32, 1u, n_cu, iters, false);
+    run("v_fmac_f32", k_fmac_f32, 1.0f, n_cu, iters, false);
+    run("v_readlane_b32", k_readlane, 1u, n_cu, iters, false);
+    run("v_cvt_f32_f64", k_cvt_f32_f64, 1.0, n_cu, iters, false);
+    run("v_div_scale_f64", k_div_scale_f64, 1.0, n_cu, iters, false);
+    run("v_div_fmas_f64", k_div_fmas_f64, 1.0, n_cu, iters, false);
+    run("v_div_fixup_f64", k_div_fixup_f64, 1.0, n_cu, iters, false);
+    run("v_cmp_lt_f64", k_cmp_f64, 1.0, n_cu, iters, false);
+    run("v_mov_b64", k_mov_b64, 1.0, n_cu, iters, false);
+    run("v_lshl_add_u64", k_lshl_add_u64, 1ull, n_cu, iters, false);
+    run("v_mad_u64_u32", k_mad_u64_u32, 1ull, n_cu, iters, true);
     printf(" }\n}\n");
     return 0;
 }
