@@ -97,6 +97,7 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     { const char* e = getenv("RTS_TILE_LPT"); if (e && e[0] == '0') c->tile_lpt = false; }
     { const char* e = getenv("RTS_COOP_FRAC"); if (e) { const double v = atof(e); if (v >= 0) c->coop_frac = v; } }                  // 0: no cooperative units; tests: tiny values put every tile at the head
     { const char* e = getenv("RTS_COOP_FLOOR"); if (e) c->coop_floor = (uint32_t)std::max(0, atoi(e)); }
+    { const char* e = getenv("RTS_COOP_SEG"); if (e) c->coop_seg_cost = (uint32_t)std::max(0, atoi(e)); }
     { const char* e = getenv("RTS_COOP_GRID"); if (e) c->coop_grid_max = (uint32_t)std::min(4096, std::max(1, atoi(e))); }
     { const char* e = getenv("RTS_EW_REL"); if (e) { const double v = atof(e); if (v > 0) c->ew_rel = v; } }
     { const char* e = getenv("RTS_STACK_LDS_DEBUG"); if (e) { int v = atoi(e); if (v >= 1 && v <= RTS_STACK_LDS) c->stack_lds = (uint32_t)v; } }   // tests: force the spill path
@@ -589,6 +590,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     const uint32_t chains = a.max_refr ? 3u : 1u;
     if ((uint64_t)n * chains > 0xfffffff0ULL) { rts_set_error("rts_trace_pulse: rays x chains exceeds 2^32"); return RTS_ERR_UNSUPPORTED; }
     a.total_threads = grid * RTS_BLOCK;
+    a.coop_seg_cost = c->coop_seg_cost; a.coop_min_cost = c->coop_seg_cost ? std::min<uint32_t>(c->coop_floor, 1875u) : 0u;      // (nothing shorter than 50 us is looked at; RTS_COOP_SEG=0: every tile is flagged)
     const uint32_t coop_threads = c->coop_frac > 0.0 ? c->coop_grid_max * RTS_BLOCK : 0u;      // the cooperative kernel's rows of the per-thread slabs
     a.slab_threads = a.total_threads + coop_threads;
     RTS_HIP(c->d_recv.reserve((size_t)n * chains + 1)); RTS_HIP(c->d_counters.reserve(16));

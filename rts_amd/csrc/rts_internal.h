@@ -162,6 +162,7 @@ struct RtsTraceArgs {
     uint32_t* tile_cost;            // [wave tiles] out: duration of the tile (shader clocks >> 6, + 1)
     uint32_t* tile_ctr;             // [RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE] draw counters (element s * STRIDE), zero at launch
     const uint32_t* tile_head;      // [1] number of tiles at the head of tile_order that are traced as 64 cooperative units (null: none)
+    uint32_t coop_min_cost, coop_seg_cost;   // a tile is flagged LONG WALKS (bit 31 of its cost record) if it took >= coop_min_cost units and >= coop_seg_cost units per traced segment
     unsigned long long* timeline;   // debug (RTS_TIMELINE, counting build): [grid][2] block start/end ticks, then [tiles] tile durations (100 MHz)
     uint32_t pre_filter;            // 1: primary rays go through the f32 pre-filter (needs the mask when there is geometry)
     const uint32_t* pmask;          // primary-ray mask: RTS_MASK_N^2 bits, then one word != 0 if the mask is void for this pulse (null: none)
@@ -258,7 +259,8 @@ struct RtsContext {
     uint64_t ray_first = 0; uint32_t n_rays = 0;
     DevBuf<RtsEndRecord> d_recv, d_all; DevBuf<unsigned long long> d_counters, d_block_counters, d_timeline;
     DevBuf<uint32_t> d_tile_cost, d_tile_key, d_tile_key_sorted, d_tile_id, d_tile_order, d_tile_hist, d_tile_ctr, d_tile_head;
-    uint32_t coop_floor = 56250;        // ... and more than this many cost units (shader clocks >> 6; 56 250 = 1.5 ms of one wave) (RTS_COOP_FLOOR)
+    uint32_t coop_floor = 7500;         // ... more than this many cost units (shader clocks >> 6; 7 500 = 0.2 ms of one wave) (RTS_COOP_FLOOR)
+    uint32_t coop_seg_cost = 300;       // ... and at least this many cost units PER TRACED SEGMENT (300 = 8 us: ~500 walk steps per segment with every lane busy) (RTS_COOP_SEG)
     double coop_frac = 0.5;            // a tile costing more than this fraction of the launch's balanced time is traced as cooperative units (RTS_COOP_FRAC; 0: never)
     bool tile_cost_pending = false, tile_hist_any = false; uint64_t tile_cost_sig[4] = {0, 0, 0, 0}; uint32_t tile_hist_n = 0;   // per-global-tile cost history (rts_post.hip)
     DevBuf<float> d_dir_hist; DevBuf<uint32_t> d_pmask; bool use_pmask = true, pre_dense = false;

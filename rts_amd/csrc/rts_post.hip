@@ -149,25 +149,27 @@ __global__ void k_tile_keys(const uint32_t* __restrict__ hist, uint32_t n_hist, 
     key[j] = ~est; id[j] = j;
 }
 
-// How many tiles at the head of the (descending) cost order are worth tracing as cooperative units: those whose estimated
-// cost exceeds `frac` of the launch's balanced time (sum of the costs / resident waves) and an absolute floor.  One block;
+// How many tiles at the head of the (descending) cost order are worth tracing as cooperative units: those flagged LONG WALKS
+// (rts_trace.hip) whose estimated cost exceeds `frac` of the launch's balanced time (sum of the costs / resident waves) and an
+// absolute floor.  One block;
 // key_sorted = ~cost, ascending.
 __global__ void __launch_bounds__(1024) k_tile_head(const uint32_t* __restrict__ key_sorted, uint32_t n, uint32_t resident_waves, double frac, uint32_t floor_cost, uint32_t max_head,
                                                     uint32_t* __restrict__ out)
 {
     __shared__ unsigned long long s_sum[1024]; __shared__ uint32_t s_cnt[1024]; __shared__ uint32_t s_thr;
     unsigned long long acc = 0;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) acc += (uint32_t)~key_sorted[i];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) acc += (uint32_t)~key_sorted[i] & 0x7fffffffu;      // (bit 31: the LONG WALKS flag of the cost record)
     s_sum[threadIdx.x] = acc; __syncthreads();
     for (uint32_t o = blockDim.x / 2; o > 0; o >>= 1) { if (threadIdx.x < o) s_sum[threadIdx.x] += s_sum[threadIdx.x + o]; __syncthreads(); }
     if (threadIdx.x == 0) {
         const double balanced = (double)s_sum[0] / (double)(resident_waves ? resident_waves : 1u);
-        double thr = frac * balanced; if (thr < (double)floor_cost) thr = (double)floor_cost; if (thr > 4.0e9) thr = 4.0e9;
+        double thr = frac * balanced; if (thr < (double)floor_cost) thr = (double)floor_cost; if (thr > 2.0e9) thr = 2.0e9;
         s_thr = (uint32_t)thr;
     }
     __syncthreads();
     const uint32_t thr = s_thr; uint32_t cnt = 0;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) cnt += ((uint32_t)~key_sorted[i] > thr) ? 1u : 0u;
+    // flagged records sort first (their bit 31), by descending cost: the flagged tiles above the threshold are a prefix of the order
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { const uint32_t v = ~key_sorted[i]; cnt += ((v >> 31) && (v & 0x7fffffffu) > thr) ? 1u : 0u; }
     s_cnt[threadIdx.x] = cnt; __syncthreads();
     for (uint32_t o = blockDim.x / 2; o > 0; o >>= 1) { if (threadIdx.x < o) s_cnt[threadIdx.x] += s_cnt[threadIdx.x + o]; __syncthreads(); }
     if (threadIdx.x == 0) out[0] = frac > 0.0 ? min(s_cnt[0], max_head) : 0u;

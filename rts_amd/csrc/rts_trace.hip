@@ -694,16 +694,31 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR || COOP) ? 2 : 4) k_trace(con
       const uint32_t tile = a.tile_order ? a.tile_order[tpos] : ((tpos & 1u) ? (n_tiles - 1u) / 2u + (tpos + 1u) / 2u : (n_tiles - 1u) / 2u - tpos / 2u);
       const uint32_t slot = coop_unit ? tile * 64u + (vpos & 63u) : tile * 64u + lane;
       const long long tile_t0 = clock64();
+      const uint32_t seg_t0 = COOP ? 0u : s_n[tid];
       const unsigned long long tl_tile = (COUNT && a.timeline && lane == 0) ? wall_clock64() : 0ULL;
       if (slot < a.n_rays) {
           rts_trace_unit<COUNT, KEEP_ALL, REFR, COOP>(a, lc, ul, tid, gtid, lane, slot, pre_on, mask_on, D, max_refr, origin, n_nodes, n_tris, hard_overflow);
       }   // slot < n_rays
+      // (the segment count of the tile is only formed for tiles long enough to matter: an all-miss tile is ~100 instructions)
+      const unsigned long long dt = (unsigned long long)(clock64() - tile_t0) >> 6;             // (s_memtime: wave-uniform)
+      bool long_walks = false;
+      if (!COOP && a.tile_cost && dt >= a.coop_min_cost) {
+          uint32_t nseg = s_n[tid] - seg_t0;
+          for (int o = 32; o > 0; o >>= 1) nseg += __shfl_xor(nseg, o);
+          long_walks = dt >= (unsigned long long)a.coop_seg_cost * nseg;
+      }
       if (lane == 0) {
-          const unsigned long long dt = (unsigned long long)(clock64() - tile_t0) >> 6;
-          // (a tile traced as cooperative units costs the SUM of its units' wave time -- at least what it costs one wave -- so
-          // a tile once above the threshold stays above it: no flip-flopping between the two modes from launch to launch)
-          if (a.tile_cost) { if (coop_unit) atomicAdd(&a.tile_cost[tile], (unsigned int)(dt > 0x00fffffeULL ? 0x00fffffeULL : dt) + 1u);
-                             else a.tile_cost[tile] = (unsigned int)(dt > 0xfffffffeULL ? 0xfffffffeULL : dt) + 1u; }
+          // Cost record of the tile: bits 0-30 its duration (shader clocks >> 6, + 1), bit 31 "LONG WALKS": the tile took more
+          // than coop_seg_cost units per traced segment (all lanes' segments) -- rays that walk thousands of steps per segment,
+          // the only kind whose walk is long enough to be worth sharing out between 64 lanes (the per-ray arithmetic outside
+          // the walk is executed by a whole wave for ONE ray in a cooperative unit: a tile of short walks and many bounces
+          // costs ten times its ordinary wave time that way; BASELINE configs[2]'s slowest tiles are of that kind).
+          // (a tile traced as cooperative units costs the SUM of its units' wave time -- at least what it costs one wave -- and
+          // keeps its flag, so a tile once at the head stays there: no flip-flopping between the two modes from launch to launch)
+          if (a.tile_cost) {
+              if (COOP) { atomicAdd(&a.tile_cost[tile], (unsigned int)(dt > 0x00fffffeULL ? 0x00fffffeULL : dt) + 1u); if ((vpos & 63u) == 0u) atomicOr(&a.tile_cost[tile], 0x80000000u); }
+              else a.tile_cost[tile] = ((unsigned int)(dt > 0x7ffffffeULL ? 0x7ffffffeULL : dt) + 1u) | (long_walks ? 0x80000000u : 0u);
+          }
           if (COUNT && a.timeline && !coop_unit) { a.timeline[(size_t)gridDim.x * 2 + tile] = wall_clock64() - tl_tile; a.timeline[(size_t)gridDim.x * 2 + n_tiles + tile] = tl_tile; }   // debug timeline (RTS_TIMELINE): duration, start tick
       }
      }   // tiles of the draw

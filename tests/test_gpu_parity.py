@@ -1047,7 +1047,7 @@ def test_cooperative_units_are_invisible(rts, scenes, monkeypatch):
             monkeypatch.setenv(k, v)
         out = {}
         for mode in ("off", "all"):
-            monkeypatch.setenv("RTS_COOP_FRAC", "0" if mode == "off" else "1e-12"); monkeypatch.setenv("RTS_COOP_FLOOR", "0")
+            monkeypatch.setenv("RTS_COOP_FRAC", "0" if mode == "off" else "1e-12"); monkeypatch.setenv("RTS_COOP_FLOOR", "0"); monkeypatch.setenv("RTS_COOP_SEG", "0")
             tr = H.gpu_tracer(rts, spec, keep_all=True, count_traversal=True)
             tp = H.gpu_tracer(rts, spec)                                        # the product build
             for rep in range(3):                                                # (launches 2 and 3 have a cost history)
