@@ -138,6 +138,9 @@ __device__ __forceinline__ void rts_walk_step(const RtsTraceArgs& a, int32_t* s_
 #undef RTS_CHILD
         int c0 = CH.x, c1 = CH.y, c2 = CH.z, c3 = CH.w;
         // sort the four (distance, child) pairs ascending (5 compare-exchanges); misses carry +inf
+        // (measured, not kept: the compare into an SGPR pair and four VOP3 selects written by hand, because a probe --
+        // tools/cndmask_probe.hip -- shows v_cndmask_b32 reading VCC at ~22 cycles each when several follow one compare, against
+        // 4.2 with an SGPR-pair mask.  Bit-identical, and no change at all in the kernel: C3 0.757 / 0.764 ms, control 2.80 / 2.83 ms.)
 #define RTS_CSWAP(da, ca, db, cb) { const bool sw = db < da; const float td = sw ? db : da; const int tc = sw ? cb : ca; db = sw ? da : db; cb = sw ? ca : cb; da = td; ca = tc; }
         RTS_CSWAP(d0, c0, d1, c1) RTS_CSWAP(d2, c2, d3, c3) RTS_CSWAP(d0, c0, d2, c2) RTS_CSWAP(d1, c1, d3, c3) RTS_CSWAP(d1, c1, d2, c2)
 #undef RTS_CSWAP
