@@ -21,18 +21,24 @@ N_XCD, N_CU, N_SIMD = 8, 256, 1024
 PEAK_CLOCK_HZ = 2.4e9                      # MI355X_MICROARCH.md: max clock
 
 
-def kernel_rows(path, needle="k_trace"):
-    rows = collections.OrderedDict()        # dispatch id -> {counter: value, "_ns": duration}
+def kernel_rows(path):
+    """-> (ordinary launches, cooperative launches, meta): per dispatch {counter: value, "_ns": duration}.  A launch of the
+    library is the ordinary trace kernel k_trace<.., false> and, when the handle's cost order has a head, the cooperative
+    kernel k_trace<.., true> beside it (rts_trace.hip); under counter collection rocprofv3 runs the dispatches one at a time."""
+    rows = {False: collections.OrderedDict(), True: collections.OrderedDict()}
     meta = {}
     for r in csv.DictReader(open(path)):
-        if needle not in r["Kernel_Name"]:
+        name = r["Kernel_Name"]
+        if "k_trace" not in name:
             continue
-        d = rows.setdefault(int(r["Dispatch_Id"]), {})
+        coop = name.split("(")[0].rstrip().endswith("true>")
+        d = rows[coop].setdefault(int(r["Dispatch_Id"]), {})
         d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
         d["_ns"] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
-        meta = dict(kernel=r["Kernel_Name"], vgpr=int(r["VGPR_Count"]), agpr=int(r["Accum_VGPR_Count"]), sgpr=int(r["SGPR_Count"]),
-                    lds=int(r["LDS_Block_Size"]), scratch=int(r["Scratch_Size"]), grid=int(r["Grid_Size"]), wg=int(r["Workgroup_Size"]))
-    return list(rows.values()), meta
+        if not coop:
+            meta = dict(kernel=name, vgpr=int(r["VGPR_Count"]), agpr=int(r["Accum_VGPR_Count"]), sgpr=int(r["SGPR_Count"]),
+                        lds=int(r["LDS_Block_Size"]), scratch=int(r["Scratch_Size"]), grid=int(r["Grid_Size"]), wg=int(r["Workgroup_Size"]))
+    return list(rows[False].values()), list(rows[True].values()), meta
 
 
 def main():
@@ -47,13 +53,21 @@ def main():
         if not files:
             continue
         files.sort(key=os.path.getmtime, reverse=True)          # (a re-collected tag: gpurun merges new files beside the old ones)
-        rows, m = kernel_rows(files[0])
+        rows, crows, m = kernel_rows(files[0])
         if len(rows) < 2:
             continue
         meta = m or meta
-        use = rows[1:]
+        use = rows[1:]                                                      # (first launch of the handle: index-order tiles, cold caches)
         avg = {k: sum(r.get(k, 0.0) for r in use) / len(use) for k in use[0]}
-        out["passes"][name] = dict(dispatches=len(use), kernel_us=avg.pop("_ns") / 1e3, counters=avg)
+        ordinary_us = avg["_ns"] / 1e3
+        coop_us = 0.0
+        if crows:                                                           # the cooperative kernel of a launch: counters ADD, and so do the durations (dispatches are serialised under --pmc)
+            cavg = {k: sum(r.get(k, 0.0) for r in crows) / len(crows) for k in crows[0]}
+            coop_us = cavg["_ns"] / 1e3
+            out.setdefault("coop_per_launch", {}).update({k: v for k, v in cavg.items() if k != "_ns"})
+            for k, v in cavg.items():
+                avg[k] = avg.get(k, 0.0) + v
+        out["passes"][name] = dict(dispatches=len(use), coop_dispatches=len(crows), kernel_us=avg.pop("_ns") / 1e3, ordinary_kernel_us=ordinary_us, coop_kernel_us=coop_us, counters=avg)
         out["per_launch"].update(avg)
         # trimmed copy of the pass for profiles/ (k_trace dispatches only)
         with open(files[0]) as fi, open(os.path.join(ROOT, "profiles", "%s_pmc_%s_%s.csv" % (tag, wl, name)), "w") as fo:
@@ -95,6 +109,27 @@ def main():
             d["vmem_return_frac_from_counts"] = L.get("SQ_INSTS_VMEM_RD", 0.0) * 16.0 / (N_CU * d["kernel_cycles"])
     if "SQ_INSTS_VALU_ADD_F64" in L:
         d["f64_wave_insts"] = sum(L.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
+    # ---- CALIBRATED VALU issue demand.  A wave-instruction does not cost "4 cycles": measured on this
+    # chip with >= 2 waves per SIMD (tools/valu_calib.hip -> profiles/<calib>_valu_calib.json) f32 add / mul / fma and simple
+    # integer / logic / move instructions cost 2.25 cycles of their SIMD, f64 arithmetic, min / max, compares, selects, shifts
+    # and conversions 4.1-4.3, v_rcp_f32 8.1, v_rcp_f64 16.1.  The counters classify f32 / f64 add, mul, fma and the
+    # transcendentals; the rest is priced with the static opcode mix of the walk loop (tools/isa_mix.py).
+    calib_tag = os.environ.get("RTS_CALIB_TAG", "r03")
+    cp, mp = os.path.join(ROOT, "profiles", "%s_valu_calib.json" % calib_tag), os.path.join(ROOT, "profiles", "%s_isa_mix.json" % calib_tag)
+    if "SQ_INSTS_VALU_ADD_F64" in L and "SQ_INSTS_VALU" in L and os.path.exists(cp) and os.path.exists(mp) and "kernel_cycles" in d:
+        cal = json.load(open(cp))["classes"]; mix = json.load(open(mp))
+        c = lambda k: cal[k]["waves_per_simd_4"]["cycles_per_wave_inst_per_simd"]
+        f32 = sum(L.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32"))
+        f64 = sum(L.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64"))
+        t32, t64 = L.get("SQ_INSTS_VALU_TRANS_F32", 0.0), L.get("SQ_INSTS_VALU_TRANS_F64", 0.0)
+        other = max(L["SQ_INSTS_VALU"] - f32 - f64 - t32 - t64, 0.0)
+        vcyc = f32 * c("v_fma_f32") + f64 * c("v_fma_f64") + t32 * c("v_rcp_f32") + t64 * c("v_rcp_f64") + other * mix["cycles_per_uncounted_valu"]
+        d["valu_classes"] = dict(f32_add_mul_fma=f32, f64_add_mul_fma=f64, trans_f32=t32, trans_f64=t64, other=other,
+                                 cycles_each=dict(f32=c("v_fma_f32"), f64=c("v_fma_f64"), trans_f32=c("v_rcp_f32"), trans_f64=c("v_rcp_f64"), other=mix["cycles_per_uncounted_valu"]),
+                                 source=[os.path.relpath(cp, ROOT), os.path.relpath(mp, ROOT)])
+        d["valu_issue_cycles_calibrated"] = vcyc
+        d["valu_cycles_per_inst_calibrated"] = vcyc / L["SQ_INSTS_VALU"]
+        d["valu_issue_frac_calibrated"] = vcyc / (N_SIMD * d["kernel_cycles"])
     if "TA_TA_BUSY_sum" in L and cyc("TA_TA_BUSY_sum"):
         d["ta_busy"] = L["TA_TA_BUSY_sum"] / (N_CU * cyc("TA_TA_BUSY_sum"))
     if "TD_TD_BUSY_sum" in L and cyc("TD_TD_BUSY_sum"):
@@ -121,6 +156,14 @@ def main():
         d["hbm_bytes_per_launch"] = d["hbm_fetch_bytes_x2"] + d["hbm_write_bytes"]
     out["derived"] = d
     out["kernel_resources"] = meta
+    # the sources the profiled library was built from (rts_build_id): bench.py prices a run with these counters only if the
+    # library it loaded carries the same hash
+    sys.path.insert(0, ROOT)
+    try:
+        from rts_amd import _lib
+        out["source_hash"] = os.environ.get("RTS_PROFILE_HASH") or _lib.source_hash()
+    except Exception as e:                                                   # pragma: no cover
+        out["source_hash"] = None; out["source_hash_error"] = str(e)
     dst = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (tag, wl))
     json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
     print(dst)
