@@ -23,14 +23,18 @@ pulses in interleaved tiles (rts_plan_cpi); "rays" splits EVERY pulse over all r
 Either way the per-(receiver, path) group tables are exchanged once per interval (one all-gather over RCCL) and the
 complex return cube is summed once (one all-reduce), both inside the timed region.
 
-roofline: the trace kernel moves ~100 MB of HBM per launch against >10 GB of cache-served traversal bytes, so HBM is not
+roofline: the trace kernel moves ~150 MB of HBM per launch against >10 GB of cache-served traversal bytes, so HBM is not
 its bound (reported as secondary fields).  What binds is instruction issue: `bound` names the busier of the two per-CU
 pipes measured with rocprofv3 counters on this binary and workload (profiles/<tag>_pmc_<workload>.json, produced by
-tools/pmc_collect.sh + tools/pmc_derive.py): VALU issue (4 cycles of one of 1024 SIMDs per wave instruction) and the
-vector-memory return path (texture-data unit busy cycles, one per CU).  `achieved` scales the profile's per-segment
-figure by this run's segments and divides by this run's kernel time, `peak` is the unit count at the 2.4 GHz maximum
-clock, so frac <= 1 by construction.  The kernel time used is the SERIAL one (one trace kernel alone on the GPU, HIP
-events on its stream, measured after the timed region); the timed region itself overlaps kernels of --inflight pulses.
+tools/pmc_collect.sh + tools/pmc_derive.py): VALU issue and the vector-memory return path.  VALU issue is priced with
+MEASURED per-class costs (tools/valu_calib.hip -> profiles/r03_valu_calib.json: 2.25-2.44 cycles of a SIMD for f32 add /
+mul / fma and simple integer instructions, 4.1-4.3 for f64, min / max, compares, selects, 8 / 16 for rcp), the classes
+from the counters plus the static opcode mix of the walk loop (tools/isa_mix.py); `frac` = demanded issue cycles / (1024
+SIMDs x 2.4 GHz x serial kernel time) <= 1.  The old convention (4 cycles per instruction) is kept as a secondary field.
+The profile carries the hash of the sources it was taken on (rts_build_id): if the loaded library was built from other
+sources the roofline is NOT priced (frac null) -- collect the counters again.  The kernel time used is the SERIAL one
+(one launch alone on the GPU, HIP events on its stream, measured after the timed region); the timed region itself
+overlaps the kernels of --inflight pulses.
 """
 import argparse
 import json
@@ -48,7 +52,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~
 PEAK_CLOCK_HZ = 2.4e9          # max shader clock (MI355X_MICROARCH.md)
 N_SIMD, N_CU = 1024, 256
 PRI = 1.0e-3                   # pulse repetition interval of the synthetic CPI
-PMC_TAG = "r02d"               # profiles/<tag>_pmc_<workload>.json: counters of the committed kernel
+PMC_TAG = "r03a"               # profiles/<tag>_pmc_<workload>.json: counters of the committed kernel (tools/pmc_collect.sh + tools/pmc_derive.py)
 
 
 def pulse_motion(spec, k):
@@ -92,14 +96,19 @@ def cpu_baseline(spec, seconds_target=12.0):
     seg = 0; t0 = time.time(); reps = 0
     per_pulse = max(r["counters"]["segments"] * total / n, 1)
     if per_pulse / rate <= seconds_target:                 # whole pulses, repeated until ~seconds_target of CPU work
-        best = None
+        times = []
         while time.time() - t0 < seconds_target and reps < 256:
             t1 = time.time()
             r = sc.trace(tx["origin"], tx["span"], tx["dir"], W, spec["max_refl"], 0, spec["smooth"], ray_first=0, ray_stride=1, n_rays=total, **kw)
-            d1 = time.time() - t1
+            times.append(time.time() - t1)
             seg += r["counters"]["segments"]; reps += 1
-            best = d1 if best is None else min(best, d1)
-        what = "%d whole pulses (%d launch indices each), best pulse %.1f ms" % (reps, total, best * 1e3)
+        best = min(times); seg_pulse = seg / reps
+        what = "%d whole pulses (%d launch indices each): best %.1f, median %.1f, worst %.1f ms per pulse" % (reps, total, best * 1e3, float(np.median(times)) * 1e3, max(times) * 1e3)
+        dt = time.time() - t0
+        return dict(value=seg_pulse / best / 1e6, unit="Mrays/s", cores=threads, kind="port", cpu=cpu_model(), mean_value=seg / dt / 1e6,
+                    spread=dict(best_ms=best * 1e3, median_ms=float(np.median(times)) * 1e3, worst_ms=max(times) * 1e3, pulses=reps),
+                    sample="%s (value = best of %d; mean %.1f Mrays/s): %d segments in %.1f s; oracle/rts_oracle.cpp in BVH mode, g++ -O3 -march=native -ffp-contract=off, %d threads on %s"
+                           % (what, reps, seg / dt / 1e6, seg, dt, threads, cpu_model()))
     else:                                                  # a strided sample of one pulse
         stride = max(int(per_pulse / (rate * seconds_target)), 1)
         m = total // stride
@@ -195,6 +204,8 @@ def main():
     cube = torch.zeros((len(spec["rx"]), max(args.steps, args.warmup, 1), n_bins), dtype=torch.complex128, device="cuda")
     for t in trs:                                              # every pulse owns one row of the cube, so the handles can share it
         t.cube_attach(cube.shape[0], cube.shape[1], n_bins, cube_t0, cube_dt, device_ptr=cube.data_ptr())
+    n_fft = 1 << max(int(cube.shape[1]) - 1, 1).bit_length()  # range-Doppler map: zero-padded power-of-two transform over the pulse axis (rts_cube_doppler)
+    dop = torch.zeros((cube.shape[0], n_fft, n_bins), dtype=torch.complex128, device="cuda") if n_fft <= 4096 else None
 
     def plan(n_pulses):
         if args.shard == "rays" and world > 1:
@@ -241,7 +252,11 @@ def main():
                 dist.all_reduce(torch.view_as_real(cube), op=dist.ReduceOp.SUM)
             else:
                 cc = torch.view_as_real(cube).cpu(); dist.all_reduce(cc, op=dist.ReduceOp.SUM); cube.copy_(torch.view_as_complex(cc))
-        acc["tail_ms"] = dict(exchange=(t_b - t_a) * 1e3, merge=(t_c - t_b) * 1e3, cube_reduce=(time.perf_counter() - t_c) * 1e3)
+        t_d = time.perf_counter()
+        if dop is not None:                                   # slow-time transform of the (summed) cube: the library's LDS-resident FFT, on the handle's stream
+            trs[0].cube_doppler(n_fft, device_ptr=dop.data_ptr(), fetch=False)
+            torch.cuda.synchronize()
+        acc["tail_ms"] = dict(exchange=(t_b - t_a) * 1e3, merge=(t_c - t_b) * 1e3, cube_reduce=(t_d - t_c) * 1e3, doppler_fft=(time.perf_counter() - t_d) * 1e3)
         return acc, resp
 
     def sync():
@@ -260,7 +275,11 @@ def main():
     assert len(resp) == args.steps, "every pulse of the interval must come back with its responses"
     # range-Doppler map of the interval (slow-time FFT of the summed cube): a check of the dense product, outside the timed
     # region -- the hot path ends with the per-pulse responses and the (all-reduced) cube
-    range_doppler_peak = float(torch.fft.fft(cube[:, :args.steps], dim=1).abs().max().item()) if args.steps > 0 else 0.0
+    # (the transform itself ran inside the timed region, in the interval's tail: rts_cube_doppler; here it is checked against torch.fft)
+    ref_rd = torch.fft.fft(cube, n=n_fft, dim=1) if dop is not None else torch.fft.fft(cube, dim=1)
+    range_doppler_peak = float((dop if dop is not None else ref_rd).abs().max().item()) if args.steps > 0 else 0.0
+    range_doppler_err = float((dop - ref_rd).abs().max().item() / max(float(ref_rd.abs().max().item()), 1e-300)) if dop is not None else None
+    assert range_doppler_err is None or range_doppler_err < 1e-9, "rts_cube_doppler disagrees with torch.fft (%g)" % range_doppler_err
     seg = acc["segments"]; ms_trace = acc["ms_trace"]; ms_scene = acc["ms_scene"]; ms_post = acc["ms_post"]
     shaded = acc["shaded"]; received = acc["received"]; launches = max(acc["launches"], 1)
 
@@ -307,8 +326,10 @@ def main():
                          what="same scene, beam span 0.004 x 0.004 rad: every launch index hits the airframe")
 
         # ---- roofline from the committed counters of this binary on this workload
-        pmc, pmc_src = load_pmc(args.config if args.config != "c3ecef" else "c3")
-        pmc_ok = pmc is not None and W == 216 and world == 1 and args.config in ("c3", "c3ecef")
+        pmc, pmc_src = load_pmc({"c3ecef": "c3", "c3ico": "c3"}.get(args.config, args.config))
+        lib_hash = rts_amd._lib.build_id()
+        pmc_stale = pmc is not None and pmc.get("source_hash") != lib_hash
+        pmc_ok = pmc is not None and not pmc_stale and world == 1 and ((W == 216 and args.config in ("c3", "c3ecef")) or (W == 100 and args.config == "c2"))
         roof = {"kernel": "k_trace", "kernel_ms_serial": ms_serial, "segments_per_launch": seg_serial,
                 "kernel_ms_overlapped_avg": ms_trace / launches, "gpu_ms_per_launch_timed_region": dt / args.steps * 1e3,
                 "hit_fraction": hit_fraction, "nodes_per_segment": V, "tri_tests_per_segment": T, "shaded_per_segment": Hh,
@@ -328,26 +349,30 @@ def main():
             t_s = ms_serial * 1e-3
             valu = d["valu_wave_insts"] * scale                     # VALU wave instructions per launch
             td = d["vmem_rd_wave_insts"] * 16.0 * scale             # data cycles of the 256 L1 -> register return paths per launch: 16 clk (64 x 16 B at 64 B/clk) per wave-wide load, counted (SQ_INSTS_VMEM_RD); TD_TD_BUSY is not used: it counts cycles with requests outstanding (0.85 on an empty launch)
-            f_valu = valu * 4.0 / (N_SIMD * PEAK_CLOCK_HZ * t_s)
+            f_valu4 = valu * 4.0 / (N_SIMD * PEAK_CLOCK_HZ * t_s)   # the old convention: every instruction 4 cycles
+            vcyc = d.get("valu_issue_cycles_calibrated")
+            f_valu = (vcyc * scale / (N_SIMD * PEAK_CLOCK_HZ * t_s)) if vcyc else f_valu4
             f_td = td / (N_CU * PEAK_CLOCK_HZ * t_s)
             hbm = d.get("hbm_bytes_per_launch")
             if f_valu >= f_td:
-                roof.update(bound="valu_issue", achieved=valu / t_s / 1e9, peak=N_SIMD * PEAK_CLOCK_HZ / 4.0 / 1e9, unit="Gwave-inst/s", frac=f_valu)
+                roof.update(bound="valu_issue", achieved=(vcyc * scale if vcyc else valu * 4.0) / t_s / 1e9, peak=N_SIMD * PEAK_CLOCK_HZ / 1e9, unit="G SIMD issue cycles/s", frac=f_valu,
+                            valu_cycles_per_inst=d.get("valu_cycles_per_inst_calibrated"), valu_classes=d.get("valu_classes"), frac_if_every_inst_cost_4_cycles=f_valu4)
             else:
                 roof.update(bound="vmem_issue", achieved=td / t_s / 1e9, peak=N_CU * PEAK_CLOCK_HZ / 1e9, unit="G return-path data cycles/s", frac=f_td)
             t_w = dt / args.steps                                   # GPU time per launch in the timed region (kernels of --inflight pulses overlap)
-            roof.update(valu_issue_frac=f_valu, vmem_return_path_frac=f_td,
-                        timed_region={"valu_issue_frac": valu * 4.0 / (N_SIMD * PEAK_CLOCK_HZ * t_w), "vmem_return_path_frac": td / (N_CU * PEAK_CLOCK_HZ * t_w),
+            roof.update(valu_issue_frac=f_valu, vmem_return_path_frac=f_td, source_hash=lib_hash,
+                        timed_region={"valu_issue_frac": (vcyc * scale if vcyc else valu * 4.0) / (N_SIMD * PEAK_CLOCK_HZ * t_w), "vmem_return_path_frac": td / (N_CU * PEAK_CLOCK_HZ * t_w),
                                       "note": "the same per-launch counters over wall time / launches of the timed region: up to --inflight trace kernels share the chip, so a launch costs less wall time than the serial kernel (kernel_ms_serial x launches > ms_per_step x steps is expected unless --link / --inflight 1)"},
                         in_profile={"valu_busy": d.get("valu_busy"), "vmem_return_frac_from_counts": d.get("vmem_return_frac_from_counts"), "td_cycles_with_requests_frac": d.get("td_busy"), "ta_busy": d.get("ta_busy"), "l1_hit_rate": d.get("l1_hit_rate"),
                                     "l2_hit_rate": d.get("l2_hit_rate"), "waves_per_simd_avg": d.get("waves_per_simd_avg"), "active_lanes_per_valu_inst": d.get("active_lanes_per_valu_inst"),
                                     "note": "utilisations formed inside the profiled passes (busy cycles over GRBM_GUI_ACTIVE of the same dispatches)"},
                         traffic=hbm, traffic_source="%s: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of this binary on this workload; static, not re-measured by this run" % pmc_src,
                         hbm_GBps_measured=(hbm / t_s / 1e9) if hbm else None, hbm_frac_of_peak=(hbm / t_s / 1e9 / HBM_PEAK_GBS) if hbm else None,
-                        note="bound = the busier of VALU issue (4 clk of one of 1024 SIMDs per VALU wave-instruction) and the vector-memory return path (16 clk of one of 256 CUs per wave-wide load), both from instruction COUNTS of the profiled launch over this run's serial kernel time at the 2.4 GHz peak clock; HBM carries ~1 % of its peak (hbm_frac_of_peak) -- the scene is cache resident, the kernel is issue bound (DESIGN.md section 5)")
+                        note="bound = the busier of VALU issue (measured cycles of one of 1024 SIMDs per wave-instruction, by class: profiles/r03_valu_calib.json, r03_isa_mix.json) and the vector-memory return path (16 clk of one of 256 CUs per wave-wide load), both from instruction COUNTS of the profiled launch over this run's serial kernel time at the 2.4 GHz peak clock; HBM carries ~1 % of its peak (hbm_frac_of_peak) -- the scene is cache resident, the kernel is issue bound (DESIGN.md section 5)")
         else:
-            roof.update(bound="valu_issue", achieved=None, peak=N_SIMD * PEAK_CLOCK_HZ / 4.0 / 1e9, unit="Gwave-inst/s", frac=None, traffic=None,
-                        note="no committed counter profile for this configuration (profiles/%s_pmc_*.json cover c3 at W = 216 on one GPU)" % PMC_TAG)
+            roof.update(bound="valu_issue", achieved=None, peak=N_SIMD * PEAK_CLOCK_HZ / 1e9, unit="G SIMD issue cycles/s", frac=None, traffic=None, source_hash=lib_hash,
+                        note=("the committed counter profile %s was taken on sources %s, this library is %s: not priced -- run tools/pmc_collect.sh + tools/pmc_derive.py again" % (pmc_src, pmc.get("source_hash"), lib_hash)) if pmc_stale
+                        else "no committed counter profile for this configuration (profiles/%s_pmc_*.json cover c3 at W = 216 and c2 at W = 100 on one GPU)" % PMC_TAG)
         out = {
             "metric": "Mrays/s (primary+bounces) & ms/pulse, 100k-tri scene",
             "value": seg_all / dt / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -357,7 +382,7 @@ def main():
                                    % (2 if args.config.startswith("c3") else 1, " at Earth-centred coordinates" if args.config == "c3ecef" else "", spec["name"], len(spec["rx"]), W, total, spec["max_refl"]),
                        "rays_per_pulse": total, "segments_per_pulse": seg_all / args.steps, "received_per_pulse": received_all / args.steps,
                        "hit_fraction": hit_fraction, "primary_Mrays_per_s": total * args.steps / dt / 1e6,
-                       "return_cube": "complex128 [%d rx][%d pulses][%d bins], all-reduced once per interval; range-Doppler peak %.6e (slow-time FFT, un-timed check)" % (cube.shape[0], args.steps, n_bins, range_doppler_peak),
+                       "return_cube": "complex128 [%d rx][%d pulses][%d bins], all-reduced once per interval, then %d-point slow-time FFT in the library (rts_cube_doppler, inside the timed region); range-Doppler peak %.6e, max deviation from torch.fft %.1e (relative)" % (cube.shape[0], cube.shape[1], n_bins, n_fft, range_doppler_peak, range_doppler_err or 0.0),
                        "sharding": ("%d-pulse interval over %d ranks, --shard %s: " % (args.steps, world, args.shard)) + ("every pulse split over all ranks in interleaved 4096-index tiles" if args.shard == "rays" else "whole pulses, left-over pulses in interleaved 4096-index tiles") + "; one group-table all-gather + one cube all-reduce per interval",
                        "pulses_in_flight": len(trs), "linked": bool(args.link), "scene_setup_s": scene_setup_s,
                        "interval_tail_ms_rank0": acc["tail_ms"],

@@ -269,6 +269,18 @@ typedef struct RtsCubeParams {
 int rts_cube_attach(RtsHandle h, const RtsCubeParams* params, void* device_ptr);
 int rts_cube_accumulate(RtsHandle h, uint32_t pulse_index, double cspeed, double carrier);
 int rts_cube_get(RtsHandle h, double* host_out, uint64_t capacity_doubles);
+/* The same product per UNIQUE PATH instead of per received ray: one contribution per response the reference would emit for
+ * the pulse (ray_tracer.cpp:1290-1321) -- sqrt(P_group) e^{j phase_group} at delay_group, the group values of
+ * aggregation.cu:88-93 -- i.e. the reference's own (incoherent: mean of sqrt p, mean of wrapped phases) combination of
+ * the rays of a path.  Needs rts_aggregate of the pulse on this handle.  rts_cube_accumulate is the COHERENT sum over the
+ * rays (sum_i sqrt(p_i) e^{j phi_i}); the two differ by design, a caller uses one of them per cube. */
+int rts_cube_accumulate_paths(RtsHandle h, uint32_t pulse_index);
+/* Slow-time (Doppler) transform: for every receiver and range bin the n_fft-point DFT over the pulse axis, n_fft a power
+ * of two with n_pulses <= n_fft <= 4096 (pulses beyond n_pulses count as zeros):
+ *     out[rx][k][bin] = sum_p cube[rx][p][bin] e^{-2 pi j k p / n_fft}          (complex128, [n_rx][n_fft][n_bins])
+ * device_out: caller-owned device memory of 2 n_rx n_fft n_bins doubles, or NULL: library-owned (rts_cube_doppler_get). */
+int rts_cube_doppler(RtsHandle h, uint32_t n_fft, void* device_out);
+int rts_cube_doppler_get(RtsHandle h, double* host_out, uint64_t capacity_doubles);
 
 /* ---------------------------------------------------------------- several GPUs (not in the reference: it is single-GPU)
  * Rays are independent (each launch index writes only its own rows, ray_tracer.cu:227-253) and so are pulses

@@ -85,6 +85,8 @@ def lib():
                                              C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_aggregate_literal.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_double, C.c_double] + \
                                            [C.c_void_p] * 6
+        L.orc_cube.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint, C.c_uint, C.c_uint, C.c_uint,
+                               C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]
         L.orc_unique_paths.restype = C.c_uint
         L.orc_unique_paths.argtypes = [C.c_void_p, C.c_uint, C.c_void_p]
         L.orc_coverage.restype = C.c_uint
@@ -240,6 +242,22 @@ def aggregate_literal(rx_results, rx_intersects, cspeed, carrier, ray_total):
     lib().orc_aggregate_literal(_p(res), _p(np.ascontiguousarray(rx_intersects, np.int32)), R, D, cspeed, carrier,
                                 _p(npath), _p(power), _p(dop), _p(delay), _p(phase), _p(pm))
     return dict(results=res, npath=npath, power_sum=power, doppler_sum=dop, delay=delay, phase=phase, pathMatch=pm)
+
+
+def cube_accumulate(cube, pulse, rx_results, t0, dt, cspeed, carrier, lit=None):
+    """adds one pulse's contributions to cube (complex128 [n_rx][n_pulses][n_bins], in place).  lit = None: per received ray
+    (rx_results = the FINALISED received rays); lit = aggregate_literal(...) output: per unique path (its results / delay /
+    phase / pathMatch)"""
+    assert cube.dtype == np.complex128 and cube.flags.c_contiguous
+    n_rx, n_pulses, n_bins = cube.shape
+    if lit is None:
+        res = np.ascontiguousarray(rx_results); dl = ph = pm = None; mode = 0
+    else:
+        res = np.ascontiguousarray(lit["results"]); dl = np.ascontiguousarray(lit["delay"]); ph = np.ascontiguousarray(lit["phase"])
+        pm = np.ascontiguousarray(lit["pathMatch"], np.int32); mode = 1
+    lib().orc_cube(_p(res), res.shape[0], _p(dl), _p(ph), _p(pm), mode, n_rx, n_pulses, n_bins, pulse, t0, dt, cspeed, carrier,
+                   cube.ctypes.data_as(C.c_void_p))
+    return cube
 
 
 def unique_paths(path_match):

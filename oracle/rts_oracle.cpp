@@ -1093,6 +1093,30 @@ void orc_aggregate_literal(PerRayData* results_arr, const int* targ_intersect_ar
     }
 }
 
+// ---------------------------------------------------------------- complex return cube (north-star product, NOT in the reference)
+// Definition, two variants of cube[rx][pulse][bin] += A e^{j phi}, bin = floor((delay - t0) / dt):
+//   mode 0, per received RAY (the coherent sum):  A = sqrt(power_i) of the FINALISED ray (ray_tracer.cpp:1247 applied),
+//           delay_i = rayLength_i / c, phi_i = -fmod(2 pi fc delay_i, 2 pi)            -- the per-ray terms of aggregation.cu:59-60
+//   mode 1, per UNIQUE PATH (one term per response the reference emits, ray_tracer.cpp:1290-1321): the representative rays
+//           u = unique(pathMatch) with the group's power, mean delay and mean phase that myKernel2 left (aggregation.cu:88-93)
+// results / delay / phase / pathMatch: for mode 1 the outputs of orc_aggregate_literal on the pulse's received rays.
+void orc_cube(const PerRayData* results, unsigned receivedRays, const double* delay_arr, const double* phase_arr, const int* pathMatch, int mode,
+              unsigned n_rx, unsigned n_pulses, unsigned n_bins, unsigned pulse, double t0, double dt, double cspeed, double carrier, double* cube)
+{
+    for (unsigned i = 0; i < receivedRays; i++) {
+        const PerRayData& r = results[i];
+        if (r.received < 0 || (unsigned)r.received >= n_rx) continue;
+        double delay, phase;
+        if (mode == 0) { delay = (r.rayLength)/cspeed; phase = -fmod(delay*2*M_PI*carrier, 2*M_PI); }
+        else { if (pathMatch[i] != (int)i) continue; delay = delay_arr[i]; phase = phase_arr[i]; }
+        const double b = floor((delay - t0) / dt);
+        if (!(b >= 0.0) || !(b < (double)n_bins)) continue;
+        const double amp = sqrt(r.power);
+        double* cell = cube + 2 * (((size_t)r.received * n_pulses + pulse) * n_bins + (size_t)b);
+        cell[0] += amp * orc_cos(phase); cell[1] += amp * orc_sin(phase);
+    }
+}
+
 // ray_tracer.cpp:1290-1292  sort + unique of pathMatch; returns count, writes ascending unique values
 unsigned orc_unique_paths(const int* pathMatch, unsigned receivedRays, int* out)
 {

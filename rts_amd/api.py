@@ -230,6 +230,19 @@ class Tracer:
     def cube_accumulate(self, pulse_index, cspeed, carrier):
         check(L.lib().rts_cube_accumulate(self.h, pulse_index, cspeed, carrier))
 
+    def cube_accumulate_paths(self, pulse_index):
+        """one contribution per unique (receiver, path) of the pulse: the group values of rts_aggregate"""
+        check(L.lib().rts_cube_accumulate_paths(self.h, pulse_index))
+
+    def cube_doppler(self, n_fft, device_ptr=None, fetch=True):
+        """slow-time DFT over the pulse axis (n_fft: power of two >= n_pulses): complex [n_rx][n_fft][n_bins]"""
+        check(L.lib().rts_cube_doppler(self.h, n_fft, C.c_void_p(device_ptr) if device_ptr else None))
+        if not fetch:
+            return None
+        out = np.zeros((self._cube_shape[0], n_fft, self._cube_shape[2], 2), np.float64)
+        check(L.lib().rts_cube_doppler_get(self.h, ptr(out), out.size))
+        return out[..., 0] + 1j * out[..., 1]
+
     def cube(self):
         out = np.zeros(self._cube_shape + (2,), np.float64)
         check(L.lib().rts_cube_get(self.h, ptr(out), out.size))

@@ -79,8 +79,6 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     e = hipStreamCreateWithPriority(&c->gate->tstream, hipStreamNonBlocking, prio_low);
     if (e != hipSuccess) { delete c->gate; (void)hipStreamDestroy(c->stream); delete c; rts_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return RTS_ERR_HIP; }
     c->tstream = c->gate->tstream;
-    e = hipStreamCreateWithPriority(&c->cstream, hipStreamNonBlocking, prio_low);
-    if (e != hipSuccess) { delete c; rts_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return RTS_ERR_HIP; }
     for (int i = 0; i < 2; i++) { e = hipEventCreateWithFlags(&c->ev_coop[i], hipEventDisableTiming); if (e != hipSuccess) { delete c; rts_set_error("hipEventCreate: %s", hipGetErrorString(e)); return RTS_ERR_HIP; } }
     for (int i = 0; i < 9; i++) { e = hipEventCreate(&c->ev[i]); if (e != hipSuccess) { delete c; rts_set_error("hipEventCreate: %s", hipGetErrorString(e)); return RTS_ERR_HIP; } }
     e = hipHostMalloc((void**)&c->pin, sizeof(RtsPinned), hipHostMallocDefault);
@@ -126,13 +124,13 @@ extern "C" int rts_destroy(RtsHandle c)
     c->d_rx_angles.release(); c->d_rx_slots.release(); c->d_all_rays.release(); c->d_all_paths.release(); c->d_all_angles.release();
     c->d_akeys.release(); c->d_akeys_sorted.release(); c->d_aidx.release(); c->d_aidx_sorted.release(); c->d_ghead.release(); c->d_gid.release();
     c->d_gsum.release(); c->d_gmin.release(); c->d_gkey.release(); c->d_gpath.release(); c->d_grow.release(); c->d_gcount.release(); c->d_delay.release(); c->d_phase.release();
-    c->d_pathmatch.release(); c->d_rcs.release(); c->d_rcsval.release(); c->d_cube_own.release();
+    c->d_pathmatch.release(); c->d_rcs.release(); c->d_rcsval.release(); c->d_cube_own.release(); c->d_doppler_own.release();
     (void)hipStreamSynchronize(c->tstream);
     if (--c->gate->refs == 0) { (void)hipStreamDestroy(c->gate->tstream); delete c->gate; }
     if (c->pin) (void)hipHostFree(c->pin);
     for (int i = 0; i < 9; i++) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 2; i++) (void)hipEventDestroy(c->ev_coop[i]);
-    (void)hipStreamSynchronize(c->cstream); (void)hipStreamDestroy(c->cstream);
+    if (c->cstream) { (void)hipStreamSynchronize(c->cstream); (void)hipStreamDestroy(c->cstream); }
     (void)hipStreamDestroy(c->stream);
     delete c;
     return RTS_OK;
@@ -786,6 +784,7 @@ extern "C" int rts_aggregate(RtsHandle c, double cspeed, double carrier, uint64_
     RTS_HIP(hipMemsetAsync(c->d_phase.p, 0, sizeof(double)*R, c->stream));
     const int32_t max_path = (int32_t)c->scene->meshes.size() - 1, max_rx = c->n_rx ? (int32_t)c->n_rx - 1 : 0;
     const bool use_rows = recv_index_base == RTS_BASE_USE_ROWS;
+    c->agg_base_local = use_rows ? 0 : (int64_t)recv_index_base;
     int rc = rts_aggregate_device(c, max_path, max_rx, c->d_rx_paths.p, R, c->depth, cspeed, carrier, use_rows ? 0 : recv_index_base, c->d_rx_rays.p,
                                   c->d_delay.p, c->d_phase.p, c->d_pathmatch.p, &c->groups, nullptr, nullptr, nullptr, INT32_MAX, use_rows ? c->d_rx_slots.p : nullptr);
     if (rc != RTS_OK) return rc;
@@ -847,6 +846,41 @@ extern "C" int rts_cube_accumulate(RtsHandle c, uint32_t pulse_index, double csp
     if (!c->cube_set) { rts_set_error("rts_cube_accumulate: call rts_cube_attach first"); return RTS_ERR_INVALID; }
     if (pulse_index >= c->cube_params.n_pulses) { rts_set_error("rts_cube_accumulate: pulse %u >= %u", pulse_index, c->cube_params.n_pulses); return RTS_ERR_INVALID; }
     return rts_cube_accumulate_device(c, pulse_index, cspeed, carrier);
+}
+
+extern "C" int rts_cube_accumulate_paths(RtsHandle c, uint32_t pulse_index)
+{
+    CHECK_HANDLE(c);
+    CHECK_CLOSED(c);
+    if (!c->cube_set) { rts_set_error("rts_cube_accumulate_paths: call rts_cube_attach first"); return RTS_ERR_INVALID; }
+    if (!c->agg_valid) { rts_set_error("rts_cube_accumulate_paths: call rts_aggregate for this pulse first (the groups' power, delay and phase are its results)"); return RTS_ERR_INVALID; }
+    if (pulse_index >= c->cube_params.n_pulses) { rts_set_error("rts_cube_accumulate_paths: pulse %u >= %u", pulse_index, c->cube_params.n_pulses); return RTS_ERR_INVALID; }
+    return rts_cube_accumulate_paths_device(c, pulse_index, c->agg_base_local);
+}
+
+extern "C" int rts_cube_doppler(RtsHandle c, uint32_t n_fft, void* device_out)
+{
+    CHECK_HANDLE(c);
+    CHECK_CLOSED(c);
+    if (!c->cube_set) { rts_set_error("rts_cube_doppler: call rts_cube_attach first"); return RTS_ERR_INVALID; }
+    if (n_fft < 2 || n_fft > 4096 || (n_fft & (n_fft - 1)) != 0 || n_fft < c->cube_params.n_pulses) {
+        rts_set_error("rts_cube_doppler: n_fft = %u must be a power of two in [max(2, n_pulses = %u), 4096]", n_fft, c->cube_params.n_pulses); return RTS_ERR_INVALID; }
+    const size_t doubles = 2 * (size_t)c->cube_params.n_rx * n_fft * c->cube_params.n_bins;
+    if (device_out) c->doppler = (double*)device_out;
+    else { RTS_HIP(c->d_doppler_own.reserve(doubles)); c->doppler = c->d_doppler_own.p; }
+    c->doppler_n = n_fft;
+    return rts_cube_doppler_device(c, n_fft, c->doppler);
+}
+
+extern "C" int rts_cube_doppler_get(RtsHandle c, double* host_out, uint64_t capacity_doubles)
+{
+    CHECK_HANDLE(c);
+    if (!c->cube_set || !c->doppler || !host_out) { rts_set_error("rts_cube_doppler_get: no transform (rts_cube_doppler) / null output"); return RTS_ERR_INVALID; }
+    const size_t doubles = 2 * (size_t)c->cube_params.n_rx * c->doppler_n * c->cube_params.n_bins;
+    if (capacity_doubles < doubles) { rts_set_error("rts_cube_doppler_get: capacity too small"); return RTS_ERR_CAPACITY; }
+    RTS_HIP(hipStreamSynchronize(c->stream));
+    RTS_HIP(hipMemcpy(host_out, c->doppler, sizeof(double) * doubles, hipMemcpyDeviceToHost));
+    return RTS_OK;
 }
 
 extern "C" int rts_cube_get(RtsHandle c, double* host_out, uint64_t capacity_doubles)

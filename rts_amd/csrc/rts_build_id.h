@@ -1,1 +1,1 @@
-#define RTS_SOURCE_HASH "b687fcd679a154a2"
+#define RTS_SOURCE_HASH "12ab77bb8bc9fee4"

@@ -239,7 +239,7 @@ struct RtsContext {
     int device;
     hipStream_t stream = nullptr;       // scene placement, ordering, finalise, aggregation (high priority: short kernels)
     hipStream_t tstream = nullptr;      // trace kernels (the link group's, see RtsGate)
-    hipStream_t cstream = nullptr; hipEvent_t ev_coop[2];      // the cooperative trace kernel of a launch runs beside the ordinary one (rts_trace.hip)
+    hipStream_t cstream = nullptr; hipEvent_t ev_coop[2];      // the cooperative trace kernel of a launch runs beside the ordinary one; stream created on first use (rts_trace.hip)
     uint32_t coop_grid_max = 1024;      // most blocks of the cooperative kernel (RTS_COOP_GRID)
     bool head_hint_valid = false;       // pin->n_head holds the count of an earlier order build
     hipEvent_t ev[9];
@@ -278,6 +278,8 @@ struct RtsContext {
     DevBuf<double> d_delay, d_phase; DevBuf<int32_t> d_pathmatch; DevBuf<double> d_rcs;
     std::vector<RtsGroup> groups; bool agg_valid = false; uint64_t recv_index_base = 0;
     RtsCubeParams cube_params; double* cube = nullptr; DevBuf<double> d_cube_own; bool cube_set = false;
+    DevBuf<double> d_doppler_own; double* doppler = nullptr; uint32_t doppler_n = 0;       // slow-time transform of the cube (rts_cube_doppler)
+    int64_t agg_base_local = 0;         // pathMatch value of received ray i after rts_aggregate = agg_base_local + i
     RtsPinned* pin = nullptr; DevBuf<double> d_rcsval; int n_cu = 0; bool stats_pending = false; bool agg_timed = false, fin_timed = false;
     RtsStats stats;
     RtsGate* gate = nullptr; bool pulse_open = false;   // gate: never null after rts_create
@@ -293,6 +295,8 @@ int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a, bool count_traversal,
 int rts_post_order_and_expand(RtsContext* c);
 int rts_post_expand_all(RtsContext* c);
 int rts_cube_accumulate_device(RtsContext* c, uint32_t pulse_index, double cspeed, double carrier);
+int rts_cube_accumulate_paths_device(RtsContext* c, uint32_t pulse_index, int64_t base);
+int rts_cube_doppler_device(RtsContext* c, uint32_t n_fft, double* out);
 int rts_post_finalise(RtsContext* c, const double* rcs_host, double wl, double gt, double gr, double carrier, double cspeed);
 int rts_aggregate_device(RtsContext* c, int32_t max_path, int32_t max_rx, const int32_t* d_paths, uint64_t R, uint32_t D,
                          double cspeed, double carrier, uint64_t base, PerRayData* d_rays, double* d_delay,

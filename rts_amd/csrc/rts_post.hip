@@ -297,6 +297,86 @@ int rts_cube_accumulate_device(RtsContext* c, uint32_t pulse_index, double cspee
     return RTS_OK;
 }
 
+// The same product PER UNIQUE PATH: one contribution per response the reference would emit for the pulse
+// (ray_tracer.cpp:1290-1321) -- the representative ray of every (receiver, path) group (pathMatch[i] == i) with the GROUP's
+// power ((sum sqrt p / n)^2), mean delay and mean phase (aggregation.cu:88-93).  Needs the aggregation of the pulse.
+__global__ void k_cube_accumulate_paths(const PerRayData* __restrict__ rays, const double* __restrict__ delay, const double* __restrict__ phase, const int32_t* __restrict__ pm,
+                                        uint32_t R, int64_t base, double* __restrict__ cube, uint32_t n_rx, uint32_t n_pulses, uint32_t n_bins, uint32_t pulse, double t0, double dt)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    if ((int64_t)pm[i] != base + (int64_t)i) return;                          // not the representative of its group
+    const PerRayData r = rays[i];
+    if (r.received < 0 || (uint32_t)r.received >= n_rx) return;
+    const double b = floor((delay[i] - t0) / dt);
+    if (!(b >= 0.0) || !(b < (double)n_bins)) return;
+    const double amp = sqrt(r.power);
+    double sn, cs; sincos(phase[i], &sn, &cs);
+    double* cell = cube + 2 * (((size_t)r.received * n_pulses + pulse) * n_bins + (size_t)b);
+    atomicAdd(cell, amp * cs); atomicAdd(cell + 1, amp * sn);
+}
+
+int rts_cube_accumulate_paths_device(RtsContext* c, uint32_t pulse_index, int64_t base)
+{
+    const uint32_t R = (uint32_t)c->n_recv;
+    if (R == 0) return RTS_OK;
+    const RtsCubeParams& q = c->cube_params;
+    k_cube_accumulate_paths<<<blocks_for(R, 256), 256, 0, c->stream>>>(c->d_rx_rays.p, c->d_delay.p, c->d_phase.p, c->d_pathmatch.p, R, base, c->cube, q.n_rx, q.n_pulses, q.n_bins,
+                                                                        pulse_index, q.t0, q.dt);
+    RTS_HIP(hipGetLastError());
+    return RTS_OK;
+}
+
+// --------------------------------------------------------------------------- slow-time (Doppler) transform of the cube
+// out[rx][k][bin] = sum_{p < n_pulses} cube[rx][p][bin] e^{-2 pi j k p / N}, N a power of two >= n_pulses (zero padded).
+// One block per (receiver, tile of BT consecutive range bins): the tile's N x BT complex128 column set lives in LDS
+// (bit-reversed on the way in), log2 N radix-2 stages with a twiddle table in LDS, every stage's N/2 x BT butterflies dealt to
+// the block's threads; rows of BT x 16 bytes are contiguous in the cube, so loads and stores are BT-bin segments.  No MFMA: a
+// 1024-point f64 transform per (receiver, bin) is 5 120 butterflies; the whole C3 interval (4 x 1024 columns) is ~20 Mflop.
+__global__ void __launch_bounds__(256) k_cube_doppler(const double* __restrict__ cube, double* __restrict__ out, uint32_t n_pulses, uint32_t n_bins, uint32_t N, uint32_t logN, uint32_t BT)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_fft[];               // [N][BT] complex, then [N/2] complex twiddles
+    double* x = s_fft; double* tw = s_fft + 2 * (size_t)N * BT;
+    const uint32_t rx = blockIdx.y, bin0 = blockIdx.x * BT, t = threadIdx.x;
+    for (uint32_t k = t; k < N / 2; k += blockDim.x) { double sn, cs; sincospi(-2.0 * (double)k / (double)N, &sn, &cs); tw[2 * k] = cs; tw[2 * k + 1] = sn; }
+    for (uint32_t idx = t; idx < N * BT; idx += blockDim.x) {
+        const uint32_t p = idx / BT, b = idx - p * BT, bin = bin0 + b;
+        double re = 0.0, im = 0.0;
+        if (p < n_pulses && bin < n_bins) { const double* src = cube + 2 * (((size_t)rx * n_pulses + p) * n_bins + bin); re = src[0]; im = src[1]; }
+        const uint32_t pr = __brev(p) >> (32u - logN);
+        x[2 * ((size_t)pr * BT + b)] = re; x[2 * ((size_t)pr * BT + b) + 1] = im;
+    }
+    __syncthreads();
+    for (uint32_t s = 1; s <= logN; s++) {
+        const uint32_t half = 1u << (s - 1), tstep = N >> s;
+        for (uint32_t idx = t; idx < (N / 2) * BT; idx += blockDim.x) {
+            const uint32_t j = idx / BT, b = idx - j * BT, k = j & (half - 1u), i0 = ((j >> (s - 1)) << s) + k, i1 = i0 + half;
+            const double wr = tw[2 * (k * tstep)], wi = tw[2 * (k * tstep) + 1];
+            double* a0 = x + 2 * ((size_t)i0 * BT + b); double* a1 = x + 2 * ((size_t)i1 * BT + b);
+            const double xr = a1[0], xi = a1[1], tr = wr * xr - wi * xi, ti = wr * xi + wi * xr, ur = a0[0], ui = a0[1];
+            a0[0] = ur + tr; a0[1] = ui + ti; a1[0] = ur - tr; a1[1] = ui - ti;
+        }
+        __syncthreads();
+    }
+    for (uint32_t idx = t; idx < N * BT; idx += blockDim.x) {
+        const uint32_t k = idx / BT, b = idx - k * BT, bin = bin0 + b;
+        if (bin < n_bins) { double* dst = out + 2 * (((size_t)rx * N + k) * n_bins + bin); dst[0] = x[2 * ((size_t)k * BT + b)]; dst[1] = x[2 * ((size_t)k * BT + b) + 1]; }
+    }
+}
+
+int rts_cube_doppler_device(RtsContext* c, uint32_t n_fft, double* out)
+{
+    const RtsCubeParams& q = c->cube_params;
+    uint32_t logN = 0; while ((1u << logN) < n_fft) logN++;
+    uint32_t BT = 8; while (BT > 1 && (size_t)n_fft * BT * 16 > 65536) BT >>= 1;
+    const size_t lds = (size_t)n_fft * BT * 16 + (size_t)n_fft * 8;
+    RTS_HIP(hipFuncSetAttribute((const void*)k_cube_doppler, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((q.n_bins + BT - 1) / BT, q.n_rx);
+    k_cube_doppler<<<grid, 256, lds, c->stream>>>(c->cube, out, q.n_pulses, q.n_bins, n_fft, logN, BT);
+    RTS_HIP(hipGetLastError());
+    return RTS_OK;
+}
+
 // --------------------------------------------------------------------------- aggregation (group-by)
 // key = rx << (D*B) | sum_k (path[k] + 1) << (k*B): equal keys <=> same receiver and identical
 // path row, which is the row_equal test of myKernel1 (aggregation.cu:46-53).

@@ -101,6 +101,7 @@ __device__ __attribute__((noinline)) int rts_stack_below_spilled(int from_lds, i
 // One step of the walk for the lanes that hold a node or a leaf (`node` != the sentinel): fetch the record, test the four
 // child boxes / the triangle, update the stack and the closest hit.
 #define RTS_STACK_SENTINEL 0x7fffffff
+#define RTS_SEG_ONE 0x00400001u      // one traced segment in the per-lane LDS counter: launch total (bits 0-21) and current tile (bits 22-31)
 template <bool COUNT>
 __device__ __forceinline__ void rts_walk_step(const RtsTraceArgs& a, int32_t* s_stack, uint32_t tid, uint32_t gtid, int lds_cap, uint32_t* n_spill_lds,
                                               int& node, int& sp, const RtsSlabRay& lr, const dvec3& prev, const dvec3& dir, float tmin,
@@ -323,7 +324,7 @@ __device__ __forceinline__ void rts_trace_unit(const RtsTraceArgs& a, const RtsL
 
         for (;;) {
             // ------------------------------------------------------------ rtTrace: closest hit over the targets' hierarchies
-            if (!COOP || lane == 0) atomicAdd(&s_n[tid], 1u);                   // (ds_add_u32, no return)
+            if (!COOP || lane == 0) atomicAdd(&s_n[tid], RTS_SEG_ONE);           // (ds_add_u32, no return; bits 0-21 the lane's segments of the launch, bits 22-31 those of the current tile)
             const float tmin = chain_start ? SCENE_EPS : SCENE_EPS_R;          // ray_tracer.cu:209, normal_shader.cu:242,297
             float best_t = RTS_DEFAULT_TMAX;
             int best_leaf = -1; uint32_t best_prim = 0xffffffffu;
@@ -655,6 +656,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR || COOP) ? 2 : 4) k_trace(con
     // whatever their address -- keeps the draws off the critical path: 69 k of them per launch over 64 lines.
     const uint32_t n_tiles = (a.n_rays + 63u) / 64u;
     const uint32_t lane = tid & 63u;
+    const uint32_t wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);      // (scalar: the wave's number in the block)
     const uint32_t stripe = __builtin_amdgcn_readfirstlane((blockIdx.x * (RTS_BLOCK / 64u) + (tid >> 6)) % RTS_TILE_CTRS);   // wave-uniform: the queue arithmetic below stays scalar
     // Draw schedule of a stripe (positions k*C + stripe, k = 0, 1, ...): the first quarter -- the expensive end of the
     // order -- one tile per draw, the cheap rest four tiles per draw (a miss-only tile is ~2 us of work, and so is a draw's
@@ -670,9 +672,18 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR || COOP) ? 2 : 4) k_trace(con
     const uint32_t per_stripe = (n_units + RTS_TILE_CTRS - 1u) / RTS_TILE_CTRS;
     const uint32_t single_draws = per_stripe >= 1024u ? per_stripe / 4u : per_stripe;      // (short queues: one tile per draw throughout)
     // The pending draw is held in a register of lane 0 (so that its latency hides behind the tiles traced meanwhile) -- except
-    // in the counting builds, which are short of registers: there the allocator spilled it to scratch, stored under
-    // EXEC = lane 0 and reloaded at the loop top, and launches then lost whole tiles' worth of counters from run to run
-    // (the reload overtaking the store is the suspicion; product builds have no scratch at all, tests/test_host_logic.py checks).
+    // in the counting builds, which are short of registers: there the allocator spilled it to scratch and launches lost whole
+    // tiles' worth of counters from run to run, until it was moved to LDS.  What the ISA of that build shows (round 3,
+    // commit 835ee13~1, k_trace<true,..>: `hipcc -S`, spill slot 8): the draw is stored by `scratch_store_dword off, v0, off
+    // offset:8` under EXEC = lane 0, AFTER `s_waitcnt vmcnt(0)` on the atomic's return value, and reloaded at the loop top by
+    // `scratch_load_dword v0, off, off offset:8` under the full mask, followed by `s_waitcnt vmcnt(0)` and
+    // `v_readfirstlane_b32` (= lane 0, whose dword the store wrote): same per-lane address, program order, the wait before the
+    // use -- the emitted code has NO ordering defect, so "the reload overtaking the store" (last round's suspicion) is not it.
+    // The only other values in scratch there are the timeline tick (slot 0) and `tid` (slot 12: stored in the prologue,
+    // reloaded in the epilogue for the `tid in 1..6` test that guards the block_counters store).  The symptom -- a garbage SUM in
+    // counters[6], i.e. block_counters rows that no block had written -- fits a wrong `tid` there better than a wrong draw; it
+    // was not reproduced this round (the builds differ: 32-bit counters came in with the same commit), so the cause stays
+    // unproven.  Product builds reload nothing from scratch (tests/test_host_logic.py checks the ISA).
     __shared__ uint32_t s_draw[RTS_BLOCK / 64];
     uint32_t draw_next = 0;
 #define RTS_DRAW() { const uint32_t dv_ = atomicAdd(&a.tile_ctr[(COOP ? RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE : 0) + stripe * RTS_TILE_CTR_STRIDE], 1u); if (COUNT) s_draw[tid >> 6] = dv_; else draw_next = dv_; }
@@ -697,7 +708,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR || COOP) ? 2 : 4) k_trace(con
       const uint32_t tile = a.tile_order ? a.tile_order[tpos] : ((tpos & 1u) ? (n_tiles - 1u) / 2u + (tpos + 1u) / 2u : (n_tiles - 1u) / 2u - tpos / 2u);
       const uint32_t slot = coop_unit ? tile * 64u + (vpos & 63u) : tile * 64u + lane;
       const long long tile_t0 = clock64();
-      const uint32_t seg_t0 = COOP ? 0u : s_n[tid];
+      if (!COOP) atomicAnd(&s_n[tid], 0x003fffffu);              // (ds_and_b32: the tile's own segment count starts at zero; a register for it would be the 129th)
       const unsigned long long tl_tile = (COUNT && a.timeline && lane == 0) ? wall_clock64() : 0ULL;
       if (slot < a.n_rays) {
           rts_trace_unit<COUNT, KEEP_ALL, REFR, COOP>(a, lc, ul, tid, gtid, lane, slot, pre_on, mask_on, D, max_refr, origin, n_nodes, n_tris, hard_overflow);
@@ -706,7 +717,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR || COOP) ? 2 : 4) k_trace(con
       const unsigned long long dt = (unsigned long long)(clock64() - tile_t0) >> 6;             // (s_memtime: wave-uniform)
       bool long_walks = false;
       if (!COOP && a.tile_cost && dt >= a.coop_min_cost) {
-          uint32_t nseg = s_n[tid] - seg_t0;
+          uint32_t nseg = s_n[tid] >> 22;
           for (int o = 32; o > 0; o >>= 1) nseg += __shfl_xor(nseg, o);
           long_walks = dt >= (unsigned long long)a.coop_seg_cost * nseg;
       }
@@ -732,7 +743,11 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR || COOP) ? 2 : 4) k_trace(con
     // ------------------------------------------------------------------ counters: wave reduce -> block reduce (LDS, the
     // traversal stack is dead by now) -> one plain store per block; k_sum_counters adds the blocks up.  (One atomic per
     // wave on the same two addresses -- 32 k same-line L2 atomics -- cost a fixed ~0.35 ms at the tail of every launch.)
-    unsigned long long n_seg = s_n[tid], n_shaded = s_n[RTS_BLOCK + tid], n_spill = s_n[2 * RTS_BLOCK + tid], n_nodes_w = n_nodes, n_tris_w = n_tris;
+    // (the thread index is re-formed here from the wave's number -- scalar, kept since the start -- and the lane number instead of
+    // being carried through the kernel: the allocator, at its 128-register limit, otherwise parks threadIdx.x in scratch in the
+    // prologue and reloads it here)
+    const uint32_t tid_e = (wave_u << 6) | __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    unsigned long long n_seg = s_n[tid_e] & 0x003fffffu, n_shaded = s_n[RTS_BLOCK + tid_e], n_spill = s_n[2 * RTS_BLOCK + tid_e], n_nodes_w = n_nodes, n_tris_w = n_tris;
     for (int off = 32; off > 0; off >>= 1) {
         n_seg += __shfl_down(n_seg, off); n_shaded += __shfl_down(n_shaded, off);
         if (COUNT) { n_nodes_w += __shfl_down(n_nodes_w, off); n_tris_w += __shfl_down(n_tris_w, off); }
@@ -740,17 +755,17 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR || COOP) ? 2 : 4) k_trace(con
     }
     __syncthreads();
     unsigned long long* s_cnt = reinterpret_cast<unsigned long long*>(s_stack);        // [waves][8]
-    const int wave = tid >> 6;
-    if ((tid & 63) == 0) {
+    const int wave = (int)wave_u;
+    if ((tid_e & 63) == 0) {
         s_cnt[wave * 8 + 1] = n_seg; s_cnt[wave * 8 + 2] = n_shaded; s_cnt[wave * 8 + 3] = COUNT ? n_nodes_w : 0ULL;
         s_cnt[wave * 8 + 4] = COUNT ? n_tris_w : 0ULL; s_cnt[wave * 8 + 5] = n_spill;
     }
     const bool any_overflow = __syncthreads_or(hard_overflow ? 1 : 0) != 0;
-    if (tid >= 1 && tid <= 6) {
+    if (tid_e >= 1 && tid_e <= 6) {
         unsigned long long v = 0;
-        if (tid <= 5) { for (int w = 0; w < RTS_BLOCK / 64; w++) v += s_cnt[w * 8 + tid]; }
+        if (tid_e <= 5) { for (int w = 0; w < RTS_BLOCK / 64; w++) v += s_cnt[w * 8 + tid_e]; }
         else v = any_overflow ? 1ULL : 0ULL;
-        a.block_counters[((size_t)(COOP ? a.total_threads / RTS_BLOCK : 0u) + blockIdx.x) * 8 + tid] = v;
+        a.block_counters[((size_t)(COOP ? a.total_threads / RTS_BLOCK : 0u) + blockIdx.x) * 8 + tid_e] = v;
     }
 }
 
@@ -786,14 +801,19 @@ static void rts_trace_dispatch(const RtsTraceArgs& a, bool count_traversal, unsi
     }
 }
 
-// coop_grid > 0: the cooperative kernel is launched FIRST (it holds the most expensive work of the launch), on the handle's
-// second trace stream, so that the ordinary kernel's blocks fill the chip beside it and behind it.
+// coop_grid > 0: the cooperative kernel is launched FIRST (it holds the most expensive work of the launch), on a stream of its
+// own at the trace stream's priority, so that the two kernels' blocks fill the chip side by side from the start (on the
+// handle's high-priority stream the cooperative blocks -- three per CU -- crowd the ordinary kernel out until they retire:
+// C4 9.4 instead of 8.7 ms).  The stream is created by the first launch that needs it: HIP maps streams onto a handful of
+// hardware queues, and one more stream per handle made unrelated handles of a three-pulse pipeline share a queue --
+// 0.69 -> 0.93 ms per pulse on C3, where there is no cooperative work at all.
 int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a, bool count_traversal, unsigned coop_grid)
 {
     if (a.n_rays == 0) return RTS_OK;
     const unsigned grid = a.total_threads / RTS_BLOCK;
     hipStream_t st = c->tstream;
     if (coop_grid) {
+        if (!c->cstream) { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); RTS_HIP(hipStreamCreateWithPriority(&c->cstream, hipStreamNonBlocking, lo)); }
         RTS_HIP(hipEventRecord(c->ev_coop[0], st));
         RTS_HIP(hipStreamWaitEvent(c->cstream, c->ev_coop[0], 0));
         rts_trace_dispatch<true>(a, count_traversal, coop_grid, c->cstream);

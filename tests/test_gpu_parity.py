@@ -500,32 +500,52 @@ def test_c4_c5_shapes(rts, oracle, scenes):
     tr.close()
 
 
-def test_return_cube(rts, scenes):
-    """complex return cube (north-star product, not in the reference): device accumulation of sqrt(P) e^{j phi} into
-    [rx][pulse][range bin] vs a numpy accumulation of the same received, finalised rays"""
+def test_return_cube(rts, oracle, scenes):
+    """complex return cube (north-star product, not in the reference; definition: oracle/rts_oracle.cpp orc_cube, DESIGN.md
+    section 4): the device accumulation of sqrt(P) e^{j phi} into [rx][pulse][range bin] -- per received ray (coherent sum)
+    and per unique path (one term per response of the reference) -- against the ORACLE's accumulation of the ORACLE's rays
+    (independent rays, independent binning), and the library's slow-time transform against numpy's FFT"""
     spec = scenes.config_multi(W=20)
-    tr = H.gpu_tracer(rts, spec)
     wl = spec["c"] / spec["carrier"]
-    n_bins, t0, dt = 64, 1.2e-6, 5.0e-9
-    tr.cube_attach(len(spec["rx"]), 3, n_bins, t0, dt)
-    want = np.zeros((len(spec["rx"]), 3, n_bins), np.complex128)
+    n_bins, t0, dt, n_p = 64, 1.2e-6, 5.0e-9, 5
+    tr = H.gpu_tracer(rts, spec); tr.cube_attach(len(spec["rx"]), n_p, n_bins, t0, dt)
+    tp = H.gpu_tracer(rts, spec); tp.cube_attach(len(spec["rx"]), n_p, n_bins, t0, dt)
+    want_rays = np.zeros((len(spec["rx"]), n_p, n_bins), np.complex128); want_paths = want_rays.copy()
     total = 0
-    for k in range(3):
+    for k in range(n_p):
         mo = [dict(position=tuple(np.add(m["position"], (0.5 * k, 0, 0))), velocity=m["velocity"]) for m in spec["motion"]]
-        H.gpu_trace(rts, spec, tr=tr, motion=mo)
-        tr.finalise_uniform(None, wl, 1.0, 1.0, spec["carrier"], spec["c"])
+        for t in (tr, tp):
+            H.gpu_trace(rts, spec, tr=t, motion=mo)
+            t.finalise_uniform(None, wl, 1.0, 1.0, spec["carrier"], spec["c"])
         tr.cube_accumulate(k, spec["c"], spec["carrier"])
-        r = tr.received()["results"]
-        delay = r["rayLength"] / spec["c"]
-        phase = -np.fmod(delay * 2 * math.pi * spec["carrier"], 2 * math.pi)
-        b = np.floor((delay - t0) / dt)
-        ok = (b >= 0) & (b < n_bins)
-        np.add.at(want, (r["received"][ok], k, b[ok].astype(int)), np.sqrt(r["power"][ok]) * np.exp(1j * phase[ok]))
-        total += int(ok.sum())
-    got = tr.cube()
-    assert total > 20 and np.count_nonzero(want) > 3
-    np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-22)
-    tr.close()
+        tp.aggregate(spec["c"], spec["carrier"]); tp.cube_accumulate_paths(k)
+        o = H.oracle_trace(oracle, spec, motion=mo)
+        rx, rxi, _ = oracle.filter_finalise(o["results"], o["path"], [1.0] * len(spec["meshes"]), wl, 1.0, 1.0, spec["carrier"], spec["c"])
+        oracle.cube_accumulate(want_rays, k, rx, t0, dt, spec["c"], spec["carrier"])
+        oracle.cube_accumulate(want_paths, k, None, t0, dt, spec["c"], spec["carrier"], lit=oracle.aggregate_literal(rx, rxi, spec["c"], spec["carrier"], spec["W"] ** 3))
+        total += len(rx)
+    got_rays = tr.cube(); got_paths = tp.cube()
+    assert total > 100 and np.count_nonzero(want_rays) > 10 and np.count_nonzero(want_paths) > 5
+    assert np.array_equal(want_rays != 0, got_rays != 0) and np.array_equal(want_paths != 0, got_paths != 0)        # same cells
+    np.testing.assert_allclose(got_rays, want_rays, rtol=1e-10, atol=1e-13 * np.abs(want_rays).max())              # (f64 atomics add in another order; OCML / libm sincos)
+    np.testing.assert_allclose(got_paths, want_paths, rtol=1e-10, atol=1e-13 * np.abs(want_paths).max())
+    assert np.count_nonzero(want_paths) < np.count_nonzero(want_rays) or not np.allclose(want_paths, want_rays)    # the two products differ (by design)
+    # slow-time transform: zero-padded to 8 and to 16 points, every (rx, bin) column
+    for n_fft in (8, 16):
+        np.testing.assert_allclose(tr.cube_doppler(n_fft), np.fft.fft(want_rays, n=n_fft, axis=1), rtol=0, atol=1e-10 * np.abs(want_rays).max())
+    from rts_amd import _lib
+    assert _lib.lib().rts_cube_doppler(tr.h, 4, None) == _lib.RTS_ERR_INVALID and _lib.lib().rts_cube_doppler(tr.h, 12, None) == _lib.RTS_ERR_INVALID   # < n_pulses; not a power of two
+    tr.close(); tp.close()
+    # a long transform on random data: 1024 points (4 bins per block), 4096 points (one bin per block), ragged bin count
+    import torch
+    for n_p2, n_fft, nb in ((1000, 1024, 37), (4096, 4096, 5), (300, 512, 16)):
+        t = rts.Tracer(8, 1); rng = np.random.default_rng(n_fft)
+        data = rng.standard_normal((2, n_p2, nb)) + 1j * rng.standard_normal((2, n_p2, nb))
+        buf = torch.from_numpy(np.ascontiguousarray(data)).cuda()
+        t.cube_attach(2, n_p2, nb, 0.0, 1.0, device_ptr=buf.data_ptr())
+        got = t.cube_doppler(n_fft)
+        np.testing.assert_allclose(got, np.fft.fft(data, n=n_fft, axis=1), rtol=0, atol=1e-10 * np.abs(data).max() * math.sqrt(n_fft))
+        t.close()
 
 
 def test_deep_tree_spills_stack(rts, oracle, scenes, monkeypatch):

@@ -293,3 +293,29 @@ def test_reference_flow_scenarios_and_their_sensitivity(oracle, tmp_path):
     AR.write_scenario(str(tmp_path / "s.scn"), sc)
     lines = open(str(tmp_path / "s.scn")).read().splitlines()
     assert [l.split()[0] for l in lines] == ["params", "tx", "rx", "rx", "target", "target", "target"]
+
+
+def test_cube_definition_closed_form(oracle):
+    """orc_cube (the definition of the complex return cube): per ray A = sqrt(P) e^{j phi} with
+    phi = -fmod(2 pi fc delay, 2 pi) in bin floor((delay - t0) / dt); per unique path one term per representative ray with the
+    group's power / delay / phase; rays outside the window or with a receiver index outside the cube are dropped"""
+    c, fc = 299792458.0, 1.0e9
+    rx = np.zeros(4, oracle.PRD_DTYPE)
+    rx["received"] = [0, 0, 1, 5]; rx["power"] = [4.0, 9.0, 16.0, 1.0]
+    rx["rayLength"] = [c * 1.05e-6, c * 1.05e-6, c * 1.31e-6, c * 1.0e-6]; rx["reflDepth"] = 1
+    cube = np.zeros((2, 3, 8), np.complex128)
+    oracle.cube_accumulate(cube, 1, rx, 1.0e-6, 0.1e-6, c, fc)
+    ph = lambda d: -math.fmod(d * 2 * math.pi * fc, 2 * math.pi)
+    d0 = rx["rayLength"][0] / c; d2 = rx["rayLength"][2] / c
+    want = np.zeros_like(cube)
+    want[0, 1, 0] = (2.0 + 3.0) * complex(math.cos(ph(d0)), math.sin(ph(d0)))
+    want[1, 1, 3] = 4.0 * complex(math.cos(ph(d2)), math.sin(ph(d2)))
+    np.testing.assert_allclose(cube, want, rtol=1e-15, atol=0)
+    # per unique path: rays 0 and 1 share receiver and path -> ONE term: sqrt(((2 + 3) / 2)^2) at the mean delay and phase
+    paths = np.array([[0], [0], [0], [0]], np.int32)
+    lit = oracle.aggregate_literal(rx[:3], paths[:3], c, fc, 100)
+    cube2 = np.zeros((2, 3, 8), np.complex128)
+    oracle.cube_accumulate(cube2, 2, None, 1.0e-6, 0.1e-6, c, fc, lit=lit)
+    assert list(oracle.unique_paths(lit["pathMatch"])) == [0, 2]
+    assert np.count_nonzero(cube2) == 2 and abs(abs(cube2[0, 2, 0]) - 2.5) < 1e-12 and abs(abs(cube2[1, 2, 3]) - 4.0) < 1e-12
+    assert abs(np.angle(cube2[0, 2, 0]) - math.remainder(ph(d0), 2 * math.pi)) < 1e-9
