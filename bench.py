@@ -205,7 +205,8 @@ def main():
     for t in trs:                                              # every pulse owns one row of the cube, so the handles can share it
         t.cube_attach(cube.shape[0], cube.shape[1], n_bins, cube_t0, cube_dt, device_ptr=cube.data_ptr())
     n_fft = 1 << max(int(cube.shape[1]) - 1, 1).bit_length()  # range-Doppler map: zero-padded power-of-two transform over the pulse axis (rts_cube_doppler)
-    dop = torch.zeros((cube.shape[0], n_fft, n_bins), dtype=torch.complex128, device="cuda") if n_fft <= 4096 else None
+    has_dop = hasattr(rts_amd._lib.lib(), "rts_cube_doppler")     # (an older library named by RTS_AMD_LIB, A/B runs: torch.fft then, outside the timed region)
+    dop = torch.zeros((cube.shape[0], n_fft, n_bins), dtype=torch.complex128, device="cuda") if (n_fft <= 4096 and has_dop) else None
 
     def plan(n_pulses):
         if args.shard == "rays" and world > 1:
@@ -327,7 +328,10 @@ def main():
 
         # ---- roofline from the committed counters of this binary on this workload
         pmc, pmc_src = load_pmc({"c3ecef": "c3", "c3ico": "c3"}.get(args.config, args.config))
-        lib_hash = rts_amd._lib.build_id()
+        try:
+            lib_hash = rts_amd._lib.build_id()
+        except AttributeError:                                  # a library from before rts_build_id (RTS_AMD_LIB)
+            lib_hash = None
         pmc_stale = pmc is not None and pmc.get("source_hash") != lib_hash
         pmc_ok = pmc is not None and not pmc_stale and world == 1 and ((W == 216 and args.config in ("c3", "c3ecef")) or (W == 100 and args.config == "c2"))
         roof = {"kernel": "k_trace", "kernel_ms_serial": ms_serial, "segments_per_launch": seg_serial,

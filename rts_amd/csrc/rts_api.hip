@@ -87,6 +87,7 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     hipDeviceProp_t prop; e = hipGetDeviceProperties(&prop, p->device);
     if (e != hipSuccess) { delete c; rts_set_error("hipGetDeviceProperties: %s", hipGetErrorString(e)); return RTS_ERR_HIP; }
     c->n_cu = prop.multiProcessorCount;
+    rts_trace_preload();
     { const char* e = getenv("RTS_PRIMARY_MASK"); if (e && e[0] == '0') c->use_pmask = false; }            // experiments / tests: no primary-ray pre-filter
     if (p->flags & RTS_FLAG_NO_PREFILTER) c->use_pmask = false;
     // experiment / test knobs, read ONCE PER HANDLE at creation (never per process: two handles of one process may differ)
@@ -96,6 +97,7 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     { const char* e = getenv("RTS_COOP_FRAC"); if (e) { const double v = atof(e); if (v >= 0) c->coop_frac = v; } }                  // 0: no cooperative units; tests: tiny values put every tile at the head
     { const char* e = getenv("RTS_COOP_FLOOR"); if (e) c->coop_floor = (uint32_t)std::max(0, atoi(e)); }
     { const char* e = getenv("RTS_COOP_SEG"); if (e) c->coop_seg_cost = (uint32_t)std::max(0, atoi(e)); }
+    { const char* e = getenv("RTS_COOP_SEG_RATIO"); if (e) c->coop_seg_ratio = std::max(0.0, atof(e)); }
     { const char* e = getenv("RTS_COOP_GRID"); if (e) c->coop_grid_max = (uint32_t)std::min(4096, std::max(1, atoi(e))); }
     { const char* e = getenv("RTS_EW_REL"); if (e) { const double v = atof(e); if (v > 0) c->ew_rel = v; } }
     { const char* e = getenv("RTS_STACK_LDS_DEBUG"); if (e) { int v = atoi(e); if (v >= 1 && v <= RTS_STACK_LDS) c->stack_lds = (uint32_t)v; } }   // tests: force the spill path
@@ -119,7 +121,7 @@ extern "C" int rts_destroy(RtsHandle c)
     c->d_verts_world.release(); c->d_normals_world.release();
     c->d_motion.release(); c->d_targets.release();
     c->d_leaves.release(); c->d_sort_tmp.release(); c->d_rx.release(); c->d_recv.release(); c->d_all.release();
-    c->d_counters.release(); c->d_block_counters.release(); c->d_timeline.release(); c->d_tile_cost.release(); c->d_tile_key.release(); c->d_tile_key_sorted.release(); c->d_tile_id.release(); c->d_tile_order.release(); c->d_tile_hist.release(); c->d_tile_ctr.release(); c->d_tile_head.release(); c->d_lc.release(); c->d_dir_hist.release(); c->d_pmask.release(); c->d_child.release(); c->d_rk64.release(); c->d_rk64_sorted.release(); c->d_hit_prim.release(); c->d_hit_t.release(); c->d_stack_ovf.release();
+    c->d_counters.release(); c->d_block_counters.release(); c->d_timeline.release(); c->d_tile_cost.release(); c->d_tile_key.release(); c->d_tile_key_sorted.release(); c->d_tile_id.release(); c->d_tile_order.release(); c->d_tile_hist.release(); c->d_tile_ctr.release(); c->d_lc.release(); c->d_dir_hist.release(); c->d_pmask.release(); c->d_child.release(); c->d_rk64.release(); c->d_rk64_sorted.release(); c->d_hit_prim.release(); c->d_hit_t.release(); c->d_stack_ovf.release();
     c->d_rk.release(); c->d_rk_sorted.release(); c->d_ri.release(); c->d_ri_sorted.release(); c->d_rx_rays.release(); c->d_rx_paths.release();
     c->d_rx_angles.release(); c->d_rx_slots.release(); c->d_all_rays.release(); c->d_all_paths.release(); c->d_all_angles.release();
     c->d_akeys.release(); c->d_akeys_sorted.release(); c->d_aidx.release(); c->d_aidx_sorted.release(); c->d_ghead.release(); c->d_gid.release();
@@ -468,7 +470,7 @@ extern "C" int rts_reserve(RtsHandle c, uint64_t n_rays)
     RTS_HIP(c->d_stack_ovf.reserve((size_t)RTS_STACK_OVF * ((size_t)c->n_cu * 1024 + coop_threads)));
     RTS_HIP(c->d_block_counters.reserve(((size_t)c->n_cu * 64 + c->coop_grid_max) * 8));
     const size_t n_tiles = (size_t)((n + RTS_WTILE - 1) / RTS_WTILE), n_hist = (size_t)((W3 + RTS_WTILE - 1) / RTS_WTILE);
-    RTS_HIP(c->d_tile_ctr.reserve(2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE)); RTS_HIP(c->d_tile_cost.reserve(n_tiles)); RTS_HIP(c->d_tile_key.reserve(n_tiles)); RTS_HIP(c->d_tile_key_sorted.reserve(n_tiles));
+    RTS_HIP(c->d_tile_ctr.reserve(2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE + 4)); RTS_HIP(c->d_tile_cost.reserve(n_tiles)); RTS_HIP(c->d_tile_key.reserve(n_tiles)); RTS_HIP(c->d_tile_key_sorted.reserve(n_tiles));
     RTS_HIP(c->d_tile_id.reserve(n_tiles)); RTS_HIP(c->d_tile_order.reserve(n_tiles));
     if (c->tile_hist_n != (uint32_t)n_hist) {
         RTS_HIP(c->d_tile_hist.reserve(n_hist)); RTS_HIP(hipMemsetAsync(c->d_tile_hist.p, 0, sizeof(uint32_t) * n_hist, c->stream));
@@ -589,6 +591,9 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     if ((uint64_t)n * chains > 0xfffffff0ULL) { rts_set_error("rts_trace_pulse: rays x chains exceeds 2^32"); return RTS_ERR_UNSUPPORTED; }
     a.total_threads = grid * RTS_BLOCK;
     a.coop_seg_cost = c->coop_seg_cost; a.coop_min_cost = c->coop_seg_cost ? std::min<uint32_t>(c->coop_floor, 1875u) : 0u;      // (nothing shorter than 50 us is looked at; RTS_COOP_SEG=0: every tile is flagged)
+    if (c->coop_seg_cost && c->last_units_per_segment > 0.0)
+        a.coop_seg_cost = (uint32_t)std::min(4.0e9, std::max((double)c->coop_seg_cost, c->coop_seg_ratio * c->last_units_per_segment));
+    else if (c->coop_seg_cost) a.coop_min_cost = 0xffffffffu;     // first launch of the handle: no yardstick yet, and its tiles run cold and in index order -- nothing is flagged
     const uint32_t coop_threads = c->coop_frac > 0.0 ? c->coop_grid_max * RTS_BLOCK : 0u;      // the cooperative kernel's rows of the per-thread slabs
     a.slab_threads = a.total_threads + coop_threads;
     RTS_HIP(c->d_recv.reserve((size_t)n * chains + 1)); RTS_HIP(c->d_counters.reserve(16));
@@ -613,7 +618,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
         const uint64_t sig[4] = {n, first, ((uint64_t)il_parts << 32) | il_tile, il_part};
         const bool aligned = first % RTS_WTILE == 0 && (il_parts <= 1 || il_tile % RTS_WTILE == 0);
         const uint32_t n_hist = (uint32_t)((total + RTS_WTILE - 1) / RTS_WTILE);
-        RTS_HIP(c->d_tile_ctr.reserve(2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE)); RTS_HIP(hipMemsetAsync(c->d_tile_ctr.p, 0, sizeof(uint32_t) * 2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE, st));
+        RTS_HIP(c->d_tile_ctr.reserve(2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE + 4)); RTS_HIP(hipMemsetAsync(c->d_tile_ctr.p, 0, sizeof(uint32_t) * (2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE + 4), st));      // draw counters of both kernels + the order's head words
         a.tile_ctr = c->d_tile_ctr.p;
         if (lpt && aligned && n_tiles > grid * (RTS_BLOCK / RTS_WTILE)) {
             if (c->tile_hist_n != n_hist) {
@@ -622,7 +627,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
             }
             if (c->tile_cost_pending || c->tile_hist_any) {
                 int rc = rts_tile_order_build(c, c->tile_cost_sig, c->tile_cost_pending, sig, n_tiles, grid * (RTS_BLOCK / RTS_WTILE)); if (rc != RTS_OK) return rc;
-                a.tile_order = c->d_tile_order.p; a.tile_head = c->coop_frac > 0.0 ? c->d_tile_head.p : nullptr; c->tile_hist_any = true;
+                a.tile_order = c->d_tile_order.p; a.tile_head = c->coop_frac > 0.0 ? c->d_tile_ctr.p + 2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE + 2 : nullptr; a.tile_head_all = a.tile_head; c->tile_hist_any = true;
             }
             RTS_HIP(c->d_tile_cost.reserve(n_tiles));
             RTS_HIP(hipMemsetAsync(c->d_tile_cost.p, 0, sizeof(uint32_t) * n_tiles, st));
@@ -642,13 +647,12 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     RTS_HIP(hipEventRecord(c->ev[2], c->tstream));
     // the cooperative kernel (tiles at the head of the cost order, one launch index per wave): its grid follows the head count
     // of the handle's previous order build (the count of THIS build is on the device; a grid too small or too large only costs
-    // balance, every unit is drawn from a queue) -- read synchronously the first time
+    // balance, every unit is drawn from a queue); it came home with that launch's counters
     // Whether there is a cooperative kernel at all is decided HERE, from that earlier count (both kernels must agree on
     // who traces the head of the order): no head last time -> none now, and the ordinary kernel traces every tile.
     unsigned coop_grid = 0;
     if (a.tile_head) {
-        if (!c->head_hint_valid) { RTS_HIP(hipStreamSynchronize(st)); c->head_hint_valid = true; }
-        const uint64_t units = 64ULL * c->pin->n_head;
+        const uint64_t units = 64ULL * c->n_head_hint;
         if (units == 0) a.tile_head = nullptr;
         else coop_grid = (unsigned)std::min<uint64_t>(c->coop_grid_max, std::max<uint64_t>(16, (units + 3) / 4));
         c->last_args = a;
@@ -682,7 +686,7 @@ extern "C" int rts_trace_pulse_end(RtsHandle c)
     unsigned long long* cnt = c->pin->cnt;
     RTS_HIP(hipStreamSynchronize(st));              // the one host sync of the launch: the received count sizes what follows
     if (cnt[6]) { rts_set_error("rts_trace_pulse: traversal stack overflow / malformed BVH guard tripped on %llu waves", cnt[6]); return RTS_ERR_HIP; }
-    c->n_recv = cnt[0];
+    c->n_recv = cnt[0]; c->n_head_hint = (uint32_t)cnt[7];
 
     // ---- order + expand the received rays (and the keep-all buffers); left in flight on the stream
     RTS_HIP(hipEventRecord(c->ev[4], st));
@@ -694,6 +698,12 @@ extern "C" int rts_trace_pulse_end(RtsHandle c)
     s.rays = n; s.segments = cnt[1]; s.shaded = cnt[2]; s.received = cnt[0]; s.node_visits = cnt[3]; s.tri_tests = cnt[4]; s.stack_overflows = (uint32_t)cnt[5];
     s.n_prims = c->scene->n_prims; s.n_nodes = c->scene->n_nodes;
     c->pre_dense = 2 * s.shaded > (uint64_t)n;                      // next launch of this handle: pre-filter only if most launch indices hit nothing
+    {   // mean cost of a traced segment in this launch, in the units of the tile cost records (shader clocks >> 6 of one wave):
+        // kernel time x resident waves / segments -- the yardstick of the LONG WALKS flag of the next launch (rts_trace.hip)
+        float ms = 0.0f;
+        if (s.segments > 0 && hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess && ms > 0.0f)
+            c->last_units_per_segment = (double)ms * 1.0e-3 * (2.4e9 / 64.0) * (double)(c->last_args.total_threads / RTS_WTILE) / (double)s.segments;
+    }
     s.ms_scene = s.ms_trace = s.ms_compact = s.ms_aggregate = 0;
     c->stats_pending = true; c->agg_timed = false; c->fin_timed = false;
     return RTS_OK;

@@ -162,6 +162,7 @@ struct RtsTraceArgs {
     uint32_t* tile_cost;            // [wave tiles] out: duration of the tile (shader clocks >> 6, + 1)
     uint32_t* tile_ctr;             // [RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE] draw counters (element s * STRIDE), zero at launch
     const uint32_t* tile_head;      // [1] number of tiles at the head of tile_order that are traced as 64 cooperative units (null: none)
+    const uint32_t* tile_head_all;  // the same word whether or not this launch has a cooperative kernel (read back with the counters)
     uint32_t coop_min_cost, coop_seg_cost;   // a tile is flagged LONG WALKS (bit 31 of its cost record) if it took >= coop_min_cost units and >= coop_seg_cost units per traced segment
     unsigned long long* timeline;   // debug (RTS_TIMELINE, counting build): [grid][2] block start/end ticks, then [tiles] tile durations (100 MHz)
     uint32_t pre_filter;            // 1: primary rays go through the f32 pre-filter (needs the mask when there is geometry)
@@ -182,7 +183,6 @@ struct RtsMeshHost {
 #define RTS_PIN_GROUPS 4096
 struct RtsPinned {
     RtsLaunchConsts lc;
-    uint32_t n_head, n_head_pad;    // rts_tile_order_build's last count of cooperative tiles (sizes the next cooperative grid)
     unsigned long long cnt[16];
     uint32_t G, pad;
     RtsTargetMotion motion[256];
@@ -241,7 +241,7 @@ struct RtsContext {
     hipStream_t tstream = nullptr;      // trace kernels (the link group's, see RtsGate)
     hipStream_t cstream = nullptr; hipEvent_t ev_coop[2];      // the cooperative trace kernel of a launch runs beside the ordinary one; stream created on first use (rts_trace.hip)
     uint32_t coop_grid_max = 1024;      // most blocks of the cooperative kernel (RTS_COOP_GRID)
-    bool head_hint_valid = false;       // pin->n_head holds the count of an earlier order build
+    uint32_t n_head_hint = 0;           // head count of the handle's previous order build (came home with that launch's counters)
     hipEvent_t ev[9];
     // scene: the shared static part, and this handle's placement of it
     RtsScene* scene = nullptr;          // never null after rts_create
@@ -258,9 +258,12 @@ struct RtsContext {
     // per pulse
     uint64_t ray_first = 0; uint32_t n_rays = 0;
     DevBuf<RtsEndRecord> d_recv, d_all; DevBuf<unsigned long long> d_counters, d_block_counters, d_timeline;
-    DevBuf<uint32_t> d_tile_cost, d_tile_key, d_tile_key_sorted, d_tile_id, d_tile_order, d_tile_hist, d_tile_ctr, d_tile_head;
+    DevBuf<uint32_t> d_tile_cost, d_tile_key, d_tile_key_sorted, d_tile_id, d_tile_order, d_tile_hist, d_tile_ctr;
     uint32_t coop_floor = 7500;         // ... more than this many cost units (shader clocks >> 6; 7 500 = 0.2 ms of one wave) (RTS_COOP_FLOOR)
-    uint32_t coop_seg_cost = 300;       // ... and at least this many cost units PER TRACED SEGMENT (300 = 8 us: ~500 walk steps per segment with every lane busy) (RTS_COOP_SEG)
+    uint32_t coop_seg_cost = 300;       // ... and at least this many cost units PER TRACED SEGMENT (300 = 8 us: ~500 walk steps per segment with every lane busy) (RTS_COOP_SEG) --
+    double coop_seg_ratio = 30.0;       // ... or, once the handle has traced a pulse, this many times the LAUNCH's mean cost per segment (kernel time x resident waves / segments),
+                                        // whichever is larger: tile durations stretch when other pulses share the GPU, and so does the mean (RTS_COOP_SEG_RATIO)
+    double last_units_per_segment = 0;  // that mean, of the handle's previous launch (0: none yet)
     double coop_frac = 0.5;            // a tile costing more than this fraction of the launch's balanced time is traced as cooperative units (RTS_COOP_FRAC; 0: never)
     bool tile_cost_pending = false, tile_hist_any = false; uint64_t tile_cost_sig[4] = {0, 0, 0, 0}; uint32_t tile_hist_n = 0;   // per-global-tile cost history (rts_post.hip)
     DevBuf<float> d_dir_hist; DevBuf<uint32_t> d_pmask; bool use_pmask = true, pre_dense = false;
@@ -292,6 +295,7 @@ int rts_scene_place(RtsContext* c);
 int rts_primary_mask_build(RtsContext* c, const RtsLaunchConsts& lc);
 int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_valid, const uint64_t* cur_sig, uint32_t n_tiles_cur, uint32_t resident_waves);
 int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a, bool count_traversal, unsigned coop_grid);
+void rts_trace_preload();
 int rts_post_order_and_expand(RtsContext* c);
 int rts_post_expand_all(RtsContext* c);
 int rts_cube_accumulate_device(RtsContext* c, uint32_t pulse_index, double cspeed, double carrier);

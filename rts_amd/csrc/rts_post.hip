@@ -123,56 +123,56 @@ __device__ __forceinline__ uint32_t tile_global(const RtsTileShape& s, uint32_t 
     return (uint32_t)((s.first + (t * s.il_parts + s.il_part) * s.il_tile + r) / RTS_WTILE);
 }
 
+// Head of the cost order (cooperative units, rts_trace.hip): the tiles flagged LONG WALKS (bit 31 of the cost record) whose
+// estimated cost exceeds `frac` of the launch's balanced time -- sum of the tile costs / resident waves -- and a floor.  The
+// sum is formed while the previous launch's costs are merged into the history, the count while the sort keys are written:
+// no kernel, no readback of its own (a single-block reduction + a 4-byte device-to-host copy per pulse on the handle's
+// stream cost the three-pulse pipeline 7 %: 0.68 -> 0.73 ms per pulse).  head[0..1] = sum (u64), head[2] = count; zeroed with
+// the draw counters they share a buffer with.
+struct RtsHeadRule { double frac; uint32_t floor_cost, resident_waves; };
+
 // fold the costs measured by the previous launch into the history
-__global__ void k_tile_merge(const uint32_t* __restrict__ cost, RtsTileShape prev, uint32_t* __restrict__ hist, uint32_t n_hist)
+__global__ void k_tile_merge(const uint32_t* __restrict__ cost, RtsTileShape prev, uint32_t* __restrict__ hist, uint32_t n_hist, unsigned long long* __restrict__ head_sum)
 {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= prev.n_tiles) return;
-    const uint32_t v = cost[j], g = tile_global(prev, j);
-    if (v && g < n_hist) hist[g] = v;
+    unsigned long long v64 = 0;
+    if (j < prev.n_tiles) {
+        const uint32_t v = cost[j], g = tile_global(prev, j);
+        if (v && g < n_hist) hist[g] = v;
+        v64 = v & 0x7fffffffu;
+    }
+    for (int o = 32; o > 0; o >>= 1) v64 += __shfl_down(v64, o);
+    if ((threadIdx.x & 63) == 0 && v64 && head_sum) atomicAdd(head_sum, v64);
 }
 
-// sort key of local tile j of the coming launch: ~(estimated cost); a tile never traced yet takes the largest cost known
-// within 16 global tiles of it (expensive regions are contiguous in launch-index space)
-__global__ void k_tile_keys(const uint32_t* __restrict__ hist, uint32_t n_hist, RtsTileShape cur, uint32_t* __restrict__ key, uint32_t* __restrict__ id)
+// sort key of local tile j of the coming launch: ~(estimated cost record); a tile never traced yet takes the largest record
+// known within 16 global tiles of it (expensive regions are contiguous in launch-index space).  Flagged records sort first
+// (their bit 31), by descending cost: the flagged tiles above the threshold are a prefix of the order.
+__global__ void k_tile_keys(const uint32_t* __restrict__ hist, uint32_t n_hist, RtsTileShape cur, uint32_t* __restrict__ key, uint32_t* __restrict__ id,
+                            const unsigned long long* __restrict__ head_sum, uint32_t* __restrict__ head_count, RtsHeadRule rule)
 {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= cur.n_tiles) return;
-    const uint32_t g = tile_global(cur, j);
-    uint32_t est = g < n_hist ? hist[g] : 0u;
-    if (est == 0) {
-        for (uint32_t d = 1; d <= 16; d++) {
-            if (g >= d && g - d < n_hist) est = max(est, hist[g - d]);
-            if (g + d < n_hist) est = max(est, hist[g + d]);
+    uint32_t is_head = 0;
+    if (j < cur.n_tiles) {
+        const uint32_t g = tile_global(cur, j);
+        uint32_t est = g < n_hist ? hist[g] : 0u;
+        if (est == 0) {
+            for (uint32_t d = 1; d <= 16; d++) {
+                if (g >= d && g - d < n_hist) est = max(est, hist[g - d]);
+                if (g + d < n_hist) est = max(est, hist[g + d]);
+            }
+        }
+        key[j] = ~est; id[j] = j;
+        if (head_count && rule.frac > 0.0 && (est >> 31)) {
+            double thr = rule.frac * (double)head_sum[0] / (double)(rule.resident_waves ? rule.resident_waves : 1u);
+            if (thr < (double)rule.floor_cost) thr = (double)rule.floor_cost;
+            is_head = ((double)(est & 0x7fffffffu) > thr) ? 1u : 0u;
         }
     }
-    key[j] = ~est; id[j] = j;
-}
-
-// How many tiles at the head of the (descending) cost order are worth tracing as cooperative units: those flagged LONG WALKS
-// (rts_trace.hip) whose estimated cost exceeds `frac` of the launch's balanced time (sum of the costs / resident waves) and an
-// absolute floor.  One block;
-// key_sorted = ~cost, ascending.
-__global__ void __launch_bounds__(1024) k_tile_head(const uint32_t* __restrict__ key_sorted, uint32_t n, uint32_t resident_waves, double frac, uint32_t floor_cost, uint32_t max_head,
-                                                    uint32_t* __restrict__ out)
-{
-    __shared__ unsigned long long s_sum[1024]; __shared__ uint32_t s_cnt[1024]; __shared__ uint32_t s_thr;
-    unsigned long long acc = 0;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) acc += (uint32_t)~key_sorted[i] & 0x7fffffffu;      // (bit 31: the LONG WALKS flag of the cost record)
-    s_sum[threadIdx.x] = acc; __syncthreads();
-    for (uint32_t o = blockDim.x / 2; o > 0; o >>= 1) { if (threadIdx.x < o) s_sum[threadIdx.x] += s_sum[threadIdx.x + o]; __syncthreads(); }
-    if (threadIdx.x == 0) {
-        const double balanced = (double)s_sum[0] / (double)(resident_waves ? resident_waves : 1u);
-        double thr = frac * balanced; if (thr < (double)floor_cost) thr = (double)floor_cost; if (thr > 2.0e9) thr = 2.0e9;
-        s_thr = (uint32_t)thr;
+    if (head_count) {                                                          // (uniform)
+        const unsigned long long m = __ballot(is_head != 0);
+        if ((threadIdx.x & 63) == 0 && m) atomicAdd(head_count, (uint32_t)__popcll(m));
     }
-    __syncthreads();
-    const uint32_t thr = s_thr; uint32_t cnt = 0;
-    // flagged records sort first (their bit 31), by descending cost: the flagged tiles above the threshold are a prefix of the order
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { const uint32_t v = ~key_sorted[i]; cnt += ((v >> 31) && (v & 0x7fffffffu) > thr) ? 1u : 0u; }
-    s_cnt[threadIdx.x] = cnt; __syncthreads();
-    for (uint32_t o = blockDim.x / 2; o > 0; o >>= 1) { if (threadIdx.x < o) s_cnt[threadIdx.x] += s_cnt[threadIdx.x + o]; __syncthreads(); }
-    if (threadIdx.x == 0) out[0] = frac > 0.0 ? min(s_cnt[0], max_head) : 0u;
 }
 
 // prev_valid: d_tile_cost holds the costs of a launch of shape prev_shape that have not been merged yet
@@ -182,18 +182,16 @@ int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_vali
     const uint32_t n_hist = c->tile_hist_n;
     auto shape = [](const uint64_t* sig) { RtsTileShape s; s.first = sig[1]; s.il_tile = (uint32_t)(sig[2] & 0xffffffffu); s.il_parts = (uint32_t)(sig[2] >> 32); s.il_part = (uint32_t)sig[3];
                                           s.n_tiles = (uint32_t)((sig[0] + RTS_WTILE - 1) / RTS_WTILE); return s; };
-    if (prev_valid) { const RtsTileShape p = shape(prev_sig); if (p.n_tiles) k_tile_merge<<<blocks_for(p.n_tiles, 256), 256, 0, st>>>(c->d_tile_cost.p, p, c->d_tile_hist.p, n_hist); }
+    uint32_t* head = c->coop_frac > 0.0 ? c->d_tile_ctr.p + 2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE : nullptr;      // [sum lo, sum hi, count, pad]: zeroed with the draw counters
+    if (prev_valid) { const RtsTileShape p = shape(prev_sig); if (p.n_tiles) k_tile_merge<<<blocks_for(p.n_tiles, 256), 256, 0, st>>>(c->d_tile_cost.p, p, c->d_tile_hist.p, n_hist, reinterpret_cast<unsigned long long*>(head)); }
     RTS_HIP(c->d_tile_key.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_key_sorted.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_id.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_order.reserve(n_tiles_cur));
     const RtsTileShape cur = shape(cur_sig);
-    k_tile_keys<<<blocks_for(n_tiles_cur, 256), 256, 0, st>>>(c->d_tile_hist.p, n_hist, cur, c->d_tile_key.p, c->d_tile_id.p);
+    const RtsHeadRule rule = {c->coop_frac, c->coop_floor, resident_waves};
+    k_tile_keys<<<blocks_for(n_tiles_cur, 256), 256, 0, st>>>(c->d_tile_hist.p, n_hist, cur, c->d_tile_key.p, c->d_tile_id.p, reinterpret_cast<const unsigned long long*>(head), head ? head + 2 : nullptr, rule);
     size_t tmp = 0;
     RTS_HIP(rocprim::radix_sort_pairs(nullptr, tmp, c->d_tile_key.p, c->d_tile_key_sorted.p, c->d_tile_id.p, c->d_tile_order.p, n_tiles_cur, 0, 32, st));
     RTS_HIP(c->d_sort_tmp.reserve(tmp));
     RTS_HIP(rocprim::radix_sort_pairs(c->d_sort_tmp.p, tmp, c->d_tile_key.p, c->d_tile_key_sorted.p, c->d_tile_id.p, c->d_tile_order.p, n_tiles_cur, 0, 32, st));
-    // cooperative head (rts_trace.hip): at most 16 384 tiles
-    RTS_HIP(c->d_tile_head.reserve(1));
-    k_tile_head<<<1, 1024, 0, st>>>(c->d_tile_key_sorted.p, n_tiles_cur, resident_waves, c->coop_frac, c->coop_floor, 16384u, c->d_tile_head.p);
-    RTS_HIP(hipMemcpyAsync(&c->pin->n_head, c->d_tile_head.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));      // read by the NEXT launch's set-up (or after a sync, the first time)
     return RTS_OK;
 }
 

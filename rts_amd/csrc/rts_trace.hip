@@ -665,7 +665,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR || COOP) ? 2 : 4) k_trace(con
     // fraction of the launch's balanced time) are traced as 64 units of ONE launch index each, all 64 lanes of a wave walking
     // that ray's hierarchy together (rts_trace_unit<.., COOP = true>) -- by the COOP kernel, whose unit v is
     // (tile_order[v / 64], ray v % 64); unit v of the ordinary kernel is tile_order[n_head + v].
-    const uint32_t n_head = (a.tile_head && a.tile_order) ? min(__builtin_amdgcn_readfirstlane(a.tile_head[0]), n_tiles) : 0u;
+    const uint32_t n_head = (a.tile_head && a.tile_order) ? min(min(__builtin_amdgcn_readfirstlane(a.tile_head[0]), n_tiles), 16384u) : 0u;
     const uint32_t n_units = COOP ? 64u * n_head : n_tiles - n_head;
     __shared__ int32_t s_exch[COOP ? RTS_BLOCK : 1];             // exchange rows of the cooperative walk (one 64-entry row per wave)
     const RtsUnitLds ul = {s_stack, s_exch, s_first, s_path, s_n, s_rx, s_rxp};
@@ -770,8 +770,9 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR || COOP) ? 2 : 4) k_trace(con
 }
 
 // counters[1..6] = sum over the blocks of a launch (single block; the launch has at most a few thousand blocks)
-__global__ void k_sum_counters(const unsigned long long* __restrict__ block_counters, unsigned int n_blocks, unsigned long long* __restrict__ counters)
+__global__ void k_sum_counters(const unsigned long long* __restrict__ block_counters, unsigned int n_blocks, unsigned long long* __restrict__ counters, const uint32_t* __restrict__ head_count)
 {
+    if (threadIdx.x == 7) counters[7] = head_count ? head_count[0] : 0u;     // the order's head count travels home with the counters (sizes the next cooperative grid)
     __shared__ unsigned long long s[256];
     const unsigned int k = threadIdx.x & 7u, lane = threadIdx.x >> 3;                   // 32 partial sums per counter
     unsigned long long v = 0;
@@ -821,7 +822,16 @@ int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a, bool count_traversal,
     }
     rts_trace_dispatch<false>(a, count_traversal, grid, st);
     if (coop_grid) RTS_HIP(hipStreamWaitEvent(st, c->ev_coop[1], 0));
-    k_sum_counters<<<1, 256, 0, st>>>(a.block_counters, grid + coop_grid, a.counters);
+    k_sum_counters<<<1, 256, 0, st>>>(a.block_counters, grid + coop_grid, a.counters, a.tile_head_all);
     RTS_HIP(hipGetLastError());
     return RTS_OK;
+}
+
+// rts_create: have the runtime load the two kernels a first pulse may need, so that the first launch of the cooperative
+// kernel -- in the middle of an interval -- does not pay for the upload of its code object
+void rts_trace_preload()
+{
+    hipFuncAttributes fa;
+    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_trace<false, false, false, false>));
+    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_trace<false, false, false, true>));
 }

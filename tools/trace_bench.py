@@ -50,6 +50,8 @@ rec = tr.received()
 h = hashlib.sha1(np.ascontiguousarray(rec["results"]["power"]).tobytes() + np.ascontiguousarray(rec["slots"]).tobytes() +
                  np.ascontiguousarray(rec["path"]).tobytes()).hexdigest()[:16]
 ms = np.array(ms)
+if os.environ.get("RTS_VERBOSE"):
+    print("trace ms per launch:", " ".join("%.3f" % x for x in ms[:, 1]))
 print("%s: segs %d recv %d | scene %.3f trace %.3f (min %.3f) compact %.3f ms | %.2f Gseg/s | sha %s" %
       (spec["name"], st["segments"], st["received"], ms[:, 0].mean(), ms[:, 1].mean(), ms[:, 1].min(), ms[:, 2].mean(),
        st["segments"] / ms[:, 1].min() / 1e6, h))
