@@ -53,10 +53,12 @@ typedef struct RtsParams {
 #define RTS_FLAG_KEEP_ALL_RAYS 1u /* also keep the full per-ray output buffers of the reference
                                      (dbuf_results / dbuf_targ_intersect / dbuf_rcs_angle for EVERY
                                      launch index) plus the per-segment hit trace -- parity/debug */
-#define RTS_FLAG_DEVICE_BUILD 4u  /* rts_set_scene builds the hierarchy ON THE DEVICE (LBVH: slab-split references, Morton codes,
-                                     radix sort, Karras hierarchy, bottom-up boxes, 4-wide collapse) instead of the host SAH
-                                     builder: set-up in milliseconds, traversal 15-40 % slower; same node format, same results (the f64 triangle
-                                     test alone decides hits).  The environment variable RTS_BUILDER=device|host overrides. */
+#define RTS_FLAG_DEVICE_BUILD 4u  /* (the default since round 3; kept for callers that set it) rts_set_scene builds the hierarchy ON THE
+                                   * DEVICE: slab-split references, top-down binned SAH level by level, 4-wide collapse, compaction --
+                                   * milliseconds for 10^5-10^6 triangles (the reference has OptiX rebuild its acceleration on the
+                                   * device every pulse, ray_tracer.cpp:1126-1130; here once per scene) */
+#define RTS_FLAG_HOST_BUILD 16u   /* build the hierarchy with the host SAH builder instead (rts_sah.cpp: seconds; a slightly better tree
+                                   * on meshes with fans of sliver triangles) */
 #define RTS_FLAG_NO_PREFILTER 8u   /* primary rays skip the conservative f32 pre-filter (direction mask over the placed triangles +
                                      widened receiver spheres) that lets rays which can meet nothing bypass the exact ray
                                      generation and the walk.  Results are identical either way (tested); the filter also switches

@@ -18,6 +18,7 @@ RTS_OK, RTS_ERR_INVALID, RTS_ERR_NO_DEVICE, RTS_ERR_HIP, RTS_ERR_UNSUPPORTED, RT
 RTS_FLAG_KEEP_ALL_RAYS = 1
 RTS_FLAG_COUNT_TRAVERSAL = 2
 RTS_FLAG_DEVICE_BUILD = 4
+RTS_FLAG_HOST_BUILD = 16
 RTS_FLAG_NO_PREFILTER = 8
 RTS_MAX_DEPTH = 16
 RTS_BASE_USE_ROWS = 0xffffffffffffffff

@@ -89,10 +89,11 @@ def device_count():
 class Tracer:
     """One RtsHandle: scene + receivers + per-pulse launch on one GPU."""
 
-    def __init__(self, width, max_refl, max_refr=0, smooth=True, device=0, keep_all=False, count_traversal=False, device_build=False, pre_filter=True):
+    def __init__(self, width, max_refl, max_refr=0, smooth=True, device=0, keep_all=False, count_traversal=False, device_build=None, pre_filter=True):
         p = L.RtsParams(width, max_refl, max_refr, 1 if smooth else 0, device,
                         (L.RTS_FLAG_KEEP_ALL_RAYS if keep_all else 0) | (L.RTS_FLAG_COUNT_TRAVERSAL if count_traversal else 0) |
-                        (L.RTS_FLAG_DEVICE_BUILD if device_build else 0) | (0 if pre_filter else L.RTS_FLAG_NO_PREFILTER))
+                        (0 if device_build is None else (L.RTS_FLAG_DEVICE_BUILD if device_build else L.RTS_FLAG_HOST_BUILD)) |      # None: the library's default (device)
+                         (0 if pre_filter else L.RTS_FLAG_NO_PREFILTER))
         self.h = C.c_void_p()
         check(L.lib().rts_create(C.byref(p), C.byref(self.h)))
         self.width = width; self.max_refl = max_refl; self.depth = max_refl + (2 if max_refr else 0)

@@ -228,15 +228,18 @@ extern "C" int rts_set_scene(RtsHandle c, const RtsMesh* meshes, uint32_t n_targ
     ns->meshes = mh; ns->n_prims = (uint32_t)nt; ns->n_verts = (uint32_t)nv; ns->n_normals = (uint32_t)nn;
 
     // ---- static target-space hierarchy, one per mesh; leaf slots name GLOBAL primitive ids.  Two builders, same node format:
-    //   host   (default) binned SAH with split references, one host thread per mesh (rts_sah.cpp): best traversal cost
-    //   device RTS_BUILDER=device / RtsParams.flags & RTS_FLAG_DEVICE_BUILD: LBVH built on the GPU (rts_lbvh.hip): set-up in milliseconds
+    //   device (default) top-down binned SAH over split references, built on the GPU level by level (rts_lbvh.hip): milliseconds;
+    //          RTS_DEVICE_TREE=lbvh: the Morton / Karras tree of round 2 instead
+    //   host   RTS_BUILDER=host / RtsParams.flags & RTS_FLAG_HOST_BUILD: the same algorithm with a greedier reference splitter on
+    //          one host thread per mesh (rts_sah.cpp): ~1 s per 100 k triangles; traces a lone C3 pulse 7 % faster (its slowest
+    //          tile runs through the pole fans of the synthetic airframe), the pipelined benchmark, the dense control, spheres
+    //          and C4 within 1-4 %
     const auto t_build0 = std::chrono::steady_clock::now();
-    bool device_build = (c->params.flags & RTS_FLAG_DEVICE_BUILD) != 0;
-    { const char* e = getenv("RTS_BUILDER"); if (e) device_build = (strcmp(e, "device") == 0); }
-    // extra references for triangles whose boxes are mostly empty (rts_sah.cpp, rts_lbvh.hip).  The host builder spends its budget
-    // where a split saves box area (2 measured best); the device builder's rule looks at box size alone and also cuts well-shaped
-    // triangles: 1 is the better compromise there (C3 0.92 ms against 0.87 at 2, a uniformly tessellated sphere 0.76 against 0.85)
-    double split_budget = device_build ? 1.0 : 2.0;
+    bool device_build = (c->params.flags & RTS_FLAG_HOST_BUILD) == 0;
+    { const char* e = getenv("RTS_BUILDER"); if (e) device_build = (strcmp(e, "host") != 0); }
+    // extra references for triangles whose boxes are mostly empty (rts_sah.cpp, rts_lbvh.hip): an average triangle gets about
+    // 1 + budget references where cutting pays (2 measured best for both builders)
+    double split_budget = 2.0;
     { const char* e = getenv("RTS_SPLIT_BUDGET"); if (e) { const double v = atof(e); if (v >= 0 && v <= 8) split_budget = v; } }
     if (device_build) {
         int rc = rts_lbvh_build_device(c, ns, vidx, mh, split_budget); if (rc != RTS_OK) return rc;

@@ -52,6 +52,31 @@ __device__ __forceinline__ void tri_extent(const TriV& t, double lo[3], double h
 {
     for (int c = 0; c < 3; c++) { lo[c] = fmin(fmin(t.v[0][c], t.v[1][c]), t.v[2][c]); hi[c] = fmax(fmax(t.v[0][c], t.v[1][c]), t.v[2][c]); }
 }
+// box of the part of triangle t between the planes x[ax] = s0 and x[ax] = s1 (its vertices inside the slab and the points
+// where its edges cross the two planes; f64, the pad of the reference boxes dwarfs the rounding), never outside [tlo, thi]
+__device__ __forceinline__ void tri_slab_box(const TriV& t, const double tlo[3], const double thi[3], int ax, double s0, double s1, double lo[3], double hi[3])
+{
+    for (int c = 0; c < 3; c++) { lo[c] = tlo[c]; hi[c] = thi[c]; }
+    double clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int a = 0; a < 3; a++) {
+        const double* p = t.v[a]; const double* q = t.v[(a + 1) % 3];
+        if (p[ax] >= s0 && p[ax] <= s1) for (int c = 0; c < 3; c++) { clo[c] = fmin(clo[c], p[c]); chi[c] = fmax(chi[c], p[c]); }
+        for (int w = 0; w < 2; w++) {
+            const double sp = w ? s1 : s0;
+            if ((p[ax] < sp && q[ax] > sp) || (p[ax] > sp && q[ax] < sp)) {
+                const double u = (sp - p[ax]) / (q[ax] - p[ax]);
+                for (int c = 0; c < 3; c++) { const double x = c == ax ? sp : p[c] + u * (q[c] - p[c]); clo[c] = fmin(clo[c], x); chi[c] = fmax(chi[c], x); }
+            }
+        }
+    }
+    if (clo[0] <= chi[0] && clo[1] <= chi[1] && clo[2] <= chi[2]) {
+        for (int c = 0; c < 3; c++) { lo[c] = fmax(clo[c], tlo[c]); hi[c] = fmin(chi[c], thi[c]); }
+    }
+    lo[ax] = fmax(lo[ax], s0); hi[ax] = fmin(hi[ax], s1);          // (an empty clip -- it cannot happen inside the extent -- keeps the slab of the whole box)
+    if (!(lo[ax] <= hi[ax])) { lo[ax] = s0; hi[ax] = s1; }
+}
+__device__ __forceinline__ double box_area3(const double lo[3], const double hi[3]) { const double ex = hi[0]-lo[0], ey = hi[1]-lo[1], ez = hi[2]-lo[2]; return 2.0 * (ex*ey + ey*ez + ex*ez); }
+
 // number of references of a triangle: slabs across the longest axis of its box, more for boxes that are large against `a_thr`
 __device__ __forceinline__ uint32_t ref_count(const double lo[3], const double hi[3], double a_thr)
 {
@@ -75,14 +100,30 @@ __global__ void k_tri_area(const uint32_t* __restrict__ tri_vidx, const double* 
     if ((threadIdx.x & 63) == 0 && c > 0.0) { atomicAdd(&acc[0], a); atomicAdd(&acc[1], c); }
 }
 // pass 1: references per triangle (an invalid triangle keeps ONE, invalid, reference: it sorts last and gets no leaf)
-__global__ void k_ref_count(const uint32_t* __restrict__ tri_vidx, const double* __restrict__ verts, uint32_t n, double a_thr, uint32_t* __restrict__ cnt, uint32_t* __restrict__ n_valid_refs)
+__global__ void k_ref_count(const uint32_t* __restrict__ tri_vidx, const double* __restrict__ verts, uint32_t n, double a_thr, int gain_rule, const uint32_t* __restrict__ boost, uint32_t* __restrict__ cnt, uint32_t* __restrict__ n_valid_refs)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t k = 0, kv = 0;
     if (i < n) {
         const TriV t = load_tri(tri_vidx, verts, i);
         k = 1;
-        if (t.finite) { double lo[3], hi[3]; tri_extent(t, lo, hi); k = ref_count(lo, hi, a_thr); kv = k; }
+        if (t.finite) {
+            double lo[3], hi[3]; tri_extent(t, lo, hi); k = ref_count(lo, hi, a_thr);
+            if (k > 1 && gain_rule) {
+                // ... but only where cutting pays (the rule of the host builder's first round, rts_sah.cpp): halving the box across
+                // its longest axis must save a quarter of its surface -- long, thin, diagonal triangles; the near-equilateral
+                // triangles of a uniformly tessellated surface keep ONE reference however large they are against the mean
+                const double ex = hi[0]-lo[0], ey = hi[1]-lo[1], ez = hi[2]-lo[2];
+                const int ax = (ex >= ey && ex >= ez) ? 0 : (ey >= ez ? 1 : 2);
+                const double mid = 0.5 * lo[ax] + 0.5 * hi[ax];
+                double l0[3], h0[3], l1[3], h1[3];
+                tri_slab_box(t, lo, hi, ax, lo[ax], mid, l0, h0); tri_slab_box(t, lo, hi, ax, mid, hi[ax], l1, h1);
+                const double a = box_area3(lo, hi), gain = a - (box_area3(l0, h0) + box_area3(l1, h1));
+                if (!(gain > 0.25 * a)) k = 1;
+            }
+            if (boost && boost[i]) k = min(2u * k, 8u);                  // a crowded spot of the provisional tree (k_crowd)
+            kv = k;
+        }
         cnt[i] = k;
     }
     for (int off = 32; off > 0; off >>= 1) kv += __shfl_down(kv, off);
@@ -114,23 +155,7 @@ __global__ void k_ref_boxes(const uint32_t* __restrict__ tri_vidx, const double*
                 if (k > 1) {
                     const double e = thi[ax] - tlo[ax];
                     const double s0 = j == 0 ? tlo[ax] : tlo[ax] + e * ((double)j / (double)k), s1 = j + 1 == k ? thi[ax] : tlo[ax] + e * ((double)(j + 1) / (double)k);
-                    double clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
-                    for (int a = 0; a < 3; a++) {
-                        const double* p = t.v[a]; const double* q = t.v[(a + 1) % 3];
-                        if (p[ax] >= s0 && p[ax] <= s1) for (int c = 0; c < 3; c++) { clo[c] = fmin(clo[c], p[c]); chi[c] = fmax(chi[c], p[c]); }
-                        for (int w = 0; w < 2; w++) {
-                            const double sp = w ? s1 : s0;
-                            if ((p[ax] < sp && q[ax] > sp) || (p[ax] > sp && q[ax] < sp)) {
-                                const double u = (sp - p[ax]) / (q[ax] - p[ax]);
-                                for (int c = 0; c < 3; c++) { const double x = c == ax ? sp : p[c] + u * (q[c] - p[c]); clo[c] = fmin(clo[c], x); chi[c] = fmax(chi[c], x); }
-                            }
-                        }
-                    }
-                    if (clo[0] <= chi[0] && clo[1] <= chi[1] && clo[2] <= chi[2]) {
-                        for (int c = 0; c < 3; c++) { lo[c] = fmax(clo[c], tlo[c]); hi[c] = fmin(chi[c], thi[c]); }
-                    }
-                    lo[ax] = fmax(lo[ax], s0); hi[ax] = fmin(hi[ax], s1);          // (an empty clip -- it cannot happen inside the extent -- keeps the slab of the whole box)
-                    if (!(lo[ax] <= hi[ax])) { lo[ax] = s0; hi[ax] = s1; }
+                    tri_slab_box(t, tlo, thi, ax, s0, s1, lo, hi);
                 }
                 const double s = fmax(fmax(fmax(fabs(lo[0]), fabs(hi[0])), fmax(fabs(lo[1]), fabs(hi[1]))), fmax(fabs(lo[2]), fabs(hi[2])));
                 const double pad = s * 2.384185791015625e-07 + 1e-30;
@@ -358,6 +383,244 @@ __global__ void k_single_leaf4(const float* __restrict__ prim_box, const uint32_
 
 inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 
+// --------------------------------------------------------------------------- top-down binned SAH over the references (device)
+// The quality builder (default of the device path; RTS_DEVICE_TREE=lbvh selects the Morton / Karras tree above): the same
+// algorithm as the host builder of rts_sah.cpp -- per node the centroid bounds, 16 bins on each of the three axes holding the
+// union of the reference boxes and their count, the split of least  A_left n_left + A_right n_right, one reference per leaf --
+// run level by level over ALL open nodes at once:
+//   k_sah_bounds : centroid bounds (and the box) of every open node            per position, wave-aggregated atomics
+//   k_sah_bins   : the 3 x 16 bins of every open node                          per position; a block whose positions all belong to
+//                                                                              one node bins into LDS and flushes once
+//   k_sah_split  : best split, child boxes, child links, the next level's open nodes       per open node
+//   k_sah_scatter: partition of the node's positions (children are contiguous ranges)       per position
+// A node's references occupy a contiguous range of the position array; a leaf is ~position, so the final position order IS
+// the leaf order.  Output: the Node2 array the collapse to 4-wide records reads (root = node 0), child boxes exact (unions
+// of bins hold every reference box).  A node whose references all have the same centroid is cut in the middle and both
+// children get the node's box (conservative; such references are duplicates).  ~20-30 levels for 10^5-10^6 references.
+#define SAH_BINS 16
+struct SahWork { int32_t begin, end, node, pad; };
+struct SahSplit { int32_t axis, bin, n_left, wl, wr, pad0, pad1, pad2; float lo, scale; };      // axis < 0: cut in the middle (wl / wr: child work index or -1)
+#define SAH_BIN_WORDS (3 * SAH_BINS * 7)
+
+__device__ __forceinline__ void ref_centroid(const float* __restrict__ b, float c[3]) { c[0] = (b[0] + b[3]) * 0.5f; c[1] = (b[1] + b[4]) * 0.5f; c[2] = (b[2] + b[5]) * 0.5f; }
+
+__global__ void k_sah_init_bins(uint32_t* __restrict__ bins, uint32_t* __restrict__ cb, uint32_t n_work)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (size_t)n_work * SAH_BIN_WORDS) { const uint32_t k = (uint32_t)(i % 7); bins[i] = k < 3 ? 0xffffffffu : 0u; }      // [lo x3 (ordered, min) | hi x3 (max) | count]
+    if (i < (size_t)n_work * 12) { const uint32_t k = (uint32_t)(i % 12); cb[i] = (k % 6) < 3 ? 0xffffffffu : 0u; }               // [centroid lo3 hi3 | box lo3 hi3]
+}
+
+__global__ void __launch_bounds__(256) k_sah_bounds(const float* __restrict__ ref_box, const uint32_t* __restrict__ idx, const int32_t* __restrict__ work_of, uint32_t* __restrict__ cb, uint32_t n)
+{
+    __shared__ uint32_t s_cb[12];
+    __shared__ int s_first, s_last;
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int w = p < n ? work_of[p] : -1;
+    if (threadIdx.x == 0) { s_first = work_of[blockIdx.x * blockDim.x]; const uint32_t lastp = min((blockIdx.x + 1) * blockDim.x, n) - 1; s_last = work_of[lastp]; }
+    if (threadIdx.x < 12) s_cb[threadIdx.x] = (threadIdx.x % 6) < 3 ? 0xffffffffu : 0u;
+    __syncthreads();
+    const bool one_node = s_first >= 0 && s_first == s_last;                     // the whole block is one node's (top levels): LDS first, twelve atomics per block
+    if (w >= 0) {
+        const float* b = ref_box + 6 * (size_t)idx[p];
+        float c[3]; ref_centroid(b, c);
+        uint32_t* o = one_node ? s_cb : cb + 12 * (size_t)w;
+        for (int k = 0; k < 3; k++) { atomicMin(o + k, f2ord(c[k])); atomicMax(o + 3 + k, f2ord(c[k])); atomicMin(o + 6 + k, f2ord(b[k])); atomicMax(o + 9 + k, f2ord(b[3 + k])); }
+    }
+    if (one_node) {
+        __syncthreads();
+        if (threadIdx.x < 12) { uint32_t* g = cb + 12 * (size_t)s_first + threadIdx.x; if ((threadIdx.x % 6) < 3) atomicMin(g, s_cb[threadIdx.x]); else atomicMax(g, s_cb[threadIdx.x]); }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_sah_bins(const float* __restrict__ ref_box, const uint32_t* __restrict__ idx, const int32_t* __restrict__ work_of, const uint32_t* __restrict__ cb,
+                                                  uint32_t* __restrict__ bins, uint32_t n)
+{
+    __shared__ uint32_t s_bins[SAH_BIN_WORDS];
+    __shared__ int s_first, s_last;
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int w = p < n ? work_of[p] : -1;
+    if (threadIdx.x == 0) { s_first = work_of[blockIdx.x * blockDim.x]; const uint32_t lastp = min((blockIdx.x + 1) * blockDim.x, n) - 1; s_last = work_of[lastp]; }
+    __syncthreads();
+    const bool one_node = s_first >= 0 && s_first == s_last;                     // (positions of a node are contiguous: first == last => the whole block)
+    if (one_node) { for (uint32_t k = threadIdx.x; k < SAH_BIN_WORDS; k += blockDim.x) s_bins[k] = (k % 7) < 3 ? 0xffffffffu : 0u; }
+    __syncthreads();
+    if (w >= 0) {
+        const float* b = ref_box + 6 * (size_t)idx[p];
+        float c[3]; ref_centroid(b, c);
+        const uint32_t* cw = cb + 12 * (size_t)w;
+        uint32_t* dst = one_node ? s_bins : bins + (size_t)w * SAH_BIN_WORDS;
+        for (int ax = 0; ax < 3; ax++) {
+            const float lo = ord2f(cw[ax]), hi = ord2f(cw[3 + ax]), ext = hi - lo;
+            if (!(ext > 0.0f)) continue;
+            int bi = (int)((c[ax] - lo) * ((float)SAH_BINS * 0.999999f / ext)); bi = bi < 0 ? 0 : (bi >= SAH_BINS ? SAH_BINS - 1 : bi);
+            uint32_t* o = dst + (ax * SAH_BINS + bi) * 7;
+            for (int k = 0; k < 3; k++) { atomicMin(o + k, f2ord(b[k])); atomicMax(o + 3 + k, f2ord(b[3 + k])); }
+            atomicAdd(o + 6, 1u);
+        }
+    }
+    if (one_node) {
+        __syncthreads();
+        uint32_t* g = bins + (size_t)s_first * SAH_BIN_WORDS;
+        for (uint32_t k = threadIdx.x; k < SAH_BIN_WORDS; k += blockDim.x) {
+            const uint32_t v = s_bins[k], kk = k % 7;
+            if (kk < 3) { if (v != 0xffffffffu) atomicMin(g + k, v); } else if (kk < 6) { if (v != 0u) atomicMax(g + k, v); } else if (v) atomicAdd(g + k, v);
+        }
+    }
+}
+
+__device__ __forceinline__ float sah_area(const float b[6]) { const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2]; return (dx < 0.0f || dy < 0.0f || dz < 0.0f) ? 0.0f : 2.0f * (dx*dy + dy*dz + dz*dx); }
+
+__global__ void k_sah_split(const SahWork* __restrict__ work, uint32_t n_work, const uint32_t* __restrict__ cb, const uint32_t* __restrict__ bins, SahSplit* __restrict__ split,
+                            Node2* __restrict__ nodes, SahWork* __restrict__ next, uint32_t* __restrict__ counters /* [0] next node id, [1] next work count */)
+{
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_work) return;
+    const SahWork wk = work[w];
+    const int n = wk.end - wk.begin;
+    const uint32_t* cw = cb + 12 * (size_t)w;
+    float best = __builtin_inff(); int best_axis = -1, best_bin = -1, best_nl = 0; float bl[6], br[6];
+    for (int ax = 0; ax < 3; ax++) {
+        const float lo = ord2f(cw[ax]), hi = ord2f(cw[3 + ax]);
+        if (!(hi - lo > 0.0f)) continue;
+        const uint32_t* B = bins + (size_t)w * SAH_BIN_WORDS + ax * SAH_BINS * 7;
+        float ra[SAH_BINS]; uint32_t rc[SAH_BINS];
+        float acc[6] = {3.0e38f, 3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f}; uint32_t c = 0;
+        for (int b = SAH_BINS - 1; b > 0; b--) {
+            const uint32_t* o = B + b * 7;
+            if (o[6]) { for (int k = 0; k < 3; k++) { acc[k] = fminf(acc[k], ord2f(o[k])); acc[3 + k] = fmaxf(acc[3 + k], ord2f(o[3 + k])); } c += o[6]; }
+            ra[b] = sah_area(acc); rc[b] = c;
+        }
+        for (int k = 0; k < 6; k++) acc[k] = k < 3 ? 3.0e38f : -3.0e38f;
+        c = 0;
+        for (int b = 0; b < SAH_BINS - 1; b++) {
+            const uint32_t* o = B + b * 7;
+            if (o[6]) { for (int k = 0; k < 3; k++) { acc[k] = fminf(acc[k], ord2f(o[k])); acc[3 + k] = fmaxf(acc[3 + k], ord2f(o[3 + k])); } c += o[6]; }
+            if (c == 0 || rc[b + 1] == 0) continue;
+            const float cost = sah_area(acc) * (float)c + ra[b + 1] * (float)rc[b + 1];
+            if (cost < best) { best = cost; best_axis = ax; best_bin = b; best_nl = (int)c; }
+        }
+    }
+    SahSplit sp; sp.axis = best_axis; sp.bin = best_bin; sp.pad0 = sp.pad1 = sp.pad2 = 0; sp.lo = 0.0f; sp.scale = 0.0f;
+    if (best_axis >= 0) {
+        const float lo = ord2f(cw[best_axis]), hi = ord2f(cw[3 + best_axis]);
+        sp.lo = lo; sp.scale = (float)SAH_BINS * 0.999999f / (hi - lo);
+        const uint32_t* B = bins + (size_t)w * SAH_BIN_WORDS + best_axis * SAH_BINS * 7;
+        for (int k = 0; k < 6; k++) { bl[k] = br[k] = k < 3 ? 3.0e38f : -3.0e38f; }
+        for (int b = 0; b < SAH_BINS; b++) {
+            const uint32_t* o = B + b * 7;
+            if (!o[6]) continue;
+            float* d = b <= best_bin ? bl : br;
+            for (int k = 0; k < 3; k++) { d[k] = fminf(d[k], ord2f(o[k])); d[3 + k] = fmaxf(d[3 + k], ord2f(o[3 + k])); }
+        }
+    } else {                                                                  // every centroid coincides: cut in the middle, both children take the node's box
+        best_nl = n / 2;
+        for (int k = 0; k < 3; k++) { bl[k] = br[k] = ord2f(cw[6 + k]); bl[3 + k] = br[3 + k] = ord2f(cw[9 + k]); }
+    }
+    sp.n_left = best_nl;
+    const int nl = best_nl, nr = n - best_nl;
+    int cl, cr; sp.wl = -1; sp.wr = -1;
+    // node numbers in DEPTH-FIRST PREORDER, without a counter: a subtree over m references has m - 1 nodes, so the left child
+    // is node + 1 and the right child node + n_left -- the records of a subtree are contiguous in memory, like its leaves
+    // (the host builder lays its tree out the same way; numbered level by level the same tree traced 6 % slower on C3)
+    if (nl > 1) { cl = wk.node + 1; atomicAdd(&counters[0], 1u); sp.wl = (int)atomicAdd(&counters[1], 1u); SahWork q; q.begin = wk.begin; q.end = wk.begin + nl; q.node = cl; q.pad = 0; next[sp.wl] = q; }
+    else cl = ~wk.begin;
+    if (nr > 1) { cr = wk.node + nl; atomicAdd(&counters[0], 1u); sp.wr = (int)atomicAdd(&counters[1], 1u); SahWork q; q.begin = wk.begin + nl; q.end = wk.end; q.node = cr; q.pad = 0; next[sp.wr] = q; }
+    else cr = ~(wk.end - 1);
+    split[w] = sp;
+    Node2 nd; nd.lo0x = bl[0]; nd.lo0y = bl[1]; nd.lo0z = bl[2]; nd.hi0x = bl[3]; nd.hi0y = bl[4]; nd.hi0z = bl[5];
+    nd.lo1x = br[0]; nd.lo1y = br[1]; nd.lo1z = br[2]; nd.hi1x = br[3]; nd.hi1y = br[4]; nd.hi1z = br[5]; nd.c0 = cl; nd.c1 = cr; nd.pad0 = 0; nd.pad1 = 0;
+    nodes[wk.node] = nd;
+}
+
+__global__ void k_sah_scatter(const float* __restrict__ ref_box, const uint32_t* __restrict__ idx, const int32_t* __restrict__ work_of, const SahWork* __restrict__ work,
+                              const SahSplit* __restrict__ split, uint32_t* __restrict__ fill /* [n_work][2] */, uint32_t* __restrict__ idx_out, int32_t* __restrict__ work_out, uint32_t n)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int w = work_of[p];
+    if (w < 0) { idx_out[p] = idx[p]; work_out[p] = -1; return; }                 // already a leaf: stays where it is
+    const SahWork wk = work[w]; const SahSplit sp = split[w];
+    const uint32_t r = idx[p];
+    bool left; uint32_t dest;
+    if (sp.axis >= 0) {
+        const float* b = ref_box + 6 * (size_t)r;
+        const float c = (b[sp.axis] + b[3 + sp.axis]) * 0.5f;
+        int bi = (int)((c - sp.lo) * sp.scale); bi = bi < 0 ? 0 : (bi >= SAH_BINS ? SAH_BINS - 1 : bi);
+        left = bi <= sp.bin;
+        dest = left ? (uint32_t)wk.begin + atomicAdd(&fill[2 * (size_t)w], 1u) : (uint32_t)(wk.begin + sp.n_left) + atomicAdd(&fill[2 * (size_t)w + 1], 1u);
+    } else { left = (int)p < wk.begin + sp.n_left; dest = p; }
+    idx_out[dest] = r; work_out[dest] = left ? sp.wl : sp.wr;
+}
+
+// Crowded spots of a provisional tree (the second and third rounds of the host builder's reference splitting, rts_sah.cpp):
+// box area saved says nothing about HOW MANY references cover the same spot -- a ray through the hub of a fan of N slivers
+// tests all N of them, however small they are.  Per reference: how many leaf boxes of the tree contain its centre; a dozen
+// overlapping neighbours is normal on a curved surface, beyond that the reference's triangle is cut into twice as many slabs
+// (if halving its box saves a tenth of its surface at all) and the tree is built again.
+__global__ void k_crowd(const Node2* __restrict__ nodes, const float* __restrict__ ref_box, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ ref_tri,
+                        const uint32_t* __restrict__ tri_vidx, const double* __restrict__ verts, uint32_t nv, uint32_t* __restrict__ boost, uint32_t* __restrict__ n_boosted)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nv) return;
+    const uint32_t r = idx[p];
+    const float* b = ref_box + 6 * (size_t)r;
+    const float cx = (b[0] + b[3]) * 0.5f, cy = (b[1] + b[4]) * 0.5f, cz = (b[2] + b[5]) * 0.5f;
+    int stack[64]; int sp = 0; stack[sp++] = 0;
+    int count = 0, steps = 0;
+    while (sp > 0 && count < 64 && steps++ < 4096) {
+        const Node2 nd = nodes[stack[--sp]];
+        const bool in0 = cx >= nd.lo0x && cx <= nd.hi0x && cy >= nd.lo0y && cy <= nd.hi0y && cz >= nd.lo0z && cz <= nd.hi0z;
+        const bool in1 = cx >= nd.lo1x && cx <= nd.hi1x && cy >= nd.lo1y && cy <= nd.hi1y && cz >= nd.lo1z && cz <= nd.hi1z;
+        if (in0) { if (nd.c0 < 0) count++; else if (sp < 64) stack[sp++] = nd.c0; }
+        if (in1) { if (nd.c1 < 0) count++; else if (sp < 64) stack[sp++] = nd.c1; }
+    }
+    if (count < 12) return;
+    const uint32_t tri = ref_tri[r];
+    const TriV t = load_tri(tri_vidx, verts, tri);
+    if (!t.finite) return;
+    double lo[3], hi[3]; tri_extent(t, lo, hi);
+    const double ex = hi[0]-lo[0], ey = hi[1]-lo[1], ez = hi[2]-lo[2];
+    const int ax = (ex >= ey && ex >= ez) ? 0 : (ey >= ez ? 1 : 2);
+    const double mid = 0.5 * lo[ax] + 0.5 * hi[ax];
+    double l0[3], h0[3], l1[3], h1[3];
+    tri_slab_box(t, lo, hi, ax, lo[ax], mid, l0, h0); tri_slab_box(t, lo, hi, ax, mid, hi[ax], l1, h1);
+    const double a = box_area3(lo, hi);
+    if (!(a - (box_area3(l0, h0) + box_area3(l1, h1)) > 0.10 * a)) return;
+    if (atomicExch(&boost[tri], 1u) == 0u) atomicAdd(n_boosted, 1u);
+}
+
+// Compaction of the 4-wide records: k_collapse4 writes one record per BINARY node, and about half of them are never referred to
+// (their node was opened into its parent's record).  Left in place they double the footprint of the hierarchy and halve the
+// density of every cache line and page the walk touches (C3: 39 MB against the host builder's 19 MB; the same tree traced
+// 5-8 % slower).  Reachable records are marked from the root, level by level, numbered by a scan -- which keeps the
+// depth-first order -- and copied out with their child links renumbered.
+__global__ void k_reach_step(const RtsNode4* __restrict__ rec, uint32_t* __restrict__ reach, uint32_t n, uint32_t* __restrict__ changed)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || reach[i] != 1u) return;
+    reach[i] = 2u;                                                            // expanded
+    for (int k = 0; k < 4; k++) { const int32_t c = rec[i].child[k]; if (c >= 0 && c != 0x7fffffff && (uint32_t)c < n && reach[c] == 0u) { reach[c] = 1u; *changed = 1u; } }
+}
+__global__ void k_reach_flag(const uint32_t* __restrict__ reach, uint32_t* __restrict__ flag, uint32_t n) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) flag[i] = reach[i] ? 1u : 0u; }
+__global__ void k_compact4(const RtsNode4* __restrict__ rec, const uint32_t* __restrict__ flag, const uint32_t* __restrict__ newid, uint32_t n, RtsNode4* __restrict__ out, int32_t node_base)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    RtsNode4 o = rec[i];
+    for (int k = 0; k < 4; k++) { const int32_t c = o.child[k]; if (c >= 0 && c != 0x7fffffff) o.child[k] = (int32_t)newid[c] + node_base; }
+    out[newid[i]] = o;
+}
+
+__global__ void k_iota(uint32_t* __restrict__ a, int32_t* __restrict__ w, uint32_t n) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) { a[i] = i; w[i] = 0; } }
+// references with the sentinel box (non-finite triangles) moved behind the valid ones: stable compaction by a flag scan is
+// not needed -- the caller sorts by (valid ? 0 : 1) with the radix sort it already has -- this kernel writes that key
+__global__ void k_valid_key(const float* __restrict__ ref_box, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const float* b = ref_box + 6 * (size_t)i; keys[i] = (b[0] > b[3]) ? 1ULL : 0ULL; vals[i] = i; }
+}
+
 }  // namespace
 
 // vidx: [n_prims][3] GLOBAL vertex indices (host copy of ns->d_tri_vidx); mh: per-mesh slices.  Fills ns->d_nodes4,
@@ -390,6 +653,69 @@ int rts_lbvh_build_device(RtsContext* c, RtsScene* ns, const std::vector<uint32_
     ns->n_nodes = 0; ns->n_leaves = 0;
     if (n_max == 0) { RTS_HIP(ns->d_nodes4.reserve(1)); RTS_HIP(ns->d_leaf_prim.reserve(1)); return RTS_OK; }
 
+    // ---- temporaries of both passes (grown on demand)
+    DevBuf<float> d_prim_box; DevBuf<uint64_t> d_keys, d_keys_sorted; DevBuf<uint32_t> d_vals, d_vals_sorted, d_bounds, d_flags, d_ref_tri; DevBuf<int32_t> d_parent, d_leaf_parent;
+    DevBuf<Node2> d_nodes2; DevBuf<int2> d_range; DevBuf<char> d_tmp;
+    struct Free { DevBuf<float>& a; DevBuf<uint64_t>& b; DevBuf<uint64_t>& b2; DevBuf<uint32_t>& c1; DevBuf<uint32_t>& c2; DevBuf<uint32_t>& c3; DevBuf<uint32_t>& c4; DevBuf<uint32_t>& c5; DevBuf<int32_t>& d1; DevBuf<int32_t>& d2; DevBuf<Node2>& e; DevBuf<int2>& f; DevBuf<char>& g;
+                  ~Free() { a.release(); b.release(); b2.release(); c1.release(); c2.release(); c3.release(); c4.release(); c5.release(); d1.release(); d2.release(); e.release(); f.release(); g.release(); } }
+        free_all{d_prim_box, d_keys, d_keys_sorted, d_vals, d_vals_sorted, d_bounds, d_flags, d_ref_tri, d_parent, d_leaf_parent, d_nodes2, d_range, d_tmp};
+    size_t tmp = 0;
+    auto ensure_tmp = [&](uint32_t r) -> int {
+        RTS_HIP(d_prim_box.reserve(6 * (size_t)r)); RTS_HIP(d_keys.reserve(r)); RTS_HIP(d_keys_sorted.reserve(r)); RTS_HIP(d_vals.reserve(r)); RTS_HIP(d_vals_sorted.reserve(r)); RTS_HIP(d_ref_tri.reserve(r));
+        RTS_HIP(d_bounds.reserve(8)); RTS_HIP(d_flags.reserve(r)); RTS_HIP(d_parent.reserve(r)); RTS_HIP(d_leaf_parent.reserve(r)); RTS_HIP(d_nodes2.reserve(r)); RTS_HIP(d_range.reserve(r));
+        size_t need = 0;
+        RTS_HIP(rocprim::radix_sort_pairs(nullptr, need, d_keys.p, d_keys_sorted.p, d_vals.p, d_vals_sorted.p, r, 0, 64, st));
+        RTS_HIP(d_tmp.reserve(need)); tmp = std::max(tmp, need);
+        return RTS_OK;
+    };
+    bool sah_tree = true;                                          // top-down binned SAH (default) or the Morton / Karras tree
+    { const char* e = getenv("RTS_DEVICE_TREE"); if (e) sah_tree = strcmp(e, "lbvh") != 0; }
+    int crowd_rounds = 1; { const char* e = getenv("RTS_CROWD_ROUNDS"); if (e) crowd_rounds = std::max(0, std::min(3, atoi(e))); }
+    DevBuf<uint32_t> d_sah_bins, d_sah_cb, d_sah_fill, d_boost; DevBuf<SahSplit> d_sah_split; DevBuf<SahWork> d_sah_work_a, d_sah_work_b;
+    DevBuf<RtsNode4> d_nodes4_tmp; DevBuf<uint32_t> d_reach, d_newid, d_rflag;
+    struct FreeC { DevBuf<RtsNode4>& a; DevBuf<uint32_t>& b; DevBuf<uint32_t>& c1; DevBuf<uint32_t>& d; ~FreeC() { a.release(); b.release(); c1.release(); d.release(); } } free_c{d_nodes4_tmp, d_reach, d_newid, d_rflag};
+    struct FreeSah { DevBuf<uint32_t>& a; DevBuf<uint32_t>& b; DevBuf<uint32_t>& c1; DevBuf<uint32_t>& c2; DevBuf<SahSplit>& d; DevBuf<SahWork>& e; DevBuf<SahWork>& f; ~FreeSah() { a.release(); b.release(); c1.release(); c2.release(); d.release(); e.release(); f.release(); } }
+        free_sah{d_sah_bins, d_sah_cb, d_sah_fill, d_boost, d_sah_split, d_sah_work_a, d_sah_work_b};
+    RTS_HIP(d_boost.reserve((size_t)ns->n_prims + 2)); RTS_HIP(hipMemsetAsync(d_boost.p, 0, sizeof(uint32_t) * ((size_t)ns->n_prims + 2), st));       // per triangle: 1 = twice the slabs (k_crowd); last word: a counter
+
+    // the level loop of the binned-SAH builder over the nv valid references of the current mesh (boxes in d_prim_box):
+    // leaves the binary tree in d_nodes2 (root 0, nv - 1 nodes) and the leaf order in d_vals_sorted
+    auto sah_levels = [&](uint32_t nr, uint32_t nv) -> int {
+        size_t tmp_n = tmp;
+        k_valid_key<<<blocks_for(nr, 256), 256, 0, st>>>(d_prim_box.p, d_keys.p, d_vals.p, nr);
+        RTS_HIP(rocprim::radix_sort_pairs(d_tmp.p, tmp_n, d_keys.p, d_keys_sorted.p, d_vals.p, d_vals_sorted.p, nr, 0, 1, st));     // valid references first (stable)
+        uint32_t* idx_a = d_vals_sorted.p; uint32_t* idx_b = d_vals.p;
+        int32_t* wo_a = d_parent.p; int32_t* wo_b = d_leaf_parent.p;                     // work-node index per position (the LBVH's link arrays are free in this mode)
+        const uint32_t max_work = nv / 2 + 2;
+        RTS_HIP(d_sah_bins.reserve((size_t)max_work * SAH_BIN_WORDS)); RTS_HIP(d_sah_cb.reserve((size_t)max_work * 12)); RTS_HIP(d_sah_fill.reserve((size_t)max_work * 2 + 2));
+        RTS_HIP(d_sah_split.reserve(max_work)); RTS_HIP(d_sah_work_a.reserve(max_work)); RTS_HIP(d_sah_work_b.reserve(max_work));
+        k_iota<<<blocks_for(nv, 256), 256, 0, st>>>(d_flags.p, wo_a, nv);            // (d_flags only as a dummy target for the iota; work_of := 0)
+        SahWork w0; w0.begin = 0; w0.end = (int32_t)nv; w0.node = 0; w0.pad = 0;
+        RTS_HIP(hipMemcpyAsync(d_sah_work_a.p, &w0, sizeof(w0), hipMemcpyHostToDevice, st));
+        uint32_t* cnt = d_sah_fill.p + (size_t)max_work * 2;                           // [0] next node id, [1] open nodes of the next level
+        uint32_t h_cnt[2] = {1u, 0u};
+        RTS_HIP(hipMemcpyAsync(cnt, h_cnt, sizeof(h_cnt), hipMemcpyHostToDevice, st));
+        SahWork* wk_a = d_sah_work_a.p; SahWork* wk_b = d_sah_work_b.p;
+        uint32_t n_work = 1;
+        for (int level = 0; n_work > 0 && level < 256; level++) {
+            const size_t init_n = std::max((size_t)n_work * SAH_BIN_WORDS, (size_t)n_work * 12);
+            k_sah_init_bins<<<blocks_for(init_n, 256), 256, 0, st>>>(d_sah_bins.p, d_sah_cb.p, n_work);
+            RTS_HIP(hipMemsetAsync(d_sah_fill.p, 0, sizeof(uint32_t) * 2 * (size_t)n_work, st));
+            RTS_HIP(hipMemsetAsync(cnt + 1, 0, sizeof(uint32_t), st));
+            k_sah_bounds<<<blocks_for(nv, 256), 256, 0, st>>>(d_prim_box.p, idx_a, wo_a, d_sah_cb.p, nv);
+            k_sah_bins<<<blocks_for(nv, 256), 256, 0, st>>>(d_prim_box.p, idx_a, wo_a, d_sah_cb.p, d_sah_bins.p, nv);
+            k_sah_split<<<blocks_for(n_work, 64), 64, 0, st>>>(wk_a, n_work, d_sah_cb.p, d_sah_bins.p, d_sah_split.p, d_nodes2.p, wk_b, cnt);
+            k_sah_scatter<<<blocks_for(nv, 256), 256, 0, st>>>(d_prim_box.p, idx_a, wo_a, wk_a, d_sah_split.p, d_sah_fill.p, idx_b, wo_b, nv);
+            RTS_HIP(hipMemcpyAsync(h_cnt, cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, st)); RTS_HIP(hipStreamSynchronize(st));
+            n_work = h_cnt[1];
+            if (n_work > max_work) { rts_set_error("rts_set_scene: device SAH builder: %u open nodes at level %d exceed the bound %u", n_work, level, max_work); return RTS_ERR_HIP; }
+            std::swap(idx_a, idx_b); std::swap(wo_a, wo_b); std::swap(wk_a, wk_b);
+        }
+        if (n_work != 0 || h_cnt[0] != nv - 1) { rts_set_error("rts_set_scene: device SAH builder did not close (%u open nodes, %u of %u nodes)", n_work, h_cnt[0], nv - 1); return RTS_ERR_HIP; }
+        if (idx_a != d_vals_sorted.p) RTS_HIP(hipMemcpyAsync(d_vals_sorted.p, idx_a, sizeof(uint32_t) * nv, hipMemcpyDeviceToDevice, st));
+        return RTS_OK;
+    };
+
     // ---- pass A: the split threshold of every mesh and its number of references (valid ones first after the sort)
     DevBuf<double> d_acc; DevBuf<uint32_t> d_cnt, d_off, d_nvr; DevBuf<char> d_scan_tmp;
     struct FreeA { DevBuf<double>& a; DevBuf<uint32_t>& b; DevBuf<uint32_t>& c1; DevBuf<uint32_t>& d; DevBuf<char>& e; ~FreeA() { a.release(); b.release(); c1.release(); d.release(); e.release(); } } free_a{d_acc, d_cnt, d_off, d_nvr, d_scan_tmp};
@@ -398,15 +724,26 @@ int rts_lbvh_build_device(RtsContext* c, RtsScene* ns, const std::vector<uint32_
     RTS_HIP(rocprim::exclusive_scan(nullptr, scan_tmp, d_cnt.p, d_off.p, 0u, n_max, rocprim::plus<uint32_t>(), st));
     RTS_HIP(d_scan_tmp.reserve(scan_tmp + 16));
     std::vector<double> a_thr(n_targets, 0.0); std::vector<uint32_t> n_refs(n_targets, 0), n_valid(n_targets, 0);
+    int gain_rule = 1; { const char* e = getenv("RTS_REF_GAIN_RULE"); if (e) gain_rule = atoi(e) != 0; }
     auto count_refs = [&](uint32_t t) -> int {                       // cnt / off of mesh t (deterministic: pass B repeats it)
         const uint32_t n = mh[t].n_tris;
         const uint32_t* tv = ns->d_tri_vidx.p + 3 * (size_t)mh[t].tri_base;
         RTS_HIP(hipMemsetAsync(d_nvr.p, 0, sizeof(uint32_t), st));
-        k_ref_count<<<blocks_for(n, 256), 256, 0, st>>>(tv, ns->d_verts_local.p, n, a_thr[t], d_cnt.p, d_nvr.p);
+        k_ref_count<<<blocks_for(n, 256), 256, 0, st>>>(tv, ns->d_verts_local.p, n, a_thr[t], gain_rule, d_boost.p + mh[t].tri_base, d_cnt.p, d_nvr.p);
         size_t tmp_n = scan_tmp;
         RTS_HIP(rocprim::exclusive_scan(d_scan_tmp.p, tmp_n, d_cnt.p, d_off.p, 0u, n, rocprim::plus<uint32_t>(), st));
         return RTS_OK;
     };
+    auto read_counts = [&](uint32_t t) -> int {
+        const uint32_t n = mh[t].n_tris;
+        uint32_t last[2] = {0, 0}, nvr = 0;
+        RTS_HIP(hipMemcpyAsync(&last[0], d_off.p + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        RTS_HIP(hipMemcpyAsync(&last[1], d_cnt.p + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        RTS_HIP(hipMemcpyAsync(&nvr, d_nvr.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st)); RTS_HIP(hipStreamSynchronize(st));
+        n_refs[t] = last[0] + last[1]; n_valid[t] = nvr;
+        return RTS_OK;
+    };
+    static const uint32_t init_bounds[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
     uint64_t node_total = 0, leaf_total = 0; uint32_t r_max = 0;
     for (uint32_t t = 0; t < n_targets; t++) {
         const uint32_t n = mh[t].n_tris;
@@ -418,13 +755,25 @@ int rts_lbvh_build_device(RtsContext* c, RtsScene* ns, const std::vector<uint32_
         RTS_HIP(hipMemcpyAsync(acc, d_acc.p, sizeof(acc), hipMemcpyDeviceToHost, st)); RTS_HIP(hipStreamSynchronize(st));
         a_thr[t] = (split_budget > 0 && acc[1] > 0 && acc[0] > 0 && std::isfinite(acc[0])) ? (acc[0] / acc[1]) / ((1.0 + split_budget) * (1.0 + split_budget)) : 0.0;
         { int rc = count_refs(t); if (rc != RTS_OK) return rc; }
-        uint32_t last[2] = {0, 0}, nvr = 0;
-        RTS_HIP(hipMemcpyAsync(&last[0], d_off.p + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        RTS_HIP(hipMemcpyAsync(&last[1], d_cnt.p + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        RTS_HIP(hipMemcpyAsync(&nvr, d_nvr.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st)); RTS_HIP(hipStreamSynchronize(st));
-        n_refs[t] = last[0] + last[1]; n_valid[t] = nvr;
+        { int rc = read_counts(t); if (rc != RTS_OK) return rc; }
+        // crowded spots: a provisional tree over these references, the triangles behind crowded references get twice the
+        // slabs, count again
+        for (int round = 0; sah_tree && split_budget > 0 && round < crowd_rounds && n_valid[t] > 1; round++) {
+            { int rc = ensure_tmp(n_refs[t]); if (rc != RTS_OK) return rc; }
+            RTS_HIP(hipMemcpyAsync(d_bounds.p, init_bounds, sizeof(init_bounds), hipMemcpyHostToDevice, st));
+            k_ref_boxes<<<blocks_for(n, 256), 256, 0, st>>>(tv, ns->d_verts_local.p, d_cnt.p, d_off.p, d_prim_box.p, d_ref_tri.p, d_bounds.p, n);
+            { int rc = sah_levels(n_refs[t], n_valid[t]); if (rc != RTS_OK) return rc; }
+            uint32_t* n_boosted = d_boost.p + ns->n_prims; uint32_t before = 0, after = 0;
+            RTS_HIP(hipMemcpyAsync(&before, n_boosted, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            k_crowd<<<blocks_for(n_valid[t], 256), 256, 0, st>>>(d_nodes2.p, d_prim_box.p, d_vals_sorted.p, d_ref_tri.p, tv, ns->d_verts_local.p, n_valid[t], d_boost.p + mh[t].tri_base, n_boosted);
+            RTS_HIP(hipMemcpyAsync(&after, n_boosted, sizeof(uint32_t), hipMemcpyDeviceToHost, st)); RTS_HIP(hipStreamSynchronize(st));
+            if (getenv("RTS_DEBUG_BUILD")) fprintf(stderr, "[rts build] mesh %u round %d: %u triangles, %u references (%u valid), %u triangles boosted\n", t, round, n, n_refs[t], n_valid[t], after - before);
+            if (after == before) break;
+            { int rc = count_refs(t); if (rc != RTS_OK) return rc; }
+            { int rc = read_counts(t); if (rc != RTS_OK) return rc; }
+        }
         RtsBlasInfo& b = ns->blas[t];
-        b.n_leaves = nvr; b.n_nodes = nvr == 0 ? 0 : std::max<uint32_t>(nvr - 1, 1);
+        b.n_leaves = n_valid[t]; b.n_nodes = n_valid[t] == 0 ? 0 : std::max<uint32_t>(n_valid[t] - 1, 1);
         node_total += b.n_nodes; leaf_total += b.n_leaves; r_max = std::max(r_max, n_refs[t]);
     }
     if (node_total > 0x7ffffff0ULL || leaf_total > 0x7ffffff0ULL) { rts_set_error("rts_set_scene: too many references"); return RTS_ERR_UNSUPPORTED; }
@@ -432,29 +781,49 @@ int rts_lbvh_build_device(RtsContext* c, RtsScene* ns, const std::vector<uint32_
     ns->n_nodes = (uint32_t)node_total; ns->n_leaves = (uint32_t)leaf_total;
     if (r_max == 0) return RTS_OK;
 
-    // ---- pass B: boxes, codes, sort, tree, boxes of the tree, 4-wide records -- per mesh, over its references
-    DevBuf<float> d_prim_box; DevBuf<uint64_t> d_keys, d_keys_sorted; DevBuf<uint32_t> d_vals, d_vals_sorted, d_bounds, d_flags, d_ref_tri; DevBuf<int32_t> d_parent, d_leaf_parent;
-    DevBuf<Node2> d_nodes2; DevBuf<int2> d_range; DevBuf<char> d_tmp;
-    struct Free { DevBuf<float>& a; DevBuf<uint64_t>& b; DevBuf<uint64_t>& b2; DevBuf<uint32_t>& c1; DevBuf<uint32_t>& c2; DevBuf<uint32_t>& c3; DevBuf<uint32_t>& c4; DevBuf<uint32_t>& c5; DevBuf<int32_t>& d1; DevBuf<int32_t>& d2; DevBuf<Node2>& e; DevBuf<int2>& f; DevBuf<char>& g;
-                  ~Free() { a.release(); b.release(); b2.release(); c1.release(); c2.release(); c3.release(); c4.release(); c5.release(); d1.release(); d2.release(); e.release(); f.release(); g.release(); } }
-        free_all{d_prim_box, d_keys, d_keys_sorted, d_vals, d_vals_sorted, d_bounds, d_flags, d_ref_tri, d_parent, d_leaf_parent, d_nodes2, d_range, d_tmp};
-    RTS_HIP(d_prim_box.reserve(6 * (size_t)r_max)); RTS_HIP(d_keys.reserve(r_max)); RTS_HIP(d_keys_sorted.reserve(r_max)); RTS_HIP(d_vals.reserve(r_max)); RTS_HIP(d_vals_sorted.reserve(r_max)); RTS_HIP(d_ref_tri.reserve(r_max));
-    RTS_HIP(d_bounds.reserve(8)); RTS_HIP(d_flags.reserve(r_max)); RTS_HIP(d_parent.reserve(r_max)); RTS_HIP(d_leaf_parent.reserve(r_max)); RTS_HIP(d_nodes2.reserve(r_max)); RTS_HIP(d_range.reserve(r_max));
-    size_t tmp = 0;
-    RTS_HIP(rocprim::radix_sort_pairs(nullptr, tmp, d_keys.p, d_keys_sorted.p, d_vals.p, d_vals_sorted.p, r_max, 0, 64, st));
-    RTS_HIP(d_tmp.reserve(tmp));
+    // ---- pass B: boxes, tree, 4-wide records -- per mesh, over its references
+    { int rc = ensure_tmp(r_max); if (rc != RTS_OK) return rc; }
     int32_t node_base = 0, leaf_base = 0;
     for (uint32_t t = 0; t < n_targets; t++) {
         const uint32_t n = mh[t].n_tris, nr = n_refs[t], nv = n_valid[t];
         RtsBlasInfo& b = ns->blas[t];
         if (nv == 0) continue;
-        static const uint32_t init_bounds[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
         RTS_HIP(hipMemcpyAsync(d_bounds.p, init_bounds, sizeof(init_bounds), hipMemcpyHostToDevice, st));
         const uint32_t* tv = ns->d_tri_vidx.p + 3 * (size_t)mh[t].tri_base;
         { int rc = count_refs(t); if (rc != RTS_OK) return rc; }
         k_ref_boxes<<<blocks_for(n, 256), 256, 0, st>>>(tv, ns->d_verts_local.p, d_cnt.p, d_off.p, d_prim_box.p, d_ref_tri.p, d_bounds.p, n);
-        k_morton<<<blocks_for(nr, 256), 256, 0, st>>>(d_prim_box.p, d_bounds.p, d_keys.p, d_vals.p, nr);
         size_t tmp_n = tmp;
+        if (sah_tree && nv > 1) {
+            // ---- top-down binned SAH over the references (the quality tree)
+            { int rc = sah_levels(nr, nv); if (rc != RTS_OK) return rc; }
+            k_leaf_order<<<blocks_for(nv, 256), 256, 0, st>>>(d_vals_sorted.p, d_ref_tri.p, mh[t].tri_base, ns->d_leaf_prim.p + leaf_base, nv);
+            const uint32_t n2 = nv - 1;
+            RTS_HIP(d_nodes4_tmp.reserve(n2)); RTS_HIP(d_reach.reserve((size_t)n2 + 1)); RTS_HIP(d_newid.reserve(n2)); RTS_HIP(d_rflag.reserve(n2));
+            k_collapse4<<<blocks_for(n2, 256), 256, 0, st>>>(d_nodes2.p, d_nodes4_tmp.p, (int)n2, 0, leaf_base);
+            RTS_HIP(hipMemsetAsync(d_reach.p, 0, sizeof(uint32_t) * ((size_t)n2 + 1), st));
+            { const uint32_t one = 1u; RTS_HIP(hipMemcpyAsync(d_reach.p, &one, sizeof(one), hipMemcpyHostToDevice, st)); }
+            uint32_t* d_changed = d_reach.p + n2;
+            for (int it = 0; it < 256; it++) {
+                RTS_HIP(hipMemsetAsync(d_changed, 0, sizeof(uint32_t), st));
+                k_reach_step<<<blocks_for(n2, 256), 256, 0, st>>>(d_nodes4_tmp.p, d_reach.p, n2, d_changed);
+                uint32_t ch = 0; RTS_HIP(hipMemcpyAsync(&ch, d_changed, sizeof(ch), hipMemcpyDeviceToHost, st)); RTS_HIP(hipStreamSynchronize(st));
+                if (!ch) break;
+            }
+            k_reach_flag<<<blocks_for(n2, 256), 256, 0, st>>>(d_reach.p, d_rflag.p, n2);
+            { size_t need = 0; RTS_HIP(rocprim::exclusive_scan(nullptr, need, d_rflag.p, d_newid.p, 0u, n2, rocprim::plus<uint32_t>(), st));
+              RTS_HIP(d_tmp.reserve(need + 16)); RTS_HIP(rocprim::exclusive_scan(d_tmp.p, need, d_rflag.p, d_newid.p, 0u, n2, rocprim::plus<uint32_t>(), st)); }
+            uint32_t last_id = 0, last_flag = 0;
+            RTS_HIP(hipMemcpyAsync(&last_id, d_newid.p + (n2 - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            RTS_HIP(hipMemcpyAsync(&last_flag, d_rflag.p + (n2 - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st)); RTS_HIP(hipStreamSynchronize(st));
+            const uint32_t n4 = last_id + last_flag;                                   // reachable records
+            k_compact4<<<blocks_for(n2, 256), 256, 0, st>>>(d_nodes4_tmp.p, d_rflag.p, d_newid.p, n2, ns->d_nodes4.p + node_base, node_base);
+            RTS_HIP(hipGetLastError());
+            b.root = node_base; b.n_nodes = n4;
+            node_base += (int32_t)n4; leaf_base += (int32_t)b.n_leaves;
+            RTS_HIP(hipStreamSynchronize(st));
+            continue;
+        }
+        k_morton<<<blocks_for(nr, 256), 256, 0, st>>>(d_prim_box.p, d_bounds.p, d_keys.p, d_vals.p, nr);
         RTS_HIP(rocprim::radix_sort_pairs(d_tmp.p, tmp_n, d_keys.p, d_keys_sorted.p, d_vals.p, d_vals_sorted.p, nr, 0, 64, st));
         k_leaf_order<<<blocks_for(nv, 256), 256, 0, st>>>(d_vals_sorted.p, d_ref_tri.p, mh[t].tri_base, ns->d_leaf_prim.p + leaf_base, nv);
         if (nv == 1) {
@@ -470,5 +839,6 @@ int rts_lbvh_build_device(RtsContext* c, RtsScene* ns, const std::vector<uint32_
         node_base += (int32_t)b.n_nodes; leaf_base += (int32_t)b.n_leaves;
         RTS_HIP(hipStreamSynchronize(st));                       // the temporaries are reused by the next mesh
     }
+    ns->n_nodes = (uint32_t)node_base;                               // (reachable records only: the binned-SAH path compacts its trees)
     return RTS_OK;
 }

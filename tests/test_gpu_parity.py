@@ -1118,7 +1118,7 @@ def test_differential_fuzz_seeds(rts):
     import fuzz_equal as F
     for seed, version in ((12661, 1), (7, 1), (1234, 1), (50301, 2), (20011, 2), (31337, 3), (200003, 3), (200040, 3)):
         spec, place, aim = F.random_scene(seed, version)
-        a = F.run(spec); b = F.run(spec, pre_filter=False); c = F.run(spec, device_build=True)
+        a = F.run(spec); b = F.run(spec, pre_filter=False); c = F.run(spec, device_build=False)
         F.same(a, b, "seed %d: pre-filter on / off" % seed)
         F.same(a, c, "seed %d: host / device tree" % seed)
         F.against_oracle(spec, a)

@@ -179,9 +179,9 @@ def main():
             os.environ.pop("RTS_SPLIT_BUDGET", None)
             a = run(spec)
             b = run(spec, pre_filter=False)
-            c = run(spec, device_build=True)
+            c = run(spec, device_build=False)
             os.environ["RTS_SPLIT_BUDGET"] = "0"
-            d = run(spec, device_build=True, pre_filter=False)
+            d = run(spec, device_build=False, pre_filter=False)
             os.environ.pop("RTS_SPLIT_BUDGET", None)
             same(a, b, "seed %d: pre-filter on / off" % seed)
             e = run(spec, count_traversal=True); f = run(spec, count_traversal=True, pre_filter=False)     # counting builds: is the filter doing anything?
