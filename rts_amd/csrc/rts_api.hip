@@ -84,6 +84,7 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     e = hipHostMalloc((void**)&c->pin, sizeof(RtsPinned), hipHostMallocDefault);
     if (e != hipSuccess) { delete c; rts_set_error("hipHostMalloc: %s", hipGetErrorString(e)); return RTS_ERR_HIP; }
     memset(c->pin, 0, sizeof(RtsPinned));
+    { void* dp = nullptr; e = hipHostGetDevicePointer(&dp, c->pin, 0); if (e != hipSuccess) { delete c; rts_set_error("hipHostGetDevicePointer: %s", hipGetErrorString(e)); return RTS_ERR_HIP; } c->pin_dev = (RtsPinned*)dp; }
     hipDeviceProp_t prop; e = hipGetDeviceProperties(&prop, p->device);
     if (e != hipSuccess) { delete c; rts_set_error("hipGetDeviceProperties: %s", hipGetErrorString(e)); return RTS_ERR_HIP; }
     c->n_cu = prop.multiProcessorCount;
@@ -98,6 +99,7 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     { const char* e = getenv("RTS_COOP_FLOOR"); if (e) c->coop_floor = (uint32_t)std::max(0, atoi(e)); }
     { const char* e = getenv("RTS_COOP_SEG"); if (e) c->coop_seg_cost = (uint32_t)std::max(0, atoi(e)); }
     { const char* e = getenv("RTS_COOP_SEG_RATIO"); if (e) c->coop_seg_ratio = std::max(0.0, atof(e)); }
+    { const char* e = getenv("RTS_COOP_BIG"); if (e) c->coop_big = std::max(0.0, atof(e)); }
     { const char* e = getenv("RTS_COOP_GRID"); if (e) c->coop_grid_max = (uint32_t)std::min(4096, std::max(1, atoi(e))); }
     { const char* e = getenv("RTS_EW_REL"); if (e) { const double v = atof(e); if (v > 0) c->ew_rel = v; } }
     { const char* e = getenv("RTS_STACK_LDS_DEBUG"); if (e) { int v = atoi(e); if (v >= 1 && v <= RTS_STACK_LDS) c->stack_lds = (uint32_t)v; } }   // tests: force the spill path
@@ -119,9 +121,9 @@ extern "C" int rts_destroy(RtsHandle c)
     if (c->scene && --c->scene->refs == 0) { c->scene->release(); delete c->scene; }
     c->scene = nullptr;
     c->d_verts_world.release(); c->d_normals_world.release();
-    c->d_motion.release(); c->d_targets.release();
+    c->d_params.release();
     c->d_leaves.release(); c->d_sort_tmp.release(); c->d_rx.release(); c->d_recv.release(); c->d_all.release();
-    c->d_counters.release(); c->d_block_counters.release(); c->d_timeline.release(); c->d_tile_cost.release(); c->d_tile_key.release(); c->d_tile_key_sorted.release(); c->d_tile_id.release(); c->d_tile_order.release(); c->d_tile_hist.release(); c->d_tile_ctr.release(); c->d_lc.release(); c->d_dir_hist.release(); c->d_pmask.release(); c->d_child.release(); c->d_rk64.release(); c->d_rk64_sorted.release(); c->d_hit_prim.release(); c->d_hit_t.release(); c->d_stack_ovf.release();
+    c->d_block_counters.release(); c->d_timeline.release(); c->d_tile_cost.release(); c->d_tile_key.release(); c->d_tile_key_sorted.release(); c->d_tile_id.release(); c->d_tile_order.release(); c->d_tile_hist.release(); c->d_tile_ctr.release(); c->d_dir_hist.release(); c->d_pmask.release(); c->d_child.release(); c->d_rk64.release(); c->d_rk64_sorted.release(); c->d_hit_prim.release(); c->d_hit_t.release(); c->d_stack_ovf.release();
     c->d_rk.release(); c->d_rk_sorted.release(); c->d_ri.release(); c->d_ri_sorted.release(); c->d_rx_rays.release(); c->d_rx_paths.release();
     c->d_rx_angles.release(); c->d_rx_slots.release(); c->d_all_rays.release(); c->d_all_paths.release(); c->d_all_angles.release();
     c->d_akeys.release(); c->d_akeys_sorted.release(); c->d_aidx.release(); c->d_aidx_sorted.release(); c->d_ghead.release(); c->d_gid.release();
@@ -285,7 +287,14 @@ static int rts_attach_scene(RtsContext* c)
     const RtsScene* sc = c->scene; const uint32_t n_targets = (uint32_t)sc->meshes.size();
     RTS_HIP(c->d_leaves.reserve((size_t)sc->n_leaves + 1));
     RTS_HIP(c->d_verts_world.reserve(3*(size_t)sc->n_verts + 1)); RTS_HIP(c->d_normals_world.reserve(3*(size_t)sc->n_normals + 1));
-    RTS_HIP(c->d_motion.reserve(n_targets + 1)); RTS_HIP(c->d_targets.reserve(n_targets + 1));
+    {   // device image of the pinned block's [lc | motion | td]
+        const size_t span = offsetof(RtsPinned, cnt);
+        RTS_HIP(c->d_params.reserve(span));
+        c->p_lc = reinterpret_cast<RtsLaunchConsts*>(c->d_params.p + offsetof(RtsPinned, lc));
+        c->p_motion = reinterpret_cast<RtsTargetMotion*>(c->d_params.p + offsetof(RtsPinned, motion));
+        c->p_targets = reinterpret_cast<RtsTargetDev*>(c->d_params.p + offsetof(RtsPinned, td));
+        c->rcs_uploaded = false;
+    }
     c->motion.assign(n_targets, RtsTargetMotion{}); c->motion_valid = false; c->bvh_valid = false; c->tile_hist_n = 0; c->tile_hist_any = false; c->tile_cost_pending = false;
     return RTS_OK;
 }
@@ -317,7 +326,7 @@ extern "C" int rts_scene_info(RtsHandle c, RtsSceneInfo* out)
     out->n_targets = (uint32_t)sc->meshes.size(); out->n_prims = sc->n_prims; out->n_nodes = sc->n_nodes; out->n_leaves = sc->n_leaves;
     out->handles_sharing = (uint32_t)sc->refs.load(); out->builder = sc->builder; out->build_ms = sc->build_ms;
     out->shared_device_bytes = sc->device_bytes();
-    out->handle_device_bytes = c->d_leaves.cap * sizeof(RtsLeafTri) + c->d_verts_world.cap * 8 + c->d_normals_world.cap * 8 + c->d_motion.cap * sizeof(RtsTargetMotion) + c->d_targets.cap * sizeof(RtsTargetDev);
+    out->handle_device_bytes = c->d_leaves.cap * sizeof(RtsLeafTri) + c->d_verts_world.cap * 8 + c->d_normals_world.cap * 8 + c->d_params.cap;
     return RTS_OK;
 }
 
@@ -466,14 +475,15 @@ extern "C" int rts_reserve(RtsHandle c, uint64_t n_rays)
     if (n * chains > 0xfffffff0ULL) { rts_set_error("rts_reserve: rays x chains exceeds 2^32"); return RTS_ERR_UNSUPPORTED; }
     const size_t threads = (size_t)c->n_cu * 64 * RTS_BLOCK;             // upper bound of any launch's grid
     const uint32_t H = c->params.max_refl + 1;
-    RTS_HIP(c->d_recv.reserve((size_t)n * chains + 1)); RTS_HIP(c->d_counters.reserve(16)); RTS_HIP(c->d_lc.reserve(1));
+    RTS_HIP(c->d_recv.reserve((size_t)n * chains + 1));
+    RTS_HIP(c->d_tile_ctr.reserve(RTS_ZERO_WORDS)); c->p_counters = reinterpret_cast<unsigned long long*>(c->d_tile_ctr.p + 2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE + 4);
     RTS_HIP(c->d_dir_hist.reserve((size_t)(c->params.max_refr ? 3 * H : std::max<uint32_t>(c->params.max_refl, 1)) * 3 * n + 4));
     const size_t coop_threads = c->coop_frac > 0.0 ? (size_t)c->coop_grid_max * RTS_BLOCK : 0;
     if (c->params.max_refr) RTS_HIP(c->d_child.reserve(2 * (threads + coop_threads)));
     RTS_HIP(c->d_stack_ovf.reserve((size_t)RTS_STACK_OVF * ((size_t)c->n_cu * 1024 + coop_threads)));
     RTS_HIP(c->d_block_counters.reserve(((size_t)c->n_cu * 64 + c->coop_grid_max) * 8));
     const size_t n_tiles = (size_t)((n + RTS_WTILE - 1) / RTS_WTILE), n_hist = (size_t)((W3 + RTS_WTILE - 1) / RTS_WTILE);
-    RTS_HIP(c->d_tile_ctr.reserve(2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE + 4)); RTS_HIP(c->d_tile_cost.reserve(n_tiles)); RTS_HIP(c->d_tile_key.reserve(n_tiles)); RTS_HIP(c->d_tile_key_sorted.reserve(n_tiles));
+    RTS_HIP(c->d_tile_ctr.reserve(RTS_ZERO_WORDS)); c->p_counters = reinterpret_cast<unsigned long long*>(c->d_tile_ctr.p + 2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE + 4); RTS_HIP(c->d_tile_cost.reserve(n_tiles)); RTS_HIP(c->d_tile_key.reserve(n_tiles)); RTS_HIP(c->d_tile_key_sorted.reserve(n_tiles));
     RTS_HIP(c->d_tile_id.reserve(n_tiles)); RTS_HIP(c->d_tile_order.reserve(n_tiles));
     if (c->tile_hist_n != (uint32_t)n_hist) {
         RTS_HIP(c->d_tile_hist.reserve(n_hist)); RTS_HIP(hipMemsetAsync(c->d_tile_hist.p, 0, sizeof(uint32_t) * n_hist, c->stream));
@@ -538,15 +548,8 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
             int rc = fill_target_placement(c, t, td[t]); if (rc != RTS_OK) { c->bvh_valid = false; c->motion_valid = false; return rc; }
             c->pin->motion[t] = c->motion[t];
         }
-        if (n_targets) {
-            RTS_HIP(hipMemcpyAsync(c->d_motion.p, c->pin->motion, sizeof(RtsTargetMotion)*n_targets, hipMemcpyHostToDevice, st));
-            RTS_HIP(hipMemcpyAsync(c->d_targets.p, td, sizeof(RtsTargetDev)*n_targets, hipMemcpyHostToDevice, st));
-        }
-        int rc = rts_scene_place(c); if (rc != RTS_OK) return rc;
-        RTS_STAGE(c, "scene_place");
-        c->bvh_valid = true; c->stats.bvh_rebuilt = 1;
+        // (uploaded below, together with the launch constants: one copy; the placement kernels follow it)
     }
-    RTS_HIP(hipEventRecord(c->ev[1], st));
 
     // ---- per-pulse buffers
     if (il_parts > 1) {      // number of launch indices of the range that fall into this part's tiles
@@ -582,11 +585,17 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     fill_mask_frame(lc, pre_filter && c->scene->n_prims > 0);
     for (int k = 0; k < 3; k++) { lc.f_bs[k] = (float)(&lc.bsx)[k]; lc.f_st[k] = (float)(&lc.stx)[k]; }
     for (int k = 0; k < 9; k++) { lc.f_rot[k] = (float)lc.rot[k]; lc.f_rot1[k] = (float)lc.rot1[k]; }
-    { int rc = rts_primary_mask_build(c, lc); if (rc != RTS_OK) return rc; }
-    RTS_HIP(c->d_lc.reserve(1));
+    // ---- the pulse's parameters in ONE upload: launch constants, and -- when a target moved -- the placements behind them
     c->pin->lc = lc;
-    RTS_HIP(hipMemcpyAsync(c->d_lc.p, &c->pin->lc, sizeof(lc), hipMemcpyHostToDevice, st));
-    a.lc = c->d_lc.p;
+    RTS_HIP(hipMemcpyAsync(c->d_params.p, &c->pin->lc, moved && n_targets ? offsetof(RtsPinned, td) + sizeof(RtsTargetDev) * n_targets : sizeof(RtsLaunchConsts), hipMemcpyHostToDevice, st));
+    a.lc = c->p_lc;
+    if (moved) {
+        int rc = rts_scene_place(c); if (rc != RTS_OK) return rc;
+        RTS_STAGE(c, "scene_place");
+        c->bvh_valid = true; c->stats.bvh_rebuilt = 1;
+    }
+    RTS_HIP(hipEventRecord(c->ev[1], st));
+    { int rc = rts_primary_mask_build(c, lc); if (rc != RTS_OK) return rc; }
     a.ray_first = first; a.n_rays = n; a.W = W; a.max_refl = c->params.max_refl; a.smooth = c->params.interpolate_smooth ? 1u : 0u;
     a.n_prims = c->scene->n_prims; a.n_targets = n_targets; a.n_rx = c->n_rx; a.keep_all = keep_all ? 1u : 0u;
     a.max_refr = c->params.max_refr; a.rows = a.max_refr ? c->params.max_refl + 3 : 1;
@@ -599,7 +608,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     else if (c->coop_seg_cost) a.coop_min_cost = 0xffffffffu;     // first launch of the handle: no yardstick yet, and its tiles run cold and in index order -- nothing is flagged
     const uint32_t coop_threads = c->coop_frac > 0.0 ? c->coop_grid_max * RTS_BLOCK : 0u;      // the cooperative kernel's rows of the per-thread slabs
     a.slab_threads = a.total_threads + coop_threads;
-    RTS_HIP(c->d_recv.reserve((size_t)n * chains + 1)); RTS_HIP(c->d_counters.reserve(16));
+    RTS_HIP(c->d_recv.reserve((size_t)n * chains + 1));
     RTS_HIP(c->d_dir_hist.reserve((size_t)(a.max_refr ? 3 * (c->params.max_refl + 1) : std::max<uint32_t>(c->params.max_refl, 1)) * 3 * n + 4));
     if (a.max_refr) RTS_HIP(c->d_child.reserve((size_t)2 * a.slab_threads));
     RTS_HIP(c->d_stack_ovf.reserve((size_t)RTS_STACK_OVF * a.slab_threads));
@@ -609,11 +618,10 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
         rts_fill_i32(st, c->d_hit_prim.p, -2, (size_t)n * (c->params.max_refl + 1));
         RTS_HIP(hipMemsetAsync(c->d_hit_t.p, 0, sizeof(float) * (size_t)n * (c->params.max_refl + 1), st));
     }
-    RTS_HIP(hipMemsetAsync(c->d_counters.p, 0, sizeof(unsigned long long) * 16, st));
     a.pmask = lc.mask.n ? c->d_pmask.p : nullptr; a.pre_filter = pre_filter ? 1u : 0u;
     a.nodes4 = c->scene->d_nodes4.p; a.stack_lds = c->stack_lds; a.leaves = c->d_leaves.p; a.tri_nidx = c->scene->d_tri_nidx.p; a.normals = c->d_normals_world.p;
-    a.targets = c->d_targets.p; a.rx = c->d_rx.p;
-    a.recv_records = c->d_recv.p; a.all_records = c->d_all.p; a.counters = c->d_counters.p; a.block_counters = c->d_block_counters.p; a.dir_hist = c->d_dir_hist.p;
+    a.targets = c->p_targets; a.rx = c->d_rx.p;
+    a.recv_records = c->d_recv.p; a.all_records = c->d_all.p; a.counters = c->p_counters; a.block_counters = c->d_block_counters.p; a.dir_hist = c->d_dir_hist.p;
     a.hit_prim = c->d_hit_prim.p; a.hit_t = c->d_hit_t.p; a.stack_ovf = c->d_stack_ovf.p; a.child = c->d_child.p;
     {   // longest-tile-first order from what this handle's earlier launches measured per global tile (rts_post.hip)
         const int lpt = c->tile_lpt ? 1 : 0;
@@ -621,7 +629,8 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
         const uint64_t sig[4] = {n, first, ((uint64_t)il_parts << 32) | il_tile, il_part};
         const bool aligned = first % RTS_WTILE == 0 && (il_parts <= 1 || il_tile % RTS_WTILE == 0);
         const uint32_t n_hist = (uint32_t)((total + RTS_WTILE - 1) / RTS_WTILE);
-        RTS_HIP(c->d_tile_ctr.reserve(2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE + 4)); RTS_HIP(hipMemsetAsync(c->d_tile_ctr.p, 0, sizeof(uint32_t) * (2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE + 4), st));      // draw counters of both kernels + the order's head words
+        RTS_HIP(c->d_tile_ctr.reserve(RTS_ZERO_WORDS)); c->p_counters = reinterpret_cast<unsigned long long*>(c->d_tile_ctr.p + 2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE + 4); a.counters = c->p_counters;
+        RTS_HIP(hipMemsetAsync(c->d_tile_ctr.p, 0, sizeof(uint32_t) * RTS_ZERO_WORDS, st));      // ONE fill: draw counters of both kernels, the order's head words, the launch's 16 counters
         a.tile_ctr = c->d_tile_ctr.p;
         if (lpt && aligned && n_tiles > grid * (RTS_BLOCK / RTS_WTILE)) {
             if (c->tile_hist_n != n_hist) {
@@ -632,8 +641,9 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
                 int rc = rts_tile_order_build(c, c->tile_cost_sig, c->tile_cost_pending, sig, n_tiles, grid * (RTS_BLOCK / RTS_WTILE)); if (rc != RTS_OK) return rc;
                 a.tile_order = c->d_tile_order.p; a.tile_head = c->coop_frac > 0.0 ? c->d_tile_ctr.p + 2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE + 2 : nullptr; a.tile_head_all = a.tile_head; c->tile_hist_any = true;
             }
+            const bool merged_all = c->tile_cost_pending && (c->tile_cost_sig[0] + RTS_WTILE - 1) / RTS_WTILE >= n_tiles && c->d_tile_cost.cap >= n_tiles;      // k_tile_merge read AND cleared the records
             RTS_HIP(c->d_tile_cost.reserve(n_tiles));
-            RTS_HIP(hipMemsetAsync(c->d_tile_cost.p, 0, sizeof(uint32_t) * n_tiles, st));
+            if (!merged_all) RTS_HIP(hipMemsetAsync(c->d_tile_cost.p, 0, sizeof(uint32_t) * n_tiles, st));
             a.tile_cost = c->d_tile_cost.p;
             c->tile_cost_pending = true; memcpy(c->tile_cost_sig, sig, sizeof(sig));
         } else c->tile_cost_pending = false;                        // (costs of an unaligned or single-sweep launch are not recorded)
@@ -665,7 +675,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     RTS_STAGE(c, "k_trace");
     RTS_HIP(hipEventRecord(c->ev[3], c->tstream));
     RTS_HIP(hipStreamWaitEvent(st, c->ev[3], 0));                // everything later on this handle's stream follows its trace
-    RTS_HIP(hipMemcpyAsync(c->pin->cnt, c->d_counters.p, sizeof(unsigned long long) * 8, hipMemcpyDeviceToHost, st));
+    // (the eight counters were written into the pinned block by k_sum_counters itself: no copy)
     c->pulse_open = true; g_open_pulses[c->device & 63]++;
     if (tl_path) {
         RTS_HIP(hipStreamSynchronize(st));
@@ -793,13 +803,13 @@ extern "C" int rts_aggregate(RtsHandle c, double cspeed, double carrier, uint64_
     if (R == 0) { c->agg_valid = true; return RTS_OK; }
     RTS_HIP(c->d_delay.reserve(R)); RTS_HIP(c->d_phase.reserve(R)); RTS_HIP(c->d_pathmatch.reserve(R));
     if (!c->fin_timed) RTS_HIP(hipEventRecord(c->ev[6], c->stream));
-    RTS_HIP(hipMemsetAsync(c->d_delay.p, 0, sizeof(double)*R, c->stream));
-    RTS_HIP(hipMemsetAsync(c->d_phase.p, 0, sizeof(double)*R, c->stream));
+    c->agg_delay_in = false;                                            // (delay / phase sums start at zero: no fills)
     const int32_t max_path = (int32_t)c->scene->meshes.size() - 1, max_rx = c->n_rx ? (int32_t)c->n_rx - 1 : 0;
     const bool use_rows = recv_index_base == RTS_BASE_USE_ROWS;
     c->agg_base_local = use_rows ? 0 : (int64_t)recv_index_base;
     int rc = rts_aggregate_device(c, max_path, max_rx, c->d_rx_paths.p, R, c->depth, cspeed, carrier, use_rows ? 0 : recv_index_base, c->d_rx_rays.p,
                                   c->d_delay.p, c->d_phase.p, c->d_pathmatch.p, &c->groups, nullptr, nullptr, nullptr, INT32_MAX, use_rows ? c->d_rx_slots.p : nullptr);
+    c->agg_delay_in = true;
     if (rc != RTS_OK) return rc;
     RTS_HIP(hipEventRecord(c->ev[7], c->stream));
     c->agg_timed = true; c->stats_pending = true;

@@ -133,8 +133,8 @@ int rts_primary_mask_build(RtsContext* c, const RtsLaunchConsts& lc)
 int rts_scene_place(RtsContext* c)
 {
     hipStream_t st = c->stream;
-    if (c->scene->n_verts) k_place<<<blocks_for(c->scene->n_verts, 256), 256, 0, st>>>(c->scene->d_verts_local.p, c->d_verts_world.p, c->scene->d_vert_targ.p, c->d_motion.p, c->scene->n_verts, 1);
-    if (c->scene->n_normals) k_place<<<blocks_for(c->scene->n_normals, 256), 256, 0, st>>>(c->scene->d_normals_local.p, c->d_normals_world.p, c->scene->d_norm_targ.p, c->d_motion.p, c->scene->n_normals, 0);
+    if (c->scene->n_verts) k_place<<<blocks_for(c->scene->n_verts, 256), 256, 0, st>>>(c->scene->d_verts_local.p, c->d_verts_world.p, c->scene->d_vert_targ.p, c->p_motion, c->scene->n_verts, 1);
+    if (c->scene->n_normals) k_place<<<blocks_for(c->scene->n_normals, 256), 256, 0, st>>>(c->scene->d_normals_local.p, c->d_normals_world.p, c->scene->d_norm_targ.p, c->p_motion, c->scene->n_normals, 0);
     if (c->scene->n_leaves) k_leaves<<<blocks_for(c->scene->n_leaves, 256), 256, 0, st>>>(c->scene->d_leaf_prim.p, c->scene->d_tri_vidx.p, c->d_verts_world.p, c->scene->d_prim_targ.p, c->d_leaves.p, c->scene->n_leaves);
     RTS_HIP(hipGetLastError());
     return RTS_OK;

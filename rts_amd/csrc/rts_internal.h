@@ -80,6 +80,7 @@ static_assert(sizeof(RtsChildState) == 128, "child state size");
 #ifndef RTS_TILE_CTRS
 #define RTS_TILE_CTRS 64           // striped draw counters of the tile queue
 #endif
+#define RTS_ZERO_WORDS (2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE + 4 + 32)      // the dwords one fill clears per launch: draw counters x 2 kernels, head words, 16 u64 counters
 #define RTS_TILE_CTR_STRIDE 32     // ... one per 128-byte line: same-LINE atomics serialise in L2 (~10 ns each) whatever their address
 #ifndef RTS_STACK_LDS
 #define RTS_STACK_LDS 24            // traversal stack entries kept in LDS per lane
@@ -182,11 +183,13 @@ struct RtsMeshHost {
 // stream never has to be drained just to recycle a pageable temporary.
 #define RTS_PIN_GROUPS 4096
 struct RtsPinned {
+    // [lc | motion | td]: the per-pulse parameters, uploaded with ONE copy into RtsContext::d_params (same layout): the launch
+    // constants alone when no target moved, else up to the last target's placement
     RtsLaunchConsts lc;
-    unsigned long long cnt[16];
-    uint32_t G, pad;
     RtsTargetMotion motion[256];
     RtsTargetDev td[256];
+    unsigned long long cnt[16];
+    uint32_t G, pad;
     double rcs[256];
     double gsum[5 * RTS_PIN_GROUPS]; uint64_t gkey[RTS_PIN_GROUPS]; uint64_t grow[RTS_PIN_GROUPS]; uint32_t gmin[RTS_PIN_GROUPS];
 };
@@ -247,8 +250,8 @@ struct RtsContext {
     RtsScene* scene = nullptr;          // never null after rts_create
     DevBuf<double> d_verts_world, d_normals_world;
     std::vector<RtsTargetMotion> motion; bool motion_valid = false; bool bvh_valid = false;   // bvh_valid: scene placed for `motion`
-    DevBuf<RtsTargetMotion> d_motion;
-    DevBuf<RtsTargetDev> d_targets;
+    DevBuf<char> d_params;              // device image of RtsPinned's [lc | motion | td]
+    RtsLaunchConsts* p_lc = nullptr; RtsTargetMotion* p_motion = nullptr; RtsTargetDev* p_targets = nullptr;     // ... and its parts
     // hierarchy: static nodes + leaf order (set_scene), leaf records refreshed per pulse
     uint32_t stack_lds = RTS_STACK_LDS;
     int grid_mult = 4, grid_spare = 160; bool grid_spare_forced = false; bool tile_lpt = true; double ew_rel = 1.7763568394002505e-15;   // per-handle knobs (rts_create reads RTS_GRID_MULT / RTS_GRID_SPARE / RTS_TILE_LPT / RTS_EW_REL)
@@ -257,19 +260,22 @@ struct RtsContext {
     DevBuf<RtsRxDev> d_rx; uint32_t n_rx = 0;
     // per pulse
     uint64_t ray_first = 0; uint32_t n_rays = 0;
-    DevBuf<RtsEndRecord> d_recv, d_all; DevBuf<unsigned long long> d_counters, d_block_counters, d_timeline;
+    DevBuf<RtsEndRecord> d_recv, d_all; DevBuf<unsigned long long> d_block_counters, d_timeline; unsigned long long* p_counters = nullptr;      // (the 16 counters live behind the draw counters: one fill zeroes both)
     DevBuf<uint32_t> d_tile_cost, d_tile_key, d_tile_key_sorted, d_tile_id, d_tile_order, d_tile_hist, d_tile_ctr;
     uint32_t coop_floor = 7500;         // ... more than this many cost units (shader clocks >> 6; 7 500 = 0.2 ms of one wave) (RTS_COOP_FLOOR)
     uint32_t coop_seg_cost = 300;       // ... and at least this many cost units PER TRACED SEGMENT (300 = 8 us: ~500 walk steps per segment with every lane busy) (RTS_COOP_SEG) --
     double coop_seg_ratio = 30.0;       // ... or, once the handle has traced a pulse, this many times the LAUNCH's mean cost per segment (kernel time x resident waves / segments),
                                         // whichever is larger: tile durations stretch when other pulses share the GPU, and so does the mean (RTS_COOP_SEG_RATIO)
     double last_units_per_segment = 0;  // that mean, of the handle's previous launch (0: none yet)
+    double coop_big = 0.0;              // ... or ANY tile costing more than this multiple of the balanced time, whatever its shape (RTS_COOP_BIG; 0 = off, the default:
+                                        // measured on C3 at 0.8 / 1.0 / 1.3 -- the slowest tile of a launch is rarely the slowest of the previous one once the target moves,
+                                        // the launch's duration did not change (0.70-0.77 ms, peaks of 1.0 ms as before) and the handle's first such launch takes 10 ms)
     double coop_frac = 0.5;            // a tile costing more than this fraction of the launch's balanced time is traced as cooperative units (RTS_COOP_FRAC; 0: never)
     bool tile_cost_pending = false, tile_hist_any = false; uint64_t tile_cost_sig[4] = {0, 0, 0, 0}; uint32_t tile_hist_n = 0;   // per-global-tile cost history (rts_post.hip)
     DevBuf<float> d_dir_hist; DevBuf<uint32_t> d_pmask; bool use_pmask = true, pre_dense = false;
     DevBuf<int32_t> d_hit_prim; DevBuf<float> d_hit_t; DevBuf<int32_t> d_stack_ovf; DevBuf<RtsChildState> d_child;
     DevBuf<uint64_t> d_rk64, d_rk64_sorted;
-    RtsTraceArgs last_args; RtsLaunchConsts last_lc; DevBuf<RtsLaunchConsts> d_lc;
+    RtsTraceArgs last_args; RtsLaunchConsts last_lc;
     // received set (ordered, expanded)
     uint64_t n_recv = 0;
     DevBuf<uint32_t> d_rk, d_rk_sorted, d_ri, d_ri_sorted;
@@ -282,8 +288,10 @@ struct RtsContext {
     std::vector<RtsGroup> groups; bool agg_valid = false; uint64_t recv_index_base = 0;
     RtsCubeParams cube_params; double* cube = nullptr; DevBuf<double> d_cube_own; bool cube_set = false;
     DevBuf<double> d_doppler_own; double* doppler = nullptr; uint32_t doppler_n = 0;       // slow-time transform of the cube (rts_cube_doppler)
+    bool agg_delay_in = true;           // rts_aggregate_device: the delay / phase arrays carry initial sums (rs::kernel_wrapper's in-out arguments); false: they start at zero
     int64_t agg_base_local = 0;         // pathMatch value of received ray i after rts_aggregate = agg_base_local + i
-    RtsPinned* pin = nullptr; DevBuf<double> d_rcsval; int n_cu = 0; bool stats_pending = false; bool agg_timed = false, fin_timed = false;
+    RtsPinned* pin = nullptr; RtsPinned* pin_dev = nullptr;      // pinned host staging and its address on the device: kernels write the small per-pulse read-backs (counters, group table) straight into it
+    bool rcs_uploaded = false; DevBuf<double> d_rcsval; int n_cu = 0; bool stats_pending = false; bool agg_timed = false, fin_timed = false;
     RtsStats stats;
     RtsGate* gate = nullptr; bool pulse_open = false;   // gate: never null after rts_create
 };

@@ -129,10 +129,10 @@ __device__ __forceinline__ uint32_t tile_global(const RtsTileShape& s, uint32_t 
 // no kernel, no readback of its own (a single-block reduction + a 4-byte device-to-host copy per pulse on the handle's
 // stream cost the three-pulse pipeline 7 %: 0.68 -> 0.73 ms per pulse).  head[0..1] = sum (u64), head[2] = count; zeroed with
 // the draw counters they share a buffer with.
-struct RtsHeadRule { double frac; uint32_t floor_cost, resident_waves; };
+struct RtsHeadRule { double frac, big; uint32_t floor_cost, resident_waves; };
 
 // fold the costs measured by the previous launch into the history
-__global__ void k_tile_merge(const uint32_t* __restrict__ cost, RtsTileShape prev, uint32_t* __restrict__ hist, uint32_t n_hist, unsigned long long* __restrict__ head_sum)
+__global__ void k_tile_merge(uint32_t* __restrict__ cost, RtsTileShape prev, uint32_t* __restrict__ hist, uint32_t n_hist, unsigned long long* __restrict__ head_sum)
 {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long v64 = 0;
@@ -140,9 +140,15 @@ __global__ void k_tile_merge(const uint32_t* __restrict__ cost, RtsTileShape pre
         const uint32_t v = cost[j], g = tile_global(prev, j);
         if (v && g < n_hist) hist[g] = v;
         v64 = v & 0x7fffffffu;
+        cost[j] = 0u;                                                          // (ready for the coming launch: no fill of its own)
     }
+    // one atomic per BLOCK (per wave they were 2 400 on one address for a C3 launch: ~25 us of serialised L2 atomics on the
+    // critical chain of every pulse)
+    __shared__ unsigned long long s_part[4];
     for (int o = 32; o > 0; o >>= 1) v64 += __shfl_down(v64, o);
-    if ((threadIdx.x & 63) == 0 && v64 && head_sum) atomicAdd(head_sum, v64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v64;
+    __syncthreads();
+    if (threadIdx.x == 0 && head_sum) { const unsigned long long t = s_part[0] + s_part[1] + s_part[2] + s_part[3]; if (t) atomicAdd(head_sum, t); }
 }
 
 // sort key of local tile j of the coming launch: ~(estimated cost record); a tile never traced yet takes the largest record
@@ -162,16 +168,21 @@ __global__ void k_tile_keys(const uint32_t* __restrict__ hist, uint32_t n_hist, 
                 if (g + d < n_hist) est = max(est, hist[g + d]);
             }
         }
-        key[j] = ~est; id[j] = j;
-        if (head_count && rule.frac > 0.0 && (est >> 31)) {
-            double thr = rule.frac * (double)head_sum[0] / (double)(rule.resident_waves ? rule.resident_waves : 1u);
-            if (thr < (double)rule.floor_cost) thr = (double)rule.floor_cost;
-            is_head = ((double)(est & 0x7fffffffu) > thr) ? 1u : 0u;
+        // head of the order = the tiles the cooperative kernel traces: LONG WALKS tiles above frac x the balanced time (and, as an
+        // experiment that is OFF by default -- RtsContext::coop_big -- any tile above big x the balanced time).  The key's top bit
+        // is this DECISION (not the record's flag): the head is a prefix of the sorted order.
+        const uint32_t cost = est & 0x7fffffffu;
+        if (head_count && rule.frac > 0.0) {
+            const double balanced = (double)head_sum[0] / (double)(rule.resident_waves ? rule.resident_waves : 1u);
+            double thr = rule.frac * balanced; if (thr < (double)rule.floor_cost) thr = (double)rule.floor_cost;
+            double thr_big = rule.big * balanced; if (thr_big < (double)rule.floor_cost) thr_big = (double)rule.floor_cost;
+            is_head = (((est >> 31) && (double)cost > thr) || (rule.big > 0.0 && balanced > 0.0 && (double)cost > thr_big)) ? 1u : 0u;
         }
+        key[j] = ~((is_head << 31) | cost); id[j] = j;
     }
     if (head_count) {                                                          // (uniform)
         const unsigned long long m = __ballot(is_head != 0);
-        if ((threadIdx.x & 63) == 0 && m) atomicAdd(head_count, (uint32_t)__popcll(m));
+        if ((threadIdx.x & 63) == 0 && m) atomicAdd(head_count, (uint32_t)__popcll(m));      // (heads are rare: a handful of waves at most)
     }
 }
 
@@ -186,7 +197,7 @@ int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_vali
     if (prev_valid) { const RtsTileShape p = shape(prev_sig); if (p.n_tiles) k_tile_merge<<<blocks_for(p.n_tiles, 256), 256, 0, st>>>(c->d_tile_cost.p, p, c->d_tile_hist.p, n_hist, reinterpret_cast<unsigned long long*>(head)); }
     RTS_HIP(c->d_tile_key.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_key_sorted.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_id.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_order.reserve(n_tiles_cur));
     const RtsTileShape cur = shape(cur_sig);
-    const RtsHeadRule rule = {c->coop_frac, c->coop_floor, resident_waves};
+    const RtsHeadRule rule = {c->coop_frac, c->coop_big, c->coop_floor, resident_waves};
     k_tile_keys<<<blocks_for(n_tiles_cur, 256), 256, 0, st>>>(c->d_tile_hist.p, n_hist, cur, c->d_tile_key.p, c->d_tile_id.p, reinterpret_cast<const unsigned long long*>(head), head ? head + 2 : nullptr, rule);
     size_t tmp = 0;
     RTS_HIP(rocprim::radix_sort_pairs(nullptr, tmp, c->d_tile_key.p, c->d_tile_key_sorted.p, c->d_tile_id.p, c->d_tile_order.p, n_tiles_cur, 0, 32, st));
@@ -259,8 +270,14 @@ int rts_post_finalise(RtsContext* c, const double* rcs_host, double wl, double g
     if (R == 0) return RTS_OK;
     const uint32_t nt = (uint32_t)c->scene->meshes.size();
     RTS_HIP(c->d_rcsval.reserve(nt + 1));
-    for (uint32_t t = 0; t < nt && t < 256; t++) c->pin->rcs[t] = rcs_host[t];
-    if (nt) RTS_HIP(hipMemcpyAsync(c->d_rcsval.p, c->pin->rcs, sizeof(double)*nt, hipMemcpyHostToDevice, c->stream));
+    bool changed = !c->rcs_uploaded;
+    for (uint32_t t = 0; t < nt && t < 256; t++) changed = changed || memcmp(&c->pin->rcs[t], &rcs_host[t], sizeof(double)) != 0;
+    if (changed) {                                                            // (the same values pulse after pulse: uploaded once)
+        RTS_HIP(hipStreamSynchronize(c->stream));                            // an upload of the previous values may still read the staging
+        for (uint32_t t = 0; t < nt && t < 256; t++) c->pin->rcs[t] = rcs_host[t];
+        if (nt) RTS_HIP(hipMemcpyAsync(c->d_rcsval.p, c->pin->rcs, sizeof(double)*nt, hipMemcpyHostToDevice, c->stream));
+        c->rcs_uploaded = true;
+    }
     k_finalise<<<blocks_for(R, 256), 256, 0, c->stream>>>(c->d_rx_rays.p, c->d_rx_paths.p, R, c->depth, c->d_rcsval.p, nt, wl, gt, gr, carrier, cspeed);
     RTS_HIP(hipGetLastError());
     return RTS_OK;
@@ -559,7 +576,7 @@ __global__ void k_agg_scatter(PerRayData* __restrict__ rays, const uint32_t* __r
                               const double* __restrict__ gsum, const uint32_t* __restrict__ gmin, const double* __restrict__ rxtot,
                               const uint32_t* __restrict__ rxmin, uint32_t n_rx_tab, uint32_t R, int64_t base,
                               const double* __restrict__ npath0, const double* __restrict__ power0, const double* __restrict__ doppler0,
-                              double* __restrict__ delay, double* __restrict__ phase, int32_t* __restrict__ pm, int32_t pm_init_const, int use_pm_in)
+                              double* __restrict__ delay, double* __restrict__ phase, int32_t* __restrict__ pm, int32_t pm_init_const, int use_pm_in, int dly_in)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R) return;
@@ -571,8 +588,8 @@ __global__ void k_agg_scatter(PerRayData* __restrict__ rays, const uint32_t* __r
     if (direct && rx < n_rx_tab) { s = rxtot + 5*(size_t)rx; mn = rxmin[rx]; } else { s = gsum + 5*(size_t)g; mn = gmin[g]; }
     const double npath = (npath0 ? npath0[r] : 0.0) + s[0];
     const double psum = (power0 ? power0[r] : 0.0) + s[1];
-    const double dsum = delay[r] + s[2];
-    const double phsum = phase[r] + s[3];
+    const double dsum = (dly_in ? delay[r] : 0.0) + s[2];                     // (dly_in = 0: the caller's delay / phase sums start at zero -- no fill of the two arrays)
+    const double phsum = (dly_in ? phase[r] : 0.0) + s[3];
     const double dopsum = (doppler0 ? doppler0[r] : 0.0) + s[4];
     double dly = dsum, ph = phsum;
     if (npath > 0) {                                                          // myKernel2
@@ -586,6 +603,18 @@ __global__ void k_agg_scatter(PerRayData* __restrict__ rays, const uint32_t* __r
     const int64_t m = base + (int64_t)mn;
     const int32_t prev = use_pm_in ? pm[r] : pm_init_const;
     pm[r] = (m < (int64_t)prev) ? (int32_t)m : prev;                          // if (r < d_pathMatch[i]) d_pathMatch[i] = r
+}
+
+// the group count and the first `spec` groups of the table, into the handle's pinned host block (device addresses of its members)
+__global__ void k_agg_export(const uint32_t* __restrict__ d_G, const double* __restrict__ gsum, const uint32_t* __restrict__ gmin, const uint64_t* __restrict__ gkey, const uint64_t* __restrict__ grow,
+                             uint32_t spec, uint32_t* __restrict__ h_G, double* __restrict__ h_gsum, uint32_t* __restrict__ h_gmin, uint64_t* __restrict__ h_gkey, uint64_t* __restrict__ h_grow)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, G = *d_G;
+    if (i == 0) *h_G = G;
+    if (i >= spec || i >= G) return;
+    for (int k = 0; k < 5; k++) h_gsum[5 * (size_t)i + k] = gsum[5 * (size_t)i + k];
+    h_gmin[i] = gmin[i]; h_gkey[i] = gkey[i];
+    if (grow) h_grow[i] = grow[i];
 }
 
 // Aggregates R device-resident rays.  d_delay/d_phase/d_pm are in-out (initial values as the
@@ -655,7 +684,7 @@ int rts_aggregate_device(RtsContext* c, int32_t max_path, int32_t max_rx, const 
     k_agg_groupinfo<<<blocks_for(R, 256), 256, 0, st>>>(gstart, c->d_aidx_sorted.p, c->d_akeys_sorted.p, c->d_gid.p, R, c->d_gmin.p, c->d_gkey.p, d_G, d_rows, d_rows ? c->d_grow.p : nullptr);
     k_agg_rxtot<<<n_rx_tab, 64, 0, st>>>(c->d_gkey.p, gsum, c->d_gmin.p, d_G, shift, d_rxtot, d_rxmin);
     k_agg_scatter<<<blocks_for(R, 256), 256, 0, st>>>(d_rays, c->d_aidx_sorted.p, c->d_gid.p, gsum, c->d_gmin.p, d_rxtot, d_rxmin, n_rx_tab, R,
-                                                       (int64_t)base, d_npath, d_power_sum, d_doppler_sum, d_delay, d_phase, d_pm, pm_init, pm_init == INT32_MIN ? 1 : 0);
+                                                       (int64_t)base, d_npath, d_power_sum, d_doppler_sum, d_delay, d_phase, d_pm, pm_init, pm_init == INT32_MIN ? 1 : 0, c->agg_delay_in ? 1 : 0);
     RTS_HIP(hipGetLastError());
     if (!groups) { RTS_HIP(hipStreamSynchronize(st)); return RTS_OK; }
     if (wide) {                                        // the groups' path rows, for the host copy of the table
@@ -666,11 +695,9 @@ int rts_aggregate_device(RtsContext* c, int32_t max_path, int32_t max_rx, const 
     // group table to the host: count + the first AGG_SPEC groups speculatively in one batch (pinned), rest on demand
     RtsPinned* pin = c->pin;
     const uint32_t spec = std::min<uint32_t>(R, RTS_PIN_GROUPS);
-    RTS_HIP(hipMemcpyAsync(&pin->G, d_G, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    RTS_HIP(hipMemcpyAsync(pin->gsum, gsum, sizeof(double)*5*spec, hipMemcpyDeviceToHost, st));
-    RTS_HIP(hipMemcpyAsync(pin->gmin, c->d_gmin.p, sizeof(uint32_t)*spec, hipMemcpyDeviceToHost, st));
-    RTS_HIP(hipMemcpyAsync(pin->gkey, c->d_gkey.p, sizeof(uint64_t)*spec, hipMemcpyDeviceToHost, st));
-    if (d_rows) RTS_HIP(hipMemcpyAsync(pin->grow, c->d_grow.p, sizeof(uint64_t)*spec, hipMemcpyDeviceToHost, st));
+    // (written by ONE kernel straight into the pinned block -- five small device-to-host copies per pulse before)
+    k_agg_export<<<blocks_for(spec, 256), 256, 0, st>>>(d_G, gsum, c->d_gmin.p, c->d_gkey.p, d_rows ? c->d_grow.p : nullptr, spec, &c->pin_dev->G, c->pin_dev->gsum, c->pin_dev->gmin, c->pin_dev->gkey, c->pin_dev->grow);
+    RTS_HIP(hipGetLastError());
     RTS_HIP(hipStreamSynchronize(st));
     const uint32_t G = pin->G;
     const double* h_gsum = pin->gsum; const uint32_t* h_gmin = pin->gmin; const uint64_t* h_gkey = pin->gkey;

@@ -770,9 +770,13 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR || COOP) ? 2 : 4) k_trace(con
 }
 
 // counters[1..6] = sum over the blocks of a launch (single block; the launch has at most a few thousand blocks)
-__global__ void k_sum_counters(const unsigned long long* __restrict__ block_counters, unsigned int n_blocks, unsigned long long* __restrict__ counters, const uint32_t* __restrict__ head_count)
+// ... and writes all eight into the handle's pinned host block (host_cnt: device address of RtsPinned::cnt) -- the host reads them
+// after its wait for the stream, without a copy of their own
+__global__ void k_sum_counters(const unsigned long long* __restrict__ block_counters, unsigned int n_blocks, unsigned long long* __restrict__ counters, const uint32_t* __restrict__ head_count,
+                               unsigned long long* __restrict__ host_cnt)
 {
-    if (threadIdx.x == 7) counters[7] = head_count ? head_count[0] : 0u;     // the order's head count travels home with the counters (sizes the next cooperative grid)
+    if (threadIdx.x == 7) { const unsigned long long h = head_count ? head_count[0] : 0u; counters[7] = h; host_cnt[7] = h; }     // the order's head count travels home with the counters (sizes the next cooperative grid)
+    if (threadIdx.x == 0) host_cnt[0] = counters[0];                          // received rays (appended by the trace kernels)
     __shared__ unsigned long long s[256];
     const unsigned int k = threadIdx.x & 7u, lane = threadIdx.x >> 3;                   // 32 partial sums per counter
     unsigned long long v = 0;
@@ -782,7 +786,7 @@ __global__ void k_sum_counters(const unsigned long long* __restrict__ block_coun
     if (threadIdx.x >= 1 && threadIdx.x <= 6) {
         unsigned long long t = 0;
         for (unsigned int l = 0; l < 32; l++) t += s[l * 8 + threadIdx.x];
-        counters[threadIdx.x] = t;
+        counters[threadIdx.x] = t; host_cnt[threadIdx.x] = t;
     }
 }
 
@@ -810,7 +814,11 @@ static void rts_trace_dispatch(const RtsTraceArgs& a, bool count_traversal, unsi
 // 0.69 -> 0.93 ms per pulse on C3, where there is no cooperative work at all.
 int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a, bool count_traversal, unsigned coop_grid)
 {
-    if (a.n_rays == 0) return RTS_OK;
+    if (a.n_rays == 0) {                                            // nothing to trace (an interleaved part without launch indices): the counters still go home, as zeros
+        k_sum_counters<<<1, 256, 0, c->tstream>>>(a.block_counters, 0u, a.counters, nullptr, c->pin_dev->cnt);
+        RTS_HIP(hipGetLastError());
+        return RTS_OK;
+    }
     const unsigned grid = a.total_threads / RTS_BLOCK;
     hipStream_t st = c->tstream;
     if (coop_grid) {
@@ -822,7 +830,7 @@ int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a, bool count_traversal,
     }
     rts_trace_dispatch<false>(a, count_traversal, grid, st);
     if (coop_grid) RTS_HIP(hipStreamWaitEvent(st, c->ev_coop[1], 0));
-    k_sum_counters<<<1, 256, 0, st>>>(a.block_counters, grid + coop_grid, a.counters, a.tile_head_all);
+    k_sum_counters<<<1, 256, 0, st>>>(a.block_counters, grid + coop_grid, a.counters, a.tile_head_all, c->pin_dev->cnt);
     RTS_HIP(hipGetLastError());
     return RTS_OK;
 }
