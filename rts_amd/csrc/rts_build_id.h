@@ -1,1 +1,1 @@
-#define RTS_SOURCE_HASH "a4002d979b746ab6"
+#define RTS_SOURCE_HASH "e3e6cb5a5a3ecc32"
