@@ -137,7 +137,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--link", action="store_true", help="rts_link_handles: the handles' trace kernels run strictly one at a time")
     ap.add_argument("--inflight", type=int, default=3, help="pulses in flight per GPU; 1 = strictly sequential pulses")
-    ap.add_argument("--config", default="c3", choices=["c2", "c2file", "c3", "c3ecef", "c3ico"])
+    ap.add_argument("--config", default="c3", choices=["c2", "c2file", "c3", "c3ecef", "c3ico", "c4"], help="c3 = BASELINE configs[2] (the metric's workload); c4 = configs[3]'s scene and size on ONE transmitter (100 M launch indices per pulse: give --steps 32)")
     ap.add_argument("--shard", default="pulses", choices=["pulses", "rays"], help="N > 1: deal whole pulses to the ranks, or split every pulse over all ranks (interleaved tiles)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks")
     args = ap.parse_args()
@@ -174,6 +174,8 @@ def main():
         spec = scenes.translate(scenes.config3(W=args.width or 216), scenes.ecef_offset(lat=math.pi / 2))
     elif args.config == "c3ico":                                  # the same airframe tessellated without pole fans (secondary line)
         spec = scenes.config3(W=args.width or 216, ico=True)
+    elif args.config == "c4":                                     # BASELINE configs[3]: 4 meshes x 250 k triangles, 8 Rx, W = 465, maxRefl = 8 (transmitter 0)
+        spec = scenes.config4(W=args.width or 465)
     elif args.config == "c2":
         spec = scenes.config2(W=args.width or 100)
     else:
@@ -333,7 +335,7 @@ def main():
         except AttributeError:                                  # a library from before rts_build_id (RTS_AMD_LIB)
             lib_hash = None
         pmc_stale = pmc is not None and pmc.get("source_hash") != lib_hash
-        pmc_ok = pmc is not None and not pmc_stale and world == 1 and ((W == 216 and args.config in ("c3", "c3ecef")) or (W == 100 and args.config == "c2"))
+        pmc_ok = pmc is not None and not pmc_stale and world == 1 and ((W == 216 and args.config in ("c3", "c3ecef")) or (W == 100 and args.config == "c2") or (W == 465 and args.config == "c4"))
         roof = {"kernel": "k_trace", "kernel_ms_serial": ms_serial, "segments_per_launch": seg_serial,
                 "kernel_ms_overlapped_avg": ms_trace / launches, "gpu_ms_per_launch_timed_region": dt / args.steps * 1e3,
                 "hit_fraction": hit_fraction, "nodes_per_segment": V, "tri_tests_per_segment": T, "shaded_per_segment": Hh,
@@ -383,7 +385,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[%d]%s: %s, 1 Tx / %d Rx, W=%d (%d launch indices/pulse), maxRefl=%d, target moves every pulse (re-placed on the device per pulse; static target-space BVH4)"
-                                   % (2 if args.config.startswith("c3") else 1, " at Earth-centred coordinates" if args.config == "c3ecef" else "", spec["name"], len(spec["rx"]), W, total, spec["max_refl"]),
+                                   % (2 if args.config.startswith("c3") else (3 if args.config == "c4" else 1), " at Earth-centred coordinates" if args.config == "c3ecef" else "", spec["name"], len(spec["rx"]), W, total, spec["max_refl"]),
                        "rays_per_pulse": total, "segments_per_pulse": seg_all / args.steps, "received_per_pulse": received_all / args.steps,
                        "hit_fraction": hit_fraction, "primary_Mrays_per_s": total * args.steps / dt / 1e6,
                        "return_cube": "complex128 [%d rx][%d pulses][%d bins], all-reduced once per interval, then %d-point slow-time FFT in the library (rts_cube_doppler, inside the timed region); range-Doppler peak %.6e, max deviation from torch.fft %.1e (relative)" % (cube.shape[0], cube.shape[1], n_bins, n_fft, range_doppler_peak, range_doppler_err or 0.0),

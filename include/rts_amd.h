@@ -213,6 +213,9 @@ int rts_get_stats(RtsHandle h, RtsStats* out);
 /* Received rays of the last pulse (ray_tracer.cpp:1186-1257 before the gain/RCS update):
  * rays[R], paths[R][D] (h_rx_intersects, D = max_refr + max_refl), rcs_angles[R][D][2],
  * slots[R] = global launch index.  Any output pointer may be NULL.  capacity in rays. */
+/* Lane statistics of the last launch's traversal (counting build, RTS_FLAG_COUNT_TRAVERSAL): out3[0] walk iterations issued x 64
+ * lanes, out3[1] the part issued to lanes that took part in their tile's bounce round, out3[2] walk steps actually taken. */
+int rts_get_lane_stats(RtsHandle h, uint64_t* out3);
 int rts_received_count(RtsHandle h, uint64_t* count);
 int rts_get_received(RtsHandle h, struct PerRayData* rays, int32_t* paths, double* rcs_angles, uint64_t* slots,
                      uint64_t capacity);

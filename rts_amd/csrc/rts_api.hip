@@ -548,6 +548,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
             int rc = fill_target_placement(c, t, td[t]); if (rc != RTS_OK) { c->bvh_valid = false; c->motion_valid = false; return rc; }
             c->pin->motion[t] = c->motion[t];
         }
+        c->bvh_valid = false;                                     // (until the upload and the placement kernels below have been enqueued: an early return in between must not leave the device with the old placement)
         // (uploaded below, together with the launch constants: one copy; the placement kernels follow it)
     }
 
@@ -738,6 +739,18 @@ extern "C" int rts_get_stats(RtsHandle c, RtsStats* out)
         c->stats_pending = false;
     }
     *out = c->stats; return RTS_OK;
+}
+
+// Lane statistics of the last launch's walk (RTS_FLAG_COUNT_TRAVERSAL builds; zeros otherwise): out[0] lane-steps ISSUED (64 x the
+// longest walk of every bounce round of every tile), out[1] of them issued to lanes that were in the round at all, out[2]
+// walk steps actually taken.  1 - out[1]/out[0]: what lanes that left their tile early cost (re-packing rays between rounds could
+// recover at most this); (out[1] - out[2])/out[0]: what waiting for the round's slowest lane costs.
+extern "C" int rts_get_lane_stats(RtsHandle c, uint64_t* out3)
+{
+    if (!c || !out3) { rts_set_error("rts_get_lane_stats: null argument"); return RTS_ERR_INVALID; }
+    CHECK_CLOSED(c);
+    for (int k = 0; k < 3; k++) out3[k] = c->pin->cnt[8 + k];
+    return RTS_OK;
 }
 
 extern "C" int rts_received_count(RtsHandle c, uint64_t* count)

@@ -255,11 +255,11 @@ __device__ __forceinline__ void rts_walk_coop(const RtsTraceArgs& a, int32_t* s_
 //                  occupies ONE wave for 7-13 ms of a launch whose balanced time is 7.8 ms; as 64 cooperative units it is
 //                  spread over 64 waves that finish each ray in a few hundred wave steps.
 // The two share every expression of the payload arithmetic (same code, same operand order): results are bit-identical.
-struct RtsUnitLds { int32_t* stack; int32_t* exch; double* first; unsigned long long* path; uint32_t* n; const RtsRxDev* rx; const float (*rxp)[6]; };
+struct RtsUnitLds { int32_t* stack; int32_t* exch; double* first; unsigned long long* path; uint32_t* n; const RtsRxDev* rx; const float (*rxp)[6]; uint32_t* lane_scratch; };
 template <bool COUNT, bool KEEP_ALL, bool REFR, bool COOP>
 __device__ __forceinline__ void rts_trace_unit(const RtsTraceArgs& a, const RtsLaunchConsts& lc, const RtsUnitLds& L_, const uint32_t tid, const uint32_t gtid, const uint32_t lane,
                                                const uint32_t slot, const bool pre_on, const bool mask_on, const uint32_t D, const uint32_t max_refr, const dvec3& origin,
-                                               uint32_t& n_nodes, uint32_t& n_tris, bool& hard_overflow)
+                                               uint32_t& n_nodes, uint32_t& n_tris, bool& hard_overflow, unsigned long long (&lane_stats)[3])
 {
       int32_t* const s_stack = L_.stack; int32_t* const s_exch = L_.exch; double* const s_first = L_.first; unsigned long long* const s_path = L_.path; uint32_t* const s_n = L_.n;
       const RtsRxDev* const s_rx = L_.rx; const float (*const s_rxp)[6] = L_.rxp;
@@ -330,9 +330,9 @@ __device__ __forceinline__ void rts_trace_unit(const RtsTraceArgs& a, const RtsL
             int best_leaf = -1; uint32_t best_prim = 0xffffffffu;
             const bool primary = chain == 0 && chain_start;
             const bool may_hit = primary ? may_target : a.n_prims > 0;
+            uint32_t steps = 0;                                                // walk steps of this lane in this segment (all targets)
             if (may_hit) {
                 float t_prune = RTS_DEFAULT_TMAX;
-                uint32_t steps = 0;
                 for (uint32_t targ = 0; targ < a.n_targets; targ++) {
                     const RtsTargetDev& TG = a.targets[targ];                            // uniform index: scalar loads
                     if (TG.root < 0) continue;
@@ -372,6 +372,17 @@ __device__ __forceinline__ void rts_trace_unit(const RtsTraceArgs& a, const RtsL
                         }
                     }
                 }
+            }
+            if (COUNT && !COOP) {
+                // lane statistics of the bounce round (counting build): the wave issues max(steps) walk iterations for its 64 lanes;
+                // `alive` of them take part in the round at all, and they walk sum(steps) iterations between them
+                //   [0] += 64 max   (lane-steps issued)   [1] += alive max   (... to lanes that are in the round)   [2] += sum   (useful)
+                uint32_t* ls = L_.lane_scratch + 2u * (tid >> 6);
+                const unsigned long long act = __ballot(true);
+                if (lane == (uint32_t)(__ffsll((long long)act) - 1)) { ls[0] = 0u; ls[1] = 0u; }
+                atomicMax(&ls[0], steps); atomicAdd(&ls[1], steps);
+                const uint32_t smax = ls[0], ssum = ls[1];
+                lane_stats[0] += 64ull * smax; lane_stats[1] += (unsigned long long)__popcll(act) * smax; lane_stats[2] += ssum;
             }
             if (KEEP_ALL && chain == 0 && (!COOP || lane == 0)) {
                 const size_t hidx = (size_t)slot * (a.max_refl + 1) + reflDepth;
@@ -668,7 +679,9 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR || COOP) ? 2 : 4) k_trace(con
     const uint32_t n_head = (a.tile_head && a.tile_order) ? min(min(__builtin_amdgcn_readfirstlane(a.tile_head[0]), n_tiles), 16384u) : 0u;
     const uint32_t n_units = COOP ? 64u * n_head : n_tiles - n_head;
     __shared__ int32_t s_exch[COOP ? RTS_BLOCK : 1];             // exchange rows of the cooperative walk (one 64-entry row per wave)
-    const RtsUnitLds ul = {s_stack, s_exch, s_first, s_path, s_n, s_rx, s_rxp};
+    __shared__ uint32_t s_lane_scratch[COUNT ? 2 * (RTS_BLOCK / 64) : 1];      // (counting build: per-wave max / sum of a round's walk steps)
+    const RtsUnitLds ul = {s_stack, s_exch, s_first, s_path, s_n, s_rx, s_rxp, s_lane_scratch};
+    unsigned long long lane_stats[3] = {0ull, 0ull, 0ull};
     const uint32_t per_stripe = (n_units + RTS_TILE_CTRS - 1u) / RTS_TILE_CTRS;
     const uint32_t single_draws = per_stripe >= 1024u ? per_stripe / 4u : per_stripe;      // (short queues: one tile per draw throughout)
     // The pending draw is held in a register of lane 0 (so that its latency hides behind the tiles traced meanwhile) -- except
@@ -711,7 +724,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR || COOP) ? 2 : 4) k_trace(con
       if (!COOP) atomicAnd(&s_n[tid], 0x003fffffu);              // (ds_and_b32: the tile's own segment count starts at zero; a register for it would be the 129th)
       const unsigned long long tl_tile = (COUNT && a.timeline && lane == 0) ? wall_clock64() : 0ULL;
       if (slot < a.n_rays) {
-          rts_trace_unit<COUNT, KEEP_ALL, REFR, COOP>(a, lc, ul, tid, gtid, lane, slot, pre_on, mask_on, D, max_refr, origin, n_nodes, n_tris, hard_overflow);
+          rts_trace_unit<COUNT, KEEP_ALL, REFR, COOP>(a, lc, ul, tid, gtid, lane, slot, pre_on, mask_on, D, max_refr, origin, n_nodes, n_tris, hard_overflow, lane_stats);
       }   // slot < n_rays
       // (the segment count of the tile is only formed for tiles long enough to matter: an all-miss tile is ~100 instructions)
       const unsigned long long dt = (unsigned long long)(clock64() - tile_t0) >> 6;             // (s_memtime: wave-uniform)
@@ -743,6 +756,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR || COOP) ? 2 : 4) k_trace(con
     // ------------------------------------------------------------------ counters: wave reduce -> block reduce (LDS, the
     // traversal stack is dead by now) -> one plain store per block; k_sum_counters adds the blocks up.  (One atomic per
     // wave on the same two addresses -- 32 k same-line L2 atomics -- cost a fixed ~0.35 ms at the tail of every launch.)
+    if (COUNT && !COOP && lane == 0 && lane_stats[0]) { atomicAdd(&a.counters[8], lane_stats[0]); atomicAdd(&a.counters[9], lane_stats[1]); atomicAdd(&a.counters[10], lane_stats[2]); }
     // (the thread index is re-formed here from the wave's number -- scalar, kept since the start -- and the lane number instead of
     // being carried through the kernel: the allocator, at its 128-register limit, otherwise parks threadIdx.x in scratch in the
     // prologue and reloads it here)
@@ -777,6 +791,7 @@ __global__ void k_sum_counters(const unsigned long long* __restrict__ block_coun
 {
     if (threadIdx.x == 7) { const unsigned long long h = head_count ? head_count[0] : 0u; counters[7] = h; host_cnt[7] = h; }     // the order's head count travels home with the counters (sizes the next cooperative grid)
     if (threadIdx.x == 0) host_cnt[0] = counters[0];                          // received rays (appended by the trace kernels)
+    if (threadIdx.x >= 8 && threadIdx.x <= 10) host_cnt[threadIdx.x] = counters[threadIdx.x];      // lane statistics of the counting build
     __shared__ unsigned long long s[256];
     const unsigned int k = threadIdx.x & 7u, lane = threadIdx.x >> 3;                   // 32 partial sums per counter
     unsigned long long v = 0;
