@@ -30,6 +30,7 @@ for p in insts f64 active wait ta ta2 td tcp tcp2 tcc fetch write; do
     timeout -k 10 240 rocprofv3 --pmc ${PASS[$p]} --kernel-trace --output-format csv -d "$OUT/$p" -- python3 "$ROOT/tools/trace_bench.py" "$WL" "$REPS" > "$OUT/$p.log" 2>&1
     rc=$?
     tail -1 "$OUT/$p.log"
+    find "$OUT/$p" -name "*_kernel_trace.csv" -delete 2>/dev/null; find "$OUT/$p" -name "*_agent_info.csv" -delete 2>/dev/null      # (gpurun copies back 64 MiB at most: the counter tables are what tools/pmc_derive.py reads)
     if [ $rc -ne 0 ]; then echo "pass $p failed rc=$rc"; rc_all=1; if [ $rc -ge 124 ]; then echo "timeout/kill: stopping"; exit 1; fi; fi
 done
 # un-profiled reference timing of the same command

@@ -1,14 +1,30 @@
+# the judged artefacts of a round, in two calls (the bench lines price themselves with counters of the SAME build):
+#   tools/round_artefacts.sh <tag> pmc      counters of c3 / dense control / c2 / c4  -> then, on the CPU: tools/pmc_derive.py <tag> <workload>, commit
+#   tools/round_artefacts.sh <tag> bench    bench lines, kernel stats, timelines, CPU baseline, adapter bench, RCCL world-1 line
 cd "${GRAFT_REPO_ROOT:?}"
-python bench.py --steps 20 --warmup 5 > gpurun_out/r02d_bench_c3_steps20.json 2> gpurun_out/r02d_bench_c3_steps20.err; tail -c 1500 gpurun_out/r02d_bench_c3_steps20.json; echo
-python bench.py --no-cpu-baseline > gpurun_out/r02d_bench_c3_default.json 2>&1
-python bench.py --no-cpu-baseline --config c3ecef --steps 64 > gpurun_out/r02d_bench_c3ecef.json 2>&1
-python bench.py --no-cpu-baseline --config c2 --steps 64 > gpurun_out/r02d_bench_c2.json 2>&1
-python bench.py --no-cpu-baseline --config c2file --steps 64 > gpurun_out/r02d_bench_c2file.json 2>&1
-for f in c3_default c3ecef c2 c2file; do python -c "
-import json,sys
-j=json.loads(open('gpurun_out/r02d_bench_$f.json').read().strip().splitlines()[-1])
-r=j['roofline']
-print('$f', round(j['value']), 'Mrays/s', round(j['ms_per_step'],3), 'ms/pulse | serial', round(r['kernel_ms_serial'],3), 'hit', round(r['hit_fraction'],3), 'V,T', round(r['nodes_per_segment'],2), round(r['tri_tests_per_segment'],2), '| bound', r['bound'], r['frac'], 'valu', r.get('valu_issue_frac'), 'td', r.get('vmem_return_path_frac'))"; done
-cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_r02d -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/r02d_bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/gpurun_out/r02d_bench_under_rocprof.err; cd $GRAFT_REPO_ROOT
-ls gpurun_out/prof_r02d/*/ | head
-python tools/cpu_baseline.py > gpurun_out/r02d_cpu_baseline.log 2>&1; cat gpurun_out/r02d_cpu_baseline.log
+T=${1:-r03b}; WHAT=${2:-bench}
+mkdir -p gpurun_out
+if [ "$WHAT" = pmc ]; then
+  for w in c3 c3narrow c2 c4; do bash tools/pmc_collect.sh $T $w 6 > gpurun_out/${T}_pmc_$w.log 2>&1; tail -1 gpurun_out/${T}_pmc_$w.log; done
+  exit 0
+fi
+python bench.py --steps 20 --warmup 5 > gpurun_out/${T}_bench_c3_steps20.json 2> gpurun_out/${T}_bench_c3_steps20.err
+python bench.py --no-cpu-baseline > gpurun_out/${T}_bench_c3_default_256steps.json 2>/dev/null
+python bench.py --no-cpu-baseline --inflight 1 --steps 64 > gpurun_out/${T}_bench_c3_inflight1.json 2>/dev/null
+python bench.py --no-cpu-baseline --config c3ecef --steps 64 > gpurun_out/${T}_bench_c3ecef.json 2>/dev/null
+python bench.py --no-cpu-baseline --config c2 --steps 64 > gpurun_out/${T}_bench_c2.json 2>/dev/null
+python bench.py --no-cpu-baseline --config c4 --steps 24 --warmup 6 > gpurun_out/${T}_bench_c4.json 2>/dev/null
+RTS_BUILDER=host python bench.py --no-cpu-baseline --steps 64 > gpurun_out/${T}_bench_c3_host_tree.json 2>/dev/null
+for f in c3_steps20 c3_default_256steps c3_inflight1 c3ecef c2 c4 c3_host_tree; do python -c "
+import json
+j=json.loads(open('gpurun_out/${T}_bench_$f.json').read().strip().splitlines()[-1]); r=j['roofline']
+print('$f', round(j['value']), 'Mrays/s', round(j['ms_per_step'],3), 'ms/pulse | serial', round(r['kernel_ms_serial'],3), 'hit', round(r['hit_fraction'],3), '| bound', r['bound'], r['frac'], r.get('frac_if_every_inst_cost_4_cycles'), 'setup_s', round(j['config']['scene_setup_s'],3))"; done
+cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$T -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/${T}_bench_under_rocprof.json 2> /dev/null; cd $GRAFT_REPO_ROOT
+find gpurun_out/prof_$T -name "*_kernel_trace.csv" -delete; find gpurun_out/prof_$T -name "*_agent_info.csv" -delete
+python tools/timeline.py c3 > gpurun_out/${T}_timeline_c3.log 2>&1; python tools/timeline.py c4 > gpurun_out/${T}_timeline_c4.log 2>&1; rm -f gpurun_out/timeline.bin gpurun_out/tile_us.npy
+python tools/count_stats.py c3 c3narrow c2 c4 > gpurun_out/${T}_count_stats.log 2>&1
+tools/adapter_bench_bin 216 64 3 6 6 > gpurun_out/${T}_adapter_bench.json 2>&1; tail -1 gpurun_out/${T}_adapter_bench.json
+RTS_BUILDER=host tools/adapter_bench_bin 216 64 3 6 6 > gpurun_out/${T}_adapter_bench_host_tree.json 2>&1; tail -1 gpurun_out/${T}_adapter_bench_host_tree.json
+RTS_COOP_FRAC=0 tools/adapter_bench_bin 216 64 3 6 6 > gpurun_out/${T}_adapter_bench_no_coop.json 2>&1; tail -1 gpurun_out/${T}_adapter_bench_no_coop.json
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --backend nccl > gpurun_out/${T}_bench_rccl_world1.json 2> gpurun_out/${T}_bench_rccl_world1.err
+python tools/cpu_baseline.py c1 c2 c3 > gpurun_out/${T}_cpu_baseline.log 2>&1; cat gpurun_out/${T}_cpu_baseline.log
