@@ -31,6 +31,7 @@ for p in insts f64 active wait ta ta2 td tcp tcp2 tcc fetch write; do
     rc=$?
     tail -1 "$OUT/$p.log"
     find "$OUT/$p" -name "*_kernel_trace.csv" -delete 2>/dev/null; find "$OUT/$p" -name "*_agent_info.csv" -delete 2>/dev/null      # (gpurun copies back 64 MiB at most: the counter tables are what tools/pmc_derive.py reads)
+    for f in $(find "$OUT/$p" -name "*_counter_collection.csv"); do { head -1 "$f"; grep k_trace "$f"; } > "$f.tmp" && mv "$f.tmp" "$f"; done      # ... and of them the trace kernels' rows (the device hierarchy build alone is ~1 000 dispatches)
     if [ $rc -ne 0 ]; then echo "pass $p failed rc=$rc"; rc_all=1; if [ $rc -ge 124 ]; then echo "timeout/kill: stopping"; exit 1; fi; fi
 done
 # un-profiled reference timing of the same command

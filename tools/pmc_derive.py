@@ -58,6 +58,9 @@ def main():
             continue
         meta = m or meta
         use = rows[1:]                                                      # (first launch of the handle: index-order tiles, cold caches)
+        if len(crows) >= 2:                                                 # launches with a cooperative kernel: the steady state starts AFTER the first of them (it runs on a hint one launch old)
+            k = len(crows) - 1
+            use = rows[-k:]; crows = crows[-k:]
         avg = {k: sum(r.get(k, 0.0) for r in use) / len(use) for k in use[0]}
         ordinary_us = avg["_ns"] / 1e3
         coop_us = 0.0
