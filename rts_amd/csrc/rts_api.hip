@@ -97,6 +97,9 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     { const char* e = getenv("RTS_TILE_LPT"); if (e && e[0] == '0') c->tile_lpt = false; }
     { const char* e = getenv("RTS_COOP_FRAC"); if (e) { const double v = atof(e); if (v >= 0) c->coop_frac = v; } }                  // 0: no cooperative units; tests: tiny values put every tile at the head
     { const char* e = getenv("RTS_COOP_FLOOR"); if (e) c->coop_floor = (uint32_t)std::max(0, atoi(e)); }
+    { const char* e = getenv("RTS_ASYNC_IDLE0"); if (e) c->async_idle0 = (uint32_t)std::min(64, std::max(0, atoi(e))); }
+    { const char* e = getenv("RTS_ASYNC_IDLE1"); if (e) c->async_idle1 = (uint32_t)std::min(64, std::max(1, atoi(e))); }
+    { const char* e = getenv("RTS_ASYNC_AGE"); if (e) c->async_age = (uint32_t)std::max(0, atoi(e)); }
     { const char* e = getenv("RTS_COOP_SEG"); if (e) c->coop_seg_cost = (uint32_t)std::max(0, atoi(e)); }
     { const char* e = getenv("RTS_COOP_SEG_RATIO"); if (e) c->coop_seg_ratio = std::max(0.0, atof(e)); }
     { const char* e = getenv("RTS_COOP_BIG"); if (e) c->coop_big = std::max(0.0, atof(e)); }
@@ -590,19 +593,16 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     c->pin->lc = lc;
     RTS_HIP(hipMemcpyAsync(c->d_params.p, &c->pin->lc, moved && n_targets ? offsetof(RtsPinned, td) + sizeof(RtsTargetDev) * n_targets : sizeof(RtsLaunchConsts), hipMemcpyHostToDevice, st));
     a.lc = c->p_lc;
-    if (moved) {
-        int rc = rts_scene_place(c); if (rc != RTS_OK) return rc;
-        RTS_STAGE(c, "scene_place");
-        c->bvh_valid = true; c->stats.bvh_rebuilt = 1;
-    }
+    { int rc = rts_scene_place(c, lc, moved); if (rc != RTS_OK) return rc; }      // placement (a target moved) + the primary-ray mask: one pass over the leaves for both
+    if (moved) { RTS_STAGE(c, "scene_place"); c->bvh_valid = true; c->stats.bvh_rebuilt = 1; }
     RTS_HIP(hipEventRecord(c->ev[1], st));
-    { int rc = rts_primary_mask_build(c, lc); if (rc != RTS_OK) return rc; }
     a.ray_first = first; a.n_rays = n; a.W = W; a.max_refl = c->params.max_refl; a.smooth = c->params.interpolate_smooth ? 1u : 0u;
     a.n_prims = c->scene->n_prims; a.n_targets = n_targets; a.n_rx = c->n_rx; a.keep_all = keep_all ? 1u : 0u;
     a.max_refr = c->params.max_refr; a.rows = a.max_refr ? c->params.max_refl + 3 : 1;
     const uint32_t chains = a.max_refr ? 3u : 1u;
     if ((uint64_t)n * chains > 0xfffffff0ULL) { rts_set_error("rts_trace_pulse: rays x chains exceeds 2^32"); return RTS_ERR_UNSUPPORTED; }
     a.total_threads = grid * RTS_BLOCK;
+    a.async_idle0 = c->async_idle0; a.async_idle1 = c->async_idle1; a.async_age = c->async_age;
     a.coop_seg_cost = c->coop_seg_cost; a.coop_min_cost = c->coop_seg_cost ? std::min<uint32_t>(c->coop_floor, 1875u) : 0u;      // (nothing shorter than 50 us is looked at; RTS_COOP_SEG=0: every tile is flagged)
     if (c->coop_seg_cost && c->last_units_per_segment > 0.0)
         a.coop_seg_cost = (uint32_t)std::min(4.0e9, std::max((double)c->coop_seg_cost, c->coop_seg_ratio * c->last_units_per_segment));

@@ -32,23 +32,6 @@ __global__ void k_place(const double* __restrict__ local, double* __restrict__ w
     world[3*i] = x; world[3*i+1] = y; world[3*i+2] = z;
 }
 
-// Leaf record i = primitive leaf_prim[i] with its world-space vertices pre-gathered (the reference gathers through
-// dbuf_triangles -> dbuf_triVertices per test, triangle_mesh.cu:147-154).
-__global__ void k_leaves(const uint32_t* __restrict__ leaf_prim, const uint32_t* __restrict__ tri_vidx, const double* __restrict__ verts,
-                         const uint32_t* __restrict__ prim_targ, RtsLeafTri* __restrict__ leaves, uint32_t n)
-{
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t g = leaf_prim[i];
-    uint32_t a = tri_vidx[3*g], b = tri_vidx[3*g+1], c = tri_vidx[3*g+2];
-    RtsLeafTri L;
-    L.p0x = verts[3*a]; L.p0y = verts[3*a+1]; L.p0z = verts[3*a+2];
-    L.p1x = verts[3*b]; L.p1y = verts[3*b+1]; L.p1z = verts[3*b+2];
-    L.p2x = verts[3*c]; L.p2y = verts[3*c+1]; L.p2z = verts[3*c+2];
-    L.prim = g; L.targ = prim_targ[g];
-    leaves[i] = L;
-}
-
 // --------------------------------------------------------------------------- primary-ray mask (see RtsMaskFrame)
 // One thread per LEAF, in leaf order: neighbouring leaves are neighbours in space, so the 256 triangles of a block cover a
 // compact patch of the bitmap.  The block rasterises into an LDS tile over the bounding rectangle of its triangles' rectangles
@@ -56,22 +39,18 @@ __global__ void k_leaves(const uint32_t* __restrict__ leaf_prim, const uint32_t*
 // (100 k triangles marking the same ~5 k words: same-line atomics serialise in L2, the per-triangle version took 80-130 us).
 // A block whose patch does not fit the tile falls back to per-triangle atomics.
 #define RTS_MASK_TILE_WORDS 2048
-__global__ void __launch_bounds__(256) k_primary_mask(const uint32_t* __restrict__ leaf_prim, const uint32_t* __restrict__ tri_vidx, const double* __restrict__ verts, uint32_t n_leaves,
-                                                      double ox, double oy, double oz, RtsMaskFrame f, uint32_t* __restrict__ mask)
+struct RtsMaskLds { uint32_t tile[RTS_MASK_TILE_WORDS]; int box[4]; };          // box: min iu0, min iv0, max iu1, max iv1 of the block
+// (called by every thread of the block: `have` = the thread holds a triangle, p[k] = its world-space vertices)
+__device__ __forceinline__ void rts_mask_mark(RtsMaskLds& S, const bool have, const double (&p)[9], const double ox, const double oy, const double oz, const RtsMaskFrame& f, uint32_t* __restrict__ mask)
 {
-    __shared__ uint32_t s_tile[RTS_MASK_TILE_WORDS];
-    __shared__ int s_box[4];                                        // min iu0, min iv0, max iu1, max iv1 of the block
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t* flag = mask + (size_t)f.n * f.n / 32u;
-    if (threadIdx.x == 0) { s_box[0] = 0x7fffffff; s_box[1] = 0x7fffffff; s_box[2] = -1; s_box[3] = -1; }
+    if (threadIdx.x == 0) { S.box[0] = 0x7fffffff; S.box[1] = 0x7fffffff; S.box[2] = -1; S.box[3] = -1; }
     __syncthreads();
     int iu0 = 0, iu1 = -1, iv0 = 0, iv1 = -1;                       // empty rectangle: nothing to mark
-    if (i < n_leaves) {
-        const uint32_t prim = leaf_prim[i];
+    if (have) {
         double u[3], v[3]; bool finite = true, front = true;
         for (int k = 0; k < 3; k++) {
-            const uint32_t a = tri_vidx[3*(size_t)prim + k];
-            const double px = verts[3*(size_t)a] - ox, py = verts[3*(size_t)a + 1] - oy, pz = verts[3*(size_t)a + 2] - oz;
+            const double px = p[3*k] - ox, py = p[3*k + 1] - oy, pz = p[3*k + 2] - oz;
             finite = finite && isfinite(px) && isfinite(py) && isfinite(pz);
             const double w = px * (double)f.bx + py * (double)f.by + pz * (double)f.bz;
             front = front && (w > 0.0) && (w * w > 1.0e-6 * (px*px + py*py + pz*pz));   // well in front of the transmitter (within ~89.94 degrees of the boresight)
@@ -91,18 +70,18 @@ __global__ void __launch_bounds__(256) k_primary_mask(const uint32_t* __restrict
         }
     }
     const bool any = iu1 >= iu0 && iv1 >= iv0;
-    if (any) { atomicMin(&s_box[0], iu0); atomicMin(&s_box[1], iv0); atomicMax(&s_box[2], iu1); atomicMax(&s_box[3], iv1); }
+    if (any) { atomicMin(&S.box[0], iu0); atomicMin(&S.box[1], iv0); atomicMax(&S.box[2], iu1); atomicMax(&S.box[3], iv1); }
     __syncthreads();
-    if (s_box[2] < 0) return;                                       // (uniform) nothing to mark in this block
-    const int W0 = s_box[0] >> 5, V0 = s_box[1], TW = (s_box[2] >> 5) - W0 + 1, TH = s_box[3] - V0 + 1;
+    if (S.box[2] < 0) return;                                       // (uniform) nothing to mark in this block
+    const int W0 = S.box[0] >> 5, V0 = S.box[1], TW = (S.box[2] >> 5) - W0 + 1, TH = S.box[3] - V0 + 1;
     const bool tiled = (long long)TW * TH <= RTS_MASK_TILE_WORDS;   // (uniform)
-    if (tiled) { for (int w = threadIdx.x; w < TW * TH; w += blockDim.x) s_tile[w] = 0u; __syncthreads(); }
+    if (tiled) { for (int w = threadIdx.x; w < TW * TH; w += blockDim.x) S.tile[w] = 0u; __syncthreads(); }
     if (any) {
         for (int iv = iv0; iv <= iv1; iv++) {
             for (int w0 = iu0 >> 5; w0 <= (iu1 >> 5); w0++) {       // one atomic per touched word of the row
                 const int lo = max(iu0, w0 << 5) & 31, hi = min(iu1, (w0 << 5) + 31) & 31;
                 const uint32_t bits = (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
-                if (tiled) atomicOr(&s_tile[(iv - V0) * TW + (w0 - W0)], bits);
+                if (tiled) atomicOr(&S.tile[(iv - V0) * TW + (w0 - W0)], bits);
                 else atomicOr(&mask[((size_t)iv * f.n >> 5) + (size_t)w0], bits);
             }
         }
@@ -110,32 +89,64 @@ __global__ void __launch_bounds__(256) k_primary_mask(const uint32_t* __restrict
     if (!tiled) return;
     __syncthreads();
     for (int w = threadIdx.x; w < TW * TH; w += blockDim.x) {
-        const uint32_t bits = s_tile[w];
+        const uint32_t bits = S.tile[w];
         if (bits) atomicOr(&mask[((size_t)(V0 + w / TW) * f.n >> 5) + (size_t)(W0 + w % TW)], bits);
     }
 }
 
-static inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
-
-int rts_primary_mask_build(RtsContext* c, const RtsLaunchConsts& lc)
+// Leaf record i = primitive leaf_prim[i] with its world-space vertices pre-gathered (the reference gathers through
+// dbuf_triangles -> dbuf_triVertices per test, triangle_mesh.cu:147-154).  LEAVES && MASK: one pass over the placed triangles
+// for both (a pulse that moves a target needs both; the vertices are gathered once).  MASK alone: the targets stand still,
+// the beam moved.
+template <bool LEAVES, bool MASK>
+__global__ void __launch_bounds__(256) k_leaves(const uint32_t* __restrict__ leaf_prim, const uint32_t* __restrict__ tri_vidx, const double* __restrict__ verts,
+                                                const uint32_t* __restrict__ prim_targ, RtsLeafTri* __restrict__ leaves, uint32_t n,
+                                                double ox, double oy, double oz, RtsMaskFrame f, uint32_t* __restrict__ mask)
 {
-    const RtsMaskFrame& f = lc.mask;
-    if (f.n == 0) return RTS_OK;
-    hipStream_t st = c->stream;
-    const size_t words = (size_t)f.n * f.n / 32u + 1u;
-    RTS_HIP(c->d_pmask.reserve(words));
-    RTS_HIP(hipMemsetAsync(c->d_pmask.p, 0, sizeof(uint32_t) * words, st));
-    if (c->scene->n_leaves) k_primary_mask<<<blocks_for(c->scene->n_leaves, 256), 256, 0, st>>>(c->scene->d_leaf_prim.p, c->scene->d_tri_vidx.p, c->d_verts_world.p, c->scene->n_leaves, lc.ox, lc.oy, lc.oz, f, c->d_pmask.p);
-    RTS_HIP(hipGetLastError());
-    return RTS_OK;
+    __shared__ __attribute__((aligned(16))) uint32_t s_raw[MASK ? sizeof(RtsMaskLds) / 4 : 1];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    double p[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (i < n) {
+        const uint32_t g = leaf_prim[i];
+        const uint32_t a = tri_vidx[3*(size_t)g], b = tri_vidx[3*(size_t)g+1], c = tri_vidx[3*(size_t)g+2];
+        p[0] = verts[3*(size_t)a]; p[1] = verts[3*(size_t)a+1]; p[2] = verts[3*(size_t)a+2];
+        p[3] = verts[3*(size_t)b]; p[4] = verts[3*(size_t)b+1]; p[5] = verts[3*(size_t)b+2];
+        p[6] = verts[3*(size_t)c]; p[7] = verts[3*(size_t)c+1]; p[8] = verts[3*(size_t)c+2];
+        if (LEAVES) {
+            RtsLeafTri L;
+            L.p0x = p[0]; L.p0y = p[1]; L.p0z = p[2]; L.p1x = p[3]; L.p1y = p[4]; L.p1z = p[5]; L.p2x = p[6]; L.p2y = p[7]; L.p2z = p[8];
+            L.prim = g; L.targ = prim_targ[g];
+            leaves[i] = L;
+        }
+    }
+    if (MASK) rts_mask_mark(*reinterpret_cast<RtsMaskLds*>(s_raw), i < n, p, ox, oy, oz, f, mask);
 }
 
-int rts_scene_place(RtsContext* c)
+static inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+
+// The placement of a pulse (when a target moved: `place`) and its primary-ray mask (when the pulse has one: lc.mask.n), with
+// one pass over the leaves for both where both are due.
+int rts_scene_place(RtsContext* c, const RtsLaunchConsts& lc, bool place)
 {
     hipStream_t st = c->stream;
-    if (c->scene->n_verts) k_place<<<blocks_for(c->scene->n_verts, 256), 256, 0, st>>>(c->scene->d_verts_local.p, c->d_verts_world.p, c->scene->d_vert_targ.p, c->p_motion, c->scene->n_verts, 1);
-    if (c->scene->n_normals) k_place<<<blocks_for(c->scene->n_normals, 256), 256, 0, st>>>(c->scene->d_normals_local.p, c->d_normals_world.p, c->scene->d_norm_targ.p, c->p_motion, c->scene->n_normals, 0);
-    if (c->scene->n_leaves) k_leaves<<<blocks_for(c->scene->n_leaves, 256), 256, 0, st>>>(c->scene->d_leaf_prim.p, c->scene->d_tri_vidx.p, c->d_verts_world.p, c->scene->d_prim_targ.p, c->d_leaves.p, c->scene->n_leaves);
+    const RtsMaskFrame& f = lc.mask;
+    const bool mask = f.n != 0;
+    const RtsScene* sc = c->scene;
+    if (mask) {
+        const size_t words = (size_t)f.n * f.n / 32u + 1u;
+        RTS_HIP(c->d_pmask.reserve(words));
+        RTS_HIP(hipMemsetAsync(c->d_pmask.p, 0, sizeof(uint32_t) * words, st));
+    }
+    if (place) {
+        if (sc->n_verts) k_place<<<blocks_for(sc->n_verts, 256), 256, 0, st>>>(sc->d_verts_local.p, c->d_verts_world.p, sc->d_vert_targ.p, c->p_motion, sc->n_verts, 1);
+        if (sc->n_normals) k_place<<<blocks_for(sc->n_normals, 256), 256, 0, st>>>(sc->d_normals_local.p, c->d_normals_world.p, sc->d_norm_targ.p, c->p_motion, sc->n_normals, 0);
+    }
+    if (sc->n_leaves) {
+        const unsigned g = blocks_for(sc->n_leaves, 256);
+        if (place && mask) k_leaves<true, true><<<g, 256, 0, st>>>(sc->d_leaf_prim.p, sc->d_tri_vidx.p, c->d_verts_world.p, sc->d_prim_targ.p, c->d_leaves.p, sc->n_leaves, lc.ox, lc.oy, lc.oz, f, c->d_pmask.p);
+        else if (place) k_leaves<true, false><<<g, 256, 0, st>>>(sc->d_leaf_prim.p, sc->d_tri_vidx.p, c->d_verts_world.p, sc->d_prim_targ.p, c->d_leaves.p, sc->n_leaves, lc.ox, lc.oy, lc.oz, f, nullptr);
+        else if (mask) k_leaves<false, true><<<g, 256, 0, st>>>(sc->d_leaf_prim.p, sc->d_tri_vidx.p, c->d_verts_world.p, sc->d_prim_targ.p, nullptr, sc->n_leaves, lc.ox, lc.oy, lc.oz, f, c->d_pmask.p);
+    }
     RTS_HIP(hipGetLastError());
     return RTS_OK;
 }

@@ -164,6 +164,7 @@ struct RtsTraceArgs {
     uint32_t* tile_ctr;             // [RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE] draw counters (element s * STRIDE), zero at launch
     const uint32_t* tile_head;      // [1] number of tiles at the head of tile_order that are traced as 64 cooperative units (null: none)
     const uint32_t* tile_head_all;  // the same word whether or not this launch has a cooperative kernel (read back with the counters)
+    uint32_t async_idle0, async_idle1, async_age;   // asynchronous bounces (rts_trace_unit_async): idle-lane limit of a walk phase for young / old tiles (0: lock-step kernel), age in cost units
     uint32_t coop_min_cost, coop_seg_cost;   // a tile is flagged LONG WALKS (bit 31 of its cost record) if it took >= coop_min_cost units and >= coop_seg_cost units per traced segment
     unsigned long long* timeline;   // debug (RTS_TIMELINE, counting build): [grid][2] block start/end ticks, then [tiles] tile durations (100 MHz)
     uint32_t pre_filter;            // 1: primary rays go through the f32 pre-filter (needs the mask when there is geometry)
@@ -270,6 +271,7 @@ struct RtsContext {
     double coop_big = 0.0;              // ... or ANY tile costing more than this multiple of the balanced time, whatever its shape (RTS_COOP_BIG; 0 = off, the default:
                                         // measured on C3 at 0.8 / 1.0 / 1.3 -- the slowest tile of a launch is rarely the slowest of the previous one once the target moves,
                                         // the launch's duration did not change (0.70-0.77 ms, peaks of 1.0 ms as before) and the handle's first such launch takes 10 ms)
+    uint32_t async_idle0 = 0, async_idle1 = 8, async_age = 7500;   // RTS_ASYNC_IDLE0 / _IDLE1 / _AGE (rts_trace_unit_async; idle0 = 0: the lock-step kernel)
     double coop_frac = 0.5;            // a tile costing more than this fraction of the launch's balanced time is traced as cooperative units (RTS_COOP_FRAC; 0: never)
     bool tile_cost_pending = false, tile_hist_any = false; uint64_t tile_cost_sig[4] = {0, 0, 0, 0}; uint32_t tile_hist_n = 0;   // per-global-tile cost history (rts_post.hip)
     DevBuf<float> d_dir_hist; DevBuf<uint32_t> d_pmask; bool use_pmask = true, pre_dense = false;
@@ -299,8 +301,7 @@ struct RtsContext {
 // implemented in the .hip units
 int rts_sah_build(const double* verts, const uint32_t* tris, uint32_t n_tris, double split_budget, std::vector<RtsNode4>& nodes, std::vector<uint32_t>& leaf_prim, RtsBlasInfo& out);
 int rts_lbvh_build_device(RtsContext* c, RtsScene* ns, const std::vector<uint32_t>& vidx, const std::vector<RtsMeshHost>& mh, double split_budget);
-int rts_scene_place(RtsContext* c);
-int rts_primary_mask_build(RtsContext* c, const RtsLaunchConsts& lc);
+int rts_scene_place(RtsContext* c, const RtsLaunchConsts& lc, bool place);      // placement kernels (place) + the primary-ray mask (lc.mask.n != 0)
 int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_valid, const uint64_t* cur_sig, uint32_t n_tiles_cur, uint32_t resident_waves);
 int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a, bool count_traversal, unsigned coop_grid);
 void rts_trace_preload();

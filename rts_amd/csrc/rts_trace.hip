@@ -256,56 +256,289 @@ __device__ __forceinline__ void rts_walk_coop(const RtsTraceArgs& a, int32_t* s_
 //                  spread over 64 waves that finish each ray in a few hundred wave steps.
 // The two share every expression of the payload arithmetic (same code, same operand order): results are bit-identical.
 struct RtsUnitLds { int32_t* stack; int32_t* exch; double* first; unsigned long long* path; uint32_t* n; const RtsRxDev* rx; const float (*rxp)[6]; uint32_t* lane_scratch; };
+// The payload of one ray chain between its segments (PerRayData fields that the walk does not touch but the shading does;
+// the first hit point, the path words and the counters live in LDS, RtsUnitLds).
+struct RtsRay { dvec3 dir, prev; double rayLength, power, doppler, refx, refy; uint32_t reflDepth, refrDepth; int received; bool end, chain_start; };
+
+// What happens to a ray after the walk of one segment: miss (receiver capture, Earth) or closest_hit (shading, the refracted
+// child, the reflected direction).  Returns true when the chain goes on with another segment.  ONE body for the three ways a
+// launch index is driven (lanes in lock step per bounce round; lanes advancing on their own, rts_trace_unit_async; one ray per
+// wave, COOP): same expressions, same operand order, bit-identical results.
+template <bool KEEP_ALL, bool REFR, bool COOP>
+__device__ __forceinline__ bool rts_shade(const RtsTraceArgs& a, const RtsUnitLds& L_, const uint32_t tid, const uint32_t gtid, const uint32_t lane, const uint32_t slot,
+                                          const uint32_t chain, const uint32_t D, const uint32_t max_refr, const dvec3& origin, const bool primary, const bool may_rx,
+                                          const float best_t, const int best_leaf, const uint32_t best_prim, const float tmin, RtsRay& S, uint32_t& pending, uint32_t& refr_code0)
+{
+    double* const s_first = L_.first; unsigned long long* const s_path = L_.path; uint32_t* const s_n = L_.n; const RtsRxDev* const s_rx = L_.rx;
+    dvec3& dir = S.dir; dvec3& prev = S.prev;
+    double& rayLength = S.rayLength; double& power = S.power; double& doppler = S.doppler; double& refx = S.refx; double& refy = S.refy;
+    uint32_t& reflDepth = S.reflDepth; uint32_t& refrDepth = S.refrDepth; int& received = S.received; bool& end = S.end; bool& chain_start = S.chain_start;
+        if (KEEP_ALL && chain == 0 && (!COOP || lane == 0)) {
+            const size_t hidx = (size_t)slot * (a.max_refl + 1) + reflDepth;
+            a.hit_prim[hidx] = (best_leaf >= 0) ? (int32_t)best_prim : -1;
+            a.hit_t[hidx] = (best_leaf >= 0) ? best_t : 0.0f;
+        }
+
+        if (best_leaf < 0) {
+            // -------------------------------------------------------- miss, ray_tracer.cu:260-478
+            if (end == false && (!primary || may_rx)) {
+                for (uint32_t Rx_i = 0; Rx_i < a.n_rx; Rx_i++) {
+                    const RtsRxDev rx = Rx_i < RTS_RX_LDS ? s_rx[Rx_i] : a.rx[Rx_i];
+                    double t[2] = {0, 0};
+                    const double A = (dir.x)*(dir.x) + (dir.y)*(dir.y) + (dir.z)*(dir.z);
+                    const double B = 2*(((prev.x - rx.cx)*dir.x) + ((prev.y - rx.cy)*dir.y) + ((prev.z - rx.cz)*dir.z));
+                    const double C = prev.x*prev.x + prev.y*prev.y + prev.z*prev.z + (rx.cx*rx.cx) + (rx.cy*rx.cy) + (rx.cz*rx.cz) -
+                                     2*((rx.cx*prev.x) + (rx.cy*prev.y) + (rx.cz*prev.z)) - rx.radius*rx.radius;
+                    double discriminant = B*B - 4*A*C;
+                    if (discriminant > 0.f) {
+                        discriminant = sqrt(discriminant);
+                        t[0] = (-B - discriminant)/(2*A);
+                        t[1] = (-B + discriminant)/(2*A);
+                        unsigned int received_root = 2;
+    #pragma unroll
+                        for (int i = 0; i < 2; i++) {
+                            if ((t[i] >= 0) && ((rayLength + t[i]) > SCENE_EPS) && ((rayLength + t[i]) > SCENE_EPS_R)) {
+                                const dvec3 ep = mk3(prev.x + t[i]*dir.x, prev.y + t[i]*dir.y, prev.z + t[i]*dir.z);
+                                // atan2f(float, float): arguments narrow to f32 first (:326-329)
+                                double theta = rts_atan2f((float)(ep.y - rx.cy), (float)(ep.x - rx.cx));
+                                double phi = rts_atan2f((float)(ep.z - rx.cz), (float)sqrt(((ep.y - rx.cy) * (ep.y - rx.cy)) + ((ep.x - rx.cx) * (ep.x - rx.cx))));
+                                if ((phi < -RTS_PI/2)) { theta += RTS_PI; phi = -RTS_PI - phi; }
+                                if ((phi > RTS_PI/2)) { theta += RTS_PI; phi = RTS_PI - phi; }
+                                double maxTheta1 = rx.maxTheta, minTheta1 = rx.minTheta, maxTheta2 = maxTheta1, minTheta2 = minTheta1;
+                                double maxPhi1 = rx.maxPhi, minPhi1 = rx.minPhi, maxPhi2 = maxPhi1, minPhi2 = minPhi1;
+                                if ((minPhi1 < -RTS_PI/2)) { maxTheta2 += RTS_PI; minTheta2 += RTS_PI; maxPhi2 = -RTS_PI - minPhi1; minPhi2 = -RTS_PI/2; minPhi1 = -RTS_PI/2; }
+                                if ((maxPhi1 > RTS_PI/2)) { maxTheta2 += RTS_PI; minTheta2 += RTS_PI; minPhi2 = RTS_PI - maxPhi1; maxPhi2 = RTS_PI/2; maxPhi1 = RTS_PI/2; }
+                                if (((rts_angle_in_range(theta, minTheta1, maxTheta1)) && (rts_angle_in_range(phi, minPhi1, maxPhi1))) ||
+                                    ((rts_angle_in_range(theta, minTheta2, maxTheta2)) && (rts_angle_in_range(phi, minPhi2, maxPhi2)))) {
+                                    if (received_root == 2) received_root = i;
+                                    else if (t[received_root] > t[i]) received_root = i;
+                                }
+                            }
+                        }
+                        if (received_root < 2) {
+                            end = true;                                                    // :396
+                            const double tr = received_root == 0 ? t[0] : t[1];
+                            const dvec3 ep = mk3(prev.x + tr*dir.x, prev.y + tr*dir.y, prev.z + tr*dir.z);
+                            if ((reflDepth == 0) && (refrDepth == 0)) {                    // direct transmission :410-417
+                                const dvec3 RxRange = sub3(ep, origin);
+                                if (len3(RxRange) >= SCENE_EPS) {
+                                    power = 1/(4*RTS_PI*4*RTS_PI*(magsq3(RxRange)));
+                                    doppler = 0;
+                                    rayLength += tr;
+                                    received = (int)Rx_i;
+                                }
+                            } else {                                                       // :419-425
+                                const dvec3 RxRange = sub3(ep, prev);
+                                if (len3(RxRange) >= SCENE_EPS_R) {
+                                    power *= 1/((magsq3(RxRange))*4*RTS_PI*4*RTS_PI);
+                                    rayLength += tr;
+                                    received = (int)Rx_i;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (end == false && rayLength > 0) {                                           // Earth sphere :438-476 (both roots require rayLength > 0, :464)
+                const double d_earthRadius = 6378136;
+                const double A = (dir.x)*(dir.x) + (dir.y)*(dir.y) + (dir.z)*(dir.z);
+                const double B = 2*(prev.x*dir.x + prev.y*dir.y + prev.z*dir.z);
+                const double C = prev.x*prev.x + prev.y*prev.y + prev.z*prev.z - d_earthRadius*d_earthRadius;
+                double discriminant = B*B - 4*A*C;
+                if (discriminant > 0.f) {
+                    discriminant = sqrt(discriminant);
+                    const double t0 = (-B - discriminant)/(2*A), t1 = (-B + discriminant)/(2*A);
+                    if ((t0 >= 0) && (rayLength > 0)) { end = true; rayLength += t0; }
+                    if ((t1 >= 0) && (rayLength > 0)) { end = true; rayLength += t1; }
+                }
+            }
+            return false;
+        }
+
+        // ------------------------------------------------------------ closest_hit, normal_shader.cu:128-340
+        if (!((end == false) && ((refrDepth < max_refr) || (reflDepth < a.max_refl)))) return false;   // gate :134 ; absorbed hit leaves the payload untouched
+        if (!COOP || lane == 0) atomicAdd(&s_n[RTS_BLOCK + tid], 1u);
+        const RtsLeafTri L = a.leaves[best_leaf];
+        const RtsTargetDev T = a.targets[L.targ];
+        if (refrDepth != 1) {                                              // path column (:140-146)
+            const uint32_t col = reflDepth + refrDepth;
+            if (col < D) {
+                const uint64_t code = (uint64_t)(L.targ + 1);
+                unsigned long long* pw = &s_path[(col < 8 ? 0 : RTS_BLOCK) + tid];
+                const uint32_t sh = 8 * (col & 7u);
+                *pw = (*pw & ~(0xffULL << sh)) | (code << sh);
+            }
+        }
+        const float hit_t = best_t;
+        const dvec3 hitPoint = mk3(prev.x + (double)hit_t*dir.x, prev.y + (double)hit_t*dir.y, prev.z + (double)hit_t*dir.z);   // :149-152
+        rayLength += hit_t;                                                // :153
+        if ((reflDepth == 0) && (refrDepth == 0)) {                        // :159-166
+            s_first[tid] = hitPoint.x; s_first[RTS_BLOCK + tid] = hitPoint.y; s_first[2 * RTS_BLOCK + tid] = hitPoint.z;
+            const dvec3 TxRange = sub3(hitPoint, origin);
+            if (len3(TxRange) >= SCENE_EPS) power = 1/((magsq3(TxRange))*4*RTS_PI);
+            else end = true;
+        } else {                                                           // :167-173
+            const dvec3 TargRange = sub3(hitPoint, prev);
+            if (len3(TargRange) >= SCENE_EPS_R) power *= 1/((magsq3(TargRange))*4*RTS_PI);
+            else end = true;
+        }
+        // attribute normal (triangle_mesh.cu:169-194): recompute the accepted test, same bits
+        const TriHit h = tri_test(L, prev, dir, tmin, RTS_DEFAULT_TMAX);
+        prev = hitPoint;                                                   // :176
+        dvec3 normal;
+        if (a.smooth) {
+            const uint32_t* ni = a.tri_nidx + 3*(size_t)L.prim;
+            if (T.perface_normals) {
+                const double* n = a.normals + 3*(size_t)ni[0];
+                normal = mk3(n[0], n[1], n[2]);
+            } else {
+                const double* n0 = a.normals + 3*(size_t)ni[0]; const double* n1 = a.normals + 3*(size_t)ni[1]; const double* n2 = a.normals + 3*(size_t)ni[2];
+                const double w = 1.0f - h.beta - h.gamma;
+                normal = mk3(n1[0]*h.beta + n2[0]*h.gamma + n0[0]*w, n1[1]*h.beta + n2[1]*h.gamma + n0[1]*w, n1[2]*h.beta + n2[2]*h.gamma + n0[2]*w);
+            }
+            normal = unit3(normal);
+        } else {
+            normal = unit3(h.n);
+        }
+        // f32 direction of the current OptiX ray: primary = normalise_float3(rayDir_d3) (ray_tracer.cu:208);
+        // bounce / refracted = the f32 reflect()/refract() result itself (normal_shader.cu:242,296-297)
+        const fvec3 dirf = (chain == 0 && chain_start) ? unit3_to_f32(dir) : mk3f((float)dir.x, (float)dir.y, (float)dir.z);
+        const fvec3 nf = unit3_to_f32(normal);
+
+        // ---- refraction branch (:191-282): prd_refr = prd; prd_refr.refrIndex.x = prd_refr.refrIndex.y
+        const double rrefx = refy;                                         // prd_refr.refrIndex.x
+        if (REFR) {
+            if ((fabs(T.reflCoeff) != 1.00000f) && (refrDepth < max_refr) && (reflDepth == 0)) {   // :198
+                const double rrefy = (rrefx == 1) ? T.refrIndex : 1.0;     // :201-206
+                const float ratio = (float)(rrefy / rrefx);                // :209
+                fvec3 rd;
+                if (refract3f(rd, dirf, nf, ratio)) {                      // :212
+                    RtsChildState cs;
+                    cs.prevx = prev.x; cs.prevy = prev.y; cs.prevz = prev.z; cs.firstx = s_first[tid]; cs.firsty = s_first[RTS_BLOCK + tid]; cs.firstz = s_first[2 * RTS_BLOCK + tid];
+                    cs.rayLength = rayLength; cs.refx = rrefx; cs.refy = rrefy; cs.end = end ? 1u : 0u;
+                    double cpower = power;
+                    if ((reflDepth + 1) < (a.max_refl + 1)) cpower *= (1 - fabs(T.reflCoeff));   // :245-246
+                    cs.power = cpower;
+                    cs.refrDepth = refrDepth + 1;                           // :247
+                    const dvec3 k0 = unit3(dir);                            // :251-256
+                    const dvec3 nd3 = widen3(rd);
+                    const dvec3 k1 = unit3(nd3);
+                    cs.doppler = doppler + dot3(mk3(T.vx, T.vy, T.vz), sub3(k1, k0));
+                    cs.dx = rd.x; cs.dy = rd.y; cs.dz = rd.z;
+                    cs.refr_code = (chain == 0) ? (L.targ + 1) : (uint32_t)(s_path[tid] & 0xff);   // prefill code travels with the first refraction only
+                    if (chain == 0) refr_code0 = L.targ + 1;
+                    a.child[(size_t)chain * a.slab_threads + gtid] = cs;
+                    pending |= 1u << (chain + 1);
+                    // direction history plane 0 of the child chain: RCS angle of the refraction event (:259-265)
+                    float* dh = a.dir_hist + (size_t)((chain + 1) * (a.max_refl + 1)) * 3 * a.n_rays;
+                    if (!COOP || lane == 0) { dh[slot] = rd.x; dh[(size_t)a.n_rays + slot] = rd.y; dh[2*(size_t)a.n_rays + slot] = rd.z; }
+                }
+            }
+        }
+        reflDepth++;                                                       // :286
+        refy = rrefx; refx = rrefx;                                        // :289-290
+        chain_start = false;
+        if (!(reflDepth < a.max_refl + 1)) return false;                          // :293 (can fail only inside a refracted chain)
+        const fvec3 nd = reflect3f(dirf, nf);                              // :296
+        power *= T.reflCoeff;                                              // :298
+        const dvec3 k0 = unit3(dir);                                       // :302
+        dir = widen3(nd);                                                  // :303
+        const dvec3 k1 = unit3(dir);                                       // :304
+        doppler += dot3(mk3(T.vx, T.vy, T.vz), sub3(k1, k0));              // :314
+        {   // direction history: the RCS angles of received rays are rebuilt from it (:320-326)
+            const size_t plane = REFR ? (size_t)chain * (a.max_refl + 1) + reflDepth : (size_t)(reflDepth - 1);
+            float* dh = a.dir_hist + plane * 3 * a.n_rays;
+            if (!COOP || lane == 0) { dh[slot] = nd.x; dh[(size_t)a.n_rays + slot] = nd.y; dh[2*(size_t)a.n_rays + slot] = nd.z; }
+        }
+    return true;
+}
+
+
+// End of a chain: the record of a received ray (and of every ray in the KEEP_ALL builds), ray_tracer.cu:246-253, normal_shader.cu:272-279
+template <bool KEEP_ALL, bool COOP>
+__device__ __forceinline__ void rts_write_back(const RtsTraceArgs& a, const RtsUnitLds& L_, const uint32_t tid, const uint32_t lane, const uint32_t slot, const uint32_t chain,
+                                               const RtsRay& S, const uint32_t pending, const uint32_t refr_code0)
+{
+    const double* const s_first = L_.first; const unsigned long long* const s_path = L_.path;
+    const dvec3& prev = S.prev; const double rayLength = S.rayLength, power = S.power, doppler = S.doppler;
+    const uint32_t reflDepth = S.reflDepth, refrDepth = S.refrDepth; const int received = S.received;
+    const bool recv = received >= 0;
+    if ((recv || KEEP_ALL) && (!COOP || lane == 0)) {
+        RtsEndRecord r;
+        r.rayLength = rayLength; r.power = power; r.doppler = doppler;
+        r.prevx = prev.x; r.prevy = prev.y; r.prevz = prev.z;
+        r.firstx = s_first[tid]; r.firsty = s_first[RTS_BLOCK + tid]; r.firstz = s_first[2 * RTS_BLOCK + tid];
+        r.path_lo = s_path[tid]; r.path_hi = s_path[RTS_BLOCK + tid]; r.slot = slot; r.received = received; r.reflDepth = reflDepth;
+        r.pad = chain | (refrDepth << 2) | ((chain == 0 ? refr_code0 : 0u) << 8) | ((pending & 6u) << 15);   // chain, refrDepth, prefill code, spawned children
+        if (KEEP_ALL) a.all_records[(size_t)chain * a.n_rays + slot] = r;
+        if (recv) {
+            // the compiler folds this into one atomic per wave (v_mbcnt + s_bcnt1)
+            unsigned long long idx = atomicAdd(&a.counters[0], 1ULL);
+            a.recv_records[idx] = r;
+        }
+    }
+}
+
+// ray_generation + payload of a launch index (ray_tracer.cu:144-224), with the conservative f32 pre-filter of primary rays:
+// may_target / may_rx come back false when the ray can meet no triangle / no receiver sphere.
+__device__ __forceinline__ void rts_primary_setup(const RtsTraceArgs& a, const RtsLaunchConsts& lc, const RtsUnitLds& L_, const uint32_t tid, const uint32_t slot, const bool pre_on,
+                                                  const bool mask_on, const dvec3& origin, RtsRay& S, bool& may_target, bool& may_rx)
+{
+    double* const s_first = L_.first; unsigned long long* const s_path = L_.path; const float (*const s_rxp)[6] = L_.rxp;
+    dvec3& dir = S.dir; dvec3& prev = S.prev; double& rayLength = S.rayLength; double& power = S.power; double& doppler = S.doppler;
+    // ------------------------------------------------------------ ray_generation + payload, ray_tracer.cu:144-224
+    if (pre_on) {
+        // ray_generation in f32 (same tree, f32 constants): lattice point, normalise, Rot, normalise, Rot1
+        uint32_t lx, ly, lz; rts_lattice_coords(lc, slot, lx, ly, lz);
+        float vx = __builtin_fmaf(lc.f_st[0], (float)lx, lc.f_bs[0]), vy = __builtin_fmaf(lc.f_st[1], (float)ly, lc.f_bs[1]), vz = __builtin_fmaf(lc.f_st[2], (float)lz, lc.f_bs[2]);
+        float inv = __frsqrt_rn(vx*vx + vy*vy + vz*vz); vx *= inv; vy *= inv; vz *= inv;
+        float rx_ = lc.f_rot[0]*vx + lc.f_rot[1]*vy + lc.f_rot[2]*vz, ry_ = lc.f_rot[3]*vx + lc.f_rot[4]*vy + lc.f_rot[5]*vz, rz_ = lc.f_rot[6]*vx + lc.f_rot[7]*vy + lc.f_rot[8]*vz;
+        inv = __frsqrt_rn(rx_*rx_ + ry_*ry_ + rz_*rz_); rx_ *= inv; ry_ *= inv; rz_ *= inv;
+        const float dx = lc.f_rot1[0]*rx_ + lc.f_rot1[1]*ry_ + lc.f_rot1[2]*rz_, dy = lc.f_rot1[3]*rx_ + lc.f_rot1[4]*ry_ + lc.f_rot1[5]*rz_, dz = lc.f_rot1[6]*rx_ + lc.f_rot1[7]*ry_ + lc.f_rot1[8]*rz_;
+        if (mask_on) {                                       // is any triangle's projection near this direction? (RtsMaskFrame)
+            const RtsMaskFrame& mf = lc.mask;
+            const float w = dx * mf.bx + dy * mf.by + dz * mf.bz;
+            const float fu = ((dx * mf.ux + dy * mf.uy + dz * mf.uz) / w - mf.u0) * mf.inv_du, fv = ((dx * mf.vx + dy * mf.vy + dz * mf.vz) / w - mf.v0) * mf.inv_dv;
+            if (w > 0.0f && fu >= 0.0f && fv >= 0.0f && fu < (float)mf.n && fv < (float)mf.n) {
+                const uint32_t cell = (uint32_t)fv * mf.n + (uint32_t)fu;
+                may_target = ((a.pmask[cell >> 5] >> (cell & 31u)) & 1u) != 0u;
+            }
+        }
+        may_rx = false;
+        const float dd = dx*dx + dy*dy + dz*dz;
+        for (uint32_t Rx_i = 0; Rx_i < a.n_rx; Rx_i++) {    // can the ray come within the widened radius of this receiver's sphere?
+            const float qx = s_rxp[Rx_i][0], qy = s_rxp[Rx_i][1], qz = s_rxp[Rx_i][2], qq = s_rxp[Rx_i][3], r2w = s_rxp[Rx_i][4], qn = s_rxp[Rx_i][5];
+            const float b = qx*dx + qy*dy + qz*dz;
+            const bool inside = qq <= r2w * 1.01f;
+            const bool ahead = b > -1.0e-3f * qn && (b*b - (qq - r2w) * dd) >= 0.0f;
+            may_rx = may_rx || inside || ahead;
+        }
+    }
+    dir = (may_target || may_rx) ? rts_primary_dir(lc, slot) : mk3(0.0, 0.0, 0.0);
+    prev = origin;
+    s_first[tid] = 0.0; s_first[RTS_BLOCK + tid] = 0.0; s_first[2 * RTS_BLOCK + tid] = 0.0;
+    s_path[tid] = 0ULL; s_path[RTS_BLOCK + tid] = 0ULL;
+    rayLength = 0; power = 0; doppler = 0;
+}
+
 template <bool COUNT, bool KEEP_ALL, bool REFR, bool COOP>
 __device__ __forceinline__ void rts_trace_unit(const RtsTraceArgs& a, const RtsLaunchConsts& lc, const RtsUnitLds& L_, const uint32_t tid, const uint32_t gtid, const uint32_t lane,
                                                const uint32_t slot, const bool pre_on, const bool mask_on, const uint32_t D, const uint32_t max_refr, const dvec3& origin,
                                                uint32_t& n_nodes, uint32_t& n_tris, bool& hard_overflow, unsigned long long (&lane_stats)[3])
 {
       int32_t* const s_stack = L_.stack; int32_t* const s_exch = L_.exch; double* const s_first = L_.first; unsigned long long* const s_path = L_.path; uint32_t* const s_n = L_.n;
-      const RtsRxDev* const s_rx = L_.rx; const float (*const s_rxp)[6] = L_.rxp;
+
       uint32_t pending = 0;                   // bit k: chain k has been spawned
       uint32_t refr_code0 = 0;                // (target + 1) of chain 0's refraction, for the path prefill of rows >= 3
       for (uint32_t chain = 0; chain < (REFR ? 3u : 1u); chain++) {
-        dvec3 dir, prev;
-        double rayLength, power, doppler, refx = 1, refy = 1;
-        uint32_t reflDepth = 0, refrDepth = 0;
-        int received = -1;
-        bool end = false;
+        RtsRay S;
+        dvec3& dir = S.dir; dvec3& prev = S.prev;
+        double& rayLength = S.rayLength; double& power = S.power; double& doppler = S.doppler; double& refx = S.refx; double& refy = S.refy;
+        uint32_t& reflDepth = S.reflDepth; uint32_t& refrDepth = S.refrDepth; bool& end = S.end; bool& chain_start = S.chain_start;
+        refx = 1; refy = 1; reflDepth = 0; refrDepth = 0; S.received = -1; end = false;
         bool may_target = a.n_prims > 0, may_rx = a.n_rx > 0;   // (primary ray: what the pre-filter could not exclude)
         if (chain == 0) {
-            // ------------------------------------------------------------ ray_generation + payload, ray_tracer.cu:144-224
-            if (pre_on) {
-                // ray_generation in f32 (same tree, f32 constants): lattice point, normalise, Rot, normalise, Rot1
-                uint32_t lx, ly, lz; rts_lattice_coords(lc, slot, lx, ly, lz);
-                float vx = __builtin_fmaf(lc.f_st[0], (float)lx, lc.f_bs[0]), vy = __builtin_fmaf(lc.f_st[1], (float)ly, lc.f_bs[1]), vz = __builtin_fmaf(lc.f_st[2], (float)lz, lc.f_bs[2]);
-                float inv = __frsqrt_rn(vx*vx + vy*vy + vz*vz); vx *= inv; vy *= inv; vz *= inv;
-                float rx_ = lc.f_rot[0]*vx + lc.f_rot[1]*vy + lc.f_rot[2]*vz, ry_ = lc.f_rot[3]*vx + lc.f_rot[4]*vy + lc.f_rot[5]*vz, rz_ = lc.f_rot[6]*vx + lc.f_rot[7]*vy + lc.f_rot[8]*vz;
-                inv = __frsqrt_rn(rx_*rx_ + ry_*ry_ + rz_*rz_); rx_ *= inv; ry_ *= inv; rz_ *= inv;
-                const float dx = lc.f_rot1[0]*rx_ + lc.f_rot1[1]*ry_ + lc.f_rot1[2]*rz_, dy = lc.f_rot1[3]*rx_ + lc.f_rot1[4]*ry_ + lc.f_rot1[5]*rz_, dz = lc.f_rot1[6]*rx_ + lc.f_rot1[7]*ry_ + lc.f_rot1[8]*rz_;
-                if (mask_on) {                                       // is any triangle's projection near this direction? (RtsMaskFrame)
-                    const RtsMaskFrame& mf = lc.mask;
-                    const float w = dx * mf.bx + dy * mf.by + dz * mf.bz;
-                    const float fu = ((dx * mf.ux + dy * mf.uy + dz * mf.uz) / w - mf.u0) * mf.inv_du, fv = ((dx * mf.vx + dy * mf.vy + dz * mf.vz) / w - mf.v0) * mf.inv_dv;
-                    if (w > 0.0f && fu >= 0.0f && fv >= 0.0f && fu < (float)mf.n && fv < (float)mf.n) {
-                        const uint32_t cell = (uint32_t)fv * mf.n + (uint32_t)fu;
-                        may_target = ((a.pmask[cell >> 5] >> (cell & 31u)) & 1u) != 0u;
-                    }
-                }
-                may_rx = false;
-                const float dd = dx*dx + dy*dy + dz*dz;
-                for (uint32_t Rx_i = 0; Rx_i < a.n_rx; Rx_i++) {    // can the ray come within the widened radius of this receiver's sphere?
-                    const float qx = s_rxp[Rx_i][0], qy = s_rxp[Rx_i][1], qz = s_rxp[Rx_i][2], qq = s_rxp[Rx_i][3], r2w = s_rxp[Rx_i][4], qn = s_rxp[Rx_i][5];
-                    const float b = qx*dx + qy*dy + qz*dz;
-                    const bool inside = qq <= r2w * 1.01f;
-                    const bool ahead = b > -1.0e-3f * qn && (b*b - (qq - r2w) * dd) >= 0.0f;
-                    may_rx = may_rx || inside || ahead;
-                }
-            }
-            dir = (may_target || may_rx) ? rts_primary_dir(lc, slot) : mk3(0.0, 0.0, 0.0);
-            prev = origin;
-            s_first[tid] = 0.0; s_first[RTS_BLOCK + tid] = 0.0; s_first[2 * RTS_BLOCK + tid] = 0.0;
-            s_path[tid] = 0ULL; s_path[RTS_BLOCK + tid] = 0ULL;
-            rayLength = 0; power = 0; doppler = 0;
+            rts_primary_setup(a, lc, L_, tid, slot, pre_on, mask_on, origin, S, may_target, may_rx);
         } else {
             if (!REFR || !(pending & (1u << chain))) continue;
             const RtsChildState cs = a.child[(size_t)(chain - 1) * a.slab_threads + gtid];
@@ -320,7 +553,7 @@ __device__ __forceinline__ void rts_trace_unit(const RtsTraceArgs& a, const RtsL
             for (uint32_t col = 0; col < (chain == 1 ? D : 2u); col++) { if (col < 8) path_lo |= code << (8 * col); else path_hi |= code << (8 * (col - 8)); }
             s_path[tid] = path_lo; s_path[RTS_BLOCK + tid] = path_hi;
         }
-        bool chain_start = true;               // first segment of this chain: incident epsilon, f32 direction rule below
+        chain_start = true;                    // first segment of this chain: incident epsilon, f32 direction rule below
 
         for (;;) {
             // ------------------------------------------------------------ rtTrace: closest hit over the targets' hierarchies
@@ -384,202 +617,120 @@ __device__ __forceinline__ void rts_trace_unit(const RtsTraceArgs& a, const RtsL
                 const uint32_t smax = ls[0], ssum = ls[1];
                 lane_stats[0] += 64ull * smax; lane_stats[1] += (unsigned long long)__popcll(act) * smax; lane_stats[2] += ssum;
             }
-            if (KEEP_ALL && chain == 0 && (!COOP || lane == 0)) {
-                const size_t hidx = (size_t)slot * (a.max_refl + 1) + reflDepth;
-                a.hit_prim[hidx] = (best_leaf >= 0) ? (int32_t)best_prim : -1;
-                a.hit_t[hidx] = (best_leaf >= 0) ? best_t : 0.0f;
-            }
-
-            if (best_leaf < 0) {
-                // -------------------------------------------------------- miss, ray_tracer.cu:260-478
-                if (end == false && (!primary || may_rx)) {
-                    for (uint32_t Rx_i = 0; Rx_i < a.n_rx; Rx_i++) {
-                        const RtsRxDev rx = Rx_i < RTS_RX_LDS ? s_rx[Rx_i] : a.rx[Rx_i];
-                        double t[2] = {0, 0};
-                        const double A = (dir.x)*(dir.x) + (dir.y)*(dir.y) + (dir.z)*(dir.z);
-                        const double B = 2*(((prev.x - rx.cx)*dir.x) + ((prev.y - rx.cy)*dir.y) + ((prev.z - rx.cz)*dir.z));
-                        const double C = prev.x*prev.x + prev.y*prev.y + prev.z*prev.z + (rx.cx*rx.cx) + (rx.cy*rx.cy) + (rx.cz*rx.cz) -
-                                         2*((rx.cx*prev.x) + (rx.cy*prev.y) + (rx.cz*prev.z)) - rx.radius*rx.radius;
-                        double discriminant = B*B - 4*A*C;
-                        if (discriminant > 0.f) {
-                            discriminant = sqrt(discriminant);
-                            t[0] = (-B - discriminant)/(2*A);
-                            t[1] = (-B + discriminant)/(2*A);
-                            unsigned int received_root = 2;
-#pragma unroll
-                            for (int i = 0; i < 2; i++) {
-                                if ((t[i] >= 0) && ((rayLength + t[i]) > SCENE_EPS) && ((rayLength + t[i]) > SCENE_EPS_R)) {
-                                    const dvec3 ep = mk3(prev.x + t[i]*dir.x, prev.y + t[i]*dir.y, prev.z + t[i]*dir.z);
-                                    // atan2f(float, float): arguments narrow to f32 first (:326-329)
-                                    double theta = rts_atan2f((float)(ep.y - rx.cy), (float)(ep.x - rx.cx));
-                                    double phi = rts_atan2f((float)(ep.z - rx.cz), (float)sqrt(((ep.y - rx.cy) * (ep.y - rx.cy)) + ((ep.x - rx.cx) * (ep.x - rx.cx))));
-                                    if ((phi < -RTS_PI/2)) { theta += RTS_PI; phi = -RTS_PI - phi; }
-                                    if ((phi > RTS_PI/2)) { theta += RTS_PI; phi = RTS_PI - phi; }
-                                    double maxTheta1 = rx.maxTheta, minTheta1 = rx.minTheta, maxTheta2 = maxTheta1, minTheta2 = minTheta1;
-                                    double maxPhi1 = rx.maxPhi, minPhi1 = rx.minPhi, maxPhi2 = maxPhi1, minPhi2 = minPhi1;
-                                    if ((minPhi1 < -RTS_PI/2)) { maxTheta2 += RTS_PI; minTheta2 += RTS_PI; maxPhi2 = -RTS_PI - minPhi1; minPhi2 = -RTS_PI/2; minPhi1 = -RTS_PI/2; }
-                                    if ((maxPhi1 > RTS_PI/2)) { maxTheta2 += RTS_PI; minTheta2 += RTS_PI; minPhi2 = RTS_PI - maxPhi1; maxPhi2 = RTS_PI/2; maxPhi1 = RTS_PI/2; }
-                                    if (((rts_angle_in_range(theta, minTheta1, maxTheta1)) && (rts_angle_in_range(phi, minPhi1, maxPhi1))) ||
-                                        ((rts_angle_in_range(theta, minTheta2, maxTheta2)) && (rts_angle_in_range(phi, minPhi2, maxPhi2)))) {
-                                        if (received_root == 2) received_root = i;
-                                        else if (t[received_root] > t[i]) received_root = i;
-                                    }
-                                }
-                            }
-                            if (received_root < 2) {
-                                end = true;                                                    // :396
-                                const double tr = received_root == 0 ? t[0] : t[1];
-                                const dvec3 ep = mk3(prev.x + tr*dir.x, prev.y + tr*dir.y, prev.z + tr*dir.z);
-                                if ((reflDepth == 0) && (refrDepth == 0)) {                    // direct transmission :410-417
-                                    const dvec3 RxRange = sub3(ep, origin);
-                                    if (len3(RxRange) >= SCENE_EPS) {
-                                        power = 1/(4*RTS_PI*4*RTS_PI*(magsq3(RxRange)));
-                                        doppler = 0;
-                                        rayLength += tr;
-                                        received = (int)Rx_i;
-                                    }
-                                } else {                                                       // :419-425
-                                    const dvec3 RxRange = sub3(ep, prev);
-                                    if (len3(RxRange) >= SCENE_EPS_R) {
-                                        power *= 1/((magsq3(RxRange))*4*RTS_PI*4*RTS_PI);
-                                        rayLength += tr;
-                                        received = (int)Rx_i;
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
-                if (end == false && rayLength > 0) {                                           // Earth sphere :438-476 (both roots require rayLength > 0, :464)
-                    const double d_earthRadius = 6378136;
-                    const double A = (dir.x)*(dir.x) + (dir.y)*(dir.y) + (dir.z)*(dir.z);
-                    const double B = 2*(prev.x*dir.x + prev.y*dir.y + prev.z*dir.z);
-                    const double C = prev.x*prev.x + prev.y*prev.y + prev.z*prev.z - d_earthRadius*d_earthRadius;
-                    double discriminant = B*B - 4*A*C;
-                    if (discriminant > 0.f) {
-                        discriminant = sqrt(discriminant);
-                        const double t0 = (-B - discriminant)/(2*A), t1 = (-B + discriminant)/(2*A);
-                        if ((t0 >= 0) && (rayLength > 0)) { end = true; rayLength += t0; }
-                        if ((t1 >= 0) && (rayLength > 0)) { end = true; rayLength += t1; }
-                    }
-                }
-                break;
-            }
-
-            // ------------------------------------------------------------ closest_hit, normal_shader.cu:128-340
-            if (!((end == false) && ((refrDepth < max_refr) || (reflDepth < a.max_refl)))) break;   // gate :134 ; absorbed hit leaves the payload untouched
-            if (!COOP || lane == 0) atomicAdd(&s_n[RTS_BLOCK + tid], 1u);
-            const RtsLeafTri L = a.leaves[best_leaf];
-            const RtsTargetDev T = a.targets[L.targ];
-            if (refrDepth != 1) {                                              // path column (:140-146)
-                const uint32_t col = reflDepth + refrDepth;
-                if (col < D) {
-                    const uint64_t code = (uint64_t)(L.targ + 1);
-                    unsigned long long* pw = &s_path[(col < 8 ? 0 : RTS_BLOCK) + tid];
-                    const uint32_t sh = 8 * (col & 7u);
-                    *pw = (*pw & ~(0xffULL << sh)) | (code << sh);
-                }
-            }
-            const float hit_t = best_t;
-            const dvec3 hitPoint = mk3(prev.x + (double)hit_t*dir.x, prev.y + (double)hit_t*dir.y, prev.z + (double)hit_t*dir.z);   // :149-152
-            rayLength += hit_t;                                                // :153
-            if ((reflDepth == 0) && (refrDepth == 0)) {                        // :159-166
-                s_first[tid] = hitPoint.x; s_first[RTS_BLOCK + tid] = hitPoint.y; s_first[2 * RTS_BLOCK + tid] = hitPoint.z;
-                const dvec3 TxRange = sub3(hitPoint, origin);
-                if (len3(TxRange) >= SCENE_EPS) power = 1/((magsq3(TxRange))*4*RTS_PI);
-                else end = true;
-            } else {                                                           // :167-173
-                const dvec3 TargRange = sub3(hitPoint, prev);
-                if (len3(TargRange) >= SCENE_EPS_R) power *= 1/((magsq3(TargRange))*4*RTS_PI);
-                else end = true;
-            }
-            // attribute normal (triangle_mesh.cu:169-194): recompute the accepted test, same bits
-            const TriHit h = tri_test(L, prev, dir, tmin, RTS_DEFAULT_TMAX);
-            prev = hitPoint;                                                   // :176
-            dvec3 normal;
-            if (a.smooth) {
-                const uint32_t* ni = a.tri_nidx + 3*(size_t)L.prim;
-                if (T.perface_normals) {
-                    const double* n = a.normals + 3*(size_t)ni[0];
-                    normal = mk3(n[0], n[1], n[2]);
-                } else {
-                    const double* n0 = a.normals + 3*(size_t)ni[0]; const double* n1 = a.normals + 3*(size_t)ni[1]; const double* n2 = a.normals + 3*(size_t)ni[2];
-                    const double w = 1.0f - h.beta - h.gamma;
-                    normal = mk3(n1[0]*h.beta + n2[0]*h.gamma + n0[0]*w, n1[1]*h.beta + n2[1]*h.gamma + n0[1]*w, n1[2]*h.beta + n2[2]*h.gamma + n0[2]*w);
-                }
-                normal = unit3(normal);
-            } else {
-                normal = unit3(h.n);
-            }
-            // f32 direction of the current OptiX ray: primary = normalise_float3(rayDir_d3) (ray_tracer.cu:208);
-            // bounce / refracted = the f32 reflect()/refract() result itself (normal_shader.cu:242,296-297)
-            const fvec3 dirf = (chain == 0 && chain_start) ? unit3_to_f32(dir) : mk3f((float)dir.x, (float)dir.y, (float)dir.z);
-            const fvec3 nf = unit3_to_f32(normal);
-
-            // ---- refraction branch (:191-282): prd_refr = prd; prd_refr.refrIndex.x = prd_refr.refrIndex.y
-            const double rrefx = refy;                                         // prd_refr.refrIndex.x
-            if (REFR) {
-                if ((fabs(T.reflCoeff) != 1.00000f) && (refrDepth < max_refr) && (reflDepth == 0)) {   // :198
-                    const double rrefy = (rrefx == 1) ? T.refrIndex : 1.0;     // :201-206
-                    const float ratio = (float)(rrefy / rrefx);                // :209
-                    fvec3 rd;
-                    if (refract3f(rd, dirf, nf, ratio)) {                      // :212
-                        RtsChildState cs;
-                        cs.prevx = prev.x; cs.prevy = prev.y; cs.prevz = prev.z; cs.firstx = s_first[tid]; cs.firsty = s_first[RTS_BLOCK + tid]; cs.firstz = s_first[2 * RTS_BLOCK + tid];
-                        cs.rayLength = rayLength; cs.refx = rrefx; cs.refy = rrefy; cs.end = end ? 1u : 0u;
-                        double cpower = power;
-                        if ((reflDepth + 1) < (a.max_refl + 1)) cpower *= (1 - fabs(T.reflCoeff));   // :245-246
-                        cs.power = cpower;
-                        cs.refrDepth = refrDepth + 1;                           // :247
-                        const dvec3 k0 = unit3(dir);                            // :251-256
-                        const dvec3 nd3 = widen3(rd);
-                        const dvec3 k1 = unit3(nd3);
-                        cs.doppler = doppler + dot3(mk3(T.vx, T.vy, T.vz), sub3(k1, k0));
-                        cs.dx = rd.x; cs.dy = rd.y; cs.dz = rd.z;
-                        cs.refr_code = (chain == 0) ? (L.targ + 1) : (uint32_t)(s_path[tid] & 0xff);   // prefill code travels with the first refraction only
-                        if (chain == 0) refr_code0 = L.targ + 1;
-                        a.child[(size_t)chain * a.slab_threads + gtid] = cs;
-                        pending |= 1u << (chain + 1);
-                        // direction history plane 0 of the child chain: RCS angle of the refraction event (:259-265)
-                        float* dh = a.dir_hist + (size_t)((chain + 1) * (a.max_refl + 1)) * 3 * a.n_rays;
-                        if (!COOP || lane == 0) { dh[slot] = rd.x; dh[(size_t)a.n_rays + slot] = rd.y; dh[2*(size_t)a.n_rays + slot] = rd.z; }
-                    }
-                }
-            }
-            reflDepth++;                                                       // :286
-            refy = rrefx; refx = rrefx;                                        // :289-290
-            chain_start = false;
-            if (!(reflDepth < a.max_refl + 1)) break;                          // :293 (can fail only inside a refracted chain)
-            const fvec3 nd = reflect3f(dirf, nf);                              // :296
-            power *= T.reflCoeff;                                              // :298
-            const dvec3 k0 = unit3(dir);                                       // :302
-            dir = widen3(nd);                                                  // :303
-            const dvec3 k1 = unit3(dir);                                       // :304
-            doppler += dot3(mk3(T.vx, T.vy, T.vz), sub3(k1, k0));              // :314
-            {   // direction history: the RCS angles of received rays are rebuilt from it (:320-326)
-                const size_t plane = REFR ? (size_t)chain * (a.max_refl + 1) + reflDepth : (size_t)(reflDepth - 1);
-                float* dh = a.dir_hist + plane * 3 * a.n_rays;
-                if (!COOP || lane == 0) { dh[slot] = nd.x; dh[(size_t)a.n_rays + slot] = nd.y; dh[2*(size_t)a.n_rays + slot] = nd.z; }
-            }
+            if (!rts_shade<KEEP_ALL, REFR, COOP>(a, L_, tid, gtid, lane, slot, chain, D, max_refr, origin, primary, may_rx, best_t, best_leaf, best_prim, tmin, S, pending, refr_code0)) break;
         }
 
-        // ---------------------------------------------------------------- write-back (ray_tracer.cu:246-253, normal_shader.cu:272-279)
-        const bool recv = received >= 0;
-        if ((recv || KEEP_ALL) && (!COOP || lane == 0)) {
-            RtsEndRecord r;
-            r.rayLength = rayLength; r.power = power; r.doppler = doppler;
-            r.prevx = prev.x; r.prevy = prev.y; r.prevz = prev.z;
-            r.firstx = s_first[tid]; r.firsty = s_first[RTS_BLOCK + tid]; r.firstz = s_first[2 * RTS_BLOCK + tid];
-            r.path_lo = s_path[tid]; r.path_hi = s_path[RTS_BLOCK + tid]; r.slot = slot; r.received = received; r.reflDepth = reflDepth;
-            r.pad = chain | (refrDepth << 2) | ((chain == 0 ? refr_code0 : 0u) << 8) | ((pending & 6u) << 15);   // chain, refrDepth, prefill code, spawned children
-            if (KEEP_ALL) a.all_records[(size_t)chain * a.n_rays + slot] = r;
-            if (recv) {
-                // the compiler folds this into one atomic per wave (v_mbcnt + s_bcnt1)
-                unsigned long long idx = atomicAdd(&a.counters[0], 1ULL);
-                a.recv_records[idx] = r;
-            }
-        }
+        rts_write_back<KEEP_ALL, COOP>(a, L_, tid, lane, slot, chain, S, pending, refr_code0);
       }   // chain
+}
+
+// ASYNCHRONOUS BOUNCES (the north star's "wave-level ballot / compaction of active rays"): the same launch
+// index per lane, but the lanes of a wave no longer move from segment to segment in lock step.  In rts_trace_unit a wave walks
+// until its SLOWEST lane has finished the segment (counting build, rts_get_lane_stats: 21-28 % of the issued lane-steps belong
+// to lanes that wait for that one, against 2 % to lanes whose ray has ended -- all that re-packing survivors between rounds
+// could recover).  Here a lane is in one of two states -- WALKING (node != sentinel) or ADVANCING (its walk of the current
+// target is over: try the next target's bounding sphere, or shade the segment and open the next one, or end) -- and the wave
+// alternates between an advance phase, run for the lanes that need it, and a walk phase that ends when no lane walks any more
+// OR when `idle_limit` lanes have come out of their walks: those are then advanced and re-join the walkers, whose walk state
+// (node, stack pointer, closest hit, prune bound, target: registers; the stack: LDS) simply stays where it is.
+// idle_limit = 64 is the lock-step schedule.  A low limit costs shading passes with few lanes in them (the shading code is
+// ~30 walk steps' worth of instructions), so the limit is a property of the TILE'S AGE: young tiles -- the 97 % that end within
+// a.async_age -- use a.async_idle0, tiles older than that a.async_idle1 (rts_api.hip: RTS_ASYNC_IDLE0/1, RTS_ASYNC_AGE).
+// No refraction chains here (REFR launches use rts_trace_unit).
+template <bool COUNT, bool KEEP_ALL>
+__device__ __forceinline__ void rts_trace_unit_async(const RtsTraceArgs& a, const RtsLaunchConsts& lc, const RtsUnitLds& L_, const uint32_t tid, const uint32_t gtid, const uint32_t lane,
+                                                     const uint32_t slot_in, const bool pre_on, const bool mask_on, const uint32_t D, const dvec3& origin, const long long tile_t0,
+                                                     uint32_t& n_nodes, uint32_t& n_tris, bool& hard_overflow, unsigned long long (&lane_stats)[3])
+{
+    int32_t* const s_stack = L_.stack; uint32_t* const s_n = L_.n;
+    const int SENTINEL = RTS_STACK_SENTINEL;
+    const int lds_cap = (int)a.stack_lds;
+    // Registers are what this schedule is short of: the walk state of the lanes that are NOT being advanced has to survive the
+    // shading code, on a kernel held to 128 VGPRs.  So between the phases a lane keeps its small payload fields packed in one
+    // word (`st`), the launch index is re-formed from the tile's first index (scalar) and the lane number where it is needed,
+    // and the malformed-tree guard counts the WAVE's walk iterations (scalar).
+    //   st: bits 0-7 reflDepth, 8 end, 9 chain_start, 10 live, 11 may_rx, 16-31 received + 1
+    const uint32_t slot0 = __builtin_amdgcn_readfirstlane(slot_in - lane);
+#define RTS_SLOT() (slot0 + __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)))
+    uint32_t st;
+    dvec3 dir, prev; double rayLength, power, doppler;
+    uint32_t targ;                                              // next target to try; the one being walked is targ - 1
+    {
+        RtsRay S;
+        bool may_target = a.n_prims > 0, may_rx = a.n_rx > 0;
+        rts_primary_setup(a, lc, L_, tid, slot_in, pre_on, mask_on, origin, S, may_target, may_rx);
+        dir = S.dir; prev = S.prev; rayLength = S.rayLength; power = S.power; doppler = S.doppler;
+        st = (1u << 9) | (1u << 10) | (may_rx ? 1u << 11 : 0u);
+        targ = may_target ? 0u : a.n_targets;                   // (a primary ray the pre-filter cleared tries no target)
+    }
+    // the open segment
+    float best_t = RTS_DEFAULT_TMAX, t_prune = RTS_DEFAULT_TMAX;
+    int best_leaf = -1; uint32_t best_prim = 0xffffffffu;
+    int node = SENTINEL, sp = 1;
+    uint32_t wave_steps = 0;
+    atomicAdd(&s_n[tid], RTS_SEG_ONE);
+    for (;;) {
+        // ---------------------------------------------------------------- advance: until the lane walks or its ray has ended
+        while ((st & (1u << 10)) && node == SENTINEL) {
+            if (targ < a.n_targets) {
+                const RtsTargetDev& TG = a.targets[targ++];
+                if (TG.root < 0) continue;
+                const dvec3 q = mk3(TG.cx - prev.x, TG.cy - prev.y, TG.cz - prev.z);          // bounding sphere of the placed target, as in rts_trace_unit
+                const double qq = q.x*q.x + q.y*q.y + q.z*q.z, b = q.x*dir.x + q.y*dir.y + q.z*dir.z;
+                if (qq > TG.r2) {
+                    const double dd = dir.x*dir.x + dir.y*dir.y + dir.z*dir.z;
+                    if (!(b > 0.0) || !(b*b >= (qq - TG.r2) * dd * 0.999999)) continue;
+                }
+                node = TG.root; sp = 1; s_stack[tid] = SENTINEL;
+            } else {
+                RtsRay S;
+                S.dir = dir; S.prev = prev; S.rayLength = rayLength; S.power = power; S.doppler = doppler; S.refx = 1; S.refy = 1;
+                S.reflDepth = st & 0xffu; S.refrDepth = 0; S.received = (int)(st >> 16) - 1; S.end = (st & (1u << 8)) != 0u; S.chain_start = (st & (1u << 9)) != 0u;
+                const bool primary = S.chain_start;
+                const float tmin = primary ? SCENE_EPS : SCENE_EPS_R;
+                uint32_t pending = 0, refr_code0 = 0;
+                const uint32_t slot = RTS_SLOT();
+                const bool go_on = rts_shade<KEEP_ALL, false, false>(a, L_, tid, gtid, lane, slot, 0u, D, 0u, origin, primary, (st & (1u << 11)) != 0u, best_t, best_leaf, best_prim, tmin, S, pending, refr_code0);
+                if (go_on) {
+                    atomicAdd(&s_n[tid], RTS_SEG_ONE);
+                    best_t = RTS_DEFAULT_TMAX; t_prune = RTS_DEFAULT_TMAX; best_leaf = -1; best_prim = 0xffffffffu;
+                    targ = a.n_prims > 0 ? 0u : a.n_targets;
+                } else {
+                    rts_write_back<KEEP_ALL, false>(a, L_, tid, lane, slot, 0u, S, pending, refr_code0);
+                }
+                dir = S.dir; prev = S.prev; rayLength = S.rayLength; power = S.power; doppler = S.doppler;
+                st = (S.reflDepth & 0xffu) | (S.end ? 1u << 8 : 0u) | (S.chain_start ? 1u << 9 : 0u) | (go_on ? 1u << 10 : 0u) | (st & (1u << 11)) | ((uint32_t)(S.received + 1) << 16);
+            }
+        }
+        const uint32_t n_live = (uint32_t)__popcll(__ballot((st & (1u << 10)) != 0u));
+        if (n_live == 0u) break;
+        // ---------------------------------------------------------------- the ray in the space of the lane's target (every live lane walks now;
+        // lanes that come back to a walk in progress recompute what they had: nothing of it is carried through the shading code)
+        RtsSlabRay lr;
+        {
+            const RtsTargetDev& TG = a.targets[targ - 1u];
+            const dvec3 q = mk3(prev.x - TG.px, prev.y - TG.py, prev.z - TG.pz);
+            const dvec3 ol = mk3(TG.rinv[0]*q.x + TG.rinv[1]*q.y + TG.rinv[2]*q.z, TG.rinv[3]*q.x + TG.rinv[4]*q.y + TG.rinv[5]*q.z, TG.rinv[6]*q.x + TG.rinv[7]*q.y + TG.rinv[8]*q.z);
+            const dvec3 dl = mk3(TG.rinv[0]*dir.x + TG.rinv[1]*dir.y + TG.rinv[2]*dir.z, TG.rinv[3]*dir.x + TG.rinv[4]*dir.y + TG.rinv[5]*dir.z,
+                                 TG.rinv[6]*dir.x + TG.rinv[7]*dir.y + TG.rinv[8]*dir.z);
+            lr = rts_slab_setup(ol, dl, TG.ew);
+        }
+        const float tmin = (st & (1u << 9)) ? SCENE_EPS : SCENE_EPS_R;
+        const uint32_t age = (uint32_t)((unsigned long long)(clock64() - tile_t0) >> 6);           // (s_memtime: wave-uniform)
+        const uint32_t idle_limit = age >= a.async_age ? a.async_idle1 : a.async_idle0;
+        // ---------------------------------------------------------------- walk
+        for (;;) {
+            if (node != SENTINEL) {
+                rts_walk_step<COUNT>(a, s_stack, tid, gtid, lds_cap, &s_n[2 * RTS_BLOCK + tid], node, sp, lr, prev, dir, tmin, best_t, best_leaf, best_prim, t_prune,
+                                     n_nodes, n_tris, hard_overflow);
+            }
+            if (++wave_steps > (1u << 26)) { hard_overflow = true; node = SENTINEL; }            // malformed tree guard (per wave and tile): every wave must drain
+            const uint32_t n_walk = (uint32_t)__popcll(__ballot(node != SENTINEL));
+            if (COUNT) { lane_stats[0] += 64u; lane_stats[1] += n_live; lane_stats[2] += n_walk; }     // (after the step: lanes that took it = n_walk + those that just finished; close enough for a ratio)
+            if (n_walk == 0u || n_live - n_walk >= idle_limit) break;
+        }
+    }
+#undef RTS_SLOT
 }
 
 // KEEP_ALL is a template parameter, not a run-time flag: hipcc (ROCm 7.2) lowered the uniform
@@ -596,7 +747,7 @@ __device__ __forceinline__ void rts_trace_unit(const RtsTraceArgs& a, const RtsL
 // history): it traces the 64 n_head launch indices of the tiles at the head of the cost order, one per wave; the ordinary
 // kernel then starts at position n_head of the order.  A kernel of its own because the shared walk needs ~40 registers more
 // than the 128 the ordinary kernel is held to (four waves per SIMD).
-template <bool COUNT, bool KEEP_ALL, bool REFR, bool COOP>
+template <bool COUNT, bool KEEP_ALL, bool REFR, bool COOP, bool ASYNC = false>
 __global__ void __launch_bounds__(RTS_BLOCK, (REFR || COOP) ? 2 : 4) k_trace(const RtsTraceArgs a)
 {
     __shared__ __attribute__((aligned(16))) int32_t s_stack[RTS_STACK_LDS * RTS_BLOCK];
@@ -724,7 +875,8 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR || COOP) ? 2 : 4) k_trace(con
       if (!COOP) atomicAnd(&s_n[tid], 0x003fffffu);              // (ds_and_b32: the tile's own segment count starts at zero; a register for it would be the 129th)
       const unsigned long long tl_tile = (COUNT && a.timeline && lane == 0) ? wall_clock64() : 0ULL;
       if (slot < a.n_rays) {
-          rts_trace_unit<COUNT, KEEP_ALL, REFR, COOP>(a, lc, ul, tid, gtid, lane, slot, pre_on, mask_on, D, max_refr, origin, n_nodes, n_tris, hard_overflow, lane_stats);
+          if (ASYNC) rts_trace_unit_async<COUNT, KEEP_ALL>(a, lc, ul, tid, gtid, lane, slot, pre_on, mask_on, D, origin, tile_t0, n_nodes, n_tris, hard_overflow, lane_stats);
+          else rts_trace_unit<COUNT, KEEP_ALL, REFR, COOP>(a, lc, ul, tid, gtid, lane, slot, pre_on, mask_on, D, max_refr, origin, n_nodes, n_tris, hard_overflow, lane_stats);
       }   // slot < n_rays
       // (the segment count of the tile is only formed for tiles long enough to matter: an all-miss tile is ~100 instructions)
       const unsigned long long dt = (unsigned long long)(clock64() - tile_t0) >> 6;             // (s_memtime: wave-uniform)
@@ -809,6 +961,15 @@ template <bool COOP>
 static void rts_trace_dispatch(const RtsTraceArgs& a, bool count_traversal, unsigned grid, hipStream_t st)
 {
     const int sel = (a.max_refr ? 4 : 0) | (a.keep_all ? 2 : 0) | (count_traversal ? 1 : 0);
+    if (!COOP && a.async_idle0 && sel < 4) {                      // asynchronous bounces (rts_trace_unit_async): ordinary kernel, no refraction chains
+        switch (sel) {
+            case 0: k_trace<false, false, false, false, true><<<grid, RTS_BLOCK, 0, st>>>(a); break;
+            case 1: k_trace<true, false, false, false, true><<<grid, RTS_BLOCK, 0, st>>>(a); break;
+            case 2: k_trace<false, true, false, false, true><<<grid, RTS_BLOCK, 0, st>>>(a); break;
+            default: k_trace<true, true, false, false, true><<<grid, RTS_BLOCK, 0, st>>>(a); break;
+        }
+        return;
+    }
     switch (sel) {
         case 0: k_trace<false, false, false, COOP><<<grid, RTS_BLOCK, 0, st>>>(a); break;
         case 1: k_trace<true, false, false, COOP><<<grid, RTS_BLOCK, 0, st>>>(a); break;

@@ -1088,6 +1088,48 @@ def test_cooperative_units_are_invisible(rts, scenes, monkeypatch):
         # triangles than ... nothing is guaranteed either way; what IS: both found the same closest hits (above)
 
 
+def test_asynchronous_bounces_are_invisible(rts, scenes, monkeypatch):
+    """RTS_ASYNC_IDLE0 > 0 selects the kernel whose lanes advance from segment to segment on their own
+    (rts_trace_unit_async: a walk phase ends as soon as `idle` lanes have come out of their walks; they are shaded and
+    re-join the lanes still walking, whose walk state stays in registers / LDS).  Which lanes are advanced together depends on
+    the limit and on timings (the limit switches with the tile's age), the results must not: lock step (the default kernel)
+    against limits 64, 8 and 1, in KEEP_ALL + counting builds and in the product build, several targets (a lane may be at
+    another target than its neighbour), a 3-entry LDS stack, Earth-centred coordinates, the miss-branch scene"""
+    import math
+    monkeypatch.setenv("RTS_GRID_MULT", "1"); monkeypatch.setenv("RTS_COOP_FRAC", "0")       # (no cooperative units: the node visits are compared)
+    c3 = scenes.config3(W=56, detail=0.3, rx_radius=300.0)
+    multi = scenes.config_multi(W=44)
+    cases = [("c3", c3, {}), ("c3 ecef", scenes.translate(c3, scenes.ecef_offset(lat=math.pi / 2)), {}), ("multi", multi, {}),
+             ("c3 short stack", c3, {"RTS_STACK_LDS_DEBUG": "3"}), ("miss branches", scenes.config_miss_branches(W=44), {})]
+    for name, spec, env in cases:
+        n = spec["W"] ** 3
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out = {}
+        for mode in ("0", "64", "8", "1"):
+            monkeypatch.setenv("RTS_ASYNC_IDLE0", mode); monkeypatch.setenv("RTS_ASYNC_IDLE1", "1" if mode == "64" else mode if mode != "0" else "1"); monkeypatch.setenv("RTS_ASYNC_AGE", "40")
+            tr = H.gpu_tracer(rts, spec, keep_all=True, count_traversal=True)
+            tp = H.gpu_tracer(rts, spec)                                        # the product build
+            for rep in range(2):
+                _, st = H.gpu_trace(rts, spec, tr=tr); _, sp = H.gpu_trace(rts, spec, tr=tp)
+            out[mode] = (tr.all_rays(n), tr.received(), st, tp.received(), sp)
+            tr.close(); tp.close()
+        for k in env:
+            monkeypatch.delenv(k)
+        a, ra, sa, pa, spa = out["0"]
+        for mode in ("64", "8", "1"):
+            b, rb, sb, pb, spb = out[mode]
+            _all_equal(a, b, "%s, idle limit %s" % (name, mode))
+            for x, y, what in ((ra, rb, "counting build"), (pa, pb, "product build"), (ra, pb, "product vs counting")):
+                assert np.array_equal(x["slots"], y["slots"]) and np.array_equal(x["path"], y["path"]), (name, mode, what)
+                H.assert_prd_equal(x["results"], y["results"], "%s (received, %s, idle limit %s)" % (name, what, mode))
+                np.testing.assert_allclose(x["rcs_angle"], y["rcs_angle"], rtol=0, atol=1e-12)
+            # the same walks, step for step: only their interleaving differs
+            assert (sa["segments"], sa["shaded"], sa["received"], sa["node_visits"], sa["tri_tests"]) == (sb["segments"], sb["shaded"], sb["received"], sb["node_visits"], sb["tri_tests"]), (name, mode)
+            assert (spb["segments"], spb["shaded"], spb["received"]) == (sa["segments"], sa["shaded"], sa["received"]), (name, mode)
+        assert sa["received"] > 0 and sa["tri_tests"] >= sa["shaded"] > 0, name
+
+
 def test_primary_prefilter_switches_off_when_most_rays_hit(rts, scenes):
     """a handle whose last launch shaded more hits than half its launch indices runs the next one without the filter
     (it would cost every ray and skip none) -- seen through the node visits of the counting build; results unchanged"""
