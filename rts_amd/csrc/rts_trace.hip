@@ -27,8 +27,8 @@
 //     t(P) = (P - o) / d  =  fma(P, i, c),   i = 1/d,  c = -o i
 // -- ONE instruction per plane, with per-ray constants (i, c) that already carry the whole error budget, chosen by the role
 // the plane plays for this ray (d > 0: the box's low plane is the entry plane, its high plane the exit plane; d < 0 the
-// other way round), so the per-node code needs no sign selects: it evaluates tL = fma(lo, iL, cL), tH = fma(hi, iH, cH)
-// and takes min / max.  Error budget (f32, eps = 2^-24):
+// other way round): the record fetch brings each lane ITS entry and exit planes (RtsSlabRay::sg below), the per-node code
+// evaluates near = fma(N, iN, cN), far = fma(F, iF, cF) per axis and takes max3 / min3 over the axes.  Error budget (f32, eps = 2^-24):
 //   o32 = fl32(o): |o - o32| <= eps |o|; c = fl(o' i') with o' = o32 -+ E: its rounding, eps |o' i'|, is a shift of the
 //   origin by eps |o'|; the f64 hit point that has to lie inside the box is off the ideal target-space point by `extra`
 //   (world-scale rounding of the placed vertices, RtsTargetDev::ew).  E = 4.5e-7 max|o| + extra covers all three (2.7 eps
@@ -38,8 +38,16 @@
 //   towards zero the clamp max(., 0) of the caller makes it irrelevant; an exit value that comes out negative belongs to
 //   a box behind the origin, E included.)
 //   d = 0 (or |1/d| beyond 1e30, where o i could overflow): the axis is dropped (entry -inf, exit +inf) -- conservative.
-struct RtsSlabRay { float iLx, cLx, iHx, cHx, iLy, cLy, iHy, cHy, iLz, cLz, iHz, cHz; };
-__device__ __forceinline__ void rts_slab_axis(float o, float d, float E, float& iL, float& cL, float& iH, float& cH)
+// Constants by ROLE, not by plane (round 3): N = the plane the ray enters the slab through (the box's LOW plane when d > 0, its
+// HIGH plane when d < 0), F = the plane it leaves through.  The SIGN of iN? says which: the N plane of an axis sits 0 or 48 bytes
+// behind the node record's low plane of that axis (hi? = lo? + 48, RtsNode4; a dropped axis has iN = +0) -- the record fetch adds
+// that to the address of the lane's N-plane load and 48 minus that to the F-plane load's, so the registers come back holding near / far planes and the node
+// code needs neither sign selects nor the min / max pair per axis that sorted the two parameters (24 of the node step's 41
+// min / max instructions, each twice the issue cost of an fma: profiles/r03_valu_calib.json).  Same values as before wherever
+// entry <= exit; an axis whose parameters come out crossed (a flat box far behind the origin) now reads as the empty
+// interval it is -- a miss either way (exit < 0).
+struct RtsSlabRay { float iNx, cNx, iFx, cFx, iNy, cNy, iFy, cFy, iNz, cNz, iFz, cFz; };
+__device__ __forceinline__ void rts_slab_axis(float o, float d, float E, float& iN_, float& cN_, float& iF_, float& cF_)
 {
     const float iv = 1.0f / d;
     const bool pos = !(iv < 0.0f);
@@ -48,18 +56,17 @@ __device__ __forceinline__ void rts_slab_axis(float o, float d, float E, float& 
     const float cN = -(oN * iN), cF = -(oF * iF);
     const bool drop = !(fabsf(iv) < 1.0e30f);                               // d == 0, denormal d, NaN
     const float NINF = -__builtin_inff(), PINF = __builtin_inff();
-    // the low plane is the entry plane when d > 0
-    iL = drop ? 0.0f : (pos ? iN : iF); cL = drop ? NINF : (pos ? cN : cF);
-    iH = drop ? 0.0f : (pos ? iF : iN); cH = drop ? PINF : (pos ? cF : cN);
+    iN_ = drop ? 0.0f : iN; cN_ = drop ? NINF : cN;
+    iF_ = drop ? 0.0f : iF; cF_ = drop ? PINF : cF;
 }
 __device__ __forceinline__ RtsSlabRay rts_slab_setup(const dvec3& o, const dvec3& d, float extra)
 {
     RtsSlabRay r;
     const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
     const float E = fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) * 4.5e-7f + extra + 1.0e-30f;
-    rts_slab_axis(ox, (float)d.x, E, r.iLx, r.cLx, r.iHx, r.cHx);
-    rts_slab_axis(oy, (float)d.y, E, r.iLy, r.cLy, r.iHy, r.cHy);
-    rts_slab_axis(oz, (float)d.z, E, r.iLz, r.cLz, r.iHz, r.cHz);
+    rts_slab_axis(ox, (float)d.x, E, r.iNx, r.cNx, r.iFx, r.cFx);
+    rts_slab_axis(oy, (float)d.y, E, r.iNy, r.cNy, r.iFy, r.cFy);
+    rts_slab_axis(oz, (float)d.z, E, r.iNz, r.cNz, r.iFz, r.cFz);
     return r;
 }
 
@@ -71,24 +78,48 @@ __device__ __forceinline__ RtsSlabRay rts_slab_setup(const dvec3& o, const dvec3
 // the backend does not track vector-memory loads issued from inline asm and the hardware has no interlock on a VGPR with a
 // load in flight, so nothing the compiler might place (a copy, a spill of q0..q6) may come between the loads and the wait.
 typedef unsigned int rts_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void rts_fetch_record(const void* p, int node, rts_u32x4& q0, rts_u32x4& q1, rts_u32x4& q2, rts_u32x4& q3,
+// Loads: q0..q2 <- N planes x, y, z (record + 0 / 16 / 32 + offset), q3..q5 <- F planes (record + 0 / 16 / 32 + 48 - offset),
+// q6 <- the child ids (record + 96); q5, q6 for the lanes at nodes only.  A lane at a leaf reads its record straight through
+// (offsets 0: nm = 0).
+__device__ __forceinline__ void rts_fetch_record(const void* p, int node, uint32_t nm, float iNx, float iNy, float iNz, rts_u32x4& q0, rts_u32x4& q1, rts_u32x4& q2, rts_u32x4& q3,
                                                  rts_u32x4& q4, rts_u32x4& q5, rts_u32x4& q6)
 {
+    // nm = 48 for a lane at a node, 0 at a leaf.  Per axis: off = (sign of iN ? 48 : 0) & nm; N-plane address = record + off,
+    // F-plane address = record + (off ^ 48) -- formed INSIDE the block, one axis after the other, in one 64-bit temporary (a
+    // load's address registers are read when it issues; its successor may overwrite them): as six 64-bit operands the
+    // addresses cost the kernel twelve registers at its tightest point, and spills in the loops around the walk.
     // (the lanes at nodes -- node >= 0 -- are found and EXEC is parked in VCC, which the allocator never hands out as a
-    // general pair: the kernel has no scalar register to spare)
-    asm volatile("global_load_dwordx4 %0, %7, off\n\t"
+    // general pair: the kernel has no scalar register to spare; the carry-out of the address additions goes to VCC as well,
+    // before that)
+    unsigned long long t; uint32_t o;
+    asm volatile("v_ashrrev_i32 %8, 31, %12\n\t"
+                 "v_and_b32 %8, %8, %11\n\t"
+                 "v_mad_u64_u32 %7, vcc, %8, 1, %9\n\t"
+                 "global_load_dwordx4 %0, %7, off\n\t"
+                 "v_xor_b32 %8, 48, %8\n\t"
+                 "v_mad_u64_u32 %7, vcc, %8, 1, %9\n\t"
+                 "global_load_dwordx4 %3, %7, off\n\t"
+                 "v_ashrrev_i32 %8, 31, %13\n\t"
+                 "v_and_b32 %8, %8, %11\n\t"
+                 "v_mad_u64_u32 %7, vcc, %8, 1, %9\n\t"
                  "global_load_dwordx4 %1, %7, off offset:16\n\t"
+                 "v_xor_b32 %8, 48, %8\n\t"
+                 "v_mad_u64_u32 %7, vcc, %8, 1, %9\n\t"
+                 "global_load_dwordx4 %4, %7, off offset:16\n\t"
+                 "v_ashrrev_i32 %8, 31, %14\n\t"
+                 "v_and_b32 %8, %8, %11\n\t"
+                 "v_mad_u64_u32 %7, vcc, %8, 1, %9\n\t"
                  "global_load_dwordx4 %2, %7, off offset:32\n\t"
-                 "global_load_dwordx4 %3, %7, off offset:48\n\t"
-                 "global_load_dwordx4 %4, %7, off offset:64\n\t"
-                 "v_cmp_lt_i32 vcc, -1, %8\n\t"
+                 "v_xor_b32 %8, 48, %8\n\t"
+                 "v_mad_u64_u32 %7, vcc, %8, 1, %9\n\t"
+                 "v_cmp_lt_i32 vcc, -1, %10\n\t"
                  "s_and_saveexec_b64 vcc, vcc\n\t"
-                 "global_load_dwordx4 %5, %7, off offset:80\n\t"
-                 "global_load_dwordx4 %6, %7, off offset:96\n\t"
+                 "global_load_dwordx4 %5, %7, off offset:32\n\t"
+                 "global_load_dwordx4 %6, %9, off offset:96\n\t"
                  "s_mov_b64 exec, vcc\n\t"
                  "s_waitcnt vmcnt(0)"
-                 : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5), "=&v"(q6)     // (q5, q6: written for the lanes at nodes only, read by them only)
-                 : "v"(p), "v"(node) : "memory", "scc", "vcc");
+                 : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5), "=&v"(q6), "=&v"(t), "=&v"(o)     // (q5, q6: written for the lanes at nodes only, read by them only)
+                 : "v"(p), "v"(node), "v"(nm), "v"(iNx), "v"(iNy), "v"(iNz) : "memory", "scc", "vcc");
 }
 
 // The stack entry below the top when it may live in the global spill slab (rare; kept out of line so that the common LDS
@@ -118,22 +149,22 @@ __device__ __forceinline__ void rts_walk_step(const RtsTraceArgs& a, int32_t* s_
     const bool at_node = node >= 0;
     const void* rp = at_node ? static_cast<const void*>(a.nodes4 + node) : static_cast<const void*>(a.leaves + ~node);
     rts_u32x4 q0, q1, q2, q3, q4, q5, q6;
-    rts_fetch_record(rp, node, q0, q1, q2, q3, q4, q5, q6);
+    rts_fetch_record(rp, node, at_node ? 48u : 0u, lr.iNx, lr.iNy, lr.iNz, q0, q1, q2, q3, q4, q5, q6);
     if (at_node) {
         // BVH4 node: six dwordx4 planes (lo/hi x,y,z of the four children) + the four child ids
         // (by value through __uint_as_float: __builtin_bit_cast applied to an ext-vector ELEMENT reads element 0)
 #define RTS_F4(q) make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w))
-        const float4 LX = RTS_F4(q0), LY = RTS_F4(q1), LZ = RTS_F4(q2), HX = RTS_F4(q3), HY = RTS_F4(q4), HZ = RTS_F4(q5);
+        const float4 NX = RTS_F4(q0), NY = RTS_F4(q1), NZ = RTS_F4(q2), FX = RTS_F4(q3), FY = RTS_F4(q4), FZ = RTS_F4(q5);     // near / far planes of the four children
 #undef RTS_F4
         const int4 CH = make_int4((int)q6.x, (int)q6.y, (int)q6.z, (int)q6.w);
         if (COUNT) n_nodes++;
         const float INF = __builtin_inff();
 #define RTS_CHILD(k, dk) float dk; { \
-            const float ax = __builtin_fmaf(LX.k, lr.iLx, lr.cLx), bx = __builtin_fmaf(HX.k, lr.iHx, lr.cHx); \
-            const float ay = __builtin_fmaf(LY.k, lr.iLy, lr.cLy), by = __builtin_fmaf(HY.k, lr.iHy, lr.cHy); \
-            const float az = __builtin_fmaf(LZ.k, lr.iLz, lr.cLz), bz = __builtin_fmaf(HZ.k, lr.iHz, lr.cHz); \
-            const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f)); \
-            const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), t_prune)); \
+            const float nx = __builtin_fmaf(NX.k, lr.iNx, lr.cNx), fx = __builtin_fmaf(FX.k, lr.iFx, lr.cFx); \
+            const float ny = __builtin_fmaf(NY.k, lr.iNy, lr.cNy), fy = __builtin_fmaf(FY.k, lr.iFy, lr.cFy); \
+            const float nz = __builtin_fmaf(NZ.k, lr.iNz, lr.cNz), fz = __builtin_fmaf(FZ.k, lr.iFz, lr.cFz); \
+            const float tn = fmaxf(fmaxf(fmaxf(nx, ny), nz), 0.0f); \
+            const float tf = fminf(fminf(fminf(fx, fy), fz), t_prune); \
             dk = (tn <= tf) ? tn : INF; }
         RTS_CHILD(x, d0) RTS_CHILD(y, d1) RTS_CHILD(z, d2) RTS_CHILD(w, d3)
 #undef RTS_CHILD
