@@ -136,6 +136,8 @@ def main():
     ap.add_argument("--width", type=int, default=0, help="W (launch indices per pulse = W^3); 0 = the config's own")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--link", action="store_true", help="rts_link_handles: the handles' trace kernels run strictly one at a time")
+    ap.add_argument("--no-bind", action="store_true", help="leave the process's CPU affinity alone (default: the CPUs of the GPU's NUMA node)")
+    ap.add_argument("--post-lag", type=int, default=0, choices=(0, 1), help="1: a pulse's group table is collected one pulse later (the submitting thread does not wait for the post-processing it has just enqueued)")
     ap.add_argument("--inflight", type=int, default=3, help="pulses in flight per GPU; 1 = strictly sequential pulses")
     ap.add_argument("--config", default="c3", choices=["c2", "c2file", "c3", "c3ecef", "c3ico", "c4"], help="c3 = BASELINE configs[2] (the metric's workload); c4 = configs[3]'s scene and size on ONE transmitter (100 M launch indices per pulse: give --steps 32)")
     ap.add_argument("--shard", default="pulses", choices=["pulses", "rays"], help="N > 1: deal whole pulses to the ranks, or split every pulse over all ranks (interleaved tiles)")
@@ -145,6 +147,28 @@ def main():
     import torch
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # One process per GPU, on the GPU's socket -- BEFORE this process touches the GPU, so that the runtime's threads, its signal
+    # pools and the handles' pinned blocks all come to live there: a child process asks the runtime for the device's PCI address
+    # (the parent must not initialise HIP for that), sysfs says which NUMA node that is and which CPUs it has.  On the
+    # two-socket hosts of this pool the other socket costs a pipelined pulse ~0.05 ms (profiles/r03c_bind_ab.log).
+    numa_node = -1
+    profiled = any(k.startswith("ROCPROF") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")      # (a profiler's preloaded library has initialised the GPU already: no child process then -- the library call below binds after the fact)
+    if not args.no_bind and not profiled:
+        try:
+            import subprocess
+            q = ("import ctypes as C\nh=C.CDLL('libamdhip64.so')\nn=C.c_int(0)\nh.hipGetDeviceCount(C.byref(n))\nb=C.create_string_buffer(64)\n"
+                 "print(b.value.decode() if n.value and h.hipDeviceGetPCIBusId(b,64,%d %% n.value)==0 else '')" % local_rank)
+            bdf = subprocess.run([sys.executable, "-c", q], capture_output=True, text=True, timeout=60).stdout.strip().lower()
+            node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read()) if bdf else -1
+            if node >= 0:
+                cpus = set()
+                for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+                    a, _, b = part.partition("-"); cpus.update(range(int(a), int(b or a) + 1))
+                cpus &= os.sched_getaffinity(0)
+                if cpus:
+                    os.sched_setaffinity(0, cpus); numa_node = node
+        except Exception:                                         # (no sysfs, no permission, another platform: the scheduler's choice stands)
+            pass
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
@@ -168,6 +192,11 @@ def main():
     import rts_amd
     from rts_amd import api, scenes, multigpu
     rts_amd._lib.require_built()                                  # never builds (see _lib.require_built)
+    if not args.no_bind and numa_node < 0 and hasattr(rts_amd._lib.lib(), "rts_bind_host_to_device"):
+        import ctypes
+        nn = ctypes.c_int(-1)
+        if rts_amd._lib.lib().rts_bind_host_to_device(local_rank % max(torch.cuda.device_count(), 1), ctypes.byref(nn)) == 0:
+            numa_node = nn.value
     if args.config == "c3":
         spec = scenes.config3(W=args.width or 216)
     elif args.config == "c3ecef":
@@ -223,12 +252,25 @@ def main():
         cube.zero_(); torch.cuda.synchronize()
         t_cpi = time.perf_counter()
 
-        def finish(t, k):
+        hp = acc.setdefault("host_ms", dict(begin=0.0, end_wait=0.0, post_enqueue=0.0, collect_wait=0.0))      # where the submitting thread spends the interval
+
+        def post(t, k):
+            """the pulse's trace has to be over (received count); everything after it is only ENQUEUED"""
+            h0 = time.perf_counter()
             t.trace_end()
+            h1 = time.perf_counter()
             t.finalise_uniform(None, wl, 1.0, 1.0, spec["carrier"], spec["c"])
             t.cube_accumulate(k, spec["c"], spec["carrier"])
-            groups = t.aggregate(spec["c"], spec["carrier"], rts_amd._lib.RTS_BASE_USE_ROWS)
-            st = t.stats()                                    # stream already drained by the aggregation's table fetch
+            t.aggregate(spec["c"], spec["carrier"], rts_amd._lib.RTS_BASE_USE_ROWS, fetch=False)
+            h2 = time.perf_counter()
+            hp["end_wait"] += (h1 - h0) * 1e3; hp["post_enqueue"] += (h2 - h1) * 1e3
+
+        def collect(t, k):
+            """wait for the pulse's post-processing and take its group table"""
+            h0 = time.perf_counter()
+            groups = t.groups()
+            hp["collect_wait"] += (time.perf_counter() - h0) * 1e3
+            st = t.stats()                                    # stream already drained by the table fetch
             parts.append(dict(pulse=k, groups=groups))
             acc["segments"] += st["segments"]; acc["shaded"] += st["shaded"]; acc["received"] += st["received"]
             acc["ms_scene"] += st["ms_scene"]; acc["ms_trace"] += st["ms_trace"]; acc["ms_post"] += st["ms_compact"] + st["ms_aggregate"]
@@ -236,15 +278,30 @@ def main():
             if os.environ.get("BENCH_DEBUG"):
                 print("pulse %d done at %.3f ms: scene %.3f trace %.3f compact %.3f agg %.3f" % (k, (time.perf_counter() - t_cpi) * 1e3, st["ms_scene"], st["ms_trace"], st["ms_compact"], st["ms_aggregate"]), file=sys.stderr)
 
-        pending = []
+        # The submitting thread never waits for a chain of small kernels it has just enqueued: with --post-lag 1 (default when
+        # there are >= 3 handles) the handles hold, in pulse order, [one pulse whose post-processing runs] [handles - 1 pulses
+        # tracing]; the oldest pulse's table is collected just before its handle takes a new pulse.  --post-lag 0: the oldest
+        # pulse is completed (trace, post-processing, table) before the next one is begun -- every handle traces.
+        lag = args.post_lag if len(trs) >= 2 else 0
+        pending = []; posted = []
         for i, (k, first, count, il) in enumerate(plan(n_pulses)):
             t = trs[i % len(trs)]
+            while any(p[0] is t for p in posted):
+                collect(*posted.pop(0))
+            h0 = time.perf_counter()
             t.trace_begin(tx["origin"], tx["span"], tx["dir"], pulse_motion(spec, k0 + k), ray_first=first, ray_count=count, interleave=il)
+            hp["begin"] += (time.perf_counter() - h0) * 1e3
             pending.append((t, k))
-            if len(pending) == len(trs):                      # the oldest pulse in flight is completed while the newer ones run
-                finish(*pending.pop(0))
+            if len(pending) == len(trs) - lag:                # the oldest pulse in flight is taken further while the newer ones run
+                tk = pending.pop(0); post(*tk)
+                if lag:
+                    posted.append(tk)
+                else:
+                    collect(*tk)
         while pending:
-            finish(*pending.pop(0))
+            tk = pending.pop(0); post(*tk); posted.append(tk)
+        while posted:
+            collect(*posted.pop(0))
         t_a = time.perf_counter()
         allp = multigpu.exchange_parts(parts, dist, torch)    # ONE exchange per CPI (RCCL all-gather), inside the timed region
         t_b = time.perf_counter()
@@ -390,8 +447,9 @@ def main():
                        "hit_fraction": hit_fraction, "primary_Mrays_per_s": total * args.steps / dt / 1e6,
                        "return_cube": "complex128 [%d rx][%d pulses][%d bins], all-reduced once per interval, then %d-point slow-time FFT in the library (rts_cube_doppler, inside the timed region); range-Doppler peak %.6e, max deviation from torch.fft %.1e (relative)" % (cube.shape[0], cube.shape[1], n_bins, n_fft, range_doppler_peak, range_doppler_err or 0.0),
                        "sharding": ("%d-pulse interval over %d ranks, --shard %s: " % (args.steps, world, args.shard)) + ("every pulse split over all ranks in interleaved 4096-index tiles" if args.shard == "rays" else "whole pulses, left-over pulses in interleaved 4096-index tiles") + "; one group-table all-gather + one cube all-reduce per interval",
-                       "pulses_in_flight": len(trs), "linked": bool(args.link), "scene_setup_s": scene_setup_s,
+                       "host_numa_node": numa_node, "pulses_in_flight": len(trs), "linked": bool(args.link), "scene_setup_s": scene_setup_s,
                        "interval_tail_ms_rank0": acc["tail_ms"],
+                       "host_ms_per_pulse_rank0": {k: v / max(acc["launches"], 1) for k, v in acc["host_ms"].items()},
                        "stage_ms_per_launch_rank0": {"scene_placement": ms_scene / launches, "trace": ms_trace / launches, "order+finalise+aggregate": ms_post / launches}},
             "roofline": roof,
         }

@@ -162,6 +162,11 @@ const char* rts_last_error(void);
 /* 16 hex digits: SHA-256 (truncated) of the sources the library was built from (rts_amd/csrc/*.hip|cpp|h + rts_amd.h + rts_prd.h,
  * in byte order of their names).  Profiles record it; bench.py refuses to price a run with counters of another build. */
 const char* rts_build_id(void);
+/* Restrict the calling process's threads to the CPUs of `device`'s NUMA node (one process per GPU, on the GPU's socket: kernel
+ * launches and completion signals then stay on one socket -- 7 % of a pipelined pulse on a two-socket host).  Optional; call it
+ * before creating handles, so that their pinned host blocks are allocated on that node too.  *numa_node (may be NULL): the node,
+ * -1 if the platform does not report one (nothing is changed then). */
+int rts_bind_host_to_device(int device, int* numa_node);
 int rts_device_count(int* n);
 
 /* ---------------------------------------------------------------- scene */

@@ -208,8 +208,12 @@ class Tracer:
         r = np.ascontiguousarray(rcs_per_target, np.float64) if rcs_per_target is not None else None
         check(L.lib().rts_finalise_uniform(self.h, ptr(r), wavelength, gt, gr, carrier, cspeed))
 
-    def aggregate(self, cspeed, carrier, recv_index_base=0):
+    def aggregate(self, cspeed, carrier, recv_index_base=0, fetch=True):
+        """fetch=False: only enqueue (the library reads the group table when it is first asked for: groups())"""
         check(L.lib().rts_aggregate(self.h, cspeed, carrier, recv_index_base))
+        return self.groups() if fetch else None
+
+    def groups(self):
         n = C.c_uint32(0)
         check(L.lib().rts_group_count(self.h, C.byref(n)))
         g = np.zeros(max(n.value, 1), GROUP_DTYPE)

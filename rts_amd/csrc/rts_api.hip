@@ -27,6 +27,50 @@ extern "C" const char* rts_last_error(void) { return g_err; }
 #include "rts_build_id.h"
 extern "C" const char* rts_build_id(void) { return RTS_SOURCE_HASH; }
 
+// One process (or one group of host threads) per GPU, ON THE GPU'S SOCKET: every kernel launch is a doorbell write and every
+// completion a signal read across the fabric otherwise -- on the two-socket hosts of this pool a pipelined BASELINE configs[2]
+// pulse took 0.68 ms instead of 0.63 ms when the scheduler happened to start the process on the other socket (the host side
+// of rts_trace_pulse_begin alone 0.13 instead of 0.08 ms).  Restricts EVERY thread the process has at the time of the call
+// (the runtime's helper threads included; threads created later inherit) to the CPUs of the device's NUMA node, within the
+// set the process is allowed already.  *numa_node: the node, -1 when the platform does not say (nothing is changed then).
+#include <dirent.h>
+#include <sched.h>
+extern "C" int rts_bind_host_to_device(int device, int* numa_node)
+{
+    if (numa_node) *numa_node = -1;
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), device) != hipSuccess) { (void)hipGetLastError(); rts_set_error("rts_bind_host_to_device: no PCI address for device %d", device); return RTS_ERR_INVALID; }
+    for (char* q = bdf; *q; q++) *q = (char)tolower((unsigned char)*q);
+    char path[256]; snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bdf);
+    int node = -1;
+    if (FILE* f = fopen(path, "r")) { if (fscanf(f, "%d", &node) != 1) node = -1; fclose(f); }
+    if (node < 0) return RTS_OK;
+    snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    cpu_set_t want; CPU_ZERO(&want); int n_want = 0;
+    if (FILE* f = fopen(path, "r")) {                                  // "64-127,192-255"
+        int a = 0, b = 0; char sep = 0;
+        while (fscanf(f, "%d", &a) == 1) {
+            b = a;
+            int ch = fgetc(f);
+            if (ch == '-') { if (fscanf(f, "%d", &b) != 1) b = a; ch = fgetc(f); }
+            for (int k = a; k <= b && k < CPU_SETSIZE; k++) { CPU_SET(k, &want); n_want++; }
+            sep = (char)ch; if (sep != ',') break;
+        }
+        fclose(f);
+    }
+    if (n_want == 0) return RTS_OK;
+    cpu_set_t have; CPU_ZERO(&have);
+    if (sched_getaffinity(0, sizeof(have), &have) != 0) return RTS_OK;
+    cpu_set_t both; CPU_AND(&both, &want, &have);
+    if (CPU_COUNT(&both) == 0) return RTS_OK;                           // (the process is confined to the other socket: leave it)
+    if (DIR* d = opendir("/proc/self/task")) {
+        while (struct dirent* e = readdir(d)) { const int tid = atoi(e->d_name); if (tid > 0) (void)sched_setaffinity(tid, sizeof(both), &both); }
+        closedir(d);
+    } else (void)sched_setaffinity(0, sizeof(both), &both);
+    if (numa_node) *numa_node = node;
+    return RTS_OK;
+}
+
 extern int rts_fill_i32(hipStream_t st, int32_t* p, int32_t v, size_t n);
 static int rts_attach_scene(RtsContext* c);
 void rts_comm_cache_forget(RtsContext* c);
@@ -524,7 +568,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     if (first > total || count > total - first) { rts_set_error("rts_trace_pulse: ray range [%llu, +%llu) outside W^3 = %llu", (unsigned long long)first, (unsigned long long)count, (unsigned long long)total); return RTS_ERR_INVALID; }
     const uint32_t n_targets = (uint32_t)c->scene->meshes.size();
     hipStream_t st = c->stream;
-    c->agg_valid = false; c->n_recv = 0;
+    c->agg_valid = false; c->agg_pending.valid = false; c->n_recv = 0;
 
     // ---- scene placement: only when a target actually moved
     RTS_HIP(hipEventRecord(c->ev[0], st));
@@ -812,6 +856,7 @@ extern "C" int rts_aggregate(RtsHandle c, double cspeed, double carrier, uint64_
     CHECK_HANDLE(c);
     CHECK_CLOSED(c);
     const uint64_t R = c->n_recv;
+    c->agg_pending.valid = false;                                       // (an unread table of an earlier call is dropped)
     c->groups.clear(); c->recv_index_base = recv_index_base;
     if (R == 0) { c->agg_valid = true; return RTS_OK; }
     RTS_HIP(c->d_delay.reserve(R)); RTS_HIP(c->d_phase.reserve(R)); RTS_HIP(c->d_pathmatch.reserve(R));
@@ -834,6 +879,7 @@ extern "C" int rts_group_count(RtsHandle c, uint32_t* count)
 {
     if (!c || !count) { rts_set_error("rts_group_count: null argument"); return RTS_ERR_INVALID; }
     if (!c->agg_valid) { rts_set_error("rts_group_count: call rts_aggregate first"); return RTS_ERR_INVALID; }
+    { int rc = rts_aggregate_fetch(c, &c->groups); if (rc != RTS_OK) return rc; }
     *count = (uint32_t)c->groups.size(); return RTS_OK;
 }
 
@@ -841,6 +887,7 @@ extern "C" int rts_get_groups(RtsHandle c, RtsGroup* groups, uint32_t capacity)
 {
     if (!c || (!groups && capacity)) { rts_set_error("rts_get_groups: null argument"); return RTS_ERR_INVALID; }
     if (!c->agg_valid) { rts_set_error("rts_get_groups: call rts_aggregate first"); return RTS_ERR_INVALID; }
+    { int rc = rts_aggregate_fetch(c, &c->groups); if (rc != RTS_OK) return rc; }
     if (capacity < c->groups.size()) { rts_set_error("rts_get_groups: capacity too small"); return RTS_ERR_CAPACITY; }
     if (!c->groups.empty()) memcpy(groups, c->groups.data(), sizeof(RtsGroup)*c->groups.size());
     return RTS_OK;
@@ -1191,7 +1238,7 @@ extern "C" int rts_kernel_wrapper_on(RtsHandle h, PerRayData* h_rx_results_arr, 
     if (!h_rx_results_arr || (depthTotal && !h_rx_intersects_arr) || !h_delay_arr || !h_phase_arr || !h_pathMatch) { rts_set_error("rts_kernel_wrapper: null array"); return RTS_ERR_INVALID; }
     RtsContext* c = h;
     if (!c) { int rc = wrapper_context(&c); if (rc != RTS_OK) return rc; }
-    else { CHECK_CLOSED(c); c->agg_valid = false; c->n_recv = 0; }      // the handle's own received set is overwritten
+    else { CHECK_CLOSED(c); c->agg_valid = false; c->agg_pending.valid = false; c->n_recv = 0; }      // the handle's own received set is overwritten
     RTS_HIP(hipSetDevice(c->device));
     const size_t R = receivedRays, D = depthTotal;
     RTS_HIP(c->d_rx_rays.reserve(R)); RTS_HIP(c->d_rx_paths.reserve(R*D + 1)); RTS_HIP(c->d_delay.reserve(R)); RTS_HIP(c->d_phase.reserve(R)); RTS_HIP(c->d_pathmatch.reserve(R));

@@ -237,6 +237,9 @@ struct RtsScene {
                      d_verts_local.release(); d_normals_local.release(); d_nodes4.release(); d_leaf_prim.release(); }
 };
 
+// rts_aggregate enqueues; the table is read (stream wait + pinned block -> RtsGroup records) by the first call that needs it
+struct RtsAggPending { bool valid = false, wide = false, rows = false; uint32_t R = 0, D = 0, B = 0, shift = 0, spec = 0; uint64_t base = 0; double* gsum = nullptr; };
+
 struct RtsContext {
     RtsParams params;
     uint32_t depth;                 // D = max_refr + max_refl
@@ -288,6 +291,7 @@ struct RtsContext {
     DevBuf<double> d_gsum; DevBuf<uint32_t> d_gmin; DevBuf<uint64_t> d_gkey; DevBuf<uint32_t> d_gcount; DevBuf<uint64_t> d_grow; DevBuf<int32_t> d_gpath;
     DevBuf<double> d_delay, d_phase; DevBuf<int32_t> d_pathmatch; DevBuf<double> d_rcs;
     std::vector<RtsGroup> groups; bool agg_valid = false; uint64_t recv_index_base = 0;
+    RtsAggPending agg_pending;          // the group table of the last rts_aggregate is still on its way (rts_aggregate_fetch reads it)
     RtsCubeParams cube_params; double* cube = nullptr; DevBuf<double> d_cube_own; bool cube_set = false;
     DevBuf<double> d_doppler_own; double* doppler = nullptr; uint32_t doppler_n = 0;       // slow-time transform of the cube (rts_cube_doppler)
     bool agg_delay_in = true;           // rts_aggregate_device: the delay / phase arrays carry initial sums (rs::kernel_wrapper's in-out arguments); false: they start at zero
@@ -311,6 +315,7 @@ int rts_cube_accumulate_device(RtsContext* c, uint32_t pulse_index, double cspee
 int rts_cube_accumulate_paths_device(RtsContext* c, uint32_t pulse_index, int64_t base);
 int rts_cube_doppler_device(RtsContext* c, uint32_t n_fft, double* out);
 int rts_post_finalise(RtsContext* c, const double* rcs_host, double wl, double gt, double gr, double carrier, double cspeed);
+int rts_aggregate_fetch(RtsContext* c, std::vector<RtsGroup>* groups);      // second half of rts_aggregate_device when groups == &c->groups: no-op when nothing is pending
 int rts_aggregate_device(RtsContext* c, int32_t max_path, int32_t max_rx, const int32_t* d_paths, uint64_t R, uint32_t D,
                          double cspeed, double carrier, uint64_t base, PerRayData* d_rays, double* d_delay,
                          double* d_phase, int32_t* d_pm, std::vector<RtsGroup>* groups, double* d_npath,

@@ -698,6 +698,25 @@ int rts_aggregate_device(RtsContext* c, int32_t max_path, int32_t max_rx, const 
     // (written by ONE kernel straight into the pinned block -- five small device-to-host copies per pulse before)
     k_agg_export<<<blocks_for(spec, 256), 256, 0, st>>>(d_G, gsum, c->d_gmin.p, c->d_gkey.p, d_rows ? c->d_grow.p : nullptr, spec, &c->pin_dev->G, c->pin_dev->gsum, c->pin_dev->gmin, c->pin_dev->gkey, c->pin_dev->grow);
     RTS_HIP(hipGetLastError());
+    // The table is READ when somebody asks for it (rts_aggregate_fetch): a caller that keeps several pulses in flight enqueues the
+    // next pulse while this one's ~16 small kernels wait their turn among the trace kernels' blocks -- the submitting thread used
+    // to sit out that chain here, 0.4 of the 0.63 ms of a pipelined BASELINE configs[2] pulse.
+    RtsAggPending& ap = c->agg_pending;
+    ap.valid = true; ap.R = R; ap.D = D; ap.B = B; ap.shift = shift; ap.wide = wide; ap.base = base; ap.rows = d_rows != nullptr; ap.spec = spec; ap.gsum = gsum;
+    if (groups != &c->groups) return rts_aggregate_fetch(c, groups);          // (a caller's own vector: now)
+    return RTS_OK;
+}
+
+// Second half of rts_aggregate_device: wait for the handle's stream and turn the exported table into RtsGroup records.
+int rts_aggregate_fetch(RtsContext* c, std::vector<RtsGroup>* groups)
+{
+    RtsAggPending& ap = c->agg_pending;
+    if (!ap.valid) return RTS_OK;
+    ap.valid = false;
+    hipStream_t st = c->stream;
+    RtsPinned* pin = c->pin;
+    const uint32_t R = ap.R, D = ap.D, B = ap.B, shift = ap.shift, spec = ap.spec; const bool wide = ap.wide; const uint64_t base = ap.base;
+    const bool d_rows = ap.rows; double* gsum = ap.gsum; (void)R;
     RTS_HIP(hipStreamSynchronize(st));
     const uint32_t G = pin->G;
     const double* h_gsum = pin->gsum; const uint32_t* h_gmin = pin->gmin; const uint64_t* h_gkey = pin->gkey;

@@ -629,8 +629,10 @@ __device__ __forceinline__ void rts_trace_unit(const RtsTraceArgs& a, const RtsL
                         s_stack[tid] = SENTINEL;
                         int sp = 1;
                         int node = TG.root;
+                        uint32_t wave_steps = 0;                                     // (wave-uniform: a scalar register; the per-lane count is the counting build's)
                         while (node != SENTINEL) {
-                            if (++steps > (1u << 24)) { hard_overflow = true; break; }   // malformed tree guard: every wave must drain
+                            if (++wave_steps > (1u << 24)) { hard_overflow = true; break; }   // malformed tree guard: every wave must drain
+                            if (COUNT) steps++;
                             rts_walk_step<COUNT>(a, s_stack, tid, gtid, lds_cap, &s_n[2 * RTS_BLOCK + tid], node, sp, lr, prev, dir, tmin, best_t, best_leaf, best_prim, t_prune,
                                                  n_nodes, n_tris, hard_overflow);
                         }
