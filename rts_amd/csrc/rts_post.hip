@@ -11,6 +11,10 @@
 #include "rts_raygen.h"
 
 static inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+#define RTS_SMALL_SORT 2048          // received sets up to this size: single-block ordering / finishing kernels (see k_agg_order_small)
+#define RTS_SMALL_THREADS 256
+#define RTS_SMALL_ITEMS (RTS_SMALL_SORT / RTS_SMALL_THREADS)
+__global__ void k_recv_order_small(const RtsEndRecord* __restrict__ rec, uint32_t n, uint32_t n_rays, int with_chain, uint32_t bits, uint32_t* __restrict__ perm);
 
 // --------------------------------------------------------------------------- record expansion
 // received rays are ordered as the reference's host scan meets them (ray_tracer.cpp:1190): ascending buffer
@@ -214,7 +218,10 @@ int rts_post_order_and_expand(RtsContext* c)
     RTS_HIP(c->d_ri.reserve(R)); RTS_HIP(c->d_ri_sorted.reserve(R));
     RTS_HIP(c->d_rx_rays.reserve(R)); RTS_HIP(c->d_rx_paths.reserve((size_t)R*D + 1)); RTS_HIP(c->d_rx_angles.reserve((size_t)R*D*2 + 1)); RTS_HIP(c->d_rx_slots.reserve(R));
     size_t tmp = 0;
-    if (c->last_args.max_refr == 0) {
+    if (c->post_small && R <= RTS_SMALL_SORT) {
+        k_recv_order_small<<<1, RTS_SMALL_THREADS, 0, st>>>(c->d_recv.p, R, c->n_rays, c->last_args.max_refr != 0 ? 1 : 0, c->last_args.max_refr != 0 ? 34u : 32u, c->d_ri_sorted.p);
+        RTS_STAGE(c, "recv order (one block)");
+    } else if (c->last_args.max_refr == 0) {
         RTS_HIP(c->d_rk.reserve(R)); RTS_HIP(c->d_rk_sorted.reserve(R));
         k_recv_keys<<<blocks_for(R, 256), 256, 0, st>>>(c->d_recv.p, c->d_rk.p, c->d_ri.p, R);
         RTS_STAGE(c, "k_recv_keys");
@@ -515,10 +522,9 @@ __global__ void __launch_bounds__(AGG_TILE) k_agg_tiles(const PerRayData* __rest
 
 // groups spanning several tiles: partials added in tile order by one wave, fixed shape.  One wave per
 // TILE (the tile in which such a group starts does the work), so the launch needs no group count.
-__global__ void __launch_bounds__(64) k_agg_span(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ gid_incl, uint32_t R,
-                                                  const double* __restrict__ tile_first, const double* __restrict__ tile_last, double* __restrict__ gsum)
+__device__ __forceinline__ void agg_span_body(const uint32_t T0, const uint32_t lane, const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ gid_incl, uint32_t R,
+                                              const double* __restrict__ tile_first, const double* __restrict__ tile_last, double* __restrict__ gsum)
 {
-    const uint32_t T0 = blockIdx.x, lane = threadIdx.x;
     const uint32_t tile_lo = T0 * AGG_TILE;
     if (tile_lo >= R) return;
     const uint32_t tile_hi = min(tile_lo + AGG_TILE, R);
@@ -537,12 +543,16 @@ __global__ void __launch_bounds__(64) k_agg_span(const uint32_t* __restrict__ gs
     for (int off = 32; off > 0; off >>= 1) for (int k = 0; k < 5; k++) acc[k] += __shfl_down(acc[k], off);
     if (lane == 0) for (int k = 0; k < 5; k++) gsum[5*(size_t)g + k] = acc[k];
 }
-
-__global__ void k_agg_groupinfo(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ idx_sorted, const uint64_t* __restrict__ keys_sorted,
-                                const uint32_t* __restrict__ gid_incl, uint32_t R, uint32_t* __restrict__ gmin, uint64_t* __restrict__ gkey, uint32_t* __restrict__ g_out,
-                                const uint64_t* __restrict__ rows, uint64_t* __restrict__ grow)
+__global__ void __launch_bounds__(64) k_agg_span(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ gid_incl, uint32_t R,
+                                                  const double* __restrict__ tile_first, const double* __restrict__ tile_last, double* __restrict__ gsum)
 {
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    agg_span_body(blockIdx.x, threadIdx.x, gstart, gid_incl, R, tile_first, tile_last, gsum);
+}
+
+__device__ __forceinline__ void agg_groupinfo_body(const uint32_t g, const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ idx_sorted, const uint64_t* __restrict__ keys_sorted,
+                                                   const uint32_t* __restrict__ gid_incl, uint32_t R, uint32_t* __restrict__ gmin, uint64_t* __restrict__ gkey, uint32_t* __restrict__ g_out,
+                                                   const uint64_t* __restrict__ rows, uint64_t* __restrict__ grow)
+{
     const uint32_t G = gid_incl[R - 1];
     if (g == 0) *g_out = G;
     if (g >= G) return;
@@ -550,14 +560,20 @@ __global__ void k_agg_groupinfo(const uint32_t* __restrict__ gstart, const uint3
     gkey[g] = keys_sorted[gstart[g]];
     if (rows) grow[g] = rows[gmin[g]];        // its global buffer row (order-isomorphic to the received index, comparable across ranks)
 }
+__global__ void k_agg_groupinfo(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ idx_sorted, const uint64_t* __restrict__ keys_sorted,
+                                const uint32_t* __restrict__ gid_incl, uint32_t R, uint32_t* __restrict__ gmin, uint64_t* __restrict__ gkey, uint32_t* __restrict__ g_out,
+                                const uint64_t* __restrict__ rows, uint64_t* __restrict__ grow)
+{
+    agg_groupinfo_body(blockIdx.x * blockDim.x + threadIdx.x, gstart, idx_sorted, keys_sorted, gid_incl, R, gmin, gkey, g_out, rows, grow);
+}
 
 // Per-receiver totals for the direct-ray rule (aggregation.cu:56): groups are sorted by key with the
 // receiver in the top bits, so a receiver's groups are one contiguous run; one wave per receiver adds
 // them with a fixed shape.  rxtot[rx][5], rxmin[rx].
-__global__ void __launch_bounds__(64) k_agg_rxtot(const uint64_t* __restrict__ gkey, const double* __restrict__ gsum, const uint32_t* __restrict__ gmin,
-                                                   const uint32_t* __restrict__ g_count, uint32_t shift, double* __restrict__ rxtot, uint32_t* __restrict__ rxmin)
+__device__ __forceinline__ void agg_rxtot_body(const uint32_t rx, const uint32_t lane, const uint64_t* __restrict__ gkey, const double* __restrict__ gsum, const uint32_t* __restrict__ gmin,
+                                               const uint32_t* __restrict__ g_count, uint32_t shift, double* __restrict__ rxtot, uint32_t* __restrict__ rxmin)
 {
-    const uint32_t rx = blockIdx.x, lane = threadIdx.x, G = *g_count;
+    const uint32_t G = *g_count;
     auto lower = [&](uint64_t rxv) {            // first group whose receiver field is >= rxv
         uint32_t lo = 0, hi = G;
         while (lo < hi) { uint32_t mid = (lo + hi) >> 1; uint64_t r = (shift >= 64) ? 0 : (gkey[mid] >> shift); if (r < rxv) lo = mid + 1; else hi = mid; }
@@ -569,16 +585,20 @@ __global__ void __launch_bounds__(64) k_agg_rxtot(const uint64_t* __restrict__ g
     for (int off = 32; off > 0; off >>= 1) { for (int k = 0; k < 5; k++) acc[k] += __shfl_down(acc[k], off); mn = min(mn, (uint32_t)__shfl_down((int)mn, off)); }
     if (lane == 0) { for (int k = 0; k < 5; k++) rxtot[5*(size_t)rx + k] = acc[k]; rxmin[rx] = mn; }
 }
+__global__ void __launch_bounds__(64) k_agg_rxtot(const uint64_t* __restrict__ gkey, const double* __restrict__ gsum, const uint32_t* __restrict__ gmin,
+                                                   const uint32_t* __restrict__ g_count, uint32_t shift, double* __restrict__ rxtot, uint32_t* __restrict__ rxmin)
+{
+    agg_rxtot_body(blockIdx.x, threadIdx.x, gkey, gsum, gmin, g_count, shift, rxtot, rxmin);
+}
 
 // myKernel1's per-ray totals + myKernel2 (aggregation.cu:56-69, 88-93), scattered back per ray.
 // rxtot: per receiver {n, sum sqrt p, sum delay, sum phase, sum doppler}, rxmin: smallest ray index.
-__global__ void k_agg_scatter(PerRayData* __restrict__ rays, const uint32_t* __restrict__ idx_sorted, const uint32_t* __restrict__ gid_incl,
+__device__ __forceinline__ void agg_scatter_body(const uint32_t i, PerRayData* __restrict__ rays, const uint32_t* __restrict__ idx_sorted, const uint32_t* __restrict__ gid_incl,
                               const double* __restrict__ gsum, const uint32_t* __restrict__ gmin, const double* __restrict__ rxtot,
                               const uint32_t* __restrict__ rxmin, uint32_t n_rx_tab, uint32_t R, int64_t base,
                               const double* __restrict__ npath0, const double* __restrict__ power0, const double* __restrict__ doppler0,
                               double* __restrict__ delay, double* __restrict__ phase, int32_t* __restrict__ pm, int32_t pm_init_const, int use_pm_in, int dly_in)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R) return;
     const uint32_t r = idx_sorted[i], g = gid_incl[i] - 1;
     PerRayData ray = rays[r];
@@ -604,17 +624,128 @@ __global__ void k_agg_scatter(PerRayData* __restrict__ rays, const uint32_t* __r
     const int32_t prev = use_pm_in ? pm[r] : pm_init_const;
     pm[r] = (m < (int64_t)prev) ? (int32_t)m : prev;                          // if (r < d_pathMatch[i]) d_pathMatch[i] = r
 }
+__global__ void k_agg_scatter(PerRayData* __restrict__ rays, const uint32_t* __restrict__ idx_sorted, const uint32_t* __restrict__ gid_incl,
+                              const double* __restrict__ gsum, const uint32_t* __restrict__ gmin, const double* __restrict__ rxtot,
+                              const uint32_t* __restrict__ rxmin, uint32_t n_rx_tab, uint32_t R, int64_t base,
+                              const double* __restrict__ npath0, const double* __restrict__ power0, const double* __restrict__ doppler0,
+                              double* __restrict__ delay, double* __restrict__ phase, int32_t* __restrict__ pm, int32_t pm_init_const, int use_pm_in, int dly_in)
+{
+    agg_scatter_body(blockIdx.x * blockDim.x + threadIdx.x, rays, idx_sorted, gid_incl, gsum, gmin, rxtot, rxmin, n_rx_tab, R, base, npath0, power0, doppler0, delay, phase, pm, pm_init_const, use_pm_in, dly_in);
+}
 
 // the group count and the first `spec` groups of the table, into the handle's pinned host block (device addresses of its members)
-__global__ void k_agg_export(const uint32_t* __restrict__ d_G, const double* __restrict__ gsum, const uint32_t* __restrict__ gmin, const uint64_t* __restrict__ gkey, const uint64_t* __restrict__ grow,
-                             uint32_t spec, uint32_t* __restrict__ h_G, double* __restrict__ h_gsum, uint32_t* __restrict__ h_gmin, uint64_t* __restrict__ h_gkey, uint64_t* __restrict__ h_grow)
+__device__ __forceinline__ void agg_export_body(const uint32_t i, const uint32_t* __restrict__ d_G, const double* __restrict__ gsum, const uint32_t* __restrict__ gmin, const uint64_t* __restrict__ gkey, const uint64_t* __restrict__ grow,
+                                                uint32_t spec, uint32_t* __restrict__ h_G, double* __restrict__ h_gsum, uint32_t* __restrict__ h_gmin, uint64_t* __restrict__ h_gkey, uint64_t* __restrict__ h_grow)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, G = *d_G;
+    const uint32_t G = *d_G;
     if (i == 0) *h_G = G;
     if (i >= spec || i >= G) return;
     for (int k = 0; k < 5; k++) h_gsum[5 * (size_t)i + k] = gsum[5 * (size_t)i + k];
     h_gmin[i] = gmin[i]; h_gkey[i] = gkey[i];
     if (grow) h_grow[i] = grow[i];
+}
+__global__ void k_agg_export(const uint32_t* __restrict__ d_G, const double* __restrict__ gsum, const uint32_t* __restrict__ gmin, const uint64_t* __restrict__ gkey, const uint64_t* __restrict__ grow,
+                             uint32_t spec, uint32_t* __restrict__ h_G, double* __restrict__ h_gsum, uint32_t* __restrict__ h_gmin, uint64_t* __restrict__ h_gkey, uint64_t* __restrict__ h_grow)
+{
+    agg_export_body(blockIdx.x * blockDim.x + threadIdx.x, d_G, gsum, gmin, gkey, grow, spec, h_G, h_gsum, h_gmin, h_gkey, h_grow);
+}
+
+// ---------------------------------------------------------------------------- small received sets: one block instead of a chain
+// A BASELINE configs[2] pulse receives ~2 000 rays.  Sorted, scanned and reduced by library calls sized for millions of
+// elements that is ~27 launches of a few microseconds each -- which, among the blocks of the neighbouring pulses' trace
+// kernels, each wait their turn: 0.35 ms of dependent launches per pulse, in the submitting thread's loop.  Up to
+// RTS_SMALL_SORT rays one block does the ordering (keys, a block-wide radix sort of (key, index) pairs -- stable, as the
+// device-wide one --, head flags, scan, group starts) and one block the tail of the aggregation
+// (spans, group table, receiver totals, the scatter back to the rays, the export): the SAME statements as the kernels above
+// (their bodies are shared), the tile sums in between unchanged, so every sum is the same bits whichever path ran.
+// (one block of 256 threads and < 40 KB of LDS: it has to fit the block slot a trace launch leaves free on a CU -- a first
+// version with 1 024 threads and 56 KB waited for a CU to drain and made the pulse slower, 0.72 against 0.63 ms)
+typedef rocprim::block_radix_sort<uint64_t, RTS_SMALL_THREADS, RTS_SMALL_ITEMS, uint32_t> RtsSmallSort;
+
+// received rays in ascending buffer row (k_recv_keys / k_recv_keys64 + the sort): perm[j] = record of output row j
+__global__ void __launch_bounds__(RTS_SMALL_THREADS) k_recv_order_small(const RtsEndRecord* __restrict__ rec, uint32_t n, uint32_t n_rays, int with_chain, uint32_t bits, uint32_t* __restrict__ perm)
+{
+    __shared__ RtsSmallSort::storage_type s_sort;
+    uint64_t k[RTS_SMALL_ITEMS]; uint32_t v[RTS_SMALL_ITEMS];
+    for (uint32_t j = 0; j < RTS_SMALL_ITEMS; j++) {
+        const uint32_t i = threadIdx.x * RTS_SMALL_ITEMS + j;
+        k[j] = i < n ? (with_chain ? (uint64_t)(rec[i].pad & 3u) * n_rays + rec[i].slot : (uint64_t)rec[i].slot) : (1ULL << bits) - 1ULL;      // (padding sorts last: no key is that large)
+        v[j] = i;
+    }
+    RtsSmallSort().sort(k, v, s_sort, 0, bits);
+    for (uint32_t j = 0; j < RTS_SMALL_ITEMS; j++) { const uint32_t i = threadIdx.x * RTS_SMALL_ITEMS + j; if (i < n) perm[i] = v[j]; }
+}
+
+// k_agg_keys + sort + k_agg_heads + inclusive scan + k_agg_starts
+__global__ void __launch_bounds__(RTS_SMALL_THREADS) k_agg_order_small(const PerRayData* __restrict__ rays, const int32_t* __restrict__ paths, uint32_t R, uint32_t D, uint32_t B, uint32_t key_bits,
+                                                                       uint64_t* __restrict__ keys_sorted, uint32_t* __restrict__ idx_sorted, uint32_t* __restrict__ head,
+                                                                       uint32_t* __restrict__ gid_incl, uint32_t* __restrict__ gstart)
+{
+    __shared__ RtsSmallSort::storage_type s_sort;
+    __shared__ uint64_t s_last[RTS_SMALL_THREADS]; __shared__ uint32_t s_sum[2][RTS_SMALL_THREADS];
+    uint64_t k[RTS_SMALL_ITEMS]; uint32_t v[RTS_SMALL_ITEMS];
+    const uint32_t i0 = threadIdx.x * RTS_SMALL_ITEMS;
+    for (uint32_t j = 0; j < RTS_SMALL_ITEMS; j++) {
+        const uint32_t i = i0 + j;
+        uint64_t key = key_bits < 64u ? 1ULL << key_bits : ~0ULL;       // (padding: one bit above every real key -- or, with 64-bit keys, equal to the largest at worst: the sort is stable and padding has the larger indices)
+        if (i < R) {
+            key = 0;
+            for (uint32_t c = 0; c < D; c++) key |= (uint64_t)(uint32_t)(paths[(size_t)i*D + c] + 1) << (c*B);
+            key |= (uint64_t)(uint32_t)rays[i].received << (D*B);
+        }
+        k[j] = key; v[j] = i;
+    }
+    // (stable: equal keys keep their index order, as after the radix sort of the general path)
+    RtsSmallSort().sort(k, v, s_sort, 0, key_bits < 64u ? key_bits + 1u : 64u);
+    // head flags and their inclusive scan: thread t owns the sorted elements [t c, (t + 1) c)
+    s_last[threadIdx.x] = k[RTS_SMALL_ITEMS - 1];
+    __syncthreads();
+    uint64_t prev = threadIdx.x ? s_last[threadIdx.x - 1] : 0ULL;
+    uint32_t h[RTS_SMALL_ITEMS], local = 0;
+    for (uint32_t j = 0; j < RTS_SMALL_ITEMS; j++) {
+        const uint32_t i = i0 + j;
+        h[j] = (i < R && (i == 0 || k[j] != prev)) ? 1u : 0u; local += h[j]; prev = k[j];
+    }
+    s_sum[0][threadIdx.x] = local;
+    __syncthreads();
+    int cur = 0;
+    for (uint32_t off = 1; off < RTS_SMALL_THREADS; off <<= 1) {
+        uint32_t x = s_sum[cur][threadIdx.x];
+        if (threadIdx.x >= off) x += s_sum[cur][threadIdx.x - off];
+        s_sum[cur ^ 1][threadIdx.x] = x; cur ^= 1;
+        __syncthreads();
+    }
+    uint32_t run = s_sum[cur][threadIdx.x] - local;                 // groups that start before this thread's elements
+    for (uint32_t j = 0; j < RTS_SMALL_ITEMS; j++) {
+        const uint32_t i = i0 + j;
+        if (i >= R) break;
+        run += h[j];
+        keys_sorted[i] = k[j]; idx_sorted[i] = v[j]; head[i] = h[j]; gid_incl[i] = run;
+        if (h[j]) gstart[run - 1] = i;
+        if (i == R - 1) gstart[run] = R;
+    }
+}
+
+// k_agg_span + k_agg_groupinfo + k_agg_rxtot + k_agg_scatter + k_agg_export (after k_agg_tiles)
+__global__ void __launch_bounds__(256) k_agg_finish_small(PerRayData* __restrict__ rays, const uint32_t* __restrict__ idx_sorted, const uint64_t* __restrict__ keys_sorted,
+        const uint32_t* __restrict__ gid_incl, const uint32_t* __restrict__ gstart, uint32_t R, uint32_t ntiles, const double* __restrict__ tile_first, const double* __restrict__ tile_last,
+        double* __restrict__ gsum, uint32_t* __restrict__ gmin, uint64_t* __restrict__ gkey, uint32_t* __restrict__ d_G, const uint64_t* __restrict__ rows, uint64_t* __restrict__ grow,
+        uint32_t shift, uint32_t n_rx_tab, double* __restrict__ rxtot, uint32_t* __restrict__ rxmin, int64_t base,
+        const double* __restrict__ npath0, const double* __restrict__ power0, const double* __restrict__ doppler0, double* __restrict__ delay, double* __restrict__ phase,
+        int32_t* __restrict__ pm, int32_t pm_init_const, int use_pm_in, int dly_in,
+        uint32_t spec, uint32_t* __restrict__ h_G, double* __restrict__ h_gsum, uint32_t* __restrict__ h_gmin, uint64_t* __restrict__ h_gkey, uint64_t* __restrict__ h_grow)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    for (uint32_t T0 = wave; T0 < ntiles; T0 += n_waves) agg_span_body(T0, lane, gstart, gid_incl, R, tile_first, tile_last, gsum);
+    __syncthreads();
+    const uint32_t G = gid_incl[R - 1];
+    for (uint32_t g = threadIdx.x; g < G; g += blockDim.x) agg_groupinfo_body(g, gstart, idx_sorted, keys_sorted, gid_incl, R, gmin, gkey, d_G, rows, grow);      // (G >= 1: thread 0 publishes the count)
+    __syncthreads();
+    for (uint32_t rx = wave; rx < n_rx_tab; rx += n_waves) agg_rxtot_body(rx, lane, gkey, gsum, gmin, d_G, shift, rxtot, rxmin);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < R; i += blockDim.x)
+        agg_scatter_body(i, rays, idx_sorted, gid_incl, gsum, gmin, rxtot, rxmin, n_rx_tab, R, base, npath0, power0, doppler0, delay, phase, pm, pm_init_const, use_pm_in, dly_in);
+    if (h_G) { __syncthreads(); for (uint32_t i = threadIdx.x; i < spec; i += blockDim.x) agg_export_body(i, d_G, gsum, gmin, gkey, grow, spec, h_G, h_gsum, h_gmin, h_gkey, h_grow); }      // (spec >= 1)
 }
 
 // Aggregates R device-resident rays.  d_delay/d_phase/d_pm are in-out (initial values as the
@@ -654,7 +785,10 @@ int rts_aggregate_device(RtsContext* c, int32_t max_path, int32_t max_rx, const 
     double* gsum = c->d_gsum.p; double* tile_first = gsum + 5*(size_t)R; double* tile_last = tile_first + 5*(size_t)ntiles;
     double* d_rxtot = c->d_rcs.p; uint32_t* d_rxmin = (uint32_t*)(c->d_rcs.p + 5*(size_t)n_rx_tab);
     size_t tmp = 0;
-    if (!wide) {
+    const bool small = c->post_small && !wide && R <= RTS_SMALL_SORT;       // one block orders, one block finishes (see k_agg_order_small)
+    if (small) {
+        k_agg_order_small<<<1, RTS_SMALL_THREADS, 0, st>>>(d_rays, d_paths, R, D, B, key_bits, c->d_akeys_sorted.p, c->d_aidx_sorted.p, c->d_ghead.p, c->d_gid.p, gstart);
+    } else if (!wide) {
         k_agg_keys<<<blocks_for(R, 256), 256, 0, st>>>(d_rays, d_paths, R, D, B, c->d_akeys.p, c->d_aidx.p);
         RTS_HIP(rocprim::radix_sort_pairs(nullptr, tmp, c->d_akeys.p, c->d_akeys_sorted.p, c->d_aidx.p, c->d_aidx_sorted.p, R, 0, key_bits, st));
         RTS_HIP(c->d_sort_tmp.reserve(tmp));
@@ -675,11 +809,27 @@ int rts_aggregate_device(RtsContext* c, int32_t max_path, int32_t max_rx, const 
         }
         k_agg_heads_wide<<<blocks_for(R, 256), 256, 0, st>>>(d_rays, d_paths, c->d_aidx_sorted.p, R, D, c->d_ghead.p, c->d_akeys_sorted.p);
     }
-    RTS_HIP(rocprim::inclusive_scan(nullptr, tmp, c->d_ghead.p, c->d_gid.p, R, rocprim::plus<uint32_t>(), st));
-    RTS_HIP(c->d_sort_tmp.reserve(tmp));
-    RTS_HIP(rocprim::inclusive_scan(c->d_sort_tmp.p, tmp, c->d_ghead.p, c->d_gid.p, R, rocprim::plus<uint32_t>(), st));
-    k_agg_starts<<<blocks_for(R, 256), 256, 0, st>>>(c->d_ghead.p, c->d_gid.p, gstart, R);
+    if (!small) {
+        RTS_HIP(rocprim::inclusive_scan(nullptr, tmp, c->d_ghead.p, c->d_gid.p, R, rocprim::plus<uint32_t>(), st));
+        RTS_HIP(c->d_sort_tmp.reserve(tmp));
+        RTS_HIP(rocprim::inclusive_scan(c->d_sort_tmp.p, tmp, c->d_ghead.p, c->d_gid.p, R, rocprim::plus<uint32_t>(), st));
+        k_agg_starts<<<blocks_for(R, 256), 256, 0, st>>>(c->d_ghead.p, c->d_gid.p, gstart, R);
+    }
     k_agg_tiles<<<ntiles, AGG_TILE, 0, st>>>(d_rays, c->d_aidx_sorted.p, c->d_gid.p, gstart, R, cspeed, carrier, gsum, tile_first, tile_last);
+    if (small) {
+        RtsPinned* pd = c->pin_dev;
+        const uint32_t spec_s = std::min<uint32_t>(R, RTS_PIN_GROUPS);
+        k_agg_finish_small<<<1, 256, 0, st>>>(d_rays, c->d_aidx_sorted.p, c->d_akeys_sorted.p, c->d_gid.p, gstart, R, ntiles, tile_first, tile_last, gsum, c->d_gmin.p, c->d_gkey.p, d_G,
+                                              d_rows, d_rows ? c->d_grow.p : nullptr, shift, n_rx_tab, d_rxtot, d_rxmin, (int64_t)base, d_npath, d_power_sum, d_doppler_sum, d_delay, d_phase, d_pm,
+                                              pm_init, pm_init == INT32_MIN ? 1 : 0, c->agg_delay_in ? 1 : 0,
+                                              spec_s, groups ? &pd->G : nullptr, pd->gsum, pd->gmin, pd->gkey, pd->grow);
+        RTS_HIP(hipGetLastError());
+        if (!groups) { RTS_HIP(hipStreamSynchronize(st)); return RTS_OK; }
+        RtsAggPending& ap = c->agg_pending;
+        ap.valid = true; ap.R = R; ap.D = D; ap.B = B; ap.shift = shift; ap.wide = false; ap.base = base; ap.rows = d_rows != nullptr; ap.spec = spec_s; ap.gsum = gsum;
+        if (groups != &c->groups) return rts_aggregate_fetch(c, groups);
+        return RTS_OK;
+    }
     k_agg_span<<<ntiles, 64, 0, st>>>(gstart, c->d_gid.p, R, tile_first, tile_last, gsum);
     k_agg_groupinfo<<<blocks_for(R, 256), 256, 0, st>>>(gstart, c->d_aidx_sorted.p, c->d_akeys_sorted.p, c->d_gid.p, R, c->d_gmin.p, c->d_gkey.p, d_G, d_rows, d_rows ? c->d_grow.p : nullptr);
     k_agg_rxtot<<<n_rx_tab, 64, 0, st>>>(c->d_gkey.p, gsum, c->d_gmin.p, d_G, shift, d_rxtot, d_rxmin);

@@ -1088,6 +1088,60 @@ def test_cooperative_units_are_invisible(rts, scenes, monkeypatch):
         # triangles than ... nothing is guaranteed either way; what IS: both found the same closest hits (above)
 
 
+def test_small_received_sets_one_block_path_is_invisible(rts, scenes, monkeypatch):
+    """up to 2 048 received rays the ordering of the received set and the aggregation run as single-block kernels
+    (k_recv_order_small, k_agg_order_small, k_agg_finish_small) instead of the chain of device-wide sorts and scans
+    (RTS_POST_SMALL=0).  The two share the statements that form every sum and the tile sums in between are the same kernel:
+    received order, finalised rays, per-ray aggregation outputs and the group table must be the same BITS -- with and without
+    refraction (64-bit row keys), for a set that fills the block exactly or nearly, and for one of a few rays"""
+    c3 = scenes.config3(W=64, detail=0.3, rx_radius=300.0)
+    multi = scenes.config_multi(W=40)
+    refr = dict(scenes.config_multi(W=36, max_refl=2), max_refr=1)
+    refr["meshes"] = [dict(m, refl_coeff=0.6, refr_index=1.5) for m in refr["meshes"]]
+    refr["rx"] = refr["rx"] + [scenes._rx_at((200.0, 0.0, 0.0), (0, 0, 0), 90.0, 2.6)]
+    few = scenes.config3(W=24, detail=0.3, rx_radius=120.0)
+    seen = []
+
+    def prefix_with(spec, lo_R, hi_R):
+        """a prefix of the launch range that receives between lo_R and hi_R rays (bisection: the count is monotone in the prefix)"""
+        n = spec["W"] ** 3
+        tr = H.gpu_tracer(rts, spec)
+        lo, hi = 1, n
+        for _ in range(40):
+            mid = (lo + hi) // 2
+            _, st = H.gpu_trace(rts, spec, tr=tr, ray_first=0, ray_count=mid)
+            if st["received"] > hi_R:
+                hi = mid
+            elif st["received"] < lo_R:
+                lo = mid
+            else:
+                tr.close(); return mid
+        tr.close()
+        raise AssertionError("no prefix of %s receives %d..%d rays" % (spec["name"], lo_R, hi_R))
+
+    for name, spec, want in (("c3", c3, (1500, 2048)), ("c3 full block", c3, (2048, 2048)), ("multi", multi, None), ("refraction", refr, (1200, 2048)), ("few", few, None)):
+        count = prefix_with(spec, *want) if want else spec["W"] ** 3
+        out = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("RTS_POST_SMALL", mode)
+            tr = H.gpu_tracer(rts, spec)
+            _, st = H.gpu_trace(rts, spec, tr=tr, ray_first=0, ray_count=count)
+            rec = tr.received()
+            tr.finalise_uniform(None, 0.03, 1.0, 1.0, 1.0e10, 299792458.0)
+            groups = tr.aggregate(299792458.0, 1.0e10)
+            out[mode] = (rec, groups, tr.aggregated(), st)
+            tr.close()
+        (ra, ga, aa, sa), (rb, gb, ab, sb) = out["1"], out["0"]
+        assert 0 < sa["received"] == sb["received"], name
+        seen.append(sa["received"])
+        assert np.array_equal(ra["slots"], rb["slots"]) and np.array_equal(ra["path"], rb["path"]) and ra["rcs_angle"].tobytes() == rb["rcs_angle"].tobytes(), name
+        assert ra["results"].tobytes() == rb["results"].tobytes(), name
+        assert ga.tobytes() == gb.tobytes() and len(ga) > 0, name
+        for k in ("results", "delay", "phase", "pathMatch"):
+            assert aa[k].tobytes() == ab[k].tobytes(), (name, k)
+    assert min(seen) < 400 and max(seen) == 2048, seen     # (both ends of the one-block range were exercised)
+
+
 def test_asynchronous_bounces_are_invisible(rts, scenes, monkeypatch):
     """RTS_ASYNC_IDLE0 > 0 selects the kernel whose lanes advance from segment to segment on their own
     (rts_trace_unit_async: a walk phase ends as soon as `idle` lanes have come out of their walks; they are shaded and
