@@ -141,6 +141,7 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     { const char* e = getenv("RTS_TILE_LPT"); if (e && e[0] == '0') c->tile_lpt = false; }
     { const char* e = getenv("RTS_COOP_FRAC"); if (e) { const double v = atof(e); if (v >= 0) c->coop_frac = v; } }                  // 0: no cooperative units; tests: tiny values put every tile at the head
     { const char* e = getenv("RTS_COOP_FLOOR"); if (e) c->coop_floor = (uint32_t)std::max(0, atoi(e)); }
+    { const char* e = getenv("RTS_TILE_SORT"); if (e) c->tile_bucket_order = strcmp(e, "radix") != 0; }
     { const char* e = getenv("RTS_POST_SMALL"); if (e) c->post_small = atoi(e) != 0; }
     { const char* e = getenv("RTS_ASYNC_IDLE0"); if (e) c->async_idle0 = (uint32_t)std::min(64, std::max(0, atoi(e))); }
     { const char* e = getenv("RTS_ASYNC_IDLE1"); if (e) c->async_idle1 = (uint32_t)std::min(64, std::max(1, atoi(e))); }

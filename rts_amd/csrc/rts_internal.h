@@ -80,7 +80,8 @@ static_assert(sizeof(RtsChildState) == 128, "child state size");
 #ifndef RTS_TILE_CTRS
 #define RTS_TILE_CTRS 64           // striped draw counters of the tile queue
 #endif
-#define RTS_ZERO_WORDS (2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE + 4 + 32)      // the dwords one fill clears per launch: draw counters x 2 kernels, head words, 16 u64 counters
+#define RTS_TILE_BUCKETS 1024       // bins of the tiles' counting order (rts_post.hip: k_tile_bucket_*)
+#define RTS_ZERO_WORDS (2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE + 4 + 32 + RTS_TILE_BUCKETS)      // the dwords one fill clears per launch: draw counters x 2 kernels, head words, 16 u64 counters, the order's bins
 #define RTS_TILE_CTR_STRIDE 32     // ... one per 128-byte line: same-LINE atomics serialise in L2 (~10 ns each) whatever their address
 #ifndef RTS_STACK_LDS
 #define RTS_STACK_LDS 24            // traversal stack entries kept in LDS per lane
@@ -291,6 +292,7 @@ struct RtsContext {
     DevBuf<double> d_gsum; DevBuf<uint32_t> d_gmin; DevBuf<uint64_t> d_gkey; DevBuf<uint32_t> d_gcount; DevBuf<uint64_t> d_grow; DevBuf<int32_t> d_gpath;
     DevBuf<double> d_delay, d_phase; DevBuf<int32_t> d_pathmatch; DevBuf<double> d_rcs;
     std::vector<RtsGroup> groups; bool agg_valid = false; uint64_t recv_index_base = 0;
+    bool tile_bucket_order = true;      // tile order by counting bins instead of a radix sort (RTS_TILE_SORT=radix: the sort)
     bool post_small = true;             // received sets of up to 4096 rays are ordered / finished by single blocks (RTS_POST_SMALL=0: the general chain)
     RtsAggPending agg_pending;          // the group table of the last rts_aggregate is still on its way (rts_aggregate_fetch reads it)
     RtsCubeParams cube_params; double* cube = nullptr; DevBuf<double> d_cube_own; bool cube_set = false;

@@ -159,10 +159,10 @@ __global__ void k_tile_merge(uint32_t* __restrict__ cost, RtsTileShape prev, uin
 // known within 16 global tiles of it (expensive regions are contiguous in launch-index space).  Flagged records sort first
 // (their bit 31), by descending cost: the flagged tiles above the threshold are a prefix of the order.
 __global__ void k_tile_keys(const uint32_t* __restrict__ hist, uint32_t n_hist, RtsTileShape cur, uint32_t* __restrict__ key, uint32_t* __restrict__ id,
-                            const unsigned long long* __restrict__ head_sum, uint32_t* __restrict__ head_count, RtsHeadRule rule)
+                            const unsigned long long* __restrict__ head_sum, uint32_t* __restrict__ head_count, RtsHeadRule rule, uint32_t* __restrict__ bucket_hist)
 {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t is_head = 0;
+    uint32_t is_head = 0, bucket = 0;
     if (j < cur.n_tiles) {
         const uint32_t g = tile_global(cur, j);
         uint32_t est = g < n_hist ? hist[g] : 0u;
@@ -183,11 +183,50 @@ __global__ void k_tile_keys(const uint32_t* __restrict__ hist, uint32_t n_hist, 
             is_head = (((est >> 31) && (double)cost > thr) || (rule.big > 0.0 && balanced > 0.0 && (double)cost > thr_big)) ? 1u : 0u;
         }
         key[j] = ~((is_head << 31) | cost); id[j] = j;
+        // bucket of the counting order (bucket_hist != nullptr): 0 = head of the order, then descending cost in steps of 1/32
+        // octave -- finer than a tile's cost repeats from pulse to pulse
+        bucket = is_head ? 0u : (RTS_TILE_BUCKETS - 1u) - min((uint32_t)(__log2f((float)cost + 1.0f) * 32.0f), RTS_TILE_BUCKETS - 2u);
+        if (bucket_hist) key[j] = bucket;
     }
     if (head_count) {                                                          // (uniform)
         const unsigned long long m = __ballot(is_head != 0);
         if ((threadIdx.x & 63) == 0 && m) atomicAdd(head_count, (uint32_t)__popcll(m));      // (heads are rare: a handful of waves at most)
     }
+    if (bucket_hist) {                                                         // (uniform) block histogram in LDS, one global atomic per non-empty bin
+        __shared__ uint32_t s_cnt[RTS_TILE_BUCKETS];
+        for (uint32_t b = threadIdx.x; b < RTS_TILE_BUCKETS; b += blockDim.x) s_cnt[b] = 0u;
+        __syncthreads();
+        if (j < cur.n_tiles) atomicAdd(&s_cnt[bucket], 1u);
+        __syncthreads();
+        for (uint32_t b = threadIdx.x; b < RTS_TILE_BUCKETS; b += blockDim.x) if (s_cnt[b]) atomicAdd(&bucket_hist[b], s_cnt[b]);
+    }
+}
+
+// Counting order of the tiles (instead of a device-wide radix sort of 157 k keys -- eight launches on the chain in front of
+// every trace launch): histogram in k_tile_keys, exclusive scan of the 1 024 bins by one block, and a scatter in which every
+// block reserves its share of each bin with ONE atomic and ranks its tiles inside it in LDS.  Tiles of a bin come out in no
+// particular order (only the schedule depends on it); the head of the order is bin 0, a prefix as before.
+__global__ void __launch_bounds__(RTS_TILE_BUCKETS) k_tile_bucket_scan(uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t s[2][RTS_TILE_BUCKETS];
+    const uint32_t t = threadIdx.x, v = hist[t];
+    s[0][t] = v; __syncthreads();
+    int cur = 0;
+    for (uint32_t off = 1; off < RTS_TILE_BUCKETS; off <<= 1) { uint32_t x = s[cur][t]; if (t >= off) x += s[cur][t - off]; s[cur ^ 1][t] = x; cur ^= 1; __syncthreads(); }
+    hist[t] = s[cur][t] - v;                                                   // exclusive: first position of the bin
+}
+__global__ void __launch_bounds__(256) k_tile_bucket_scatter(const uint32_t* __restrict__ bucket_of, uint32_t n, uint32_t* __restrict__ next, uint32_t* __restrict__ order)
+{
+    __shared__ uint32_t s_cnt[RTS_TILE_BUCKETS], s_base[RTS_TILE_BUCKETS];
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t b = threadIdx.x; b < RTS_TILE_BUCKETS; b += blockDim.x) s_cnt[b] = 0u;
+    __syncthreads();
+    uint32_t b = 0, r = 0;
+    if (j < n) { b = bucket_of[j]; r = atomicAdd(&s_cnt[b], 1u); }
+    __syncthreads();
+    for (uint32_t q = threadIdx.x; q < RTS_TILE_BUCKETS; q += blockDim.x) if (s_cnt[q]) s_base[q] = atomicAdd(&next[q], s_cnt[q]);
+    __syncthreads();
+    if (j < n) order[s_base[b] + r] = j;
 }
 
 // prev_valid: d_tile_cost holds the costs of a launch of shape prev_shape that have not been merged yet
@@ -202,7 +241,14 @@ int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_vali
     RTS_HIP(c->d_tile_key.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_key_sorted.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_id.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_order.reserve(n_tiles_cur));
     const RtsTileShape cur = shape(cur_sig);
     const RtsHeadRule rule = {c->coop_frac, c->coop_big, c->coop_floor, resident_waves};
-    k_tile_keys<<<blocks_for(n_tiles_cur, 256), 256, 0, st>>>(c->d_tile_hist.p, n_hist, cur, c->d_tile_key.p, c->d_tile_id.p, reinterpret_cast<const unsigned long long*>(head), head ? head + 2 : nullptr, rule);
+    uint32_t* bins = c->tile_bucket_order ? c->d_tile_ctr.p + RTS_ZERO_WORDS - RTS_TILE_BUCKETS : nullptr;      // zeroed with the draw counters
+    k_tile_keys<<<blocks_for(n_tiles_cur, 256), 256, 0, st>>>(c->d_tile_hist.p, n_hist, cur, c->d_tile_key.p, c->d_tile_id.p, reinterpret_cast<const unsigned long long*>(head), head ? head + 2 : nullptr, rule, bins);
+    if (bins) {
+        k_tile_bucket_scan<<<1, RTS_TILE_BUCKETS, 0, st>>>(bins);
+        k_tile_bucket_scatter<<<blocks_for(n_tiles_cur, 256), 256, 0, st>>>(c->d_tile_key.p, n_tiles_cur, bins, c->d_tile_order.p);
+        RTS_HIP(hipGetLastError());
+        return RTS_OK;
+    }
     size_t tmp = 0;
     RTS_HIP(rocprim::radix_sort_pairs(nullptr, tmp, c->d_tile_key.p, c->d_tile_key_sorted.p, c->d_tile_id.p, c->d_tile_order.p, n_tiles_cur, 0, 32, st));
     RTS_HIP(c->d_sort_tmp.reserve(tmp));
