@@ -4,7 +4,7 @@ issue costs of profiles/<tag>_valu_calib.json.  tools/pmc_derive.py uses the res
 hardware counters do not classify (everything that is not f32 / f64 add, mul, fma or a transcendental): selects, min / max,
 compares, integer and address arithmetic, moves.
 
-  python tools/isa_mix.py <tag>      writes profiles/<tag>_isa_mix.json   (needs hipcc; no GPU)
+  python tools/isa_mix.py <tag> [calibration tag]      writes profiles/<tag>_isa_mix.json   (needs hipcc; no GPU)
 """
 import collections
 import json
@@ -15,7 +15,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "_Z7k_traceILb0ELb0ELb0ELb0EEv12RtsTraceArgs"
+KERNEL = "_Z7k_traceILb0ELb0ELb0ELb0ELb0EEv12RtsTraceArgs"      # k_trace<COUNT, KEEP_ALL, REFR, COOP, ASYNC> = all false
 # counted by SQ_INSTS_VALU_{ADD,MUL,FMA}_F32 / _F64 / TRANS_*: priced from the counters, not from this mix
 COUNTED = re.compile(r"^v_(add|sub|subrev|mul|fma|fmac|mac|mad)_(f32|f64)$|^v_pk_(add|mul|fma)_f32$|^v_(rcp|rsq|sqrt|exp|log|sin|cos)_(f32|f64)$")
 
@@ -42,8 +42,8 @@ def price(op, costs, fast, slow):
 
 
 def main():
-    tag = sys.argv[1]
-    calib = json.load(open(os.path.join(ROOT, "profiles", "%s_valu_calib.json" % tag)))
+    tag = sys.argv[1]; calib_tag = sys.argv[2] if len(sys.argv) > 2 else tag      # (the issue costs are the chip's: one calibration serves every build)
+    calib = json.load(open(os.path.join(ROOT, "profiles", "%s_valu_calib.json" % calib_tag)))
     costs = opcode_costs(calib)
     fast = costs["v_add_u32"]; slow = costs["v_min_f32"]
     src = os.path.join(ROOT, "rts_amd", "csrc", "rts_trace.hip")
@@ -73,7 +73,7 @@ def main():
     for op, n in sorted(other.items(), key=lambda kv: -kv[1]):
         c, measured = price(op, costs, fast, slow)
         cyc += c * n; detail[op] = dict(count=n, cycles=c, measured=measured); unmeasured += 0 if measured else n
-    res = dict(tag=tag, kernel=KERNEL, loop_header=hdr, valu_in_loop=sum(hist.values()), uncounted_valu_in_loop=n_other,
+    res = dict(tag=tag, calibration="profiles/%s_valu_calib.json" % calib_tag, kernel=KERNEL, loop_header=hdr, valu_in_loop=sum(hist.values()), uncounted_valu_in_loop=n_other,
                cycles_per_uncounted_valu=cyc / max(n_other, 1), unmeasured_share=unmeasured / max(n_other, 1),
                fast_class_cycles=fast, slow_class_cycles=slow,
                note="static mix of the walk loop (every block of the loop counted once); opcodes without a calibration run are priced by their family (64-bit, compare, min/max, shift, convert, lane ops: slow class; the rest: fast class)",

@@ -23,15 +23,16 @@ PEAK_CLOCK_HZ = 2.4e9                      # MI355X_MICROARCH.md: max clock
 
 def kernel_rows(path):
     """-> (ordinary launches, cooperative launches, meta): per dispatch {counter: value, "_ns": duration}.  A launch of the
-    library is the ordinary trace kernel k_trace<.., false> and, when the handle's cost order has a head, the cooperative
-    kernel k_trace<.., true> beside it (rts_trace.hip); under counter collection rocprofv3 runs the dispatches one at a time."""
+    library is the ordinary trace kernel k_trace<.., COOP = false, ..> and, when the handle's cost order has a head, the cooperative
+    kernel k_trace<.., COOP = true, ..> beside it (rts_trace.hip); under counter collection rocprofv3 runs the dispatches one at a time."""
     rows = {False: collections.OrderedDict(), True: collections.OrderedDict()}
     meta = {}
     for r in csv.DictReader(open(path)):
         name = r["Kernel_Name"]
         if "k_trace" not in name:
             continue
-        coop = name.split("(")[0].rstrip().endswith("true>")
+        targs = [x.strip() for x in name.split("(")[0].split("<", 1)[-1].rstrip("> ").split(",")]      # k_trace<COUNT, KEEP_ALL, REFR, COOP[, ASYNC]>
+        coop = len(targs) >= 4 and targs[3] == "true"
         d = rows[coop].setdefault(int(r["Dispatch_Id"]), {})
         d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
         d["_ns"] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
@@ -119,6 +120,8 @@ def main():
     # transcendentals; the rest is priced with the static opcode mix of the walk loop (tools/isa_mix.py).
     calib_tag = os.environ.get("RTS_CALIB_TAG", "r03")
     cp, mp = os.path.join(ROOT, "profiles", "%s_valu_calib.json" % calib_tag), os.path.join(ROOT, "profiles", "%s_isa_mix.json" % calib_tag)
+    if os.path.exists(os.path.join(ROOT, "profiles", "%s_isa_mix.json" % tag)):      # the opcode mix of THIS build's walk loop (tools/isa_mix.py <tag> <calibration tag>)
+        mp = os.path.join(ROOT, "profiles", "%s_isa_mix.json" % tag)
     if "SQ_INSTS_VALU_ADD_F64" in L and "SQ_INSTS_VALU" in L and os.path.exists(cp) and os.path.exists(mp) and "kernel_cycles" in d:
         cal = json.load(open(cp))["classes"]; mix = json.load(open(mp))
         c = lambda k: cal[k]["waves_per_simd_4"]["cycles_per_wave_inst_per_simd"]
