@@ -72,6 +72,20 @@ extern "C" int rts_bind_host_to_device(int device, int* numa_node)
 }
 
 extern int rts_fill_i32(hipStream_t st, int32_t* p, int32_t v, size_t n);
+
+// The two waits of a pulse (its trace, its post-processing): a thread blocked in hipStreamSynchronize lets its core fall
+// asleep, and every wake-up -- two per pulse, each in front of work the GPU is waiting for -- costs tens of microseconds on
+// the hosts of this pool (the C++ adapter's loop ran 0.44 ms per pulse right after a second of host-side hierarchy build had
+// kept the core awake, 0.72 ms otherwise).  RtsContext::spin_wait (default on; RTS_SPIN_WAIT=0): poll the stream instead.
+hipError_t rts_stream_wait(RtsContext* c, hipStream_t st)
+{
+    if (!c->spin_wait) return hipStreamSynchronize(st);
+    for (;;) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e != hipErrorNotReady) return e;
+        __builtin_ia32_pause();
+    }
+}
 static int rts_attach_scene(RtsContext* c);
 void rts_comm_cache_forget(RtsContext* c);
 
@@ -141,6 +155,7 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     { const char* e = getenv("RTS_TILE_LPT"); if (e && e[0] == '0') c->tile_lpt = false; }
     { const char* e = getenv("RTS_COOP_FRAC"); if (e) { const double v = atof(e); if (v >= 0) c->coop_frac = v; } }                  // 0: no cooperative units; tests: tiny values put every tile at the head
     { const char* e = getenv("RTS_COOP_FLOOR"); if (e) c->coop_floor = (uint32_t)std::max(0, atoi(e)); }
+    { const char* e = getenv("RTS_SPIN_WAIT"); if (e) c->spin_wait = atoi(e) != 0; }
     { const char* e = getenv("RTS_TILE_SORT"); if (e) c->tile_bucket_order = strcmp(e, "radix") != 0; }
     { const char* e = getenv("RTS_POST_SMALL"); if (e) c->post_small = atoi(e) != 0; }
     { const char* e = getenv("RTS_ASYNC_IDLE0"); if (e) c->async_idle0 = (uint32_t)std::min(64, std::max(0, atoi(e))); }
@@ -744,7 +759,7 @@ extern "C" int rts_trace_pulse_end(RtsHandle c)
     const bool keep_all = (c->params.flags & RTS_FLAG_KEEP_ALL_RAYS) != 0;
     const uint32_t n = c->n_rays;
     unsigned long long* cnt = c->pin->cnt;
-    RTS_HIP(hipStreamSynchronize(st));              // the one host sync of the launch: the received count sizes what follows
+    RTS_HIP(rts_stream_wait(c, st));                // the one host sync of the launch: the received count sizes what follows
     if (cnt[6]) { rts_set_error("rts_trace_pulse: traversal stack overflow / malformed BVH guard tripped on %llu waves", cnt[6]); return RTS_ERR_HIP; }
     c->n_recv = cnt[0]; c->n_head_hint = (uint32_t)cnt[7];
 

@@ -913,7 +913,7 @@ int rts_aggregate_fetch(RtsContext* c, std::vector<RtsGroup>* groups)
     RtsPinned* pin = c->pin;
     const uint32_t R = ap.R, D = ap.D, B = ap.B, shift = ap.shift, spec = ap.spec; const bool wide = ap.wide; const uint64_t base = ap.base;
     const bool d_rows = ap.rows; double* gsum = ap.gsum; (void)R;
-    RTS_HIP(hipStreamSynchronize(st));
+    RTS_HIP(rts_stream_wait(c, st));
     const uint32_t G = pin->G;
     const double* h_gsum = pin->gsum; const uint32_t* h_gmin = pin->gmin; const uint64_t* h_gkey = pin->gkey;
     const uint64_t* h_grow = pin->grow; std::vector<uint64_t> v_grow;
