@@ -1,1 +1,1 @@
-#define RTS_SOURCE_HASH "815fb4c5754f2067"
+#define RTS_SOURCE_HASH "aafcabcf5ea5198e"

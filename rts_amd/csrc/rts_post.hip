@@ -183,9 +183,10 @@ __global__ void k_tile_keys(const uint32_t* __restrict__ hist, uint32_t n_hist, 
             is_head = (((est >> 31) && (double)cost > thr) || (rule.big > 0.0 && balanced > 0.0 && (double)cost > thr_big)) ? 1u : 0u;
         }
         key[j] = ~((is_head << 31) | cost); id[j] = j;
-        // bucket of the counting order (bucket_hist != nullptr): 0 = head of the order, then descending cost in steps of 1/32
-        // octave -- finer than a tile's cost repeats from pulse to pulse
-        bucket = is_head ? 0u : (RTS_TILE_BUCKETS - 1u) - min((uint32_t)(__log2f((float)cost + 1.0f) * 32.0f), RTS_TILE_BUCKETS - 2u);
+        // bucket of the counting order (bucket_hist != nullptr): the head of the order in the first half of the bins, the rest in
+        // the second, each by descending cost in steps of 1/16 octave -- finer than a tile's cost repeats from pulse to pulse
+        // (the head is ordered too: its longest cooperative unit has to start first)
+        bucket = (is_head ? 0u : RTS_TILE_BUCKETS / 2u) + (RTS_TILE_BUCKETS / 2u - 1u) - min((uint32_t)(__log2f((float)cost + 1.0f) * 16.0f), RTS_TILE_BUCKETS / 2u - 1u);
         if (bucket_hist) key[j] = bucket;
     }
     if (head_count) {                                                          // (uniform)
@@ -205,7 +206,7 @@ __global__ void k_tile_keys(const uint32_t* __restrict__ hist, uint32_t n_hist, 
 // Counting order of the tiles (instead of a device-wide radix sort of 157 k keys -- eight launches on the chain in front of
 // every trace launch): histogram in k_tile_keys, exclusive scan of the 1 024 bins by one block, and a scatter in which every
 // block reserves its share of each bin with ONE atomic and ranks its tiles inside it in LDS.  Tiles of a bin come out in no
-// particular order (only the schedule depends on it); the head of the order is bin 0, a prefix as before.
+// particular order (only the schedule depends on it); the head of the order is the first half of the bins, a prefix as before.
 __global__ void __launch_bounds__(RTS_TILE_BUCKETS) k_tile_bucket_scan(uint32_t* __restrict__ hist)
 {
     __shared__ uint32_t s[2][RTS_TILE_BUCKETS];

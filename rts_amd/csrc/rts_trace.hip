@@ -122,6 +122,37 @@ __device__ __forceinline__ void rts_fetch_record(const void* p, int node, uint32
                  : "v"(p), "v"(node), "v"(nm), "v"(iNx), "v"(iNy), "v"(iNz) : "memory", "scc", "vcc");
 }
 
+// The record read straight through (offsets 0 .. 96): the cooperative kernel's fetch.  Its waves are few and wait for memory,
+// not for issue slots; the address arithmetic between the loads of the fetch above spreads them over ~15 instructions, and on
+// BASELINE configs[3] -- 440 MB of records streaming through the L1 -- lines were evicted between the first and the last load
+// of a record: +15 % L2 requests, the cooperative kernel 2.5 -> 2.95 ms (profiles/r03c_c4_ab.log).
+__device__ __forceinline__ void rts_fetch_record_plain(const void* p, int node, rts_u32x4& q0, rts_u32x4& q1, rts_u32x4& q2, rts_u32x4& q3,
+                                                       rts_u32x4& q4, rts_u32x4& q5, rts_u32x4& q6)
+{
+    asm volatile("global_load_dwordx4 %0, %7, off\n\t"
+                 "global_load_dwordx4 %1, %7, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %7, off offset:32\n\t"
+                 "global_load_dwordx4 %3, %7, off offset:48\n\t"
+                 "global_load_dwordx4 %4, %7, off offset:64\n\t"
+                 "v_cmp_lt_i32 vcc, -1, %8\n\t"
+                 "s_and_saveexec_b64 vcc, vcc\n\t"
+                 "global_load_dwordx4 %5, %7, off offset:80\n\t"
+                 "global_load_dwordx4 %6, %7, off offset:96\n\t"
+                 "s_mov_b64 exec, vcc\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5), "=&v"(q6)
+                 : "v"(p), "v"(node) : "memory", "scc", "vcc");
+}
+// the constants of a ray by PLANE for that fetch: N* <- the low plane's pair, F* <- the high plane's
+__device__ __forceinline__ RtsSlabRay rts_slab_by_plane(const RtsSlabRay& r)
+{
+    RtsSlabRay p = r;
+    if ((int32_t)__float_as_uint(r.iNx) < 0) { p.iNx = r.iFx; p.cNx = r.cFx; p.iFx = r.iNx; p.cFx = r.cNx; }
+    if ((int32_t)__float_as_uint(r.iNy) < 0) { p.iNy = r.iFy; p.cNy = r.cFy; p.iFy = r.iNy; p.cFy = r.cNy; }
+    if ((int32_t)__float_as_uint(r.iNz) < 0) { p.iNz = r.iFz; p.cNz = r.cFz; p.iFz = r.iNz; p.cFz = r.cNz; }
+    return p;
+}
+
 // The stack entry below the top when it may live in the global spill slab (rare; kept out of line so that the common LDS
 // read stays a ds_read).
 __device__ __attribute__((noinline)) int rts_stack_below_spilled(int from_lds, int sp, int lds_cap, const int32_t* ovf, uint32_t total_threads, uint32_t gtid)
@@ -133,7 +164,7 @@ __device__ __attribute__((noinline)) int rts_stack_below_spilled(int from_lds, i
 // child boxes / the triangle, update the stack and the closest hit.
 #define RTS_STACK_SENTINEL 0x7fffffff
 #define RTS_SEG_ONE 0x00400001u      // one traced segment in the per-lane LDS counter: launch total (bits 0-21) and current tile (bits 22-31)
-template <bool COUNT>
+template <bool COUNT, bool ROLES = true>      // ROLES: the fetch delivers entry / exit planes (lr by role); else low / high planes (lr by plane, rts_slab_by_plane)
 __device__ __forceinline__ void rts_walk_step(const RtsTraceArgs& a, int32_t* s_stack, uint32_t tid, uint32_t gtid, int lds_cap, uint32_t* n_spill_lds,
                                               int& node, int& sp, const RtsSlabRay& lr, const dvec3& prev, const dvec3& dir, float tmin,
                                               float& best_t, int& best_leaf, uint32_t& best_prim, float& t_prune,
@@ -149,7 +180,8 @@ __device__ __forceinline__ void rts_walk_step(const RtsTraceArgs& a, int32_t* s_
     const bool at_node = node >= 0;
     const void* rp = at_node ? static_cast<const void*>(a.nodes4 + node) : static_cast<const void*>(a.leaves + ~node);
     rts_u32x4 q0, q1, q2, q3, q4, q5, q6;
-    rts_fetch_record(rp, node, at_node ? 48u : 0u, lr.iNx, lr.iNy, lr.iNz, q0, q1, q2, q3, q4, q5, q6);
+    if (ROLES) rts_fetch_record(rp, node, at_node ? 48u : 0u, lr.iNx, lr.iNy, lr.iNz, q0, q1, q2, q3, q4, q5, q6);
+    else rts_fetch_record_plain(rp, node, q0, q1, q2, q3, q4, q5, q6);
     if (at_node) {
         // BVH4 node: six dwordx4 planes (lo/hi x,y,z of the four children) + the four child ids
         // (by value through __uint_as_float: __builtin_bit_cast applied to an ext-vector ELEMENT reads element 0)
@@ -163,8 +195,8 @@ __device__ __forceinline__ void rts_walk_step(const RtsTraceArgs& a, int32_t* s_
             const float nx = __builtin_fmaf(NX.k, lr.iNx, lr.cNx), fx = __builtin_fmaf(FX.k, lr.iFx, lr.cFx); \
             const float ny = __builtin_fmaf(NY.k, lr.iNy, lr.cNy), fy = __builtin_fmaf(FY.k, lr.iFy, lr.cFy); \
             const float nz = __builtin_fmaf(NZ.k, lr.iNz, lr.cNz), fz = __builtin_fmaf(FZ.k, lr.iFz, lr.cFz); \
-            const float tn = fmaxf(fmaxf(fmaxf(nx, ny), nz), 0.0f); \
-            const float tf = fminf(fminf(fminf(fx, fy), fz), t_prune); \
+            const float tn = ROLES ? fmaxf(fmaxf(fmaxf(nx, ny), nz), 0.0f) : fmaxf(fmaxf(fminf(nx, fx), fminf(ny, fy)), fmaxf(fminf(nz, fz), 0.0f)); \
+            const float tf = ROLES ? fminf(fminf(fminf(fx, fy), fz), t_prune) : fminf(fminf(fmaxf(nx, fx), fmaxf(ny, fy)), fminf(fmaxf(nz, fz), t_prune)); \
             dk = (tn <= tf) ? tn : INF; }
         RTS_CHILD(x, d0) RTS_CHILD(y, d1) RTS_CHILD(z, d2) RTS_CHILD(w, d3)
 #undef RTS_CHILD
@@ -237,6 +269,7 @@ __device__ __forceinline__ void rts_walk_coop(const RtsTraceArgs& a, int32_t* s_
     int sp = 1, bot = 1;                                  // pending entries of this lane: [bot, sp)
     int node = lane == 0 ? root : SENTINEL;
     uint32_t steps = 0;
+    const RtsSlabRay lp = rts_slab_by_plane(lr);          // (this kernel reads its records straight through: rts_fetch_record_plain)
     for (;;) {
         const bool busy = node != SENTINEL;
         const unsigned long long busy_m = __ballot(busy);
@@ -259,7 +292,7 @@ __device__ __forceinline__ void rts_walk_coop(const RtsTraceArgs& a, int32_t* s_
         bool improved = false;
         if (node != SENTINEL) {
             const float before = t_prune;
-            rts_walk_step<COUNT>(a, s_stack, tid, gtid, lds_cap, n_spill_lds, node, sp, lr, prev, dir, tmin, best_t, best_leaf, best_prim, t_prune, n_nodes, n_tris, hard_overflow);
+            rts_walk_step<COUNT, false>(a, s_stack, tid, gtid, lds_cap, n_spill_lds, node, sp, lp, prev, dir, tmin, best_t, best_leaf, best_prim, t_prune, n_nodes, n_tris, hard_overflow);
             improved = t_prune != before;
         }
         if (__any(improved)) t_prune = rts_wave_min_f32(t_prune);
