@@ -13,7 +13,7 @@ python bench.py --no-cpu-baseline > gpurun_out/${T}_bench_c3_default_256steps.js
 python bench.py --no-cpu-baseline --inflight 1 --steps 64 > gpurun_out/${T}_bench_c3_inflight1.json 2>/dev/null
 python bench.py --no-cpu-baseline --config c3ecef --steps 64 > gpurun_out/${T}_bench_c3ecef.json 2>/dev/null
 python bench.py --no-cpu-baseline --config c2 --steps 64 > gpurun_out/${T}_bench_c2.json 2>/dev/null
-python bench.py --no-cpu-baseline --config c4 --steps 24 --warmup 6 > gpurun_out/${T}_bench_c4.json 2>/dev/null
+python bench.py --no-cpu-baseline --config c4 --steps 24 --warmup 12 > gpurun_out/${T}_bench_c4.json 2>/dev/null
 RTS_BUILDER=host python bench.py --no-cpu-baseline --steps 64 > gpurun_out/${T}_bench_c3_host_tree.json 2>/dev/null
 for f in c3_steps20 c3_default_256steps c3_inflight1 c3ecef c2 c4 c3_host_tree; do python -c "
 import json
