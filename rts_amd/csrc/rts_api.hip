@@ -155,6 +155,8 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     { const char* e = getenv("RTS_TILE_LPT"); if (e && e[0] == '0') c->tile_lpt = false; }
     { const char* e = getenv("RTS_COOP_FRAC"); if (e) { const double v = atof(e); if (v >= 0) c->coop_frac = v; } }                  // 0: no cooperative units; tests: tiny values put every tile at the head
     { const char* e = getenv("RTS_COOP_FLOOR"); if (e) c->coop_floor = (uint32_t)std::max(0, atoi(e)); }
+    c->debug_coop = getenv("RTS_DEBUG_COOP") != nullptr;
+    { const char* e = getenv("RTS_SUM_IN_KERNEL"); if (e) c->sum_in_kernel = atoi(e) != 0; }
     { const char* e = getenv("RTS_SPIN_WAIT"); if (e) c->spin_wait = atoi(e) != 0; }
     { const char* e = getenv("RTS_TILE_SORT"); if (e) c->tile_bucket_order = strcmp(e, "radix") != 0; }
     { const char* e = getenv("RTS_POST_SMALL"); if (e) c->post_small = atoi(e) != 0; }
@@ -540,14 +542,14 @@ extern "C" int rts_reserve(RtsHandle c, uint64_t n_rays)
     const size_t threads = (size_t)c->n_cu * 64 * RTS_BLOCK;             // upper bound of any launch's grid
     const uint32_t H = c->params.max_refl + 1;
     RTS_HIP(c->d_recv.reserve((size_t)n * chains + 1));
-    RTS_HIP(c->d_tile_ctr.reserve(RTS_ZERO_WORDS)); c->p_counters = reinterpret_cast<unsigned long long*>(c->d_tile_ctr.p + 2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE + 4);
+    RTS_HIP(c->d_tile_ctr.reserve(RTS_ZERO_WORDS + RTS_MASK_WORDS + 64)); c->p_counters = reinterpret_cast<unsigned long long*>(c->d_tile_ctr.p + 2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE + 4);
     RTS_HIP(c->d_dir_hist.reserve((size_t)(c->params.max_refr ? 3 * H : std::max<uint32_t>(c->params.max_refl, 1)) * 3 * n + 4));
     const size_t coop_threads = c->coop_frac > 0.0 ? (size_t)c->coop_grid_max * RTS_BLOCK : 0;
     if (c->params.max_refr) RTS_HIP(c->d_child.reserve(2 * (threads + coop_threads)));
     RTS_HIP(c->d_stack_ovf.reserve((size_t)RTS_STACK_OVF * ((size_t)c->n_cu * 1024 + coop_threads)));
     RTS_HIP(c->d_block_counters.reserve(((size_t)c->n_cu * 64 + c->coop_grid_max) * 8));
     const size_t n_tiles = (size_t)((n + RTS_WTILE - 1) / RTS_WTILE), n_hist = (size_t)((W3 + RTS_WTILE - 1) / RTS_WTILE);
-    RTS_HIP(c->d_tile_ctr.reserve(RTS_ZERO_WORDS)); c->p_counters = reinterpret_cast<unsigned long long*>(c->d_tile_ctr.p + 2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE + 4); RTS_HIP(c->d_tile_cost.reserve(n_tiles)); RTS_HIP(c->d_tile_key.reserve(n_tiles)); RTS_HIP(c->d_tile_key_sorted.reserve(n_tiles));
+    RTS_HIP(c->d_tile_ctr.reserve(RTS_ZERO_WORDS + RTS_MASK_WORDS + 64)); c->p_counters = reinterpret_cast<unsigned long long*>(c->d_tile_ctr.p + 2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE + 4); RTS_HIP(c->d_tile_cost.reserve(n_tiles)); RTS_HIP(c->d_tile_key.reserve(n_tiles)); RTS_HIP(c->d_tile_key_sorted.reserve(n_tiles));
     RTS_HIP(c->d_tile_id.reserve(n_tiles)); RTS_HIP(c->d_tile_order.reserve(n_tiles));
     if (c->tile_hist_n != (uint32_t)n_hist) {
         RTS_HIP(c->d_tile_hist.reserve(n_hist)); RTS_HIP(hipMemsetAsync(c->d_tile_hist.p, 0, sizeof(uint32_t) * n_hist, c->stream));
@@ -654,7 +656,12 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     c->pin->lc = lc;
     RTS_HIP(hipMemcpyAsync(c->d_params.p, &c->pin->lc, moved && n_targets ? offsetof(RtsPinned, td) + sizeof(RtsTargetDev) * n_targets : sizeof(RtsLaunchConsts), hipMemcpyHostToDevice, st));
     a.lc = c->p_lc;
-    { int rc = rts_scene_place(c, lc, moved); if (rc != RTS_OK) return rc; }      // placement (a target moved) + the primary-ray mask: one pass over the leaves for both
+    // ONE fill per pulse: the draw counters of both kernels, the order's head words and bins, the launch's 16 counters and --
+    // behind them, when this pulse has one -- the primary-ray mask
+    RTS_HIP(c->d_tile_ctr.reserve(RTS_ZERO_WORDS + RTS_MASK_WORDS + 64));
+    RTS_HIP(hipMemsetAsync(c->d_tile_ctr.p, 0, sizeof(uint32_t) * (((RTS_ZERO_WORDS + (lc.mask.n ? (size_t)lc.mask.n * lc.mask.n / 32u + 1u : 0u)) + 63u) & ~(size_t)63u), st));      // (a whole number of 256-byte pieces: the runtime splits an odd-sized fill into two kernels)
+    uint32_t* const pmask = c->d_tile_ctr.p + RTS_ZERO_WORDS;
+    { int rc = rts_scene_place(c, lc, moved, pmask); if (rc != RTS_OK) return rc; }      // placement (a target moved) + the primary-ray mask: one pass over the leaves for both
     if (moved) { RTS_STAGE(c, "scene_place"); c->bvh_valid = true; c->stats.bvh_rebuilt = 1; }
     RTS_HIP(hipEventRecord(c->ev[1], st));
     a.ray_first = first; a.n_rays = n; a.W = W; a.max_refl = c->params.max_refl; a.smooth = c->params.interpolate_smooth ? 1u : 0u;
@@ -680,7 +687,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
         rts_fill_i32(st, c->d_hit_prim.p, -2, (size_t)n * (c->params.max_refl + 1));
         RTS_HIP(hipMemsetAsync(c->d_hit_t.p, 0, sizeof(float) * (size_t)n * (c->params.max_refl + 1), st));
     }
-    a.pmask = lc.mask.n ? c->d_pmask.p : nullptr; a.pre_filter = pre_filter ? 1u : 0u;
+    a.pmask = lc.mask.n ? pmask : nullptr; a.pre_filter = pre_filter ? 1u : 0u;
     a.nodes4 = c->scene->d_nodes4.p; a.stack_lds = c->stack_lds; a.leaves = c->d_leaves.p; a.tri_nidx = c->scene->d_tri_nidx.p; a.normals = c->d_normals_world.p;
     a.targets = c->p_targets; a.rx = c->d_rx.p;
     a.recv_records = c->d_recv.p; a.all_records = c->d_all.p; a.counters = c->p_counters; a.block_counters = c->d_block_counters.p; a.dir_hist = c->d_dir_hist.p;
@@ -691,8 +698,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
         const uint64_t sig[4] = {n, first, ((uint64_t)il_parts << 32) | il_tile, il_part};
         const bool aligned = first % RTS_WTILE == 0 && (il_parts <= 1 || il_tile % RTS_WTILE == 0);
         const uint32_t n_hist = (uint32_t)((total + RTS_WTILE - 1) / RTS_WTILE);
-        RTS_HIP(c->d_tile_ctr.reserve(RTS_ZERO_WORDS)); c->p_counters = reinterpret_cast<unsigned long long*>(c->d_tile_ctr.p + 2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE + 4); a.counters = c->p_counters;
-        RTS_HIP(hipMemsetAsync(c->d_tile_ctr.p, 0, sizeof(uint32_t) * RTS_ZERO_WORDS, st));      // ONE fill: draw counters of both kernels, the order's head words, the launch's 16 counters
+        RTS_HIP(c->d_tile_ctr.reserve(RTS_ZERO_WORDS + RTS_MASK_WORDS + 64)); c->p_counters = reinterpret_cast<unsigned long long*>(c->d_tile_ctr.p + 2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE + 4); a.counters = c->p_counters;
         a.tile_ctr = c->d_tile_ctr.p;
         if (lpt && aligned && n_tiles > grid * (RTS_BLOCK / RTS_WTILE)) {
             if (c->tile_hist_n != n_hist) {
@@ -732,6 +738,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
         else coop_grid = (unsigned)std::min<uint64_t>(c->coop_grid_max, std::max<uint64_t>(16, (units + 3) / 4));
         c->last_args = a;
     }
+    if (c->debug_coop) fprintf(stderr, "[rts] launch: n_rays %u grid %u head hint %u coop grid %u seg threshold %u min cost %u order %d\n", n, grid, c->n_head_hint, coop_grid, a.coop_seg_cost, a.coop_min_cost, a.tile_order ? 1 : 0);
     int rc = rts_trace_launch(c, a, count_trav, coop_grid);
     if (rc != RTS_OK) return rc;
     RTS_STAGE(c, "k_trace");

@@ -1,1 +1,1 @@
-#define RTS_SOURCE_HASH "aafcabcf5ea5198e"
+#define RTS_SOURCE_HASH "7e7efb2ebaaf52d4"

@@ -14,11 +14,9 @@
 // --------------------------------------------------------------------------- placement
 // verts_rot[v][i] = sum_k R[i][k] * vert[v][k], accumulated from 0 in k order
 // (matrix_multiply, ray_tracer.cpp:120-137,166), then += position (:1010-1014).
-__global__ void k_place(const double* __restrict__ local, double* __restrict__ world, const uint32_t* __restrict__ targ_of,
-                        const RtsTargetMotion* __restrict__ motion, uint32_t n, int add_position)
+__device__ __forceinline__ void place_one(const double* __restrict__ local, double* __restrict__ world, const uint32_t* __restrict__ targ_of,
+                                          const RtsTargetMotion* __restrict__ motion, uint32_t i, bool add_position)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
     const RtsTargetMotion m = motion[targ_of[i]];
     double x = local[3*i], y = local[3*i+1], z = local[3*i+2];
     if (m.has_rotation) {
@@ -30,6 +28,15 @@ __global__ void k_place(const double* __restrict__ local, double* __restrict__ w
     }
     if (add_position) { x += m.position[0]; y += m.position[1]; z += m.position[2]; }
     world[3*i] = x; world[3*i+1] = y; world[3*i+2] = z;
+}
+// vertices (rotated, then moved) and normals (rotated) of all targets in ONE launch: thread i < n_verts places vertex i, the rest normal i - n_verts
+__global__ void k_place(const double* __restrict__ v_local, double* __restrict__ v_world, const uint32_t* __restrict__ v_targ, uint32_t n_verts,
+                        const double* __restrict__ n_local, double* __restrict__ n_world, const uint32_t* __restrict__ n_targ, uint32_t n_normals,
+                        const RtsTargetMotion* __restrict__ motion)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_verts) place_one(v_local, v_world, v_targ, motion, i, true);
+    else if (i - n_verts < n_normals) place_one(n_local, n_world, n_targ, motion, i - n_verts, false);
 }
 
 // --------------------------------------------------------------------------- primary-ray mask (see RtsMaskFrame)
@@ -126,26 +133,22 @@ static inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n 
 
 // The placement of a pulse (when a target moved: `place`) and its primary-ray mask (when the pulse has one: lc.mask.n), with
 // one pass over the leaves for both where both are due.
-int rts_scene_place(RtsContext* c, const RtsLaunchConsts& lc, bool place)
+int rts_scene_place(RtsContext* c, const RtsLaunchConsts& lc, bool place, uint32_t* pmask)
 {
     hipStream_t st = c->stream;
     const RtsMaskFrame& f = lc.mask;
     const bool mask = f.n != 0;
     const RtsScene* sc = c->scene;
-    if (mask) {
-        const size_t words = (size_t)f.n * f.n / 32u + 1u;
-        RTS_HIP(c->d_pmask.reserve(words));
-        RTS_HIP(hipMemsetAsync(c->d_pmask.p, 0, sizeof(uint32_t) * words, st));
-    }
+    // (the mask buffer -- behind the handle's zero block -- has been cleared with it: rts_trace_pulse_begin)
     if (place) {
-        if (sc->n_verts) k_place<<<blocks_for(sc->n_verts, 256), 256, 0, st>>>(sc->d_verts_local.p, c->d_verts_world.p, sc->d_vert_targ.p, c->p_motion, sc->n_verts, 1);
-        if (sc->n_normals) k_place<<<blocks_for(sc->n_normals, 256), 256, 0, st>>>(sc->d_normals_local.p, c->d_normals_world.p, sc->d_norm_targ.p, c->p_motion, sc->n_normals, 0);
+        if (sc->n_verts + sc->n_normals) k_place<<<blocks_for((size_t)sc->n_verts + sc->n_normals, 256), 256, 0, st>>>(sc->d_verts_local.p, c->d_verts_world.p, sc->d_vert_targ.p, sc->n_verts,
+                                                                                                                         sc->d_normals_local.p, c->d_normals_world.p, sc->d_norm_targ.p, sc->n_normals, c->p_motion);
     }
     if (sc->n_leaves) {
         const unsigned g = blocks_for(sc->n_leaves, 256);
-        if (place && mask) k_leaves<true, true><<<g, 256, 0, st>>>(sc->d_leaf_prim.p, sc->d_tri_vidx.p, c->d_verts_world.p, sc->d_prim_targ.p, c->d_leaves.p, sc->n_leaves, lc.ox, lc.oy, lc.oz, f, c->d_pmask.p);
+        if (place && mask) k_leaves<true, true><<<g, 256, 0, st>>>(sc->d_leaf_prim.p, sc->d_tri_vidx.p, c->d_verts_world.p, sc->d_prim_targ.p, c->d_leaves.p, sc->n_leaves, lc.ox, lc.oy, lc.oz, f, pmask);
         else if (place) k_leaves<true, false><<<g, 256, 0, st>>>(sc->d_leaf_prim.p, sc->d_tri_vidx.p, c->d_verts_world.p, sc->d_prim_targ.p, c->d_leaves.p, sc->n_leaves, lc.ox, lc.oy, lc.oz, f, nullptr);
-        else if (mask) k_leaves<false, true><<<g, 256, 0, st>>>(sc->d_leaf_prim.p, sc->d_tri_vidx.p, c->d_verts_world.p, sc->d_prim_targ.p, nullptr, sc->n_leaves, lc.ox, lc.oy, lc.oz, f, c->d_pmask.p);
+        else if (mask) k_leaves<false, true><<<g, 256, 0, st>>>(sc->d_leaf_prim.p, sc->d_tri_vidx.p, c->d_verts_world.p, sc->d_prim_targ.p, nullptr, sc->n_leaves, lc.ox, lc.oy, lc.oz, f, pmask);
     }
     RTS_HIP(hipGetLastError());
     return RTS_OK;

@@ -114,6 +114,7 @@ static_assert(sizeof(RtsChildState) == 128, "child state size");
 // RTS_MASK_MIN_CELL (tangent units = radians): the f32 direction of the pre-filter must stay inside the one-cell margin.
 #define RTS_MASK_MIN_CELL 1.0e-5
 #define RTS_MASK_N 1024u
+#define RTS_MASK_WORDS (RTS_MASK_N * RTS_MASK_N / 32u + 1u)      // the mask lives behind the handle's zero block (RTS_ZERO_WORDS): ONE fill per pulse clears both
 #define RTS_MASK_MAX_CELLS 4096
 struct RtsMaskFrame { float bx, by, bz, ux, uy, uz, vx, vy, vz; float u0, v0, inv_du, inv_dv; uint32_t n, pad0, pad1; };
 
@@ -165,6 +166,7 @@ struct RtsTraceArgs {
     uint32_t* tile_ctr;             // [RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE] draw counters (element s * STRIDE), zero at launch
     const uint32_t* tile_head;      // [1] number of tiles at the head of tile_order that are traced as 64 cooperative units (null: none)
     const uint32_t* tile_head_all;  // the same word whether or not this launch has a cooperative kernel (read back with the counters)
+    uint32_t* done_ctr; uint32_t n_blocks_all; unsigned long long* host_cnt;      // the last block of the launch (ticket from done_ctr, zero at launch) sums the block counters and writes them home
     uint32_t async_idle0, async_idle1, async_age;   // asynchronous bounces (rts_trace_unit_async): idle-lane limit of a walk phase for young / old tiles (0: lock-step kernel), age in cost units
     uint32_t coop_min_cost, coop_seg_cost;   // a tile is flagged LONG WALKS (bit 31 of its cost record) if it took >= coop_min_cost units and >= coop_seg_cost units per traced segment
     unsigned long long* timeline;   // debug (RTS_TIMELINE, counting build): [grid][2] block start/end ticks, then [tiles] tile durations (100 MHz)
@@ -292,6 +294,9 @@ struct RtsContext {
     DevBuf<double> d_gsum; DevBuf<uint32_t> d_gmin; DevBuf<uint64_t> d_gkey; DevBuf<uint32_t> d_gcount; DevBuf<uint64_t> d_grow; DevBuf<int32_t> d_gpath;
     DevBuf<double> d_delay, d_phase; DevBuf<int32_t> d_pathmatch; DevBuf<double> d_rcs;
     std::vector<RtsGroup> groups; bool agg_valid = false; uint64_t recv_index_base = 0;
+    bool debug_coop = false;            // RTS_DEBUG_COOP: one line per launch on stderr (grids, head hint, thresholds)
+    bool sum_in_kernel = false;         // the launch's last block sums the block counters (RTS_SUM_IN_KERNEL=1) instead of k_sum_counters -- measured SLOWER, off: the ticket's
+                                        // release / acquire fences (one per block) write back and invalidate L2, and the post-processing behind the trace took 0.40 instead of 0.34 ms
     bool spin_wait = true;              // the pulse's two host waits poll the stream instead of blocking (rts_stream_wait; RTS_SPIN_WAIT=0)
     bool tile_bucket_order = true;      // tile order by counting bins instead of a radix sort (RTS_TILE_SORT=radix: the sort)
     bool post_small = true;             // received sets of up to 4096 rays are ordered / finished by single blocks (RTS_POST_SMALL=0: the general chain)
@@ -309,7 +314,7 @@ struct RtsContext {
 // implemented in the .hip units
 int rts_sah_build(const double* verts, const uint32_t* tris, uint32_t n_tris, double split_budget, std::vector<RtsNode4>& nodes, std::vector<uint32_t>& leaf_prim, RtsBlasInfo& out);
 int rts_lbvh_build_device(RtsContext* c, RtsScene* ns, const std::vector<uint32_t>& vidx, const std::vector<RtsMeshHost>& mh, double split_budget);
-int rts_scene_place(RtsContext* c, const RtsLaunchConsts& lc, bool place);      // placement kernels (place) + the primary-ray mask (lc.mask.n != 0)
+int rts_scene_place(RtsContext* c, const RtsLaunchConsts& lc, bool place, uint32_t* pmask);      // placement kernels (place) + the primary-ray mask (lc.mask.n != 0)
 int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_valid, const uint64_t* cur_sig, uint32_t n_tiles_cur, uint32_t resident_waves);
 int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a, bool count_traversal, unsigned coop_grid);
 void rts_trace_preload();

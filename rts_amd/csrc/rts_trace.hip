@@ -799,6 +799,29 @@ __device__ __forceinline__ void rts_trace_unit_async(const RtsTraceArgs& a, cons
 #undef RTS_SLOT
 }
 
+// counters[1..6] = sum over the blocks of a launch (256 threads of ONE block; the launch has at most a few thousand blocks)
+// ... and all of them into the handle's pinned host block (host_cnt: device address of RtsPinned::cnt) -- the host reads them
+// after its wait for the stream, without a copy of their own.  s: 256 u64 of LDS.  Loads at agent scope (see k_trace's epilogue).
+__device__ __forceinline__ void rts_sum_counters_body(const uint32_t t, unsigned long long* s, const unsigned long long* block_counters, unsigned int n_blocks,
+                                                      unsigned long long* counters, const uint32_t* head_count, unsigned long long* host_cnt)
+{
+#define RTS_LD64(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+    if (t == 7) { const unsigned long long h = head_count ? (unsigned long long)__hip_atomic_load(head_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL; counters[7] = h; host_cnt[7] = h; }     // the order's head count travels home with the counters (sizes the next cooperative grid)
+    if (t == 0) host_cnt[0] = RTS_LD64(&counters[0]);                          // received rays (appended by the trace kernels)
+    if (t >= 8 && t <= 10) host_cnt[t] = RTS_LD64(&counters[t]);               // lane statistics of the counting build
+    const unsigned int k = t & 7u, lane = t >> 3;                              // 32 partial sums per counter
+    unsigned long long v = 0;
+    if (k >= 1 && k <= 6) for (unsigned int b = lane; b < n_blocks; b += 32) v += RTS_LD64(&block_counters[(size_t)b * 8 + k]);
+    s[t] = v;
+    __syncthreads();
+    if (t >= 1 && t <= 6) {
+        unsigned long long sum = 0;
+        for (unsigned int l = 0; l < 32; l++) sum += s[l * 8 + t];
+        counters[t] = sum; host_cnt[t] = sum;
+    }
+#undef RTS_LD64
+}
+
 // KEEP_ALL is a template parameter, not a run-time flag: hipcc (ROCm 7.2) lowered the uniform
 // `if (a.keep_all)` to a per-lane v_cmp mask computed under the divergent exec of the bounce loop
 // and re-used it at the write-back under a different exec, so lanes that were inactive at the
@@ -999,28 +1022,30 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR || COOP) ? 2 : 4) k_trace(con
         else v = any_overflow ? 1ULL : 0ULL;
         a.block_counters[((size_t)(COOP ? a.total_threads / RTS_BLOCK : 0u) + blockIdx.x) * 8 + tid_e] = v;
     }
+    // The LAST block of the launch -- of either kernel -- to get here adds the blocks' rows up and writes the launch's counters
+    // into the handle's pinned host block: no kernel of its own between the end of the trace and the host's wake-up (it ran
+    // 20-35 us among the neighbouring pulses' blocks).  Release / acquire around the ticket: every thread fences after its
+    // stores, the last block fences before its loads, which bypass the non-coherent caches (the head count a few words away
+    // was read by every block when it started).
+    if (a.done_ctr) {
+        __threadfence();
+        __syncthreads();
+        uint32_t* s_ticket = reinterpret_cast<uint32_t*>(s_stack) + 1024;                 // (beyond the [waves][8] sums above)
+        if (tid_e == 0) *s_ticket = atomicAdd(a.done_ctr, 1u);
+        __syncthreads();
+        if (*s_ticket == a.n_blocks_all - 1u) {
+            __threadfence();
+            rts_sum_counters_body(tid_e, reinterpret_cast<unsigned long long*>(s_stack) + 1024, a.block_counters, a.n_blocks_all, a.counters, a.tile_head_all, a.host_cnt);
+        }
+    }
 }
 
-// counters[1..6] = sum over the blocks of a launch (single block; the launch has at most a few thousand blocks)
-// ... and writes all eight into the handle's pinned host block (host_cnt: device address of RtsPinned::cnt) -- the host reads them
-// after its wait for the stream, without a copy of their own
+// k_sum_counters for a launch without launch indices (an interleaved part that is empty): zeros go home
 __global__ void k_sum_counters(const unsigned long long* __restrict__ block_counters, unsigned int n_blocks, unsigned long long* __restrict__ counters, const uint32_t* __restrict__ head_count,
                                unsigned long long* __restrict__ host_cnt)
 {
-    if (threadIdx.x == 7) { const unsigned long long h = head_count ? head_count[0] : 0u; counters[7] = h; host_cnt[7] = h; }     // the order's head count travels home with the counters (sizes the next cooperative grid)
-    if (threadIdx.x == 0) host_cnt[0] = counters[0];                          // received rays (appended by the trace kernels)
-    if (threadIdx.x >= 8 && threadIdx.x <= 10) host_cnt[threadIdx.x] = counters[threadIdx.x];      // lane statistics of the counting build
     __shared__ unsigned long long s[256];
-    const unsigned int k = threadIdx.x & 7u, lane = threadIdx.x >> 3;                   // 32 partial sums per counter
-    unsigned long long v = 0;
-    if (k >= 1 && k <= 6) for (unsigned int b = lane; b < n_blocks; b += 32) v += block_counters[(size_t)b * 8 + k];
-    s[threadIdx.x] = v;
-    __syncthreads();
-    if (threadIdx.x >= 1 && threadIdx.x <= 6) {
-        unsigned long long t = 0;
-        for (unsigned int l = 0; l < 32; l++) t += s[l * 8 + threadIdx.x];
-        counters[threadIdx.x] = t; host_cnt[threadIdx.x] = t;
-    }
+    rts_sum_counters_body(threadIdx.x, s, block_counters, n_blocks, counters, head_count, host_cnt);
 }
 
 template <bool COOP>
@@ -1054,8 +1079,11 @@ static void rts_trace_dispatch(const RtsTraceArgs& a, bool count_traversal, unsi
 // C4 9.4 instead of 8.7 ms).  The stream is created by the first launch that needs it: HIP maps streams onto a handful of
 // hardware queues, and one more stream per handle made unrelated handles of a three-pulse pipeline share a queue --
 // 0.69 -> 0.93 ms per pulse on C3, where there is no cooperative work at all.
-int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a, bool count_traversal, unsigned coop_grid)
+int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a_in, bool count_traversal, unsigned coop_grid)
 {
+    RtsTraceArgs a = a_in;
+    a.done_ctr = c->sum_in_kernel ? a.tile_ctr + 2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE + 3 : nullptr;      // (the pad word behind the head words: zeroed with them)
+    a.n_blocks_all = a.total_threads / RTS_BLOCK + coop_grid; a.host_cnt = c->pin_dev->cnt;
     if (a.n_rays == 0) {                                            // nothing to trace (an interleaved part without launch indices): the counters still go home, as zeros
         k_sum_counters<<<1, 256, 0, c->tstream>>>(a.block_counters, 0u, a.counters, nullptr, c->pin_dev->cnt);
         RTS_HIP(hipGetLastError());
@@ -1072,7 +1100,7 @@ int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a, bool count_traversal,
     }
     rts_trace_dispatch<false>(a, count_traversal, grid, st);
     if (coop_grid) RTS_HIP(hipStreamWaitEvent(st, c->ev_coop[1], 0));
-    k_sum_counters<<<1, 256, 0, st>>>(a.block_counters, grid + coop_grid, a.counters, a.tile_head_all, c->pin_dev->cnt);
+    if (!c->sum_in_kernel) k_sum_counters<<<1, 256, 0, st>>>(a.block_counters, grid + coop_grid, a.counters, a.tile_head_all, c->pin_dev->cnt);
     RTS_HIP(hipGetLastError());
     return RTS_OK;
 }
