@@ -73,6 +73,13 @@ extern "C" int rts_bind_host_to_device(int device, int* numa_node)
 
 extern int rts_fill_i32(hipStream_t st, int32_t* p, int32_t v, size_t n);
 
+__global__ void k_children_to_prims(RtsNode4* __restrict__ nodes, uint32_t n, const uint32_t* __restrict__ leaf_prim)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int k = 0; k < 4; k++) { const int32_t ch = nodes[i].child[k]; nodes[i].pad[k] = ch; if (ch < 0) nodes[i].child[k] = ~(int32_t)leaf_prim[~ch]; }
+}
+
 // The two waits of a pulse (its trace, its post-processing): a thread blocked in hipStreamSynchronize lets its core fall
 // asleep, and every wake-up -- two per pulse, each in front of work the GPU is waiting for -- costs tens of microseconds on
 // the hosts of this pool (the C++ adapter's loop ran 0.44 ms per pulse right after a second of host-side hierarchy build had
@@ -339,6 +346,11 @@ extern "C" int rts_set_scene(RtsHandle c, const RtsMesh* meshes, uint32_t n_targ
         ns->blas = blas; ns->n_nodes = (uint32_t)nodes4.size(); ns->n_leaves = (uint32_t)leaf_prim.size();
         ns->builder = 0;
     }
+    // Leaf records are kept per PRIMITIVE, not per leaf slot (a triangle cut into several references has several slots): the
+    // nodes' leaf children are rewritten from ~slot to ~primitive here, once, whichever builder ran; the slot form is parked in
+    // the record's unused words for rts_get_bvh.  A third of the per-pulse leaf refresh and of the leaf bytes on C3 (300 k slots
+    // for 100 k triangles), and of the 240 MB per handle on BASELINE configs[3].
+    if (ns->n_nodes) { k_children_to_prims<<<(ns->n_nodes + 255) / 256, 256, 0, c->stream>>>(ns->d_nodes4.p, ns->n_nodes, ns->d_leaf_prim.p); RTS_HIP(hipGetLastError()); RTS_HIP(hipStreamSynchronize(c->stream)); }
     ns->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build0).count();
 
     // ---- swap it in
@@ -351,7 +363,7 @@ extern "C" int rts_set_scene(RtsHandle c, const RtsMesh* meshes, uint32_t n_targ
 static int rts_attach_scene(RtsContext* c)
 {
     const RtsScene* sc = c->scene; const uint32_t n_targets = (uint32_t)sc->meshes.size();
-    RTS_HIP(c->d_leaves.reserve((size_t)sc->n_leaves + 1));
+    RTS_HIP(c->d_leaves.reserve((size_t)sc->n_prims + 1));      // one record per primitive (k_children_to_prims)
     RTS_HIP(c->d_verts_world.reserve(3*(size_t)sc->n_verts + 1)); RTS_HIP(c->d_normals_world.reserve(3*(size_t)sc->n_normals + 1));
     {   // device image of the pinned block's [lc | motion | td]
         const size_t span = offsetof(RtsPinned, cnt);
@@ -1322,7 +1334,11 @@ extern "C" int rts_get_bvh(RtsHandle c, void* nodes128, uint32_t* leaf_prim, int
     if (n_leaves) *n_leaves = c->scene->n_leaves;
     if ((nodes128 && node_capacity < c->scene->n_nodes) || (leaf_prim && leaf_capacity < c->scene->n_leaves)) { rts_set_error("rts_get_bvh: capacity too small (%u nodes, %u leaves)", c->scene->n_nodes, c->scene->n_leaves); return RTS_ERR_CAPACITY; }
     RTS_HIP(hipStreamSynchronize(c->stream));
-    if (nodes128 && c->scene->n_nodes) RTS_HIP(hipMemcpy(nodes128, c->scene->d_nodes4.p, sizeof(RtsNode4)*c->scene->n_nodes, hipMemcpyDeviceToHost));
+    if (nodes128 && c->scene->n_nodes) {
+        RTS_HIP(hipMemcpy(nodes128, c->scene->d_nodes4.p, sizeof(RtsNode4)*c->scene->n_nodes, hipMemcpyDeviceToHost));
+        RtsNode4* nd = static_cast<RtsNode4*>(nodes128);              // (the builders' form: leaf children as ~slot, see k_children_to_prims)
+        for (uint32_t i = 0; i < c->scene->n_nodes; i++) for (int k = 0; k < 4; k++) { nd[i].child[k] = nd[i].pad[k]; nd[i].pad[k] = 0; }
+    }
     if (leaf_prim && c->scene->n_leaves) RTS_HIP(hipMemcpy(leaf_prim, c->scene->d_leaf_prim.p, sizeof(uint32_t)*c->scene->n_leaves, hipMemcpyDeviceToHost));
     if (roots) for (size_t t = 0; t < c->scene->blas.size(); t++) roots[t] = c->scene->blas[t].root;
     return RTS_OK;

@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(256) k_leaves(const uint32_t* __restrict__ lea
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     double p[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (i < n) {
-        const uint32_t g = leaf_prim[i];
+        const uint32_t g = leaf_prim ? leaf_prim[i] : i;                 // (one record per primitive: leaf_prim == nullptr)
         const uint32_t a = tri_vidx[3*(size_t)g], b = tri_vidx[3*(size_t)g+1], c = tri_vidx[3*(size_t)g+2];
         p[0] = verts[3*(size_t)a]; p[1] = verts[3*(size_t)a+1]; p[2] = verts[3*(size_t)a+2];
         p[3] = verts[3*(size_t)b]; p[4] = verts[3*(size_t)b+1]; p[5] = verts[3*(size_t)b+2];
@@ -144,11 +144,11 @@ int rts_scene_place(RtsContext* c, const RtsLaunchConsts& lc, bool place, uint32
         if (sc->n_verts + sc->n_normals) k_place<<<blocks_for((size_t)sc->n_verts + sc->n_normals, 256), 256, 0, st>>>(sc->d_verts_local.p, c->d_verts_world.p, sc->d_vert_targ.p, sc->n_verts,
                                                                                                                          sc->d_normals_local.p, c->d_normals_world.p, sc->d_norm_targ.p, sc->n_normals, c->p_motion);
     }
-    if (sc->n_leaves) {
-        const unsigned g = blocks_for(sc->n_leaves, 256);
-        if (place && mask) k_leaves<true, true><<<g, 256, 0, st>>>(sc->d_leaf_prim.p, sc->d_tri_vidx.p, c->d_verts_world.p, sc->d_prim_targ.p, c->d_leaves.p, sc->n_leaves, lc.ox, lc.oy, lc.oz, f, pmask);
-        else if (place) k_leaves<true, false><<<g, 256, 0, st>>>(sc->d_leaf_prim.p, sc->d_tri_vidx.p, c->d_verts_world.p, sc->d_prim_targ.p, c->d_leaves.p, sc->n_leaves, lc.ox, lc.oy, lc.oz, f, nullptr);
-        else if (mask) k_leaves<false, true><<<g, 256, 0, st>>>(sc->d_leaf_prim.p, sc->d_tri_vidx.p, c->d_verts_world.p, sc->d_prim_targ.p, nullptr, sc->n_leaves, lc.ox, lc.oy, lc.oz, f, pmask);
+    if (sc->n_prims) {                                               // one leaf record per primitive (rts_api.hip: k_children_to_prims)
+        const unsigned g = blocks_for(sc->n_prims, 256);
+        if (place && mask) k_leaves<true, true><<<g, 256, 0, st>>>(nullptr, sc->d_tri_vidx.p, c->d_verts_world.p, sc->d_prim_targ.p, c->d_leaves.p, sc->n_prims, lc.ox, lc.oy, lc.oz, f, pmask);
+        else if (place) k_leaves<true, false><<<g, 256, 0, st>>>(nullptr, sc->d_tri_vidx.p, c->d_verts_world.p, sc->d_prim_targ.p, c->d_leaves.p, sc->n_prims, lc.ox, lc.oy, lc.oz, f, nullptr);
+        else if (mask) k_leaves<false, true><<<g, 256, 0, st>>>(nullptr, sc->d_tri_vidx.p, c->d_verts_world.p, sc->d_prim_targ.p, nullptr, sc->n_prims, lc.ox, lc.oy, lc.oz, f, pmask);
     }
     RTS_HIP(hipGetLastError());
     return RTS_OK;

@@ -28,3 +28,4 @@ RTS_BUILDER=host tools/adapter_bench_bin 216 64 3 6 6 > gpurun_out/${T}_adapter_
 RTS_COOP_FRAC=0 tools/adapter_bench_bin 216 64 3 6 6 > gpurun_out/${T}_adapter_bench_no_coop.json 2>&1; tail -1 gpurun_out/${T}_adapter_bench_no_coop.json
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --backend nccl > gpurun_out/${T}_bench_rccl_world1.json 2> gpurun_out/${T}_bench_rccl_world1.err
 python tools/cpu_baseline.py c1 c2 c3 > gpurun_out/${T}_cpu_baseline.log 2>&1; cat gpurun_out/${T}_cpu_baseline.log
+python tools/scene_info.py c3 c4 > gpurun_out/${T}_scene_info.log 2>&1; cat gpurun_out/${T}_scene_info.log
