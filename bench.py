@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--width", type=int, default=0, help="W (launch indices per pulse = W^3); 0 = the config's own")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--link", action="store_true", help="rts_link_handles: the handles' trace kernels run strictly one at a time")
+    ap.add_argument("--fused-post", action="store_true", help="rts_trace_pulse_end_uniform (the post-processing enqueued on the device-side received count, no host wait for the trace) instead of rts_trace_pulse_end + rts_finalise_uniform + rts_cube_accumulate + rts_aggregate: measured equal or slower (DESIGN.md section 5)")
     ap.add_argument("--no-bind", action="store_true", help="leave the process's CPU affinity alone (default: the CPUs of the GPU's NUMA node)")
     ap.add_argument("--post-lag", type=int, default=0, choices=(0, 1), help="1: a pulse's group table is collected one pulse later (the submitting thread does not wait for the post-processing it has just enqueued)")
     ap.add_argument("--inflight", type=int, default=3, help="pulses in flight per GPU; 1 = strictly sequential pulses")
@@ -255,8 +256,14 @@ def main():
         hp = acc.setdefault("host_ms", dict(begin=0.0, end_wait=0.0, post_enqueue=0.0, collect_wait=0.0))      # where the submitting thread spends the interval
 
         def post(t, k):
-            """the pulse's trace has to be over (received count); everything after it is only ENQUEUED"""
+            """everything after the trace is only ENQUEUED.  One call (rts_trace_pulse_end_uniform): on the device-side received
+            count, without waiting for the trace, when the handle's previous pulse received few rays (--fused-post); default: the
+            pulse's trace has to be over first (rts_trace_pulse_end reads the count), then three more calls"""
             h0 = time.perf_counter()
+            if fused_post:
+                t.trace_end_uniform(None, wl, 1.0, 1.0, spec["carrier"], spec["c"], cube_pulse=k, recv_index_base=rts_amd._lib.RTS_BASE_USE_ROWS)
+                hp["post_enqueue"] += (time.perf_counter() - h0) * 1e3
+                return
             t.trace_end()
             h1 = time.perf_counter()
             t.finalise_uniform(None, wl, 1.0, 1.0, spec["carrier"], spec["c"])
@@ -283,6 +290,7 @@ def main():
         # tracing]; the oldest pulse's table is collected just before its handle takes a new pulse.  --post-lag 0: the oldest
         # pulse is completed (trace, post-processing, table) before the next one is begun -- every handle traces.
         lag = args.post_lag if len(trs) >= 2 else 0
+        fused_post = args.fused_post and hasattr(rts_amd._lib.lib(), "rts_trace_pulse_end_uniform")
         pending = []; posted = []
         for i, (k, first, count, il) in enumerate(plan(n_pulses)):
             t = trs[i % len(trs)]
@@ -291,6 +299,11 @@ def main():
             h0 = time.perf_counter()
             t.trace_begin(tx["origin"], tx["span"], tx["dir"], pulse_motion(spec, k0 + k), ray_first=first, ray_count=count, interleave=il)
             hp["begin"] += (time.perf_counter() - h0) * 1e3
+            if fused_post:                                    # the whole pulse -- placement, trace, post-processing -- is enqueued in one go ...
+                post(t, k); posted.append((t, k))
+                if len(posted) == len(trs):                   # ... and the oldest pulse's table collected while the newer ones run
+                    collect(*posted.pop(0))
+                continue
             pending.append((t, k))
             if len(pending) == len(trs) - lag:                # the oldest pulse in flight is taken further while the newer ones run
                 tk = pending.pop(0); post(*tk)
@@ -447,7 +460,7 @@ def main():
                        "hit_fraction": hit_fraction, "primary_Mrays_per_s": total * args.steps / dt / 1e6,
                        "return_cube": "complex128 [%d rx][%d pulses][%d bins], all-reduced once per interval, then %d-point slow-time FFT in the library (rts_cube_doppler, inside the timed region); range-Doppler peak %.6e, max deviation from torch.fft %.1e (relative)" % (cube.shape[0], cube.shape[1], n_bins, n_fft, range_doppler_peak, range_doppler_err or 0.0),
                        "sharding": ("%d-pulse interval over %d ranks, --shard %s: " % (args.steps, world, args.shard)) + ("every pulse split over all ranks in interleaved 4096-index tiles" if args.shard == "rays" else "whole pulses, left-over pulses in interleaved 4096-index tiles") + "; one group-table all-gather + one cube all-reduce per interval",
-                       "host_numa_node": numa_node, "pulses_in_flight": len(trs), "linked": bool(args.link), "scene_setup_s": scene_setup_s,
+                       "host_numa_node": numa_node, "post_processing_call": "rts_trace_pulse_end_uniform" if (args.fused_post and hasattr(rts_amd._lib.lib(), "rts_trace_pulse_end_uniform")) else "rts_trace_pulse_end + rts_finalise_uniform + rts_cube_accumulate + rts_aggregate", "pulses_in_flight": len(trs), "linked": bool(args.link), "scene_setup_s": scene_setup_s,
                        "interval_tail_ms_rank0": acc["tail_ms"],
                        "host_ms_per_pulse_rank0": {k: v / max(acc["launches"], 1) for k, v in acc["host_ms"].items()},
                        "stage_ms_per_launch_rank0": {"scene_placement": ms_scene / launches, "trace": ms_trace / launches, "order+finalise+aggregate": ms_post / launches}},

@@ -241,6 +241,18 @@ int rts_get_all_rays(RtsHandle h, struct PerRayData* results, int32_t* targ_inte
 int rts_finalise_uniform(RtsHandle h, const double* rcs_per_target, double wavelength, double gt, double gr,
                          double carrier, double cspeed);
 
+/* One call instead of rts_trace_pulse_end + rts_finalise_uniform (+ rts_cube_accumulate when cube_pulse >= 0) + rts_aggregate, for a
+ * caller that needs no host callbacks between them (ray_tracer.cpp:1180-1285 with constant RCS / gains).  When the handle's previous
+ * pulse received few rays (at most 3 072 -- 1 536 with refraction chains or a (receiver, path) key beyond 31 bits) the whole chain is
+ * enqueued behind the trace WITHOUT waiting for its received count -- the kernels take it from the device -- and the call returns
+ * at once; the count, the statistics and the group table come home with the first call that asks for them (rts_received_count,
+ * rts_get_stats, rts_group_count, rts_get_groups, rts_get_received, ...; the handle's next rts_trace_pulse_begin at the latest).  A
+ * pulse that then turns out to have received more than the chain was sized for (4 096 / 2 048 rays) is post-processed again, the
+ * ordinary way, at that point.  Results are those of the four calls, bit for bit.  (Measured on an MI355X with ROCm 7: the
+ * submitting thread's wait for the trace disappears, the pulse rate does not change -- DESIGN.md section 5.) */
+int rts_trace_pulse_end_uniform(RtsHandle h, const double* rcs_per_target, double wavelength, double gt, double gr,
+                                double carrier, double cspeed, int32_t cube_pulse, uint64_t recv_index_base);
+
 /* rts_aggregate: myKernel1 + myKernel2 + unique paths (aggregation.cu:32-97,
  * ray_tracer.cpp:1283-1292) on the device-resident received set, as a sort/group-by.
  * recv_index_base offsets the received-list indices (multi-GPU with contiguous ranges: number of received

@@ -150,7 +150,7 @@ _lib = None
 # every symbol include/rts_amd.h declares
 EXPORTS = ["rts_create", "rts_destroy", "rts_last_error", "rts_device_count", "rts_set_scene", "rts_share_scene", "rts_scene_info", "rts_set_receivers",
            "rts_trace_pulse", "rts_reserve", "rts_trace_pulse_begin", "rts_trace_pulse_end", "rts_link_handles", "rts_get_stats", "rts_received_count", "rts_get_received", "rts_get_all_rays",
-           "rts_finalise_uniform", "rts_aggregate", "rts_group_count", "rts_get_groups", "rts_get_aggregated",
+           "rts_finalise_uniform", "rts_trace_pulse_end_uniform", "rts_aggregate", "rts_group_count", "rts_get_groups", "rts_get_aggregated",
            "rts_merge_groups", "rts_groups_to_responses", "rts_kernel_wrapper", "rts_vertex_rotation",
            "rts_rotation_matrix", "rts_rect_mesh", "rts_sphere_mesh", "rts_file_mesh", "rts_rx_sphere", "rts_get_bvh",
            "rts_build_id", "rts_bind_host_to_device", "rts_get_lane_stats", "rts_self_test_math", "rts_cube_attach", "rts_cube_accumulate", "rts_cube_get", "rts_cube_accumulate_paths", "rts_cube_doppler", "rts_cube_doppler_get", "rts_plan_cpi", "rts_cube_reduce", "rts_kernel_wrapper_on"]
@@ -185,6 +185,7 @@ def lib():
         "rts_get_all_rays": [vp, vp, vp, vp, vp, vp, u64],
         "rts_finalise_uniform": [vp, vp, dbl, dbl, dbl, dbl, dbl],
         "rts_aggregate": [vp, dbl, dbl, u64],
+        "rts_trace_pulse_end_uniform": [vp, vp, dbl, dbl, dbl, dbl, dbl, C.c_int32, u64],
         "rts_group_count": [vp, C.POINTER(u32)],
         "rts_get_groups": [vp, vp, u32],
         "rts_get_aggregated": [vp, vp, vp, vp, vp, u64],

@@ -208,6 +208,12 @@ class Tracer:
         r = np.ascontiguousarray(rcs_per_target, np.float64) if rcs_per_target is not None else None
         check(L.lib().rts_finalise_uniform(self.h, ptr(r), wavelength, gt, gr, carrier, cspeed))
 
+    def trace_end_uniform(self, rcs_per_target, wavelength, gt, gr, carrier, cspeed, cube_pulse=-1, recv_index_base=0):
+        """rts_trace_pulse_end + rts_finalise_uniform (+ rts_cube_accumulate) + rts_aggregate in one call that does not wait for the
+        trace when the handle's previous pulse received few rays; received_count() / stats() / groups() wait"""
+        r = np.ascontiguousarray(rcs_per_target, np.float64) if rcs_per_target is not None else None
+        check(L.lib().rts_trace_pulse_end_uniform(self.h, ptr(r), wavelength, gt, gr, carrier, cspeed, cube_pulse, recv_index_base))
+
     def aggregate(self, cspeed, carrier, recv_index_base=0, fetch=True):
         """fetch=False: only enqueue (the library reads the group table when it is first asked for: groups())"""
         check(L.lib().rts_aggregate(self.h, cspeed, carrier, recv_index_base))

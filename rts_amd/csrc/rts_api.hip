@@ -144,6 +144,7 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     e = hipStreamCreateWithPriority(&c->gate->tstream, hipStreamNonBlocking, prio_low);
     if (e != hipSuccess) { delete c->gate; (void)hipStreamDestroy(c->stream); delete c; rts_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return RTS_ERR_HIP; }
     c->tstream = c->gate->tstream;
+    e = hipEventCreateWithFlags(&c->ev_spec, hipEventDisableTiming); if (e != hipSuccess) { delete c; rts_set_error("hipEventCreate: %s", hipGetErrorString(e)); return RTS_ERR_HIP; }
     for (int i = 0; i < 2; i++) { e = hipEventCreateWithFlags(&c->ev_coop[i], hipEventDisableTiming); if (e != hipSuccess) { delete c; rts_set_error("hipEventCreate: %s", hipGetErrorString(e)); return RTS_ERR_HIP; } }
     for (int i = 0; i < 9; i++) { e = hipEventCreate(&c->ev[i]); if (e != hipSuccess) { delete c; rts_set_error("hipEventCreate: %s", hipGetErrorString(e)); return RTS_ERR_HIP; } }
     e = hipHostMalloc((void**)&c->pin, sizeof(RtsPinned), hipHostMallocDefault);
@@ -166,6 +167,8 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     { const char* e = getenv("RTS_SUM_IN_KERNEL"); if (e) c->sum_in_kernel = atoi(e) != 0; }
     { const char* e = getenv("RTS_SPIN_WAIT"); if (e) c->spin_wait = atoi(e) != 0; }
     { const char* e = getenv("RTS_TILE_SORT"); if (e) c->tile_bucket_order = strcmp(e, "radix") != 0; }
+    { const char* e = getenv("RTS_SPEC_STREAM"); if (e) c->spec_on_trace_stream = strcmp(e, "trace") == 0; }
+    { const char* e = getenv("RTS_SPECULATE"); if (e) c->spec_enabled = atoi(e) != 0; }
     { const char* e = getenv("RTS_POST_SMALL"); if (e) c->post_small = atoi(e) != 0; }
     { const char* e = getenv("RTS_ASYNC_IDLE0"); if (e) c->async_idle0 = (uint32_t)std::min(64, std::max(0, atoi(e))); }
     { const char* e = getenv("RTS_ASYNC_IDLE1"); if (e) c->async_idle1 = (uint32_t)std::min(64, std::max(1, atoi(e))); }
@@ -189,7 +192,7 @@ extern "C" int rts_destroy(RtsHandle c)
     if (!c) return RTS_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    if (c->pulse_open) { c->pulse_open = false; g_open_pulses[c->device & 63]--; }
+    if (c->pulse_open || c->spec_pending) { c->pulse_open = false; c->spec_pending = false; g_open_pulses[c->device & 63]--; }
     rts_comm_cache_forget(c);
     if (c->scene && --c->scene->refs == 0) { c->scene->release(); delete c->scene; }
     c->scene = nullptr;
@@ -206,6 +209,7 @@ extern "C" int rts_destroy(RtsHandle c)
     if (--c->gate->refs == 0) { (void)hipStreamDestroy(c->gate->tstream); delete c->gate; }
     if (c->pin) (void)hipHostFree(c->pin);
     for (int i = 0; i < 9; i++) (void)hipEventDestroy(c->ev[i]);
+    if (c->ev_spec) (void)hipEventDestroy(c->ev_spec);
     for (int i = 0; i < 2; i++) (void)hipEventDestroy(c->ev_coop[i]);
     if (c->cstream) { (void)hipStreamSynchronize(c->cstream); (void)hipStreamDestroy(c->cstream); }
     (void)hipStreamDestroy(c->stream);
@@ -215,7 +219,9 @@ extern "C" int rts_destroy(RtsHandle c)
 
 #define CHECK_HANDLE(c) do { if (!(c)) { rts_set_error("null handle"); return RTS_ERR_INVALID; } RTS_HIP(hipSetDevice((c)->device)); } while (0)
 // entry points that consume a pulse's results complete a pulse that was begun but not yet ended
-#define CHECK_CLOSED(c) do { if ((c)->pulse_open) { int rc_ = rts_trace_pulse_end(c); if (rc_ != RTS_OK) return rc_; } } while (0)
+static int rts_spec_resolve(RtsContext* c);
+#define CHECK_CLOSED(c) do { if ((c)->pulse_open) { int rc_ = rts_trace_pulse_end(c); if (rc_ != RTS_OK) return rc_; } \
+                             if ((c)->spec_pending) { int rc_ = rts_spec_resolve(c); if (rc_ != RTS_OK) return rc_; } } while (0)
 
 extern "C" int rts_link_handles(RtsHandle a, RtsHandle b)
 {
@@ -588,6 +594,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     CHECK_HANDLE(c);
     if (!p) { rts_set_error("rts_trace_pulse: null pulse"); return RTS_ERR_INVALID; }
     if (c->pulse_open) { rts_set_error("rts_trace_pulse_begin: the previous pulse of this handle was begun but not ended"); return RTS_ERR_INVALID; }
+    if (c->spec_pending) { int rc_ = rts_spec_resolve(c); if (rc_ != RTS_OK) return rc_; }
     const uint32_t W = c->params.width;
     const uint64_t total = (uint64_t)W * W * W;
     uint64_t first = p->ray_first, count = p->ray_count ? p->ray_count : (total > first ? total - first : 0);
@@ -769,6 +776,25 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
 }
 
 // Waits for the pulse begun on this handle, then orders + expands its received rays (left in flight).
+// counters of a finished launch -> the handle's statistics and the hints its next launch uses
+static void rts_pulse_account(RtsContext* c, const unsigned long long* cnt)
+{
+    const uint32_t n = c->n_rays;
+    RtsStats& s = c->stats;
+    s.rays = n; s.segments = cnt[1]; s.shaded = cnt[2]; s.received = cnt[0]; s.node_visits = cnt[3]; s.tri_tests = cnt[4]; s.stack_overflows = (uint32_t)cnt[5];
+    s.n_prims = c->scene->n_prims; s.n_nodes = c->scene->n_nodes;
+    c->pre_dense = 2 * s.shaded > (uint64_t)n;                      // next launch of this handle: pre-filter only if most launch indices hit nothing
+    {   // mean cost of a traced segment in this launch, in the units of the tile cost records (shader clocks >> 6 of one wave):
+        // kernel time x resident waves / segments -- the yardstick of the LONG WALKS flag of the next launch (rts_trace.hip)
+        float ms = 0.0f;
+        if (s.segments > 0 && hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess && ms > 0.0f)
+            c->last_units_per_segment = (double)ms * 1.0e-3 * (2.4e9 / 64.0) * (double)(c->last_args.total_threads / RTS_WTILE) / (double)s.segments;
+    }
+    s.ms_scene = s.ms_trace = s.ms_compact = s.ms_aggregate = 0;
+    c->stats_pending = true;
+    c->recv_hint = cnt[0]; c->recv_hint_valid = true;
+}
+
 extern "C" int rts_trace_pulse_end(RtsHandle c)
 {
     CHECK_HANDLE(c);
@@ -788,18 +814,8 @@ extern "C" int rts_trace_pulse_end(RtsHandle c)
     if (keep_all) { rc = rts_post_expand_all(c); if (rc != RTS_OK) return rc; }
     RTS_HIP(hipEventRecord(c->ev[5], st));
 
-    RtsStats& s = c->stats;
-    s.rays = n; s.segments = cnt[1]; s.shaded = cnt[2]; s.received = cnt[0]; s.node_visits = cnt[3]; s.tri_tests = cnt[4]; s.stack_overflows = (uint32_t)cnt[5];
-    s.n_prims = c->scene->n_prims; s.n_nodes = c->scene->n_nodes;
-    c->pre_dense = 2 * s.shaded > (uint64_t)n;                      // next launch of this handle: pre-filter only if most launch indices hit nothing
-    {   // mean cost of a traced segment in this launch, in the units of the tile cost records (shader clocks >> 6 of one wave):
-        // kernel time x resident waves / segments -- the yardstick of the LONG WALKS flag of the next launch (rts_trace.hip)
-        float ms = 0.0f;
-        if (s.segments > 0 && hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess && ms > 0.0f)
-            c->last_units_per_segment = (double)ms * 1.0e-3 * (2.4e9 / 64.0) * (double)(c->last_args.total_threads / RTS_WTILE) / (double)s.segments;
-    }
-    s.ms_scene = s.ms_trace = s.ms_compact = s.ms_aggregate = 0;
-    c->stats_pending = true; c->agg_timed = false; c->fin_timed = false;
+    c->agg_timed = false; c->fin_timed = false;
+    rts_pulse_account(c, cnt);
     return RTS_OK;
 }
 
@@ -887,10 +903,8 @@ extern "C" int rts_finalise_uniform(RtsHandle c, const double* rcs_per_target, d
     return RTS_OK;
 }
 
-extern "C" int rts_aggregate(RtsHandle c, double cspeed, double carrier, uint64_t recv_index_base)
+static int rts_aggregate_impl(RtsContext* c, double cspeed, double carrier, uint64_t recv_index_base)
 {
-    CHECK_HANDLE(c);
-    CHECK_CLOSED(c);
     const uint64_t R = c->n_recv;
     c->agg_pending.valid = false;                                       // (an unread table of an earlier call is dropped)
     c->groups.clear(); c->recv_index_base = recv_index_base;
@@ -911,9 +925,102 @@ extern "C" int rts_aggregate(RtsHandle c, double cspeed, double carrier, uint64_
     return RTS_OK;
 }
 
+extern "C" int rts_aggregate(RtsHandle c, double cspeed, double carrier, uint64_t recv_index_base)
+{
+    CHECK_HANDLE(c);
+    CHECK_CLOSED(c);
+    return rts_aggregate_impl(c, cspeed, carrier, recv_index_base);
+}
+
+// ------------------------------------------------------------------------------------- a pulse's post-processing without the host in it
+// rts_trace_pulse_end_uniform = rts_trace_pulse_end + rts_finalise_uniform (+ rts_cube_accumulate) + rts_aggregate for a caller that
+// needs no host callbacks between them ("device-side received count feeding the post kernels").  When the handle's
+// previous pulse received no more than 3/4 of what the one-block ordering kernels take (4 096 rays with 32-bit sort keys, 2 048 with
+// 64-bit ones) the whole chain is ENQUEUED behind the trace at once, sized for that capacity; its kernels read the received count the trace kernel left on the device and do nothing if it exceeds that
+// capacity.  The count, the statistics and the group table come home with the first call that asks (rts_received_count,
+// rts_get_stats, rts_group_count, ...; the handle's next rts_trace_pulse_begin at the latest): if the count did exceed the
+// capacity the chain is run again then, the ordinary way.  Otherwise -- no history yet, KEEP_ALL, a large received set -- the
+// call is the four calls it stands for.
+static int rts_post_chain(RtsContext* c)
+{
+    const RtsSpecParams& q = c->spec;
+    hipStream_t st = c->stream;
+    const bool keep_all = (c->params.flags & RTS_FLAG_KEEP_ALL_RAYS) != 0;
+    RTS_HIP(hipEventRecord(c->ev[4], st));
+    int rc = rts_post_order_and_expand(c); if (rc != RTS_OK) return rc;
+    if (keep_all) { rc = rts_post_expand_all(c); if (rc != RTS_OK) return rc; }
+    RTS_HIP(hipEventRecord(c->ev[5], st));
+    RTS_HIP(hipEventRecord(c->ev[6], st));
+    rc = rts_post_finalise(c, q.rcs.data(), q.wl, q.gt, q.gr, q.carrier, q.cspeed); if (rc != RTS_OK) return rc;
+    c->fin_timed = true; c->agg_valid = false;
+    if (q.cube_pulse >= 0) { rc = rts_cube_accumulate_device(c, (uint32_t)q.cube_pulse, q.cspeed, q.carrier); if (rc != RTS_OK) return rc; }
+    rc = rts_aggregate_impl(c, q.cspeed, q.carrier, q.base);
+    return rc;
+}
+
+static int rts_spec_resolve(RtsContext* c)
+{
+    if (!c->spec_pending) return RTS_OK;
+    c->spec_pending = false; g_open_pulses[c->device & 63]--;
+    RTS_HIP(hipSetDevice(c->device));
+    const unsigned long long* cnt = c->pin->cnt;
+    RTS_HIP(rts_stream_wait(c, c->stream));
+    if (cnt[6]) { rts_set_error("rts_trace_pulse: traversal stack overflow / malformed BVH guard tripped on %llu waves", cnt[6]); return RTS_ERR_HIP; }
+    c->n_recv = cnt[0]; c->n_head_hint = (uint32_t)cnt[7];
+    rts_pulse_account(c, cnt);
+    if (c->n_recv > c->spec_cap) {                                      // more rays than the speculative chain was sized for: it did nothing; the ordinary chain now
+        c->agg_pending.valid = false;
+        return rts_post_chain(c);
+    }
+    if (c->n_recv == 0) { c->agg_pending.valid = false; c->groups.clear(); c->agg_valid = true; return RTS_OK; }
+    c->agg_pending.R = (uint32_t)c->n_recv; c->agg_pending.spec = std::min<uint32_t>((uint32_t)c->n_recv, RTS_PIN_GROUPS);
+    return RTS_OK;
+}
+
+extern "C" int rts_trace_pulse_end_uniform(RtsHandle c, const double* rcs_per_target, double wavelength, double gt, double gr, double carrier, double cspeed,
+                                           int32_t cube_pulse, uint64_t recv_index_base)
+{
+    CHECK_HANDLE(c);
+    if (!c->pulse_open) { rts_set_error("rts_trace_pulse_end_uniform: no pulse in flight on this handle"); return RTS_ERR_INVALID; }
+    if (cube_pulse >= 0 && (!c->cube_set || (uint32_t)cube_pulse >= c->cube_params.n_pulses)) { rts_set_error("rts_trace_pulse_end_uniform: no cube attached, or pulse %d outside it", cube_pulse); return RTS_ERR_INVALID; }
+    RtsSpecParams& q = c->spec;
+    const size_t nt = c->scene->meshes.size();
+    q.rcs.assign(nt + 1, 1.0); if (rcs_per_target) for (size_t t = 0; t < nt; t++) q.rcs[t] = rcs_per_target[t];
+    q.wl = wavelength; q.gt = gt; q.gr = gr; q.carrier = carrier; q.cspeed = cspeed; q.cube_pulse = cube_pulse; q.base = recv_index_base;
+    const bool keep_all = (c->params.flags & RTS_FLAG_KEEP_ALL_RAYS) != 0;
+    {   // capacity of a speculative chain: the smaller of its two one-block sorts (row keys: 32 bits without refraction chains; (receiver, path) keys: D x B + RXB bits)
+        uint32_t B = 1; while (((uint64_t)1 << B) < (uint64_t)(c->scene->meshes.size() + 1)) B++;
+        uint32_t RXB = 1; while (((uint64_t)1 << RXB) < (uint64_t)std::max<uint32_t>(c->n_rx, 1u)) RXB++;
+        const uint32_t key_bits = (c->depth ? c->depth * B : 0u) + RXB;
+        c->spec_cap = (c->last_args.max_refr == 0 && key_bits < 32u) ? RTS_SMALL_CAP32 : RTS_SMALL_CAP64;
+    }
+    const bool speculate = c->post_small && c->spec_enabled && !keep_all && c->n_rays > 0 && c->recv_hint_valid && c->recv_hint <= ((uint64_t)c->spec_cap * 3ull) / 4ull;
+    if (!speculate) {
+        int rc = rts_trace_pulse_end(c); if (rc != RTS_OK) return rc;
+        return rts_post_chain(c);
+    }
+    c->pulse_open = false;                                              // (the pulse stays counted as open on its device until it is resolved)
+    c->spec_pending = true;
+    c->agg_timed = false; c->fin_timed = false;
+    c->n_recv = c->spec_cap; c->recv_dev = c->p_counters;              // sizes for the capacity, the count itself from the device
+    // ... on the TRACE stream, behind the trace kernel: enqueued on the handle's other stream -- which waits for the trace through
+    // an event -- every launch call of the chain blocked (0.22 ms per pulse in the submitting thread)
+    int rc;
+    if (c->spec_on_trace_stream) {
+        hipStream_t own = c->stream; c->stream = c->tstream;
+        rc = rts_post_chain(c);
+        RTS_HIP(hipEventRecord(c->ev_spec, c->tstream)); c->stream = own;
+        RTS_HIP(hipStreamWaitEvent(c->stream, c->ev_spec, 0));          // (what the handle enqueues next on its own stream comes after the chain)
+    } else rc = rts_post_chain(c);                                      // (the handle's own stream already waits for the trace: rts_trace_pulse_begin)
+    c->recv_dev = nullptr; c->n_recv = 0;
+    if (rc != RTS_OK) { c->spec_pending = false; g_open_pulses[c->device & 63]--; return rc; }
+    return RTS_OK;
+}
+
 extern "C" int rts_group_count(RtsHandle c, uint32_t* count)
 {
     if (!c || !count) { rts_set_error("rts_group_count: null argument"); return RTS_ERR_INVALID; }
+    CHECK_CLOSED(c);
     if (!c->agg_valid) { rts_set_error("rts_group_count: call rts_aggregate first"); return RTS_ERR_INVALID; }
     { int rc = rts_aggregate_fetch(c, &c->groups); if (rc != RTS_OK) return rc; }
     *count = (uint32_t)c->groups.size(); return RTS_OK;
@@ -922,6 +1029,7 @@ extern "C" int rts_group_count(RtsHandle c, uint32_t* count)
 extern "C" int rts_get_groups(RtsHandle c, RtsGroup* groups, uint32_t capacity)
 {
     if (!c || (!groups && capacity)) { rts_set_error("rts_get_groups: null argument"); return RTS_ERR_INVALID; }
+    CHECK_CLOSED(c);
     if (!c->agg_valid) { rts_set_error("rts_get_groups: call rts_aggregate first"); return RTS_ERR_INVALID; }
     { int rc = rts_aggregate_fetch(c, &c->groups); if (rc != RTS_OK) return rc; }
     if (capacity < c->groups.size()) { rts_set_error("rts_get_groups: capacity too small"); return RTS_ERR_CAPACITY; }
@@ -932,6 +1040,7 @@ extern "C" int rts_get_groups(RtsHandle c, RtsGroup* groups, uint32_t capacity)
 extern "C" int rts_get_aggregated(RtsHandle c, PerRayData* rays, double* delay, double* phase, int32_t* path_match, uint64_t capacity)
 {
     CHECK_HANDLE(c);
+    CHECK_CLOSED(c);
     if (!c->agg_valid) { rts_set_error("rts_get_aggregated: call rts_aggregate first"); return RTS_ERR_INVALID; }
     const uint64_t R = c->n_recv;
     if (capacity < R) { rts_set_error("rts_get_aggregated: capacity too small"); return RTS_ERR_CAPACITY; }
@@ -994,6 +1103,7 @@ extern "C" int rts_cube_doppler(RtsHandle c, uint32_t n_fft, void* device_out)
 extern "C" int rts_cube_doppler_get(RtsHandle c, double* host_out, uint64_t capacity_doubles)
 {
     CHECK_HANDLE(c);
+    CHECK_CLOSED(c);
     if (!c->cube_set || !c->doppler || !host_out) { rts_set_error("rts_cube_doppler_get: no transform (rts_cube_doppler) / null output"); return RTS_ERR_INVALID; }
     const size_t doubles = 2 * (size_t)c->cube_params.n_rx * c->doppler_n * c->cube_params.n_bins;
     if (capacity_doubles < doubles) { rts_set_error("rts_cube_doppler_get: capacity too small"); return RTS_ERR_CAPACITY; }
@@ -1005,6 +1115,7 @@ extern "C" int rts_cube_doppler_get(RtsHandle c, double* host_out, uint64_t capa
 extern "C" int rts_cube_get(RtsHandle c, double* host_out, uint64_t capacity_doubles)
 {
     CHECK_HANDLE(c);
+    CHECK_CLOSED(c);
     if (!c->cube_set || !host_out) { rts_set_error("rts_cube_get: no cube / null output"); return RTS_ERR_INVALID; }
     const size_t doubles = 2 * (size_t)c->cube_params.n_rx * c->cube_params.n_pulses * c->cube_params.n_bins;
     if (capacity_doubles < doubles) { rts_set_error("rts_cube_get: capacity too small"); return RTS_ERR_CAPACITY; }

@@ -240,6 +240,9 @@ struct RtsScene {
                      d_verts_local.release(); d_normals_local.release(); d_nodes4.release(); d_leaf_prim.release(); }
 };
 
+#define RTS_SMALL_CAP32 4096u         // received rays the one-block ordering kernels take with 32-bit sort keys (rts_post.hip) ...
+#define RTS_SMALL_CAP64 2048u         // ... and with 64-bit keys; a speculatively enqueued post-processing chain is sized for the smaller of its two sorts
+struct RtsSpecParams { std::vector<double> rcs; double wl = 0, gt = 0, gr = 0, carrier = 0, cspeed = 0; int32_t cube_pulse = -1; uint64_t base = 0; };
 // rts_aggregate enqueues; the table is read (stream wait + pinned block -> RtsGroup records) by the first call that needs it
 struct RtsAggPending { bool valid = false, wide = false, rows = false; uint32_t R = 0, D = 0, B = 0, shift = 0, spec = 0; uint64_t base = 0; double* gsum = nullptr; };
 
@@ -300,6 +303,10 @@ struct RtsContext {
     bool spin_wait = true;              // the pulse's two host waits poll the stream instead of blocking (rts_stream_wait; RTS_SPIN_WAIT=0)
     bool tile_bucket_order = true;      // tile order by counting bins instead of a radix sort (RTS_TILE_SORT=radix: the sort)
     bool post_small = true;             // received sets of up to 4096 rays are ordered / finished by single blocks (RTS_POST_SMALL=0: the general chain)
+    hipEvent_t ev_spec = nullptr; uint32_t spec_cap = RTS_SMALL_CAP64; bool spec_on_trace_stream = false;      // (RTS_SPEC_STREAM=trace: the speculative chain behind the trace kernel on ITS stream)
+    RtsSpecParams spec; bool spec_pending = false, spec_enabled = true;      // rts_trace_pulse_end_uniform: parameters of the chain; a chain enqueued on the device-side count awaits its resolution (RTS_SPECULATE=0: never)
+    const unsigned long long* recv_dev = nullptr;                           // != nullptr while such a chain is being enqueued: its kernels take the received count from here
+    uint64_t recv_hint = 0; bool recv_hint_valid = false;                    // received rays of the handle's previous pulse
     RtsAggPending agg_pending;          // the group table of the last rts_aggregate is still on its way (rts_aggregate_fetch reads it)
     RtsCubeParams cube_params; double* cube = nullptr; DevBuf<double> d_cube_own; bool cube_set = false;
     DevBuf<double> d_doppler_own; double* doppler = nullptr; uint32_t doppler_n = 0;       // slow-time transform of the cube (rts_cube_doppler)

@@ -11,10 +11,13 @@
 #include "rts_raygen.h"
 
 static inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
-#define RTS_SMALL_SORT 2048          // received sets up to this size: single-block ordering / finishing kernels (see k_agg_order_small)
+static inline uint32_t rts_small_cap_recv(const RtsContext* c) { return c->last_args.max_refr == 0 ? RTS_SMALL_CAP32 : RTS_SMALL_CAP64; }
+// received sets up to this size: single-block ordering / finishing kernels (see k_agg_order_small) -- 4 096 rays when the sort
+// keys fit 32 bits (no refraction chains in the row key; a (receiver, path) key of <= 31 bits), 2 048 with 64-bit keys: the
+// block's sort storage has to stay below the 40 KB of a free block slot
 #define RTS_SMALL_THREADS 256
-#define RTS_SMALL_ITEMS (RTS_SMALL_SORT / RTS_SMALL_THREADS)
-__global__ void k_recv_order_small(const RtsEndRecord* __restrict__ rec, uint32_t n, uint32_t n_rays, int with_chain, uint32_t bits, uint32_t* __restrict__ perm);
+static_assert(RTS_SMALL_CAP32 == 16 * RTS_SMALL_THREADS && RTS_SMALL_CAP64 == 8 * RTS_SMALL_THREADS, "items per thread of the one-block sorts");
+template <typename K, int ITEMS> __global__ void k_recv_order_small(const RtsEndRecord* __restrict__ rec, uint32_t n, uint32_t n_rays, int with_chain, uint32_t bits, uint32_t* __restrict__ perm, const unsigned long long* __restrict__ R_dev);
 
 // --------------------------------------------------------------------------- record expansion
 // received rays are ordered as the reference's host scan meets them (ray_tracer.cpp:1190): ascending buffer
@@ -47,9 +50,10 @@ __device__ __forceinline__ void put_angle(double* angles, size_t row, uint32_t D
 // One thread per output row j.  perm != nullptr: row j is received record perm[j].  perm == nullptr: the full
 // buffers of the reference (keep-all): row j = chain * n + slot for chain < rows, rec = all_records.
 __global__ void k_expand(const RtsTraceArgs a, const RtsEndRecord* __restrict__ rec, const uint32_t* __restrict__ perm, uint32_t n_out, uint32_t D,
-                         PerRayData* __restrict__ rays, int32_t* __restrict__ paths, double* __restrict__ angles, uint64_t* __restrict__ slots)
+                         PerRayData* __restrict__ rays, int32_t* __restrict__ paths, double* __restrict__ angles, uint64_t* __restrict__ slots, const unsigned long long* __restrict__ R_dev)
 {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    { uint32_t R = n_out; if (R_dev) { const unsigned long long v_ = *R_dev; if (v_ > (unsigned long long)R) return; R = (uint32_t)v_; } n_out = R; }
     if (j >= n_out) return;
     RtsEndRecord r; bool valid = true; uint32_t chain, slot, prefill_code = 0;
     if (perm) { r = rec[perm[j]]; chain = r.pad & 3u; slot = r.slot; }
@@ -265,8 +269,9 @@ int rts_post_order_and_expand(RtsContext* c)
     RTS_HIP(c->d_ri.reserve(R)); RTS_HIP(c->d_ri_sorted.reserve(R));
     RTS_HIP(c->d_rx_rays.reserve(R)); RTS_HIP(c->d_rx_paths.reserve((size_t)R*D + 1)); RTS_HIP(c->d_rx_angles.reserve((size_t)R*D*2 + 1)); RTS_HIP(c->d_rx_slots.reserve(R));
     size_t tmp = 0;
-    if (c->post_small && R <= RTS_SMALL_SORT) {
-        k_recv_order_small<<<1, RTS_SMALL_THREADS, 0, st>>>(c->d_recv.p, R, c->n_rays, c->last_args.max_refr != 0 ? 1 : 0, c->last_args.max_refr != 0 ? 34u : 32u, c->d_ri_sorted.p);
+    if (c->post_small && R <= rts_small_cap_recv(c)) {
+        if (c->last_args.max_refr == 0) k_recv_order_small<uint32_t, 16><<<1, RTS_SMALL_THREADS, 0, st>>>(c->d_recv.p, R, c->n_rays, 0, 32u, c->d_ri_sorted.p, c->recv_dev);
+        else k_recv_order_small<uint64_t, 8><<<1, RTS_SMALL_THREADS, 0, st>>>(c->d_recv.p, R, c->n_rays, 1, 34u, c->d_ri_sorted.p, c->recv_dev);
         RTS_STAGE(c, "recv order (one block)");
     } else if (c->last_args.max_refr == 0) {
         RTS_HIP(c->d_rk.reserve(R)); RTS_HIP(c->d_rk_sorted.reserve(R));
@@ -283,7 +288,7 @@ int rts_post_order_and_expand(RtsContext* c)
         RTS_HIP(rocprim::radix_sort_pairs(c->d_sort_tmp.p, tmp, c->d_rk64.p, c->d_rk64_sorted.p, c->d_ri.p, c->d_ri_sorted.p, R, 0, 34, st));
     }
     RTS_STAGE(c, "recv sort");
-    k_expand<<<blocks_for(R, 256), 256, 0, st>>>(c->last_args, c->d_recv.p, c->d_ri_sorted.p, R, D, c->d_rx_rays.p, c->d_rx_paths.p, c->d_rx_angles.p, c->d_rx_slots.p);
+    k_expand<<<blocks_for(R, 256), 256, 0, st>>>(c->last_args, c->d_recv.p, c->d_ri_sorted.p, R, D, c->d_rx_rays.p, c->d_rx_paths.p, c->d_rx_angles.p, c->d_rx_slots.p, c->recv_dev);
     RTS_STAGE(c, "k_expand");
     RTS_HIP(hipGetLastError());
     return RTS_OK;
@@ -296,16 +301,17 @@ int rts_post_expand_all(RtsContext* c)
     if (n64 > 0xffffffffULL) { rts_set_error("keep-all buffers: rows * rays exceeds 2^32"); return RTS_ERR_UNSUPPORTED; }
     const uint32_t n = (uint32_t)n64;
     RTS_HIP(c->d_all_rays.reserve(n)); RTS_HIP(c->d_all_paths.reserve((size_t)n*D + 1)); RTS_HIP(c->d_all_angles.reserve((size_t)n*D*2 + 1));
-    k_expand<<<blocks_for(n, 256), 256, 0, c->stream>>>(c->last_args, c->d_all.p, nullptr, n, D, c->d_all_rays.p, c->d_all_paths.p, c->d_all_angles.p, nullptr);
+    k_expand<<<blocks_for(n, 256), 256, 0, c->stream>>>(c->last_args, c->d_all.p, nullptr, n, D, c->d_all_rays.p, c->d_all_paths.p, c->d_all_angles.p, nullptr, nullptr);
     RTS_HIP(hipGetLastError());
     return RTS_OK;
 }
 
 // --------------------------------------------------------------------------- uniform finalisation, ray_tracer.cpp:1219-1253
 __global__ void k_finalise(PerRayData* __restrict__ rays, const int32_t* __restrict__ paths, uint32_t R, uint32_t D,
-                           const double* __restrict__ rcs, uint32_t n_targets, double wl, double gt, double gr, double carrier, double cspeed)
+                           const double* __restrict__ rcs, uint32_t n_targets, double wl, double gt, double gr, double carrier, double cspeed, const unsigned long long* __restrict__ R_dev)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (R_dev) { const unsigned long long v_ = *R_dev; if (v_ > (unsigned long long)R) return; R = (uint32_t)v_; }      // (speculative post-processing: the count is the trace kernel's, on the device; more than the caller's capacity: nothing is done here)
     if (i >= R) return;
     double power = rays[i].power;
     for (uint32_t k = 0; k < D; k++) {
@@ -332,7 +338,7 @@ int rts_post_finalise(RtsContext* c, const double* rcs_host, double wl, double g
         if (nt) RTS_HIP(hipMemcpyAsync(c->d_rcsval.p, c->pin->rcs, sizeof(double)*nt, hipMemcpyHostToDevice, c->stream));
         c->rcs_uploaded = true;
     }
-    k_finalise<<<blocks_for(R, 256), 256, 0, c->stream>>>(c->d_rx_rays.p, c->d_rx_paths.p, R, c->depth, c->d_rcsval.p, nt, wl, gt, gr, carrier, cspeed);
+    k_finalise<<<blocks_for(R, 256), 256, 0, c->stream>>>(c->d_rx_rays.p, c->d_rx_paths.p, R, c->depth, c->d_rcsval.p, nt, wl, gt, gr, carrier, cspeed, c->recv_dev);
     RTS_HIP(hipGetLastError());
     return RTS_OK;
 }
@@ -340,9 +346,10 @@ int rts_post_finalise(RtsContext* c, const double* rcs_host, double wl, double g
 // --------------------------------------------------------------------------- complex return cube
 // one lane per received ray, two f64 atomics (global_atomic_add_f64) into cube[rx][pulse][bin]
 __global__ void k_cube_accumulate(const PerRayData* __restrict__ rays, uint32_t R, double* __restrict__ cube, uint32_t n_rx, uint32_t n_pulses,
-                                  uint32_t n_bins, uint32_t pulse, double t0, double dt, double cspeed, double carrier)
+                                  uint32_t n_bins, uint32_t pulse, double t0, double dt, double cspeed, double carrier, const unsigned long long* __restrict__ R_dev)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (R_dev) { const unsigned long long v_ = *R_dev; if (v_ > (unsigned long long)R) return; R = (uint32_t)v_; }      // (speculative post-processing: the count is the trace kernel's, on the device; more than the caller's capacity: nothing is done here)
     if (i >= R) return;
     const PerRayData r = rays[i];
     if (r.received < 0 || (uint32_t)r.received >= n_rx) return;
@@ -361,7 +368,7 @@ int rts_cube_accumulate_device(RtsContext* c, uint32_t pulse_index, double cspee
     const uint32_t R = (uint32_t)c->n_recv;
     if (R == 0) return RTS_OK;
     const RtsCubeParams& q = c->cube_params;
-    k_cube_accumulate<<<blocks_for(R, 256), 256, 0, c->stream>>>(c->d_rx_rays.p, R, c->cube, q.n_rx, q.n_pulses, q.n_bins, pulse_index, q.t0, q.dt, cspeed, carrier);
+    k_cube_accumulate<<<blocks_for(R, 256), 256, 0, c->stream>>>(c->d_rx_rays.p, R, c->cube, q.n_rx, q.n_pulses, q.n_bins, pulse_index, q.t0, q.dt, cspeed, carrier, c->recv_dev);
     RTS_HIP(hipGetLastError());
     return RTS_OK;
 }
@@ -526,8 +533,9 @@ __global__ void k_agg_starts(const uint32_t* __restrict__ head, const uint32_t* 
 // the f64 sums are reproducible run to run.  vals: 5 doubles {n, sqrt(power), delay, phase, doppler}.
 __global__ void __launch_bounds__(AGG_TILE) k_agg_tiles(const PerRayData* __restrict__ rays, const uint32_t* __restrict__ idx_sorted,
         const uint32_t* __restrict__ gid_incl, const uint32_t* __restrict__ gstart, uint32_t R, double cspeed, double carrier,
-        double* __restrict__ gsum, double* __restrict__ tile_first, double* __restrict__ tile_last)
+        double* __restrict__ gsum, double* __restrict__ tile_first, double* __restrict__ tile_last, const unsigned long long* __restrict__ R_dev)
 {
+    if (R_dev) { const unsigned long long v_ = *R_dev; if (v_ > (unsigned long long)R) return; R = (uint32_t)v_; }      // (speculative post-processing: the count is the trace kernel's, on the device; more than the caller's capacity: nothing is done here)
     __shared__ double s_v[2][5][AGG_TILE];
     __shared__ uint32_t s_g[AGG_TILE];
     const uint32_t t = threadIdx.x, tile = blockIdx.x, i = tile * AGG_TILE + t;
@@ -701,55 +709,61 @@ __global__ void k_agg_export(const uint32_t* __restrict__ d_G, const double* __r
 // A BASELINE configs[2] pulse receives ~2 000 rays.  Sorted, scanned and reduced by library calls sized for millions of
 // elements that is ~27 launches of a few microseconds each -- which, among the blocks of the neighbouring pulses' trace
 // kernels, each wait their turn: 0.35 ms of dependent launches per pulse, in the submitting thread's loop.  Up to
-// RTS_SMALL_SORT rays one block does the ordering (keys, a block-wide radix sort of (key, index) pairs -- stable, as the
+// RTS_SMALL_CAP32 / RTS_SMALL_CAP64 rays one block does the ordering (keys, a block-wide radix sort of (key, index) pairs -- stable, as the
 // device-wide one --, head flags, scan, group starts) and one block the tail of the aggregation
 // (spans, group table, receiver totals, the scatter back to the rays, the export): the SAME statements as the kernels above
 // (their bodies are shared), the tile sums in between unchanged, so every sum is the same bits whichever path ran.
 // (one block of 256 threads and < 40 KB of LDS: it has to fit the block slot a trace launch leaves free on a CU -- a first
 // version with 1 024 threads and 56 KB waited for a CU to drain and made the pulse slower, 0.72 against 0.63 ms)
-typedef rocprim::block_radix_sort<uint64_t, RTS_SMALL_THREADS, RTS_SMALL_ITEMS, uint32_t> RtsSmallSort;
 
 // received rays in ascending buffer row (k_recv_keys / k_recv_keys64 + the sort): perm[j] = record of output row j
-__global__ void __launch_bounds__(RTS_SMALL_THREADS) k_recv_order_small(const RtsEndRecord* __restrict__ rec, uint32_t n, uint32_t n_rays, int with_chain, uint32_t bits, uint32_t* __restrict__ perm)
+template <typename K, int ITEMS>
+__global__ void __launch_bounds__(RTS_SMALL_THREADS) k_recv_order_small(const RtsEndRecord* __restrict__ rec, uint32_t n, uint32_t n_rays, int with_chain, uint32_t bits, uint32_t* __restrict__ perm, const unsigned long long* __restrict__ R_dev)
 {
-    __shared__ RtsSmallSort::storage_type s_sort;
-    uint64_t k[RTS_SMALL_ITEMS]; uint32_t v[RTS_SMALL_ITEMS];
-    for (uint32_t j = 0; j < RTS_SMALL_ITEMS; j++) {
-        const uint32_t i = threadIdx.x * RTS_SMALL_ITEMS + j;
-        k[j] = i < n ? (with_chain ? (uint64_t)(rec[i].pad & 3u) * n_rays + rec[i].slot : (uint64_t)rec[i].slot) : (1ULL << bits) - 1ULL;      // (padding sorts last: no key is that large)
-        v[j] = i;
+    typedef rocprim::block_radix_sort<K, RTS_SMALL_THREADS, ITEMS, uint32_t> Sort;
+    { uint32_t R = n; bool skip = false; if (R_dev) { const unsigned long long v_ = *R_dev; if (v_ > (unsigned long long)R) skip = true; else R = (uint32_t)v_; } if (skip) return; n = R; }
+    __shared__ typename Sort::storage_type s_sort;
+    K k[ITEMS]; uint32_t v[ITEMS];
+    for (uint32_t j = 0; j < ITEMS; j++) {
+        const uint32_t i = threadIdx.x * ITEMS + j;
+        const unsigned long long key = i < n ? (with_chain ? (unsigned long long)(rec[i].pad & 3u) * n_rays + rec[i].slot : (unsigned long long)rec[i].slot) : (1ULL << bits) - 1ULL;      // (padding sorts last: no key is that large)
+        k[j] = (K)key; v[j] = i;
     }
-    RtsSmallSort().sort(k, v, s_sort, 0, bits);
-    for (uint32_t j = 0; j < RTS_SMALL_ITEMS; j++) { const uint32_t i = threadIdx.x * RTS_SMALL_ITEMS + j; if (i < n) perm[i] = v[j]; }
+    Sort().sort(k, v, s_sort, 0, bits);
+    for (uint32_t j = 0; j < ITEMS; j++) { const uint32_t i = threadIdx.x * ITEMS + j; if (i < n) perm[i] = v[j]; }
 }
 
 // k_agg_keys + sort + k_agg_heads + inclusive scan + k_agg_starts
+template <typename K, int ITEMS>
 __global__ void __launch_bounds__(RTS_SMALL_THREADS) k_agg_order_small(const PerRayData* __restrict__ rays, const int32_t* __restrict__ paths, uint32_t R, uint32_t D, uint32_t B, uint32_t key_bits,
                                                                        uint64_t* __restrict__ keys_sorted, uint32_t* __restrict__ idx_sorted, uint32_t* __restrict__ head,
-                                                                       uint32_t* __restrict__ gid_incl, uint32_t* __restrict__ gstart)
+                                                                       uint32_t* __restrict__ gid_incl, uint32_t* __restrict__ gstart, const unsigned long long* __restrict__ R_dev)
 {
-    __shared__ RtsSmallSort::storage_type s_sort;
-    __shared__ uint64_t s_last[RTS_SMALL_THREADS]; __shared__ uint32_t s_sum[2][RTS_SMALL_THREADS];
-    uint64_t k[RTS_SMALL_ITEMS]; uint32_t v[RTS_SMALL_ITEMS];
-    const uint32_t i0 = threadIdx.x * RTS_SMALL_ITEMS;
-    for (uint32_t j = 0; j < RTS_SMALL_ITEMS; j++) {
+    typedef rocprim::block_radix_sort<K, RTS_SMALL_THREADS, ITEMS, uint32_t> Sort;
+    if (R_dev) { const unsigned long long v_ = *R_dev; if (v_ > (unsigned long long)R) return; R = (uint32_t)v_; }      // (speculative post-processing: the count is the trace kernel's, on the device; more than the caller's capacity: nothing is done here)
+    __shared__ typename Sort::storage_type s_sort;
+    __shared__ K s_last[RTS_SMALL_THREADS]; __shared__ uint32_t s_sum[2][RTS_SMALL_THREADS];
+    K k[ITEMS]; uint32_t v[ITEMS];
+    const uint32_t i0 = threadIdx.x * ITEMS;
+    const uint32_t sort_bits = key_bits < 8u * (uint32_t)sizeof(K) ? key_bits + 1u : 8u * (uint32_t)sizeof(K);
+    for (uint32_t j = 0; j < ITEMS; j++) {
         const uint32_t i = i0 + j;
-        uint64_t key = key_bits < 64u ? 1ULL << key_bits : ~0ULL;       // (padding: one bit above every real key -- or, with 64-bit keys, equal to the largest at worst: the sort is stable and padding has the larger indices)
+        unsigned long long key = key_bits < 64u ? 1ULL << key_bits : ~0ULL;       // (padding: one bit above every real key -- or, with keys that fill the word, equal to the largest at worst: the sort is stable and padding has the larger indices)
         if (i < R) {
             key = 0;
-            for (uint32_t c = 0; c < D; c++) key |= (uint64_t)(uint32_t)(paths[(size_t)i*D + c] + 1) << (c*B);
-            key |= (uint64_t)(uint32_t)rays[i].received << (D*B);
+            for (uint32_t c = 0; c < D; c++) key |= (unsigned long long)(uint32_t)(paths[(size_t)i*D + c] + 1) << (c*B);
+            key |= (unsigned long long)(uint32_t)rays[i].received << (D*B);
         }
-        k[j] = key; v[j] = i;
+        k[j] = (K)key; v[j] = i;
     }
     // (stable: equal keys keep their index order, as after the radix sort of the general path)
-    RtsSmallSort().sort(k, v, s_sort, 0, key_bits < 64u ? key_bits + 1u : 64u);
+    Sort().sort(k, v, s_sort, 0, sort_bits);
     // head flags and their inclusive scan: thread t owns the sorted elements [t c, (t + 1) c)
-    s_last[threadIdx.x] = k[RTS_SMALL_ITEMS - 1];
+    s_last[threadIdx.x] = k[ITEMS - 1];
     __syncthreads();
-    uint64_t prev = threadIdx.x ? s_last[threadIdx.x - 1] : 0ULL;
-    uint32_t h[RTS_SMALL_ITEMS], local = 0;
-    for (uint32_t j = 0; j < RTS_SMALL_ITEMS; j++) {
+    K prev = threadIdx.x ? s_last[threadIdx.x - 1] : (K)0;
+    uint32_t h[ITEMS], local = 0;
+    for (uint32_t j = 0; j < ITEMS; j++) {
         const uint32_t i = i0 + j;
         h[j] = (i < R && (i == 0 || k[j] != prev)) ? 1u : 0u; local += h[j]; prev = k[j];
     }
@@ -763,11 +777,11 @@ __global__ void __launch_bounds__(RTS_SMALL_THREADS) k_agg_order_small(const Per
         __syncthreads();
     }
     uint32_t run = s_sum[cur][threadIdx.x] - local;                 // groups that start before this thread's elements
-    for (uint32_t j = 0; j < RTS_SMALL_ITEMS; j++) {
+    for (uint32_t j = 0; j < ITEMS; j++) {
         const uint32_t i = i0 + j;
         if (i >= R) break;
         run += h[j];
-        keys_sorted[i] = k[j]; idx_sorted[i] = v[j]; head[i] = h[j]; gid_incl[i] = run;
+        keys_sorted[i] = (uint64_t)k[j]; idx_sorted[i] = v[j]; head[i] = h[j]; gid_incl[i] = run;
         if (h[j]) gstart[run - 1] = i;
         if (i == R - 1) gstart[run] = R;
     }
@@ -780,8 +794,15 @@ __global__ void __launch_bounds__(256) k_agg_finish_small(PerRayData* __restrict
         uint32_t shift, uint32_t n_rx_tab, double* __restrict__ rxtot, uint32_t* __restrict__ rxmin, int64_t base,
         const double* __restrict__ npath0, const double* __restrict__ power0, const double* __restrict__ doppler0, double* __restrict__ delay, double* __restrict__ phase,
         int32_t* __restrict__ pm, int32_t pm_init_const, int use_pm_in, int dly_in,
-        uint32_t spec, uint32_t* __restrict__ h_G, double* __restrict__ h_gsum, uint32_t* __restrict__ h_gmin, uint64_t* __restrict__ h_gkey, uint64_t* __restrict__ h_grow)
+        uint32_t spec, uint32_t* __restrict__ h_G, double* __restrict__ h_gsum, uint32_t* __restrict__ h_gmin, uint64_t* __restrict__ h_gkey, uint64_t* __restrict__ h_grow,
+        const unsigned long long* __restrict__ R_dev)
 {
+    if (R_dev) {
+        const unsigned long long v_ = *R_dev;
+        if (v_ > (unsigned long long)R) return;
+        R = (uint32_t)v_; ntiles = (R + AGG_TILE - 1) / AGG_TILE; spec = min(spec, R);
+        if (R == 0u) { if (h_G && threadIdx.x == 0) *h_G = 0u; return; }
+    }
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     for (uint32_t T0 = wave; T0 < ntiles; T0 += n_waves) agg_span_body(T0, lane, gstart, gid_incl, R, tile_first, tile_last, gsum);
     __syncthreads();
@@ -832,9 +853,10 @@ int rts_aggregate_device(RtsContext* c, int32_t max_path, int32_t max_rx, const 
     double* gsum = c->d_gsum.p; double* tile_first = gsum + 5*(size_t)R; double* tile_last = tile_first + 5*(size_t)ntiles;
     double* d_rxtot = c->d_rcs.p; uint32_t* d_rxmin = (uint32_t*)(c->d_rcs.p + 5*(size_t)n_rx_tab);
     size_t tmp = 0;
-    const bool small = c->post_small && !wide && R <= RTS_SMALL_SORT;       // one block orders, one block finishes (see k_agg_order_small)
+    const bool small = c->post_small && !wide && R <= (key_bits < 32u ? RTS_SMALL_CAP32 : RTS_SMALL_CAP64);       // one block orders, one block finishes (see k_agg_order_small)
     if (small) {
-        k_agg_order_small<<<1, RTS_SMALL_THREADS, 0, st>>>(d_rays, d_paths, R, D, B, key_bits, c->d_akeys_sorted.p, c->d_aidx_sorted.p, c->d_ghead.p, c->d_gid.p, gstart);
+        if (key_bits < 32u) k_agg_order_small<uint32_t, 16><<<1, RTS_SMALL_THREADS, 0, st>>>(d_rays, d_paths, R, D, B, key_bits, c->d_akeys_sorted.p, c->d_aidx_sorted.p, c->d_ghead.p, c->d_gid.p, gstart, c->recv_dev);
+        else k_agg_order_small<uint64_t, 8><<<1, RTS_SMALL_THREADS, 0, st>>>(d_rays, d_paths, R, D, B, key_bits, c->d_akeys_sorted.p, c->d_aidx_sorted.p, c->d_ghead.p, c->d_gid.p, gstart, c->recv_dev);
     } else if (!wide) {
         k_agg_keys<<<blocks_for(R, 256), 256, 0, st>>>(d_rays, d_paths, R, D, B, c->d_akeys.p, c->d_aidx.p);
         RTS_HIP(rocprim::radix_sort_pairs(nullptr, tmp, c->d_akeys.p, c->d_akeys_sorted.p, c->d_aidx.p, c->d_aidx_sorted.p, R, 0, key_bits, st));
@@ -862,14 +884,14 @@ int rts_aggregate_device(RtsContext* c, int32_t max_path, int32_t max_rx, const 
         RTS_HIP(rocprim::inclusive_scan(c->d_sort_tmp.p, tmp, c->d_ghead.p, c->d_gid.p, R, rocprim::plus<uint32_t>(), st));
         k_agg_starts<<<blocks_for(R, 256), 256, 0, st>>>(c->d_ghead.p, c->d_gid.p, gstart, R);
     }
-    k_agg_tiles<<<ntiles, AGG_TILE, 0, st>>>(d_rays, c->d_aidx_sorted.p, c->d_gid.p, gstart, R, cspeed, carrier, gsum, tile_first, tile_last);
+    k_agg_tiles<<<ntiles, AGG_TILE, 0, st>>>(d_rays, c->d_aidx_sorted.p, c->d_gid.p, gstart, R, cspeed, carrier, gsum, tile_first, tile_last, c->recv_dev);
     if (small) {
         RtsPinned* pd = c->pin_dev;
         const uint32_t spec_s = std::min<uint32_t>(R, RTS_PIN_GROUPS);
         k_agg_finish_small<<<1, 256, 0, st>>>(d_rays, c->d_aidx_sorted.p, c->d_akeys_sorted.p, c->d_gid.p, gstart, R, ntiles, tile_first, tile_last, gsum, c->d_gmin.p, c->d_gkey.p, d_G,
                                               d_rows, d_rows ? c->d_grow.p : nullptr, shift, n_rx_tab, d_rxtot, d_rxmin, (int64_t)base, d_npath, d_power_sum, d_doppler_sum, d_delay, d_phase, d_pm,
                                               pm_init, pm_init == INT32_MIN ? 1 : 0, c->agg_delay_in ? 1 : 0,
-                                              spec_s, groups ? &pd->G : nullptr, pd->gsum, pd->gmin, pd->gkey, pd->grow);
+                                              spec_s, groups ? &pd->G : nullptr, pd->gsum, pd->gmin, pd->gkey, pd->grow, c->recv_dev);
         RTS_HIP(hipGetLastError());
         if (!groups) { RTS_HIP(hipStreamSynchronize(st)); return RTS_OK; }
         RtsAggPending& ap = c->agg_pending;

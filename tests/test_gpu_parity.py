@@ -1089,7 +1089,7 @@ def test_cooperative_units_are_invisible(rts, scenes, monkeypatch):
 
 
 def test_small_received_sets_one_block_path_is_invisible(rts, scenes, monkeypatch):
-    """up to 2 048 received rays the ordering of the received set and the aggregation run as single-block kernels
+    """up to 4 096 received rays (2 048 where a sort key needs 64 bits) the ordering of the received set and the aggregation run as single-block kernels
     (k_recv_order_small, k_agg_order_small, k_agg_finish_small) instead of the chain of device-wide sorts and scans
     (RTS_POST_SMALL=0).  The two share the statements that form every sum and the tile sums in between are the same kernel:
     received order, finalised rays, per-ray aggregation outputs and the group table must be the same BITS -- with and without
@@ -1119,7 +1119,7 @@ def test_small_received_sets_one_block_path_is_invisible(rts, scenes, monkeypatc
         tr.close()
         raise AssertionError("no prefix of %s receives %d..%d rays" % (spec["name"], lo_R, hi_R))
 
-    for name, spec, want in (("c3", c3, (1500, 2048)), ("c3 full block", c3, (2048, 2048)), ("multi", multi, None), ("refraction", refr, (1200, 2048)), ("few", few, None)):
+    for name, spec, want in (("c3", c3, (1500, 2048)), ("c3 2048", c3, (2048, 2048)), ("c3 nearly 4096", c3, (3800, 4096)), ("multi", multi, None), ("refraction", refr, (1200, 2048)), ("few", few, None)):
         count = prefix_with(spec, *want) if want else spec["W"] ** 3
         out = {}
         for mode in ("1", "0"):
@@ -1139,7 +1139,60 @@ def test_small_received_sets_one_block_path_is_invisible(rts, scenes, monkeypatc
         assert ga.tobytes() == gb.tobytes() and len(ga) > 0, name
         for k in ("results", "delay", "phase", "pathMatch"):
             assert aa[k].tobytes() == ab[k].tobytes(), (name, k)
-    assert min(seen) < 400 and max(seen) == 2048, seen     # (both ends of the one-block range were exercised)
+    assert min(seen) < 400 and 3800 <= max(seen) <= 4096 and 2048 in seen, seen     # (both ends of the one-block range were exercised; 64-bit row keys -- refraction -- up to 2 048)
+
+
+def test_pulse_end_uniform_equals_the_four_calls(rts, scenes, monkeypatch):
+    """rts_trace_pulse_end_uniform = rts_trace_pulse_end + rts_finalise_uniform + rts_cube_accumulate + rts_aggregate.  From a
+    handle's second pulse on (the first gives it a received count to judge by) the chain is enqueued behind the trace on the
+    DEVICE-side count, without the host waiting in between: received rays, finalised values, per-ray aggregation outputs, group
+    table, statistics and the return cube must be the same bits as with the four calls -- for a pulse of ~1 900 rays (C3-like), of
+    none, and for one whose count exceeds what the speculative chain was sized for after a small one made it speculate (the
+    chain then does nothing and is run again the ordinary way when the results are asked for); RTS_SPECULATE=0 likewise"""
+    c3 = scenes.config3(W=64, detail=0.3, rx_radius=300.0)
+    tx = c3["tx"]; n_all = c3["W"] ** 3
+    cs, fc, wl = 299792458.0, 1.0e10, 0.03
+
+    def prefix_with(lo_R, hi_R):
+        tr = H.gpu_tracer(rts, c3); lo, hi = 1, n_all
+        for _ in range(40):
+            mid = (lo + hi) // 2
+            _, st = H.gpu_trace(rts, c3, tr=tr, ray_first=0, ray_count=mid)
+            if st["received"] > hi_R: hi = mid
+            elif st["received"] < lo_R: lo = mid
+            else: tr.close(); return mid
+        raise AssertionError("no prefix")
+    small, big = prefix_with(1500, 1800), prefix_with(5000, 9000)
+    plan = [small, small, 3, big, small, big, big, small]            # launch indices per pulse: speculation engages from pulse 2, meets a miss at 4 and 6
+    cube_shape = (len(c3["rx"]), len(plan), 64)
+    r0 = 2.0 * float(np.linalg.norm(np.asarray(tx["origin"]) - np.asarray(c3["motion"][0]["position"]))); t0 = (r0 - 150.0) / cs; dt = 300.0 / cs / 64
+
+    def run(mode):
+        monkeypatch.setenv("RTS_SPECULATE", "0" if mode == "nospec" else "1")
+        tr = H.gpu_tracer(rts, c3)
+        tr.cube_attach(cube_shape[0], cube_shape[1], cube_shape[2], t0, dt)
+        out = []
+        for k, count in enumerate(plan):
+            tr.trace_begin(tx["origin"], tx["span"], tx["dir"], c3["motion"], ray_first=0, ray_count=count)
+            if mode == "four":
+                tr.trace_end(); tr.finalise_uniform(None, wl, 1.0, 1.0, fc, cs); tr.cube_accumulate(k, cs, fc); g = tr.aggregate(cs, fc)
+            else:
+                tr.trace_end_uniform(None, wl, 1.0, 1.0, fc, cs, cube_pulse=k); g = tr.groups()
+            st = tr.stats(); rec = tr.received(); agg = tr.aggregated()
+            out.append((g, {k2: st[k2] for k2 in ("segments", "shaded", "received")}, rec, agg))
+        cube = tr.cube().copy(); tr.close()
+        return out, cube
+    ref, cube_ref = run("four")
+    assert [o[1]["received"] for o in ref][2] < 5 and max(o[1]["received"] for o in ref) > 2048 > min(o[1]["received"] for o in ref if o[1]["received"] > 100)
+    for mode in ("spec", "nospec"):
+        got, cube = run(mode)
+        for k, ((ga, sa, ra, aa), (gb, sb, rb, ab)) in enumerate(zip(ref, got)):
+            assert sa == sb, (mode, k, sa, sb)
+            assert ga.tobytes() == gb.tobytes(), (mode, k)
+            assert np.array_equal(ra["slots"], rb["slots"]) and ra["results"].tobytes() == rb["results"].tobytes() and np.array_equal(ra["path"], rb["path"]), (mode, k)
+            for f in ("results", "delay", "phase", "pathMatch"):
+                assert aa[f].tobytes() == ab[f].tobytes(), (mode, k, f)
+        np.testing.assert_allclose(cube, cube_ref, rtol=0, atol=1e-18 + 1e-12 * np.abs(cube_ref).max())      # (atomic adds: order varies)
 
 
 def test_asynchronous_bounces_are_invisible(rts, scenes, monkeypatch):
