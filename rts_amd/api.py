@@ -183,6 +183,14 @@ class Tracer:
         check(L.lib().rts_get_stats(self.h, C.byref(s)))
         return {k: getattr(s, k) for k, _ in L.RtsStats._fields_}
 
+    def stats_raw(self):
+        """rts_get_stats into ONE struct kept by the tracer (a caller in a per-pulse loop reads the few fields it wants)"""
+        s = getattr(self, "_stats_struct", None)
+        if s is None:
+            s = self._stats_struct = L.RtsStats()
+        check(L.lib().rts_get_stats(self.h, C.byref(s)))
+        return s
+
     def received_count(self):
         n = C.c_uint64(0)
         check(L.lib().rts_received_count(self.h, C.byref(n)))
