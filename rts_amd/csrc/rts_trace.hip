@@ -543,41 +543,47 @@ __device__ __forceinline__ void rts_write_back(const RtsTraceArgs& a, const RtsU
     }
 }
 
+// The conservative f32 pre-filter of a primary ray: can it meet any triangle's projection (the pulse's direction bitmap,
+// RtsMaskFrame) / come within the widened radius of a receiver sphere?  rxp: the receivers' constants (k_trace's s_rxp).
+__device__ __forceinline__ void rts_prefilter(const RtsLaunchConsts& lc, const uint32_t slot, const bool mask_on, const uint32_t* __restrict__ pmask, const uint32_t n_rx,
+                                              const float (*rxp)[6], bool& may_target, bool& may_rx)
+{
+    // ray_generation in f32 (same tree, f32 constants): lattice point, normalise, Rot, normalise, Rot1
+    uint32_t lx, ly, lz; rts_lattice_coords(lc, slot, lx, ly, lz);
+    float vx = __builtin_fmaf(lc.f_st[0], (float)lx, lc.f_bs[0]), vy = __builtin_fmaf(lc.f_st[1], (float)ly, lc.f_bs[1]), vz = __builtin_fmaf(lc.f_st[2], (float)lz, lc.f_bs[2]);
+    float inv = __frsqrt_rn(vx*vx + vy*vy + vz*vz); vx *= inv; vy *= inv; vz *= inv;
+    float rx_ = lc.f_rot[0]*vx + lc.f_rot[1]*vy + lc.f_rot[2]*vz, ry_ = lc.f_rot[3]*vx + lc.f_rot[4]*vy + lc.f_rot[5]*vz, rz_ = lc.f_rot[6]*vx + lc.f_rot[7]*vy + lc.f_rot[8]*vz;
+    inv = __frsqrt_rn(rx_*rx_ + ry_*ry_ + rz_*rz_); rx_ *= inv; ry_ *= inv; rz_ *= inv;
+    const float dx = lc.f_rot1[0]*rx_ + lc.f_rot1[1]*ry_ + lc.f_rot1[2]*rz_, dy = lc.f_rot1[3]*rx_ + lc.f_rot1[4]*ry_ + lc.f_rot1[5]*rz_, dz = lc.f_rot1[6]*rx_ + lc.f_rot1[7]*ry_ + lc.f_rot1[8]*rz_;
+    if (mask_on) {                                       // is any triangle's projection near this direction? (RtsMaskFrame)
+        const RtsMaskFrame& mf = lc.mask;
+        const float w = dx * mf.bx + dy * mf.by + dz * mf.bz;
+        const float fu = ((dx * mf.ux + dy * mf.uy + dz * mf.uz) / w - mf.u0) * mf.inv_du, fv = ((dx * mf.vx + dy * mf.vy + dz * mf.vz) / w - mf.v0) * mf.inv_dv;
+        if (w > 0.0f && fu >= 0.0f && fv >= 0.0f && fu < (float)mf.n && fv < (float)mf.n) {
+            const uint32_t cell = (uint32_t)fv * mf.n + (uint32_t)fu;
+            may_target = ((pmask[cell >> 5] >> (cell & 31u)) & 1u) != 0u;
+        }
+    }
+    may_rx = false;
+    const float dd = dx*dx + dy*dy + dz*dz;
+    for (uint32_t Rx_i = 0; Rx_i < n_rx; Rx_i++) {    // can the ray come within the widened radius of this receiver's sphere?
+        const float qx = rxp[Rx_i][0], qy = rxp[Rx_i][1], qz = rxp[Rx_i][2], qq = rxp[Rx_i][3], r2w = rxp[Rx_i][4], qn = rxp[Rx_i][5];
+        const float b = qx*dx + qy*dy + qz*dz;
+        const bool inside = qq <= r2w * 1.01f;
+        const bool ahead = b > -1.0e-3f * qn && (b*b - (qq - r2w) * dd) >= 0.0f;
+        may_rx = may_rx || inside || ahead;
+    }
+}
+
 // ray_generation + payload of a launch index (ray_tracer.cu:144-224), with the conservative f32 pre-filter of primary rays:
 // may_target / may_rx come back false when the ray can meet no triangle / no receiver sphere.
 __device__ __forceinline__ void rts_primary_setup(const RtsTraceArgs& a, const RtsLaunchConsts& lc, const RtsUnitLds& L_, const uint32_t tid, const uint32_t slot, const bool pre_on,
-                                                  const bool mask_on, const dvec3& origin, RtsRay& S, bool& may_target, bool& may_rx)
+                                                  const bool mask_on, const dvec3& origin, RtsRay& S, bool& may_target, bool& may_rx, const bool pre_done = false)
 {
     double* const s_first = L_.first; unsigned long long* const s_path = L_.path; const float (*const s_rxp)[6] = L_.rxp;
     dvec3& dir = S.dir; dvec3& prev = S.prev; double& rayLength = S.rayLength; double& power = S.power; double& doppler = S.doppler;
     // ------------------------------------------------------------ ray_generation + payload, ray_tracer.cu:144-224
-    if (pre_on) {
-        // ray_generation in f32 (same tree, f32 constants): lattice point, normalise, Rot, normalise, Rot1
-        uint32_t lx, ly, lz; rts_lattice_coords(lc, slot, lx, ly, lz);
-        float vx = __builtin_fmaf(lc.f_st[0], (float)lx, lc.f_bs[0]), vy = __builtin_fmaf(lc.f_st[1], (float)ly, lc.f_bs[1]), vz = __builtin_fmaf(lc.f_st[2], (float)lz, lc.f_bs[2]);
-        float inv = __frsqrt_rn(vx*vx + vy*vy + vz*vz); vx *= inv; vy *= inv; vz *= inv;
-        float rx_ = lc.f_rot[0]*vx + lc.f_rot[1]*vy + lc.f_rot[2]*vz, ry_ = lc.f_rot[3]*vx + lc.f_rot[4]*vy + lc.f_rot[5]*vz, rz_ = lc.f_rot[6]*vx + lc.f_rot[7]*vy + lc.f_rot[8]*vz;
-        inv = __frsqrt_rn(rx_*rx_ + ry_*ry_ + rz_*rz_); rx_ *= inv; ry_ *= inv; rz_ *= inv;
-        const float dx = lc.f_rot1[0]*rx_ + lc.f_rot1[1]*ry_ + lc.f_rot1[2]*rz_, dy = lc.f_rot1[3]*rx_ + lc.f_rot1[4]*ry_ + lc.f_rot1[5]*rz_, dz = lc.f_rot1[6]*rx_ + lc.f_rot1[7]*ry_ + lc.f_rot1[8]*rz_;
-        if (mask_on) {                                       // is any triangle's projection near this direction? (RtsMaskFrame)
-            const RtsMaskFrame& mf = lc.mask;
-            const float w = dx * mf.bx + dy * mf.by + dz * mf.bz;
-            const float fu = ((dx * mf.ux + dy * mf.uy + dz * mf.uz) / w - mf.u0) * mf.inv_du, fv = ((dx * mf.vx + dy * mf.vy + dz * mf.vz) / w - mf.v0) * mf.inv_dv;
-            if (w > 0.0f && fu >= 0.0f && fv >= 0.0f && fu < (float)mf.n && fv < (float)mf.n) {
-                const uint32_t cell = (uint32_t)fv * mf.n + (uint32_t)fu;
-                may_target = ((a.pmask[cell >> 5] >> (cell & 31u)) & 1u) != 0u;
-            }
-        }
-        may_rx = false;
-        const float dd = dx*dx + dy*dy + dz*dz;
-        for (uint32_t Rx_i = 0; Rx_i < a.n_rx; Rx_i++) {    // can the ray come within the widened radius of this receiver's sphere?
-            const float qx = s_rxp[Rx_i][0], qy = s_rxp[Rx_i][1], qz = s_rxp[Rx_i][2], qq = s_rxp[Rx_i][3], r2w = s_rxp[Rx_i][4], qn = s_rxp[Rx_i][5];
-            const float b = qx*dx + qy*dy + qz*dz;
-            const bool inside = qq <= r2w * 1.01f;
-            const bool ahead = b > -1.0e-3f * qn && (b*b - (qq - r2w) * dd) >= 0.0f;
-            may_rx = may_rx || inside || ahead;
-        }
-    }
+    if (pre_on && !pre_done) rts_prefilter(lc, slot, mask_on, a.pmask, a.n_rx, s_rxp, may_target, may_rx);
     dir = (may_target || may_rx) ? rts_primary_dir(lc, slot) : mk3(0.0, 0.0, 0.0);
     prev = origin;
     s_first[tid] = 0.0; s_first[RTS_BLOCK + tid] = 0.0; s_first[2 * RTS_BLOCK + tid] = 0.0;
@@ -588,7 +594,8 @@ __device__ __forceinline__ void rts_primary_setup(const RtsTraceArgs& a, const R
 template <bool COUNT, bool KEEP_ALL, bool REFR, bool COOP>
 __device__ __forceinline__ void rts_trace_unit(const RtsTraceArgs& a, const RtsLaunchConsts& lc, const RtsUnitLds& L_, const uint32_t tid, const uint32_t gtid, const uint32_t lane,
                                                const uint32_t slot, const bool pre_on, const bool mask_on, const uint32_t D, const uint32_t max_refr, const dvec3& origin,
-                                               uint32_t& n_nodes, uint32_t& n_tris, bool& hard_overflow, unsigned long long (&lane_stats)[3])
+                                               uint32_t& n_nodes, uint32_t& n_tris, bool& hard_overflow, unsigned long long (&lane_stats)[3],
+                                               const uint32_t pre = 0u)      // pre: bit 0 = k_trace ran the pre-filter already, bits 1 / 2 = its may_target / may_rx
 {
       int32_t* const s_stack = L_.stack; int32_t* const s_exch = L_.exch; double* const s_first = L_.first; unsigned long long* const s_path = L_.path; uint32_t* const s_n = L_.n;
 
@@ -601,8 +608,9 @@ __device__ __forceinline__ void rts_trace_unit(const RtsTraceArgs& a, const RtsL
         uint32_t& reflDepth = S.reflDepth; uint32_t& refrDepth = S.refrDepth; bool& end = S.end; bool& chain_start = S.chain_start;
         refx = 1; refy = 1; reflDepth = 0; refrDepth = 0; S.received = -1; end = false;
         bool may_target = a.n_prims > 0, may_rx = a.n_rx > 0;   // (primary ray: what the pre-filter could not exclude)
+        if (pre & 1u) { may_target = (pre & 2u) != 0u; may_rx = (pre & 4u) != 0u; }      // (k_trace ran the pre-filter already, to see whether the tile is dead)
         if (chain == 0) {
-            rts_primary_setup(a, lc, L_, tid, slot, pre_on, mask_on, origin, S, may_target, may_rx);
+            rts_primary_setup(a, lc, L_, tid, slot, pre_on, mask_on, origin, S, may_target, may_rx, (pre & 1u) != 0u);
         } else {
             if (!REFR || !(pending & (1u << chain))) continue;
             const RtsChildState cs = a.child[(size_t)(chain - 1) * a.slab_threads + gtid];
@@ -960,12 +968,27 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR || COOP) ? 2 : 4) k_trace(con
       // the targets, so the expensive tiles sit in the middle of the lattice and should be started first
       const uint32_t tile = a.tile_order ? a.tile_order[tpos] : ((tpos & 1u) ? (n_tiles - 1u) / 2u + (tpos + 1u) / 2u : (n_tiles - 1u) / 2u - tpos / 2u);
       const uint32_t slot = coop_unit ? tile * 64u + (vpos & 63u) : tile * 64u + lane;
+      // A DEAD tile -- the pre-filter clears every one of its launch indices (most tiles of a pulse: the beam is wider than the
+      // targets) -- ends here: its launch indices' one segment each is counted, nothing else of the per-tile machinery runs
+      // (payload initialisation, the bounce loop's tests, clocks, the cost record's arithmetic: half of the ~190 vector and ~90 scalar
+      // instructions such a tile cost, 10 % of a BASELINE configs[2] launch's instructions)
+      uint32_t pre = 0u;
+      if (!COOP && !ASYNC && !KEEP_ALL && pre_on) {
+          bool pre_target = a.n_prims > 0, pre_rx = a.n_rx > 0;
+          if (slot < a.n_rays) rts_prefilter(lc, slot, mask_on, a.pmask, a.n_rx, s_rxp, pre_target, pre_rx);
+          if (!__any(slot < a.n_rays && (pre_target || pre_rx))) {
+              if (slot < a.n_rays) atomicAdd(&s_n[tid], 1u);       // (bits 0-21: the lane's segments of the launch)
+              if (lane == 0 && a.tile_cost) a.tile_cost[tile] = 1u;
+              continue;
+          }
+          pre = 1u | (pre_target ? 2u : 0u) | (pre_rx ? 4u : 0u);
+      }
       const long long tile_t0 = clock64();
       if (!COOP) atomicAnd(&s_n[tid], 0x003fffffu);              // (ds_and_b32: the tile's own segment count starts at zero; a register for it would be the 129th)
       const unsigned long long tl_tile = (COUNT && a.timeline && lane == 0) ? wall_clock64() : 0ULL;
       if (slot < a.n_rays) {
           if (ASYNC) rts_trace_unit_async<COUNT, KEEP_ALL>(a, lc, ul, tid, gtid, lane, slot, pre_on, mask_on, D, origin, tile_t0, n_nodes, n_tris, hard_overflow, lane_stats);
-          else rts_trace_unit<COUNT, KEEP_ALL, REFR, COOP>(a, lc, ul, tid, gtid, lane, slot, pre_on, mask_on, D, max_refr, origin, n_nodes, n_tris, hard_overflow, lane_stats);
+          else rts_trace_unit<COUNT, KEEP_ALL, REFR, COOP>(a, lc, ul, tid, gtid, lane, slot, pre_on, mask_on, D, max_refr, origin, n_nodes, n_tris, hard_overflow, lane_stats, pre);
       }   // slot < n_rays
       // (the segment count of the tile is only formed for tiles long enough to matter: an all-miss tile is ~100 instructions)
       const unsigned long long dt = (unsigned long long)(clock64() - tile_t0) >> 6;             // (s_memtime: wave-uniform)
