@@ -270,8 +270,18 @@ int rts_post_order_and_expand(RtsContext* c)
     RTS_HIP(c->d_rx_rays.reserve(R)); RTS_HIP(c->d_rx_paths.reserve((size_t)R*D + 1)); RTS_HIP(c->d_rx_angles.reserve((size_t)R*D*2 + 1)); RTS_HIP(c->d_rx_slots.reserve(R));
     size_t tmp = 0;
     if (c->post_small && R <= rts_small_cap_recv(c)) {
-        if (c->last_args.max_refr == 0) k_recv_order_small<uint32_t, 16><<<1, RTS_SMALL_THREADS, 0, st>>>(c->d_recv.p, R, c->n_rays, 0, 32u, c->d_ri_sorted.p, c->recv_dev);
-        else k_recv_order_small<uint64_t, 8><<<1, RTS_SMALL_THREADS, 0, st>>>(c->d_recv.p, R, c->n_rays, 1, 34u, c->d_ri_sorted.p, c->recv_dev);
+        // items per thread by the size of the set (a speculative chain -- count on the device -- is sized for the capacity); sort bits by the largest row
+        const uint32_t cap = c->recv_dev ? rts_small_cap_recv(c) : R;
+        const uint64_t rows = (uint64_t)c->n_rays * (c->last_args.max_refr != 0 ? 3u : 1u);
+        uint32_t bits = 1; while (bits < 40 && ((uint64_t)1 << bits) <= rows) bits++;       // (the padding key, 2^bits - 1, stays above every row)
+        if (c->last_args.max_refr == 0) {
+            if (cap <= 4u * RTS_SMALL_THREADS) k_recv_order_small<uint32_t, 4><<<1, RTS_SMALL_THREADS, 0, st>>>(c->d_recv.p, R, c->n_rays, 0, bits, c->d_ri_sorted.p, c->recv_dev);
+            else if (cap <= 8u * RTS_SMALL_THREADS) k_recv_order_small<uint32_t, 8><<<1, RTS_SMALL_THREADS, 0, st>>>(c->d_recv.p, R, c->n_rays, 0, bits, c->d_ri_sorted.p, c->recv_dev);
+            else k_recv_order_small<uint32_t, 16><<<1, RTS_SMALL_THREADS, 0, st>>>(c->d_recv.p, R, c->n_rays, 0, bits, c->d_ri_sorted.p, c->recv_dev);
+        } else {
+            if (cap <= 4u * RTS_SMALL_THREADS) k_recv_order_small<uint64_t, 4><<<1, RTS_SMALL_THREADS, 0, st>>>(c->d_recv.p, R, c->n_rays, 1, bits, c->d_ri_sorted.p, c->recv_dev);
+            else k_recv_order_small<uint64_t, 8><<<1, RTS_SMALL_THREADS, 0, st>>>(c->d_recv.p, R, c->n_rays, 1, bits, c->d_ri_sorted.p, c->recv_dev);
+        }
         RTS_STAGE(c, "recv order (one block)");
     } else if (c->last_args.max_refr == 0) {
         RTS_HIP(c->d_rk.reserve(R)); RTS_HIP(c->d_rk_sorted.reserve(R));
@@ -855,8 +865,11 @@ int rts_aggregate_device(RtsContext* c, int32_t max_path, int32_t max_rx, const 
     size_t tmp = 0;
     const bool small = c->post_small && !wide && R <= (key_bits < 32u ? RTS_SMALL_CAP32 : RTS_SMALL_CAP64);       // one block orders, one block finishes (see k_agg_order_small)
     if (small) {
-        if (key_bits < 32u) k_agg_order_small<uint32_t, 16><<<1, RTS_SMALL_THREADS, 0, st>>>(d_rays, d_paths, R, D, B, key_bits, c->d_akeys_sorted.p, c->d_aidx_sorted.p, c->d_ghead.p, c->d_gid.p, gstart, c->recv_dev);
-        else k_agg_order_small<uint64_t, 8><<<1, RTS_SMALL_THREADS, 0, st>>>(d_rays, d_paths, R, D, B, key_bits, c->d_akeys_sorted.p, c->d_aidx_sorted.p, c->d_ghead.p, c->d_gid.p, gstart, c->recv_dev);
+        const uint32_t cap = c->recv_dev ? (key_bits < 32u ? RTS_SMALL_CAP32 : RTS_SMALL_CAP64) : R;
+#define RTS_AGG_ORDER(K, I) k_agg_order_small<K, I><<<1, RTS_SMALL_THREADS, 0, st>>>(d_rays, d_paths, R, D, B, key_bits, c->d_akeys_sorted.p, c->d_aidx_sorted.p, c->d_ghead.p, c->d_gid.p, gstart, c->recv_dev)
+        if (key_bits < 32u) { if (cap <= 4u * RTS_SMALL_THREADS) RTS_AGG_ORDER(uint32_t, 4); else if (cap <= 8u * RTS_SMALL_THREADS) RTS_AGG_ORDER(uint32_t, 8); else RTS_AGG_ORDER(uint32_t, 16); }
+        else { if (cap <= 4u * RTS_SMALL_THREADS) RTS_AGG_ORDER(uint64_t, 4); else RTS_AGG_ORDER(uint64_t, 8); }
+#undef RTS_AGG_ORDER
     } else if (!wide) {
         k_agg_keys<<<blocks_for(R, 256), 256, 0, st>>>(d_rays, d_paths, R, D, B, c->d_akeys.p, c->d_aidx.p);
         RTS_HIP(rocprim::radix_sort_pairs(nullptr, tmp, c->d_akeys.p, c->d_akeys_sorted.p, c->d_aidx.p, c->d_aidx_sorted.p, R, 0, key_bits, st));
