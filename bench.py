@@ -59,6 +59,8 @@ def pulse_motion(spec, k):
     """target placement of pulse k; the config's interval is n_pulses long (C3: 256 pulses = 51 m of flight), longer runs
     repeat it so that the workload does not drift out of the beam"""
     k = k % max(int(spec.get("n_pulses", 256)), 1)
+    if "motion_fn" in spec:                                    # (a placement with a per-pulse rotation: configs[4], the adapter benchmark's sphere)
+        return spec["motion_fn"](k)
     out = []
     for m in spec["motion"]:
         v = np.asarray(m["velocity"], np.float64); p0 = np.asarray(m["position"], np.float64)
@@ -140,7 +142,8 @@ def main():
     ap.add_argument("--no-bind", action="store_true", help="leave the process's CPU affinity alone (default: the CPUs of the GPU's NUMA node)")
     ap.add_argument("--post-lag", type=int, default=0, choices=(0, 1), help="1: a pulse's group table is collected one pulse later (the submitting thread does not wait for the post-processing it has just enqueued)")
     ap.add_argument("--inflight", type=int, default=3, help="pulses in flight per GPU; 1 = strictly sequential pulses")
-    ap.add_argument("--config", default="c3", choices=["c2", "c2file", "c3", "c3ecef", "c3ico", "c4"], help="c3 = BASELINE configs[2] (the metric's workload); c4 = configs[3]'s scene and size on ONE transmitter (100 M launch indices per pulse: give --steps 32)")
+    ap.add_argument("--config", default="c3", choices=["c2", "c2file", "c3", "c3ecef", "c3ico", "c4", "c5", "sphere6"], help="c3 = BASELINE configs[2] (the metric's workload); c4 = configs[3]'s scene and size (100 M launch indices per pulse: give --steps 32; --tx both: its two transmitters in turn); c5 = configs[4]: the C3 airframe re-rotated AND translated every pulse, 1024-pulse interval (give --steps 1024), the transmitter tracking it; sphere6 = the scene of the C++ boundary benchmark (tests/adapter/adapter_bench.cpp)")
+    ap.add_argument("--tx", default="0", choices=["0", "1", "both"], help="c4: which of configs[3]'s two transmitters; both = the first half of the interval's pulses from transmitter 0, the second half from transmitter 1 (the reference's transmitter loop is the outer one, ray_tracer.cpp:806)")
     ap.add_argument("--shard", default="pulses", choices=["pulses", "rays"], help="N > 1: deal whole pulses to the ranks, or split every pulse over all ranks (interleaved tiles)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks")
     args = ap.parse_args()
@@ -206,12 +209,35 @@ def main():
         spec = scenes.config3(W=args.width or 216, ico=True)
     elif args.config == "c4":                                     # BASELINE configs[3]: 4 meshes x 250 k triangles, 8 Rx, W = 465, maxRefl = 8 (transmitter 0)
         spec = scenes.config4(W=args.width or 465)
+    elif args.config == "c5":                                     # BASELINE configs[4]: per-pulse rotation + translation (ray_tracer.cpp:993-1014), 1024-pulse interval
+        spec = scenes.config5(W=args.width or 216)
+    elif args.config == "sphere6":
+        spec = scenes.config_sphere6(W=args.width or 216)
     elif args.config == "c2":
         spec = scenes.config2(W=args.width or 100)
     else:
         spec = scenes.config2_file(W=args.width or 100)
     W = spec["W"]; total = W ** 3
     tx = spec["tx"]; wl = spec["c"] / spec["carrier"]
+    if args.tx != "0" and "tx_list" not in spec:
+        raise SystemExit("--tx %s: configuration %s has one transmitter" % (args.tx, args.config))
+    if args.tx == "1":
+        tx = spec["tx_list"][1]
+    two_tx = args.tx == "both"
+    half = (args.steps + 1) // 2                                  # --tx both: pulses [0, half) of transmitter 0, then [0, steps - half) of transmitter 1
+
+    def tx_of(k_rel, motion):
+        """transmitter of the interval's k_rel-th pulse; a configuration with tx_track aims the boresight at the (first) target's
+        position of that pulse (the reference reads the transmitter's rotation per pulse, ray_tracer.cpp:888)"""
+        t = tx if not two_tx else spec["tx_list"][0 if k_rel < half else 1]
+        if spec.get("tx_track"):
+            d = np.asarray(motion[0]["position"], np.float64) - np.asarray(t["origin"], np.float64)
+            t = dict(t, dir=(math.atan2(d[1], d[0]), math.atan2(d[2], math.hypot(d[0], d[1]))))
+        return t
+
+    def pulse_of(k_rel):
+        """pulse number (placement) of the interval's k_rel-th pulse: with two transmitters each runs through the same pulses"""
+        return k_rel if not two_tx or k_rel < half else k_rel - half
 
     # --inflight handles take the pulses in turn; they SHARE one copy of the immutable scene (hierarchy built once)
     trs = []
@@ -251,7 +277,8 @@ def main():
         """the interval's INPUTS: this rank's plan and the target placements of its pulses (synthetic data: generated before the
         clock starts, like the scene)"""
         items = plan(n_pulses)
-        return items, [pulse_motion(spec, k0 + k) for (k, _, _, _) in items]
+        motions = [pulse_motion(spec, k0 + pulse_of(k)) for (k, _, _, _) in items]
+        return items, motions, [tx_of(k, m) for (k, _, _, _), m in zip(items, motions)]
 
     def run_cpi(k0, n_pulses, prepared=None):
         """pulses k0 .. k0+n_pulses-1 as one coherent processing interval, sharded over the ranks"""
@@ -298,7 +325,7 @@ def main():
         lag = args.post_lag if len(trs) >= 2 else 0
         fused_post = args.fused_post and hasattr(rts_amd._lib.lib(), "rts_trace_pulse_end_uniform")
         pending = []; posted = []
-        items, motions = prepared if prepared is not None else prepare_cpi(k0, n_pulses)
+        items, motions, txs = prepared if prepared is not None else prepare_cpi(k0, n_pulses)
         bench_debug = bool(os.environ.get("BENCH_DEBUG"))
         t_cpi = time.perf_counter()                                   # (the interval's clock for BENCH_DEBUG lines)
         for i, (k, first, count, il) in enumerate(items):
@@ -306,7 +333,7 @@ def main():
             while any(p[0] is t for p in posted):
                 collect(*posted.pop(0))
             h0 = time.perf_counter()
-            t.trace_begin(tx["origin"], tx["span"], tx["dir"], motions[i], ray_first=first, ray_count=count, interleave=il)
+            t.trace_begin(txs[i]["origin"], txs[i]["span"], txs[i]["dir"], motions[i], ray_first=first, ray_count=count, interleave=il)
             hp["begin"] += (time.perf_counter() - h0) * 1e3
             if fused_post:                                    # the whole pulse -- placement, trace, post-processing -- is enqueued in one go ...
                 post(t, k); posted.append((t, k))
@@ -380,7 +407,8 @@ def main():
         # (1) the SERIAL trace kernel: whole pulses one after the other on one handle; HIP events on the kernel's own stream
         ser = []
         for k in range(12):
-            st = trs[0].trace(tx["origin"], tx["span"], tx["dir"], pulse_motion(spec, args.warmup + k))
+            mo = pulse_motion(spec, args.warmup + k); tk = tx_of(0, mo)
+            st = trs[0].trace(tk["origin"], tk["span"], tk["dir"], mo)
             if k >= 2:
                 ser.append((st["ms_trace"], st["segments"]))
         ms_serial = float(np.mean([s[0] for s in ser])); seg_serial = float(np.mean([s[1] for s in ser]))
@@ -388,11 +416,12 @@ def main():
         #     (every primary hit then spawns exactly one more segment, so hit fraction = (segments - rays) / rays)
         trc = api.Tracer(W, spec["max_refl"], 0, spec["smooth"], device=local_rank, count_traversal=True)
         trc.share_scene(trs[0]); trc.set_receivers(spec["rx"])
-        sc = trc.trace(tx["origin"], tx["span"], tx["dir"], pulse_motion(spec, args.warmup))
+        mo = pulse_motion(spec, args.warmup); tk = tx_of(0, mo)
+        sc = trc.trace(tk["origin"], tk["span"], tk["dir"], mo)
         trc.close()
         tr1 = api.Tracer(W, 1, 0, spec["smooth"], device=local_rank)
         tr1.share_scene(trs[0]); tr1.set_receivers(spec["rx"])
-        s1 = tr1.trace(tx["origin"], tx["span"], tx["dir"], pulse_motion(spec, args.warmup))
+        s1 = tr1.trace(tk["origin"], tk["span"], tk["dir"], mo)
         tr1.close()
         hit_fraction = (s1["segments"] - s1["rays"]) / max(s1["rays"], 1)
         V = sc["node_visits"] / max(sc["segments"], 1); T = sc["tri_tests"] / max(sc["segments"], 1); Hh = sc["shaded"] / max(sc["segments"], 1)
@@ -465,7 +494,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[%d]%s: %s, 1 Tx / %d Rx, W=%d (%d launch indices/pulse), maxRefl=%d, target moves every pulse (re-placed on the device per pulse; static target-space BVH4)"
-                                   % (2 if args.config.startswith("c3") else (3 if args.config == "c4" else 1), " at Earth-centred coordinates" if args.config == "c3ecef" else "", spec["name"], len(spec["rx"]), W, total, spec["max_refl"]),
+                                   % ({"c3": 2, "c3ecef": 2, "c3ico": 2, "c4": 3, "c5": 4}.get(args.config, 1), " at Earth-centred coordinates" if args.config == "c3ecef" else (" (both transmitters in turn: pulses [0, %d) from Tx 0, [%d, %d) from Tx 1; a receiver's noise temperature grows by the signal's once per transmitter, ray_tracer.cpp:829 -- host side, the SOARS adapter's)" % (half, half, args.steps) if two_tx else (" -- NOT a BASELINE configuration: the scene of the C++ boundary benchmark (tests/adapter/adapter_bench.cpp)" if args.config == "sphere6" else (" (target re-rotated and translated every pulse, ray_tracer.cpp:993-1014; the transmitter's boresight tracks it)" if args.config == "c5" else ""))), spec["name"], len(spec["rx"]), W, total, spec["max_refl"]),
                        "rays_per_pulse": total, "segments_per_pulse": seg_all / args.steps, "received_per_pulse": received_all / args.steps,
                        "hit_fraction": hit_fraction, "primary_Mrays_per_s": total * args.steps / dt / 1e6,
                        "return_cube": "complex128 [%d rx][%d pulses][%d bins], all-reduced once per interval, then %d-point slow-time FFT in the library (rts_cube_doppler, inside the timed region); range-Doppler peak %.6e, max deviation from torch.fft %.1e (relative)" % (cube.shape[0], cube.shape[1], n_bins, n_fft, range_doppler_peak, range_doppler_err or 0.0),

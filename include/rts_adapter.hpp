@@ -23,6 +23,7 @@
 #define RTS_ADAPTER_HPP
 
 #include <algorithm>
+#include <chrono>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -73,6 +74,18 @@ HostMesh build_target_mesh(Target* targ) {
     return m;
 }
 
+// Optional instrumentation of a run (RunOptions::times): when each pulse was FINISHED (its responses emitted), on the steady
+// clock, in seconds since run() was entered, in pulse order over all transmitters -- the differences are the pulse rate the
+// simulator sees, set-up excluded -- and where the submitting thread spent its time, per section of the pulse loop.
+struct RunTimes {
+    std::vector<double> pulse_done_s;
+    double setup_s = 0;                    // run() entry -> the first pulse is begun (handles, meshes, hierarchy)
+    enum { BEGIN_HOST = 0, BEGIN_CALL, END_WAIT, GET_RECEIVED, CALLBACKS, AGGREGATE, RESPONSES, N_LAPS };
+    double lap_s[N_LAPS] = {0, 0, 0, 0, 0, 0, 0};      // simulator calls + rts_set_receivers | rts_trace_pulse_begin | rts_trace_pulse_end (wait for the trace) |
+                                           // rts_get_received | RCS / gain callbacks | aggregation round trip | unique paths + Response emission
+    static const char* lap_name(int k) { static const char* n[] = {"begin_host", "trace_pulse_begin", "end_wait", "get_received", "callbacks", "aggregate", "responses"}; return n[k]; }
+};
+
 // How the pulses of a run are spread over the GPUs of the machine (the reference is single-GPU).
 struct RunOptions {
     std::vector<int> devices;      // HIP device ordinals, one SET of handles each; empty = every visible device.  An ordinal may
@@ -85,6 +98,7 @@ struct RunOptions {
     unsigned flags = 0;            // RtsParams.flags of every handle: RTS_FLAG_DEVICE_BUILD builds the hierarchy on the GPU in milliseconds
                                    // (a CPI of a few hundred pulses is over before the host SAH build of a large scene has paid for itself)
     RtsStats* last_stats = nullptr;
+    RunTimes* times = nullptr;     // optional instrumentation (per-pulse completion stamps, host lap timers)
 };
 
 // Traits: the simulator types the driver touches.
@@ -95,6 +109,14 @@ template <class Tr>
 void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlocks, const RunOptions& opt)
 {
     using Vec3 = typename Tr::Vec3; using SVec3 = typename Tr::SVec3;
+    using Clock = std::chrono::steady_clock;
+    const Clock::time_point t_run0 = Clock::now();
+    RunTimes* const tm = opt.times;
+    auto now_s = [&]() { return std::chrono::duration<double>(Clock::now() - t_run0).count(); };
+    // lap(k, t0): adds the time since t0 to section k and returns the new t0 (no-ops without RunOptions::times)
+    auto lap = [&](int k, double t0) -> double { if (!tm) return 0.0; const double t1 = now_s(); tm->lap_s[k] += t1 - t0; return t1; };
+    if (tm) { tm->pulse_done_s.clear(); tm->setup_s = 0; for (double& v : tm->lap_s) v = 0; }
+    bool first_begin = true;
     const auto rts_vars = Tr::Params::GetRTSVariables();                       // ray_tracer.cpp:600-605
     RtsParams params{};
     params.width = rts_vars.x; params.max_refl = rts_vars.y; params.max_refr = rts_vars.z > 0 ? 2u : 0u;
@@ -147,6 +169,8 @@ void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlo
         // ---- everything of pulse k up to the launch (:843-1165), left in flight on handle h; item: the part of the pulse's
         // launch indices this handle traces.  Returns the pulse time.
         auto begin_pulse = [&](unsigned k, RtsHandle h, const RtsPlanItem& item) -> double {
+            double tl = tm ? now_s() : 0.0;
+            if (tm && first_begin) { tm->setup_s = tl; first_begin = false; }
             trans->GetPulse(signal, k);
             const double time_t = signal->time;
             const auto txrot = trans->GetRotation(time_t);
@@ -180,18 +204,23 @@ void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlo
                 }
             }
             pulse.motion = motion.data();
+            tl = lap(RunTimes::BEGIN_HOST, tl);
             check(rts_trace_pulse_begin(h, &pulse), "rts_trace_pulse_begin");   // replaces :1126-1165
+            lap(RunTimes::BEGIN_CALL, tl);
             return time_t;
         };
 
         // ---- read-back, finalisation, aggregation and responses of one pulse whose launch indices were traced by the handles
         // `parts` (one handle: a whole pulse; several: interleaved parts, merged here in launch-index order) (:1180-1321)
         auto finish_pulse = [&](const std::vector<RtsHandle>& parts, double time_t) {
+            double tl = tm ? now_s() : 0.0;
+            struct Done { RunTimes* t; decltype(now_s)& now; ~Done() { if (t) t->pulse_done_s.push_back(now()); } } done_stamp{tm, now_s};      // (every way out of this pulse)
             uint64_t R = 0; std::vector<uint64_t> Rp(parts.size(), 0);
             for (size_t q = 0; q < parts.size(); q++) {
                 check(rts_trace_pulse_end(parts[q]), "rts_trace_pulse_end");
                 check(rts_received_count(parts[q], &Rp[q]), "rts_received_count"); R += Rp[q];
             }
+            tl = lap(RunTimes::END_WAIT, tl);
             if (opt.last_stats) rts_get_stats(parts[0], opt.last_stats);
             if (R == 0) return;
             if (R > 0x7ffffffeULL) throw std::runtime_error("rts_adapter: more than 2^31 received rays in one pulse");
@@ -216,6 +245,7 @@ void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlo
                 }
             }
 
+            tl = lap(RunTimes::GET_RECEIVED, tl);
             const Vec3 origin = trpos;
             for (uint64_t i = 0; i < R; i++) {                                 // :1198-1256 for the received rays
                 PerRayData& r = rx_results[i];
@@ -242,6 +272,7 @@ void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlo
                 r.doppler = carrier * (((1 + Vr / cspeed) / (1 - Vr / cspeed)) - 1);
             }
 
+            tl = lap(RunTimes::CALLBACKS, tl);
             std::vector<double> npath(R, 0), power(R, 0), doppler(R, 0), delay(R, 0), phase(R, 0);      // :1266-1271
             std::vector<int> pathMatch(R, (int)std::min<uint64_t>(rayTotal + 1, 0x7fffffffULL));
             // rs::kernel_wrapper's arithmetic (aggregation.cu:103-184) on the device and stream of the handle that traced the
@@ -249,6 +280,7 @@ void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlo
             check(rts_kernel_wrapper_on(parts[0], rx_results.data(), rx_intersects.data(), (unsigned)R, D, MaxThreads, MaxBlocks, cspeed, carrier,
                                         npath.data(), power.data(), doppler.data(), delay.data(), phase.data(), pathMatch.data()), "rs::kernel_wrapper");
 
+            tl = lap(RunTimes::AGGREGATE, tl);
             std::vector<int> uniq(pathMatch);                                  // :1290-1292
             std::sort(uniq.begin(), uniq.end()); uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
             for (int i : uniq) {                                               // :1301-1321
@@ -260,6 +292,7 @@ void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlo
                 response->AddInterpPoint(point);
                 receivers[rx]->AddResponse(response);
             }
+            lap(RunTimes::RESPONSES, tl);
         };
 
         // ---- the pulse loop (:843), software-pipelined.  Pulses are FINISHED strictly in pulse order, so every side effect

@@ -135,6 +135,10 @@ typedef struct RtsStats {
     float ms_aggregate;          /* finalise + group-by                                 */
     uint32_t bvh_rebuilt;        /* 1 if a target moved and the scene was re-placed      */
     uint32_t stack_overflows;    /* traversal stack spills to global memory             */
+    uint64_t walked_segments;    /* segments that entered a target's hierarchy at all -- the rest were cleared by the primary-ray
+                                    pre-filter or by the targets' bounding spheres (RTS_FLAG_COUNT_TRAVERSAL only)              */
+    uint32_t coop_tiles;         /* wave tiles of this launch traced as cooperative units (one launch index per wave)           */
+    uint32_t reserved;
 } RtsStats;
 
 /* One aggregated return: what ray_tracer.cpp:1301-1321 turns into an InterpPoint/Response. */
@@ -224,6 +228,28 @@ int rts_get_lane_stats(RtsHandle h, uint64_t* out3);
 int rts_received_count(RtsHandle h, uint64_t* count);
 int rts_get_received(RtsHandle h, struct PerRayData* rays, int32_t* paths, double* rcs_angles, uint64_t* slots,
                      uint64_t capacity);
+
+/* The same without copy calls, for a caller in a pulse loop that needs the received rays on the HOST (the simulator's RCS and
+ * antenna-gain callbacks of ray_tracer.cpp:1198-1256; include/rts_adapter.hpp):
+ *     rts_trace_pulse_begin(h, pulse); rts_received_prefetch(h);       // enqueued, returns at once
+ *     ... other handles' pulses ...
+ *     rts_received_view(h, &rays, &paths, &angles, NULL, &R);          // ONE wait; pointers into the handle's pinned host mirror
+ *     for i < R: power[i], doppler[i] = callbacks(rays[i], paths[i], angles[i])
+ *     rts_finalise_values(h, power, doppler, R); rts_aggregate(h, c, fc, 0);      // enqueued
+ *     ... other handles' pulses ...
+ *     rts_aggregated_view(h, &power, &doppler, &delay, &phase, &path_match, &R);   // ONE wait; what rs::kernel_wrapper returns
+ * rts_received_prefetch enqueues the ordering + expansion of the pulse's received rays behind its trace and has a kernel store
+ * the result into mapped host memory -- without waiting for the trace when the handle's previous pulse received at most 3 072
+ * rays (1 536 with refraction chains), otherwise it only marks the pulse and the first accessor's (blocking) rts_trace_pulse_end
+ * feeds the mirror.  Either way the views equal rts_get_received / rts_get_aggregated bit for bit; sets beyond the mirror
+ * (4 096 rays, or what the handle has seen) are served by copies.  View pointers stay valid until the handle's next
+ * rts_trace_pulse_begin; rts_received_view's records are the set AS RECEIVED even after rts_finalise_values / rts_aggregate. */
+int rts_received_prefetch(RtsHandle h);
+int rts_received_view(RtsHandle h, const struct PerRayData** rays, const int32_t** paths, const double** rcs_angles, const uint64_t** slots,
+                      uint64_t* count);
+int rts_finalise_values(RtsHandle h, const double* power, const double* doppler, uint64_t count);
+int rts_aggregated_view(RtsHandle h, const double** power, const double** doppler, const double** delay, const double** phase,
+                        const int32_t** path_match, uint64_t* count);
 
 /* Full per-launch-index buffers (RTS_FLAG_KEEP_ALL_RAYS): results[n] / targ_intersect[n][D] /
  * rcs_angle[n][D][2] as mapped at ray_tracer.cpp:1180-1182, plus hit_prim[n][max_refl+1] (global

@@ -83,7 +83,7 @@ class RtsStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("segments", C.c_uint64), ("shaded", C.c_uint64), ("received", C.c_uint64),
                 ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64), ("n_prims", C.c_uint32), ("n_nodes", C.c_uint32),
                 ("ms_scene", C.c_float), ("ms_trace", C.c_float), ("ms_compact", C.c_float), ("ms_aggregate", C.c_float),
-                ("bvh_rebuilt", C.c_uint32), ("stack_overflows", C.c_uint32)]
+                ("bvh_rebuilt", C.c_uint32), ("stack_overflows", C.c_uint32), ("walked_segments", C.c_uint64), ("coop_tiles", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 RESPONSE_DTYPE = np.dtype([("ray", "<u8"), ("rx", "<i4"), ("n", "<u4"), ("power", "<f8"), ("delay", "<f8"),
@@ -153,7 +153,8 @@ EXPORTS = ["rts_create", "rts_destroy", "rts_last_error", "rts_device_count", "r
            "rts_finalise_uniform", "rts_trace_pulse_end_uniform", "rts_aggregate", "rts_group_count", "rts_get_groups", "rts_get_aggregated",
            "rts_merge_groups", "rts_groups_to_responses", "rts_kernel_wrapper", "rts_vertex_rotation",
            "rts_rotation_matrix", "rts_rect_mesh", "rts_sphere_mesh", "rts_file_mesh", "rts_rx_sphere", "rts_get_bvh",
-           "rts_build_id", "rts_bind_host_to_device", "rts_get_lane_stats", "rts_self_test_math", "rts_cube_attach", "rts_cube_accumulate", "rts_cube_get", "rts_cube_accumulate_paths", "rts_cube_doppler", "rts_cube_doppler_get", "rts_plan_cpi", "rts_cube_reduce", "rts_kernel_wrapper_on"]
+           "rts_build_id", "rts_bind_host_to_device", "rts_get_lane_stats", "rts_self_test_math", "rts_cube_attach", "rts_cube_accumulate", "rts_cube_get", "rts_cube_accumulate_paths", "rts_cube_doppler", "rts_cube_doppler_get", "rts_plan_cpi", "rts_cube_reduce", "rts_kernel_wrapper_on",
+           "rts_received_prefetch", "rts_received_view", "rts_finalise_values", "rts_aggregated_view"]
 
 
 def lib():
@@ -184,6 +185,10 @@ def lib():
         "rts_get_received": [vp, vp, vp, vp, vp, u64],
         "rts_get_all_rays": [vp, vp, vp, vp, vp, vp, u64],
         "rts_finalise_uniform": [vp, vp, dbl, dbl, dbl, dbl, dbl],
+        "rts_received_prefetch": [vp],
+        "rts_received_view": [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)],
+        "rts_finalise_values": [vp, vp, vp, u64],
+        "rts_aggregated_view": [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)],
         "rts_aggregate": [vp, dbl, dbl, u64],
         "rts_trace_pulse_end_uniform": [vp, vp, dbl, dbl, dbl, dbl, dbl, C.c_int32, u64],
         "rts_group_count": [vp, C.POINTER(u32)],

@@ -202,6 +202,36 @@ class Tracer:
         check(L.lib().rts_get_received(self.h, ptr(rays), ptr(paths), ptr(ang), ptr(slots), R))
         return dict(results=rays, path=paths, rcs_angle=ang, slots=slots)
 
+    def received_prefetch(self):
+        """rts_received_prefetch: the pulse in flight delivers its received set into the handle's pinned host mirror"""
+        check(L.lib().rts_received_prefetch(self.h))
+
+    def received_view(self):
+        """rts_received_view: COPIES of the mirror's records (the views themselves only live until the next pulse)"""
+        pr, pp, pa, ps = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(); n = C.c_uint64(0)
+        check(L.lib().rts_received_view(self.h, C.byref(pr), C.byref(pp), C.byref(pa), C.byref(ps), C.byref(n)))
+        R = n.value; D = self.depth
+
+        def arr(p, dtype, shape):
+            count = int(np.prod(shape))
+            if count == 0 or not p.value:
+                return np.zeros(shape, dtype)
+            return np.frombuffer((C.c_char * (count * np.dtype(dtype).itemsize)).from_address(p.value), dtype=dtype).reshape(shape).copy()
+        return dict(results=arr(pr, PRD_DTYPE, (R,)), path=arr(pp, np.int32, (R, D)), rcs_angle=arr(pa, np.float64, (R, D, 2)), slots=arr(ps, np.uint64, (R,)))
+
+    def finalise_values(self, power, doppler):
+        p = np.ascontiguousarray(power, np.float64); d = np.ascontiguousarray(doppler, np.float64)
+        check(L.lib().rts_finalise_values(self.h, ptr(p), ptr(d), len(p)))
+
+    def aggregated_view(self):
+        ps = [C.c_void_p() for _ in range(5)]; n = C.c_uint64(0)
+        check(L.lib().rts_aggregated_view(self.h, *[C.byref(q) for q in ps], C.byref(n)))
+        R = n.value
+        out = {}
+        for name, q, dt in zip(("power", "doppler", "delay", "phase", "pathMatch"), ps, (np.float64,) * 4 + (np.int32,)):
+            out[name] = np.frombuffer((C.c_char * (R * np.dtype(dt).itemsize)).from_address(q.value), dtype=dt).copy() if R and q.value else np.zeros(R, dt)
+        return out
+
     def all_rays(self, n_rays, rows=None):
         """full per-row buffers (keep_all): rows * n_rays records (rows = max_refl + 3 with refraction, else 1)"""
         D = self.depth; H = self.max_refl + 1

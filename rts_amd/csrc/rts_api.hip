@@ -208,6 +208,8 @@ extern "C" int rts_destroy(RtsHandle c)
     (void)hipStreamSynchronize(c->tstream);
     if (--c->gate->refs == 0) { (void)hipStreamDestroy(c->gate->tstream); delete c->gate; }
     if (c->pin) (void)hipHostFree(c->pin);
+    if (c->pin_rx) (void)hipHostFree(c->pin_rx);
+    if (c->mirror.host) (void)hipHostFree(c->mirror.host);
     for (int i = 0; i < 9; i++) (void)hipEventDestroy(c->ev[i]);
     if (c->ev_spec) (void)hipEventDestroy(c->ev_spec);
     for (int i = 0; i < 2; i++) (void)hipEventDestroy(c->ev_coop[i]);
@@ -430,10 +432,25 @@ extern "C" int rts_set_receivers(RtsHandle c, const RtsReceiverSphere* rx, uint3
         if (std::fabs(r.min_theta) > 1e4 || std::fabs(r.max_theta) > 1e4 || std::fabs(r.min_phi) > 1e4 || std::fabs(r.max_phi) > 1e4) { rts_set_error("rts_set_receivers: receiver %u window angle magnitude > 1e4 rad", i); return RTS_ERR_INVALID; }
         h[i] = RtsRxDev{ r.centre[0], r.centre[1], r.centre[2], r.radius, r.min_theta, r.max_theta, r.min_phi, r.max_phi };
     }
-    RTS_HIP(hipStreamSynchronize(c->stream));
-    RTS_HIP(c->d_rx.reserve(n_rx + 1));
-    if (n_rx) RTS_HIP(hipMemcpy(c->d_rx.p, h.data(), sizeof(RtsRxDev)*n_rx, hipMemcpyHostToDevice));
-    c->n_rx = n_rx;
+    // A caller in a pulse loop sets the receivers before every pulse (the reference recomputes the capture spheres per pulse,
+    // ray_tracer.cpp:894-918): an unchanged set costs nothing, a changed one is uploaded from pinned staging ON THE HANDLE'S
+    // STREAM, ahead of the next trace -- no stream drain, no blocking copy (the handle has no pulse in flight here, so the
+    // previous upload from the staging has long completed: its pulse was waited for).
+    if (c->n_rx == n_rx && c->rx_host.size() == n_rx && (n_rx == 0 || memcmp(c->rx_host.data(), h.data(), sizeof(RtsRxDev) * n_rx) == 0)) return RTS_OK;
+    if (n_rx <= 1024) {
+        if (c->pin_rx_cap < n_rx) {
+            if (c->pin_rx) { RTS_HIP(hipStreamSynchronize(c->stream)); (void)hipHostFree(c->pin_rx); c->pin_rx = nullptr; c->pin_rx_cap = 0; }
+            const uint32_t cap = std::max<uint32_t>(64u, n_rx);
+            RTS_HIP(hipHostMalloc((void**)&c->pin_rx, sizeof(RtsRxDev) * cap, hipHostMallocDefault)); c->pin_rx_cap = cap;
+        }
+        if (c->d_rx.cap < (size_t)n_rx + 1) { RTS_HIP(hipStreamSynchronize(c->stream)); RTS_HIP(c->d_rx.reserve(n_rx + 1)); }
+        if (n_rx) { memcpy(c->pin_rx, h.data(), sizeof(RtsRxDev) * n_rx); RTS_HIP(hipMemcpyAsync(c->d_rx.p, c->pin_rx, sizeof(RtsRxDev) * n_rx, hipMemcpyHostToDevice, c->stream)); }
+    } else {
+        RTS_HIP(hipStreamSynchronize(c->stream));
+        RTS_HIP(c->d_rx.reserve(n_rx + 1));
+        RTS_HIP(hipMemcpy(c->d_rx.p, h.data(), sizeof(RtsRxDev)*n_rx, hipMemcpyHostToDevice));
+    }
+    c->rx_host = h; c->n_rx = n_rx;
     return RTS_OK;
 }
 
@@ -607,6 +624,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     const uint32_t n_targets = (uint32_t)c->scene->meshes.size();
     hipStream_t st = c->stream;
     c->agg_valid = false; c->agg_pending.valid = false; c->n_recv = 0;
+    c->mirror.want = false; c->mirror.recv_valid = false; c->mirror.agg_valid = false;
 
     // ---- scene placement: only when a target actually moved
     RTS_HIP(hipEventRecord(c->ev[0], st));
@@ -758,6 +776,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
         c->last_args = a;
     }
     if (c->debug_coop) fprintf(stderr, "[rts] launch: n_rays %u grid %u head hint %u coop grid %u seg threshold %u min cost %u order %d\n", n, grid, c->n_head_hint, coop_grid, a.coop_seg_cost, a.coop_min_cost, a.tile_order ? 1 : 0);
+    c->last_coop_grid = coop_grid;
     int rc = rts_trace_launch(c, a, count_trav, coop_grid);
     if (rc != RTS_OK) return rc;
     RTS_STAGE(c, "k_trace");
@@ -783,6 +802,8 @@ static void rts_pulse_account(RtsContext* c, const unsigned long long* cnt)
     RtsStats& s = c->stats;
     s.rays = n; s.segments = cnt[1]; s.shaded = cnt[2]; s.received = cnt[0]; s.node_visits = cnt[3]; s.tri_tests = cnt[4]; s.stack_overflows = (uint32_t)cnt[5];
     s.n_prims = c->scene->n_prims; s.n_nodes = c->scene->n_nodes;
+    s.walked_segments = cnt[11]; s.reserved = 0;
+    s.coop_tiles = c->last_coop_grid ? (uint32_t)std::min<unsigned long long>(std::min<unsigned long long>(cnt[7], (n + RTS_WTILE - 1) / RTS_WTILE), 16384ull) : 0u;      // (the bounds k_trace applies to the order's head count)
     c->pre_dense = 2 * s.shaded > (uint64_t)n;                      // next launch of this handle: pre-filter only if most launch indices hit nothing
     {   // mean cost of a traced segment in this launch, in the units of the tile cost records (shader clocks >> 6 of one wave):
         // kernel time x resident waves / segments -- the yardstick of the LONG WALKS flag of the next launch (rts_trace.hip)
@@ -812,6 +833,7 @@ extern "C" int rts_trace_pulse_end(RtsHandle c)
     RTS_HIP(hipEventRecord(c->ev[4], st));
     int rc = rts_post_order_and_expand(c); if (rc != RTS_OK) return rc;
     if (keep_all) { rc = rts_post_expand_all(c); if (rc != RTS_OK) return rc; }
+    if (c->mirror.want) { rc = rts_post_mirror_received(c); if (rc != RTS_OK) return rc; }
     RTS_HIP(hipEventRecord(c->ev[5], st));
 
     c->agg_timed = false; c->fin_timed = false;
@@ -899,7 +921,7 @@ extern "C" int rts_finalise_uniform(RtsHandle c, const double* rcs_per_target, d
     int rc = rts_post_finalise(c, rcs_per_target, wavelength, gt, gr, carrier, cspeed); if (rc != RTS_OK) return rc;
     RTS_HIP(hipEventRecord(c->ev[7], c->stream));
     c->fin_timed = true; c->stats_pending = true;
-    c->agg_valid = false;
+    c->agg_valid = false; c->mirror.recv_valid = false;
     return RTS_OK;
 }
 
@@ -919,6 +941,8 @@ static int rts_aggregate_impl(RtsContext* c, double cspeed, double carrier, uint
                                   c->d_delay.p, c->d_phase.p, c->d_pathmatch.p, &c->groups, nullptr, nullptr, nullptr, INT32_MAX, use_rows ? c->d_rx_slots.p : nullptr);
     c->agg_delay_in = true;
     if (rc != RTS_OK) return rc;
+    c->mirror.recv_valid = false;                                       // (the rays' power / Doppler are the group values now: the mirror holds the set as it was received)
+    if (c->mirror.want) { rc = rts_post_mirror_aggregated(c); if (rc != RTS_OK) return rc; }
     RTS_HIP(hipEventRecord(c->ev[7], c->stream));
     c->agg_timed = true; c->stats_pending = true;
     c->agg_valid = true;
@@ -941,15 +965,20 @@ extern "C" int rts_aggregate(RtsHandle c, double cspeed, double carrier, uint64_
 // rts_get_stats, rts_group_count, ...; the handle's next rts_trace_pulse_begin at the latest): if the count did exceed the
 // capacity the chain is run again then, the ordinary way.  Otherwise -- no history yet, KEEP_ALL, a large received set -- the
 // call is the four calls it stands for.
-static int rts_post_chain(RtsContext* c)
+static int rts_post_chain(RtsContext* c, bool ordered = false)      // ordered: rts_trace_pulse_end has ordered + expanded the received set already (its events ev[4] / ev[5] stand)
 {
     const RtsSpecParams& q = c->spec;
     hipStream_t st = c->stream;
     const bool keep_all = (c->params.flags & RTS_FLAG_KEEP_ALL_RAYS) != 0;
-    RTS_HIP(hipEventRecord(c->ev[4], st));
-    int rc = rts_post_order_and_expand(c); if (rc != RTS_OK) return rc;
-    if (keep_all) { rc = rts_post_expand_all(c); if (rc != RTS_OK) return rc; }
-    RTS_HIP(hipEventRecord(c->ev[5], st));
+    int rc = RTS_OK;
+    if (!ordered) {
+        RTS_HIP(hipEventRecord(c->ev[4], st));
+        rc = rts_post_order_and_expand(c); if (rc != RTS_OK) return rc;
+        if (keep_all) { rc = rts_post_expand_all(c); if (rc != RTS_OK) return rc; }
+        if (c->mirror.want) { rc = rts_post_mirror_received(c); if (rc != RTS_OK) return rc; }
+        RTS_HIP(hipEventRecord(c->ev[5], st));
+    }
+    if (q.mode == 1) return RTS_OK;                                     // rts_received_prefetch: the received set goes home, the caller finalises it
     RTS_HIP(hipEventRecord(c->ev[6], st));
     rc = rts_post_finalise(c, q.rcs.data(), q.wl, q.gt, q.gr, q.carrier, q.cspeed); if (rc != RTS_OK) return rc;
     c->fin_timed = true; c->agg_valid = false;
@@ -986,18 +1015,23 @@ extern "C" int rts_trace_pulse_end_uniform(RtsHandle c, const double* rcs_per_ta
     RtsSpecParams& q = c->spec;
     const size_t nt = c->scene->meshes.size();
     q.rcs.assign(nt + 1, 1.0); if (rcs_per_target) for (size_t t = 0; t < nt; t++) q.rcs[t] = rcs_per_target[t];
-    q.wl = wavelength; q.gt = gt; q.gr = gr; q.carrier = carrier; q.cspeed = cspeed; q.cube_pulse = cube_pulse; q.base = recv_index_base;
+    q.wl = wavelength; q.gt = gt; q.gr = gr; q.carrier = carrier; q.cspeed = cspeed; q.cube_pulse = cube_pulse; q.base = recv_index_base; q.mode = 0;
     const bool keep_all = (c->params.flags & RTS_FLAG_KEEP_ALL_RAYS) != 0;
+    bool narrow_key = true;
     {   // capacity of a speculative chain: the smaller of its two one-block sorts (row keys: 32 bits without refraction chains; (receiver, path) keys: D x B + RXB bits)
         uint32_t B = 1; while (((uint64_t)1 << B) < (uint64_t)(c->scene->meshes.size() + 1)) B++;
         uint32_t RXB = 1; while (((uint64_t)1 << RXB) < (uint64_t)std::max<uint32_t>(c->n_rx, 1u)) RXB++;
         const uint32_t key_bits = (c->depth ? c->depth * B : 0u) + RXB;
         c->spec_cap = (c->last_args.max_refr == 0 && key_bits < 32u) ? RTS_SMALL_CAP32 : RTS_SMALL_CAP64;
+        // a key beyond 64 bits (e.g. 16 bounces among >= 8 targets) is sorted as two or three words by the GENERAL chain, whose
+        // kernels take the received count from the host (rts_post.hip: only the one-block path reads it on the device): such a
+        // handle never speculates
+        narrow_key = key_bits <= 64u;
     }
-    const bool speculate = c->post_small && c->spec_enabled && !keep_all && c->n_rays > 0 && c->recv_hint_valid && c->recv_hint <= ((uint64_t)c->spec_cap * 3ull) / 4ull;
+    const bool speculate = c->post_small && c->spec_enabled && narrow_key && !keep_all && c->n_rays > 0 && c->recv_hint_valid && c->recv_hint <= ((uint64_t)c->spec_cap * 3ull) / 4ull;
     if (!speculate) {
         int rc = rts_trace_pulse_end(c); if (rc != RTS_OK) return rc;
-        return rts_post_chain(c);
+        return rts_post_chain(c, true);
     }
     c->pulse_open = false;                                              // (the pulse stays counted as open on its device until it is resolved)
     c->spec_pending = true;
@@ -1014,6 +1048,120 @@ extern "C" int rts_trace_pulse_end_uniform(RtsHandle c, const double* rcs_per_ta
     } else rc = rts_post_chain(c);                                      // (the handle's own stream already waits for the trace: rts_trace_pulse_begin)
     c->recv_dev = nullptr; c->n_recv = 0;
     if (rc != RTS_OK) { c->spec_pending = false; g_open_pulses[c->device & 63]--; return rc; }
+    return RTS_OK;
+}
+
+// ------------------------------------------------------------------------------------- the received set at home without copy calls
+// rts_received_prefetch: for a caller that needs the received rays on the HOST (the simulator's RCS / gain callbacks,
+// ray_tracer.cpp:1198-1256).  Behind the pulse's trace -- and, when the handle's previous pulse received few rays, without
+// waiting for it: the kernels take the count from the device, like rts_trace_pulse_end_uniform's chain -- the received set is
+// ordered, expanded and STORED BY A KERNEL into the handle's pinned host mirror; rts_received_view then waits once and hands out
+// pointers into it.  No history yet, a large set, KEEP_ALL: the call only marks the pulse, and the ordinary (blocking)
+// rts_trace_pulse_end that the first accessor runs feeds the mirror.
+extern "C" int rts_received_prefetch(RtsHandle c)
+{
+    CHECK_HANDLE(c);
+    if (!c->pulse_open) { rts_set_error("rts_received_prefetch: no pulse in flight on this handle"); return RTS_ERR_INVALID; }
+    const bool keep_all = (c->params.flags & RTS_FLAG_KEEP_ALL_RAYS) != 0;
+    const uint32_t cap = c->last_args.max_refr == 0 ? RTS_SMALL_CAP32 : RTS_SMALL_CAP64;
+    { int rc = rts_mirror_reserve(c, cap); if (rc != RTS_OK) return rc; }
+    c->mirror.want = true;
+    const bool speculate = c->post_small && c->spec_enabled && !keep_all && c->n_rays > 0 && c->recv_hint_valid && c->recv_hint <= ((uint64_t)cap * 3ull) / 4ull;
+    if (!speculate) return RTS_OK;
+    c->spec.mode = 1; c->spec_cap = cap;
+    c->pulse_open = false; c->spec_pending = true;                     // (the pulse stays counted as open on its device until it is resolved)
+    c->agg_timed = false; c->fin_timed = false;
+    c->n_recv = cap; c->recv_dev = c->p_counters;
+    const int rc = rts_post_chain(c);
+    c->recv_dev = nullptr; c->n_recv = 0;
+    if (rc != RTS_OK) { c->spec_pending = false; g_open_pulses[c->device & 63]--; return rc; }
+    return RTS_OK;
+}
+
+extern "C" int rts_received_view(RtsHandle c, const PerRayData** rays, const int32_t** paths, const double** rcs_angles, const uint64_t** slots, uint64_t* count)
+{
+    CHECK_HANDLE(c);
+    if (!count) { rts_set_error("rts_received_view: null count"); return RTS_ERR_INVALID; }
+    CHECK_CLOSED(c);
+    const uint64_t R = c->n_recv; const uint32_t D = c->depth;
+    *count = R;
+    if (rays) *rays = nullptr; if (paths) *paths = nullptr; if (rcs_angles) *rcs_angles = nullptr; if (slots) *slots = nullptr;
+    if (R == 0) return RTS_OK;
+    RTS_HIP(rts_stream_wait(c, c->stream));
+    const RtsHostMirror& m = c->mirror;
+    if (m.recv_valid && R <= m.cap) {
+        if (rays) *rays = (const PerRayData*)(m.host + m.o_rays); if (paths) *paths = (const int32_t*)(m.host + m.o_paths);
+        if (rcs_angles) *rcs_angles = (const double*)(m.host + m.o_angles); if (slots) *slots = (const uint64_t*)(m.host + m.o_slots);
+        return RTS_OK;
+    }
+    // no mirror of this set (not asked for, or larger than the mirror): copies into storage the handle keeps
+    if (rays) { c->v_rays.resize(R); RTS_HIP(hipMemcpy(c->v_rays.data(), c->d_rx_rays.p, sizeof(PerRayData) * R, hipMemcpyDeviceToHost)); *rays = c->v_rays.data(); }
+    if (paths && D) { c->v_paths.resize(R * D); RTS_HIP(hipMemcpy(c->v_paths.data(), c->d_rx_paths.p, sizeof(int32_t) * R * D, hipMemcpyDeviceToHost)); *paths = c->v_paths.data(); }
+    if (rcs_angles && D) { c->v_angles.resize(2 * R * D); RTS_HIP(hipMemcpy(c->v_angles.data(), c->d_rx_angles.p, sizeof(double) * 2 * R * D, hipMemcpyDeviceToHost)); *rcs_angles = c->v_angles.data(); }
+    if (slots) { c->v_slots.resize(R); RTS_HIP(hipMemcpy(c->v_slots.data(), c->d_rx_slots.p, sizeof(uint64_t) * R, hipMemcpyDeviceToHost)); *slots = c->v_slots.data(); }
+    return RTS_OK;
+}
+
+// The per-received-ray update of ray_tracer.cpp:1219-1253 when the factors come from the simulator's callbacks: the caller has
+// formed every received ray's final power and Doppler shift on the host (from rts_received_view's records); they replace the
+// traced values on the device, in received order.  Enqueued (the values are copied out of the caller's arrays before the call
+// returns); rts_aggregate follows.
+extern "C" int rts_finalise_values(RtsHandle c, const double* power, const double* doppler, uint64_t count)
+{
+    CHECK_HANDLE(c);
+    CHECK_CLOSED(c);
+    if (count != c->n_recv) { rts_set_error("rts_finalise_values: %llu values for %llu received rays", (unsigned long long)count, (unsigned long long)c->n_recv); return RTS_ERR_INVALID; }
+    if (count == 0) return RTS_OK;
+    if (!power || !doppler) { rts_set_error("rts_finalise_values: null array"); return RTS_ERR_INVALID; }
+    RTS_HIP(hipEventRecord(c->ev[6], c->stream));
+    RtsHostMirror& m = c->mirror;
+    if (!m.host) { int rc = rts_mirror_reserve(c, RTS_SMALL_CAP32); if (rc != RTS_OK) return rc; }
+    if (count <= m.cap) {
+        // (the staging is free: what read it last -- this handle's previous pulse -- was waited for before this pulse was begun)
+        memcpy(m.host + m.o_vpower, power, sizeof(double) * count); memcpy(m.host + m.o_vdoppler, doppler, sizeof(double) * count);
+        int rc = rts_post_set_values(c, (const double*)(m.dev + m.o_vpower), (const double*)(m.dev + m.o_vdoppler)); if (rc != RTS_OK) return rc;
+    } else {                                                            // a set beyond the mirror: blocking uploads into scratch the aggregation overwrites later
+        RTS_HIP(c->d_delay.reserve(count)); RTS_HIP(c->d_phase.reserve(count));
+        RTS_HIP(hipMemcpyAsync(c->d_delay.p, power, sizeof(double) * count, hipMemcpyHostToDevice, c->stream));
+        RTS_HIP(hipMemcpyAsync(c->d_phase.p, doppler, sizeof(double) * count, hipMemcpyHostToDevice, c->stream));
+        int rc = rts_post_set_values(c, c->d_delay.p, c->d_phase.p); if (rc != RTS_OK) return rc;
+        RTS_HIP(hipStreamSynchronize(c->stream));
+    }
+    RTS_HIP(hipEventRecord(c->ev[7], c->stream));
+    c->fin_timed = true; c->stats_pending = true;
+    c->agg_valid = false; c->mirror.recv_valid = false;
+    return RTS_OK;
+}
+
+// Per-ray outputs of the last rts_aggregate (what rs::kernel_wrapper leaves in h_rx_results_arr[].power / .doppler, h_delay_arr,
+// h_phase_arr, h_pathMatch): pointers into the host mirror when the pulse was prefetched (the call waits for the handle's stream
+// once), copies otherwise.  Valid until the handle's next rts_trace_pulse_begin.
+extern "C" int rts_aggregated_view(RtsHandle c, const double** power, const double** doppler, const double** delay, const double** phase, const int32_t** path_match, uint64_t* count)
+{
+    CHECK_HANDLE(c);
+    if (!count) { rts_set_error("rts_aggregated_view: null count"); return RTS_ERR_INVALID; }
+    CHECK_CLOSED(c);
+    if (!c->agg_valid) { rts_set_error("rts_aggregated_view: call rts_aggregate first"); return RTS_ERR_INVALID; }
+    const uint64_t R = c->n_recv;
+    *count = R;
+    if (power) *power = nullptr; if (doppler) *doppler = nullptr; if (delay) *delay = nullptr; if (phase) *phase = nullptr; if (path_match) *path_match = nullptr;
+    if (R == 0) return RTS_OK;
+    RTS_HIP(rts_stream_wait(c, c->stream));
+    const RtsHostMirror& m = c->mirror;
+    if (m.agg_valid && R <= m.cap) {
+        if (power) *power = (const double*)(m.host + m.o_apower); if (doppler) *doppler = (const double*)(m.host + m.o_adoppler);
+        if (delay) *delay = (const double*)(m.host + m.o_adelay); if (phase) *phase = (const double*)(m.host + m.o_aphase); if (path_match) *path_match = (const int32_t*)(m.host + m.o_apm);
+        return RTS_OK;
+    }
+    if (power || doppler) {
+        c->v_rays.resize(R); RTS_HIP(hipMemcpy(c->v_rays.data(), c->d_rx_rays.p, sizeof(PerRayData) * R, hipMemcpyDeviceToHost));
+        c->v_apower.resize(R); c->v_adoppler.resize(R);
+        for (uint64_t i = 0; i < R; i++) { c->v_apower[i] = c->v_rays[i].power; c->v_adoppler[i] = c->v_rays[i].doppler; }
+        if (power) *power = c->v_apower.data(); if (doppler) *doppler = c->v_adoppler.data();
+    }
+    if (delay) { c->v_adelay.resize(R); RTS_HIP(hipMemcpy(c->v_adelay.data(), c->d_delay.p, sizeof(double) * R, hipMemcpyDeviceToHost)); *delay = c->v_adelay.data(); }
+    if (phase) { c->v_aphase.resize(R); RTS_HIP(hipMemcpy(c->v_aphase.data(), c->d_phase.p, sizeof(double) * R, hipMemcpyDeviceToHost)); *phase = c->v_aphase.data(); }
+    if (path_match) { c->v_apm.resize(R); RTS_HIP(hipMemcpy(c->v_apm.data(), c->d_pathmatch.p, sizeof(int32_t) * R, hipMemcpyDeviceToHost)); *path_match = c->v_apm.data(); }
     return RTS_OK;
 }
 
@@ -1385,7 +1533,7 @@ extern "C" int rts_kernel_wrapper_on(RtsHandle h, PerRayData* h_rx_results_arr, 
     if (!h_rx_results_arr || (depthTotal && !h_rx_intersects_arr) || !h_delay_arr || !h_phase_arr || !h_pathMatch) { rts_set_error("rts_kernel_wrapper: null array"); return RTS_ERR_INVALID; }
     RtsContext* c = h;
     if (!c) { int rc = wrapper_context(&c); if (rc != RTS_OK) return rc; }
-    else { CHECK_CLOSED(c); c->agg_valid = false; c->agg_pending.valid = false; c->n_recv = 0; }      // the handle's own received set is overwritten
+    else { CHECK_CLOSED(c); c->agg_valid = false; c->agg_pending.valid = false; c->n_recv = 0; c->mirror.recv_valid = false; c->mirror.agg_valid = false; c->mirror.want = false; }      // the handle's own received set is overwritten
     RTS_HIP(hipSetDevice(c->device));
     const size_t R = receivedRays, D = depthTotal;
     RTS_HIP(c->d_rx_rays.reserve(R)); RTS_HIP(c->d_rx_paths.reserve(R*D + 1)); RTS_HIP(c->d_delay.reserve(R)); RTS_HIP(c->d_phase.reserve(R)); RTS_HIP(c->d_pathmatch.reserve(R));

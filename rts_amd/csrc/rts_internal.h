@@ -242,7 +242,18 @@ struct RtsScene {
 
 #define RTS_SMALL_CAP32 4096u         // received rays the one-block ordering kernels take with 32-bit sort keys (rts_post.hip) ...
 #define RTS_SMALL_CAP64 2048u         // ... and with 64-bit keys; a speculatively enqueued post-processing chain is sized for the smaller of its two sorts
-struct RtsSpecParams { std::vector<double> rcs; double wl = 0, gt = 0, gr = 0, carrier = 0, cspeed = 0; int32_t cube_pulse = -1; uint64_t base = 0; };
+struct RtsSpecParams { std::vector<double> rcs; double wl = 0, gt = 0, gr = 0, carrier = 0, cspeed = 0; int32_t cube_pulse = -1; uint64_t base = 0;
+                       int mode = 0; };     // 0: the uniform chain (rts_trace_pulse_end_uniform); 1: order + expand + the received set to the host mirror (rts_received_prefetch)
+// Host mirror of a pulse's received set and of its aggregation outputs (rts_received_prefetch, the C++ adapter's path): ONE pinned
+// allocation that KERNELS write (k_mirror_rows, k_mirror_agg: only the rows that exist cross the bus, no copy calls) and read
+// (k_set_values: the power / Doppler the simulator's callbacks produced).  cap rows of: PerRayData | path row | RCS-angle row | slot |
+// aggregated power, doppler, delay, phase, pathMatch | values in: power, doppler.
+struct RtsHostMirror {
+    char* host = nullptr; char* dev = nullptr; size_t bytes = 0; uint32_t cap = 0, D = 0;
+    size_t o_rays = 0, o_paths = 0, o_angles = 0, o_slots = 0, o_apower = 0, o_adoppler = 0, o_adelay = 0, o_aphase = 0, o_apm = 0, o_vpower = 0, o_vdoppler = 0;
+    bool recv_valid = false, agg_valid = false;      // the mirror holds the last pulse's received set / aggregation outputs (once the stream has drained)
+    bool want = false;                               // this pulse's post-processing feeds the mirror (set by rts_received_prefetch, cleared by the next rts_trace_pulse_begin)
+};
 // rts_aggregate enqueues; the table is read (stream wait + pinned block -> RtsGroup records) by the first call that needs it
 struct RtsAggPending { bool valid = false, wide = false, rows = false; uint32_t R = 0, D = 0, B = 0, shift = 0, spec = 0; uint64_t base = 0; double* gsum = nullptr; };
 
@@ -255,6 +266,7 @@ struct RtsContext {
     hipStream_t cstream = nullptr; hipEvent_t ev_coop[2];      // the cooperative trace kernel of a launch runs beside the ordinary one; stream created on first use (rts_trace.hip)
     uint32_t coop_grid_max = 1024;      // most blocks of the cooperative kernel (RTS_COOP_GRID)
     uint32_t n_head_hint = 0;           // head count of the handle's previous order build (came home with that launch's counters)
+    uint32_t last_coop_grid = 0;        // blocks of the cooperative kernel in the handle's last launch (0: none was launched)
     hipEvent_t ev[9];
     // scene: the shared static part, and this handle's placement of it
     RtsScene* scene = nullptr;          // never null after rts_create
@@ -308,6 +320,9 @@ struct RtsContext {
     const unsigned long long* recv_dev = nullptr;                           // != nullptr while such a chain is being enqueued: its kernels take the received count from here
     uint64_t recv_hint = 0; bool recv_hint_valid = false;                    // received rays of the handle's previous pulse
     RtsAggPending agg_pending;          // the group table of the last rts_aggregate is still on its way (rts_aggregate_fetch reads it)
+    RtsHostMirror mirror;               // rts_received_prefetch / rts_received_view / rts_finalise_values / rts_aggregated_view
+    std::vector<PerRayData> v_rays; std::vector<int32_t> v_paths; std::vector<double> v_angles, v_apower, v_adoppler, v_adelay, v_aphase; std::vector<uint64_t> v_slots; std::vector<int32_t> v_apm;      // the views' fallback storage (sets beyond the mirror's capacity)
+    RtsRxDev* pin_rx = nullptr; uint32_t pin_rx_cap = 0; std::vector<RtsRxDev> rx_host;      // receivers: last values set (an unchanged set is not uploaded again) and the pinned staging of the asynchronous upload
     RtsCubeParams cube_params; double* cube = nullptr; DevBuf<double> d_cube_own; bool cube_set = false;
     DevBuf<double> d_doppler_own; double* doppler = nullptr; uint32_t doppler_n = 0;       // slow-time transform of the cube (rts_cube_doppler)
     bool agg_delay_in = true;           // rts_aggregate_device: the delay / phase arrays carry initial sums (rs::kernel_wrapper's in-out arguments); false: they start at zero
@@ -326,6 +341,10 @@ int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_vali
 int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a, bool count_traversal, unsigned coop_grid);
 void rts_trace_preload();
 int rts_post_order_and_expand(RtsContext* c);
+int rts_mirror_reserve(RtsContext* c, uint32_t rows);
+int rts_post_mirror_received(RtsContext* c);       // the ordered, expanded received set -> the host mirror (kernel stores, count from c->recv_dev when set)
+int rts_post_mirror_aggregated(RtsContext* c);     // per-ray aggregation outputs -> the host mirror
+int rts_post_set_values(RtsContext* c, const double* power, const double* doppler);      // power / Doppler of the received rays <- device-readable arrays (the mirror's values-in area)
 int rts_post_expand_all(RtsContext* c);
 int rts_cube_accumulate_device(RtsContext* c, uint32_t pulse_index, double cspeed, double carrier);
 int rts_cube_accumulate_paths_device(RtsContext* c, uint32_t pulse_index, int64_t base);

@@ -6,7 +6,9 @@
 // vector<vector<double>>, and the icosphere de-duplication is a sort instead of the
 // reference's O(V^2) std::find over a std::set.
 #include <algorithm>
+#include <cctype>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <numeric>
@@ -162,20 +164,36 @@ extern "C" int rts_file_mesh(const char* v_file, const char* n_file, float yaw, 
     if (*n_triangles < lines) { fclose(fp); *n_triangles = lines; rts_set_error("rts_file_mesh: capacity too small"); return RTS_ERR_CAPACITY; }
     *n_triangles = lines;
     rewind(fp);
-    auto read9 = [&](FILE* f, double* dst) -> bool {
-        for (uint32_t i = 0; i < lines; i++) {
+    // The reference's loop tests fscanf() == EOF only (:459-476): a line that yields fewer than its nine numbers -- a missing
+    // comma, a word where a number belongs -- leaves the remaining coordinates at whatever the vector held (zeros) and the
+    // stream wherever the match failed, i.e. a silently wrong mesh (NaN normals downstream).  A C-ABI that promises status codes
+    // reports it: RTS_ERR_IO naming the file and the 1-based triangle (line) that did not parse.  Well-formed files -- the only
+    // ones whose result the reference defines -- read exactly as there.
+    // (line by line: a line with too few numbers must not borrow the next line's -- fscanf's white space crosses line ends)
+    auto read9 = [&](FILE* f, double* dst, uint32_t* bad_line, int* got) -> bool {
+        char* line = nullptr; size_t cap = 0; bool ok = true;
+        for (uint32_t i = 0; i < lines && ok; i++) {
             double* p = dst + 9*(size_t)i;
-            if (fscanf(f, "%lf %lf %lf, %lf %lf %lf, %lf %lf %lf,\n", p, p+1, p+2, p+3, p+4, p+5, p+6, p+7, p+8) == EOF) return false;
+            int n = EOF, used = -1;
+            if (getline(&line, &cap, f) >= 0) {
+                n = sscanf(line, "%lf %lf %lf, %lf %lf %lf, %lf %lf %lf,%n", p, p+1, p+2, p+3, p+4, p+5, p+6, p+7, p+8, &used);
+                if (n == EOF) n = 0;                                   // (an empty line)
+                if (n == 9 && used < 0) n = 8;                         // the closing comma is missing
+                if (n == 9) for (const char* q = line + used; *q; q++) if (!isspace((unsigned char)*q)) { n = 10; break; }      // something behind it
+            }
+            if (n != 9) { *bad_line = i + 1; *got = n; ok = false; }
         }
-        return true;
+        free(line);
+        return ok;
     };
     memset(vertices, 0, sizeof(double)*9*(size_t)lines); memset(normals, 0, sizeof(double)*9*(size_t)lines);
-    bool ok = read9(fp, vertices); fclose(fp);
-    if (!ok) { rts_set_error("rts_file_mesh: short vertex file %s", v_file); return RTS_ERR_IO; }
+    uint32_t bad = 0; int got = 0;
+    bool ok = read9(fp, vertices, &bad, &got); fclose(fp);
+    if (!ok) { rts_set_error("rts_file_mesh: vertex file %s: triangle %u of %u %s (expected \"x y z, x y z, x y z,\": 9 numbers and nothing else, matched %d)", v_file, bad, lines, got == EOF ? "is missing (file ends early)" : "does not parse", got == EOF ? 0 : got); return RTS_ERR_IO; }
     fp = fopen(n_file, "r");
     if (!fp) { rts_set_error("rts_file_mesh: cannot open vertex normals file %s", n_file); return RTS_ERR_IO; }      // :480-483
-    ok = read9(fp, normals); fclose(fp);
-    if (!ok) { rts_set_error("rts_file_mesh: short normals file %s", n_file); return RTS_ERR_IO; }
+    ok = read9(fp, normals, &bad, &got); fclose(fp);
+    if (!ok) { rts_set_error("rts_file_mesh: normals file %s: triangle %u of %u %s (expected \"x y z, x y z, x y z,\": 9 numbers and nothing else, matched %d)", n_file, bad, lines, got == EOF ? "is missing (file ends early)" : "does not parse", got == EOF ? 0 : got); return RTS_ERR_IO; }
     double R[3][3]; rotation_matrix(yaw, pitch, roll, R);
     rotate_in_place(vertices, 3*(size_t)lines, R);
     rotate_in_place(normals, 3*(size_t)lines, R);

@@ -304,6 +304,97 @@ int rts_post_order_and_expand(RtsContext* c)
     return RTS_OK;
 }
 
+// --------------------------------------------------------------------------- host mirror (rts_received_prefetch; rts_internal.h: RtsHostMirror)
+// The received set of a BASELINE configs[2] pulse is ~2 000 rays x 272 bytes.  Fetched with copy calls it cost the C++ adapter
+// three blocking hipMemcpy from pageable memory per pulse -- 0.12 ms, or 0.34 ms in a process whose runtime had not grown its
+// staging pool (profiles/r04a_adapter_bench.json: the whole host-tree / device-tree difference of round 3) -- and the aggregation
+// another eight uploads and four downloads.  Here kernels store the rows that exist straight into mapped pinned host memory,
+// behind the kernels that produce them, and the host reads them after the ONE wait it has anyway.
+struct RtsMirrorSegs { uint32_t* dst[4]; const uint32_t* src[4]; uint32_t row_words[4]; };
+__global__ void __launch_bounds__(256) k_mirror_rows(const RtsMirrorSegs g, uint32_t R, const unsigned long long* __restrict__ R_dev)
+{
+    if (R_dev) { const unsigned long long v_ = *R_dev; if (v_ > (unsigned long long)R) return; R = (uint32_t)v_; }
+    const uint32_t k = blockIdx.y;
+    const size_t n = (size_t)R * g.row_words[k];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) g.dst[k][i] = g.src[k][i];
+}
+__global__ void k_mirror_agg(const PerRayData* __restrict__ rays, const double* __restrict__ delay, const double* __restrict__ phase, const int32_t* __restrict__ pm, uint32_t R,
+                             double* __restrict__ h_power, double* __restrict__ h_doppler, double* __restrict__ h_delay, double* __restrict__ h_phase, int32_t* __restrict__ h_pm,
+                             const unsigned long long* __restrict__ R_dev)
+{
+    if (R_dev) { const unsigned long long v_ = *R_dev; if (v_ > (unsigned long long)R) return; R = (uint32_t)v_; }
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    h_power[i] = rays[i].power; h_doppler[i] = rays[i].doppler; h_delay[i] = delay[i]; h_phase[i] = phase[i]; h_pm[i] = pm[i];
+}
+// ray_tracer.cpp:1219-1253 with the simulator's own RCS / gain callbacks: the host has formed every received ray's power and
+// Doppler shift; they replace the traced values before the aggregation
+__global__ void k_set_values(PerRayData* __restrict__ rays, const double* __restrict__ power, const double* __restrict__ doppler, uint32_t R)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    rays[i].power = power[i]; rays[i].doppler = doppler[i];
+}
+
+int rts_mirror_reserve(RtsContext* c, uint32_t rows)
+{
+    RtsHostMirror& m = c->mirror;
+    const uint32_t D = c->depth;
+    if (m.host && m.cap >= rows && m.D == D) return RTS_OK;
+    if (m.host) { RTS_HIP(hipStreamSynchronize(c->stream)); (void)hipHostFree(m.host); m.host = nullptr; m.dev = nullptr; m.cap = 0; }
+    uint32_t cap = std::max<uint32_t>(rows, RTS_SMALL_CAP32); cap = (cap + 63u) & ~63u;
+    size_t o = 0;
+    auto take = [&](size_t bytes_per_row) { const size_t at = o; o += ((size_t)cap * bytes_per_row + 255) & ~(size_t)255; return at; };
+    m.o_rays = take(sizeof(PerRayData)); m.o_paths = take(4 * (size_t)std::max(D, 1u)); m.o_angles = take(16 * (size_t)std::max(D, 1u)); m.o_slots = take(8);
+    m.o_apower = take(8); m.o_adoppler = take(8); m.o_adelay = take(8); m.o_aphase = take(8); m.o_apm = take(4); m.o_vpower = take(8); m.o_vdoppler = take(8);
+    RTS_HIP(hipHostMalloc((void**)&m.host, o, hipHostMallocDefault));
+    void* dp = nullptr; RTS_HIP(hipHostGetDevicePointer(&dp, m.host, 0));
+    m.dev = (char*)dp; m.bytes = o; m.cap = cap; m.D = D; m.recv_valid = false; m.agg_valid = false;
+    return RTS_OK;
+}
+
+int rts_post_mirror_received(RtsContext* c)
+{
+    RtsHostMirror& m = c->mirror;
+    const uint32_t R = (uint32_t)c->n_recv, D = c->depth;
+    m.recv_valid = false; m.agg_valid = false;
+    if (R == 0) { m.recv_valid = true; return RTS_OK; }
+    if (R > m.cap) return RTS_OK;                                  // (a set beyond the mirror: the views fall back to copies)
+    RtsMirrorSegs g;
+    g.dst[0] = (uint32_t*)(m.dev + m.o_rays); g.src[0] = (const uint32_t*)c->d_rx_rays.p; g.row_words[0] = sizeof(PerRayData) / 4;
+    g.dst[1] = (uint32_t*)(m.dev + m.o_paths); g.src[1] = (const uint32_t*)c->d_rx_paths.p; g.row_words[1] = D;
+    g.dst[2] = (uint32_t*)(m.dev + m.o_angles); g.src[2] = (const uint32_t*)c->d_rx_angles.p; g.row_words[2] = 4 * D;
+    g.dst[3] = (uint32_t*)(m.dev + m.o_slots); g.src[3] = (const uint32_t*)c->d_rx_slots.p; g.row_words[3] = 2;
+    const uint32_t bx = std::min<uint32_t>(blocks_for((size_t)R * (sizeof(PerRayData) / 4), 256), 64u);
+    k_mirror_rows<<<dim3(bx, 4), 256, 0, c->stream>>>(g, R, c->recv_dev);
+    RTS_HIP(hipGetLastError());
+    m.recv_valid = true;
+    return RTS_OK;
+}
+
+int rts_post_mirror_aggregated(RtsContext* c)
+{
+    RtsHostMirror& m = c->mirror;
+    const uint32_t R = (uint32_t)c->n_recv;
+    m.agg_valid = false;
+    if (R == 0) { m.agg_valid = true; return RTS_OK; }
+    if (!m.host || R > m.cap) return RTS_OK;
+    k_mirror_agg<<<blocks_for(R, 256), 256, 0, c->stream>>>(c->d_rx_rays.p, c->d_delay.p, c->d_phase.p, c->d_pathmatch.p, R, (double*)(m.dev + m.o_apower), (double*)(m.dev + m.o_adoppler),
+                                                           (double*)(m.dev + m.o_adelay), (double*)(m.dev + m.o_aphase), (int32_t*)(m.dev + m.o_apm), c->recv_dev);
+    RTS_HIP(hipGetLastError());
+    m.agg_valid = true;
+    return RTS_OK;
+}
+
+int rts_post_set_values(RtsContext* c, const double* power, const double* doppler)
+{
+    const uint32_t R = (uint32_t)c->n_recv;
+    if (R == 0) return RTS_OK;
+    k_set_values<<<blocks_for(R, 256), 256, 0, c->stream>>>(c->d_rx_rays.p, power, doppler, R);
+    RTS_HIP(hipGetLastError());
+    return RTS_OK;
+}
+
 int rts_post_expand_all(RtsContext* c)
 {
     const uint64_t n64 = (uint64_t)c->n_rays * c->last_args.rows; const uint32_t D = c->depth;

@@ -594,7 +594,7 @@ __device__ __forceinline__ void rts_primary_setup(const RtsTraceArgs& a, const R
 template <bool COUNT, bool KEEP_ALL, bool REFR, bool COOP>
 __device__ __forceinline__ void rts_trace_unit(const RtsTraceArgs& a, const RtsLaunchConsts& lc, const RtsUnitLds& L_, const uint32_t tid, const uint32_t gtid, const uint32_t lane,
                                                const uint32_t slot, const bool pre_on, const bool mask_on, const uint32_t D, const uint32_t max_refr, const dvec3& origin,
-                                               uint32_t& n_nodes, uint32_t& n_tris, bool& hard_overflow, unsigned long long (&lane_stats)[3],
+                                               uint32_t& n_nodes, uint32_t& n_tris, bool& hard_overflow, unsigned long long (&lane_stats)[4],
                                                const uint32_t pre = 0u)      // pre: bit 0 = k_trace ran the pre-filter already, bits 1 / 2 = its may_target / may_rx
 {
       int32_t* const s_stack = L_.stack; int32_t* const s_exch = L_.exch; double* const s_first = L_.first; unsigned long long* const s_path = L_.path; uint32_t* const s_n = L_.n;
@@ -666,6 +666,7 @@ __device__ __forceinline__ void rts_trace_unit(const RtsTraceArgs& a, const RtsL
                     if (COOP) {
                         rts_walk_coop<COUNT>(a, s_stack, s_exch, tid, gtid, lane, lds_cap, &s_n[2 * RTS_BLOCK + tid], TG.root, lr, prev, dir, tmin, best_t, best_leaf, best_prim, t_prune,
                                              n_nodes, n_tris, hard_overflow);
+                        if (COUNT) steps = 1u;                                       // (the segment entered a hierarchy: RtsStats::walked_segments)
                     } else {
                         s_stack[tid] = SENTINEL;
                         int sp = 1;
@@ -690,7 +691,9 @@ __device__ __forceinline__ void rts_trace_unit(const RtsTraceArgs& a, const RtsL
                 atomicMax(&ls[0], steps); atomicAdd(&ls[1], steps);
                 const uint32_t smax = ls[0], ssum = ls[1];
                 lane_stats[0] += 64ull * smax; lane_stats[1] += (unsigned long long)__popcll(act) * smax; lane_stats[2] += ssum;
+                lane_stats[3] += (unsigned long long)__popcll(__ballot(steps > 0u));      // segments that walked at all (the others: cleared by the pre-filter or by every target's bounding sphere)
             }
+            if (COUNT && COOP && steps) lane_stats[3] += 1ull;
             if (!rts_shade<KEEP_ALL, REFR, COOP>(a, L_, tid, gtid, lane, slot, chain, D, max_refr, origin, primary, may_rx, best_t, best_leaf, best_prim, tmin, S, pending, refr_code0)) break;
         }
 
@@ -714,7 +717,7 @@ __device__ __forceinline__ void rts_trace_unit(const RtsTraceArgs& a, const RtsL
 template <bool COUNT, bool KEEP_ALL>
 __device__ __forceinline__ void rts_trace_unit_async(const RtsTraceArgs& a, const RtsLaunchConsts& lc, const RtsUnitLds& L_, const uint32_t tid, const uint32_t gtid, const uint32_t lane,
                                                      const uint32_t slot_in, const bool pre_on, const bool mask_on, const uint32_t D, const dvec3& origin, const long long tile_t0,
-                                                     uint32_t& n_nodes, uint32_t& n_tris, bool& hard_overflow, unsigned long long (&lane_stats)[3])
+                                                     uint32_t& n_nodes, uint32_t& n_tris, bool& hard_overflow, unsigned long long (&lane_stats)[4])
 {
     int32_t* const s_stack = L_.stack; uint32_t* const s_n = L_.n;
     const int SENTINEL = RTS_STACK_SENTINEL;
@@ -816,7 +819,7 @@ __device__ __forceinline__ void rts_sum_counters_body(const uint32_t t, unsigned
 #define RTS_LD64(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
     if (t == 7) { const unsigned long long h = head_count ? (unsigned long long)__hip_atomic_load(head_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL; counters[7] = h; host_cnt[7] = h; }     // the order's head count travels home with the counters (sizes the next cooperative grid)
     if (t == 0) host_cnt[0] = RTS_LD64(&counters[0]);                          // received rays (appended by the trace kernels)
-    if (t >= 8 && t <= 10) host_cnt[t] = RTS_LD64(&counters[t]);               // lane statistics of the counting build
+    if (t >= 8 && t <= 11) host_cnt[t] = RTS_LD64(&counters[t]);               // lane statistics and walked segments of the counting build
     const unsigned int k = t & 7u, lane = t >> 3;                              // 32 partial sums per counter
     unsigned long long v = 0;
     if (k >= 1 && k <= 6) for (unsigned int b = lane; b < n_blocks; b += 32) v += RTS_LD64(&block_counters[(size_t)b * 8 + k]);
@@ -929,7 +932,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR || COOP) ? 2 : 4) k_trace(con
     __shared__ int32_t s_exch[COOP ? RTS_BLOCK : 1];             // exchange rows of the cooperative walk (one 64-entry row per wave)
     __shared__ uint32_t s_lane_scratch[COUNT ? 2 * (RTS_BLOCK / 64) : 1];      // (counting build: per-wave max / sum of a round's walk steps)
     const RtsUnitLds ul = {s_stack, s_exch, s_first, s_path, s_n, s_rx, s_rxp, s_lane_scratch};
-    unsigned long long lane_stats[3] = {0ull, 0ull, 0ull};
+    unsigned long long lane_stats[4] = {0ull, 0ull, 0ull, 0ull};
     const uint32_t per_stripe = (n_units + RTS_TILE_CTRS - 1u) / RTS_TILE_CTRS;
     const uint32_t single_draws = per_stripe >= 1024u ? per_stripe / 4u : per_stripe;      // (short queues: one tile per draw throughout)
     // The pending draw is held in a register of lane 0 (so that its latency hides behind the tiles traced meanwhile) -- except
@@ -1021,6 +1024,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR || COOP) ? 2 : 4) k_trace(con
     // traversal stack is dead by now) -> one plain store per block; k_sum_counters adds the blocks up.  (One atomic per
     // wave on the same two addresses -- 32 k same-line L2 atomics -- cost a fixed ~0.35 ms at the tail of every launch.)
     if (COUNT && !COOP && lane == 0 && lane_stats[0]) { atomicAdd(&a.counters[8], lane_stats[0]); atomicAdd(&a.counters[9], lane_stats[1]); atomicAdd(&a.counters[10], lane_stats[2]); }
+    if (COUNT && lane == 0 && lane_stats[3]) atomicAdd(&a.counters[11], lane_stats[3]);
     // (the thread index is re-formed here from the wave's number -- scalar, kept since the start -- and the lane number instead of
     // being carried through the kernel: the allocator, at its 128-register limit, otherwise parks threadIdx.x in scratch in the
     // prologue and reloads it here)

@@ -204,6 +204,8 @@ def config5(W=216, detail=1.0, rx_radius=50.0):
     s = config3(W=W, detail=detail, rx_radius=rx_radius, n_rx=1)
     s["name"] = s["name"].replace("C3", "C5-moving"); s["n_pulses"] = 1024
     s["motion_fn"] = config5_motion
+    s["tx_track"] = True          # 1024 pulses at 200 m/s are 205 m of flight across a 32 m beam: the transmitter's boresight follows the target
+                                  # (Transmitter::GetRotation is read per pulse, ray_tracer.cpp:888); callers that honour it aim tx dir at motion[0].position
     return s
 
 
@@ -212,6 +214,35 @@ def config5_motion(pulse, speed=200.0, yaw_rate=1.0, prf=1000.0):
     tt = pulse / prf
     R = api.rotation_matrix(yaw_rate * tt, 0.0, 0.0)
     return [dict(position=(0.0, speed * tt, 0.0), velocity=(0.0, speed, 0.0), rotation=R)]
+
+
+def config_sphere6(W=216, subdiv=6, max_refl=6):
+    """The scene of the C++ boundary benchmark (tests/adapter/adapter_bench.cpp over the mock SOARS world), so that the ctypes
+    bench and the C++ adapter are timed on ONE scene: an icosphere of 20 * 4^subdiv triangles (6: 81 920), r = 15 m, 2 km from
+    the transmitter, moving at (200, 20, 0) m/s and yawing at 1 rad/s, four receivers on a 2 km arc, W = 216, 6 bounces."""
+    v, t, n = api.sphere_mesh(subdiv, 15.0)
+    rx = []
+    for k in range(4):
+        a = -0.6 + 0.4 * k
+        pos = (-2000.0 * math.cos(a), 2000.0 * math.sin(a), 20.0 * k)
+        az = math.atan2(-pos[1], -pos[0]); el = math.atan2(-pos[2], math.hypot(pos[0], pos[1]))
+        rx.append(api.rx_sphere(pos, az, el, 50.0, 2.6, 2.6))
+    s = dict(name="sphere6-icosphere-%dtri" % t.shape[0], W=W, max_refl=max_refl, smooth=True, n_pulses=256,
+             meshes=[dict(tris=t, verts=v, normals=n, refl_coeff=0.9, refr_index=1.0)],
+             motion=_static_motion(1, [(0.0, 0.0, 0.0)], [(200.0, 20.0, 0.0)]),
+             tx=dict(origin=(-2000.0, 0.0, 0.0), span=(0.04, 0.04, 0.05), dir=(0.0, 0.0)), rx=rx, carrier=FC, c=C0)
+    s["motion_fn"] = sphere6_motion
+    return s
+
+
+def sphere6_motion(pulse, prf=1000.0):
+    """placement of the adapter benchmark's target at pulse `pulse`: p0 + v t, yaw = 1 rad/s x t (applied for t > 0, as
+    ray_tracer.cpp:993 does)"""
+    tt = pulse / prf
+    m = dict(position=(200.0 * tt, 20.0 * tt, 0.0), velocity=(200.0, 20.0, 0.0))
+    if tt > 0:
+        m["rotation"] = api.rotation_matrix(1.0 * tt, 0.0, 0.0)
+    return [m]
 
 
 def world_vertices(mesh, motion):

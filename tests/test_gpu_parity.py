@@ -1195,6 +1195,47 @@ def test_pulse_end_uniform_equals_the_four_calls(rts, scenes, monkeypatch):
         np.testing.assert_allclose(cube, cube_ref, rtol=0, atol=1e-18 + 1e-12 * np.abs(cube_ref).max())      # (atomic adds: order varies)
 
 
+def test_pulse_end_uniform_with_wide_keys(rts, scenes, monkeypatch):
+    """a (receiver, path) aggregation key beyond 64 bits -- 16 bounces among 8 targets: 16 x 4 + 1 = 65 bits -- is sorted as two
+    words by the GENERAL aggregation chain, whose kernels take the received count from the host: rts_trace_pulse_end_uniform must
+    not enqueue that chain on the device-side count (it then ran over its 2 048-row capacity and exported groups made
+    of stale rows).  Same bits as the four calls, pulse after pulse, with RTS_SPECULATE 1 and 0"""
+    sv, st_, sn = rts.sphere_mesh(1, 3.0)
+    meshes, motion = [], []
+    for i in range(8):
+        a = 2.0 * math.pi * i / 8.0
+        meshes.append(dict(tris=st_, verts=sv, normals=sn, refl_coeff=0.95, refr_index=1.0))
+        motion.append(dict(position=(9.0 * math.cos(a), 9.0 * math.sin(a), 1.5 * (i % 3) - 1.5), velocity=(3.0 * i, -2.0 * i, 0.5)))
+    rx = [scenes._rx_at((-200.0, 0.0, 0.0), (0, 0, 0), 120.0, 2.6), scenes._rx_at((-150.0, 130.0, 10.0), (0, 0, 0), 120.0, 2.6)]
+    spec = dict(name="eight-spheres", W=40, max_refl=16, smooth=True, n_pulses=1, meshes=meshes, motion=motion,
+                tx=dict(origin=(-200.0, 0.0, 0.0), span=(0.14, 0.14, 0.05), dir=(0.0, 0.0)), rx=rx, carrier=1.0e10, c=299792458.0)
+    tx = spec["tx"]; cs, fc, wl = 299792458.0, 1.0e10, 0.03
+
+    def run(mode):
+        monkeypatch.setenv("RTS_SPECULATE", "0" if mode == "nospec" else "1")
+        tr = H.gpu_tracer(rts, spec)
+        out = []
+        for k in range(4):
+            mo = [dict(m, position=tuple(np.add(m["position"], (0.05 * k, 0.0, 0.0)))) for m in motion]
+            tr.trace_begin(tx["origin"], tx["span"], tx["dir"], mo)
+            if mode == "four":
+                tr.trace_end(); tr.finalise_uniform(None, wl, 1.0, 1.0, fc, cs); g = tr.aggregate(cs, fc)
+            else:
+                tr.trace_end_uniform(None, wl, 1.0, 1.0, fc, cs); g = tr.groups()
+            out.append((g, tr.stats()["received"], tr.received(), tr.aggregated()))
+        tr.close()
+        return out
+    ref = run("four")
+    assert all(0 < o[1] < 1500 for o in ref), [o[1] for o in ref]                      # small enough that a narrow key WOULD speculate
+    assert max(int((o[2]["path"] >= 0).sum(axis=1).max()) for o in ref) >= 2            # multi-bounce paths among the targets
+    for mode in ("spec", "nospec"):
+        for k, ((ga, na, ra, aa), (gb, nb, rb, ab)) in enumerate(zip(ref, run(mode))):
+            assert na == nb and ga.tobytes() == gb.tobytes(), (mode, k, na, nb, len(ga), len(gb))
+            assert ra["results"].tobytes() == rb["results"].tobytes() and np.array_equal(ra["path"], rb["path"]), (mode, k)
+            for f in ("results", "delay", "phase", "pathMatch"):
+                assert aa[f].tobytes() == ab[f].tobytes(), (mode, k, f)
+
+
 def test_asynchronous_bounces_are_invisible(rts, scenes, monkeypatch):
     """RTS_ASYNC_IDLE0 > 0 selects the kernel whose lanes advance from segment to segment on their own
     (rts_trace_unit_async: a walk phase ends as soon as `idle` lanes have come out of their walks; they are shaded and
