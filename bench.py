@@ -377,11 +377,17 @@ def main():
     if args.warmup:
         run_cpi(0, args.warmup)
     prepared = prepare_cpi(args.warmup, args.steps)
+    # The harness is Python: its cyclic garbage collector, once a few thousand ctypes / numpy objects have been allocated by the
+    # loop, makes full passes over everything torch imported (~40 ms each) -- measured as 0.15 ms per pulse in trace_begin at 256
+    # pulses, none at 64 (gpurun_out r04h).  Not the product's time: collected once here, then off for the timed interval.
+    import gc
+    gc.collect(); gc.disable()
     sync()
     t0 = time.perf_counter()
     acc, resp = run_cpi(args.warmup, args.steps, prepared)
     sync()
     dt = time.perf_counter() - t0
+    gc.enable()
     assert len(resp) == args.steps, "every pulse of the interval must come back with its responses"
     # range-Doppler map of the interval (slow-time FFT of the summed cube): a check of the dense product, outside the timed
     # region -- the hot path ends with the per-pulse responses and the (all-reduced) cube
@@ -510,6 +516,8 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
+    if api._PY_LAP:
+        print("python side of trace_begin, us per call:", {k: round(v / max(api._PY_LAP["n"], 1) * 1e6, 1) for k, v in api._PY_LAP.items() if k != "n"}, file=sys.stderr)
     for t in trs:
         t.close()
     if dist is not None:

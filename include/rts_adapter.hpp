@@ -135,10 +135,15 @@ void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlo
     if (devices.empty()) { int n = 0; check(rts_device_count(&n), "rts_device_count"); for (int i = 0; i < n; i++) devices.push_back(i); }
     if (devices.empty()) throw std::runtime_error("rts_adapter: no HIP device");
     const unsigned S = (unsigned)devices.size(), F = opt.in_flight > 1 ? opt.in_flight : 1u;
+    // Whole pulses are finished in TWO stages (below): a pulse keeps its handle one pulse longer than it is "in flight", so a set
+    // has F + 1 slots -- unless pulses are strictly sequential (F = 1 on one set) or split over the sets (finished in one stage).
+    const bool split = opt.shard_rays && S > 1;
+    const bool staged = !split && !(S == 1 && F == 1);
+    const unsigned Fh = staged ? F + 1 : F;
     struct Handles { std::vector<RtsHandle> h; ~Handles() { for (RtsHandle x : h) rts_destroy(x); } } hs;
-    hs.h.assign((size_t)S * F, nullptr);
+    hs.h.assign((size_t)S * Fh, nullptr);
     auto H = [&](unsigned set, unsigned slot) -> RtsHandle& { return hs.h[(size_t)slot * S + set]; };
-    for (unsigned f = 0; f < F; f++) for (unsigned s = 0; s < S; s++) { params.device = devices[s]; check(rts_create(&params, &H(s, f)), "rts_create"); }
+    for (unsigned f = 0; f < Fh; f++) for (unsigned s = 0; s < S; s++) { params.device = devices[s]; check(rts_create(&params, &H(s, f)), "rts_create"); }
 
     // scene: once (the reference regenerates identical meshes every pulse)
     std::vector<HostMesh> host(targsize); std::vector<RtsMesh> meshes(targsize);
@@ -151,7 +156,7 @@ void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlo
     }
     for (unsigned s = 0; s < S; s++) {
         check(rts_set_scene(H(s, 0), meshes.data(), targsize), "rts_set_scene");
-        for (unsigned f = 1; f < F; f++) check(rts_share_scene(H(s, f), H(s, 0)), "rts_share_scene");
+        for (unsigned f = 1; f < Fh; f++) check(rts_share_scene(H(s, f), H(s, 0)), "rts_share_scene");
     }
 
     for (size_t tx_i = 0; tx_i < transmitters.size(); tx_i++) {                // ray_tracer.cpp:806
@@ -206,6 +211,8 @@ void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlo
             pulse.motion = motion.data();
             tl = lap(RunTimes::BEGIN_HOST, tl);
             check(rts_trace_pulse_begin(h, &pulse), "rts_trace_pulse_begin");   // replaces :1126-1165
+            // a whole pulse: its received set comes home through the handle's pinned mirror, enqueued behind the trace
+            if (!split) check(rts_received_prefetch(h), "rts_received_prefetch");
             lap(RunTimes::BEGIN_CALL, tl);
             return time_t;
         };
@@ -295,14 +302,87 @@ void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlo
             lap(RunTimes::RESPONSES, tl);
         };
 
+        // ---- a WHOLE pulse on one handle, finished in two stages that never wait for work they have just enqueued, and without
+        // a copy call: stage 1 -- the received set is read where the device left it (rts_received_view: the handle's pinned
+        // mirror, stored by a kernel behind the trace), the simulator's callbacks form every ray's power and Doppler shift
+        // (:1198-1256), which go back for the aggregation on the device-resident set (rts_finalise_values + rts_aggregate:
+        // rs::kernel_wrapper's arithmetic without its eight uploads); stage 2, one pulse later -- the per-ray outputs are read
+        // (rts_aggregated_view), unique paths, Responses (:1290-1321).  Same bits as finish_pulse (one device routine serves both).
+        struct Stage1 { RtsHandle h; double time_t; uint64_t R; const PerRayData* rays; };
+        auto finish_stage1 = [&](RtsHandle h, double time_t) -> Stage1 {
+            double tl = tm ? now_s() : 0.0;
+            Stage1 o{h, time_t, 0, nullptr};
+            const int32_t* rx_intersects = nullptr; const double* rcs_angle = nullptr;
+            check(rts_received_view(h, &o.rays, &rx_intersects, &rcs_angle, nullptr, &o.R), "rts_received_view");
+            tl = lap(RunTimes::END_WAIT, tl);
+            if (opt.last_stats) rts_get_stats(h, opt.last_stats);
+            const uint64_t R = o.R;
+            if (R == 0) return o;
+            if (R > 0x7ffffffeULL) throw std::runtime_error("rts_adapter: more than 2^31 received rays in one pulse");
+            tl = lap(RunTimes::GET_RECEIVED, tl);
+            std::vector<double> power(R), doppler(R);
+            const Vec3 origin = trpos;
+            for (uint64_t i = 0; i < R; i++) {                                 // :1198-1256 for the received rays
+                const PerRayData& r = o.rays[i];
+                auto* recv = receivers[r.received];
+                const Vec3 repos = recv->GetPosition(0);
+                SVec3 transvec, recvvec;
+                if (r.reflDepth == 0 && r.refrDepth == 0) {
+                    transvec = SVec3(Vec3(origin.x - repos.x, origin.y - repos.y, origin.z - repos.z));
+                    recvvec = SVec3(Vec3(repos.x - origin.x, repos.y - origin.y, repos.z - origin.z));
+                } else {
+                    transvec = SVec3(Vec3(r.firstHitPoint.x - origin.x, r.firstHitPoint.y - origin.y, r.firstHitPoint.z - origin.z));
+                    recvvec = SVec3(Vec3(r.prevHitPoint.x - repos.x, r.prevHitPoint.y - repos.y, r.prevHitPoint.z - repos.z));
+                }
+                transvec.length = 1; recvvec.length = 1;
+                const double delay = r.rayLength / cspeed;
+                double pw = r.power;
+                for (unsigned d = 0; d < D; d++) {
+                    const int targ_k = rx_intersects[(size_t)i * D + d];
+                    if (targ_k >= 0) pw *= targets[targ_k]->GetRCS(rcs_angle[((size_t)i * D + d) * 2], rcs_angle[((size_t)i * D + d) * 2 + 1], Wl);
+                }
+                const double Gt = trans->GetGain(transvec, trans->GetRotation(time_t), Wl);
+                const double Gr = recv->GetGain(recvvec, recv->GetRotation(delay + time_t), Wl);
+                pw *= (Wl * Wl * Gt * Gr);
+                const double Vr = r.doppler / 2;
+                power[i] = pw; doppler[i] = carrier * (((1 + Vr / cspeed) / (1 - Vr / cspeed)) - 1);
+            }
+            tl = lap(RunTimes::CALLBACKS, tl);
+            check(rts_finalise_values(h, power.data(), doppler.data(), R), "rts_finalise_values");
+            check(rts_aggregate(h, cspeed, carrier, 0), "rts_aggregate");      // rs::kernel_wrapper's arithmetic (aggregation.cu:32-97) on the device-resident set; enqueued
+            lap(RunTimes::AGGREGATE, tl);
+            return o;
+        };
+        auto finish_stage2 = [&](const Stage1& o) {
+            double tl = tm ? now_s() : 0.0;
+            struct Done { RunTimes* t; decltype(now_s)& now; ~Done() { if (t) t->pulse_done_s.push_back(now()); } } done_stamp{tm, now_s};
+            if (o.R == 0) return;
+            const double *power = nullptr, *doppler = nullptr, *delay = nullptr, *phase = nullptr; const int32_t* pathMatch = nullptr; uint64_t R = 0;
+            check(rts_aggregated_view(o.h, &power, &doppler, &delay, &phase, &pathMatch, &R), "rts_aggregated_view");
+            if (R != o.R) throw std::runtime_error("rts_adapter: the aggregation returned another number of rays than were received");
+            tl = lap(RunTimes::AGGREGATE, tl);
+            std::vector<int> uniq(pathMatch, pathMatch + R);                   // :1290-1292
+            std::sort(uniq.begin(), uniq.end()); uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+            for (int i : uniq) {                                               // :1301-1321
+                if (i < 0 || (uint64_t)i >= R) throw std::runtime_error("rts_adapter: aggregation returned a representative ray outside the received list");
+                const int rx = o.rays[i].received;
+                typename Tr::InterpPoint point(power[i], o.time_t + delay[i], delay[i], doppler[i], phase[i], receivers[rx]->GetNoiseTemperature());
+                auto* response = new typename Tr::Response(wave, trans);
+                response->AddInterpPoint(point);
+                receivers[rx]->AddResponse(response);
+            }
+            lap(RunTimes::RESPONSES, tl);
+        };
+
         // ---- the pulse loop (:843), software-pipelined.  Pulses are FINISHED strictly in pulse order, so every side effect
         // (AddResponse) happens in the order of the sequential loop whatever the number of handle sets and slots.
         struct InFlight { std::vector<RtsHandle> parts; double time_t; };
         std::vector<InFlight> fly; size_t done = 0;                            // fly[k] for pulse k; finished up to `done`
-        const unsigned lanes = opt.shard_rays ? F : S * F;                     // pulses in flight
+        std::vector<Stage1> st1; size_t done2 = 0;                             // staged finish: st1[k] once pulse k's stage 1 has run; stage 2 done up to `done2`
+        const unsigned lanes = split ? F : S * F;                              // pulses in flight
         for (unsigned k = 0; k < pulseCount; k++) {
             InFlight fl;
-            if (opt.shard_rays && S > 1) {                                     // every handle set takes its interleaved part of pulse k
+            if (split) {                                                       // every handle set takes its interleaved part of pulse k
                 const unsigned f = k % F;
                 for (unsigned s = 0; s < S; s++) {
                     RtsPlanItem item{}; uint32_t n_items = 0;
@@ -310,14 +390,31 @@ void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlo
                     fl.time_t = begin_pulse(k, H(s, f), item); fl.parts.push_back(H(s, f));
                 }
             } else {                                                           // whole pulse on the next (set, slot) in turn
-                const unsigned w = k % (S * F);
+                const unsigned w = k % (S * Fh);
                 RtsPlanItem item{}; item.ray_first = 0; item.ray_count = launchTotal;
                 fl.time_t = begin_pulse(k, H(w % S, w / S), item); fl.parts.push_back(H(w % S, w / S));
             }
             fly.push_back(fl);
-            if (fly.size() - done >= lanes) { finish_pulse(fly[done].parts, fly[done].time_t); done++; }
+            if (fly.size() - done >= lanes) {
+                if (split) finish_pulse(fly[done].parts, fly[done].time_t);
+                else {
+                    st1.push_back(finish_stage1(fly[done].parts[0], fly[done].time_t));
+                    // stage 2 of the pulse BEFORE (its handle is the next one a pulse is begun on); sequential pulses: of this one
+                    if (!staged) { finish_stage2(st1[done2]); done2++; }
+                    else if (st1.size() - done2 >= 2) { finish_stage2(st1[done2]); done2++; }
+                }
+                done++;
+            }
         }
-        while (done < fly.size()) { finish_pulse(fly[done].parts, fly[done].time_t); done++; }
+        while (done < fly.size()) {
+            if (split) finish_pulse(fly[done].parts, fly[done].time_t);
+            else {
+                st1.push_back(finish_stage1(fly[done].parts[0], fly[done].time_t));
+                while (st1.size() - done2 >= (staged ? 2u : 1u)) { finish_stage2(st1[done2]); done2++; }
+            }
+            done++;
+        }
+        while (done2 < st1.size()) { finish_stage2(st1[done2]); done2++; }
     }
 }
 

@@ -163,7 +163,7 @@ typedef struct RtsGroup {
 int rts_create(const RtsParams* params, RtsHandle* out);      /* rtContextCreate .. ray_tracer.cpp:532-800 */
 int rts_destroy(RtsHandle h);                                 /* ray_tracer.cpp:1342-1360                  */
 const char* rts_last_error(void);
-/* 16 hex digits: SHA-256 (truncated) of the sources the library was built from (rts_amd/csrc/*.hip|cpp|h + rts_amd.h + rts_prd.h,
+/* 16 hex digits: SHA-256 (truncated) of the sources the library was built from (the .hip / .cpp / .h files of rts_amd/csrc + rts_amd.h + rts_prd.h,
  * in byte order of their names).  Profiles record it; bench.py refuses to price a run with counters of another build. */
 const char* rts_build_id(void);
 /* Restrict the calling process's threads to the CPUs of `device`'s NUMA node (one process per GPU, on the GPU's socket: kernel
@@ -398,6 +398,11 @@ int rts_rx_sphere(const double* rx_position, double azimuth, double elevation, d
  * roots[n_targets] = root node per target (-1: no geometry).  Any output may be NULL (sizes: call with NULLs first). */
 int rts_get_bvh(RtsHandle h, void* nodes128, uint32_t* leaf_prim, int32_t* roots, uint32_t node_capacity,
                 uint32_t leaf_capacity, uint32_t* n_leaves);
+/* The host SAH builder (rts_sah.cpp; RTS_FLAG_HOST_BUILD) on one mesh, without a device: nodes128 / leaf_prim as rts_get_bvh returns
+ * them (leaf_prim[slot] = triangle index of the mesh).  Null outputs: sizes only.  Pure host code. */
+int rts_build_hierarchy_host(const double* vertices, const uint32_t* triangles, uint32_t n_triangles, double split_budget, void* nodes128,
+                             uint32_t node_capacity, uint32_t* leaf_prim, uint32_t leaf_capacity, uint32_t* n_nodes, uint32_t* n_leaves,
+                             int32_t* root);
 int rts_self_test_math(RtsHandle h, const float* y, const float* x, float* atan2f_out, const double* a,
                        const double* b, double* div_out, double* sqrt_out, uint32_t n);
 

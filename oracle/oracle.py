@@ -13,7 +13,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RTS_ORACLE_NATIVE=1 (set by bench.py's cpu_baseline leg before the first use): the -O3 -march=native build
 _NATIVE = os.environ.get("RTS_ORACLE_NATIVE", "0") == "1"
-_LIB = os.path.join(_HERE, "librts_oracle_native.so" if _NATIVE else "librts_oracle.so")
+# RTS_ORACLE_LIB: another build of the same source, made by the caller (the sanitizer build, oracle/Makefile: asan)
+_LIB = os.environ.get("RTS_ORACLE_LIB") or os.path.join(_HERE, "librts_oracle_native.so" if _NATIVE else "librts_oracle.so")
 
 # PerRayData, /root/reference/ray_tracer.h:13-28 (144 B, 16-aligned; offsets verified with hipcc)
 PRD_DTYPE = np.dtype({
@@ -27,6 +28,8 @@ PRD_DTYPE = np.dtype({
 
 def build(force=False):
     src = os.path.join(_HERE, "rts_oracle.cpp")
+    if os.environ.get("RTS_ORACLE_LIB"):
+        return _LIB
     if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
         # a child of a profiled process must not inherit the profiler's preload (it would initialise the GPU in make / g++)
         env = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD", "HSA_TOOLS_LIB") and not k.startswith("ROCP")}

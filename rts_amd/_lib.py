@@ -154,7 +154,7 @@ EXPORTS = ["rts_create", "rts_destroy", "rts_last_error", "rts_device_count", "r
            "rts_merge_groups", "rts_groups_to_responses", "rts_kernel_wrapper", "rts_vertex_rotation",
            "rts_rotation_matrix", "rts_rect_mesh", "rts_sphere_mesh", "rts_file_mesh", "rts_rx_sphere", "rts_get_bvh",
            "rts_build_id", "rts_bind_host_to_device", "rts_get_lane_stats", "rts_self_test_math", "rts_cube_attach", "rts_cube_accumulate", "rts_cube_get", "rts_cube_accumulate_paths", "rts_cube_doppler", "rts_cube_doppler_get", "rts_plan_cpi", "rts_cube_reduce", "rts_kernel_wrapper_on",
-           "rts_received_prefetch", "rts_received_view", "rts_finalise_values", "rts_aggregated_view"]
+           "rts_received_prefetch", "rts_received_view", "rts_finalise_values", "rts_aggregated_view", "rts_build_hierarchy_host"]
 
 
 def lib():
@@ -185,6 +185,7 @@ def lib():
         "rts_get_received": [vp, vp, vp, vp, vp, u64],
         "rts_get_all_rays": [vp, vp, vp, vp, vp, vp, u64],
         "rts_finalise_uniform": [vp, vp, dbl, dbl, dbl, dbl, dbl],
+        "rts_build_hierarchy_host": [vp, vp, u32, dbl, vp, u32, vp, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_int32)],
         "rts_received_prefetch": [vp],
         "rts_received_view": [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)],
         "rts_finalise_values": [vp, vp, vp, u64],

@@ -79,10 +79,24 @@ def kernel_wrapper(rx_results, rx_intersects, cspeed, carrier, ray_total, max_th
     return dict(results=res, delay=delay, phase=phase, pathMatch=pm)
 
 
+def build_hierarchy_host(verts, tris, split_budget=2.0):
+    """rts_build_hierarchy_host: the host SAH builder on one mesh (no device): (nodes [n][32] f32 view, leaf_prim, root)"""
+    v = np.ascontiguousarray(verts, np.float64); t = np.ascontiguousarray(tris, np.uint32)
+    nn = C.c_uint32(0); nl = C.c_uint32(0); root = C.c_int32(-1)
+    check(L.lib().rts_build_hierarchy_host(ptr(v), ptr(t), t.shape[0], split_budget, None, 0, None, 0, C.byref(nn), C.byref(nl), C.byref(root)))
+    nodes = np.zeros((max(nn.value, 1), 32), np.float32); leaf = np.zeros(max(nl.value, 1), np.uint32)
+    check(L.lib().rts_build_hierarchy_host(ptr(v), ptr(t), t.shape[0], split_budget, ptr(nodes), nodes.shape[0], ptr(leaf), leaf.shape[0], C.byref(nn), C.byref(nl), C.byref(root)))
+    return nodes[:nn.value], leaf[:nl.value], root.value
+
+
 def device_count():
     n = C.c_int(0)
     rc = L.lib().rts_device_count(C.byref(n))
     return n.value if rc == 0 else 0
+
+
+import os as _os
+_PY_LAP = {} if _os.environ.get("RTS_PY_LAP") == "1" else None
 
 
 # ------------------------------------------------------------------------------- the tracer handle
@@ -151,7 +165,18 @@ class Tracer:
 
     def trace_begin(self, origin, tx_span, tx_dir, motion=None, ray_first=0, ray_count=0, interleave=None):
         """enqueue a pulse (rts_trace_pulse_begin); trace_end() -- or any accessor -- completes it"""
-        check(L.lib().rts_trace_pulse_begin(self.h, C.byref(self._pulse(origin, tx_span, tx_dir, motion, ray_first, ray_count, interleave))))
+        if _PY_LAP is None:
+            check(L.lib().rts_trace_pulse_begin(self.h, C.byref(self._pulse(origin, tx_span, tx_dir, motion, ray_first, ray_count, interleave))))
+            return
+        import time                                                  # RTS_PY_LAP=1: where this call's time goes on the Python side
+        t0 = time.perf_counter(); p = self._pulse(origin, tx_span, tx_dir, motion, ray_first, ray_count, interleave)
+        t1 = time.perf_counter(); f = L.lib().rts_trace_pulse_begin
+        t2 = time.perf_counter(); rc = f(self.h, C.byref(p))
+        t3 = time.perf_counter(); check(rc)
+        t4 = time.perf_counter()
+        for k, v in zip(("marshal", "lookup", "call", "check"), (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+            _PY_LAP[k] = _PY_LAP.get(k, 0.0) + v
+        _PY_LAP["n"] = _PY_LAP.get("n", 0) + 1
 
     def trace_end(self):
         check(L.lib().rts_trace_pulse_end(self.h))
@@ -161,21 +186,30 @@ class Tracer:
         check(L.lib().rts_link_handles(self.h, other.h))
 
     def _pulse(self, origin, tx_span, tx_dir, motion, ray_first, ray_count, interleave):
-        p = L.RtsPulse()
-        p.ray_origin[:] = list(origin); p.tx_span[:] = list(tx_span); p.tx_dir[:] = list(tx_dir)
+        # ONE RtsPulse and ONE motion array per tracer, refilled per call: the library copies what it needs before
+        # rts_trace_pulse_begin returns, and a per-call ctypes allocation is a gc-tracked object -- in a long pulse loop the
+        # collector's full passes over everything torch has imported then land in this function (0.15 ms per call at 256 pulses)
+        p = self._pulse_struct = getattr(self, "_pulse_struct", None) or L.RtsPulse()
+        p.ray_origin[:] = origin; p.tx_span[:] = tx_span; p.tx_dir[:] = tx_dir
         p.ray_first = ray_first; p.ray_count = ray_count
-        if interleave is not None:                                   # (tile, parts, part)
-            p.interleave_tile, p.interleave_parts, p.interleave_part = interleave
+        p.interleave_tile, p.interleave_parts, p.interleave_part = interleave if interleave is not None else (0, 0, 0)      # (tile, parts, part)
         if motion is not None:
             assert len(motion) == self.n_targets
-            marr = (L.RtsTargetMotion * max(len(motion), 1))()
+            marr = getattr(self, "_motion_arr", None)
+            if marr is None or len(marr) != max(len(motion), 1):
+                marr = self._motion_arr = (L.RtsTargetMotion * max(len(motion), 1))()
+                self._motion_ptr = C.cast(marr, C.POINTER(L.RtsTargetMotion))
             for i, m in enumerate(motion):
-                marr[i].position[:] = list(m["position"]); marr[i].velocity[:] = list(m.get("velocity", (0, 0, 0)))
+                q = marr[i]
+                q.position[:] = m["position"]; q.velocity[:] = m.get("velocity", (0.0, 0.0, 0.0))
                 rot = m.get("rotation")
                 if rot is not None:
-                    marr[i].rotation[:] = list(np.asarray(rot, np.float64).reshape(9)); marr[i].has_rotation = 1
-            p.motion = C.cast(marr, C.POINTER(L.RtsTargetMotion))
-            self._keep = [marr]
+                    q.rotation[:] = np.asarray(rot, np.float64).reshape(9).tolist(); q.has_rotation = 1
+                else:
+                    q.has_rotation = 0
+            p.motion = self._motion_ptr
+        else:
+            p.motion = None
         return p
 
     def stats(self):

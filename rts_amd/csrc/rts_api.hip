@@ -183,6 +183,15 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     return RTS_OK;
 }
 
+// RTS_LAP=1: where the host side of rts_trace_pulse_begin spends its time, per section, summed per handle and printed by
+// rts_destroy (stderr) -- the tool behind DESIGN.md's "what a slow run is"
+static int rts_lap_on() { static int on = -1; if (on < 0) { const char* e = getenv("RTS_LAP"); on = (e && e[0] == '1') ? 1 : 0; } return on; }
+struct RtsLapTimer {
+    RtsContext* c; std::chrono::steady_clock::time_point t0; bool on;
+    explicit RtsLapTimer(RtsContext* c_) : c(c_), on(rts_lap_on() != 0) { if (on) t0 = std::chrono::steady_clock::now(); }
+    void lap(int k) { if (!on) return; const auto t1 = std::chrono::steady_clock::now(); c->lap_s[k] += std::chrono::duration<double>(t1 - t0).count(); c->lap_n[k]++; t0 = t1; }
+};
+
 // pulses begun and not yet ended, per device: a trace launch that will share the GPU with another pulse's kernels leaves block
 // slots free for them (RtsContext::grid_spare), a lone pulse takes the whole chip
 static std::atomic<int> g_open_pulses[64];
@@ -192,6 +201,12 @@ extern "C" int rts_destroy(RtsHandle c)
     if (!c) return RTS_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (rts_lap_on() && c->lap_n[0]) {
+        static const char* names[8] = {"host prep", "upload + fill", "scene place", "buffers + tile order", "events + trace launch", "hipSetDevice", "resolve previous", ""};
+        fprintf(stderr, "[rts lap] handle %p, %llu pulses begun, us per pulse:", (void*)c, (unsigned long long)c->lap_n[0]);
+        for (int k = 0; k < 7; k++) fprintf(stderr, " %s %.1f |", names[k], c->lap_s[k] / (double)c->lap_n[0] * 1e6);
+        fprintf(stderr, "\n");
+    }
     if (c->pulse_open || c->spec_pending) { c->pulse_open = false; c->spec_pending = false; g_open_pulses[c->device & 63]--; }
     rts_comm_cache_forget(c);
     if (c->scene && --c->scene->refs == 0) { c->scene->release(); delete c->scene; }
@@ -608,10 +623,14 @@ extern "C" int rts_trace_pulse(RtsHandle c, const RtsPulse* p)
 // Everything of a pulse up to and including the trace kernel, left in flight on the handle's stream.
 extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
 {
+    if (!c) { rts_set_error("null handle"); return RTS_ERR_INVALID; }
+    RtsLapTimer lt(c);
     CHECK_HANDLE(c);
+    lt.lap(5);
     if (!p) { rts_set_error("rts_trace_pulse: null pulse"); return RTS_ERR_INVALID; }
     if (c->pulse_open) { rts_set_error("rts_trace_pulse_begin: the previous pulse of this handle was begun but not ended"); return RTS_ERR_INVALID; }
     if (c->spec_pending) { int rc_ = rts_spec_resolve(c); if (rc_ != RTS_OK) return rc_; }
+    lt.lap(6);
     const uint32_t W = c->params.width;
     const uint64_t total = (uint64_t)W * W * W;
     uint64_t first = p->ray_first, count = p->ray_count ? p->ray_count : (total > first ? total - first : 0);
@@ -689,6 +708,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     fill_mask_frame(lc, pre_filter && c->scene->n_prims > 0);
     for (int k = 0; k < 3; k++) { lc.f_bs[k] = (float)(&lc.bsx)[k]; lc.f_st[k] = (float)(&lc.stx)[k]; }
     for (int k = 0; k < 9; k++) { lc.f_rot[k] = (float)lc.rot[k]; lc.f_rot1[k] = (float)lc.rot1[k]; }
+    lt.lap(0);
     // ---- the pulse's parameters in ONE upload: launch constants, and -- when a target moved -- the placements behind them
     c->pin->lc = lc;
     RTS_HIP(hipMemcpyAsync(c->d_params.p, &c->pin->lc, moved && n_targets ? offsetof(RtsPinned, td) + sizeof(RtsTargetDev) * n_targets : sizeof(RtsLaunchConsts), hipMemcpyHostToDevice, st));
@@ -698,9 +718,11 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     RTS_HIP(c->d_tile_ctr.reserve(RTS_ZERO_WORDS + RTS_MASK_WORDS + 64));
     RTS_HIP(hipMemsetAsync(c->d_tile_ctr.p, 0, sizeof(uint32_t) * (((RTS_ZERO_WORDS + (lc.mask.n ? (size_t)lc.mask.n * lc.mask.n / 32u + 1u : 0u)) + 63u) & ~(size_t)63u), st));      // (a whole number of 256-byte pieces: the runtime splits an odd-sized fill into two kernels)
     uint32_t* const pmask = c->d_tile_ctr.p + RTS_ZERO_WORDS;
+    lt.lap(1);
     { int rc = rts_scene_place(c, lc, moved, pmask); if (rc != RTS_OK) return rc; }      // placement (a target moved) + the primary-ray mask: one pass over the leaves for both
     if (moved) { RTS_STAGE(c, "scene_place"); c->bvh_valid = true; c->stats.bvh_rebuilt = 1; }
     RTS_HIP(hipEventRecord(c->ev[1], st));
+    lt.lap(2);
     a.ray_first = first; a.n_rays = n; a.W = W; a.max_refl = c->params.max_refl; a.smooth = c->params.interpolate_smooth ? 1u : 0u;
     a.n_prims = c->scene->n_prims; a.n_targets = n_targets; a.n_rx = c->n_rx; a.keep_all = keep_all ? 1u : 0u;
     a.max_refr = c->params.max_refr; a.rows = a.max_refr ? c->params.max_refl + 3 : 1;
@@ -758,6 +780,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     if (tl_path) { RTS_HIP(c->d_timeline.reserve(cnt_tl + 1)); RTS_HIP(hipMemsetAsync(c->d_timeline.p, 0, sizeof(unsigned long long) * (cnt_tl + 1), st)); a.timeline = c->d_timeline.p; }
     c->last_args = a;
 
+    lt.lap(3);
     // ---- trace
     RTS_STAGE(c, "pre-trace");
     RTS_HIP(hipEventRecord(c->ev[8], st));                       // scene + per-pulse buffers of this handle are ready
@@ -782,6 +805,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     RTS_STAGE(c, "k_trace");
     RTS_HIP(hipEventRecord(c->ev[3], c->tstream));
     RTS_HIP(hipStreamWaitEvent(st, c->ev[3], 0));                // everything later on this handle's stream follows its trace
+    lt.lap(4);
     // (the eight counters were written into the pinned block by k_sum_counters itself: no copy)
     c->pulse_open = true; g_open_pulses[c->device & 63]++;
     if (tl_path) {

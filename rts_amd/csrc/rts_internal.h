@@ -330,6 +330,7 @@ struct RtsContext {
     RtsPinned* pin = nullptr; RtsPinned* pin_dev = nullptr;      // pinned host staging and its address on the device: kernels write the small per-pulse read-backs (counters, group table) straight into it
     bool rcs_uploaded = false; DevBuf<double> d_rcsval; int n_cu = 0; bool stats_pending = false; bool agg_timed = false, fin_timed = false;
     RtsStats stats;
+    double lap_s[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t lap_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // RTS_LAP=1: host time per section of rts_trace_pulse_begin
     RtsGate* gate = nullptr; bool pulse_open = false;   // gate: never null after rts_create
 };
 

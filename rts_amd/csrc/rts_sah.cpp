@@ -275,3 +275,22 @@ int rts_sah_build(const double* verts, const uint32_t* tris, uint32_t n_tris, do
     for (int k = 0; k < 3; k++) { out.lo[k] = N[0].box.lo[k]; out.hi[k] = N[0].box.hi[k]; out.max_abs = std::max(out.max_abs, std::max(std::fabs(out.lo[k]), std::fabs(out.hi[k]))); }
     return RTS_OK;
 }
+
+// The host builder on its own, without a device (tests: the invariants of the hierarchy, and the builder under the sanitizers):
+// nodes as rts_get_bvh returns them (128-byte records, leaf children as ~slot), leaf_prim[slot] = triangle index.  Two calls:
+// null outputs give the sizes.
+extern "C" int rts_build_hierarchy_host(const double* vertices, const uint32_t* triangles, uint32_t n_triangles, double split_budget, void* nodes128, uint32_t node_capacity,
+                                        uint32_t* leaf_prim, uint32_t leaf_capacity, uint32_t* n_nodes, uint32_t* n_leaves, int32_t* root)
+{
+    if ((n_triangles && (!vertices || !triangles)) || !n_nodes || !n_leaves) { rts_set_error("rts_build_hierarchy_host: null argument"); return RTS_ERR_INVALID; }
+    std::vector<RtsNode4> nodes; std::vector<uint32_t> lp; RtsBlasInfo info; memset(&info, 0, sizeof(info));
+    const int rc = rts_sah_build(vertices, triangles, n_triangles, split_budget, nodes, lp, info);
+    if (rc != RTS_OK) return rc;
+    *n_nodes = (uint32_t)nodes.size(); *n_leaves = (uint32_t)lp.size();
+    if (root) *root = info.root;
+    if (!nodes128 && !leaf_prim) return RTS_OK;
+    if (!nodes128 || !leaf_prim || node_capacity < nodes.size() || leaf_capacity < lp.size()) { rts_set_error("rts_build_hierarchy_host: capacity too small (%zu nodes, %zu leaf slots)", nodes.size(), lp.size()); return RTS_ERR_CAPACITY; }
+    if (!nodes.empty()) memcpy(nodes128, nodes.data(), sizeof(RtsNode4) * nodes.size());
+    if (!lp.empty()) memcpy(leaf_prim, lp.data(), sizeof(uint32_t) * lp.size());
+    return RTS_OK;
+}

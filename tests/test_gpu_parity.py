@@ -1195,6 +1195,69 @@ def test_pulse_end_uniform_equals_the_four_calls(rts, scenes, monkeypatch):
         np.testing.assert_allclose(cube, cube_ref, rtol=0, atol=1e-18 + 1e-12 * np.abs(cube_ref).max())      # (atomic adds: order varies)
 
 
+def test_host_mirror_equals_the_copy_calls(rts, scenes, monkeypatch):
+    """rts_received_prefetch / rts_received_view / rts_finalise_values / rts_aggregate / rts_aggregated_view -- the C++ adapter's
+    per-pulse path: the received set stored into pinned host memory by a kernel behind the trace (on the device-side count from
+    the handle's second pulse on), the simulator's per-ray power / Doppler sent back, per-ray aggregation outputs read from the
+    mirror -- against rts_get_received + rs::kernel_wrapper (the reference's boundary, aggregation.cuh:19-22) on a second handle:
+    same bits, for a first pulse (no history: blocking path feeds the mirror), ~1 700-ray pulses (speculative), a pulse of three
+    launch indices, pulses beyond the mirror's 4 096 rows (served by copies) before and after small ones, RTS_SPECULATE=0"""
+    c3 = scenes.config3(W=64, detail=0.3, rx_radius=300.0)
+    tx = c3["tx"]; n_all = c3["W"] ** 3
+    cs, fc = 299792458.0, 1.0e10
+
+    def prefix_with(lo_R, hi_R):
+        tr = H.gpu_tracer(rts, c3); lo, hi = 1, n_all
+        for _ in range(40):
+            mid = (lo + hi) // 2
+            _, st = H.gpu_trace(rts, c3, tr=tr, ray_first=0, ray_count=mid)
+            if st["received"] > hi_R: hi = mid
+            elif st["received"] < lo_R: lo = mid
+            else: tr.close(); return mid
+        raise AssertionError("no prefix")
+    small, big = prefix_with(1500, 1800), prefix_with(5000, 9000)
+    plan = [small, small, 3, big, small, big, big, small]
+
+    def callbacks(rec):
+        """stand-in for the simulator's RCS / gain callbacks: any deterministic function of the received records"""
+        r = rec["results"]; ang = rec["rcs_angle"]
+        w = 1.0 + 0.25 * np.cos(np.where(rec["path"] >= 0, ang[..., 0], 0.0)).sum(axis=1) + 0.1 * np.sin(r["firstHitPoint"][:, 1])
+        vr = r["doppler"] / 2
+        return r["power"] * w * 9.0e-4, fc * (((1 + vr / cs) / (1 - vr / cs)) - 1)
+
+    ref = H.gpu_tracer(rts, c3)
+    want = []
+    for count in plan:
+        ref.trace(tx["origin"], tx["span"], tx["dir"], c3["motion"], ray_first=0, ray_count=count)
+        rec = ref.received()
+        pw, dp = callbacks(rec)
+        res = rec["results"].copy(); res["power"] = pw; res["doppler"] = dp
+        want.append((rec, rts.kernel_wrapper(res, rec["path"], cs, fc, n_all)))
+    ref.close()
+    assert max(len(w[0]["results"]) for w in want) > 4096 > min(len(w[0]["results"]) for w in want if len(w[0]["results"]) > 100)
+    for spec in ("1", "0"):
+        monkeypatch.setenv("RTS_SPECULATE", spec)
+        tr = H.gpu_tracer(rts, c3)
+        for k, count in enumerate(plan):
+            tr.trace_begin(tx["origin"], tx["span"], tx["dir"], c3["motion"], ray_first=0, ray_count=count)
+            tr.received_prefetch()
+            rec = tr.received_view()
+            wrec, wagg = want[k]
+            H.assert_prd_equal(rec["results"], wrec["results"], "received records (%s, pulse %d)" % (spec, k))      # (field by field: the records' padding bytes are whatever the two handles' buffers held)
+            assert np.array_equal(rec["path"], wrec["path"]) and np.array_equal(rec["slots"], wrec["slots"]), (spec, k)
+            assert rec["rcs_angle"].tobytes() == wrec["rcs_angle"].tobytes(), (spec, k)
+            assert tr.received_count() == len(wrec["results"])
+            pw, dp = callbacks(rec)
+            tr.finalise_values(pw, dp)
+            tr.aggregate(cs, fc, 0, fetch=False)
+            agg = tr.aggregated_view()
+            assert agg["power"].tobytes() == wagg["results"]["power"].tobytes() and agg["doppler"].tobytes() == wagg["results"]["doppler"].tobytes(), (spec, k)
+            assert agg["delay"].tobytes() == wagg["delay"].tobytes() and agg["phase"].tobytes() == wagg["phase"].tobytes() and np.array_equal(agg["pathMatch"], wagg["pathMatch"]), (spec, k)
+            again = tr.received()                       # the copy call after the aggregation: the rays carry the group values now (as after rs::kernel_wrapper)
+            assert again["results"]["power"].tobytes() == wagg["results"]["power"].tobytes(), (spec, k)
+        tr.close()
+
+
 def test_pulse_end_uniform_with_wide_keys(rts, scenes, monkeypatch):
     """a (receiver, path) aggregation key beyond 64 bits -- 16 bounces among 8 targets: 16 x 4 + 1 = 65 bits -- is sorted as two
     words by the GENERAL aggregation chain, whose kernels take the received count from the host: rts_trace_pulse_end_uniform must
@@ -1206,7 +1269,7 @@ def test_pulse_end_uniform_with_wide_keys(rts, scenes, monkeypatch):
         a = 2.0 * math.pi * i / 8.0
         meshes.append(dict(tris=st_, verts=sv, normals=sn, refl_coeff=0.95, refr_index=1.0))
         motion.append(dict(position=(9.0 * math.cos(a), 9.0 * math.sin(a), 1.5 * (i % 3) - 1.5), velocity=(3.0 * i, -2.0 * i, 0.5)))
-    rx = [scenes._rx_at((-200.0, 0.0, 0.0), (0, 0, 0), 120.0, 2.6), scenes._rx_at((-150.0, 130.0, 10.0), (0, 0, 0), 120.0, 2.6)]
+    rx = [scenes._rx_at((-200.0, 60.0, 0.0), (0, 0, 0), 12.0, 2.6), scenes._rx_at((-150.0, 130.0, 10.0), (0, 0, 0), 12.0, 2.6)]
     spec = dict(name="eight-spheres", W=40, max_refl=16, smooth=True, n_pulses=1, meshes=meshes, motion=motion,
                 tx=dict(origin=(-200.0, 0.0, 0.0), span=(0.14, 0.14, 0.05), dir=(0.0, 0.0)), rx=rx, carrier=1.0e10, c=299792458.0)
     tx = spec["tx"]; cs, fc, wl = 299792458.0, 1.0e10, 0.03

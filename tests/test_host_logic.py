@@ -112,6 +112,67 @@ def test_file_mesh_reports_malformed_lines(rts, tmp_path, where, damage):
     assert t.shape == (12, 3) and np.isfinite(v).all() and np.isfinite(n).all()
 
 
+def check_bvh4(nodes, leaf_prim, root, tris_verts, all_reachable=True):
+    """invariants of one mesh's BVH4 as the library stores it (nodes [n][32] f32 view of the 128-byte records): every node reachable
+    exactly once from the root, child boxes nested in the parent's, unused slots unreachable points, every triangle in at least
+    one leaf slot, an unsplit triangle strictly inside its (padded) box, the boxes of a split triangle's references together
+    covering its vertices and its centroid"""
+    nprim = tris_verts.shape[0]
+    refs = np.bincount(leaf_prim, minlength=nprim)
+    assert refs.min() >= 1
+    child = nodes[:, 24:28].copy().view(np.int32)
+    lo = np.stack([nodes[:, 0:4], nodes[:, 4:8], nodes[:, 8:12]], axis=2); hi = np.stack([nodes[:, 12:16], nodes[:, 16:20], nodes[:, 20:24]], axis=2)
+    seen_nodes = np.zeros(len(nodes), bool); seen_leaves = np.zeros(len(leaf_prim), bool); covered = np.zeros((nprim, 4), bool)
+    stack = [(int(root), np.full(3, -np.inf), np.full(3, np.inf))]
+    while stack:
+        i, plo, phi = stack.pop()
+        assert not seen_nodes[i]; seen_nodes[i] = True
+        used = 0
+        for k in range(4):
+            c = child[i, k]
+            if c == 0x7fffffff:
+                assert (lo[i, k] == hi[i, k]).all() and (lo[i, k] > 1e38).all()
+                continue
+            used += 1
+            assert (lo[i, k] >= plo).all() and (hi[i, k] <= phi).all()
+            if c < 0:
+                leaf = ~c; assert not seen_leaves[leaf]; seen_leaves[leaf] = True
+                p = leaf_prim[leaf]
+                pts = np.concatenate([tris_verts[p], tris_verts[p].mean(axis=0, keepdims=True)])
+                inside = ((pts > lo[i, k].astype(np.float64)) & (pts < hi[i, k].astype(np.float64))).all(axis=1)
+                covered[p] |= inside
+                if refs[p] == 1:
+                    assert inside.all()
+            else:
+                stack.append((int(c), lo[i, k], hi[i, k]))
+        assert used >= 1
+    assert seen_leaves.all() and covered.all() and (seen_nodes.all() or not all_reachable)
+    return refs
+
+
+def test_host_sah_builder_invariants(rts):
+    """rts_sah.cpp without a device (rts_build_hierarchy_host): the airframe's ellipsoids with their pole fans (split references),
+    an icosphere, a single triangle, a mesh with a non-finite vertex (that triangle gets no leaf), no triangles at all"""
+    from rts_amd import scenes
+    v, t, _ = scenes.aircraft_mesh(detail=0.05)
+    nodes, leaf, root = rts.build_hierarchy_host(v, t)
+    refs = check_bvh4(nodes, leaf, root, v[t])
+    assert refs.max() > 1 and len(leaf) > len(t)                      # the sliver fans are cut into several references
+    nodes0, leaf0, root0 = rts.build_hierarchy_host(v, t, split_budget=0.0)
+    assert len(leaf0) == len(t) and check_bvh4(nodes0, leaf0, root0, v[t]).max() == 1
+    sv, st, _ = rts.sphere_mesh(3, 2.0)
+    check_bvh4(*rts.build_hierarchy_host(sv, st), sv[st])
+    one_v = np.array([[3.0, -2, -2], [3.0, 2, -2], [3.2, 0, 2.5]]); one_t = np.array([[0, 1, 2]], np.uint32)
+    n1, l1, r1 = rts.build_hierarchy_host(one_v, one_t)
+    assert len(n1) == 1 and set(l1.tolist()) == {0} and r1 == 0 and check_bvh4(n1, l1, r1, one_v[one_t]).max() <= 8
+    bv = sv.copy(); bv[st[5, 1]] = np.nan
+    nb, lb, rb = rts.build_hierarchy_host(bv, st)
+    hit = np.isnan(bv[st]).any(axis=(1, 2))
+    assert hit.sum() >= 1 and not np.isin(np.nonzero(hit)[0], lb).any() and set(np.nonzero(~hit)[0]) == set(lb.tolist())
+    ne, le, re_ = rts.build_hierarchy_host(np.zeros((0, 3)), np.zeros((0, 3), np.uint32))
+    assert len(le) == 0 and re_ < 0
+
+
 def test_vertex_rotation_and_rx_sphere_match_oracle(rts, oracle):
     rng = np.random.default_rng(2)
     v = rng.normal(size=(50, 3))
