@@ -167,6 +167,7 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     { const char* e = getenv("RTS_SUM_IN_KERNEL"); if (e) c->sum_in_kernel = atoi(e) != 0; }
     { const char* e = getenv("RTS_SPIN_WAIT"); if (e) c->spin_wait = atoi(e) != 0; }
     { const char* e = getenv("RTS_TILE_SORT"); if (e) c->tile_bucket_order = strcmp(e, "radix") != 0; }
+    { const char* e = getenv("RTS_XCD_AFFINE"); if (e) c->xcd_affine = e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2); }
     { const char* e = getenv("RTS_SPEC_STREAM"); if (e) c->spec_on_trace_stream = strcmp(e, "trace") == 0; }
     { const char* e = getenv("RTS_SPECULATE"); if (e) c->spec_enabled = atoi(e) != 0; }
     { const char* e = getenv("RTS_POST_SMALL"); if (e) c->post_small = atoi(e) != 0; }
@@ -176,6 +177,7 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     { const char* e = getenv("RTS_COOP_SEG"); if (e) c->coop_seg_cost = (uint32_t)std::max(0, atoi(e)); }
     { const char* e = getenv("RTS_COOP_SEG_RATIO"); if (e) c->coop_seg_ratio = std::max(0.0, atof(e)); }
     { const char* e = getenv("RTS_COOP_BIG"); if (e) c->coop_big = std::max(0.0, atof(e)); }
+    { const char* e = getenv("RTS_COOP_SPREAD"); if (e) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) c->coop_spread = (uint32_t)v; } }
     { const char* e = getenv("RTS_COOP_GRID"); if (e) c->coop_grid_max = (uint32_t)std::min(4096, std::max(1, atoi(e))); }
     { const char* e = getenv("RTS_EW_REL"); if (e) { const double v = atof(e); if (v > 0) c->ew_rel = v; } }
     { const char* e = getenv("RTS_STACK_LDS_DEBUG"); if (e) { int v = atoi(e); if (v >= 1 && v <= RTS_STACK_LDS) c->stack_lds = (uint32_t)v; } }   // tests: force the spill path
@@ -215,6 +217,7 @@ extern "C" int rts_destroy(RtsHandle c)
     c->d_params.release();
     c->d_leaves.release(); c->d_sort_tmp.release(); c->d_rx.release(); c->d_recv.release(); c->d_all.release();
     c->d_block_counters.release(); c->d_timeline.release(); c->d_tile_cost.release(); c->d_tile_key.release(); c->d_tile_key_sorted.release(); c->d_tile_id.release(); c->d_tile_order.release(); c->d_tile_hist.release(); c->d_tile_ctr.release(); c->d_dir_hist.release(); c->d_pmask.release(); c->d_child.release(); c->d_rk64.release(); c->d_rk64_sorted.release(); c->d_hit_prim.release(); c->d_hit_t.release(); c->d_stack_ovf.release();
+    c->d_xcd.release();
     c->d_rk.release(); c->d_rk_sorted.release(); c->d_ri.release(); c->d_ri_sorted.release(); c->d_rx_rays.release(); c->d_rx_paths.release();
     c->d_rx_angles.release(); c->d_rx_slots.release(); c->d_all_rays.release(); c->d_all_paths.release(); c->d_all_angles.release();
     c->d_akeys.release(); c->d_akeys_sorted.release(); c->d_aidx.release(); c->d_aidx_sorted.release(); c->d_ghead.release(); c->d_gid.release();
@@ -592,14 +595,14 @@ extern "C" int rts_reserve(RtsHandle c, uint64_t n_rays)
     const size_t threads = (size_t)c->n_cu * 64 * RTS_BLOCK;             // upper bound of any launch's grid
     const uint32_t H = c->params.max_refl + 1;
     RTS_HIP(c->d_recv.reserve((size_t)n * chains + 1));
-    RTS_HIP(c->d_tile_ctr.reserve(RTS_ZERO_WORDS + RTS_MASK_WORDS + 64)); c->p_counters = reinterpret_cast<unsigned long long*>(c->d_tile_ctr.p + 2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE + 4);
+    RTS_HIP(c->d_tile_ctr.reserve(RTS_ZERO_WORDS + RTS_MASK_WORDS + 64)); c->p_counters = reinterpret_cast<unsigned long long*>(c->d_tile_ctr.p + RTS_OFF_COUNTERS);
     RTS_HIP(c->d_dir_hist.reserve((size_t)(c->params.max_refr ? 3 * H : std::max<uint32_t>(c->params.max_refl, 1)) * 3 * n + 4));
     const size_t coop_threads = c->coop_frac > 0.0 ? (size_t)c->coop_grid_max * RTS_BLOCK : 0;
     if (c->params.max_refr) RTS_HIP(c->d_child.reserve(2 * (threads + coop_threads)));
     RTS_HIP(c->d_stack_ovf.reserve((size_t)RTS_STACK_OVF * ((size_t)c->n_cu * 1024 + coop_threads)));
     RTS_HIP(c->d_block_counters.reserve(((size_t)c->n_cu * 64 + c->coop_grid_max) * 8));
     const size_t n_tiles = (size_t)((n + RTS_WTILE - 1) / RTS_WTILE), n_hist = (size_t)((W3 + RTS_WTILE - 1) / RTS_WTILE);
-    RTS_HIP(c->d_tile_ctr.reserve(RTS_ZERO_WORDS + RTS_MASK_WORDS + 64)); c->p_counters = reinterpret_cast<unsigned long long*>(c->d_tile_ctr.p + 2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE + 4); RTS_HIP(c->d_tile_cost.reserve(n_tiles)); RTS_HIP(c->d_tile_key.reserve(n_tiles)); RTS_HIP(c->d_tile_key_sorted.reserve(n_tiles));
+    RTS_HIP(c->d_tile_ctr.reserve(RTS_ZERO_WORDS + RTS_MASK_WORDS + 64)); c->p_counters = reinterpret_cast<unsigned long long*>(c->d_tile_ctr.p + RTS_OFF_COUNTERS); RTS_HIP(c->d_tile_cost.reserve(n_tiles)); RTS_HIP(c->d_tile_key.reserve(n_tiles)); RTS_HIP(c->d_tile_key_sorted.reserve(n_tiles));
     RTS_HIP(c->d_tile_id.reserve(n_tiles)); RTS_HIP(c->d_tile_order.reserve(n_tiles));
     if (c->tile_hist_n != (uint32_t)n_hist) {
         RTS_HIP(c->d_tile_hist.reserve(n_hist)); RTS_HIP(hipMemsetAsync(c->d_tile_hist.p, 0, sizeof(uint32_t) * n_hist, c->stream));
@@ -730,6 +733,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     if ((uint64_t)n * chains > 0xfffffff0ULL) { rts_set_error("rts_trace_pulse: rays x chains exceeds 2^32"); return RTS_ERR_UNSUPPORTED; }
     a.total_threads = grid * RTS_BLOCK;
     a.async_idle0 = c->async_idle0; a.async_idle1 = c->async_idle1; a.async_age = c->async_age;
+    a.coop_spread = c->coop_spread;
     a.coop_seg_cost = c->coop_seg_cost; a.coop_min_cost = c->coop_seg_cost ? std::min<uint32_t>(c->coop_floor, 1875u) : 0u;      // (nothing shorter than 50 us is looked at; RTS_COOP_SEG=0: every tile is flagged)
     if (c->coop_seg_cost && c->last_units_per_segment > 0.0)
         a.coop_seg_cost = (uint32_t)std::min(4.0e9, std::max((double)c->coop_seg_cost, c->coop_seg_ratio * c->last_units_per_segment));
@@ -757,7 +761,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
         const uint64_t sig[4] = {n, first, ((uint64_t)il_parts << 32) | il_tile, il_part};
         const bool aligned = first % RTS_WTILE == 0 && (il_parts <= 1 || il_tile % RTS_WTILE == 0);
         const uint32_t n_hist = (uint32_t)((total + RTS_WTILE - 1) / RTS_WTILE);
-        RTS_HIP(c->d_tile_ctr.reserve(RTS_ZERO_WORDS + RTS_MASK_WORDS + 64)); c->p_counters = reinterpret_cast<unsigned long long*>(c->d_tile_ctr.p + 2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE + 4); a.counters = c->p_counters;
+        RTS_HIP(c->d_tile_ctr.reserve(RTS_ZERO_WORDS + RTS_MASK_WORDS + 64)); c->p_counters = reinterpret_cast<unsigned long long*>(c->d_tile_ctr.p + RTS_OFF_COUNTERS); a.counters = c->p_counters;
         a.tile_ctr = c->d_tile_ctr.p;
         if (lpt && aligned && n_tiles > grid * (RTS_BLOCK / RTS_WTILE)) {
             if (c->tile_hist_n != n_hist) {
@@ -766,7 +770,8 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
             }
             if (c->tile_cost_pending || c->tile_hist_any) {
                 int rc = rts_tile_order_build(c, c->tile_cost_sig, c->tile_cost_pending, sig, n_tiles, grid * (RTS_BLOCK / RTS_WTILE)); if (rc != RTS_OK) return rc;
-                a.tile_order = c->d_tile_order.p; a.tile_head = c->coop_frac > 0.0 ? c->d_tile_ctr.p + 2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE + 2 : nullptr; a.tile_head_all = a.tile_head; c->tile_hist_any = true;
+                a.xcd_seg = c->xcd_affine_now ? c->d_xcd.p : nullptr;
+                a.tile_order = c->d_tile_order.p; a.tile_head = c->coop_frac > 0.0 ? c->d_tile_ctr.p + RTS_OFF_HEAD + 2 : nullptr; a.tile_head_all = a.tile_head; c->tile_hist_any = true;
             }
             const bool merged_all = c->tile_cost_pending && (c->tile_cost_sig[0] + RTS_WTILE - 1) / RTS_WTILE >= n_tiles && c->d_tile_cost.cap >= n_tiles;      // k_tile_merge read AND cleared the records
             RTS_HIP(c->d_tile_cost.reserve(n_tiles));

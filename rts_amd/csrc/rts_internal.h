@@ -81,8 +81,21 @@ static_assert(sizeof(RtsChildState) == 128, "child state size");
 #define RTS_TILE_CTRS 64           // striped draw counters of the tile queue
 #endif
 #define RTS_TILE_BUCKETS 1024       // bins of the tiles' counting order (rts_post.hip: k_tile_bucket_*)
-#define RTS_ZERO_WORDS (2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE + 4 + 32 + RTS_TILE_BUCKETS)      // the dwords one fill clears per launch: draw counters x 2 kernels, head words, 16 u64 counters, the order's bins
 #define RTS_TILE_CTR_STRIDE 32     // ... one per 128-byte line: same-LINE atomics serialise in L2 (~10 ns each) whatever their address
+// XCD-AFFINE sub-orders (big launches, rts_post.hip: rts_tile_order_build): the order is cut into a head-rest segment + one segment
+// per XCD (a contiguous band of the lattice holding an eighth of the cost last seen), each drawn through 8 counters of its own
+#define RTS_XCD 8
+#define RTS_SEG_STRIPES 8
+#define RTS_TILE_CTRS_LAYOUT ((RTS_XCD + 1) * RTS_SEG_STRIPES + 8)       // counters reserved per kernel in the zero block (>= RTS_TILE_CTRS)
+#define RTS_COARSE_CELLS 1024       // cost of the last launch by 1/1024 of its tile range (the bands' boundaries come from it)
+// the zero block: ONE fill per launch clears [draw counters of the ordinary kernel | of the cooperative kernel | head words: cost
+// sum lo, hi, head count, ticket | the launch's 16 u64 counters | the order's bins | the coarse cost cells]
+#define RTS_OFF_CTR_COOP (RTS_TILE_CTRS_LAYOUT * RTS_TILE_CTR_STRIDE)
+#define RTS_OFF_HEAD (2 * RTS_TILE_CTRS_LAYOUT * RTS_TILE_CTR_STRIDE)
+#define RTS_OFF_COUNTERS (RTS_OFF_HEAD + 4)
+#define RTS_OFF_BINS (RTS_OFF_COUNTERS + 32)
+#define RTS_OFF_COARSE (RTS_OFF_BINS + RTS_TILE_BUCKETS)
+#define RTS_ZERO_WORDS (RTS_OFF_COARSE + RTS_COARSE_CELLS)
 #ifndef RTS_STACK_LDS
 #define RTS_STACK_LDS 24            // traversal stack entries kept in LDS per lane
 #endif
@@ -163,7 +176,9 @@ struct RtsTraceArgs {
     uint32_t slab_threads;          // row length of the per-thread slabs (stack_ovf, child): total_threads + the cooperative kernel's threads
     const uint32_t* tile_order;     // [wave tiles] tile ids in descending order of the cost last seen by the handle (null: identity)
     uint32_t* tile_cost;            // [wave tiles] out: duration of the tile (shader clocks >> 6, + 1)
-    uint32_t* tile_ctr;             // [RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE] draw counters (element s * STRIDE), zero at launch
+    uint32_t* tile_ctr;             // the zero block: draw counters (element s * RTS_TILE_CTR_STRIDE; the cooperative kernel's at RTS_OFF_CTR_COOP), zero at launch
+    uint32_t coop_spread;           // 1, 2, 4 or 8: XCD lists a head tile's 64 cooperative units are dealt to (rts_trace.hip)
+    const uint32_t* xcd_seg;        // != null: XCD-affine sub-orders -- [RTS_XCD + 1] first position of each band's segment in tile_order (the last entry: its end)
     const uint32_t* tile_head;      // [1] number of tiles at the head of tile_order that are traced as 64 cooperative units (null: none)
     const uint32_t* tile_head_all;  // the same word whether or not this launch has a cooperative kernel (read back with the counters)
     uint32_t* done_ctr; uint32_t n_blocks_all; unsigned long long* host_cnt;      // the last block of the launch (ticket from done_ctr, zero at launch) sums the block counters and writes them home
@@ -265,6 +280,7 @@ struct RtsContext {
     hipStream_t tstream = nullptr;      // trace kernels (the link group's, see RtsGate)
     hipStream_t cstream = nullptr; hipEvent_t ev_coop[2];      // the cooperative trace kernel of a launch runs beside the ordinary one; stream created on first use (rts_trace.hip)
     uint32_t coop_grid_max = 1024;      // most blocks of the cooperative kernel (RTS_COOP_GRID)
+    uint32_t coop_spread = 1;           // XCD lists a head tile's units are dealt to (RTS_COOP_SPREAD = 1 / 2 / 4 / 8)
     uint32_t n_head_hint = 0;           // head count of the handle's previous order build (came home with that launch's counters)
     uint32_t last_coop_grid = 0;        // blocks of the cooperative kernel in the handle's last launch (0: none was launched)
     hipEvent_t ev[9];
@@ -314,6 +330,7 @@ struct RtsContext {
                                         // release / acquire fences (one per block) write back and invalidate L2, and the post-processing behind the trace took 0.40 instead of 0.34 ms
     bool spin_wait = true;              // the pulse's two host waits poll the stream instead of blocking (rts_stream_wait; RTS_SPIN_WAIT=0)
     bool tile_bucket_order = true;      // tile order by counting bins instead of a radix sort (RTS_TILE_SORT=radix: the sort)
+    int xcd_affine = 0; bool xcd_affine_now = false; uint32_t xcd_bnd_tiles = 0; DevBuf<uint32_t> d_xcd;      // XCD-affine sub-orders of the ORDINARY kernel (RTS_XCD_AFFINE = 0, the default / 1 / auto; rts_post.hip: rts_tile_order_build) -- measured slower, DESIGN.md section 5
     bool post_small = true;             // received sets of up to 4096 rays are ordered / finished by single blocks (RTS_POST_SMALL=0: the general chain)
     hipEvent_t ev_spec = nullptr; uint32_t spec_cap = RTS_SMALL_CAP64; bool spec_on_trace_stream = false;      // (RTS_SPEC_STREAM=trace: the speculative chain behind the trace kernel on ITS stream)
     RtsSpecParams spec; bool spec_pending = false, spec_enabled = true;      // rts_trace_pulse_end_uniform: parameters of the chain; a chain enqueued on the device-side count awaits its resolution (RTS_SPECULATE=0: never)

@@ -140,7 +140,7 @@ __device__ __forceinline__ uint32_t tile_global(const RtsTileShape& s, uint32_t 
 struct RtsHeadRule { double frac, big; uint32_t floor_cost, resident_waves; };
 
 // fold the costs measured by the previous launch into the history
-__global__ void k_tile_merge(uint32_t* __restrict__ cost, RtsTileShape prev, uint32_t* __restrict__ hist, uint32_t n_hist, unsigned long long* __restrict__ head_sum)
+__global__ void k_tile_merge(uint32_t* __restrict__ cost, RtsTileShape prev, uint32_t* __restrict__ hist, uint32_t n_hist, unsigned long long* __restrict__ head_sum, uint32_t* __restrict__ coarse)
 {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long v64 = 0;
@@ -149,6 +149,16 @@ __global__ void k_tile_merge(uint32_t* __restrict__ cost, RtsTileShape prev, uin
         if (v && g < n_hist) hist[g] = v;
         v64 = v & 0x7fffffffu;
         cost[j] = 0u;                                                          // (ready for the coming launch: no fill of its own)
+    }
+    if (coarse) {                                                              // (uniform) XCD-affine sub-orders: the launch's cost by 1/1024 of its tile range, in units of 16
+        __shared__ uint32_t s_cc[257];                                         // a block's 256 tiles touch at most 257 cells (one or two when the launch is large)
+        for (uint32_t q = threadIdx.x; q < 257u; q += blockDim.x) s_cc[q] = 0u;
+        __syncthreads();
+        const uint32_t cell0 = (uint32_t)(((unsigned long long)(blockIdx.x * blockDim.x) * RTS_COARSE_CELLS) / prev.n_tiles);
+        if (j < prev.n_tiles && v64) atomicAdd(&s_cc[(uint32_t)(((unsigned long long)j * RTS_COARSE_CELLS) / prev.n_tiles) - cell0], (uint32_t)((v64 + 15u) >> 4));
+        __syncthreads();
+        for (uint32_t q = threadIdx.x; q < 257u; q += blockDim.x) if (s_cc[q] && cell0 + q < RTS_COARSE_CELLS) atomicAdd(&coarse[cell0 + q], s_cc[q]);
+        __syncthreads();
     }
     // one atomic per BLOCK (per wave they were 2 400 on one address for a C3 launch: ~25 us of serialised L2 atomics on the
     // critical chain of every pulse)
@@ -163,7 +173,8 @@ __global__ void k_tile_merge(uint32_t* __restrict__ cost, RtsTileShape prev, uin
 // known within 16 global tiles of it (expensive regions are contiguous in launch-index space).  Flagged records sort first
 // (their bit 31), by descending cost: the flagged tiles above the threshold are a prefix of the order.
 __global__ void k_tile_keys(const uint32_t* __restrict__ hist, uint32_t n_hist, RtsTileShape cur, uint32_t* __restrict__ key, uint32_t* __restrict__ id,
-                            const unsigned long long* __restrict__ head_sum, uint32_t* __restrict__ head_count, RtsHeadRule rule, uint32_t* __restrict__ bucket_hist)
+                            const unsigned long long* __restrict__ head_sum, uint32_t* __restrict__ head_count, RtsHeadRule rule, uint32_t* __restrict__ bucket_hist,
+                            int affine, const uint32_t* __restrict__ bnd)
 {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t is_head = 0, bucket = 0;
@@ -191,6 +202,16 @@ __global__ void k_tile_keys(const uint32_t* __restrict__ hist, uint32_t n_hist, 
         // the second, each by descending cost in steps of 1/16 octave -- finer than a tile's cost repeats from pulse to pulse
         // (the head is ordered too: its longest cooperative unit has to start first)
         bucket = (is_head ? 0u : RTS_TILE_BUCKETS / 2u) + (RTS_TILE_BUCKETS / 2u - 1u) - min((uint32_t)(__log2f((float)cost + 1.0f) * 16.0f), RTS_TILE_BUCKETS / 2u - 1u);
+        if (affine) {
+            // XCD-affine sub-orders: [64 head bins, half octaves | RTS_XCD bands x 120 bins, quarter octaves]; band = the contiguous range
+            // of local tile indices (a slab of the lattice) that held an eighth of the cost of the launch before last (bnd: written by
+            // k_tile_bucket_scan of the previous build; none yet: equal counts)
+            uint32_t band = 0;
+            if (bnd) { for (uint32_t r = 1; r < RTS_XCD; r++) if (j >= bnd[r]) band = r; }
+            else band = min((uint32_t)(((unsigned long long)j * RTS_XCD) / cur.n_tiles), (uint32_t)RTS_XCD - 1u);
+            const float lg = __log2f((float)cost + 1.0f);
+            bucket = is_head ? 63u - min((uint32_t)(lg * 2.0f), 63u) : 64u + band * 120u + 119u - min((uint32_t)(lg * 4.0f), 119u);
+        }
         if (bucket_hist) key[j] = bucket;
     }
     if (head_count) {                                                          // (uniform)
@@ -211,7 +232,10 @@ __global__ void k_tile_keys(const uint32_t* __restrict__ hist, uint32_t n_hist, 
 // every trace launch): histogram in k_tile_keys, exclusive scan of the 1 024 bins by one block, and a scatter in which every
 // block reserves its share of each bin with ONE atomic and ranks its tiles inside it in LDS.  Tiles of a bin come out in no
 // particular order (only the schedule depends on it); the head of the order is the first half of the bins, a prefix as before.
-__global__ void __launch_bounds__(RTS_TILE_BUCKETS) k_tile_bucket_scan(uint32_t* __restrict__ hist)
+// xcd != null (XCD-affine sub-orders): xcd[0 .. RTS_XCD] <- first order position of each band's segment (the last entry: the number of
+// tiles), and xcd[16 .. 16 + RTS_XCD] <- the bands of the NEXT build: local tile indices at which the cost cells of the launch just
+// merged (coarse) reach 1/8, 2/8, ... of their sum
+__global__ void __launch_bounds__(RTS_TILE_BUCKETS) k_tile_bucket_scan(uint32_t* __restrict__ hist, uint32_t* __restrict__ xcd, const uint32_t* __restrict__ coarse, uint32_t n_tiles)
 {
     __shared__ uint32_t s[2][RTS_TILE_BUCKETS];
     const uint32_t t = threadIdx.x, v = hist[t];
@@ -219,6 +243,22 @@ __global__ void __launch_bounds__(RTS_TILE_BUCKETS) k_tile_bucket_scan(uint32_t*
     int cur = 0;
     for (uint32_t off = 1; off < RTS_TILE_BUCKETS; off <<= 1) { uint32_t x = s[cur][t]; if (t >= off) x += s[cur][t - off]; s[cur ^ 1][t] = x; cur ^= 1; __syncthreads(); }
     hist[t] = s[cur][t] - v;                                                   // exclusive: first position of the bin
+    if (!xcd) return;                                                          // (uniform)
+    if (t >= 64u && (t - 64u) % 120u == 0u && (t - 64u) / 120u < RTS_XCD) xcd[(t - 64u) / 120u] = s[cur][t] - v;
+    if (t == 0) xcd[RTS_XCD] = s[cur][RTS_TILE_BUCKETS - 1];
+    __syncthreads();
+    static_assert(RTS_COARSE_CELLS == RTS_TILE_BUCKETS, "one thread per coarse cell");
+    __shared__ unsigned long long p[2][RTS_COARSE_CELLS];
+    p[0][t] = coarse[t]; __syncthreads();
+    cur = 0;
+    for (uint32_t off = 1; off < RTS_COARSE_CELLS; off <<= 1) { unsigned long long x = p[cur][t]; if (t >= off) x += p[cur][t - off]; p[cur ^ 1][t] = x; cur ^= 1; __syncthreads(); }
+    const unsigned long long total = p[cur][RTS_COARSE_CELLS - 1], mine = p[cur][t], before = t ? p[cur][t - 1] : 0ULL;
+    if (t == 0) { xcd[16] = 0u; xcd[16 + RTS_XCD] = n_tiles; }
+    for (uint32_t r = 1; r < RTS_XCD; r++) {
+        if (total == 0ULL) { if (t == 0) xcd[16 + r] = (uint32_t)(((unsigned long long)n_tiles * r) / RTS_XCD); continue; }
+        const unsigned long long thr = (total * r + RTS_XCD - 1u) / RTS_XCD;      // band r starts behind the cell in which the running sum reaches r/8 of the total
+        if (before < thr && mine >= thr) xcd[16 + r] = (uint32_t)(((unsigned long long)(t + 1u) * n_tiles) / RTS_COARSE_CELLS);
+    }
 }
 __global__ void __launch_bounds__(256) k_tile_bucket_scatter(const uint32_t* __restrict__ bucket_of, uint32_t n, uint32_t* __restrict__ next, uint32_t* __restrict__ order)
 {
@@ -241,15 +281,27 @@ int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_vali
     const uint32_t n_hist = c->tile_hist_n;
     auto shape = [](const uint64_t* sig) { RtsTileShape s; s.first = sig[1]; s.il_tile = (uint32_t)(sig[2] & 0xffffffffu); s.il_parts = (uint32_t)(sig[2] >> 32); s.il_part = (uint32_t)sig[3];
                                           s.n_tiles = (uint32_t)((sig[0] + RTS_WTILE - 1) / RTS_WTILE); return s; };
-    uint32_t* head = c->coop_frac > 0.0 ? c->d_tile_ctr.p + 2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE : nullptr;      // [sum lo, sum hi, count, pad]: zeroed with the draw counters
-    if (prev_valid) { const RtsTileShape p = shape(prev_sig); if (p.n_tiles) k_tile_merge<<<blocks_for(p.n_tiles, 256), 256, 0, st>>>(c->d_tile_cost.p, p, c->d_tile_hist.p, n_hist, reinterpret_cast<unsigned long long*>(head)); }
+    uint32_t* head = c->coop_frac > 0.0 ? c->d_tile_ctr.p + RTS_OFF_HEAD : nullptr;      // [sum lo, sum hi, count, pad]: zeroed with the draw counters
+    uint32_t* bins = c->tile_bucket_order ? c->d_tile_ctr.p + RTS_OFF_BINS : nullptr;      // zeroed with the draw counters
+    // XCD-AFFINE sub-orders (RtsContext::xcd_affine: 0 never, 1 whenever there is a counting order, 2 -- the default -- for launches of
+    // >= 2^18 wave tiles, i.e. BASELINE configs[3]'s 100 M launch indices, whose scene is a hundred times an XCD's L2)
+    const bool affine = bins != nullptr && (c->xcd_affine == 1 || (c->xcd_affine == 2 && n_tiles_cur >= (1u << 18)));
+    c->xcd_affine_now = affine;
+    if (affine) RTS_HIP(c->d_xcd.reserve(64));
+    uint32_t* coarse = affine ? c->d_tile_ctr.p + RTS_OFF_COARSE : nullptr;
+    bool merged = false;
+    if (prev_valid) { const RtsTileShape p = shape(prev_sig); if (p.n_tiles) { k_tile_merge<<<blocks_for(p.n_tiles, 256), 256, 0, st>>>(c->d_tile_cost.p, p, c->d_tile_hist.p, n_hist, reinterpret_cast<unsigned long long*>(head), coarse); merged = p.n_tiles == n_tiles_cur; } }
     RTS_HIP(c->d_tile_key.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_key_sorted.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_id.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_order.reserve(n_tiles_cur));
     const RtsTileShape cur = shape(cur_sig);
     const RtsHeadRule rule = {c->coop_frac, c->coop_big, c->coop_floor, resident_waves};
-    uint32_t* bins = c->tile_bucket_order ? c->d_tile_ctr.p + RTS_ZERO_WORDS - RTS_TILE_BUCKETS : nullptr;      // zeroed with the draw counters
-    k_tile_keys<<<blocks_for(n_tiles_cur, 256), 256, 0, st>>>(c->d_tile_hist.p, n_hist, cur, c->d_tile_key.p, c->d_tile_id.p, reinterpret_cast<const unsigned long long*>(head), head ? head + 2 : nullptr, rule, bins);
+    // (the bands in force were computed by the previous build's scan from the launch before last; a launch of another shape, or no
+    // build yet: equal counts)
+    const uint32_t* bnd = affine && c->xcd_bnd_tiles == n_tiles_cur ? c->d_xcd.p + 16 : nullptr;
+    k_tile_keys<<<blocks_for(n_tiles_cur, 256), 256, 0, st>>>(c->d_tile_hist.p, n_hist, cur, c->d_tile_key.p, c->d_tile_id.p, reinterpret_cast<const unsigned long long*>(head), head ? head + 2 : nullptr, rule, bins,
+                                                              affine ? 1 : 0, bnd);
     if (bins) {
-        k_tile_bucket_scan<<<1, RTS_TILE_BUCKETS, 0, st>>>(bins);
+        k_tile_bucket_scan<<<1, RTS_TILE_BUCKETS, 0, st>>>(bins, affine ? c->d_xcd.p : nullptr, coarse, n_tiles_cur);
+        if (affine) c->xcd_bnd_tiles = merged ? n_tiles_cur : 0u;               // (bands from a launch of another shape are not used)
         k_tile_bucket_scatter<<<blocks_for(n_tiles_cur, 256), 256, 0, st>>>(c->d_tile_key.p, n_tiles_cur, bins, c->d_tile_order.p);
         RTS_HIP(hipGetLastError());
         return RTS_OK;

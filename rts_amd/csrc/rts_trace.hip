@@ -847,7 +847,7 @@ __device__ __forceinline__ void rts_sum_counters_body(const uint32_t t, unsigned
 // history): it traces the 64 n_head launch indices of the tiles at the head of the cost order, one per wave; the ordinary
 // kernel then starts at position n_head of the order.  A kernel of its own because the shared walk needs ~40 registers more
 // than the 128 the ordinary kernel is held to (four waves per SIMD).
-template <bool COUNT, bool KEEP_ALL, bool REFR, bool COOP, bool ASYNC = false>
+template <bool COUNT, bool KEEP_ALL, bool REFR, bool COOP, bool ASYNC = false, bool AFFINE = false>
 __global__ void __launch_bounds__(RTS_BLOCK, (REFR || COOP) ? 2 : 4) k_trace(const RtsTraceArgs a)
 {
     __shared__ __attribute__((aligned(16))) int32_t s_stack[RTS_STACK_LDS * RTS_BLOCK];
@@ -933,8 +933,51 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR || COOP) ? 2 : 4) k_trace(con
     __shared__ uint32_t s_lane_scratch[COUNT ? 2 * (RTS_BLOCK / 64) : 1];      // (counting build: per-wave max / sum of a round's walk steps)
     const RtsUnitLds ul = {s_stack, s_exch, s_first, s_path, s_n, s_rx, s_rxp, s_lane_scratch};
     unsigned long long lane_stats[4] = {0ull, 0ull, 0ull, 0ull};
-    const uint32_t per_stripe = (n_units + RTS_TILE_CTRS - 1u) / RTS_TILE_CTRS;
-    const uint32_t single_draws = per_stripe >= 1024u ? per_stripe / 4u : per_stripe;      // (short queues: one tile per draw throughout)
+    // XCD-AFFINE SUB-ORDERS (a.xcd_seg, big launches; ordinary kernel only): the order behind the head is cut into one segment per XCD
+    // -- a band of the lattice that held an eighth of the cost last seen, longest tiles first inside it -- so that the ~500 waves of
+    // an XCD trace neighbouring tiles at the same time and its 4 MB of L2 serves ONE part of a scene that is a hundred times that
+    // size (BASELINE configs[3]: every XCD used to stream the whole scene, 13.5 GB of fabric traffic per launch at an L2 hit rate
+    // of 0.66).  Segment 0 = what is left of the head when no cooperative kernel runs, segments 1 .. 8 = the bands; each has
+    // RTS_SEG_STRIPES draw counters.  A wave starts on segment 0, goes on with ITS XCD's band (HW_REG_XCC_ID) and, when that runs
+    // dry, with the next bands in turn -- every wave visits every segment, so every position is drawn whoever sits where.
+    // (a kernel of its own -- AFFINE -- whose queue state lives in LDS, one row per wave: as five more scalars of the ordinary kernel
+    // they pushed it over its 128 registers, 14 VGPRs into scratch)
+    static_assert(!AFFINE || (!COOP && !ASYNC), "affine sub-orders: ordinary lock-step kernel only");
+    __shared__ uint32_t s_seg[AFFINE ? RTS_XCD + 2 : 1];         // s_seg[i] .. s_seg[i + 1]: order positions of segment i
+    __shared__ uint32_t s_q[AFFINE ? (RTS_BLOCK / 64) * 8 : 1];  // per wave: [0] segment, [1] its first unit, [2] its length, [3] positions per stripe, [4] single draws, [5] segments visited
+    // (LDS addresses formed from the scalar wave number AT EACH USE: hoisted out of the tile loop as vector registers they were
+    // parked in scratch and reloaded eight times per draw)
+#define RTS_OPAQUE_S(x) ({ uint32_t o_ = (x); asm volatile("" : "+s"(o_)); o_; })
+#define RTS_Q(k) s_q[RTS_OPAQUE_S(wave_u) * 8u + (k)]
+    if (AFFINE) {
+        if (tid <= RTS_XCD) s_seg[tid + 1u] = max(min(a.xcd_seg[tid], n_tiles), n_head);
+        if (tid == 0) s_seg[0] = n_head;
+        __syncthreads();
+        if (lane == 0) {
+            const uint32_t len0 = s_seg[1] - s_seg[0], ps0 = (len0 + RTS_SEG_STRIPES - 1u) / RTS_SEG_STRIPES;
+            RTS_Q(0) = 0u; RTS_Q(1) = s_seg[0] - n_head; RTS_Q(2) = len0; RTS_Q(3) = ps0; RTS_Q(4) = ps0 >= 128u ? ps0 / 4u : ps0; RTS_Q(5) = 0u;
+        }
+    }
+    // THE COOPERATIVE KERNEL keeps a head tile's 64 units on ONE XCD: head tile h belongs to the list of XCD h mod 8 (the head is
+    // sorted by cost, so dealing it out in turn balances the lists), each list drawn through 8 counters; a wave works through its
+    // own XCD's list first and then through the others'.  The 64 rays of a tile are 64 nearly parallel rays along one radial line
+    // of the lattice: they walk the same few hundred KB of records, thousands of steps each -- spread over all eight XCDs (the
+    // striped queue dealt unit v to stripe v mod 64) every L2 fetched every head tile's records: 5.4 of the 6.4 GB a BASELINE
+    // configs[3] launch moves over the fabric, at an L2 hit rate of 0.64 (profiles/r04_c4_xcd_affine_pmc.log).
+    // a.coop_spread = P in {1, 2, 4, 8}: a head tile's 64 units are dealt to P of the eight lists (rays r mod P = c to list
+    // (h + (8 / P) c) mod 8); P = 1: the whole tile on one XCD, P = 8: eight rays on each (every L2 sees every tile).
+    uint32_t coop_x = 0, coop_sweep = 0, coop_len = 0;           // (COOP) current list, lists visited, head tiles that feed the list
+    const uint32_t coop_P = COOP ? a.coop_spread : 1u, coop_G = RTS_XCD / coop_P;
+#define RTS_COOP_LEN(x) (n_head > ((x) % coop_G) ? (n_head - ((x) % coop_G) + coop_G - 1u) / coop_G : 0u)
+    if (COOP) {
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(coop_x));
+        coop_x &= (RTS_XCD - 1u);
+        coop_len = RTS_COOP_LEN(coop_x);
+    }
+    const uint32_t S = (AFFINE || COOP) ? (uint32_t)RTS_SEG_STRIPES : (uint32_t)RTS_TILE_CTRS;      // stripes of a segment
+#define RTS_LSTRIPE (AFFINE ? (RTS_OPAQUE_S(stripe) & (RTS_SEG_STRIPES - 1u)) : (COOP ? (stripe & (RTS_SEG_STRIPES - 1u)) : stripe))
+    const uint32_t per_stripe_all = (n_units + RTS_TILE_CTRS - 1u) / RTS_TILE_CTRS;
+    const uint32_t single_draws_all = per_stripe_all >= 1024u ? per_stripe_all / 4u : per_stripe_all;      // (short queues: one tile per draw throughout)
     // The pending draw is held in a register of lane 0 (so that its latency hides behind the tiles traced meanwhile) -- except
     // in the counting builds, which are short of registers: there the allocator spilled it to scratch and launches lost whole
     // tiles' worth of counters from run to run, until it was moved to LDS.  What the ISA of that build shows (round 3,
@@ -950,21 +993,49 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR || COOP) ? 2 : 4) k_trace(con
     // unproven.  Product builds reload nothing from scratch (tests/test_host_logic.py checks the ISA).
     __shared__ uint32_t s_draw[RTS_BLOCK / 64];
     uint32_t draw_next = 0;
-#define RTS_DRAW() { const uint32_t dv_ = atomicAdd(&a.tile_ctr[(COOP ? RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE : 0) + stripe * RTS_TILE_CTR_STRIDE], 1u); if (COUNT) s_draw[tid >> 6] = dv_; else draw_next = dv_; }
+#define RTS_DRAW() { const uint32_t dv_ = atomicAdd(&a.tile_ctr[(COOP ? RTS_OFF_CTR_COOP : 0) + ((AFFINE ? RTS_Q(0) * S : (COOP ? coop_x * S : 0u)) + RTS_LSTRIPE) * RTS_TILE_CTR_STRIDE], 1u); if (AFFINE) s_draw[RTS_OPAQUE_S(wave_u)] = dv_; else if (COUNT) s_draw[wave_u] = dv_; else draw_next = dv_; }
     if (lane == 0) RTS_DRAW()
     for (;;) {
-      const uint32_t draw = __builtin_amdgcn_readfirstlane(COUNT ? s_draw[tid >> 6] : draw_next);
+      const uint32_t draw = __builtin_amdgcn_readfirstlane(AFFINE ? s_draw[RTS_OPAQUE_S(wave_u)] : (COUNT ? s_draw[wave_u] : draw_next));      // (AFFINE: in LDS like the counting builds' -- the kernel has no register for it across the tile loop, see above)
+      const uint32_t per_stripe = AFFINE ? __builtin_amdgcn_readfirstlane(RTS_Q(3)) : (COOP ? (coop_len * (64u / coop_P) + RTS_SEG_STRIPES - 1u) / RTS_SEG_STRIPES : per_stripe_all);
+      const uint32_t single_draws = AFFINE ? __builtin_amdgcn_readfirstlane(RTS_Q(4)) : (COOP ? per_stripe : single_draws_all);      // (COOP: one unit per draw -- units are long)
       const uint32_t k0 = draw < single_draws ? draw : single_draws + 4u * (draw - single_draws);
       const uint32_t kn = draw < single_draws ? 1u : 4u;
-      if (k0 >= per_stripe) break;
+      if (k0 >= per_stripe) {
+          if (COOP) {                                                       // this XCD's list is empty: the next XCD's
+              if (++coop_sweep >= RTS_XCD) break;
+              coop_x = (coop_x + 1u) & (RTS_XCD - 1u);
+              coop_len = RTS_COOP_LEN(coop_x);
+              if (lane == 0) RTS_DRAW()
+              continue;
+          }
+          if (!AFFINE) break;
+          const uint32_t sweep = __builtin_amdgcn_readfirstlane(RTS_Q(5)) + 1u;
+          if (sweep > RTS_XCD) break;
+          if (lane == 0) {
+              uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));      // (read where it is used: a scalar less to carry through the tile loop)
+              const uint32_t si = 1u + ((xcc & (RTS_XCD - 1u)) + sweep - 1u) % RTS_XCD;       // own band first, then the others in turn
+              const uint32_t len = s_seg[si + 1u] - s_seg[si], ps = (len + RTS_SEG_STRIPES - 1u) / RTS_SEG_STRIPES;
+              RTS_Q(0) = si; RTS_Q(1) = s_seg[si] - n_head; RTS_Q(2) = len; RTS_Q(3) = ps; RTS_Q(4) = ps >= 128u ? ps / 4u : ps; RTS_Q(5) = sweep;
+              RTS_DRAW()
+          }
+          continue;
+      }
+      const uint32_t seg_base = AFFINE ? __builtin_amdgcn_readfirstlane(RTS_Q(1)) : 0u, seg_len = AFFINE ? __builtin_amdgcn_readfirstlane(RTS_Q(2)) : (COOP ? coop_len * (64u / coop_P) : n_units);
       // (only in the cheap part of the order: a draw made before an EXPENSIVE tile would reserve the stripe's next most
       // expensive tile for as long as this one takes -- the launch then ends with that tile, traced alone)
       const bool ahead = draw >= single_draws;
       if (ahead && lane == 0) RTS_DRAW()
      for (uint32_t kb = 0; kb < kn; kb++) {
-      const uint64_t vpos64 = (uint64_t)(k0 + kb) * RTS_TILE_CTRS + stripe;
-      if (vpos64 >= n_units) break;
-      const uint32_t vpos = (uint32_t)vpos64;
+      const uint64_t vloc64 = (uint64_t)(k0 + kb) * S + RTS_LSTRIPE;      // position inside the segment
+      if (vloc64 >= seg_len) break;
+      // (COOP: unit u of list x: head tile h = x mod G + G (u / (64 / P)), ray c + P (u mod (64 / P)) with c = ((x - h) mod 8) / G;
+      // vpos = 64 x head tile + ray, as before)
+      uint32_t vpos = seg_base + (uint32_t)vloc64;
+      if (COOP) {
+          const uint32_t per = 64u / coop_P, j = (uint32_t)vloc64 / per, i = (uint32_t)vloc64 - j * per, h = (coop_x % coop_G) + coop_G * j;
+          vpos = (h << 6) | ((((coop_x - h) & (RTS_XCD - 1u)) / coop_G) + coop_P * i);
+      }
       const bool coop_unit = COOP;
       const uint32_t tpos = COOP ? (vpos >> 6) : vpos + n_head;
       // no history yet (first launch of the handle): centre-out over the launch range -- the beam is normally centred on
@@ -1079,6 +1150,11 @@ template <bool COOP>
 static void rts_trace_dispatch(const RtsTraceArgs& a, bool count_traversal, unsigned grid, hipStream_t st)
 {
     const int sel = (a.max_refr ? 4 : 0) | (a.keep_all ? 2 : 0) | (count_traversal ? 1 : 0);
+    if (!COOP && a.xcd_seg && a.tile_order && !a.async_idle0 && sel < 2) {      // XCD-affine sub-orders: product and counting build of the plain reflection chain (every other
+        if (sel == 0) k_trace<false, false, false, false, false, true><<<grid, RTS_BLOCK, 0, st>>>(a);      // build traces the same order without the segments)
+        else k_trace<true, false, false, false, false, true><<<grid, RTS_BLOCK, 0, st>>>(a);
+        return;
+    }
     if (!COOP && a.async_idle0 && sel < 4) {                      // asynchronous bounces (rts_trace_unit_async): ordinary kernel, no refraction chains
         switch (sel) {
             case 0: k_trace<false, false, false, false, true><<<grid, RTS_BLOCK, 0, st>>>(a); break;
@@ -1109,7 +1185,7 @@ static void rts_trace_dispatch(const RtsTraceArgs& a, bool count_traversal, unsi
 int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a_in, bool count_traversal, unsigned coop_grid)
 {
     RtsTraceArgs a = a_in;
-    a.done_ctr = c->sum_in_kernel ? a.tile_ctr + 2 * RTS_TILE_CTRS * RTS_TILE_CTR_STRIDE + 3 : nullptr;      // (the pad word behind the head words: zeroed with them)
+    a.done_ctr = c->sum_in_kernel ? a.tile_ctr + RTS_OFF_HEAD + 3 : nullptr;      // (the pad word behind the head words: zeroed with them)
     a.n_blocks_all = a.total_threads / RTS_BLOCK + coop_grid; a.host_cnt = c->pin_dev->cnt;
     if (a.n_rays == 0) {                                            // nothing to trace (an interleaved part without launch indices): the counters still go home, as zeros
         k_sum_counters<<<1, 256, 0, c->tstream>>>(a.block_counters, 0u, a.counters, nullptr, c->pin_dev->cnt);

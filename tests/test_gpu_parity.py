@@ -1195,6 +1195,46 @@ def test_pulse_end_uniform_equals_the_four_calls(rts, scenes, monkeypatch):
         np.testing.assert_allclose(cube, cube_ref, rtol=0, atol=1e-18 + 1e-12 * np.abs(cube_ref).max())      # (atomic adds: order varies)
 
 
+def test_xcd_affine_sub_orders_are_invisible(rts, oracle, scenes, monkeypatch):
+    """RTS_XCD_AFFINE=1 forces the XCD-affine sub-orders (rts_post.hip: the cost order cut into a head-rest segment and one band of
+    the lattice per XCD, each drawn through eight counters of its own; k_trace<.., AFFINE>: a wave sweeps every segment, its own
+    XCD's band first) onto launches far smaller than the 2^18 tiles they are meant for: another SCHEDULE, the same results --
+    every launch index traced exactly once (segment accounting), the received set field by field, pulse after pulse on one handle
+    (bands from the launch before last, equal counts before that), whole pulses and an interleaved part, product and counting
+    build; and the pulse's received records against the oracle's brute force"""
+    c3 = scenes.config3(W=80, detail=0.3, rx_radius=300.0)
+    tx = c3["tx"]; n_all = c3["W"] ** 3
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RTS_XCD_AFFINE", mode)
+        for count in (False, True):
+            tr = rts.Tracer(c3["W"], c3["max_refl"], 0, c3["smooth"], count_traversal=count)
+            tr.set_scene(c3["meshes"]); tr.set_receivers(c3["rx"])
+            res = []
+            for k in range(5):
+                mo = [dict(m, position=tuple(np.add(m["position"], (0.3 * k, 0.05 * k, 0.0)))) for m in c3["motion"]]
+                il = (4096, 2, 1) if k == 3 else None
+                st = tr.trace(tx["origin"], tx["span"], tx["dir"], mo, ray_first=0, ray_count=n_all, interleave=il)
+                res.append((st, tr.received()))
+            out[(mode, count)] = res
+            tr.close()
+    for count in (False, True):
+        for k, ((sa, ra), (sb, rb)) in enumerate(zip(out[("0", count)], out[("1", count)])):
+            for f in ("rays", "segments", "shaded", "received") + (("node_visits", "tri_tests", "walked_segments") if count else ()):
+                assert sa[f] == sb[f], (count, k, f, sa[f], sb[f])
+            H.assert_prd_equal(ra["results"], rb["results"], "affine vs global order, pulse %d" % k)
+            assert np.array_equal(ra["slots"], rb["slots"]) and np.array_equal(ra["path"], rb["path"]) and ra["rcs_angle"].tobytes() == rb["rcs_angle"].tobytes()
+    st, rec = out[("1", False)][4]
+    assert st["rays"] == n_all and st["received"] > 500
+    mo = [dict(m, position=tuple(np.add(m["position"], (0.3 * 4, 0.05 * 4, 0.0)))) for m in c3["motion"]]
+    idx = rec["slots"][:: max(len(rec["slots"]) // 400, 1)].astype(np.int64)
+    sc = H.oracle_scene(oracle, c3, mo)
+    for i in idx[:400]:
+        o = sc.trace(tx["origin"], tx["span"], tx["dir"], c3["W"], c3["max_refl"], 0, c3["smooth"], ray_first=int(i), ray_stride=1, n_rays=1, use_bvh=False)
+        j = int(np.searchsorted(rec["slots"], i))
+        H.assert_prd_equal(o["results"][:1], rec["results"][j:j + 1], "launch index %d against the brute-force oracle" % i)
+
+
 def test_host_mirror_equals_the_copy_calls(rts, scenes, monkeypatch):
     """rts_received_prefetch / rts_received_view / rts_finalise_values / rts_aggregate / rts_aggregated_view -- the C++ adapter's
     per-pulse path: the received set stored into pinned host memory by a kernel behind the trace (on the device-side count from

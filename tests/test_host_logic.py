@@ -371,13 +371,14 @@ def test_product_trace_kernels_use_no_scratch():
         seen += 1
         scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1)); vspill = int(re.search(r"VGPRs Spill: (\d+)", b).group(1))
         lds = int(re.search(r"LDS Size \[bytes/block\]: (\d+)", b).group(1)); occ = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1))
-        async_k = name.split("EEv")[0].split("ELb")[-1] == "1" and len(name.split("EEv")[0].split("Lb")) == 6
+        flags = [q == "1" for q in re.findall(r"Lb([01])", name.split("EEv")[0])]      # k_trace<COUNT, KEEP_ALL, REFR, COOP, ASYNC, AFFINE>
+        assert len(flags) == 6, name
+        async_k = flags[4]
         if async_k:
             assert scratch <= 64 and vspill <= 16, (name, scratch, vspill)
         else:
             assert scratch <= 16 and vspill <= 3, (name, scratch, vspill)
-        coop = name.split("EEv")[0].split("ELb")[3] == "1"      # k_trace<COUNT, KEEP_ALL, REFR, COOP, ASYNC>
-        refr = name[len("_Z7k_traceILb0ELb0ELb"):][:1] == "1" or name[len("_Z7k_traceILb0ELb1ELb"):][:1] == "1"
+        coop = flags[3]; refr = flags[2]
         if coop:
             assert lds * 3 <= 160 * 1024 and occ >= 2, (name, lds, occ)      # the cooperative kernel: three blocks per CU
         else:
@@ -405,7 +406,7 @@ def test_product_trace_kernels_use_no_scratch():
             if "scratch_" in t:                                   # prologue stores / epilogue reloads of a value the tile loop has no register for: once per wave
                 assert not in_loop, (name, t)
         assert fetch_blocks >= 1 and asm_loads == 0, (name, fetch_blocks, asm_loads)     # every asm load group ends in its own wait
-    assert seen == 10
+    assert seen == 11      # 4 ordinary + 4 cooperative + 2 asynchronous + 1 XCD-affine product instantiations
 
 
 def test_fuzz_generator_versions_are_frozen(rts):
