@@ -138,7 +138,7 @@ def main():
     ap.add_argument("--width", type=int, default=0, help="W (launch indices per pulse = W^3); 0 = the config's own")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--link", action="store_true", help="rts_link_handles: the handles' trace kernels run strictly one at a time")
-    ap.add_argument("--fused-post", action="store_true", help="rts_trace_pulse_end_uniform (the post-processing enqueued on the device-side received count, no host wait for the trace) instead of rts_trace_pulse_end + rts_finalise_uniform + rts_cube_accumulate + rts_aggregate: measured equal or slower (DESIGN.md section 5)")
+    ap.add_argument("--fused-post", action="store_true", help="rts_trace_pulse_end_uniform (a pulse's post-processing enqueued behind its trace on the device-side received count, ONE kernel for a small received set since round 4, no host wait for the trace) instead of rts_trace_pulse_end + rts_finalise_uniform + rts_cube_accumulate + rts_aggregate.  Measured (round 4, DESIGN.md section 5): sequential pulses 1.03 against 1.10 ms, three pulses in flight 0.60 against 0.58 -- the default stays the four calls, except with --inflight 1")
     ap.add_argument("--no-bind", action="store_true", help="leave the process's CPU affinity alone (default: the CPUs of the GPU's NUMA node)")
     ap.add_argument("--post-lag", type=int, default=0, choices=(0, 1), help="1: a pulse's group table is collected one pulse later (the submitting thread does not wait for the post-processing it has just enqueued)")
     ap.add_argument("--inflight", type=int, default=3, help="pulses in flight per GPU; 1 = strictly sequential pulses")
@@ -323,7 +323,7 @@ def main():
         # tracing]; the oldest pulse's table is collected just before its handle takes a new pulse.  --post-lag 0: the oldest
         # pulse is completed (trace, post-processing, table) before the next one is begun -- every handle traces.
         lag = args.post_lag if len(trs) >= 2 else 0
-        fused_post = args.fused_post and hasattr(rts_amd._lib.lib(), "rts_trace_pulse_end_uniform")
+        fused_post = (args.fused_post or len(trs) == 1) and hasattr(rts_amd._lib.lib(), "rts_trace_pulse_end_uniform")
         pending = []; posted = []
         items, motions, txs = prepared if prepared is not None else prepare_cpi(k0, n_pulses)
         bench_debug = bool(os.environ.get("BENCH_DEBUG"))
@@ -505,7 +505,7 @@ def main():
                        "hit_fraction": hit_fraction, "primary_Mrays_per_s": total * args.steps / dt / 1e6,
                        "return_cube": "complex128 [%d rx][%d pulses][%d bins], all-reduced once per interval, then %d-point slow-time FFT in the library (rts_cube_doppler, inside the timed region); range-Doppler peak %.6e, max deviation from torch.fft %.1e (relative)" % (cube.shape[0], cube.shape[1], n_bins, n_fft, range_doppler_peak, range_doppler_err or 0.0),
                        "sharding": ("%d-pulse interval over %d ranks, --shard %s: " % (args.steps, world, args.shard)) + ("every pulse split over all ranks in interleaved 4096-index tiles" if args.shard == "rays" else "whole pulses, left-over pulses in interleaved 4096-index tiles") + "; one group-table all-gather + one cube all-reduce per interval",
-                       "host_numa_node": numa_node, "post_processing_call": "rts_trace_pulse_end_uniform" if (args.fused_post and hasattr(rts_amd._lib.lib(), "rts_trace_pulse_end_uniform")) else "rts_trace_pulse_end + rts_finalise_uniform + rts_cube_accumulate + rts_aggregate", "pulses_in_flight": len(trs), "linked": bool(args.link), "scene_setup_s": scene_setup_s,
+                       "host_numa_node": numa_node, "post_processing_call": "rts_trace_pulse_end_uniform" if ((args.fused_post or len(trs) == 1) and hasattr(rts_amd._lib.lib(), "rts_trace_pulse_end_uniform")) else "rts_trace_pulse_end + rts_finalise_uniform + rts_cube_accumulate + rts_aggregate", "pulses_in_flight": len(trs), "linked": bool(args.link), "scene_setup_s": scene_setup_s,
                        "interval_tail_ms_rank0": acc["tail_ms"],
                        "host_ms_per_pulse_rank0": {k: v / max(acc["launches"], 1) for k, v in acc["host_ms"].items()},
                        "stage_ms_per_launch_rank0": {"scene_placement": ms_scene / launches, "trace": ms_trace / launches, "order+finalise+aggregate": ms_post / launches}},

@@ -166,11 +166,15 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     c->debug_coop = getenv("RTS_DEBUG_COOP") != nullptr;
     { const char* e = getenv("RTS_SUM_IN_KERNEL"); if (e) c->sum_in_kernel = atoi(e) != 0; }
     { const char* e = getenv("RTS_SPIN_WAIT"); if (e) c->spin_wait = atoi(e) != 0; }
+    { const char* e = getenv("RTS_ORDER_FUSED"); if (e) c->order_fused = atoi(e) != 0; }
+    { const char* e = getenv("RTS_PLACE_FUSED"); if (e) c->place_fused = atoi(e) != 0; }
     { const char* e = getenv("RTS_TILE_SORT"); if (e) c->tile_bucket_order = strcmp(e, "radix") != 0; }
     { const char* e = getenv("RTS_XCD_AFFINE"); if (e) c->xcd_affine = e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2); }
     { const char* e = getenv("RTS_SPEC_STREAM"); if (e) c->spec_on_trace_stream = strcmp(e, "trace") == 0; }
     { const char* e = getenv("RTS_SPECULATE"); if (e) c->spec_enabled = atoi(e) != 0; }
     { const char* e = getenv("RTS_POST_SMALL"); if (e) c->post_small = atoi(e) != 0; }
+    { const char* e = getenv("RTS_POST_ONE"); if (e) c->post_one = atoi(e) != 0; }
+    { const char* e = getenv("RTS_POST_PRIO"); if (e) c->post_prio = (uint32_t)std::min(3, std::max(0, atoi(e))); }
     { const char* e = getenv("RTS_ASYNC_IDLE0"); if (e) c->async_idle0 = (uint32_t)std::min(64, std::max(0, atoi(e))); }
     { const char* e = getenv("RTS_ASYNC_IDLE1"); if (e) c->async_idle1 = (uint32_t)std::min(64, std::max(1, atoi(e))); }
     { const char* e = getenv("RTS_ASYNC_AGE"); if (e) c->async_age = (uint32_t)std::max(0, atoi(e)); }
@@ -399,6 +403,7 @@ static int rts_attach_scene(RtsContext* c)
         c->p_targets = reinterpret_cast<RtsTargetDev*>(c->d_params.p + offsetof(RtsPinned, td));
         c->rcs_uploaded = false;
     }
+    c->verts_world_valid = false; c->order_sum_valid = false;
     c->motion.assign(n_targets, RtsTargetMotion{}); c->motion_valid = false; c->bvh_valid = false; c->tile_hist_n = 0; c->tile_hist_any = false; c->tile_cost_pending = false;
     return RTS_OK;
 }
@@ -1000,6 +1005,15 @@ static int rts_post_chain(RtsContext* c, bool ordered = false)      // ordered: 
     hipStream_t st = c->stream;
     const bool keep_all = (c->params.flags & RTS_FLAG_KEEP_ALL_RAYS) != 0;
     int rc = RTS_OK;
+    if (!ordered && q.mode == 0 && c->recv_dev && c->post_one && c->post_small && !keep_all && !c->mirror.want && c->n_recv <= c->spec_cap) {
+        // the speculative chain as ONE kernel (rts_post.hip: k_post_all): sized for the capacity, the count from the device
+        RTS_HIP(hipEventRecord(c->ev[4], st)); RTS_HIP(hipEventRecord(c->ev[5], st)); RTS_HIP(hipEventRecord(c->ev[6], st));
+        c->agg_pending.valid = false; c->groups.clear();
+        rc = rts_post_all_small(c, (uint32_t)c->n_recv, q, true); if (rc != RTS_OK) return rc;
+        RTS_HIP(hipEventRecord(c->ev[7], st));
+        c->fin_timed = true; c->agg_timed = true; c->stats_pending = true; c->agg_valid = true; c->mirror.recv_valid = false;
+        return RTS_OK;
+    }
     if (!ordered) {
         RTS_HIP(hipEventRecord(c->ev[4], st));
         rc = rts_post_order_and_expand(c); if (rc != RTS_OK) return rc;

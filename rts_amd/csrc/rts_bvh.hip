@@ -105,20 +105,48 @@ __device__ __forceinline__ void rts_mask_mark(RtsMaskLds& S, const bool have, co
 // dbuf_triangles -> dbuf_triVertices per test, triangle_mesh.cu:147-154).  LEAVES && MASK: one pass over the placed triangles
 // for both (a pulse that moves a target needs both; the vertices are gathered once).  MASK alone: the targets stand still,
 // the beam moved.
-template <bool LEAVES, bool MASK>
+// PLACE (r04): the kernel places what it gathers -- the three vertices of its primitive from the LOCAL arrays through the pulse's
+// placement (place_one's arithmetic on registers: the bits of k_place's world array, which it then does not need) -- and its
+// blocks behind the primitives' place the normals: ONE launch for the whole per-pulse scene update instead of k_place + k_leaves.
+__device__ __forceinline__ void place_vertex(const double* __restrict__ local, const RtsTargetMotion& m, uint32_t i, double* __restrict__ out3)
+{
+    double x = local[3*(size_t)i], y = local[3*(size_t)i+1], z = local[3*(size_t)i+2];
+    if (m.has_rotation) {
+        double rx = 0.0, ry = 0.0, rz = 0.0;
+        rx += m.rotation[0] * x; rx += m.rotation[1] * y; rx += m.rotation[2] * z;
+        ry += m.rotation[3] * x; ry += m.rotation[4] * y; ry += m.rotation[5] * z;
+        rz += m.rotation[6] * x; rz += m.rotation[7] * y; rz += m.rotation[8] * z;
+        x = rx; y = ry; z = rz;
+    }
+    x += m.position[0]; y += m.position[1]; z += m.position[2];
+    out3[0] = x; out3[1] = y; out3[2] = z;
+}
+template <bool LEAVES, bool MASK, bool PLACE = false>
 __global__ void __launch_bounds__(256) k_leaves(const uint32_t* __restrict__ leaf_prim, const uint32_t* __restrict__ tri_vidx, const double* __restrict__ verts,
                                                 const uint32_t* __restrict__ prim_targ, RtsLeafTri* __restrict__ leaves, uint32_t n,
-                                                double ox, double oy, double oz, RtsMaskFrame f, uint32_t* __restrict__ mask)
+                                                double ox, double oy, double oz, RtsMaskFrame f, uint32_t* __restrict__ mask,
+                                                const RtsTargetMotion* __restrict__ motion = nullptr, uint32_t prim_blocks = 0, const double* __restrict__ n_local = nullptr,
+                                                double* __restrict__ n_world = nullptr, const uint32_t* __restrict__ n_targ = nullptr, uint32_t n_normals = 0)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_raw[MASK ? sizeof(RtsMaskLds) / 4 : 1];
+    if (PLACE && blockIdx.x >= prim_blocks) {                            // (uniform per block) the blocks behind the primitives': normals
+        const uint32_t q = (blockIdx.x - prim_blocks) * blockDim.x + threadIdx.x;
+        if (q < n_normals) place_one(n_local, n_world, n_targ, motion, q, false);
+        return;
+    }
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     double p[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (i < n) {
         const uint32_t g = leaf_prim ? leaf_prim[i] : i;                 // (one record per primitive: leaf_prim == nullptr)
         const uint32_t a = tri_vidx[3*(size_t)g], b = tri_vidx[3*(size_t)g+1], c = tri_vidx[3*(size_t)g+2];
+        if (PLACE) {                                                     // verts = the LOCAL vertices
+            const RtsTargetMotion m = motion[prim_targ[g]];
+            place_vertex(verts, m, a, p); place_vertex(verts, m, b, p + 3); place_vertex(verts, m, c, p + 6);
+        } else {
         p[0] = verts[3*(size_t)a]; p[1] = verts[3*(size_t)a+1]; p[2] = verts[3*(size_t)a+2];
         p[3] = verts[3*(size_t)b]; p[4] = verts[3*(size_t)b+1]; p[5] = verts[3*(size_t)b+2];
         p[6] = verts[3*(size_t)c]; p[7] = verts[3*(size_t)c+1]; p[8] = verts[3*(size_t)c+2];
+        }
         if (LEAVES) {
             RtsLeafTri L;
             L.p0x = p[0]; L.p0y = p[1]; L.p0z = p[2]; L.p1x = p[3]; L.p1y = p[4]; L.p1z = p[5]; L.p2x = p[6]; L.p2y = p[7]; L.p2z = p[8];
@@ -140,6 +168,24 @@ int rts_scene_place(RtsContext* c, const RtsLaunchConsts& lc, bool place, uint32
     const bool mask = f.n != 0;
     const RtsScene* sc = c->scene;
     // (the mask buffer -- behind the handle's zero block -- has been cleared with it: rts_trace_pulse_begin)
+    // ONE launch for a pulse that moves a target (RtsContext::place_fused, RTS_PLACE_FUSED=0: k_place + k_leaves): the leaf kernel
+    // places its primitive's vertices itself, its trailing blocks the normals.  (A later pulse that only re-marks the mask -- the
+    // targets stand still, the beam moved -- gathers from the world vertices: kept up to date by k_place in that mode only.)
+    if (place && c->place_fused && sc->n_prims) {
+        const unsigned gp = blocks_for(sc->n_prims, 256), gn = blocks_for(sc->n_normals, 256);
+        if (mask) k_leaves<true, true, true><<<gp + gn, 256, 0, st>>>(nullptr, sc->d_tri_vidx.p, sc->d_verts_local.p, sc->d_prim_targ.p, c->d_leaves.p, sc->n_prims, lc.ox, lc.oy, lc.oz, f, pmask,
+                                                                     c->p_motion, gp, sc->d_normals_local.p, c->d_normals_world.p, sc->d_norm_targ.p, sc->n_normals);
+        else k_leaves<true, false, true><<<gp + gn, 256, 0, st>>>(nullptr, sc->d_tri_vidx.p, sc->d_verts_local.p, sc->d_prim_targ.p, c->d_leaves.p, sc->n_prims, lc.ox, lc.oy, lc.oz, f, nullptr,
+                                                                  c->p_motion, gp, sc->d_normals_local.p, c->d_normals_world.p, sc->d_norm_targ.p, sc->n_normals);
+        c->verts_world_valid = false;
+        RTS_HIP(hipGetLastError());
+        return RTS_OK;
+    }
+    if (!place && mask && !c->verts_world_valid && sc->n_verts) {        // the world vertices the mask-only pass gathers from: placed now, once
+        k_place<<<blocks_for((size_t)sc->n_verts, 256), 256, 0, st>>>(sc->d_verts_local.p, c->d_verts_world.p, sc->d_vert_targ.p, sc->n_verts, sc->d_normals_local.p, c->d_normals_world.p, sc->d_norm_targ.p, 0u, c->p_motion);
+        c->verts_world_valid = true;
+    }
+    if (place) c->verts_world_valid = true;
     if (place) {
         if (sc->n_verts + sc->n_normals) k_place<<<blocks_for((size_t)sc->n_verts + sc->n_normals, 256), 256, 0, st>>>(sc->d_verts_local.p, c->d_verts_world.p, sc->d_vert_targ.p, sc->n_verts,
                                                                                                                          sc->d_normals_local.p, c->d_normals_world.p, sc->d_norm_targ.p, sc->n_normals, c->p_motion);

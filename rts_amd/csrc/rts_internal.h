@@ -329,8 +329,12 @@ struct RtsContext {
     bool sum_in_kernel = false;         // the launch's last block sums the block counters (RTS_SUM_IN_KERNEL=1) instead of k_sum_counters -- measured SLOWER, off: the ticket's
                                         // release / acquire fences (one per block) write back and invalidate L2, and the post-processing behind the trace took 0.40 instead of 0.34 ms
     bool spin_wait = true;              // the pulse's two host waits poll the stream instead of blocking (rts_stream_wait; RTS_SPIN_WAIT=0)
+    bool order_fused = true, order_sum_valid = false;        // the tile order in two launches when the previous launch had this launch's shape (RTS_ORDER_FUSED=0: four)
+    bool place_fused = true, verts_world_valid = false;      // the per-pulse scene update in one launch (RTS_PLACE_FUSED=0: k_place + k_leaves); d_verts_world holds the current placement
     bool tile_bucket_order = true;      // tile order by counting bins instead of a radix sort (RTS_TILE_SORT=radix: the sort)
     int xcd_affine = 0; bool xcd_affine_now = false; uint32_t xcd_bnd_tiles = 0; DevBuf<uint32_t> d_xcd;      // XCD-affine sub-orders of the ORDINARY kernel (RTS_XCD_AFFINE = 0, the default / 1 / auto; rts_post.hip: rts_tile_order_build) -- measured slower, DESIGN.md section 5
+    uint32_t post_prio = 3;             // s_setprio of k_post_all's waves (RTS_POST_PRIO = 0 .. 3)
+    bool post_one = true;               // rts_trace_pulse_end_uniform: ONE kernel for order + expand + finalise + cube + aggregation of a small received set (RTS_POST_ONE=0: seven)
     bool post_small = true;             // received sets of up to 4096 rays are ordered / finished by single blocks (RTS_POST_SMALL=0: the general chain)
     hipEvent_t ev_spec = nullptr; uint32_t spec_cap = RTS_SMALL_CAP64; bool spec_on_trace_stream = false;      // (RTS_SPEC_STREAM=trace: the speculative chain behind the trace kernel on ITS stream)
     RtsSpecParams spec; bool spec_pending = false, spec_enabled = true;      // rts_trace_pulse_end_uniform: parameters of the chain; a chain enqueued on the device-side count awaits its resolution (RTS_SPECULATE=0: never)
@@ -364,6 +368,7 @@ int rts_post_mirror_received(RtsContext* c);       // the ordered, expanded rece
 int rts_post_mirror_aggregated(RtsContext* c);     // per-ray aggregation outputs -> the host mirror
 int rts_post_set_values(RtsContext* c, const double* power, const double* doppler);      // power / Doppler of the received rays <- device-readable arrays (the mirror's values-in area)
 int rts_post_expand_all(RtsContext* c);
+int rts_post_all_small(RtsContext* c, uint32_t cap, const RtsSpecParams& sp, bool want_groups);      // the whole uniform post-processing of a small received set in ONE one-block kernel (count from the device)
 int rts_cube_accumulate_device(RtsContext* c, uint32_t pulse_index, double cspeed, double carrier);
 int rts_cube_accumulate_paths_device(RtsContext* c, uint32_t pulse_index, int64_t base);
 int rts_cube_doppler_device(RtsContext* c, uint32_t n_fft, double* out);

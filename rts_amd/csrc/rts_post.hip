@@ -49,12 +49,9 @@ __device__ __forceinline__ void put_angle(double* angles, size_t row, uint32_t D
 
 // One thread per output row j.  perm != nullptr: row j is received record perm[j].  perm == nullptr: the full
 // buffers of the reference (keep-all): row j = chain * n + slot for chain < rows, rec = all_records.
-__global__ void k_expand(const RtsTraceArgs a, const RtsEndRecord* __restrict__ rec, const uint32_t* __restrict__ perm, uint32_t n_out, uint32_t D,
-                         PerRayData* __restrict__ rays, int32_t* __restrict__ paths, double* __restrict__ angles, uint64_t* __restrict__ slots, const unsigned long long* __restrict__ R_dev)
+__device__ __forceinline__ void expand_row(const RtsTraceArgs& a, const RtsEndRecord* __restrict__ rec, const uint32_t* __restrict__ perm, const uint32_t j, const uint32_t D,
+                                           PerRayData* __restrict__ rays, int32_t* __restrict__ paths, double* __restrict__ angles, uint64_t* __restrict__ slots)
 {
-    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    { uint32_t R = n_out; if (R_dev) { const unsigned long long v_ = *R_dev; if (v_ > (unsigned long long)R) return; R = (uint32_t)v_; } n_out = R; }
-    if (j >= n_out) return;
     RtsEndRecord r; bool valid = true; uint32_t chain, slot, prefill_code = 0;
     if (perm) { r = rec[perm[j]]; chain = r.pad & 3u; slot = r.slot; }
     else {
@@ -112,6 +109,14 @@ __global__ void k_expand(const RtsTraceArgs a, const RtsEndRecord* __restrict__ 
             for (uint32_t q = 1; q <= nrefl && q + 1 < D; q++) { const dvec3 k1 = hist_dir(a, 2*P + q, slot); put_angle(angles, j, D, q + 1, kin, k1); kin = k1; }
         }
     }
+}
+__global__ void k_expand(const RtsTraceArgs a, const RtsEndRecord* __restrict__ rec, const uint32_t* __restrict__ perm, uint32_t n_out, uint32_t D,
+                         PerRayData* __restrict__ rays, int32_t* __restrict__ paths, double* __restrict__ angles, uint64_t* __restrict__ slots, const unsigned long long* __restrict__ R_dev)
+{
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    { uint32_t R = n_out; if (R_dev) { const unsigned long long v_ = *R_dev; if (v_ > (unsigned long long)R) return; R = (uint32_t)v_; } n_out = R; }
+    if (j >= n_out) return;
+    expand_row(a, rec, perm, j, D, rays, paths, angles, slots);
 }
 
 __global__ void k_fill_i32(int32_t* p, int32_t v, size_t n) { size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
@@ -274,6 +279,70 @@ __global__ void __launch_bounds__(256) k_tile_bucket_scatter(const uint32_t* __r
     if (j < n) order[s_base[b] + r] = j;
 }
 
+// ---- the same order in TWO launches instead of four (r04), for the common case: the launch before had this launch's shape, so
+// every tile has a fresh cost record and k_tile_merge + k_tile_keys are one pass over the tiles; and every block of the scatter
+// scans the 1 024 bins for itself instead of waiting for a one-block scan kernel.  The head decision needs the launch's balanced
+// time -- the SUM of the costs, a grid-wide quantity: the sum of the launch BEFORE (persist[0..1], written by the previous
+// build's scatter) stands in for it; pulses of an interval look alike, and only the schedule depends on it.
+__global__ void k_tile_merge_keys(uint32_t* __restrict__ cost, RtsTileShape cur, uint32_t* __restrict__ hist, uint32_t n_hist, unsigned long long* __restrict__ head_sum,
+                                  const unsigned long long* __restrict__ sum_before, uint32_t* __restrict__ head_count, RtsHeadRule rule, uint32_t* __restrict__ key, uint32_t* __restrict__ bucket_hist)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t is_head = 0, bucket = 0; unsigned long long v64 = 0;
+    if (j < cur.n_tiles) {
+        const uint32_t v = cost[j], g = tile_global(cur, j);
+        if (v && g < n_hist) hist[g] = v;
+        cost[j] = 0u;
+        uint32_t est = v ? v : (g < n_hist ? hist[g] : 0u);
+        v64 = v & 0x7fffffffu;
+        const uint32_t c = est & 0x7fffffffu;
+        if (head_count && rule.frac > 0.0) {
+            const double balanced = (double)sum_before[0] / (double)(rule.resident_waves ? rule.resident_waves : 1u);
+            double thr = rule.frac * balanced; if (thr < (double)rule.floor_cost) thr = (double)rule.floor_cost;
+            double thr_big = rule.big * balanced; if (thr_big < (double)rule.floor_cost) thr_big = (double)rule.floor_cost;
+            is_head = (((est >> 31) && (double)c > thr) || (rule.big > 0.0 && balanced > 0.0 && (double)c > thr_big)) ? 1u : 0u;
+        }
+        bucket = (is_head ? 0u : RTS_TILE_BUCKETS / 2u) + (RTS_TILE_BUCKETS / 2u - 1u) - min((uint32_t)(__log2f((float)c + 1.0f) * 16.0f), RTS_TILE_BUCKETS / 2u - 1u);
+        key[j] = bucket;
+    }
+    __shared__ unsigned long long s_part[4];
+    __shared__ uint32_t s_cnt[RTS_TILE_BUCKETS];
+    for (uint32_t b = threadIdx.x; b < RTS_TILE_BUCKETS; b += blockDim.x) s_cnt[b] = 0u;
+    for (int o = 32; o > 0; o >>= 1) v64 += __shfl_down(v64, o);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v64;
+    if (head_count) { const unsigned long long m = __ballot(is_head != 0); if ((threadIdx.x & 63) == 0 && m) atomicAdd(head_count, (uint32_t)__popcll(m)); }
+    __syncthreads();
+    if (threadIdx.x == 0 && head_sum) { const unsigned long long t = s_part[0] + s_part[1] + s_part[2] + s_part[3]; if (t) atomicAdd(head_sum, t); }
+    if (j < cur.n_tiles) atomicAdd(&s_cnt[bucket], 1u);
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < RTS_TILE_BUCKETS; b += blockDim.x) if (s_cnt[b]) atomicAdd(&bucket_hist[b], s_cnt[b]);
+}
+// scatter with the bins' scan inside every block: hist = the bins' COUNTS (left untouched), taken = zeroed reservation counters
+__global__ void __launch_bounds__(256) k_tile_scan_scatter(const uint32_t* __restrict__ bucket_of, uint32_t n, const uint32_t* __restrict__ hist, uint32_t* __restrict__ taken, uint32_t* __restrict__ order,
+                                                           const unsigned long long* __restrict__ head_sum, unsigned long long* __restrict__ sum_persist)
+{
+    __shared__ uint32_t s_cnt[RTS_TILE_BUCKETS], s_base[RTS_TILE_BUCKETS], s_wave[4];
+    const uint32_t t = threadIdx.x, j = blockIdx.x * blockDim.x + t;
+    if (blockIdx.x == 0 && t == 0 && sum_persist) sum_persist[0] = head_sum[0];      // (complete: the keys kernel is over) the next build's "sum of the launch before"
+    static_assert(RTS_TILE_BUCKETS == 4 * 256, "four bins per thread");
+    const uint32_t h0 = hist[4 * t], h1 = hist[4 * t + 1], h2 = hist[4 * t + 2], h3 = hist[4 * t + 3];
+    s_cnt[4 * t] = 0u; s_cnt[4 * t + 1] = 0u; s_cnt[4 * t + 2] = 0u; s_cnt[4 * t + 3] = 0u;
+    uint32_t x = h0 + h1 + h2 + h3;                              // inclusive scan of the threads' sums: wave shuffle, then the four waves
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if ((t & 63u) >= (uint32_t)o) x += y; }
+    if ((t & 63u) == 63u) s_wave[t >> 6] = x;
+    __syncthreads();
+    uint32_t before = x - (h0 + h1 + h2 + h3);
+    for (uint32_t w = 0; w < (t >> 6); w++) before += s_wave[w];
+    s_base[4 * t] = before; s_base[4 * t + 1] = before + h0; s_base[4 * t + 2] = before + h0 + h1; s_base[4 * t + 3] = before + h0 + h1 + h2;
+    __syncthreads();
+    uint32_t b = 0, r = 0;
+    if (j < n) { b = bucket_of[j]; r = atomicAdd(&s_cnt[b], 1u); }
+    __syncthreads();
+    for (uint32_t q = t; q < RTS_TILE_BUCKETS; q += blockDim.x) if (s_cnt[q]) s_base[q] += atomicAdd(&taken[q], s_cnt[q]);
+    __syncthreads();
+    if (j < n) order[s_base[b] + r] = j;
+}
+
 // prev_valid: d_tile_cost holds the costs of a launch of shape prev_shape that have not been merged yet
 int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_valid, const uint64_t* cur_sig, uint32_t n_tiles_cur, uint32_t resident_waves)
 {
@@ -289,6 +358,16 @@ int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_vali
     c->xcd_affine_now = affine;
     if (affine) RTS_HIP(c->d_xcd.reserve(64));
     uint32_t* coarse = affine ? c->d_tile_ctr.p + RTS_OFF_COARSE : nullptr;
+    if (bins && !affine && c->order_fused && prev_valid && memcmp(prev_sig, cur_sig, 4 * sizeof(uint64_t)) == 0 && c->order_sum_valid) {
+        const RtsTileShape cur2 = shape(cur_sig);
+        const RtsHeadRule rule2 = {c->coop_frac, c->coop_big, c->coop_floor, resident_waves};
+        RTS_HIP(c->d_tile_key.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_order.reserve(n_tiles_cur)); RTS_HIP(c->d_xcd.reserve(64));
+        unsigned long long* persist = reinterpret_cast<unsigned long long*>(c->d_xcd.p + 32);
+        k_tile_merge_keys<<<blocks_for(n_tiles_cur, 256), 256, 0, st>>>(c->d_tile_cost.p, cur2, c->d_tile_hist.p, n_hist, reinterpret_cast<unsigned long long*>(head), persist, head ? head + 2 : nullptr, rule2, c->d_tile_key.p, bins);
+        k_tile_scan_scatter<<<blocks_for(n_tiles_cur, 256), 256, 0, st>>>(c->d_tile_key.p, n_tiles_cur, bins, c->d_tile_ctr.p + RTS_OFF_COARSE, c->d_tile_order.p, reinterpret_cast<const unsigned long long*>(head), head ? persist : nullptr);
+        RTS_HIP(hipGetLastError());
+        return RTS_OK;
+    }
     bool merged = false;
     if (prev_valid) { const RtsTileShape p = shape(prev_sig); if (p.n_tiles) { k_tile_merge<<<blocks_for(p.n_tiles, 256), 256, 0, st>>>(c->d_tile_cost.p, p, c->d_tile_hist.p, n_hist, reinterpret_cast<unsigned long long*>(head), coarse); merged = p.n_tiles == n_tiles_cur; } }
     RTS_HIP(c->d_tile_key.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_key_sorted.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_id.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_order.reserve(n_tiles_cur));
@@ -304,6 +383,11 @@ int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_vali
         if (affine) c->xcd_bnd_tiles = merged ? n_tiles_cur : 0u;               // (bands from a launch of another shape are not used)
         k_tile_bucket_scatter<<<blocks_for(n_tiles_cur, 256), 256, 0, st>>>(c->d_tile_key.p, n_tiles_cur, bins, c->d_tile_order.p);
         RTS_HIP(hipGetLastError());
+        if (head && c->order_fused && prev_valid) {                     // the launch's cost sum, kept for the two-launch form of the next build
+            RTS_HIP(c->d_xcd.reserve(64));
+            RTS_HIP(hipMemcpyAsync(c->d_xcd.p + 32, head, sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
+            c->order_sum_valid = true;
+        } else if (!head && c->order_fused) { RTS_HIP(c->d_xcd.reserve(64)); RTS_HIP(hipMemsetAsync(c->d_xcd.p + 32, 0, sizeof(unsigned long long), st)); c->order_sum_valid = true; }
         return RTS_OK;
     }
     size_t tmp = 0;
@@ -460,12 +544,9 @@ int rts_post_expand_all(RtsContext* c)
 }
 
 // --------------------------------------------------------------------------- uniform finalisation, ray_tracer.cpp:1219-1253
-__global__ void k_finalise(PerRayData* __restrict__ rays, const int32_t* __restrict__ paths, uint32_t R, uint32_t D,
-                           const double* __restrict__ rcs, uint32_t n_targets, double wl, double gt, double gr, double carrier, double cspeed, const unsigned long long* __restrict__ R_dev)
+__device__ __forceinline__ void finalise_row(PerRayData* __restrict__ rays, const int32_t* __restrict__ paths, const uint32_t i, const uint32_t D, const double* __restrict__ rcs, const uint32_t n_targets,
+                                             const double wl, const double gt, const double gr, const double carrier, const double cspeed)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (R_dev) { const unsigned long long v_ = *R_dev; if (v_ > (unsigned long long)R) return; R = (uint32_t)v_; }      // (speculative post-processing: the count is the trace kernel's, on the device; more than the caller's capacity: nothing is done here)
-    if (i >= R) return;
     double power = rays[i].power;
     for (uint32_t k = 0; k < D; k++) {
         int targ_k = paths[(size_t)i*D + k];
@@ -475,6 +556,14 @@ __global__ void k_finalise(PerRayData* __restrict__ rays, const int32_t* __restr
     double Vr = rays[i].doppler/2;                                           // :1252
     rays[i].doppler = carrier*(((1 + Vr/cspeed)/(1 - Vr/cspeed)) - 1);       // :1253
     rays[i].power = power;
+}
+__global__ void k_finalise(PerRayData* __restrict__ rays, const int32_t* __restrict__ paths, uint32_t R, uint32_t D,
+                           const double* __restrict__ rcs, uint32_t n_targets, double wl, double gt, double gr, double carrier, double cspeed, const unsigned long long* __restrict__ R_dev)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (R_dev) { const unsigned long long v_ = *R_dev; if (v_ > (unsigned long long)R) return; R = (uint32_t)v_; }      // (speculative post-processing: the count is the trace kernel's, on the device; more than the caller's capacity: nothing is done here)
+    if (i >= R) return;
+    finalise_row(rays, paths, i, D, rcs, n_targets, wl, gt, gr, carrier, cspeed);
 }
 
 int rts_post_finalise(RtsContext* c, const double* rcs_host, double wl, double gt, double gr, double carrier, double cspeed)
@@ -498,12 +587,9 @@ int rts_post_finalise(RtsContext* c, const double* rcs_host, double wl, double g
 
 // --------------------------------------------------------------------------- complex return cube
 // one lane per received ray, two f64 atomics (global_atomic_add_f64) into cube[rx][pulse][bin]
-__global__ void k_cube_accumulate(const PerRayData* __restrict__ rays, uint32_t R, double* __restrict__ cube, uint32_t n_rx, uint32_t n_pulses,
-                                  uint32_t n_bins, uint32_t pulse, double t0, double dt, double cspeed, double carrier, const unsigned long long* __restrict__ R_dev)
+__device__ __forceinline__ void cube_row(const PerRayData* __restrict__ rays, const uint32_t i, double* __restrict__ cube, const uint32_t n_rx, const uint32_t n_pulses, const uint32_t n_bins,
+                                         const uint32_t pulse, const double t0, const double dt, const double cspeed, const double carrier)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (R_dev) { const unsigned long long v_ = *R_dev; if (v_ > (unsigned long long)R) return; R = (uint32_t)v_; }      // (speculative post-processing: the count is the trace kernel's, on the device; more than the caller's capacity: nothing is done here)
-    if (i >= R) return;
     const PerRayData r = rays[i];
     if (r.received < 0 || (uint32_t)r.received >= n_rx) return;
     const double delay = (r.rayLength)/cspeed;                               // aggregation.cu:59
@@ -514,6 +600,14 @@ __global__ void k_cube_accumulate(const PerRayData* __restrict__ rays, uint32_t 
     double sn, cs; sincos(phase, &sn, &cs);
     double* cell = cube + 2 * (((size_t)r.received * n_pulses + pulse) * n_bins + (size_t)b);
     atomicAdd(cell, amp * cs); atomicAdd(cell + 1, amp * sn);
+}
+__global__ void k_cube_accumulate(const PerRayData* __restrict__ rays, uint32_t R, double* __restrict__ cube, uint32_t n_rx, uint32_t n_pulses,
+                                  uint32_t n_bins, uint32_t pulse, double t0, double dt, double cspeed, double carrier, const unsigned long long* __restrict__ R_dev)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (R_dev) { const unsigned long long v_ = *R_dev; if (v_ > (unsigned long long)R) return; R = (uint32_t)v_; }      // (speculative post-processing: the count is the trace kernel's, on the device; more than the caller's capacity: nothing is done here)
+    if (i >= R) return;
+    cube_row(rays, i, cube, n_rx, n_pulses, n_bins, pulse, t0, dt, cspeed, carrier);
 }
 
 int rts_cube_accumulate_device(RtsContext* c, uint32_t pulse_index, double cspeed, double carrier)
@@ -684,14 +778,16 @@ __global__ void k_agg_starts(const uint32_t* __restrict__ head, const uint32_t* 
 // Per-ray contributions (aggregation.cu:59-65) summed per group with a FIXED reduction shape
 // (segmented Hillis-Steele scan inside 256-element tiles, then tile partials in tile order), so
 // the f64 sums are reproducible run to run.  vals: 5 doubles {n, sqrt(power), delay, phase, doppler}.
-__global__ void __launch_bounds__(AGG_TILE) k_agg_tiles(const PerRayData* __restrict__ rays, const uint32_t* __restrict__ idx_sorted,
-        const uint32_t* __restrict__ gid_incl, const uint32_t* __restrict__ gstart, uint32_t R, double cspeed, double carrier,
-        double* __restrict__ gsum, double* __restrict__ tile_first, double* __restrict__ tile_last, const unsigned long long* __restrict__ R_dev)
+#define RTS_AGG_TILE_LDS (2 * 5 * AGG_TILE * 8 + AGG_TILE * 4)      // bytes of LDS one tile's reduction takes
+// (raw: RTS_AGG_TILE_LDS bytes of LDS, 8-byte aligned; called by all AGG_TILE threads of the block; ends with the block in step only
+// if the caller synchronises before `raw` is reused)
+__device__ __forceinline__ void agg_tile_block(unsigned char* __restrict__ raw, const uint32_t tile, const PerRayData* __restrict__ rays, const uint32_t* __restrict__ idx_sorted,
+        const uint32_t* __restrict__ gid_incl, const uint32_t* __restrict__ gstart, const uint32_t R, const double cspeed, const double carrier,
+        double* __restrict__ gsum, double* __restrict__ tile_first, double* __restrict__ tile_last)
 {
-    if (R_dev) { const unsigned long long v_ = *R_dev; if (v_ > (unsigned long long)R) return; R = (uint32_t)v_; }      // (speculative post-processing: the count is the trace kernel's, on the device; more than the caller's capacity: nothing is done here)
-    __shared__ double s_v[2][5][AGG_TILE];
-    __shared__ uint32_t s_g[AGG_TILE];
-    const uint32_t t = threadIdx.x, tile = blockIdx.x, i = tile * AGG_TILE + t;
+    double (*s_v)[5][AGG_TILE] = reinterpret_cast<double (*)[5][AGG_TILE]>(raw);
+    uint32_t* s_g = reinterpret_cast<uint32_t*>(raw + 2 * 5 * AGG_TILE * 8);
+    const uint32_t t = threadIdx.x, i = tile * AGG_TILE + t;
     const bool valid = i < R;
     uint32_t g = 0xffffffffu;
     double v[5] = {0, 0, 0, 0, 0};
@@ -726,6 +822,14 @@ __global__ void __launch_bounds__(AGG_TILE) k_agg_tiles(const PerRayData* __rest
     else if (gs < tile_lo) dst = tile_first + 5*(size_t)tile;                // run continues from the previous tile
     else dst = tile_last + 5*(size_t)tile;                                   // run continues into the next tile
     for (int k = 0; k < 5; k++) dst[k] = s_v[cur][k][t];
+}
+__global__ void __launch_bounds__(AGG_TILE) k_agg_tiles(const PerRayData* __restrict__ rays, const uint32_t* __restrict__ idx_sorted,
+        const uint32_t* __restrict__ gid_incl, const uint32_t* __restrict__ gstart, uint32_t R, double cspeed, double carrier,
+        double* __restrict__ gsum, double* __restrict__ tile_first, double* __restrict__ tile_last, const unsigned long long* __restrict__ R_dev)
+{
+    if (R_dev) { const unsigned long long v_ = *R_dev; if (v_ > (unsigned long long)R) return; R = (uint32_t)v_; }      // (speculative post-processing: the count is the trace kernel's, on the device; more than the caller's capacity: nothing is done here)
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[RTS_AGG_TILE_LDS];
+    agg_tile_block(s_raw, blockIdx.x, rays, idx_sorted, gid_incl, gstart, R, cspeed, carrier, gsum, tile_first, tile_last);
 }
 
 // groups spanning several tiles: partials added in tile order by one wave, fixed shape.  One wave per
@@ -870,12 +974,12 @@ __global__ void k_agg_export(const uint32_t* __restrict__ d_G, const double* __r
 // version with 1 024 threads and 56 KB waited for a CU to drain and made the pulse slower, 0.72 against 0.63 ms)
 
 // received rays in ascending buffer row (k_recv_keys / k_recv_keys64 + the sort): perm[j] = record of output row j
+// (raw: LDS for the block sort's storage, 16-byte aligned, at least sizeof(block_radix_sort<K, 256, ITEMS, uint32_t>::storage_type))
 template <typename K, int ITEMS>
-__global__ void __launch_bounds__(RTS_SMALL_THREADS) k_recv_order_small(const RtsEndRecord* __restrict__ rec, uint32_t n, uint32_t n_rays, int with_chain, uint32_t bits, uint32_t* __restrict__ perm, const unsigned long long* __restrict__ R_dev)
+__device__ __forceinline__ void recv_order_block(unsigned char* __restrict__ raw, const RtsEndRecord* __restrict__ rec, const uint32_t n, const uint32_t n_rays, const int with_chain, const uint32_t bits, uint32_t* __restrict__ perm)
 {
     typedef rocprim::block_radix_sort<K, RTS_SMALL_THREADS, ITEMS, uint32_t> Sort;
-    { uint32_t R = n; bool skip = false; if (R_dev) { const unsigned long long v_ = *R_dev; if (v_ > (unsigned long long)R) skip = true; else R = (uint32_t)v_; } if (skip) return; n = R; }
-    __shared__ typename Sort::storage_type s_sort;
+    typename Sort::storage_type& s_sort = *reinterpret_cast<typename Sort::storage_type*>(raw);
     K k[ITEMS]; uint32_t v[ITEMS];
     for (uint32_t j = 0; j < ITEMS; j++) {
         const uint32_t i = threadIdx.x * ITEMS + j;
@@ -885,17 +989,27 @@ __global__ void __launch_bounds__(RTS_SMALL_THREADS) k_recv_order_small(const Rt
     Sort().sort(k, v, s_sort, 0, bits);
     for (uint32_t j = 0; j < ITEMS; j++) { const uint32_t i = threadIdx.x * ITEMS + j; if (i < n) perm[i] = v[j]; }
 }
-
-// k_agg_keys + sort + k_agg_heads + inclusive scan + k_agg_starts
 template <typename K, int ITEMS>
-__global__ void __launch_bounds__(RTS_SMALL_THREADS) k_agg_order_small(const PerRayData* __restrict__ rays, const int32_t* __restrict__ paths, uint32_t R, uint32_t D, uint32_t B, uint32_t key_bits,
-                                                                       uint64_t* __restrict__ keys_sorted, uint32_t* __restrict__ idx_sorted, uint32_t* __restrict__ head,
-                                                                       uint32_t* __restrict__ gid_incl, uint32_t* __restrict__ gstart, const unsigned long long* __restrict__ R_dev)
+__global__ void __launch_bounds__(RTS_SMALL_THREADS) k_recv_order_small(const RtsEndRecord* __restrict__ rec, uint32_t n, uint32_t n_rays, int with_chain, uint32_t bits, uint32_t* __restrict__ perm, const unsigned long long* __restrict__ R_dev)
 {
     typedef rocprim::block_radix_sort<K, RTS_SMALL_THREADS, ITEMS, uint32_t> Sort;
-    if (R_dev) { const unsigned long long v_ = *R_dev; if (v_ > (unsigned long long)R) return; R = (uint32_t)v_; }      // (speculative post-processing: the count is the trace kernel's, on the device; more than the caller's capacity: nothing is done here)
-    __shared__ typename Sort::storage_type s_sort;
-    __shared__ K s_last[RTS_SMALL_THREADS]; __shared__ uint32_t s_sum[2][RTS_SMALL_THREADS];
+    { uint32_t R = n; bool skip = false; if (R_dev) { const unsigned long long v_ = *R_dev; if (v_ > (unsigned long long)R) skip = true; else R = (uint32_t)v_; } if (skip) return; n = R; }
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[sizeof(typename Sort::storage_type)];
+    recv_order_block<K, ITEMS>(s_raw, rec, n, n_rays, with_chain, bits, perm);
+}
+
+// k_agg_keys + sort + k_agg_heads + inclusive scan + k_agg_starts
+template <typename K, int ITEMS> struct RtsAggOrderLds {
+    typedef rocprim::block_radix_sort<K, RTS_SMALL_THREADS, ITEMS, uint32_t> Sort;
+    typename Sort::storage_type sort; K last[RTS_SMALL_THREADS]; uint32_t sum[2][RTS_SMALL_THREADS];
+};
+template <typename K, int ITEMS>
+__device__ __forceinline__ void agg_order_block(unsigned char* __restrict__ raw, const PerRayData* __restrict__ rays, const int32_t* __restrict__ paths, const uint32_t R, const uint32_t D, const uint32_t B, const uint32_t key_bits,
+                                                uint64_t* __restrict__ keys_sorted, uint32_t* __restrict__ idx_sorted, uint32_t* __restrict__ head, uint32_t* __restrict__ gid_incl, uint32_t* __restrict__ gstart)
+{
+    typedef rocprim::block_radix_sort<K, RTS_SMALL_THREADS, ITEMS, uint32_t> Sort;
+    RtsAggOrderLds<K, ITEMS>& L = *reinterpret_cast<RtsAggOrderLds<K, ITEMS>*>(raw);
+    typename Sort::storage_type& s_sort = L.sort; K* s_last = L.last; uint32_t (*s_sum)[RTS_SMALL_THREADS] = L.sum;
     K k[ITEMS]; uint32_t v[ITEMS];
     const uint32_t i0 = threadIdx.x * ITEMS;
     const uint32_t sort_bits = key_bits < 8u * (uint32_t)sizeof(K) ? key_bits + 1u : 8u * (uint32_t)sizeof(K);
@@ -939,34 +1053,168 @@ __global__ void __launch_bounds__(RTS_SMALL_THREADS) k_agg_order_small(const Per
         if (i == R - 1) gstart[run] = R;
     }
 }
+template <typename K, int ITEMS>
+__global__ void __launch_bounds__(RTS_SMALL_THREADS) k_agg_order_small(const PerRayData* __restrict__ rays, const int32_t* __restrict__ paths, uint32_t R, uint32_t D, uint32_t B, uint32_t key_bits,
+                                                                       uint64_t* __restrict__ keys_sorted, uint32_t* __restrict__ idx_sorted, uint32_t* __restrict__ head,
+                                                                       uint32_t* __restrict__ gid_incl, uint32_t* __restrict__ gstart, const unsigned long long* __restrict__ R_dev)
+{
+    if (R_dev) { const unsigned long long v_ = *R_dev; if (v_ > (unsigned long long)R) return; R = (uint32_t)v_; }      // (speculative post-processing: the count is the trace kernel's, on the device; more than the caller's capacity: nothing is done here)
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[sizeof(RtsAggOrderLds<K, ITEMS>)];
+    agg_order_block<K, ITEMS>(s_raw, rays, paths, R, D, B, key_bits, keys_sorted, idx_sorted, head, gid_incl, gstart);
+}
 
 // k_agg_span + k_agg_groupinfo + k_agg_rxtot + k_agg_scatter + k_agg_export (after k_agg_tiles)
-__global__ void __launch_bounds__(256) k_agg_finish_small(PerRayData* __restrict__ rays, const uint32_t* __restrict__ idx_sorted, const uint64_t* __restrict__ keys_sorted,
-        const uint32_t* __restrict__ gid_incl, const uint32_t* __restrict__ gstart, uint32_t R, uint32_t ntiles, const double* __restrict__ tile_first, const double* __restrict__ tile_last,
-        double* __restrict__ gsum, uint32_t* __restrict__ gmin, uint64_t* __restrict__ gkey, uint32_t* __restrict__ d_G, const uint64_t* __restrict__ rows, uint64_t* __restrict__ grow,
-        uint32_t shift, uint32_t n_rx_tab, double* __restrict__ rxtot, uint32_t* __restrict__ rxmin, int64_t base,
-        const double* __restrict__ npath0, const double* __restrict__ power0, const double* __restrict__ doppler0, double* __restrict__ delay, double* __restrict__ phase,
-        int32_t* __restrict__ pm, int32_t pm_init_const, int use_pm_in, int dly_in,
-        uint32_t spec, uint32_t* __restrict__ h_G, double* __restrict__ h_gsum, uint32_t* __restrict__ h_gmin, uint64_t* __restrict__ h_gkey, uint64_t* __restrict__ h_grow,
-        const unsigned long long* __restrict__ R_dev)
+struct RtsAggFinish {
+    PerRayData* rays; const uint32_t* idx_sorted; const uint64_t* keys_sorted; const uint32_t* gid_incl; const uint32_t* gstart; const double* tile_first; const double* tile_last;
+    double* gsum; uint32_t* gmin; uint64_t* gkey; uint32_t* d_G; const uint64_t* rows; uint64_t* grow; uint32_t shift, n_rx_tab; double* rxtot; uint32_t* rxmin; int64_t base;
+    const double* npath0; const double* power0; const double* doppler0; double* delay; double* phase; int32_t* pm; int32_t pm_init_const; int use_pm_in, dly_in;
+    uint32_t spec; uint32_t* h_G; double* h_gsum; uint32_t* h_gmin; uint64_t* h_gkey; uint64_t* h_grow;
+};
+// (R >= 1; spec <= R; called by all 256 threads of the block)
+__device__ __forceinline__ void agg_finish_block(const RtsAggFinish& q, const uint32_t R, const uint32_t ntiles, const uint32_t spec)
 {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    for (uint32_t T0 = wave; T0 < ntiles; T0 += n_waves) agg_span_body(T0, lane, q.gstart, q.gid_incl, R, q.tile_first, q.tile_last, q.gsum);
+    __syncthreads();
+    const uint32_t G = q.gid_incl[R - 1];
+    for (uint32_t g = threadIdx.x; g < G; g += blockDim.x) agg_groupinfo_body(g, q.gstart, q.idx_sorted, q.keys_sorted, q.gid_incl, R, q.gmin, q.gkey, q.d_G, q.rows, q.grow);      // (G >= 1: thread 0 publishes the count)
+    __syncthreads();
+    for (uint32_t rx = wave; rx < q.n_rx_tab; rx += n_waves) agg_rxtot_body(rx, lane, q.gkey, q.gsum, q.gmin, q.d_G, q.shift, q.rxtot, q.rxmin);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < R; i += blockDim.x)
+        agg_scatter_body(i, q.rays, q.idx_sorted, q.gid_incl, q.gsum, q.gmin, q.rxtot, q.rxmin, q.n_rx_tab, R, q.base, q.npath0, q.power0, q.doppler0, q.delay, q.phase, q.pm, q.pm_init_const, q.use_pm_in, q.dly_in);
+    if (q.h_G) { __syncthreads(); for (uint32_t i = threadIdx.x; i < spec; i += blockDim.x) agg_export_body(i, q.d_G, q.gsum, q.gmin, q.gkey, q.grow, spec, q.h_G, q.h_gsum, q.h_gmin, q.h_gkey, q.h_grow); }      // (spec >= 1)
+}
+__global__ void __launch_bounds__(256) k_agg_finish_small(const RtsAggFinish q, uint32_t R, uint32_t ntiles, const unsigned long long* __restrict__ R_dev)
+{
+    uint32_t spec = q.spec;
     if (R_dev) {
         const unsigned long long v_ = *R_dev;
         if (v_ > (unsigned long long)R) return;
         R = (uint32_t)v_; ntiles = (R + AGG_TILE - 1) / AGG_TILE; spec = min(spec, R);
-        if (R == 0u) { if (h_G && threadIdx.x == 0) *h_G = 0u; return; }
+        if (R == 0u) { if (q.h_G && threadIdx.x == 0) *q.h_G = 0u; return; }
     }
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
-    for (uint32_t T0 = wave; T0 < ntiles; T0 += n_waves) agg_span_body(T0, lane, gstart, gid_incl, R, tile_first, tile_last, gsum);
+    agg_finish_block(q, R, ntiles, spec);
+}
+
+// ---------------------------------------------------------------------------- ONE kernel behind the trace (r04)
+// A pulse's post-processing for a caller without host callbacks (rts_trace_pulse_end_uniform) and a received set the one-block
+// kernels take: order -> expand -> finalise -> cube -> aggregation order -> tile sums -> finish in ONE block of ONE launch instead
+// of seven launches of one or a few blocks each.  Every one of the seven waited its turn among the blocks of the neighbouring
+// pulses' trace kernels -- 40-350 us apiece in profiles/r03c_pulse_timeline.log for 4-50 us of work -- and the chain was the
+// longest dependent sequence behind a trace.  Same bodies as the separate kernels (shared functions above), same bits.  The
+// received count is read from the device (the trace kernel's counter): the launch needs no host wait, and sorts as many items per
+// thread as the count asks for (the separate kernels are sized on the host, by a hint).
+struct RtsPostAll {
+    RtsTraceArgs ta; const RtsEndRecord* rec; uint32_t cap, n_rays; int with_chain; uint32_t bits; uint32_t* perm;
+    uint32_t D; PerRayData* rays; int32_t* paths; double* angles; uint64_t* slots;
+    const double* rcs; uint32_t n_targets; double wl, gt, gr, carrier, cspeed;
+    int cube_on; double* cube; uint32_t cube_rx, cube_pulses, cube_bins, cube_pulse; double cube_t0, cube_dt;
+    uint32_t B, key_bits; uint32_t* ahead;
+    RtsAggFinish fin;
+    const unsigned long long* R_dev; uint32_t prio;
+};
+template <typename K> struct RtsSortMax { enum { ITEMS = sizeof(K) == 4 ? 16 : 8 }; };
+#define RTS_POST_ALL_LDS 36864
+template <typename KR, typename KA>
+__global__ void __launch_bounds__(RTS_SMALL_THREADS) k_post_all(const RtsPostAll q)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[RTS_POST_ALL_LDS];
+    static_assert(sizeof(RtsAggOrderLds<KA, RtsSortMax<KA>::ITEMS>) <= RTS_POST_ALL_LDS && sizeof(typename rocprim::block_radix_sort<KR, RTS_SMALL_THREADS, RtsSortMax<KR>::ITEMS, uint32_t>::storage_type) <= RTS_POST_ALL_LDS &&
+                  RTS_AGG_TILE_LDS <= RTS_POST_ALL_LDS, "LDS of the fused post-processing kernel");
+    // (one block that shares its CU with three blocks of trace kernels, on the critical path of its pulse: its four waves take the
+    // issue slots first -- RTS_POST_PRIO, default 3)
+    if (q.prio) { if (q.prio == 1) __builtin_amdgcn_s_setprio(1); else if (q.prio == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3); }
+    const unsigned long long R64 = *q.R_dev;
+    if (R64 > (unsigned long long)q.cap) return;                       // more than the buffers were sized for: nothing is done, the host runs the general chain
+    const uint32_t R = (uint32_t)R64;
+    if (R == 0u) { if (q.fin.h_G && threadIdx.x == 0) *q.fin.h_G = 0u; return; }
+    // ---- received rays in ascending buffer row
+    if (R <= 4u * RTS_SMALL_THREADS) recv_order_block<KR, 4>(s_raw, q.rec, R, q.n_rays, q.with_chain, q.bits, q.perm);
+    else if (R <= 8u * RTS_SMALL_THREADS || RtsSortMax<KR>::ITEMS == 8) recv_order_block<KR, 8>(s_raw, q.rec, R, q.n_rays, q.with_chain, q.bits, q.perm);
+    else recv_order_block<KR, RtsSortMax<KR>::ITEMS>(s_raw, q.rec, R, q.n_rays, q.with_chain, q.bits, q.perm);
     __syncthreads();
-    const uint32_t G = gid_incl[R - 1];
-    for (uint32_t g = threadIdx.x; g < G; g += blockDim.x) agg_groupinfo_body(g, gstart, idx_sorted, keys_sorted, gid_incl, R, gmin, gkey, d_G, rows, grow);      // (G >= 1: thread 0 publishes the count)
+    // ---- the reference's output records, the uniform finalisation, the return cube: row by row
+    for (uint32_t j = threadIdx.x; j < R; j += RTS_SMALL_THREADS) {
+        expand_row(q.ta, q.rec, q.perm, j, q.D, q.rays, q.paths, q.angles, q.slots);
+        finalise_row(q.rays, q.paths, j, q.D, q.rcs, q.n_targets, q.wl, q.gt, q.gr, q.carrier, q.cspeed);
+        if (q.cube_on) cube_row(q.rays, j, q.cube, q.cube_rx, q.cube_pulses, q.cube_bins, q.cube_pulse, q.cube_t0, q.cube_dt, q.cspeed, q.carrier);
+    }
     __syncthreads();
-    for (uint32_t rx = wave; rx < n_rx_tab; rx += n_waves) agg_rxtot_body(rx, lane, gkey, gsum, gmin, d_G, shift, rxtot, rxmin);
+    // ---- aggregation: order, tile sums, finish
+    if (R <= 4u * RTS_SMALL_THREADS) agg_order_block<KA, 4>(s_raw, q.rays, q.paths, R, q.D, q.B, q.key_bits, const_cast<uint64_t*>(q.fin.keys_sorted), const_cast<uint32_t*>(q.fin.idx_sorted), q.ahead, const_cast<uint32_t*>(q.fin.gid_incl), const_cast<uint32_t*>(q.fin.gstart));
+    else if (R <= 8u * RTS_SMALL_THREADS || RtsSortMax<KA>::ITEMS == 8) agg_order_block<KA, 8>(s_raw, q.rays, q.paths, R, q.D, q.B, q.key_bits, const_cast<uint64_t*>(q.fin.keys_sorted), const_cast<uint32_t*>(q.fin.idx_sorted), q.ahead, const_cast<uint32_t*>(q.fin.gid_incl), const_cast<uint32_t*>(q.fin.gstart));
+    else agg_order_block<KA, RtsSortMax<KA>::ITEMS>(s_raw, q.rays, q.paths, R, q.D, q.B, q.key_bits, const_cast<uint64_t*>(q.fin.keys_sorted), const_cast<uint32_t*>(q.fin.idx_sorted), q.ahead, const_cast<uint32_t*>(q.fin.gid_incl), const_cast<uint32_t*>(q.fin.gstart));
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < R; i += blockDim.x)
-        agg_scatter_body(i, rays, idx_sorted, gid_incl, gsum, gmin, rxtot, rxmin, n_rx_tab, R, base, npath0, power0, doppler0, delay, phase, pm, pm_init_const, use_pm_in, dly_in);
-    if (h_G) { __syncthreads(); for (uint32_t i = threadIdx.x; i < spec; i += blockDim.x) agg_export_body(i, d_G, gsum, gmin, gkey, grow, spec, h_G, h_gsum, h_gmin, h_gkey, h_grow); }      // (spec >= 1)
+    const uint32_t ntiles = (R + AGG_TILE - 1) / AGG_TILE;
+    for (uint32_t tile = 0; tile < ntiles; tile++) {
+        agg_tile_block(s_raw, tile, q.rays, q.fin.idx_sorted, q.fin.gid_incl, q.fin.gstart, R, q.cspeed, q.carrier, q.fin.gsum, const_cast<double*>(q.fin.tile_first), const_cast<double*>(q.fin.tile_last));
+        __syncthreads();
+    }
+    agg_finish_block(q.fin, R, ntiles, min(q.fin.spec, R));
+}
+
+// Enqueues k_post_all for the pulse whose trace is in flight or over: buffers sized for `cap` rays, the count from the device.
+// The caller has checked: no KEEP_ALL, a (receiver, path) key of <= 64 bits, cap within the one-block sorts.
+int rts_post_all_small(RtsContext* c, uint32_t cap, const RtsSpecParams& sp, bool want_groups)
+{
+    const uint32_t D = c->depth; hipStream_t st = c->stream;
+    const uint32_t nt = (uint32_t)c->scene->meshes.size();
+    // ---- what rts_post_order_and_expand, rts_post_finalise and rts_aggregate_device reserve, for cap rays
+    RTS_HIP(c->d_ri.reserve(cap)); RTS_HIP(c->d_ri_sorted.reserve(cap));
+    RTS_HIP(c->d_rx_rays.reserve(cap)); RTS_HIP(c->d_rx_paths.reserve((size_t)cap*D + 1)); RTS_HIP(c->d_rx_angles.reserve((size_t)cap*D*2 + 1)); RTS_HIP(c->d_rx_slots.reserve(cap));
+    RTS_HIP(c->d_rcsval.reserve(nt + 1));
+    bool changed = !c->rcs_uploaded;
+    for (uint32_t t = 0; t < nt && t < 256; t++) changed = changed || memcmp(&c->pin->rcs[t], &sp.rcs[t], sizeof(double)) != 0;
+    if (changed) {
+        RTS_HIP(hipStreamSynchronize(st));
+        for (uint32_t t = 0; t < nt && t < 256; t++) c->pin->rcs[t] = sp.rcs[t];
+        if (nt) RTS_HIP(hipMemcpyAsync(c->d_rcsval.p, c->pin->rcs, sizeof(double)*nt, hipMemcpyHostToDevice, st));
+        c->rcs_uploaded = true;
+    }
+    const int32_t max_path = (int32_t)nt - 1, max_rx = c->n_rx ? (int32_t)c->n_rx - 1 : 0;
+    uint32_t B = 1; while (((uint64_t)1 << B) < (uint64_t)(max_path + 2)) B++;
+    uint32_t RXB = 1; while (((uint64_t)1 << RXB) < (uint64_t)(max_rx + 1)) RXB++;
+    if (D == 0) B = 0;
+    const uint32_t key_bits = D * B + RXB, shift = D * B, n_rx_tab = (uint32_t)max_rx + 1, ntiles = blocks_for(cap, AGG_TILE);
+    const size_t R = cap;
+    RTS_HIP(c->d_delay.reserve(R)); RTS_HIP(c->d_phase.reserve(R)); RTS_HIP(c->d_pathmatch.reserve(R));
+    RTS_HIP(c->d_akeys.reserve(R)); RTS_HIP(c->d_akeys_sorted.reserve(R)); RTS_HIP(c->d_aidx.reserve(R)); RTS_HIP(c->d_aidx_sorted.reserve(R));
+    RTS_HIP(c->d_ghead.reserve(R)); RTS_HIP(c->d_gid.reserve(R));
+    RTS_HIP(c->d_gcount.reserve(R + 4)); RTS_HIP(c->d_gsum.reserve(5*(R + 2*(size_t)ntiles) + 16));
+    RTS_HIP(c->d_gmin.reserve(R)); RTS_HIP(c->d_gkey.reserve(R));
+    const bool use_rows = sp.base == RTS_BASE_USE_ROWS;
+    if (use_rows) RTS_HIP(c->d_grow.reserve(R));
+    RTS_HIP(c->d_rcs.reserve(5*(size_t)n_rx_tab + n_rx_tab + 8));
+    uint32_t* gstart = c->d_gcount.p; uint32_t* d_G = c->d_gcount.p + R + 2;
+    double* gsum = c->d_gsum.p; double* tile_first = gsum + 5*R; double* tile_last = tile_first + 5*(size_t)ntiles;
+    double* d_rxtot = c->d_rcs.p; uint32_t* d_rxmin = (uint32_t*)(c->d_rcs.p + 5*(size_t)n_rx_tab);
+    RtsPinned* pd = c->pin_dev;
+    const uint64_t base = use_rows ? 0 : sp.base;
+    RtsPostAll q; memset(&q, 0, sizeof(q));
+    q.ta = c->last_args; q.rec = c->d_recv.p; q.cap = cap; q.n_rays = c->n_rays; q.with_chain = c->last_args.max_refr != 0 ? 1 : 0;
+    { const uint64_t rows = (uint64_t)c->n_rays * (c->last_args.max_refr != 0 ? 3u : 1u); uint32_t bits = 1; while (bits < 40 && ((uint64_t)1 << bits) <= rows) bits++; q.bits = bits; }
+    q.perm = c->d_ri_sorted.p; q.D = D; q.rays = c->d_rx_rays.p; q.paths = c->d_rx_paths.p; q.angles = c->d_rx_angles.p; q.slots = c->d_rx_slots.p;
+    q.rcs = c->d_rcsval.p; q.n_targets = nt; q.wl = sp.wl; q.gt = sp.gt; q.gr = sp.gr; q.carrier = sp.carrier; q.cspeed = sp.cspeed;
+    q.cube_on = sp.cube_pulse >= 0 ? 1 : 0;
+    if (q.cube_on) { const RtsCubeParams& cp = c->cube_params; q.cube = c->cube; q.cube_rx = cp.n_rx; q.cube_pulses = cp.n_pulses; q.cube_bins = cp.n_bins; q.cube_pulse = (uint32_t)sp.cube_pulse; q.cube_t0 = cp.t0; q.cube_dt = cp.dt; }
+    q.B = B; q.key_bits = key_bits; q.ahead = c->d_ghead.p;
+    const uint32_t spec_s = std::min<uint32_t>(cap, RTS_PIN_GROUPS);
+    q.fin = RtsAggFinish{c->d_rx_rays.p, c->d_aidx_sorted.p, c->d_akeys_sorted.p, c->d_gid.p, gstart, tile_first, tile_last, gsum, c->d_gmin.p, c->d_gkey.p, d_G,
+                         use_rows ? c->d_rx_slots.p : nullptr, use_rows ? c->d_grow.p : nullptr, shift, n_rx_tab, d_rxtot, d_rxmin, (int64_t)base, nullptr, nullptr, nullptr,
+                         c->d_delay.p, c->d_phase.p, c->d_pathmatch.p, INT32_MAX, 0, 0,
+                         spec_s, want_groups ? &pd->G : nullptr, pd->gsum, pd->gmin, pd->gkey, pd->grow};
+    q.R_dev = c->p_counters; q.prio = c->post_prio;
+    const bool kr64 = c->last_args.max_refr != 0, ka64 = key_bits >= 32u;
+    if (!kr64 && !ka64) k_post_all<uint32_t, uint32_t><<<1, RTS_SMALL_THREADS, 0, st>>>(q);
+    else if (!kr64) k_post_all<uint32_t, uint64_t><<<1, RTS_SMALL_THREADS, 0, st>>>(q);
+    else if (!ka64) k_post_all<uint64_t, uint32_t><<<1, RTS_SMALL_THREADS, 0, st>>>(q);
+    else k_post_all<uint64_t, uint64_t><<<1, RTS_SMALL_THREADS, 0, st>>>(q);
+    RTS_HIP(hipGetLastError());
+    c->recv_index_base = sp.base; c->agg_base_local = use_rows ? 0 : (int64_t)sp.base;
+    RtsAggPending& ap = c->agg_pending;
+    ap.valid = true; ap.R = cap; ap.D = D; ap.B = B; ap.shift = shift; ap.wide = false; ap.base = base; ap.rows = use_rows; ap.spec = spec_s; ap.gsum = gsum;
+    return RTS_OK;
 }
 
 // Aggregates R device-resident rays.  d_delay/d_phase/d_pm are in-out (initial values as the
@@ -1044,10 +1292,11 @@ int rts_aggregate_device(RtsContext* c, int32_t max_path, int32_t max_rx, const 
     if (small) {
         RtsPinned* pd = c->pin_dev;
         const uint32_t spec_s = std::min<uint32_t>(R, RTS_PIN_GROUPS);
-        k_agg_finish_small<<<1, 256, 0, st>>>(d_rays, c->d_aidx_sorted.p, c->d_akeys_sorted.p, c->d_gid.p, gstart, R, ntiles, tile_first, tile_last, gsum, c->d_gmin.p, c->d_gkey.p, d_G,
-                                              d_rows, d_rows ? c->d_grow.p : nullptr, shift, n_rx_tab, d_rxtot, d_rxmin, (int64_t)base, d_npath, d_power_sum, d_doppler_sum, d_delay, d_phase, d_pm,
-                                              pm_init, pm_init == INT32_MIN ? 1 : 0, c->agg_delay_in ? 1 : 0,
-                                              spec_s, groups ? &pd->G : nullptr, pd->gsum, pd->gmin, pd->gkey, pd->grow, c->recv_dev);
+        const RtsAggFinish fq = {d_rays, c->d_aidx_sorted.p, c->d_akeys_sorted.p, c->d_gid.p, gstart, tile_first, tile_last, gsum, c->d_gmin.p, c->d_gkey.p, d_G,
+                                 d_rows, d_rows ? c->d_grow.p : nullptr, shift, n_rx_tab, d_rxtot, d_rxmin, (int64_t)base, d_npath, d_power_sum, d_doppler_sum, d_delay, d_phase, d_pm,
+                                 pm_init, pm_init == INT32_MIN ? 1 : 0, c->agg_delay_in ? 1 : 0,
+                                 spec_s, groups ? &pd->G : nullptr, pd->gsum, pd->gmin, pd->gkey, pd->grow};
+        k_agg_finish_small<<<1, 256, 0, st>>>(fq, R, ntiles, c->recv_dev);
         RTS_HIP(hipGetLastError());
         if (!groups) { RTS_HIP(hipStreamSynchronize(st)); return RTS_OK; }
         RtsAggPending& ap = c->agg_pending;
