@@ -178,8 +178,8 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     { const char* e = getenv("RTS_ASYNC_IDLE0"); if (e) c->async_idle0 = (uint32_t)std::min(64, std::max(0, atoi(e))); }
     { const char* e = getenv("RTS_ASYNC_IDLE1"); if (e) c->async_idle1 = (uint32_t)std::min(64, std::max(1, atoi(e))); }
     { const char* e = getenv("RTS_ASYNC_AGE"); if (e) c->async_age = (uint32_t)std::max(0, atoi(e)); }
-    { const char* e = getenv("RTS_COOP_SEG"); if (e) c->coop_seg_cost = (uint32_t)std::max(0, atoi(e)); }
-    { const char* e = getenv("RTS_COOP_SEG_RATIO"); if (e) c->coop_seg_ratio = std::max(0.0, atof(e)); }
+    { const char* e = getenv("RTS_COOP_STEPS"); if (e) c->coop_walk_steps = (uint32_t)std::max(0, atoi(e)); }
+    { const char* e = getenv("RTS_COOP_SEG"); if (e && atoi(e) == 0) c->coop_walk_steps = 0; }      // (the tests' old switch: every tile above the floor is flagged)
     { const char* e = getenv("RTS_COOP_BIG"); if (e) c->coop_big = std::max(0.0, atof(e)); }
     { const char* e = getenv("RTS_COOP_SPREAD"); if (e) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) c->coop_spread = (uint32_t)v; } }
     { const char* e = getenv("RTS_COOP_GRID"); if (e) c->coop_grid_max = (uint32_t)std::min(4096, std::max(1, atoi(e))); }
@@ -739,10 +739,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     a.total_threads = grid * RTS_BLOCK;
     a.async_idle0 = c->async_idle0; a.async_idle1 = c->async_idle1; a.async_age = c->async_age;
     a.coop_spread = c->coop_spread;
-    a.coop_seg_cost = c->coop_seg_cost; a.coop_min_cost = c->coop_seg_cost ? std::min<uint32_t>(c->coop_floor, 1875u) : 0u;      // (nothing shorter than 50 us is looked at; RTS_COOP_SEG=0: every tile is flagged)
-    if (c->coop_seg_cost && c->last_units_per_segment > 0.0)
-        a.coop_seg_cost = (uint32_t)std::min(4.0e9, std::max((double)c->coop_seg_cost, c->coop_seg_ratio * c->last_units_per_segment));
-    else if (c->coop_seg_cost) a.coop_min_cost = 0xffffffffu;     // first launch of the handle: no yardstick yet, and its tiles run cold and in index order -- nothing is flagged
+    a.coop_walk_steps = c->coop_walk_steps; a.coop_min_cost = c->coop_walk_steps ? std::min<uint32_t>(c->coop_floor, 1875u) : 0u;      // (nothing shorter than 50 us is looked at; RTS_COOP_STEPS=0: every tile is flagged)
     const uint32_t coop_threads = c->coop_frac > 0.0 ? c->coop_grid_max * RTS_BLOCK : 0u;      // the cooperative kernel's rows of the per-thread slabs
     a.slab_threads = a.total_threads + coop_threads;
     RTS_HIP(c->d_recv.reserve((size_t)n * chains + 1));
@@ -808,7 +805,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
         else coop_grid = (unsigned)std::min<uint64_t>(c->coop_grid_max, std::max<uint64_t>(16, (units + 3) / 4));
         c->last_args = a;
     }
-    if (c->debug_coop) fprintf(stderr, "[rts] launch: n_rays %u grid %u head hint %u coop grid %u seg threshold %u min cost %u order %d\n", n, grid, c->n_head_hint, coop_grid, a.coop_seg_cost, a.coop_min_cost, a.tile_order ? 1 : 0);
+    if (c->debug_coop) fprintf(stderr, "[rts] launch: n_rays %u grid %u head hint %u coop grid %u walk-steps threshold %u min cost %u order %d\n", n, grid, c->n_head_hint, coop_grid, a.coop_walk_steps, a.coop_min_cost, a.tile_order ? 1 : 0);
     c->last_coop_grid = coop_grid;
     int rc = rts_trace_launch(c, a, count_trav, coop_grid);
     if (rc != RTS_OK) return rc;
@@ -839,12 +836,6 @@ static void rts_pulse_account(RtsContext* c, const unsigned long long* cnt)
     s.walked_segments = cnt[11]; s.reserved = 0;
     s.coop_tiles = c->last_coop_grid ? (uint32_t)std::min<unsigned long long>(std::min<unsigned long long>(cnt[7], (n + RTS_WTILE - 1) / RTS_WTILE), 16384ull) : 0u;      // (the bounds k_trace applies to the order's head count)
     c->pre_dense = 2 * s.shaded > (uint64_t)n;                      // next launch of this handle: pre-filter only if most launch indices hit nothing
-    {   // mean cost of a traced segment in this launch, in the units of the tile cost records (shader clocks >> 6 of one wave):
-        // kernel time x resident waves / segments -- the yardstick of the LONG WALKS flag of the next launch (rts_trace.hip)
-        float ms = 0.0f;
-        if (s.segments > 0 && hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess && ms > 0.0f)
-            c->last_units_per_segment = (double)ms * 1.0e-3 * (2.4e9 / 64.0) * (double)(c->last_args.total_threads / RTS_WTILE) / (double)s.segments;
-    }
     s.ms_scene = s.ms_trace = s.ms_compact = s.ms_aggregate = 0;
     c->stats_pending = true;
     c->recv_hint = cnt[0]; c->recv_hint_valid = true;

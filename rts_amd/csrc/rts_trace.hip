@@ -319,7 +319,7 @@ __device__ __forceinline__ void rts_walk_coop(const RtsTraceArgs& a, int32_t* s_
 //                  occupies ONE wave for 7-13 ms of a launch whose balanced time is 7.8 ms; as 64 cooperative units it is
 //                  spread over 64 waves that finish each ray in a few hundred wave steps.
 // The two share every expression of the payload arithmetic (same code, same operand order): results are bit-identical.
-struct RtsUnitLds { int32_t* stack; int32_t* exch; double* first; unsigned long long* path; uint32_t* n; const RtsRxDev* rx; const float (*rxp)[6]; uint32_t* lane_scratch; };
+struct RtsUnitLds { int32_t* stack; int32_t* exch; double* first; unsigned long long* path; uint32_t* n; const RtsRxDev* rx; const float (*rxp)[6]; uint32_t* lane_scratch; uint32_t* walk; };      // walk: per wave [walk iterations of the tile, walks]
 // The payload of one ray chain between its segments (PerRayData fields that the walk does not touch but the shading does;
 // the first hit point, the path words and the counters live in LDS, RtsUnitLds).
 struct RtsRay { dvec3 dir, prev; double rayLength, power, doppler, refx, refy; uint32_t reflDepth, refrDepth; int received; bool end, chain_start; };
@@ -630,6 +630,8 @@ __device__ __forceinline__ void rts_trace_unit(const RtsTraceArgs& a, const RtsL
         for (;;) {
             // ------------------------------------------------------------ rtTrace: closest hit over the targets' hierarchies
             if (!COOP || lane == 0) atomicAdd(&s_n[tid], RTS_SEG_ONE);           // (ds_add_u32, no return; bits 0-21 the lane's segments of the launch, bits 22-31 those of the current tile)
+            if (!COOP) { const unsigned long long ex_ = __ballot(true);             // one bounce round more in the tile's walk statistics (first lane still in the chain)
+                         if (__builtin_amdgcn_mbcnt_hi((uint32_t)(ex_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ex_, 0u)) == 0u) atomicAdd(&L_.walk[2u * __builtin_amdgcn_readfirstlane(tid >> 6) + 1u], 1u); }
             const float tmin = chain_start ? SCENE_EPS : SCENE_EPS_R;          // ray_tracer.cu:209, normal_shader.cu:242,297
             float best_t = RTS_DEFAULT_TMAX;
             int best_leaf = -1; uint32_t best_prim = 0xffffffffu;
@@ -678,6 +680,10 @@ __device__ __forceinline__ void rts_trace_unit(const RtsTraceArgs& a, const RtsL
                             rts_walk_step<COUNT>(a, s_stack, tid, gtid, lds_cap, &s_n[2 * RTS_BLOCK + tid], node, sp, lr, prev, dir, tmin, best_t, best_leaf, best_prim, t_prune,
                                                  n_nodes, n_tris, hard_overflow);
                         }
+                        // the tile's walk statistics (LONG WALKS flag, k_trace): iterations the wave spent in this walk -- its slowest lane's;
+                        // by the first lane that is in the walk at all
+                        { const unsigned long long ex_ = __ballot(true);
+                          if (__builtin_amdgcn_mbcnt_hi((uint32_t)(ex_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ex_, 0u)) == 0u) { atomicAdd(&L_.walk[2u * __builtin_amdgcn_readfirstlane(tid >> 6)], wave_steps); } }
                     }
                 }
             }
@@ -931,7 +937,8 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR || COOP) ? 2 : 4) k_trace(con
     const uint32_t n_units = COOP ? 64u * n_head : n_tiles - n_head;
     __shared__ int32_t s_exch[COOP ? RTS_BLOCK : 1];             // exchange rows of the cooperative walk (one 64-entry row per wave)
     __shared__ uint32_t s_lane_scratch[COUNT ? 2 * (RTS_BLOCK / 64) : 1];      // (counting build: per-wave max / sum of a round's walk steps)
-    const RtsUnitLds ul = {s_stack, s_exch, s_first, s_path, s_n, s_rx, s_rxp, s_lane_scratch};
+    __shared__ uint32_t s_walk[2 * (RTS_BLOCK / 64)];           // per wave: walk iterations of the current tile (each walk's slowest lane), walks
+    const RtsUnitLds ul = {s_stack, s_exch, s_first, s_path, s_n, s_rx, s_rxp, s_lane_scratch, s_walk};
     unsigned long long lane_stats[4] = {0ull, 0ull, 0ull, 0ull};
     // XCD-AFFINE SUB-ORDERS (a.xcd_seg, big launches; ordinary kernel only): the order behind the head is cut into one segment per XCD
     // -- a band of the lattice that held an eighth of the cost last seen, longest tiles first inside it -- so that the ~500 waves of
@@ -1059,6 +1066,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR || COOP) ? 2 : 4) k_trace(con
       }
       const long long tile_t0 = clock64();
       if (!COOP) atomicAnd(&s_n[tid], 0x003fffffu);              // (ds_and_b32: the tile's own segment count starts at zero; a register for it would be the 129th)
+      if (!COOP && lane == 0) { s_walk[2u * wave_u] = 0u; s_walk[2u * wave_u + 1u] = 0u; }
       const unsigned long long tl_tile = (COUNT && a.timeline && lane == 0) ? wall_clock64() : 0ULL;
       if (slot < a.n_rays) {
           if (ASYNC) rts_trace_unit_async<COUNT, KEEP_ALL>(a, lc, ul, tid, gtid, lane, slot, pre_on, mask_on, D, origin, tile_t0, n_nodes, n_tris, hard_overflow, lane_stats);
@@ -1068,13 +1076,17 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR || COOP) ? 2 : 4) k_trace(con
       const unsigned long long dt = (unsigned long long)(clock64() - tile_t0) >> 6;             // (s_memtime: wave-uniform)
       bool long_walks = false;
       if (!COOP && a.tile_cost && dt >= a.coop_min_cost) {
-          uint32_t nseg = s_n[tid] >> 22;
-          for (int o = 32; o > 0; o >>= 1) nseg += __shfl_xor(nseg, o);
-          long_walks = dt >= (unsigned long long)a.coop_seg_cost * nseg;
+          // LONG WALKS: the tile's bounce rounds took a.coop_walk_steps walk iterations of the wave on average -- rays that graze along a surface
+          // through thousands of boxes (BASELINE configs[3]: ~4 000 per segment; an ordinary tile's walks: 20-150).  Counted, not
+          // timed: a duration per segment (rounds 2-3) had to be judged against the launch's mean, and a launch that consists of its
+          // tail -- one GPU's interleaved eighth of a configs[3] pulse -- raised that mean until nothing was flagged (r04: 5-12 ms per
+          // eighth instead of 1.5).
+          const uint32_t wsteps = __builtin_amdgcn_readfirstlane(s_walk[2u * wave_u]), walks = __builtin_amdgcn_readfirstlane(s_walk[2u * wave_u + 1u]);      // (walks: bounce rounds)
+          long_walks = walks != 0u && (unsigned long long)wsteps >= (unsigned long long)a.coop_walk_steps * walks;
       }
       if (lane == 0) {
-          // Cost record of the tile: bits 0-30 its duration (shader clocks >> 6, + 1), bit 31 "LONG WALKS": the tile took more
-          // than coop_seg_cost units per traced segment (all lanes' segments) -- rays that walk thousands of steps per segment,
+          // Cost record of the tile: bits 0-30 its duration (shader clocks >> 6, + 1), bit 31 "LONG WALKS": its walks took
+          // coop_walk_steps iterations each on average -- rays that walk thousands of steps per segment,
           // the only kind whose walk is long enough to be worth sharing out between 64 lanes (the per-ray arithmetic outside
           // the walk is executed by a whole wave for ONE ray in a cooperative unit: a tile of short walks and many bounces
           // costs ten times its ordinary wave time that way; BASELINE configs[2]'s slowest tiles are of that kind).

@@ -404,7 +404,10 @@ def test_product_trace_kernels_use_no_scratch():
                 assert "scratch_" not in t or depth <= 2, (name, depth, t)
                 continue
             if "scratch_" in t:                                   # prologue stores / epilogue reloads of a value the tile loop has no register for: once per wave
-                assert not in_loop, (name, t)
+                if flags[5]:                                      # the XCD-affine instantiation (an experiment, off by default): RELOADS of loop-invariant values outside the walk loop are tolerated, stores in a loop are not
+                    assert not in_loop or (t.startswith("scratch_load") and depth <= 2), (name, depth, t)
+                else:
+                    assert not in_loop, (name, t)
         assert fetch_blocks >= 1 and asm_loads == 0, (name, fetch_blocks, asm_loads)     # every asm load group ends in its own wait
     assert seen == 11      # 4 ordinary + 4 cooperative + 2 asynchronous + 1 XCD-affine product instantiations
 

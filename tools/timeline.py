@@ -18,8 +18,11 @@ if which == "c3narrow":
     spec["tx"] = dict(spec["tx"], span=(0.004, 0.004, 0.1))
 tr = api.Tracer(spec["W"], spec["max_refl"], 0, spec["smooth"], count_traversal=True)
 tr.set_scene(spec["meshes"]); tr.set_receivers(spec["rx"]); tx = spec["tx"]
-for _ in range(3):
-    st = tr.trace(tx["origin"], tx["span"], tx["dir"], spec["motion"])
+shard = int(os.environ.get("RTS_SHARD", "1"))                     # part RTS_SHARD_PART of RTS_SHARD interleaved parts (one GPU's share of a ray-sharded pulse)
+il = (4096, shard, int(os.environ.get("RTS_SHARD_PART", "0"))) if shard > 1 else None
+for _ in range(int(os.environ.get("RTS_TIMELINE_LAUNCHES", "3"))):
+    st = tr.trace(tx["origin"], tx["span"], tx["dir"], spec["motion"], ray_first=0, ray_count=spec["W"] ** 3, interleave=il)
+print("stats of the last launch:", {k: st[k] for k in ("rays", "segments", "coop_tiles", "ms_trace")})
 d = np.fromfile(out, np.uint64)
 grid, ntiles = int(d[0]), int(d[1]); blk = d[2:2 + 2 * grid].reshape(grid, 2).astype(np.int64); tile = d[2 + 2 * grid:2 + 2 * grid + ntiles].astype(np.float64) / 100.0   # us
 tstart = d[2 + 2 * grid + ntiles:2 + 2 * grid + 2 * ntiles].astype(np.int64)

@@ -37,7 +37,7 @@ tx = spec["tx"]
 ms = []
 shard = int(os.environ.get("RTS_SHARD", "1"))                     # trace part 0 of `shard` interleaved parts of the launch (C4: one GPU's share of an 8-way ray split, rts_plan_cpi's 4096-index tiles)
 count = spec["W"] ** 3
-il = (4096, shard, int(os.environ.get("RTS_SHARD_PART", "0"))) if shard > 1 else None
+il = (int(os.environ.get("RTS_SHARD_TILE", "4096")), shard, int(os.environ.get("RTS_SHARD_PART", "0"))) if shard > 1 else None      # (RTS_SHARD_TILE: launch indices per interleaved tile, rts_plan_cpi's `tile`)
 for k in range(reps + 1):
     if "motion_fn" in spec:
         mo = spec["motion_fn"](k)
