@@ -68,6 +68,38 @@ def pulse_motion(spec, k):
     return out
 
 
+def bounding_sphere_fraction(spec, tx, motion, max_rays=4_000_000):
+    """fraction of a pulse's launch indices whose primary ray meets the bounding sphere of (any) target -- SURVEY section 8d asks that
+    the beam be chosen so that this is >= 0.5 and that it be stated.  The lattice directions of ray_generation (ray_tracer.cu:155-203,
+    restated in numpy: lattice point, normalise, Rot(azimuth), Rot1(elevation about the rotated y axis)) against the spheres around
+    the placed meshes; a strided sample of at most max_rays launch indices."""
+    W = spec["W"]; total = W ** 3
+    spx, spy, spz = tx["span"]; az, el = tx["dir"]
+    s2c = lambda a, e: np.array([math.cos(a) * math.cos(e), math.sin(a) * math.cos(e), math.sin(e)])
+    bs, be = s2c(-spx / 2, -spy / 2), s2c(spx / 2, spy / 2)
+    st = np.array([((be[0] * (1 + spz)) - bs[0]) / (W - 1), (be[1] - bs[1]) / (W - 1), (be[2] - bs[2]) / (W - 1)]) if W > 1 else np.zeros(3)
+    idx = np.arange(0, total, max(total // max_rays, 1), dtype=np.int64)
+    lx = idx % W; ly = (idx // W) % W; lz = idx // (W * W)
+    v = bs[None, :] + np.stack([lx, ly, lz], 1) * st[None, :]
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    Rot = np.array([[math.cos(az), -math.sin(az), 0], [math.sin(az), math.cos(az), 0], [0, 0, 1.0]])
+    o = Rot[:, 1] / np.linalg.norm(Rot[:, 1]); c, sn = math.cos(el), math.sin(el)
+    Rot1 = np.array([[c + o[0] * o[0] * (1 - c), o[0] * o[1] * (1 - c) + o[2] * sn, o[0] * o[2] * (1 - c) - o[1] * sn],
+                     [o[1] * o[0] * (1 - c) - o[2] * sn, c + o[1] * o[1] * (1 - c), o[1] * o[2] * (1 - c) + o[0] * sn],
+                     [o[2] * o[0] * (1 - c) + o[1] * sn, o[2] * o[1] * (1 - c) - o[0] * sn, c + o[2] * o[2] * (1 - c)]])
+    d = v @ Rot.T; d /= np.linalg.norm(d, axis=1, keepdims=True); d = d @ Rot1.T
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    hit = np.zeros(len(idx), bool)
+    from rts_amd import scenes as S
+    for m, mo in zip(spec["meshes"], motion):
+        vw, _ = S.world_vertices(m, mo)
+        cen = 0.5 * (vw.min(axis=0) + vw.max(axis=0)); rad = float(np.linalg.norm(vw - cen[None, :], axis=1).max())
+        q = cen - np.asarray(tx["origin"], np.float64)
+        b = d @ q
+        hit |= (b > 0) & ((q @ q) - b * b <= rad * rad)
+    return float(hit.mean())
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -430,6 +462,8 @@ def main():
         s1 = tr1.trace(tk["origin"], tk["span"], tk["dir"], mo)
         tr1.close()
         hit_fraction = (s1["segments"] - s1["rays"]) / max(s1["rays"], 1)
+        sphere_fraction = bounding_sphere_fraction(spec, tk, mo)
+        walked_per_pulse = float(sc.get("walked_segments", 0))       # segments that entered a hierarchy at all (counting build: the others were cleared by the pre-filter or by the bounding spheres)
         V = sc["node_visits"] / max(sc["segments"], 1); T = sc["tri_tests"] / max(sc["segments"], 1); Hh = sc["shaded"] / max(sc["segments"], 1)
         # (3) dense control: the beam squeezed onto the fuselage, (nearly) every launch index hits and bounces
         dense = None
@@ -451,7 +485,8 @@ def main():
             lib_hash = None
         pmc_stale = pmc is not None and pmc.get("source_hash") != lib_hash
         pmc_ok = pmc is not None and not pmc_stale and world == 1 and ((W == 216 and args.config in ("c3", "c3ecef")) or (W == 100 and args.config == "c2") or (W == 465 and args.config == "c4"))
-        roof = {"kernel": "k_trace", "kernel_ms_serial": ms_serial, "segments_per_launch": seg_serial,
+        roof = {"kernel": "k_trace", "kernel_ms_serial": ms_serial, "segments_per_launch": seg_serial, "walked_segments_per_launch": walked_per_pulse,
+                "walked_Gseg_per_s_serial": walked_per_pulse / max(ms_serial, 1e-9) / 1e6,
                 "kernel_ms_overlapped_avg": ms_trace / launches, "gpu_ms_per_launch_timed_region": dt / args.steps * 1e3,
                 "hit_fraction": hit_fraction, "nodes_per_segment": V, "tri_tests_per_segment": T, "shaded_per_segment": Hh,
                 "dense_control": dense, "counters_source": pmc_src if pmc_ok else None}
@@ -462,7 +497,7 @@ def main():
         alg = bytes_per_seg * seg_serial
         roof["secondary_hbm_yardstick"] = {"algorithmic_bytes_per_launch": alg, "bytes_per_segment": bytes_per_seg,
                                            "GBps_if_it_were_hbm": alg / (ms_serial * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (ms_serial * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                           "note": "cache-served bytes priced as if they came from HBM (SURVEY 8d figure B): NOT a bound, the 20 MB scene lives in L1/L2"}
+                                           "note": "cache-served bytes priced as if they came from HBM (SURVEY 8d figure B): NOT a bound" + (": the 20 MB scene lives in L1/L2" if args.config != "c4" else ": configs[3]'s ~0.5 GB of records do NOT fit the 8 x 4 MB of L2 -- the measured fabric traffic is roofline.traffic (profiles/r04_c4_xcd_affine_pmc.log)")}
         if pmc_ok:
             d = pmc["derived"]; pl = pmc["per_launch"]
             seg_prof = float(pmc.get("segments_per_launch") or seg_serial)
@@ -502,7 +537,10 @@ def main():
             "config": {"workload": "BASELINE.json configs[%d]%s: %s, 1 Tx / %d Rx, W=%d (%d launch indices/pulse), maxRefl=%d, target moves every pulse (re-placed on the device per pulse; static target-space BVH4)"
                                    % ({"c3": 2, "c3ecef": 2, "c3ico": 2, "c4": 3, "c5": 4}.get(args.config, 1), " at Earth-centred coordinates" if args.config == "c3ecef" else (" (both transmitters in turn: pulses [0, %d) from Tx 0, [%d, %d) from Tx 1; a receiver's noise temperature grows by the signal's once per transmitter, ray_tracer.cpp:829 -- host side, the SOARS adapter's)" % (half, half, args.steps) if two_tx else (" -- NOT a BASELINE configuration: the scene of the C++ boundary benchmark (tests/adapter/adapter_bench.cpp)" if args.config == "sphere6" else (" (target re-rotated and translated every pulse, ray_tracer.cpp:993-1014; the transmitter's boresight tracks it)" if args.config == "c5" else ""))), spec["name"], len(spec["rx"]), W, total, spec["max_refl"]),
                        "rays_per_pulse": total, "segments_per_pulse": seg_all / args.steps, "received_per_pulse": received_all / args.steps,
-                       "hit_fraction": hit_fraction, "primary_Mrays_per_s": total * args.steps / dt / 1e6,
+                       "hit_fraction": hit_fraction, "bounding_sphere_fraction": sphere_fraction, "primary_Mrays_per_s": total * args.steps / dt / 1e6,
+                       "walked_segments_per_pulse": walked_per_pulse, "walked_Mrays_per_s": walked_per_pulse * (seg_all / max(seg_serial * args.steps, 1)) * args.steps / dt / 1e6,
+                       "walked_note": "segments that entered a target's hierarchy (counting build, one pulse); the rest of segments_per_pulse are primaries the conservative pre-filter or the bounding spheres cleared -- counted as rtTrace calls (SURVEY 8d), but bulk culling, not traversal",
+                       "dense_control_Gseg_per_s": (dense or {}).get("Gseg_per_s"),
                        "return_cube": "complex128 [%d rx][%d pulses][%d bins], all-reduced once per interval, then %d-point slow-time FFT in the library (rts_cube_doppler, inside the timed region); range-Doppler peak %.6e, max deviation from torch.fft %.1e (relative)" % (cube.shape[0], cube.shape[1], n_bins, n_fft, range_doppler_peak, range_doppler_err or 0.0),
                        "sharding": ("%d-pulse interval over %d ranks, --shard %s: " % (args.steps, world, args.shard)) + ("every pulse split over all ranks in interleaved 4096-index tiles" if args.shard == "rays" else "whole pulses, left-over pulses in interleaved 4096-index tiles") + "; one group-table all-gather + one cube all-reduce per interval",
                        "host_numa_node": numa_node, "post_processing_call": "rts_trace_pulse_end_uniform" if ((args.fused_post or len(trs) == 1) and hasattr(rts_amd._lib.lib(), "rts_trace_pulse_end_uniform")) else "rts_trace_pulse_end + rts_finalise_uniform + rts_cube_accumulate + rts_aggregate", "pulses_in_flight": len(trs), "linked": bool(args.link), "scene_setup_s": scene_setup_s,

@@ -937,7 +937,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR || COOP) ? 2 : 4) k_trace(con
     const uint32_t n_units = COOP ? 64u * n_head : n_tiles - n_head;
     __shared__ int32_t s_exch[COOP ? RTS_BLOCK : 1];             // exchange rows of the cooperative walk (one 64-entry row per wave)
     __shared__ uint32_t s_lane_scratch[COUNT ? 2 * (RTS_BLOCK / 64) : 1];      // (counting build: per-wave max / sum of a round's walk steps)
-    __shared__ uint32_t s_walk[2 * (RTS_BLOCK / 64)];           // per wave: walk iterations of the current tile (each walk's slowest lane), walks
+    __shared__ uint32_t s_walk[ASYNC ? 1 : 2 * (RTS_BLOCK / 64)];           // per wave: walk iterations of the current tile (each walk's slowest lane), walks
     const RtsUnitLds ul = {s_stack, s_exch, s_first, s_path, s_n, s_rx, s_rxp, s_lane_scratch, s_walk};
     unsigned long long lane_stats[4] = {0ull, 0ull, 0ull, 0ull};
     // XCD-AFFINE SUB-ORDERS (a.xcd_seg, big launches; ordinary kernel only): the order behind the head is cut into one segment per XCD
@@ -1066,7 +1066,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR || COOP) ? 2 : 4) k_trace(con
       }
       const long long tile_t0 = clock64();
       if (!COOP) atomicAnd(&s_n[tid], 0x003fffffu);              // (ds_and_b32: the tile's own segment count starts at zero; a register for it would be the 129th)
-      if (!COOP && lane == 0) { s_walk[2u * wave_u] = 0u; s_walk[2u * wave_u + 1u] = 0u; }
+      if (!COOP && !ASYNC && lane == 0) { const uint32_t z_ = RTS_OPAQUE_S(0u); s_walk[2u * wave_u] = z_; s_walk[2u * wave_u + 1u] = z_; }      // (an opaque zero: hoisted out of the tile loop as a register pair the constant was parked in SCRATCH and reloaded per tile)
       const unsigned long long tl_tile = (COUNT && a.timeline && lane == 0) ? wall_clock64() : 0ULL;
       if (slot < a.n_rays) {
           if (ASYNC) rts_trace_unit_async<COUNT, KEEP_ALL>(a, lc, ul, tid, gtid, lane, slot, pre_on, mask_on, D, origin, tile_t0, n_nodes, n_tris, hard_overflow, lane_stats);
@@ -1075,7 +1075,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR || COOP) ? 2 : 4) k_trace(con
       // (the segment count of the tile is only formed for tiles long enough to matter: an all-miss tile is ~100 instructions)
       const unsigned long long dt = (unsigned long long)(clock64() - tile_t0) >> 6;             // (s_memtime: wave-uniform)
       bool long_walks = false;
-      if (!COOP && a.tile_cost && dt >= a.coop_min_cost) {
+      if (!COOP && !ASYNC && a.tile_cost && dt >= a.coop_min_cost) {      // (the asynchronous-bounce experiment keeps no walk statistics: it flags nothing)
           // LONG WALKS: the tile's bounce rounds took a.coop_walk_steps walk iterations of the wave on average -- rays that graze along a surface
           // through thousands of boxes (BASELINE configs[3]: ~4 000 per segment; an ordinary tile's walks: 20-150).  Counted, not
           // timed: a duration per segment (rounds 2-3) had to be judged against the launch's mean, and a launch that consists of its

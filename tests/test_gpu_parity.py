@@ -857,35 +857,50 @@ def test_tile_schedule_does_not_change_results(rts, scenes, monkeypatch):
 
 def test_c4_full_size_sampled_parity(rts, oracle, scenes):
     """BASELINE configs[3] at full size (4 airframes, 999 824 triangles, W = 465: 100 544 625 launch indices, 8 bounces,
-    8 receivers): segment accounting + every 1999th launch index through the oracle (BVH mode); the received subset
-    must match record for record, and two interleaved parts must add up to the whole"""
+    8 receivers), BOTH transmitters (the reference's transmitter loop, ray_tracer.cpp:806-832): segment accounting + every
+    1999th launch index through the oracle (BVH mode); the received subset must match record for record -- for the handle's FIRST
+    launch (ordinary kernel only) and for its THIRD (tile-cost history: the tiles at the head of the order traced by the
+    cooperative kernel, RtsStats.coop_tiles > 0), whose whole received set must also equal the first's; two interleaved parts
+    must add up to the whole"""
     spec = scenes.config4()
     spec["rx"] = [dict(r, radius=max(r["radius"], 400.0)) for r in spec["rx"]]        # wide capture spheres: enough received rays to compare
-    tx = spec["tx_list"][0] if "tx_list" in spec else spec["tx"]
-    spec["tx"] = tx
     n = spec["W"] ** 3
-    tr = H.gpu_tracer(rts, spec)
-    _, st = H.gpu_trace(rts, spec, tr=tr)
-    whole = tr.received()
-    R = st["received"]
-    assert st["rays"] == n and st["segments"] == n + st["shaded"] and R == len(whole["slots"]) and R > 200
-    assert (np.diff(whole["slots"].astype(np.int64)) > 0).all()
     stride = 1999; m = n // stride
-    o = H.oracle_trace(oracle, spec, ray_first=11, ray_stride=stride, n_rays=m, use_bvh=True, threads=8, debug=False)
     samp = 11 + stride * np.arange(m, dtype=np.int64)
-    o_idx = np.nonzero(o["results"]["received"] >= 0)[0]
-    slots = whole["slots"].astype(np.int64)
-    pos_c = np.minimum(np.searchsorted(slots, samp), R - 1)
-    is_recv = slots[pos_c] == samp
-    assert len(o_idx) > 0 and np.array_equal(np.nonzero(is_recv)[0], o_idx)
-    H.assert_prd_equal(o["results"][o_idx], whole["results"][pos_c[is_recv]], "C4 sampled received records")
-    assert np.array_equal(o["path"][o_idx], whole["path"][pos_c[is_recv]])
-    parts = []
-    for part in range(2):
-        H.gpu_trace(rts, spec, tr=tr, interleave=(4096, 2, part)); parts.append(tr.received())
-    ps = np.concatenate([p["slots"] for p in parts]); order = np.argsort(ps, kind="stable")
-    assert np.array_equal(ps[order], whole["slots"])
-    H.assert_prd_equal(np.concatenate([p["results"] for p in parts])[order], whole["results"], "C4 interleaved halves")
+    tr = H.gpu_tracer(rts, spec)
+    for ti, tx in enumerate(spec["tx_list"]):
+        spec["tx"] = tx
+        o = H.oracle_trace(oracle, spec, ray_first=11, ray_stride=stride, n_rays=m, use_bvh=True, threads=8, debug=False)
+        o_idx = np.nonzero(o["results"]["received"] >= 0)[0]
+        assert len(o_idx) > 0
+
+        def against_oracle(rec, what):
+            slots = rec["slots"].astype(np.int64); R = len(slots)
+            pos_c = np.minimum(np.searchsorted(slots, samp), R - 1)
+            is_recv = slots[pos_c] == samp
+            assert np.array_equal(np.nonzero(is_recv)[0], o_idx), what
+            H.assert_prd_equal(o["results"][o_idx], rec["results"][pos_c[is_recv]], "C4 Tx %d sampled received records, %s" % (ti, what))
+            assert np.array_equal(o["path"][o_idx], rec["path"][pos_c[is_recv]]), what
+        _, st = H.gpu_trace(rts, spec, tr=tr)
+        whole = tr.received()
+        R = st["received"]
+        assert st["rays"] == n and st["segments"] == n + st["shaded"] and R == len(whole["slots"]) and R > 200
+        assert (np.diff(whole["slots"].astype(np.int64)) > 0).all()
+        against_oracle(whole, "first launch of this transmitter")
+        if ti == 0:
+            _, st2 = H.gpu_trace(rts, spec, tr=tr)
+            _, st3 = H.gpu_trace(rts, spec, tr=tr)
+            third = tr.received()
+            assert st3["coop_tiles"] > 0 and st3["segments"] == st["segments"] and st3["received"] == R, (st3["coop_tiles"], st3["segments"], st["segments"])
+            against_oracle(third, "third launch: cooperative kernel engaged on %d tiles" % st3["coop_tiles"])
+            assert np.array_equal(third["slots"], whole["slots"]) and np.array_equal(third["path"], whole["path"])
+            H.assert_prd_equal(third["results"], whole["results"], "C4 third launch (cooperative head) against the first")
+            parts = []
+            for part in range(2):
+                H.gpu_trace(rts, spec, tr=tr, interleave=(4096, 2, part)); parts.append(tr.received())
+            ps = np.concatenate([p["slots"] for p in parts]); order = np.argsort(ps, kind="stable")
+            assert np.array_equal(ps[order], whole["slots"])
+            H.assert_prd_equal(np.concatenate([p["results"] for p in parts])[order], whole["results"], "C4 interleaved halves")
     tr.close()
 
 
@@ -1045,7 +1060,7 @@ def test_primary_prefilter_is_invisible(rts, scenes):
             assert sa["node_visits"] == sb["node_visits"], name
 
 
-def test_cooperative_units_are_invisible(rts, scenes, monkeypatch):
+def test_cooperative_units_are_invisible(rts, oracle, scenes, monkeypatch):
     """the tiles at the head of a handle's cost order are traced by the COOPERATIVE kernel -- one launch index per wave, its
     64 lanes sharing out the walk (rts_walk_coop) -- beside the ordinary kernel; which tiles those are depends on timings of
     the previous launch, so every output buffer must be the same bits whatever the split: no cooperative units
@@ -1084,6 +1099,15 @@ def test_cooperative_units_are_invisible(rts, scenes, monkeypatch):
             np.testing.assert_allclose(x["rcs_angle"], y["rcs_angle"], rtol=0, atol=1e-12)
         assert (sa["segments"], sa["shaded"], sa["received"]) == (sb["segments"], sb["shaded"], sb["received"]) == (spb["segments"], spb["shaded"], spb["received"]), name
         assert sa["received"] > 0 and sb["tri_tests"] >= sb["shaded"] > 0, name
+        # ... and the launch compared really was traced by the cooperative kernel (RtsStats.coop_tiles of the handle's THIRD launch:
+        # every tile with a cost record at the head of the order), whose every ray is then held against the ORACLE directly -- brute
+        # force over all primitives, hit by hit: not only against the ordinary kernel's launch
+        assert sa["coop_tiles"] == 0 and sb["coop_tiles"] > 0 and spb["coop_tiles"] > 0, (name, sa["coop_tiles"], sb["coop_tiles"], spb["coop_tiles"])
+        if name in ("multi", "refraction", "miss branches"):
+            rows = spec["max_refl"] + 3 if spec.get("max_refr", 0) else 1
+            o = H.oracle_trace(oracle, spec, use_bvh=False, threads=8)
+            H.compare_full(o, b, n * rows)
+            assert sb["segments"] == o["counters"]["segments"] and sb["shaded"] == o["counters"]["shaded"], name
         # the cooperative walk shares the prune bound late and opens subtrees in another order: it may test more, never fewer
         # triangles than ... nothing is guaranteed either way; what IS: both found the same closest hits (above)
 

@@ -400,8 +400,8 @@ def test_product_trace_kernels_use_no_scratch():
                     asm_loads += 1
                 if t.startswith("s_waitcnt vmcnt(0)") and asm_loads:
                     assert asm_loads == 7, (name, asm_loads); fetch_blocks += 1; asm_loads = 0
-            if async_k:
-                assert "scratch_" not in t or depth <= 2, (name, depth, t)
+            if async_k:                                            # (an experiment, off by default) no STORE to scratch below the tile level; r04: the base of the stack's spill
+                assert "scratch_" not in t or depth <= 2 or t.startswith("scratch_load"), (name, depth, t)      # slab is reloaded in the (rare) deep-stack branch of its walk step
                 continue
             if "scratch_" in t:                                   # prologue stores / epilogue reloads of a value the tile loop has no register for: once per wave
                 if flags[5]:                                      # the XCD-affine instantiation (an experiment, off by default): RELOADS of loop-invariant values outside the walk loop are tolerated, stores in a loop are not
