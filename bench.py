@@ -52,7 +52,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~
 PEAK_CLOCK_HZ = 2.4e9          # max shader clock (MI355X_MICROARCH.md)
 N_SIMD, N_CU = 1024, 256
 PRI = 1.0e-3                   # pulse repetition interval of the synthetic CPI
-PMC_TAG = "r03c"               # profiles/<tag>_pmc_<workload>.json: counters of the committed kernel (tools/pmc_collect.sh + tools/pmc_derive.py)
+PMC_TAG = "r04"                # profiles/<tag>_pmc_<workload>.json: counters of the committed kernel (tools/pmc_collect.sh + tools/pmc_derive.py)
 
 
 def pulse_motion(spec, k):
@@ -524,7 +524,7 @@ def main():
                                     "note": "utilisations formed inside the profiled passes (busy cycles over GRBM_GUI_ACTIVE of the same dispatches)"},
                         traffic=hbm, traffic_source="%s: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of this binary on this workload; static, not re-measured by this run" % pmc_src,
                         hbm_GBps_measured=(hbm / t_s / 1e9) if hbm else None, hbm_frac_of_peak=(hbm / t_s / 1e9 / HBM_PEAK_GBS) if hbm else None,
-                        note="bound = the busier of VALU issue (measured cycles of one of 1024 SIMDs per wave-instruction, by class: profiles/r03_valu_calib.json, r03_isa_mix.json) and the vector-memory return path (16 clk of one of 256 CUs per wave-wide load), both from instruction COUNTS of the profiled launch over this run's serial kernel time at the 2.4 GHz peak clock; HBM carries ~1 % of its peak (hbm_frac_of_peak) -- the scene is cache resident, the kernel is issue bound (DESIGN.md section 5)")
+                        note="bound = the busier of VALU issue (measured cycles of one of 1024 SIMDs per wave-instruction, by class: profiles/r03_valu_calib.json, r04_isa_mix.json) and the vector-memory return path (16 clk of one of 256 CUs per wave-wide load), both from instruction COUNTS of the profiled launch over this run's serial kernel time at the 2.4 GHz peak clock; HBM carries ~1 % of its peak (hbm_frac_of_peak) -- the scene is cache resident, the kernel is issue bound (DESIGN.md section 5)")
         else:
             roof.update(bound="valu_issue", achieved=None, peak=N_SIMD * PEAK_CLOCK_HZ / 1e9, unit="G SIMD issue cycles/s", frac=None, traffic=None, source_hash=lib_hash,
                         note=("the committed counter profile %s was taken on sources %s, this library is %s: not priced -- run tools/pmc_collect.sh + tools/pmc_derive.py again" % (pmc_src, pmc.get("source_hash"), lib_hash)) if pmc_stale

@@ -347,9 +347,21 @@ extern "C" int rts_set_scene(RtsHandle c, const RtsMesh* meshes, uint32_t n_targ
     double split_budget = 2.0;
     { const char* e = getenv("RTS_SPLIT_BUDGET"); if (e) { const double v = atof(e); if (v >= 0 && v <= 8) split_budget = v; } }
     if (device_build) {
-        int rc = rts_lbvh_build_device(c, ns, vidx, mh, split_budget); if (rc != RTS_OK) return rc;
-        ns->builder = 1;
-    } else {
+        // The device builder sizes its bins by the references of a level and closes within 256 levels or gives up: out of memory, or
+        // a mesh it does not close on, must not fail the scene -- the host builder takes over (RTS_DEVICE_BUILD_FALLBACK=0:
+        // the error is returned, for tests of the builder itself).
+        int rc = rts_lbvh_build_device(c, ns, vidx, mh, split_budget);
+        if (rc == RTS_OK && getenv("RTS_DEBUG_FAIL_DEVICE_BUILD")) { rts_set_error("rts_set_scene: device builder failure injected (RTS_DEBUG_FAIL_DEVICE_BUILD)"); rc = RTS_ERR_HIP; }      // tests: the fall-back below, with the builder's state to clean up
+        if (rc != RTS_OK) {
+            const char* e = getenv("RTS_DEVICE_BUILD_FALLBACK");
+            if (rc == RTS_ERR_INVALID || (e && e[0] == '0')) return rc;
+            (void)hipGetLastError();                                     // (a failed allocation leaves a sticky error code behind)
+            fprintf(stderr, "[rts] device hierarchy build failed (%s): falling back to the host builder\n", rts_last_error());
+            ns->d_nodes4.release(); ns->d_leaf_prim.release(); ns->blas.clear(); ns->n_nodes = 0; ns->n_leaves = 0;
+            device_build = false;
+        } else ns->builder = 1;
+    }
+    if (!device_build) {
         std::vector<RtsNode4> nodes4; std::vector<uint32_t> leaf_prim; std::vector<RtsBlasInfo> blas(n_targets);
         {   // the meshes are independent: one host thread each (at most 16 at a time), results concatenated in target order
             std::vector<std::vector<RtsNode4>> pn(n_targets); std::vector<std::vector<uint32_t>> pl(n_targets); std::vector<int> prc(n_targets, RTS_OK);
@@ -851,6 +863,7 @@ extern "C" int rts_trace_pulse_end(RtsHandle c)
     const uint32_t n = c->n_rays;
     unsigned long long* cnt = c->pin->cnt;
     RTS_HIP(rts_stream_wait(c, st));                // the one host sync of the launch: the received count sizes what follows
+    if (cnt[13]) { rts_set_error("rts_trace_pulse: %llu counter rows of the launch were never written by their blocks (counting build)", cnt[13]); return RTS_ERR_HIP; }
     if (cnt[6]) { rts_set_error("rts_trace_pulse: traversal stack overflow / malformed BVH guard tripped on %llu waves", cnt[6]); return RTS_ERR_HIP; }
     c->n_recv = cnt[0]; c->n_head_hint = (uint32_t)cnt[7];
 

@@ -828,14 +828,19 @@ __device__ __forceinline__ void rts_sum_counters_body(const uint32_t t, unsigned
     if (t >= 8 && t <= 11) host_cnt[t] = RTS_LD64(&counters[t]);               // lane statistics and walked segments of the counting build
     const unsigned int k = t & 7u, lane = t >> 3;                              // 32 partial sums per counter
     unsigned long long v = 0;
-    if (k >= 1 && k <= 6) for (unsigned int b = lane; b < n_blocks; b += 32) v += RTS_LD64(&block_counters[(size_t)b * 8 + k]);
+    // (counting builds poison the rows before the launch -- rts_trace_launch -- : a row no block wrote is COUNTED, counters[13], instead
+    // of summed; round 3 saw such launches -- a garbage sum in counters[6] -- and could not reproduce them: this names them if they return)
+    unsigned long long poisoned = 0;
+    if (k >= 1 && k <= 6) for (unsigned int b = lane; b < n_blocks; b += 32) { const unsigned long long x = RTS_LD64(&block_counters[(size_t)b * 8 + k]); if (x == ~0ULL) poisoned++; else v += x; }
     s[t] = v;
+    if (k == 1 && poisoned) { atomicAdd(&counters[13], poisoned); __threadfence(); }      // (the rows' first counter; never in a healthy launch)
     __syncthreads();
     if (t >= 1 && t <= 6) {
         unsigned long long sum = 0;
         for (unsigned int l = 0; l < 32; l++) sum += s[l * 8 + t];
         counters[t] = sum; host_cnt[t] = sum;
     }
+    if (t == 13) host_cnt[13] = RTS_LD64(&counters[13]);                       // rows of block_counters still poisoned (counting builds)
 #undef RTS_LD64
 }
 
@@ -1206,6 +1211,7 @@ int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a_in, bool count_travers
     }
     const unsigned grid = a.total_threads / RTS_BLOCK;
     hipStream_t st = c->tstream;
+    if (count_traversal) RTS_HIP(hipMemsetAsync(a.block_counters, 0xff, sizeof(unsigned long long) * 8 * ((size_t)grid + coop_grid), st));      // poison: every block must write its row
     if (coop_grid) {
         if (!c->cstream) { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); RTS_HIP(hipStreamCreateWithPriority(&c->cstream, hipStreamNonBlocking, lo)); }
         RTS_HIP(hipEventRecord(c->ev_coop[0], st));

@@ -500,6 +500,28 @@ def test_c4_c5_shapes(rts, oracle, scenes):
     tr.close()
 
 
+def test_device_builder_failure_falls_back_to_the_host_builder(rts, oracle, scenes, monkeypatch):
+    """a device hierarchy build that fails (out of memory on a huge mesh, a mesh it does not close on within its level bound) must
+    not fail rts_set_scene: the host SAH builder takes over.  Injected after a complete device build, so that the
+    fall-back also has that builder's buffers to drop; results against the oracle; RTS_DEVICE_BUILD_FALLBACK=0 returns the error"""
+    from rts_amd import _lib
+    spec = scenes.config_multi(W=18)
+    monkeypatch.setenv("RTS_DEBUG_FAIL_DEVICE_BUILD", "1")
+    tr = rts.Tracer(spec["W"], spec["max_refl"], 0, spec["smooth"], keep_all=True, device_build=True)
+    tr.set_scene(spec["meshes"]); tr.set_receivers(spec["rx"])
+    assert tr.scene_info()["builder"] == 0                             # built by the host after all
+    _, st = H.gpu_trace(rts, spec, tr=tr)
+    n = spec["W"] ** 3
+    H.compare_full(H.oracle_trace(oracle, spec), tr.all_rays(n), n)
+    tr.close()
+    monkeypatch.setenv("RTS_DEVICE_BUILD_FALLBACK", "0")
+    tr = rts.Tracer(spec["W"], spec["max_refl"], 0, spec["smooth"], device_build=True)
+    with pytest.raises(_lib.RtsError) as e:
+        tr.set_scene(spec["meshes"])
+    assert e.value.code == _lib.RTS_ERR_HIP and "injected" in str(e.value)
+    tr.close()
+
+
 def test_return_cube(rts, oracle, scenes):
     """complex return cube (north-star product, not in the reference; definition: oracle/rts_oracle.cpp orc_cube, DESIGN.md
     section 4): the device accumulation of sqrt(P) e^{j phi} into [rx][pulse][range bin] -- per received ray (coherent sum)
