@@ -179,6 +179,8 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     { const char* e = getenv("RTS_ASYNC_IDLE1"); if (e) c->async_idle1 = (uint32_t)std::min(64, std::max(1, atoi(e))); }
     { const char* e = getenv("RTS_ASYNC_AGE"); if (e) c->async_age = (uint32_t)std::max(0, atoi(e)); }
     { const char* e = getenv("RTS_COOP_STEPS"); if (e) c->coop_walk_steps = (uint32_t)std::max(0, atoi(e)); }
+    { const char* e = getenv("RTS_COOP_STEPS_LO"); if (e) c->coop_walk_steps_lo = (uint32_t)std::max(0, atoi(e)); }
+    { const char* e = getenv("RTS_COOP_MID"); if (e) c->coop_mid = std::max(0.0, atof(e)); }
     { const char* e = getenv("RTS_COOP_SEG"); if (e && atoi(e) == 0) c->coop_walk_steps = 0; }      // (the tests' old switch: every tile above the floor is flagged)
     { const char* e = getenv("RTS_COOP_BIG"); if (e) c->coop_big = std::max(0.0, atof(e)); }
     { const char* e = getenv("RTS_COOP_SPREAD"); if (e) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) c->coop_spread = (uint32_t)v; } }
@@ -751,6 +753,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     a.total_threads = grid * RTS_BLOCK;
     a.async_idle0 = c->async_idle0; a.async_idle1 = c->async_idle1; a.async_age = c->async_age;
     a.coop_spread = c->coop_spread;
+    a.coop_walk_steps_lo = std::min(c->coop_walk_steps_lo, c->coop_walk_steps);
     a.coop_walk_steps = c->coop_walk_steps; a.coop_min_cost = c->coop_walk_steps ? std::min<uint32_t>(c->coop_floor, 1875u) : 0u;      // (nothing shorter than 50 us is looked at; RTS_COOP_STEPS=0: every tile is flagged)
     const uint32_t coop_threads = c->coop_frac > 0.0 ? c->coop_grid_max * RTS_BLOCK : 0u;      // the cooperative kernel's rows of the per-thread slabs
     a.slab_threads = a.total_threads + coop_threads;

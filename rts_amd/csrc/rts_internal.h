@@ -183,6 +183,7 @@ struct RtsTraceArgs {
     const uint32_t* tile_head_all;  // the same word whether or not this launch has a cooperative kernel (read back with the counters)
     uint32_t* done_ctr; uint32_t n_blocks_all; unsigned long long* host_cnt;      // the last block of the launch (ticket from done_ctr, zero at launch) sums the block counters and writes them home
     uint32_t async_idle0, async_idle1, async_age;   // asynchronous bounces (rts_trace_unit_async): idle-lane limit of a walk phase for young / old tiles (0: lock-step kernel), age in cost units
+    uint32_t coop_walk_steps_lo;    // ... bit 30 of the record: >= this many (LONGISH WALKS; the head rule asks more of such a tile's cost, rts_post.hip)
     uint32_t coop_min_cost, coop_walk_steps;   // a tile is flagged LONG WALKS (bit 31 of its cost record) if it took >= coop_min_cost units and >= coop_walk_steps walk iterations per bounce round
     unsigned long long* timeline;   // debug (RTS_TIMELINE, counting build): [grid][2] block start/end ticks, then [tiles] tile durations (100 MHz)
     uint32_t pre_filter;            // 1: primary rays go through the f32 pre-filter (needs the mask when there is geometry)
@@ -301,7 +302,8 @@ struct RtsContext {
     DevBuf<RtsEndRecord> d_recv, d_all; DevBuf<unsigned long long> d_block_counters, d_timeline; unsigned long long* p_counters = nullptr;      // (the 16 counters live behind the draw counters: one fill zeroes both)
     DevBuf<uint32_t> d_tile_cost, d_tile_key, d_tile_key_sorted, d_tile_id, d_tile_order, d_tile_hist, d_tile_ctr;
     uint32_t coop_floor = 7500;         // ... more than this many cost units (shader clocks >> 6; 7 500 = 0.2 ms of one wave) (RTS_COOP_FLOOR)
-    uint32_t coop_walk_steps = 400;     // ... and whose bounce rounds took at least this many walk iterations each, on average (RTS_COOP_STEPS; 0: every tile above the floor is flagged) --
+    uint32_t coop_walk_steps_lo = 400; double coop_mid = 3.0;      // LONGISH WALKS (RTS_COOP_STEPS_LO) go to the head only if the tile cost more than coop_mid x the balanced time (RTS_COOP_MID; 0: never)
+    uint32_t coop_walk_steps = 1000;     // ... and whose bounce rounds took at least this many walk iterations each, on average (RTS_COOP_STEPS; 0: every tile above the floor is flagged) --
                                         // counted by the kernel, so neither other pulses sharing the GPU nor a launch that is all tail move it
     double coop_big = 0.0;              // ... or ANY tile costing more than this multiple of the balanced time, whatever its shape (RTS_COOP_BIG; 0 = off, the default:
                                         // measured on C3 at 0.8 / 1.0 / 1.3 -- the slowest tile of a launch is rarely the slowest of the previous one once the target moves,

@@ -142,7 +142,19 @@ __device__ __forceinline__ uint32_t tile_global(const RtsTileShape& s, uint32_t 
 // no kernel, no readback of its own (a single-block reduction + a 4-byte device-to-host copy per pulse on the handle's
 // stream cost the three-pulse pipeline 7 %: 0.68 -> 0.73 ms per pulse).  head[0..1] = sum (u64), head[2] = count; zeroed with
 // the draw counters they share a buffer with.
-struct RtsHeadRule { double frac, big; uint32_t floor_cost, resident_waves; };
+struct RtsHeadRule { double frac, big, mid; uint32_t floor_cost, resident_waves; };
+// A tile goes to the head of the order -- to the cooperative kernel -- if its cost record says
+//   LONG WALKS (bit 31: >= coop_walk_steps walk iterations per bounce round, 1 000) and it cost more than frac x the launch's balanced time; or
+//   LONGISH WALKS (bit 30: >= coop_walk_steps_lo, 400) and it cost more than mid x the balanced time (3: alone it would triple the
+//   launch -- a launch that consists of its tail, e.g. one GPU's eighth of a BASELINE configs[3] pulse, where the ~5 x more work of
+//   64 units with short walks is free because the chip is idle; in a launch that is busy throughout the same tile stays where it is:
+//   BASELINE configs[4] lost 9 % when such tiles were made cooperative, profiles/r04_coop_steps_scan.log); or
+//   the experiment RtsContext::coop_big.
+__device__ __forceinline__ bool rts_head_rule(const uint32_t est, const double cost, const double balanced, const double thr, const double thr_big, const RtsHeadRule& rule)
+{
+    const double thr_mid = fmax(rule.mid * balanced, (double)rule.floor_cost);
+    return ((est >> 31) && cost > thr) || (rule.mid > 0.0 && ((est >> 30) & 1u) && balanced > 0.0 && cost > thr_mid) || (rule.big > 0.0 && balanced > 0.0 && cost > thr_big);
+}
 
 // fold the costs measured by the previous launch into the history
 __global__ void k_tile_merge(uint32_t* __restrict__ cost, RtsTileShape prev, uint32_t* __restrict__ hist, uint32_t n_hist, unsigned long long* __restrict__ head_sum, uint32_t* __restrict__ coarse)
@@ -152,7 +164,7 @@ __global__ void k_tile_merge(uint32_t* __restrict__ cost, RtsTileShape prev, uin
     if (j < prev.n_tiles) {
         const uint32_t v = cost[j], g = tile_global(prev, j);
         if (v && g < n_hist) hist[g] = v;
-        v64 = v & 0x7fffffffu;
+        v64 = v & 0x3fffffffu;
         cost[j] = 0u;                                                          // (ready for the coming launch: no fill of its own)
     }
     if (coarse) {                                                              // (uniform) XCD-affine sub-orders: the launch's cost by 1/1024 of its tile range, in units of 16
@@ -195,12 +207,12 @@ __global__ void k_tile_keys(const uint32_t* __restrict__ hist, uint32_t n_hist, 
         // head of the order = the tiles the cooperative kernel traces: LONG WALKS tiles above frac x the balanced time (and, as an
         // experiment that is OFF by default -- RtsContext::coop_big -- any tile above big x the balanced time).  The key's top bit
         // is this DECISION (not the record's flag): the head is a prefix of the sorted order.
-        const uint32_t cost = est & 0x7fffffffu;
+        const uint32_t cost = est & 0x3fffffffu;
         if (head_count && rule.frac > 0.0) {
             const double balanced = (double)head_sum[0] / (double)(rule.resident_waves ? rule.resident_waves : 1u);
             double thr = rule.frac * balanced; if (thr < (double)rule.floor_cost) thr = (double)rule.floor_cost;
             double thr_big = rule.big * balanced; if (thr_big < (double)rule.floor_cost) thr_big = (double)rule.floor_cost;
-            is_head = (((est >> 31) && (double)cost > thr) || (rule.big > 0.0 && balanced > 0.0 && (double)cost > thr_big)) ? 1u : 0u;
+            is_head = rts_head_rule(est, (double)cost, balanced, thr, thr_big, rule) ? 1u : 0u;
         }
         key[j] = ~((is_head << 31) | cost); id[j] = j;
         // bucket of the counting order (bucket_hist != nullptr): the head of the order in the first half of the bins, the rest in
@@ -294,13 +306,13 @@ __global__ void k_tile_merge_keys(uint32_t* __restrict__ cost, RtsTileShape cur,
         if (v && g < n_hist) hist[g] = v;
         cost[j] = 0u;
         uint32_t est = v ? v : (g < n_hist ? hist[g] : 0u);
-        v64 = v & 0x7fffffffu;
-        const uint32_t c = est & 0x7fffffffu;
+        v64 = v & 0x3fffffffu;
+        const uint32_t c = est & 0x3fffffffu;
         if (head_count && rule.frac > 0.0) {
             const double balanced = (double)sum_before[0] / (double)(rule.resident_waves ? rule.resident_waves : 1u);
             double thr = rule.frac * balanced; if (thr < (double)rule.floor_cost) thr = (double)rule.floor_cost;
             double thr_big = rule.big * balanced; if (thr_big < (double)rule.floor_cost) thr_big = (double)rule.floor_cost;
-            is_head = (((est >> 31) && (double)c > thr) || (rule.big > 0.0 && balanced > 0.0 && (double)c > thr_big)) ? 1u : 0u;
+            is_head = rts_head_rule(est, (double)c, balanced, thr, thr_big, rule) ? 1u : 0u;
         }
         bucket = (is_head ? 0u : RTS_TILE_BUCKETS / 2u) + (RTS_TILE_BUCKETS / 2u - 1u) - min((uint32_t)(__log2f((float)c + 1.0f) * 16.0f), RTS_TILE_BUCKETS / 2u - 1u);
         key[j] = bucket;
@@ -360,7 +372,7 @@ int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_vali
     uint32_t* coarse = affine ? c->d_tile_ctr.p + RTS_OFF_COARSE : nullptr;
     if (bins && !affine && c->order_fused && prev_valid && memcmp(prev_sig, cur_sig, 4 * sizeof(uint64_t)) == 0 && c->order_sum_valid) {
         const RtsTileShape cur2 = shape(cur_sig);
-        const RtsHeadRule rule2 = {c->coop_frac, c->coop_big, c->coop_floor, resident_waves};
+        const RtsHeadRule rule2 = {c->coop_frac, c->coop_big, c->coop_mid, c->coop_floor, resident_waves};
         RTS_HIP(c->d_tile_key.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_order.reserve(n_tiles_cur)); RTS_HIP(c->d_xcd.reserve(64));
         unsigned long long* persist = reinterpret_cast<unsigned long long*>(c->d_xcd.p + 32);
         k_tile_merge_keys<<<blocks_for(n_tiles_cur, 256), 256, 0, st>>>(c->d_tile_cost.p, cur2, c->d_tile_hist.p, n_hist, reinterpret_cast<unsigned long long*>(head), persist, head ? head + 2 : nullptr, rule2, c->d_tile_key.p, bins);
@@ -372,7 +384,7 @@ int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_vali
     if (prev_valid) { const RtsTileShape p = shape(prev_sig); if (p.n_tiles) { k_tile_merge<<<blocks_for(p.n_tiles, 256), 256, 0, st>>>(c->d_tile_cost.p, p, c->d_tile_hist.p, n_hist, reinterpret_cast<unsigned long long*>(head), coarse); merged = p.n_tiles == n_tiles_cur; } }
     RTS_HIP(c->d_tile_key.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_key_sorted.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_id.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_order.reserve(n_tiles_cur));
     const RtsTileShape cur = shape(cur_sig);
-    const RtsHeadRule rule = {c->coop_frac, c->coop_big, c->coop_floor, resident_waves};
+    const RtsHeadRule rule = {c->coop_frac, c->coop_big, c->coop_mid, c->coop_floor, resident_waves};
     // (the bands in force were computed by the previous build's scan from the launch before last; a launch of another shape, or no
     // build yet: equal counts)
     const uint32_t* bnd = affine && c->xcd_bnd_tiles == n_tiles_cur ? c->d_xcd.p + 16 : nullptr;

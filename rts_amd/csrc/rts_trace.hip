@@ -1079,7 +1079,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR || COOP) ? 2 : 4) k_trace(con
       }   // slot < n_rays
       // (the segment count of the tile is only formed for tiles long enough to matter: an all-miss tile is ~100 instructions)
       const unsigned long long dt = (unsigned long long)(clock64() - tile_t0) >> 6;             // (s_memtime: wave-uniform)
-      bool long_walks = false;
+      bool long_walks = false, longish_walks = false;
       if (!COOP && !ASYNC && a.tile_cost && dt >= a.coop_min_cost) {      // (the asynchronous-bounce experiment keeps no walk statistics: it flags nothing)
           // LONG WALKS: the tile's bounce rounds took a.coop_walk_steps walk iterations of the wave on average -- rays that graze along a surface
           // through thousands of boxes (BASELINE configs[3]: ~4 000 per segment; an ordinary tile's walks: 20-150).  Counted, not
@@ -1088,10 +1088,11 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR || COOP) ? 2 : 4) k_trace(con
           // eighth instead of 1.5).
           const uint32_t wsteps = __builtin_amdgcn_readfirstlane(s_walk[2u * wave_u]), walks = __builtin_amdgcn_readfirstlane(s_walk[2u * wave_u + 1u]);      // (walks: bounce rounds)
           long_walks = walks != 0u && (unsigned long long)wsteps >= (unsigned long long)a.coop_walk_steps * walks;
+          longish_walks = walks != 0u && (unsigned long long)wsteps >= (unsigned long long)a.coop_walk_steps_lo * walks;
       }
       if (lane == 0) {
-          // Cost record of the tile: bits 0-30 its duration (shader clocks >> 6, + 1), bit 31 "LONG WALKS": its walks took
-          // coop_walk_steps iterations each on average -- rays that walk thousands of steps per segment,
+          // Cost record of the tile: bits 0-29 its duration (shader clocks >> 6, + 1), bit 31 "LONG WALKS": its bounce rounds took
+          // coop_walk_steps walk iterations on average (bit 30: coop_walk_steps_lo) -- rays that walk thousands of steps per segment,
           // the only kind whose walk is long enough to be worth sharing out between 64 lanes (the per-ray arithmetic outside
           // the walk is executed by a whole wave for ONE ray in a cooperative unit: a tile of short walks and many bounces
           // costs ten times its ordinary wave time that way; BASELINE configs[2]'s slowest tiles are of that kind).
@@ -1099,7 +1100,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR || COOP) ? 2 : 4) k_trace(con
           // keeps its flag, so a tile once at the head stays there: no flip-flopping between the two modes from launch to launch)
           if (a.tile_cost) {
               if (COOP) { atomicAdd(&a.tile_cost[tile], (unsigned int)(dt > 0x00fffffeULL ? 0x00fffffeULL : dt) + 1u); if ((vpos & 63u) == 0u) atomicOr(&a.tile_cost[tile], 0x80000000u); }
-              else a.tile_cost[tile] = ((unsigned int)(dt > 0x7ffffffeULL ? 0x7ffffffeULL : dt) + 1u) | (long_walks ? 0x80000000u : 0u);
+              else a.tile_cost[tile] = ((unsigned int)(dt > 0x3ffffffeULL ? 0x3ffffffeULL : dt) + 1u) | (long_walks ? 0x80000000u : 0u) | (longish_walks ? 0x40000000u : 0u);
           }
           if (COUNT && a.timeline && !coop_unit) { a.timeline[(size_t)gridDim.x * 2 + tile] = wall_clock64() - tl_tile; a.timeline[(size_t)gridDim.x * 2 + n_tiles + tile] = tl_tile; }   // debug timeline (RTS_TIMELINE): duration, start tick
       }
