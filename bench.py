@@ -484,7 +484,7 @@ def main():
         except AttributeError:                                  # a library from before rts_build_id (RTS_AMD_LIB)
             lib_hash = None
         pmc_stale = pmc is not None and pmc.get("source_hash") != lib_hash
-        pmc_ok = pmc is not None and not pmc_stale and world == 1 and ((W == 216 and args.config in ("c3", "c3ecef")) or (W == 100 and args.config == "c2") or (W == 465 and args.config == "c4"))
+        pmc_ok = pmc is not None and not pmc_stale and world == 1 and ((W == 216 and args.config in ("c3", "c3ecef", "c5")) or (W == 100 and args.config == "c2") or (W == 465 and args.config == "c4" and args.tx == "0"))
         roof = {"kernel": "k_trace", "kernel_ms_serial": ms_serial, "segments_per_launch": seg_serial, "walked_segments_per_launch": walked_per_pulse,
                 "walked_Gseg_per_s_serial": walked_per_pulse / max(ms_serial, 1e-9) / 1e6,
                 "kernel_ms_overlapped_avg": ms_trace / launches, "gpu_ms_per_launch_timed_region": dt / args.steps * 1e3,
@@ -528,7 +528,7 @@ def main():
         else:
             roof.update(bound="valu_issue", achieved=None, peak=N_SIMD * PEAK_CLOCK_HZ / 1e9, unit="G SIMD issue cycles/s", frac=None, traffic=None, source_hash=lib_hash,
                         note=("the committed counter profile %s was taken on sources %s, this library is %s: not priced -- run tools/pmc_collect.sh + tools/pmc_derive.py again" % (pmc_src, pmc.get("source_hash"), lib_hash)) if pmc_stale
-                        else "no committed counter profile for this configuration (profiles/%s_pmc_*.json cover c3 at W = 216 and c2 at W = 100 on one GPU)" % PMC_TAG)
+                        else "no committed counter profile for this configuration (profiles/%s_pmc_*.json cover c3 / c5 at W = 216, c2 at W = 100 and c4 -- transmitter 0 -- at W = 465 on one GPU)" % PMC_TAG)
         out = {
             "metric": "Mrays/s (primary+bounces) & ms/pulse, 100k-tri scene",
             "value": seg_all / dt / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
