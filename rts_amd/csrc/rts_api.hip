@@ -869,6 +869,20 @@ extern "C" int rts_trace_pulse_end(RtsHandle c)
     if (cnt[13]) { rts_set_error("rts_trace_pulse: %llu counter rows of the launch were never written by their blocks (counting build)", cnt[13]); return RTS_ERR_HIP; }
     if (cnt[6]) { rts_set_error("rts_trace_pulse: traversal stack overflow / malformed BVH guard tripped on %llu waves", cnt[6]); return RTS_ERR_HIP; }
     c->n_recv = cnt[0]; c->n_head_hint = (uint32_t)cnt[7];
+    if (c->debug_coop && c->d_xcd.p && c->d_tile_ctr.p) {      // debug: what the head rule of this launch's order build saw (blocking read-backs)
+        unsigned long long sums[2] = {0, 0};
+        (void)hipMemcpy(&sums[0], c->d_xcd.p + 32, sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&sums[1], c->d_tile_ctr.p + RTS_OFF_HEAD, sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[rts] end: handle %p head count %llu coop grid %u | cost sum persisted %llu, this build's %llu\n", (void*)c, cnt[7], c->last_coop_grid, sums[0], sums[1]);
+        if (c->tile_cost_pending && c->d_tile_cost.p) {          // the cost records this launch wrote (merged by the next order build)
+            const uint32_t nt = (uint32_t)((c->tile_cost_sig[0] + RTS_WTILE - 1) / RTS_WTILE);
+            std::vector<uint32_t> h(nt);
+            (void)hipMemcpy(h.data(), c->d_tile_cost.p, sizeof(uint32_t) * nt, hipMemcpyDeviceToHost);
+            unsigned long long sum = 0, big = 0, flagged = 0; uint32_t mx = 0, shown = 0;
+            for (uint32_t j = 0; j < nt; j++) { const uint32_t v = h[j] & 0x3fffffffu; sum += v; if (v > mx) mx = v; if (h[j] >> 31) flagged++; if (v > (1u << 26)) { big++; if (shown++ < 6) fprintf(stderr, "[rts]    tile %u record 0x%08x\n", j, h[j]); } }
+            fprintf(stderr, "[rts]    records of this launch: sum %llu max %u, %llu above 2^26, %llu flagged LONG WALKS\n", sum, mx, big, flagged);
+        }
+    }
 
     // ---- order + expand the received rays (and the keep-all buffers); left in flight on the stream
     RTS_HIP(hipEventRecord(c->ev[4], st));

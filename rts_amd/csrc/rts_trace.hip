@@ -1098,7 +1098,12 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR || COOP) ? 2 : 4) k_trace(con
           // costs ten times its ordinary wave time that way; BASELINE configs[2]'s slowest tiles are of that kind).
           // (a tile traced as cooperative units costs the SUM of its units' wave time -- at least what it costs one wave -- and
           // keeps its flag, so a tile once at the head stays there: no flip-flopping between the two modes from launch to launch)
-          if (a.tile_cost) {
+          // (a duration of 2^26 x 64 clocks -- half an hour -- is no duration: the shader clock read back a value from BEFORE the tile's
+          // start.  Seen on gfx950 with three pulses in flight: ~1 000 tiles of ONE launch in fifteen, all at once, came out "negative";
+          // clamped to the field's maximum they made the launch's cost sum 1 000 x too large, the head rule of the handle's next order
+          // found no tile above half THAT balanced time, and a BASELINE configs[3] pulse went without its cooperative kernel: 13 ms
+          // instead of 8.5, profiles/r04_c4_cost_glitch.log.  Such a tile leaves no record; the history keeps what it had.)
+          if (a.tile_cost && dt < (1ULL << 26)) {
               if (COOP) { atomicAdd(&a.tile_cost[tile], (unsigned int)(dt > 0x00fffffeULL ? 0x00fffffeULL : dt) + 1u); if ((vpos & 63u) == 0u) atomicOr(&a.tile_cost[tile], 0x80000000u); }
               else a.tile_cost[tile] = ((unsigned int)(dt > 0x3ffffffeULL ? 0x3ffffffeULL : dt) + 1u) | (long_walks ? 0x80000000u : 0u) | (longish_walks ? 0x40000000u : 0u);
           }
