@@ -176,6 +176,8 @@ def main():
     ap.add_argument("--inflight", type=int, default=3, help="pulses in flight per GPU; 1 = strictly sequential pulses")
     ap.add_argument("--config", default="c3", choices=["c2", "c2file", "c3", "c3ecef", "c3ico", "c4", "c5", "sphere6"], help="c3 = BASELINE configs[2] (the metric's workload); c4 = configs[3]'s scene and size (100 M launch indices per pulse: give --steps 32; --tx both: its two transmitters in turn); c5 = configs[4]: the C3 airframe re-rotated AND translated every pulse, 1024-pulse interval (give --steps 1024), the transmitter tracking it; sphere6 = the scene of the C++ boundary benchmark (tests/adapter/adapter_bench.cpp)")
     ap.add_argument("--tx", default="0", choices=["0", "1", "both"], help="c4: which of configs[3]'s two transmitters; both = the first half of the interval's pulses from transmitter 0, the second half from transmitter 1 (the reference's transmitter loop is the outer one, ray_tracer.cpp:806)")
+    ap.add_argument("--as-rank", default="", help="debug, one process: 'r/N' runs the plan rank r of N ranks would run (with --shard rays: its part of EVERY pulse), without a process group -- one GPU's share of a ray-sharded interval at the pipelined rate, every r in turn gives the critical path of an N-GPU run; value / ms_per_step are that rank's alone")
+    ap.add_argument("--deal", default="interleave", choices=["interleave", "cost"], help="--shard rays: 'cost' = after the warm-up pulses (traced as interleaved parts) the ranks exchange what every tile cost the rank that traced it (ONE all-reduce of a uint32 per 64 launch indices, outside the timed interval: it belongs to the previous interval), adopt the merged table as their tile history and trace the timed interval's pulses as tile lists dealt longest-first from it (rts_deal_tiles, rts_set_tile_list) instead of the static interleave.  With --as-rank the table comes from two whole pulses traced by this process (standing in for the other ranks)")
     ap.add_argument("--shard", default="pulses", choices=["pulses", "rays"], help="N > 1: deal whole pulses to the ranks, or split every pulse over all ranks (interleaved tiles)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks")
     args = ap.parse_args()
@@ -298,11 +300,19 @@ def main():
     has_dop = hasattr(rts_amd._lib.lib(), "rts_cube_doppler")     # (an older library named by RTS_AMD_LIB, A/B runs: torch.fft then, outside the timed region)
     dop = torch.zeros((cube.shape[0], n_fft, n_bins), dtype=torch.complex128, device="cuda") if (n_fft <= 4096 and has_dop) else None
 
+    plan_rank, plan_world = (int(args.as_rank.split("/")[0]), int(args.as_rank.split("/")[1])) if args.as_rank else (rank, world)
+    if args.as_rank and (world != 1 or not 0 <= plan_rank < plan_world or args.shard != "rays"):
+        raise SystemExit("--as-rank r/N needs a single process, 0 <= r < N and --shard rays")
+
+    dealt = {}                                               # --deal cost: {"tile": launch indices per plan tile, "cost": every rank's share by the records} once the tile lists are set
+
     def plan(n_pulses):
-        if args.shard == "rays" and world > 1:
-            p = multigpu.plan_rays(total, n_pulses, rank, world)
+        if dealt:
+            return [(k, 0, total, (dealt["tile"], api.INTERLEAVE_LIST, 0)) for k in range(n_pulses)]
+        if args.shard == "rays" and plan_world > 1:
+            p = multigpu.plan_rays(total, n_pulses, plan_rank, plan_world)
         else:
-            p = multigpu.plan_cpi(total, n_pulses, rank, world)
+            p = multigpu.plan_cpi(total, n_pulses, plan_rank, plan_world)
         return multigpu.refine_plan(p, len(trs))
 
     def prepare_cpi(k0, n_pulses):
@@ -408,6 +418,19 @@ def main():
 
     if args.warmup:
         run_cpi(0, args.warmup)
+    if args.deal == "cost" and args.shard == "rays" and plan_world > 1:
+        if args.as_rank:                                      # one process: two whole pulses stand in for what the other ranks measured
+            m0 = pulse_motion(spec, 0); x0 = tx_of(0, m0)
+            for _ in range(2):
+                trs[0].trace(x0["origin"], x0["span"], x0["dir"], m0, ray_first=0, ray_count=total)
+            table = trs[0].tile_records_get()
+        else:
+            table = multigpu.exchange_tile_records([t.tile_records_get() for t in trs], dist, torch)
+        tile_, ids_, cost_ = multigpu.dealt_tiles(table, total, plan_rank, plan_world)
+        for t in trs:
+            t.tile_records_set(table); t.set_tile_list(tile_, ids_)
+        dealt.update(tile=tile_, cost=[float(x) for x in cost_ / max(float(cost_.mean()), 1.0)], tiles_of_this_rank=int(ids_.shape[0]))
+        run_cpi(args.warmup, min(args.warmup, 2 * len(trs)))  # (every handle's first launch over its list: the cooperative stream, the order build of a new shape)
     prepared = prepare_cpi(args.warmup, args.steps)
     # The harness is Python: its cyclic garbage collector, once a few thousand ctypes / numpy objects have been allocated by the
     # loop, makes full passes over everything torch imported (~40 ms each) -- measured as 0.15 ms per pulse in trace_begin at 256
@@ -542,6 +565,7 @@ def main():
                        "walked_note": "segments that entered a target's hierarchy (counting build, one pulse); the rest of segments_per_pulse are primaries the conservative pre-filter or the bounding spheres cleared -- counted as rtTrace calls (SURVEY 8d), but bulk culling, not traversal",
                        "dense_control_Gseg_per_s": (dense or {}).get("Gseg_per_s"),
                        "return_cube": "complex128 [%d rx][%d pulses][%d bins], all-reduced once per interval, then %d-point slow-time FFT in the library (rts_cube_doppler, inside the timed region); range-Doppler peak %.6e, max deviation from torch.fft %.1e (relative)" % (cube.shape[0], cube.shape[1], n_bins, n_fft, range_doppler_peak, range_doppler_err or 0.0),
+                       "as_rank": args.as_rank or None, "deal": (dict(dealt, how="tiles dealt longest-first from the cost records of the warm-up interval (one all-reduce), rts_deal_tiles") if dealt else "static interleave") if args.shard == "rays" and plan_world > 1 else None,
                        "sharding": ("%d-pulse interval over %d ranks, --shard %s: " % (args.steps, world, args.shard)) + ("every pulse split over all ranks in interleaved 4096-index tiles" if args.shard == "rays" else "whole pulses, left-over pulses in interleaved 4096-index tiles") + "; one group-table all-gather + one cube all-reduce per interval",
                        "host_numa_node": numa_node, "post_processing_call": "rts_trace_pulse_end_uniform" if ((args.fused_post or len(trs) == 1) and hasattr(rts_amd._lib.lib(), "rts_trace_pulse_end_uniform")) else "rts_trace_pulse_end + rts_finalise_uniform + rts_cube_accumulate + rts_aggregate", "pulses_in_flight": len(trs), "linked": bool(args.link), "scene_setup_s": scene_setup_s,
                        "interval_tail_ms_rank0": acc["tail_ms"],

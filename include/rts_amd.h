@@ -115,9 +115,12 @@ typedef struct RtsPulse {
     /* Interleaved sharding inside [ray_first, ray_first + ray_count): the range is cut into tiles of
      * interleave_tile launch indices and this launch traces tiles part, part + parts, part + 2 parts, ...
      * (parts <= 1: the whole range).  Rays that hit cluster in launch-index space, so ranks that share one
-     * pulse balance far better with interleaved tiles than with contiguous sub-ranges. */
+     * pulse balance far better with interleaved tiles than with contiguous sub-ranges.
+     * interleave_parts == RTS_INTERLEAVE_LIST: the launch traces the tiles DEALT to the handle with rts_set_tile_list
+     * (interleave_tile must be that list's tile size; interleave_part is ignored). */
     uint32_t interleave_tile, interleave_parts, interleave_part, reserved;
 } RtsPulse;
+#define RTS_INTERLEAVE_LIST 0xffffffffu
 
 /* Per-pulse counters and stage timings (the reference prints four wall-clock timers,
  * ray_tracer.cpp:1158,1170,1332; aggregation.cu:166). */
@@ -354,6 +357,25 @@ typedef struct RtsPlanItem {
 int rts_plan_cpi(uint64_t total_rays, uint32_t n_pulses, uint32_t rank, uint32_t world, uint32_t mode, uint32_t min_items,
                  uint32_t tile /* launch indices per interleaved tile; 0 = RTS_PLAN_TILE */, RtsPlanItem* out, uint32_t capacity,
                  uint32_t* n_out);
+/* Ray sharding BALANCED BY LAST-SEEN COST (instead of the static interleave): the tiles of a pulse are dealt to the workers
+ * longest-first from what every tile cost the last time any worker traced it -- one exchange of a cost table per interval.
+ * (The reference is single-GPU, ray_tracer.cpp:1165 is one rtContextLaunch1D over all W^3 indices; rays are independent,
+ * ray_tracer.cu:227-253, so any partition of the launch indices gives the same rows.)
+ *   rts_tile_records_get   the handle's cost records (one uint32 per 64 consecutive launch indices of the W^3 lattice, n =
+ *                          ceil(W^3 / 64); bits 0-29 wave time in units of 64 shader clocks, bits 30-31 the walk-length flags of
+ *                          the cooperative kernel's head rule) of the tiles its LAST launch traced, 0 for every other tile:
+ *                          tables of workers that traced disjoint parts of a pulse merge with a plain sum (or max)
+ *   rts_tile_records_set   replaces the handle's history with a merged table: its next launches order their tiles -- and pick
+ *                          the cooperative kernel's head tiles -- from what ANY worker measured
+ *   rts_deal_tiles         host code, deterministic (every worker computes the same map from the same table): plan tiles of `tile`
+ *                          launch indices (a multiple of 64) in descending cost, each to the worker with the least cost so far;
+ *                          tiles without a record are dealt round-robin.  part_of_tile[ceil(total_rays / tile)] <- worker
+ *   rts_set_tile_list      the plan tiles (ascending, unique, < ceil(range / tile)) the handle's launches with
+ *                          interleave_parts == RTS_INTERLEAVE_LIST trace; n_ids == 0 forgets the list */
+int rts_tile_records_get(RtsHandle h, uint32_t* records, uint32_t n);
+int rts_tile_records_set(RtsHandle h, const uint32_t* records, uint32_t n);
+int rts_deal_tiles(const uint32_t* records, uint32_t n_records, uint64_t total_rays, uint32_t tile, uint32_t parts, uint32_t* part_of_tile, uint64_t* cost_of_part /* [parts] or NULL */);
+int rts_set_tile_list(RtsHandle h, uint32_t tile, const uint32_t* tile_ids, uint32_t n_ids);
 /* Sum of the complex return cubes of several handles (same RtsCubeParams; one handle per GPU, or several per GPU), left in
  * EVERY handle's cube: the "RCCL reduce over the per-receiver return buffers" of a multi-GPU interval when all GPUs belong
  * to one process.  transport 0: RCCL (ncclCommInitAll + ncclAllReduce, loaded on first use) when the handles sit on

@@ -79,6 +79,18 @@ def kernel_wrapper(rx_results, rx_intersects, cspeed, carrier, ray_total, max_th
     return dict(results=res, delay=delay, phase=phase, pathMatch=pm)
 
 
+INTERLEAVE_LIST = 0xffffffff
+
+
+def deal_tiles(records, total_rays, tile, parts):
+    """rts_deal_tiles (host code): plan tiles of `tile` launch indices, longest first, each to the worker with the least cost so far.
+    Returns (part_of_tile uint32[ceil(total_rays / tile)], cost_of_part uint64[parts])."""
+    r = np.ascontiguousarray(records, np.uint32)
+    part = np.zeros((total_rays + tile - 1) // tile, np.uint32); cost = np.zeros(parts, np.uint64)
+    check(L.lib().rts_deal_tiles(ptr(r), r.shape[0], total_rays, tile, parts, ptr(part), ptr(cost)))
+    return part, cost
+
+
 def build_hierarchy_host(verts, tris, split_budget=2.0):
     """rts_build_hierarchy_host: the host SAH builder on one mesh (no device): (nodes [n][32] f32 view, leaf_prim, root)"""
     v = np.ascontiguousarray(verts, np.float64); t = np.ascontiguousarray(tris, np.uint32)
@@ -180,6 +192,23 @@ class Tracer:
 
     def trace_end(self):
         check(L.lib().rts_trace_pulse_end(self.h))
+
+    # ---- ray sharding dealt by last-seen cost (rts_amd.h: rts_tile_records_get / _set, rts_set_tile_list; deal_tiles below)
+    def tile_records_get(self):
+        """cost records (uint32 per 64 launch indices) of the tiles this tracer's LAST launch traced, 0 elsewhere"""
+        n = (self.width ** 3 + 63) // 64
+        out = np.zeros(n, np.uint32)
+        check(L.lib().rts_tile_records_get(self.h, ptr(out), n))
+        return out
+
+    def tile_records_set(self, records):
+        r = np.ascontiguousarray(records, np.uint32)
+        check(L.lib().rts_tile_records_set(self.h, ptr(r), r.shape[0]))
+
+    def set_tile_list(self, tile, tile_ids):
+        """the plan tiles (of `tile` launch indices, ascending) that launches with interleave=(tile, INTERLEAVE_LIST, 0) trace"""
+        ids = np.ascontiguousarray(tile_ids, np.uint32)
+        check(L.lib().rts_set_tile_list(self.h, tile, ptr(ids) if ids.shape[0] else None, ids.shape[0]))
 
     def link(self, other):
         """rts_link_handles: trace kernels of linked tracers run one at a time, everything else overlaps"""

@@ -161,6 +161,7 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     { const char* e = getenv("RTS_GRID_MULT"); if (e) c->grid_mult = std::max(1, atoi(e)); }
     { const char* e = getenv("RTS_GRID_SPARE"); if (e) { c->grid_spare = std::max(0, atoi(e)); c->grid_spare_forced = true; } }
     { const char* e = getenv("RTS_TILE_LPT"); if (e && e[0] == '0') c->tile_lpt = false; }
+    { const char* e = getenv("RTS_COOP_BIG_PART"); if (e) { const double v = atof(e); if (v >= 0) c->coop_big_part = v; } }
     { const char* e = getenv("RTS_COOP_FRAC"); if (e) { const double v = atof(e); if (v >= 0) c->coop_frac = v; } }                  // 0: no cooperative units; tests: tiny values put every tile at the head
     { const char* e = getenv("RTS_COOP_FLOOR"); if (e) c->coop_floor = (uint32_t)std::max(0, atoi(e)); }
     c->debug_coop = getenv("RTS_DEBUG_COOP") != nullptr;
@@ -418,7 +419,7 @@ static int rts_attach_scene(RtsContext* c)
         c->rcs_uploaded = false;
     }
     c->verts_world_valid = false; c->order_sum_valid = false;
-    c->motion.assign(n_targets, RtsTargetMotion{}); c->motion_valid = false; c->bvh_valid = false; c->tile_hist_n = 0; c->tile_hist_any = false; c->tile_cost_pending = false;
+    c->motion.assign(n_targets, RtsTargetMotion{}); c->motion_valid = false; c->bvh_valid = false; c->tile_hist_n = 0; c->tile_hist_any = false; c->tile_cost_pending = false; c->tile_last_valid = false;
     return RTS_OK;
 }
 
@@ -657,7 +658,11 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     const uint64_t total = (uint64_t)W * W * W;
     uint64_t first = p->ray_first, count = p->ray_count ? p->ray_count : (total > first ? total - first : 0);
     uint32_t il_tile = 0, il_parts = 0, il_part = 0;
-    if (p->interleave_parts > 1) {
+    const bool il_list = p->interleave_parts == RTS_INTERLEAVE_LIST;      // the tiles dealt to this handle (rts_set_tile_list)
+    if (il_list) {
+        if (c->il_list_n == 0 || p->interleave_tile != c->il_list_tile) { rts_set_error("rts_trace_pulse: RTS_INTERLEAVE_LIST with tile %u, but the handle's tile list has %u tiles of %u launch indices (rts_set_tile_list)", p->interleave_tile, c->il_list_n, c->il_list_tile); return RTS_ERR_INVALID; }
+        il_tile = c->il_list_tile; il_parts = RTS_INTERLEAVE_LIST; il_part = c->il_list_gen;
+    } else if (p->interleave_parts > 1) {
         il_tile = p->interleave_tile; il_parts = p->interleave_parts; il_part = p->interleave_part;
         if (il_tile == 0 || il_part >= il_parts) { rts_set_error("rts_trace_pulse: bad interleave (tile %u, part %u of %u)", il_tile, il_part, il_parts); return RTS_ERR_INVALID; }
     }
@@ -697,7 +702,13 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     }
 
     // ---- per-pulse buffers
-    if (il_parts > 1) {      // number of launch indices of the range that fall into this part's tiles
+    if (il_list) {           // every listed tile is whole, except the last tile of the range when it is listed (the list is ascending: it is the last entry)
+        const uint64_t range_tiles = (count + il_tile - 1) / il_tile;
+        if (c->il_list_last >= range_tiles) { rts_set_error("rts_trace_pulse: the handle's tile list names tile %u, the range has %llu tiles of %u launch indices", c->il_list_last, (unsigned long long)range_tiles, il_tile); return RTS_ERR_INVALID; }
+        uint64_t cnt = (uint64_t)c->il_list_n * il_tile;
+        if (c->il_list_last == range_tiles - 1) cnt -= range_tiles * il_tile - count;
+        count = cnt;
+    } else if (il_parts > 1) {      // number of launch indices of the range that fall into this part's tiles
         const uint64_t stride = (uint64_t)il_tile * il_parts, full = count / stride, rem = count % stride;
         const uint64_t lo = (uint64_t)il_part * il_tile;
         count = full * il_tile + (rem > lo ? std::min<uint64_t>(rem - lo, il_tile) : 0);
@@ -715,7 +726,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     RtsTraceArgs a; memset(&a, 0, sizeof(a));
     RtsLaunchConsts& lc = c->last_lc; memset(&lc, 0, sizeof(lc));
     fill_launch_constants(lc, *p, W);
-    lc.ray_first = first; lc.W = W; lc.il_tile = il_tile; lc.il_parts = il_parts; lc.il_part = il_part;
+    lc.ray_first = first; lc.W = W; lc.il_tile = il_tile; lc.il_parts = il_parts; lc.il_part = il_part; lc.il_list = il_list ? c->d_il_list.p : nullptr;
     if (W >= 2) {                                                     // branch-free magic number of the division by W (libdivide's u32 scheme)
         const uint32_t fl = 31u - (uint32_t)__builtin_clz(W);
         if ((W & (W - 1)) == 0) { lc.w_magic = 0; lc.w_more = fl - 1; }
@@ -786,6 +797,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
                 c->tile_hist_n = n_hist; c->tile_hist_any = false; c->tile_cost_pending = false;
             }
             if (c->tile_cost_pending || c->tile_hist_any) {
+                c->coop_big_now = (il_parts > 1 && !shared_gpu && c->coop_big_part > c->coop_big) ? c->coop_big_part : c->coop_big;
                 int rc = rts_tile_order_build(c, c->tile_cost_sig, c->tile_cost_pending, sig, n_tiles, grid * (RTS_BLOCK / RTS_WTILE)); if (rc != RTS_OK) return rc;
                 a.xcd_seg = c->xcd_affine_now ? c->d_xcd.p : nullptr;
                 a.tile_order = c->d_tile_order.p; a.tile_head = c->coop_frac > 0.0 ? c->d_tile_ctr.p + RTS_OFF_HEAD + 2 : nullptr; a.tile_head_all = a.tile_head; c->tile_hist_any = true;
@@ -794,8 +806,8 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
             RTS_HIP(c->d_tile_cost.reserve(n_tiles));
             if (!merged_all) RTS_HIP(hipMemsetAsync(c->d_tile_cost.p, 0, sizeof(uint32_t) * n_tiles, st));
             a.tile_cost = c->d_tile_cost.p;
-            c->tile_cost_pending = true; memcpy(c->tile_cost_sig, sig, sizeof(sig));
-        } else c->tile_cost_pending = false;                        // (costs of an unaligned or single-sweep launch are not recorded)
+            c->tile_cost_pending = true; memcpy(c->tile_cost_sig, sig, sizeof(sig)); memcpy(c->tile_last_sig, sig, sizeof(sig)); c->tile_last_valid = true;
+        } else { c->tile_cost_pending = false; c->tile_last_valid = false; }      // (costs of an unaligned or single-sweep launch are not recorded)
     }
     const char* tl_path = count_trav ? getenv("RTS_TIMELINE") : nullptr;      // debug: dump the block/tile timeline of this launch
     const size_t cnt_tl = (size_t)grid * 2 + 2 * (size_t)((n + RTS_WTILE - 1) / RTS_WTILE);          // [grid][2] block ticks, [tiles] durations, [tiles] start ticks
@@ -1337,6 +1349,88 @@ extern "C" int rts_cube_get(RtsHandle c, double* host_out, uint64_t capacity_dou
 }
 
 // ------------------------------------------------------------------------------------- several GPUs: the plan of an interval
+// ---------------------------------------------------------------------------------------------------------------------
+// Ray sharding dealt by last-seen cost (include/rts_amd.h: rts_tile_records_get / _set, rts_deal_tiles, rts_set_tile_list)
+extern "C" int rts_set_tile_list(RtsHandle c, uint32_t tile, const uint32_t* tile_ids, uint32_t n_ids)
+{
+    CHECK_HANDLE(c);
+    if (c->pulse_open) { rts_set_error("rts_set_tile_list: a pulse of this handle is in flight"); return RTS_ERR_INVALID; }
+    if (c->spec_pending) { int rc_ = rts_spec_resolve(c); if (rc_ != RTS_OK) return rc_; }
+    // the cost records of the last launch are indexed through the list in force: into the history before it goes
+    { int rc = rts_tile_costs_flush(c); if (rc != RTS_OK) return rc; }
+    if (n_ids == 0) { c->il_list_n = 0; c->il_list_tile = 0; c->il_list_gen++; return RTS_OK; }
+    if (!tile_ids || tile == 0 || tile % RTS_WTILE != 0) { rts_set_error("rts_set_tile_list: tile must be a positive multiple of %d launch indices (got %u)", RTS_WTILE, tile); return RTS_ERR_INVALID; }
+    for (uint32_t k = 1; k < n_ids; k++) if (tile_ids[k] <= tile_ids[k - 1]) { rts_set_error("rts_set_tile_list: tile ids must be ascending and unique (entry %u: %u after %u)", k, tile_ids[k], tile_ids[k - 1]); return RTS_ERR_INVALID; }
+    const uint64_t total = (uint64_t)c->params.width * c->params.width * c->params.width;
+    if ((uint64_t)tile_ids[n_ids - 1] * tile >= total) { rts_set_error("rts_set_tile_list: tile %u of %u launch indices lies beyond W^3 = %llu", tile_ids[n_ids - 1], tile, (unsigned long long)total); return RTS_ERR_INVALID; }
+    if ((uint64_t)n_ids * tile > 0xffffffffull) { rts_set_error("rts_set_tile_list: more than 2^32 launch indices"); return RTS_ERR_INVALID; }
+    RTS_HIP(hipStreamSynchronize(c->stream));                      // (kernels still reading the old list through their launch constants: k_expand of the last pulse)
+    RTS_HIP(c->d_il_list.reserve(n_ids));
+    RTS_HIP(hipMemcpy(c->d_il_list.p, tile_ids, sizeof(uint32_t) * n_ids, hipMemcpyHostToDevice));
+    c->il_list_n = n_ids; c->il_list_tile = tile; c->il_list_last = tile_ids[n_ids - 1]; c->il_list_gen++;
+    c->tile_last_valid = false;
+    return RTS_OK;
+}
+
+extern "C" int rts_tile_records_get(RtsHandle c, uint32_t* records, uint32_t n)
+{
+    CHECK_HANDLE(c);
+    if (c->pulse_open) { rts_set_error("rts_tile_records_get: a pulse of this handle is in flight"); return RTS_ERR_INVALID; }
+    const uint64_t total = (uint64_t)c->params.width * c->params.width * c->params.width;
+    if (!records || n != (uint32_t)((total + RTS_WTILE - 1) / RTS_WTILE)) { rts_set_error("rts_tile_records_get: n must be ceil(W^3 / %d) = %llu", RTS_WTILE, (unsigned long long)((total + RTS_WTILE - 1) / RTS_WTILE)); return RTS_ERR_INVALID; }
+    { int rc = rts_tile_costs_flush(c); if (rc != RTS_OK) return rc; }
+    RTS_HIP(c->d_rec_tmp.reserve(n));
+    { int rc = rts_tile_records_masked(c, c->d_rec_tmp.p, n); if (rc != RTS_OK) return rc; }
+    RTS_HIP(hipMemcpyAsync(records, c->d_rec_tmp.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
+    RTS_HIP(hipStreamSynchronize(c->stream));
+    return RTS_OK;
+}
+
+extern "C" int rts_tile_records_set(RtsHandle c, const uint32_t* records, uint32_t n)
+{
+    CHECK_HANDLE(c);
+    if (c->pulse_open) { rts_set_error("rts_tile_records_set: a pulse of this handle is in flight"); return RTS_ERR_INVALID; }
+    const uint64_t total = (uint64_t)c->params.width * c->params.width * c->params.width;
+    if (!records || n != (uint32_t)((total + RTS_WTILE - 1) / RTS_WTILE)) { rts_set_error("rts_tile_records_set: n must be ceil(W^3 / %d) = %llu", RTS_WTILE, (unsigned long long)((total + RTS_WTILE - 1) / RTS_WTILE)); return RTS_ERR_INVALID; }
+    RTS_HIP(hipStreamSynchronize(c->stream));
+    RTS_HIP(c->d_tile_hist.reserve(n));
+    RTS_HIP(hipMemcpy(c->d_tile_hist.p, records, sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+    c->tile_hist_n = n; c->tile_hist_any = true; c->tile_cost_pending = false; c->order_sum_valid = false;      // (records of the last launch not merged yet are superseded)
+    return RTS_OK;
+}
+
+// Longest-first dealing of plan tiles to `parts` workers.  Deterministic: ties go to the lower tile number, then to the lower worker.
+extern "C" int rts_deal_tiles(const uint32_t* records, uint32_t n_records, uint64_t total_rays, uint32_t tile, uint32_t parts, uint32_t* part_of_tile, uint64_t* cost_of_part)
+{
+    if (!records || !part_of_tile || parts == 0 || tile == 0 || tile % RTS_WTILE != 0 || total_rays == 0) { rts_set_error("rts_deal_tiles: bad arguments (tile must be a positive multiple of %d, parts >= 1)", RTS_WTILE); return RTS_ERR_INVALID; }
+    if ((uint64_t)n_records != (total_rays + RTS_WTILE - 1) / RTS_WTILE) { rts_set_error("rts_deal_tiles: n_records must be ceil(total_rays / %d)", RTS_WTILE); return RTS_ERR_INVALID; }
+    const uint64_t n_plan64 = (total_rays + tile - 1) / tile;
+    if (n_plan64 > 0xffffffffull) { rts_set_error("rts_deal_tiles: too many tiles"); return RTS_ERR_INVALID; }
+    const uint32_t n_plan = (uint32_t)n_plan64, per = tile / RTS_WTILE;
+    std::vector<uint64_t> cost(n_plan);
+    for (uint32_t t = 0; t < n_plan; t++) {
+        uint64_t v = 0; const uint64_t w0 = (uint64_t)t * per, w1 = std::min<uint64_t>(w0 + per, n_records);
+        for (uint64_t w = w0; w < w1; w++) v += records[w] & 0x3fffffffu;
+        cost[t] = v ? v : 1;                                       // (a tile nobody traced yet: dealt like the cheapest, so that the COUNTS balance too)
+    }
+    std::vector<uint32_t> order(n_plan);
+    for (uint32_t t = 0; t < n_plan; t++) order[t] = t;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
+    // min-heap of (load, worker)
+    std::vector<std::pair<uint64_t, uint32_t>> heap(parts);
+    for (uint32_t r = 0; r < parts; r++) heap[r] = {0, r};
+    auto cmp = [](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& b) { return a > b; };
+    std::make_heap(heap.begin(), heap.end(), cmp);
+    for (uint32_t k = 0; k < n_plan; k++) {
+        std::pop_heap(heap.begin(), heap.end(), cmp);
+        std::pair<uint64_t, uint32_t>& top = heap.back();
+        part_of_tile[order[k]] = top.second; top.first += cost[order[k]];
+        std::push_heap(heap.begin(), heap.end(), cmp);
+    }
+    if (cost_of_part) for (const auto& h : heap) cost_of_part[h.second] = h.first;
+    return RTS_OK;
+}
+
 static uint64_t plan_part_count(uint64_t total, uint32_t tile, uint32_t parts, uint32_t part)
 {
     if (parts <= 1) return total;

@@ -142,6 +142,7 @@ struct RtsLaunchConsts {
     uint32_t W, pad;
     uint32_t w_magic, w_more;       // division by W (>= 2) without a divide: q = mulhi(magic, g); ((g - q) >> 1) + q >> more  (fill_launch_constants)
     uint32_t il_tile, il_parts, il_part, pad2;     // interleaved tiles (il_parts <= 1: contiguous)
+    const uint32_t* il_list;        // != nullptr: local tile j of il_tile launch indices is tile il_list[j] of the range (rts_set_tile_list: tiles DEALT to this launch, ascending) instead of j * il_parts + il_part
     RtsMaskFrame mask;              // primary-ray mask frame (n = 0: no mask this launch)
     // f32 copies for the primary-ray PRE-FILTER (rts_trace.hip): beamStart, lattice step, Rot, Rot1
     float f_bs[3], f_st[3], f_rot[9], f_rot1[9];
@@ -305,12 +306,20 @@ struct RtsContext {
     uint32_t coop_walk_steps_lo = 400; double coop_mid = 3.0;      // LONGISH WALKS (RTS_COOP_STEPS_LO) go to the head only if the tile cost more than coop_mid x the balanced time (RTS_COOP_MID; 0: never)
     uint32_t coop_walk_steps = 1000;     // ... and whose bounce rounds took at least this many walk iterations each, on average (RTS_COOP_STEPS; 0: every tile above the floor is flagged) --
                                         // counted by the kernel, so neither other pulses sharing the GPU nor a launch that is all tail move it
+    double coop_big_part = 1.5, coop_big_now = 0.0;      // coop_big for a launch that is a PART of a pulse (interleaved or dealt tiles) on a GPU no other pulse shares (RTS_COOP_BIG_PART; 0: off) -- one
+                                        // pulse split over N GPUs for latency: such a launch is all tail, 1-2 ms tiles of moderately long walks bound it, and the ~5 x work of
+                                        // cooperative units is free on an idle chip: one GPU's eighth of a BASELINE configs[3] pulse 1.1-2.3 -> 1.1-1.5 ms (profiles/r04_c4_deal*.log).  Whole pulses:
+                                        // off (configs[4] one pulse at a time loses 3-5 % with it, the others do not move, profiles/r04_coop_big_inflight1.log); coop_big_now: the launch's value
     double coop_big = 0.0;              // ... or ANY tile costing more than this multiple of the balanced time, whatever its shape (RTS_COOP_BIG; 0 = off, the default:
                                         // measured on C3 at 0.8 / 1.0 / 1.3 -- the slowest tile of a launch is rarely the slowest of the previous one once the target moves,
                                         // the launch's duration did not change (0.70-0.77 ms, peaks of 1.0 ms as before) and the handle's first such launch takes 10 ms)
     uint32_t async_idle0 = 0, async_idle1 = 8, async_age = 7500;   // RTS_ASYNC_IDLE0 / _IDLE1 / _AGE (rts_trace_unit_async; idle0 = 0: the lock-step kernel)
     double coop_frac = 0.5;            // a tile costing more than this fraction of the launch's balanced time is traced as cooperative units (RTS_COOP_FRAC; 0: never)
     bool tile_cost_pending = false, tile_hist_any = false; uint64_t tile_cost_sig[4] = {0, 0, 0, 0}; uint32_t tile_hist_n = 0;   // per-global-tile cost history (rts_post.hip)
+    // tiles DEALT to this handle (rts_set_tile_list: ray sharding balanced by last-seen cost instead of interleaved parts): ascending tile
+    // numbers in units of il_list_tile launch indices; a pulse with interleave_parts == RTS_INTERLEAVE_LIST traces them
+    DevBuf<uint32_t> d_il_list; uint32_t il_list_n = 0, il_list_tile = 0, il_list_gen = 0; uint32_t il_list_last = 0;
+    uint64_t tile_last_sig[4] = {0, 0, 0, 0}; bool tile_last_valid = false; DevBuf<uint32_t> d_rec_tmp;      // shape of the last launch that recorded costs (rts_tile_records_get)
     DevBuf<float> d_dir_hist; DevBuf<uint32_t> d_pmask; bool use_pmask = true, pre_dense = false;
     DevBuf<int32_t> d_hit_prim; DevBuf<float> d_hit_t; DevBuf<int32_t> d_stack_ovf; DevBuf<RtsChildState> d_child;
     DevBuf<uint64_t> d_rk64, d_rk64_sorted;
@@ -359,6 +368,8 @@ struct RtsContext {
 int rts_sah_build(const double* verts, const uint32_t* tris, uint32_t n_tris, double split_budget, std::vector<RtsNode4>& nodes, std::vector<uint32_t>& leaf_prim, RtsBlasInfo& out);
 int rts_lbvh_build_device(RtsContext* c, RtsScene* ns, const std::vector<uint32_t>& vidx, const std::vector<RtsMeshHost>& mh, double split_budget);
 int rts_scene_place(RtsContext* c, const RtsLaunchConsts& lc, bool place, uint32_t* pmask);      // placement kernels (place) + the primary-ray mask (lc.mask.n != 0)
+int rts_tile_costs_flush(RtsContext* c);      // merge the cost records of the last launch into the history now (before its launch shape goes away)
+int rts_tile_records_masked(RtsContext* c, uint32_t* d_out, uint32_t n);      // the history's records of the tiles the last launch traced, 0 elsewhere
 int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_valid, const uint64_t* cur_sig, uint32_t n_tiles_cur, uint32_t resident_waves);
 int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a, bool count_traversal, unsigned coop_grid);
 void rts_trace_preload();

@@ -126,14 +126,15 @@ int rts_fill_i32(hipStream_t st, int32_t* p, int32_t v, size_t n) { if (n) k_fil
 // The handle keeps what every GLOBAL wave tile (64 consecutive launch indices of the W^3 lattice) cost the last time one of
 // its launches traced it, so the history carries over between launch shapes (whole pulse, contiguous shard, interleaved
 // part): a launch's local tile j is global tile (ray_first + local index of its first ray) / 64.
-struct RtsTileShape { uint64_t first; uint32_t il_tile, il_parts, il_part, n_tiles; };
+struct RtsTileShape { uint64_t first; uint32_t il_tile, il_parts, il_part, n_tiles; const uint32_t* il_list; };
 
 __device__ __forceinline__ uint32_t tile_global(const RtsTileShape& s, uint32_t j)
 {
     const uint64_t slot = (uint64_t)j * RTS_WTILE;
     if (s.il_parts <= 1) return (uint32_t)((s.first + slot) / RTS_WTILE);
     const uint64_t t = slot / s.il_tile, r = slot - t * s.il_tile;
-    return (uint32_t)((s.first + (t * s.il_parts + s.il_part) * s.il_tile + r) / RTS_WTILE);
+    const uint64_t g = s.il_list ? (uint64_t)s.il_list[t] : t * s.il_parts + s.il_part;      // a dealt list of tiles (rts_set_tile_list) or interleaved parts
+    return (uint32_t)((s.first + g * s.il_tile + r) / RTS_WTILE);
 }
 
 // Head of the cost order (cooperative units, rts_trace.hip): the tiles flagged LONG WALKS (bit 31 of the cost record) whose
@@ -355,13 +356,64 @@ __global__ void __launch_bounds__(256) k_tile_scan_scatter(const uint32_t* __res
     if (j < n) order[s_base[b] + r] = j;
 }
 
+// ---- the history as a table other workers can use (rts_tile_records_get / _set: ray sharding dealt by last-seen cost)
+static RtsTileShape rts_shape_of(const RtsContext* c, const uint64_t* sig)
+{
+    RtsTileShape s; s.first = sig[1]; s.il_tile = (uint32_t)(sig[2] & 0xffffffffu); s.il_parts = (uint32_t)(sig[2] >> 32); s.il_part = (uint32_t)sig[3];
+    s.n_tiles = (uint32_t)((sig[0] + RTS_WTILE - 1) / RTS_WTILE); s.il_list = s.il_parts == RTS_INTERLEAVE_LIST ? c->d_il_list.p : nullptr; return s;
+}
+__global__ void k_tile_records_masked(const uint32_t* __restrict__ hist, uint32_t n_hist, RtsTileShape last, uint32_t* __restrict__ out)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= last.n_tiles) return;
+    const uint32_t g = tile_global(last, j);
+    if (g < n_hist) out[g] = hist[g];
+}
+// the cost of the coming launch as the history knows it (the order build's "sum of the previous launch" when there was none of
+// this handle's to merge: a history set from other workers' records, a change of launch shape)
+__global__ void k_tile_est_sum(const uint32_t* __restrict__ hist, uint32_t n_hist, RtsTileShape cur, unsigned long long* __restrict__ head_sum)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long v64 = 0;
+    if (j < cur.n_tiles) { const uint32_t g = tile_global(cur, j); if (g < n_hist) v64 = hist[g] & 0x3fffffffu; }
+    __shared__ unsigned long long s_part[4];
+    for (int o = 32; o > 0; o >>= 1) v64 += __shfl_down(v64, o);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v64;
+    __syncthreads();
+    if (threadIdx.x == 0) { const unsigned long long t = s_part[0] + s_part[1] + s_part[2] + s_part[3]; if (t) atomicAdd(head_sum, t); }
+}
+int rts_tile_costs_flush(RtsContext* c)
+{
+    if (!c->tile_cost_pending) return RTS_OK;
+    c->tile_cost_pending = false; c->order_sum_valid = false;
+    if (c->tile_hist_n == 0 || !c->d_tile_cost.p || !c->d_tile_hist.p) return RTS_OK;
+    const RtsTileShape p = rts_shape_of(c, c->tile_cost_sig);
+    if (p.n_tiles == 0) return RTS_OK;
+    k_tile_merge<<<blocks_for(p.n_tiles, 256), 256, 0, c->stream>>>(c->d_tile_cost.p, p, c->d_tile_hist.p, c->tile_hist_n, nullptr, nullptr);
+    RTS_HIP(hipGetLastError());
+    c->tile_hist_any = true;
+    return RTS_OK;
+}
+int rts_tile_records_masked(RtsContext* c, uint32_t* d_out, uint32_t n)
+{
+    RTS_HIP(hipMemsetAsync(d_out, 0, sizeof(uint32_t) * n, c->stream));
+    if (!c->tile_last_valid || c->tile_hist_n == 0 || !c->d_tile_hist.p) return RTS_OK;
+    const RtsTileShape p = rts_shape_of(c, c->tile_last_sig);
+    if (p.n_tiles == 0) return RTS_OK;
+    k_tile_records_masked<<<blocks_for(p.n_tiles, 256), 256, 0, c->stream>>>(c->d_tile_hist.p, std::min(c->tile_hist_n, n), p, d_out);
+    RTS_HIP(hipGetLastError());
+    return RTS_OK;
+}
+
 // prev_valid: d_tile_cost holds the costs of a launch of shape prev_shape that have not been merged yet
 int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_valid, const uint64_t* cur_sig, uint32_t n_tiles_cur, uint32_t resident_waves)
 {
     hipStream_t st = c->stream;
     const uint32_t n_hist = c->tile_hist_n;
-    auto shape = [](const uint64_t* sig) { RtsTileShape s; s.first = sig[1]; s.il_tile = (uint32_t)(sig[2] & 0xffffffffu); s.il_parts = (uint32_t)(sig[2] >> 32); s.il_part = (uint32_t)sig[3];
-                                          s.n_tiles = (uint32_t)((sig[0] + RTS_WTILE - 1) / RTS_WTILE); return s; };
+    // (a launch over a dealt tile list has il_parts = RTS_INTERLEAVE_LIST and the list's generation in il_part; the list on the device is
+    // the one BOTH shapes mean: rts_set_tile_list merges pending cost records before it replaces the list)
+    auto shape = [c](const uint64_t* sig) { RtsTileShape s; s.first = sig[1]; s.il_tile = (uint32_t)(sig[2] & 0xffffffffu); s.il_parts = (uint32_t)(sig[2] >> 32); s.il_part = (uint32_t)sig[3];
+                                           s.n_tiles = (uint32_t)((sig[0] + RTS_WTILE - 1) / RTS_WTILE); s.il_list = s.il_parts == RTS_INTERLEAVE_LIST ? c->d_il_list.p : nullptr; return s; };
     uint32_t* head = c->coop_frac > 0.0 ? c->d_tile_ctr.p + RTS_OFF_HEAD : nullptr;      // [sum lo, sum hi, count, pad]: zeroed with the draw counters
     uint32_t* bins = c->tile_bucket_order ? c->d_tile_ctr.p + RTS_OFF_BINS : nullptr;      // zeroed with the draw counters
     // XCD-AFFINE sub-orders (RtsContext::xcd_affine: 0 never, 1 whenever there is a counting order, 2 -- the default -- for launches of
@@ -372,7 +424,7 @@ int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_vali
     uint32_t* coarse = affine ? c->d_tile_ctr.p + RTS_OFF_COARSE : nullptr;
     if (bins && !affine && c->order_fused && prev_valid && memcmp(prev_sig, cur_sig, 4 * sizeof(uint64_t)) == 0 && c->order_sum_valid) {
         const RtsTileShape cur2 = shape(cur_sig);
-        const RtsHeadRule rule2 = {c->coop_frac, c->coop_big, c->coop_mid, c->coop_floor, resident_waves};
+        const RtsHeadRule rule2 = {c->coop_frac, c->coop_big_now, c->coop_mid, c->coop_floor, resident_waves};
         RTS_HIP(c->d_tile_key.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_order.reserve(n_tiles_cur)); RTS_HIP(c->d_xcd.reserve(64));
         unsigned long long* persist = reinterpret_cast<unsigned long long*>(c->d_xcd.p + 32);
         k_tile_merge_keys<<<blocks_for(n_tiles_cur, 256), 256, 0, st>>>(c->d_tile_cost.p, cur2, c->d_tile_hist.p, n_hist, reinterpret_cast<unsigned long long*>(head), persist, head ? head + 2 : nullptr, rule2, c->d_tile_key.p, bins);
@@ -381,10 +433,11 @@ int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_vali
         return RTS_OK;
     }
     bool merged = false;
+    if (!prev_valid && head) { const RtsTileShape cur0 = shape(cur_sig); k_tile_est_sum<<<blocks_for(n_tiles_cur, 256), 256, 0, st>>>(c->d_tile_hist.p, n_hist, cur0, reinterpret_cast<unsigned long long*>(head)); }
     if (prev_valid) { const RtsTileShape p = shape(prev_sig); if (p.n_tiles) { k_tile_merge<<<blocks_for(p.n_tiles, 256), 256, 0, st>>>(c->d_tile_cost.p, p, c->d_tile_hist.p, n_hist, reinterpret_cast<unsigned long long*>(head), coarse); merged = p.n_tiles == n_tiles_cur; } }
     RTS_HIP(c->d_tile_key.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_key_sorted.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_id.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_order.reserve(n_tiles_cur));
     const RtsTileShape cur = shape(cur_sig);
-    const RtsHeadRule rule = {c->coop_frac, c->coop_big, c->coop_mid, c->coop_floor, resident_waves};
+    const RtsHeadRule rule = {c->coop_frac, c->coop_big_now, c->coop_mid, c->coop_floor, resident_waves};
     // (the bands in force were computed by the previous build's scan from the launch before last; a launch of another shape, or no
     // build yet: equal counts)
     const uint32_t* bnd = affine && c->xcd_bnd_tiles == n_tiles_cur ? c->d_xcd.p + 16 : nullptr;

@@ -10,7 +10,8 @@ __device__ __forceinline__ uint64_t rts_global_index(const RtsLaunchConsts& a, u
 {
     if (a.il_parts <= 1) return a.ray_first + slot;
     const uint32_t j = slot / a.il_tile, r = slot - j * a.il_tile;
-    return a.ray_first + ((uint64_t)j * a.il_parts + a.il_part) * a.il_tile + r;
+    const uint64_t t = a.il_list ? (uint64_t)a.il_list[j] : (uint64_t)j * a.il_parts + a.il_part;      // (uniform branch; the list entry is one broadcast load per wave tile)
+    return a.ray_first + t * a.il_tile + r;
 }
 
 // direction of lattice point (lx, ly, lz); host + device: the host uses it for the extent of the primary-ray mask

@@ -127,6 +127,35 @@ def part_ray_count(total_rays, interleave):
     return full * tile + max(0, min(rem - part * tile, tile))
 
 
+# ------------------------------------------------------------------------------- ray sharding dealt by last-seen cost
+# The static interleave gives every rank the same NUMBER of tiles; what a tile costs differs by four orders of magnitude (a dead
+# tile 5 us of one wave, a grazing tile of BASELINE configs[3] milliseconds), so the ranks' parts of a pulse differ by 2 x.  Once per
+# interval the ranks exchange what each tile cost the rank that traced it (one uint32 per 64 launch indices: 6 MB for 100 M indices),
+# every rank adopts the merged table as its history -- tile order AND cooperative-kernel head tiles for tiles it never traced --
+# and computes the same longest-first deal from it (rts_deal_tiles); the next interval's launches use interleave = (tile,
+# INTERLEAVE_LIST, 0) after Tracer.set_tile_list.  The data path has no collective: results are keyed by global buffer rows as before.
+def exchange_tile_records(local_tables, dist, torch):
+    """local_tables: Tracer.tile_records_get() of every tracer of this rank (they traced the same part, pulse after pulse: the
+    element-wise maximum stands for the rank) -> the table of all ranks (their parts are disjoint: a sum)"""
+    mine = np.maximum.reduce([np.ascontiguousarray(t, np.uint32) for t in local_tables]) if len(local_tables) > 1 else np.ascontiguousarray(local_tables[0], np.uint32)
+    if dist is None or dist.get_world_size() == 1:
+        return mine
+    t = torch.from_numpy(mine.astype(np.int64)).to(_device_for(dist, torch))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy().astype(np.uint32)
+
+
+def dealt_tiles(records, total_rays, rank, world, tile=None):
+    """(tile, ascending plan-tile ids of `rank`, cost of every rank's part) from a merged record table"""
+    tile = tile or IL_TILE
+    part_of, cost = api.deal_tiles(records, total_rays, tile, world)
+    return tile, np.flatnonzero(part_of == rank).astype(np.uint32), cost
+
+
+def list_ray_count(total_rays, tile, ids):
+    return int(sum(min(tile, total_rays - int(i) * tile) for i in ids))
+
+
 def exchange_parts(parts, dist, torch):
     """parts: [dict(pulse, groups)] of this rank -> the same list for ALL ranks.  Group tables must be keyed by
     global buffer rows (rts_aggregate(..., RTS_BASE_USE_ROWS)) so that they merge with a plain min.

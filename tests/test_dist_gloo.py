@@ -136,6 +136,65 @@ def test_cpi_sharding(tmp_path, world, n_pulses, shard, oracle):
             np.testing.assert_allclose(resp["delay"], lit["delay"][uniq], rtol=1e-12)
 
 
+def _deal_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from rts_amd import scenes, multigpu
+    import helpers as H
+    from test_host_logic import numpy_group_table
+    spec = scenes.config_multi(W=12)
+    total = spec["W"] ** 3; tile = 64; n_rec = (total + 63) // 64
+    wl = spec["c"] / spec["carrier"]
+    o = H.oracle_trace(O, spec)                                  # whole pulse; a rank keeps ITS launch indices (stand-in for the device)
+    # interval 0: the static interleave.  What a tile "cost" this rank: its shaded segments (a stand-in for the device's clock)
+    mine0 = _tile_indices(total, (tile, world, rank))
+    seg = np.zeros(n_rec, np.uint32)
+    np.add.at(seg, mine0 // 64, (1 + o["results"]["reflDepth"][mine0]).astype(np.uint32))
+    table = multigpu.exchange_tile_records([seg], dist, torch)
+    t, ids, cost = multigpu.dealt_tiles(table, total, rank, world, tile)
+    assert multigpu.list_ray_count(total, t, ids) > 0
+    # interval 1: the dealt tiles
+    mine = np.concatenate([np.arange(int(i) * t, min((int(i) + 1) * t, total), dtype=np.int64) for i in ids])
+    rx, rxi, slots = O.filter_finalise(o["results"][mine], o["path"][mine], [1.0] * 3, wl, 1.0, 1.0, spec["carrier"], spec["c"])
+    g = numpy_group_table(rx, rxi, spec["c"], spec["carrier"], base=0)
+    g["min_ray"] = mine[slots.astype(np.int64)][g["min_ray"].astype(np.int64)]
+    allp = multigpu.exchange_parts([dict(pulse=0, groups=g)], dist, torch)
+    merged = multigpu.merge_cpi(allp, spec["max_refl"])
+    np.savez(os.path.join(out_dir, "deal_rank%d.npz" % rank), table=table, ids=ids, cost=cost, resp=merged[0][0], seg=seg)
+    dist.barrier(); dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ray_sharding_dealt_by_cost(tmp_path, world, oracle):
+    """one exchange of the tile cost table per interval (all-reduce), the same longest-first deal computed on every rank, the
+    next interval's pulse traced as dealt tile lists: the ranks' lists partition the lattice, their costs are level, and the
+    merged responses are the literal single-process pipeline's"""
+    mp.spawn(_deal_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, HERE)
+    from rts_amd import scenes
+    import helpers as H
+    spec = scenes.config_multi(W=12); total = spec["W"] ** 3
+    wl = spec["c"] / spec["carrier"]
+    outs = [np.load(os.path.join(str(tmp_path), "deal_rank%d.npz" % r)) for r in range(world)]
+    for x in outs[1:]:
+        assert np.array_equal(x["table"], outs[0]["table"]) and np.array_equal(x["cost"], outs[0]["cost"])
+    assert np.array_equal(outs[0]["table"], np.sum([x["seg"] for x in outs], axis=0))          # disjoint parts: the sum IS the table
+    ids = np.concatenate([x["ids"] for x in outs])
+    assert np.array_equal(np.sort(ids), np.arange((total + 63) // 64))                         # a partition of the plan tiles
+    cost = outs[0]["cost"].astype(np.int64)
+    assert cost.max() - cost.min() <= int(outs[0]["table"].max())
+    o = H.oracle_trace(oracle, spec)
+    rx, rxi, slots = oracle.filter_finalise(o["results"], o["path"], [1.0] * 3, wl, 1.0, 1.0, spec["carrier"], spec["c"])
+    lit = oracle.aggregate_literal(rx, rxi, spec["c"], spec["carrier"], total)
+    uniq = oracle.unique_paths(lit["pathMatch"])
+    for x in outs:
+        assert np.array_equal(x["resp"]["ray"].astype(np.int64), slots[uniq].astype(np.int64))
+        np.testing.assert_allclose(x["resp"]["power"], lit["results"]["power"][uniq], rtol=1e-12)
+        np.testing.assert_allclose(x["resp"]["delay"], lit["delay"][uniq], rtol=1e-12)
+
+
 def test_plan_cpi_covers_exactly():
     from rts_amd import multigpu
     for total in (1000, 216 ** 3):

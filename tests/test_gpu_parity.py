@@ -746,6 +746,68 @@ def test_interleaved_parts_equal_whole(rts, oracle, scenes):
     tr.close()
 
 
+def test_dealt_tile_lists_equal_whole(rts, scenes):
+    """ray sharding dealt by last-seen cost (rts_tile_records_get / _set, rts_deal_tiles, rts_set_tile_list): for ARBITRARY tile ->
+    worker maps -- random ones, and the longest-first deal from the cost records of a whole pulse -- the parts' received sets,
+    merged by buffer row, are the whole launch's; the records a part hands out cover exactly its tiles; a handle that never traced
+    a tile takes its order from records another handle measured"""
+    from rts_amd import _lib, api
+    spec = scenes.config_multi(W=128)          # (a launch keeps cost records only when it is more than one sweep of the grid: > 2^18 launch indices)
+    n = spec["W"] ** 3
+    wl = spec["c"] / spec["carrier"]
+    tr = H.gpu_tracer(rts, spec)
+    H.gpu_trace(rts, spec, tr=tr); _, st_whole = H.gpu_trace(rts, spec, tr=tr)
+    whole = tr.received()
+    tr.finalise_uniform(None, wl, 1.0, 1.0, spec["carrier"], spec["c"])
+    g_whole = tr.aggregate(spec["c"], spec["carrier"], _lib.RTS_BASE_USE_ROWS)
+    rec_whole = tr.tile_records_get()
+    assert rec_whole.shape[0] == (n + 63) // 64 and np.count_nonzero(rec_whole) == rec_whole.shape[0]      # every wave tile of the whole pulse has a record
+    rng = np.random.default_rng(7)
+    other = H.gpu_tracer(rts, spec)                                  # a second handle: no history of its own
+    for tile, parts, how in [(64, 3, "random"), (256, 4, "lpt"), (4096, 2, "random"), (512, 5, "lpt")]:
+        n_plan = (n + tile - 1) // tile
+        if how == "lpt":
+            part_of, cost = api.deal_tiles(rec_whole, n, tile, parts)
+            assert cost.max() - cost.min() <= np.add.reduceat((rec_whole & 0x3fffffff).astype(np.uint64), np.arange(0, rec_whole.shape[0], tile // 64)).max()
+        else:
+            part_of = rng.integers(0, parts, n_plan).astype(np.uint32)
+        recs, tabs, seen = [], [], np.zeros(rec_whole.shape[0], np.uint32)
+        for part in range(parts):
+            ids = np.flatnonzero(part_of == part).astype(np.uint32)
+            t = tr if part % 2 == 0 else other
+            if t is other: t.tile_records_set(rec_whole)
+            t.set_tile_list(tile, ids)
+            expect = int(sum(min(tile, n - int(i) * tile) for i in ids))
+            if expect == 0: continue
+            _, st = H.gpu_trace(rts, spec, tr=t, interleave=(tile, api.INTERLEAVE_LIST, 0))
+            assert st["rays"] == expect
+            recs.append(t.received())
+            t.finalise_uniform(None, wl, 1.0, 1.0, spec["carrier"], spec["c"])
+            tabs.append(t.aggregate(spec["c"], spec["carrier"], _lib.RTS_BASE_USE_ROWS))
+            r = t.tile_records_get()
+            mine = np.repeat(part_of == part, tile // 64)[:r.shape[0]]
+            if expect >= 400000:                                     # (launches of one sweep of the grid keep no cost records)
+                assert np.all(r[~mine] == 0) and np.all(r[mine] != 0)
+                assert not np.any(seen[mine]); seen[mine] = r[mine]
+        slots = np.concatenate([r["slots"] for r in recs]); order = np.argsort(slots, kind="stable")
+        assert np.array_equal(slots[order], whole["slots"]), (tile, parts, how)
+        H.assert_prd_equal(np.concatenate([r["results"] for r in recs])[order], whole["results"], "dealt parts")
+        assert np.array_equal(np.concatenate([r["path"] for r in recs])[order], whole["path"])
+        merged = rts.merge_groups(np.concatenate(tabs), spec["max_refl"])
+        mo, wo = np.argsort(merged["min_ray"]), np.argsort(g_whole["min_ray"])         # (the order of a group table is not part of the contract: responses are emitted by representative ray)
+        assert np.array_equal(merged["min_ray"][mo], g_whole["min_ray"][wo]) and np.array_equal(merged["n"][mo], g_whole["n"][wo])
+        np.testing.assert_allclose(merged["sum_sqrt_power"][mo], g_whole["sum_sqrt_power"][wo], rtol=1e-12)
+    # a list is refused where it cannot be right, and forgotten on request
+    with pytest.raises(Exception): tr.set_tile_list(100, np.array([0, 1], np.uint32))                # not a multiple of 64
+    with pytest.raises(Exception): tr.set_tile_list(64, np.array([3, 3], np.uint32))                 # not ascending
+    with pytest.raises(Exception): tr.set_tile_list(64, np.array([(n + 63) // 64], np.uint32))       # beyond W^3
+    tr.set_tile_list(64, np.zeros(0, np.uint32))
+    with pytest.raises(Exception): H.gpu_trace(rts, spec, tr=tr, interleave=(64, api.INTERLEAVE_LIST, 0))
+    _, st = H.gpu_trace(rts, spec, tr=tr)
+    assert st["rays"] == n and st["segments"] == st_whole["segments"]
+    tr.close(); other.close()
+
+
 def test_far_rotated_placement(rts, oracle, scenes):
     """the hierarchy is walked in target space (ray mapped through the inverse placement), the exact test runs on the
     world-space vertices: a target rotated by float-trig matrices (orthonormal only to ~1e-7) and displaced by tens of

@@ -319,6 +319,37 @@ def test_soars_traits_branch_compiles_and_links(rts, tmp_path):
     assert subprocess.run([exe], timeout=60).returncode == 0
 
 
+def test_deal_tiles_longest_first(rts):
+    """rts_deal_tiles (host code; ray sharding dealt by last-seen cost): every plan tile goes to exactly one worker, the workers'
+    costs differ by at most the dearest tile, tiles without a record are spread by count, the deal is a function of the table
+    alone (every rank computes the same map), flags in bits 30-31 do not count as cost, bad arguments are refused"""
+    from rts_amd import api
+    rng = np.random.default_rng(11)
+    total = 216 ** 3; n = (total + 63) // 64
+    rec = np.zeros(n, np.uint32)
+    hot = rng.choice(n, 30000, replace=False)
+    rec[hot] = rng.integers(1, 900000, hot.shape[0]).astype(np.uint32)
+    rec[hot[:300]] |= np.uint32(0x80000000); rec[hot[300:500]] |= np.uint32(0x40000000)
+    for tile, parts in [(4096, 8), (64, 3), (1024, 5), (4096, 1)]:
+        part, cost = api.deal_tiles(rec, total, tile, parts)
+        n_plan = (total + tile - 1) // tile
+        assert part.shape[0] == n_plan and part.max() < parts
+        c = np.maximum(np.add.reduceat((rec & 0x3fffffff).astype(np.uint64), np.arange(0, n, tile // 64)), 1)
+        loads = np.array([int(c[part == r].sum()) for r in range(parts)], np.uint64)
+        assert np.array_equal(loads, cost)
+        assert int(loads.max() - loads.min()) <= int(c.max())
+        cnt = np.bincount(part[c == 1], minlength=parts)                 # tiles nobody traced: by count
+        assert cnt.max() - cnt.min() <= 1 + int(c.max())                  # (they fill the valleys the dear tiles left: never more than that many apart)
+        part2, _ = api.deal_tiles(rec.copy(), total, tile, parts)
+        assert np.array_equal(part, part2)
+    # no records at all: round-robin by count
+    part, cost = api.deal_tiles(np.zeros(n, np.uint32), total, 4096, 8)
+    assert np.bincount(part).max() - np.bincount(part).min() <= 1
+    for bad in [dict(tile=100), dict(parts=0), dict(total=total + 64)]:
+        with pytest.raises(Exception):
+            api.deal_tiles(rec, bad.get("total", total), bad.get("tile", 4096), bad.get("parts", 8))
+
+
 def test_plan_cpi_in_the_library(rts):
     """rts_plan_cpi (the plan the C++ adapter and bench.py share): ray mode gives every rank its interleaved part of every
     pulse; min_items refines to that many items without changing what the rank owns; bad arguments are refused"""
