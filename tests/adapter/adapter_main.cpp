@@ -75,7 +75,8 @@ int main(int argc, char** argv)
     rts_amd::RunOptions opt;
     opt.in_flight = argc > 2 ? (unsigned)atoi(argv[2]) : 2u;
     opt.devices.assign(argc > 3 ? (size_t)std::max(1, atoi(argv[3])) : 1u, 0);
-    opt.shard_rays = argc > 4 && std::string(argv[4]) == "rays";
+    opt.shard_rays = argc > 4 && (std::string(argv[4]) == "rays" || std::string(argv[4]) == "deal");
+    opt.deal_after = argc > 4 && std::string(argv[4]) == "deal" ? 2u : 0u;      // from the third pulse on: tile lists dealt from the cost records
     opt.last_stats = &st;
     try { rts_amd::run<mock::Traits>(&w, 1024, 65535, opt); }
     catch (const std::exception& e) { fprintf(stderr, "adapter failed: %s\n", e.what()); return 2; }

@@ -451,9 +451,10 @@ def test_adapter_end_to_end(rts, oracle, tmp_path):
         AR.write_scenario(path, sc)
         out = subprocess.run([exe, path], capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, (name, out.stderr)
-        variants = [["1"]] if name != "base" else [["1"], ["2", "2"], ["1", "3"], ["2", "2", "rays"], ["1", "3", "rays"], ["3", "2", "rays"]]
+        variants = [["1"]] if name != "base" else [["1"], ["2", "2"], ["1", "3"], ["2", "2", "rays"], ["1", "3", "rays"], ["3", "2", "rays"], ["2", "2", "deal"], ["3", "3", "deal"]]
         if name == "refraction":
             variants.append(["2", "2", "rays"])                                   # chains k W^3 apart come from the same part
+            variants.append(["2", "3", "deal"])                                   # ... also when the tiles are dealt from the cost records after two pulses (RunOptions::deal_after)
         for argv in variants:
             # sequential pulses; several handle sets on device 0 (the multi-device path on one GPU) -- whole pulses dealt to the
             # sets in turn, and every pulse split over the sets in interleaved tiles: byte-identical output
