@@ -29,8 +29,9 @@ python tools/timeline.py c3 > gpurun_out/${T}_timeline_c3.log 2>&1; python tools
 python tools/count_stats.py c3 c3narrow c2 c4 > gpurun_out/${T}_count_stats.log 2>&1
 tools/adapter_bench_bin 216 256 3 6 6 5 dh > gpurun_out/${T}_adapter_bench.json 2> gpurun_out/${T}_adapter_bench.err; python tools/adapter_line.py gpurun_out/${T}_adapter_bench.json
 tools/adapter_bench_bin 216 256 1 6 6 3 d > gpurun_out/${T}_adapter_bench_inflight1.json 2>/dev/null; python tools/adapter_line.py gpurun_out/${T}_adapter_bench_inflight1.json
-for r in 0 1 2 3 4 5 6 7; do echo "part $r/8: $(RTS_SHARD=8 RTS_SHARD_PART=$r RTS_VERBOSE=1 python tools/trace_bench.py c4 8 2>&1 | tail -2 | tr '\n' ' ' | cut -c1-300)" >> gpurun_out/${T}_c4_eighths.log; done
-echo "whole: $(RTS_VERBOSE=1 python tools/trace_bench.py c4 10 2>&1 | tail -2 | tr '\n' ' ' | cut -c1-330)" >> gpurun_out/${T}_c4_eighths.log
+for r in 0 1 2 3 4 5 6 7; do echo "part $r/8: $(RTS_SHARD=8 RTS_SHARD_PART=$r RTS_VERBOSE=1 python tools/trace_bench.py c4 8 2>&1 | tail -2 | tr '\n' ' ' | cut -c1-300)" >> gpurun_out/${T}_c4_eighths_final.log; done
+python tools/deal_bench.py c4 8 4096 > gpurun_out/${T}_c4_deal.log 2>&1; tail -2 gpurun_out/${T}_c4_deal.log
+echo "whole: $(RTS_VERBOSE=1 python tools/trace_bench.py c4 10 2>&1 | tail -2 | tr '\n' ' ' | cut -c1-330)" >> gpurun_out/${T}_c4_eighths_final.log
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --backend nccl > gpurun_out/${T}_bench_rccl_world1.json 2> gpurun_out/${T}_bench_rccl_world1.err
 python tools/cpu_baseline.py c1 c2 c3 > gpurun_out/${T}_cpu_baseline.log 2>&1; cat gpurun_out/${T}_cpu_baseline.log
 python tools/scene_info.py c3 c4 > gpurun_out/${T}_scene_info.log 2>&1; cat gpurun_out/${T}_scene_info.log
