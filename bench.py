@@ -436,7 +436,9 @@ def main():
     # loop, makes full passes over everything torch imported (~40 ms each) -- measured as 0.15 ms per pulse in trace_begin at 256
     # pulses, none at 64 (gpurun_out r04h).  Not the product's time: collected once here, then off for the timed interval.
     import gc
-    gc.collect(); gc.disable()
+    gc.collect()
+    if not os.environ.get("RTS_BENCH_GC"):                 # (RTS_BENCH_GC=1: leave the collector on -- the control run of profiles/r04_fresh_processes_gc.log)
+        gc.disable()
     sync()
     t0 = time.perf_counter()
     acc, resp = run_cpi(args.warmup, args.steps, prepared)
