@@ -145,6 +145,30 @@ def pulses_on_one_handle(spec, seed):
     tr.close()
 
 
+def dealt_parts(spec, seed, whole):
+    """the launch split into 2-4 parts by a RANDOM map of plan tiles (rts_set_tile_list, RTS_INTERLEAVE_LIST): the parts' received sets,
+    merged by buffer row, and their segment / shaded counts are the whole launch's"""
+    rng = np.random.default_rng(seed + 424242)
+    n = spec["W"] ** 3; tile = int(rng.choice([64, 128, 256, 4096])); parts = int(rng.integers(2, 5)); n_plan = (n + tile - 1) // tile
+    part_of = rng.integers(0, parts, n_plan)
+    tr = H.gpu_tracer(api, spec)
+    recs = []; seg = sh = 0
+    for p in range(parts):
+        ids = np.flatnonzero(part_of == p).astype(np.uint32)
+        if ids.shape[0] == 0: continue
+        tr.set_tile_list(tile, ids)
+        _, st = H.gpu_trace(api, spec, tr=tr, interleave=(tile, api.INTERLEAVE_LIST, 0))
+        assert st["rays"] == sum(min(tile, n - int(i) * tile) for i in ids), (seed, "rays of a dealt part")
+        recs.append(tr.received()); seg += st["segments"]; sh += st["shaded"]
+    tr.close()
+    ra = whole[1]
+    slots = np.concatenate([r["slots"] for r in recs]); order = np.argsort(slots, kind="stable")
+    assert np.array_equal(slots[order], ra["slots"]), (seed, "dealt parts: received rows")
+    H.assert_prd_equal(np.concatenate([r["results"] for r in recs])[order], ra["results"], "seed %d: dealt parts (received)" % seed)
+    assert np.array_equal(np.concatenate([r["path"] for r in recs])[order], ra["path"]), (seed, "dealt parts: paths")
+    assert (seg, sh) == (whole[2]["segments"], whole[2]["shaded"]), (seed, "dealt parts: counts", seg, sh, whole[2])
+
+
 def same(a, b, what):
     (ga, ra, sa, _), (gb, rb, sb, _) = a, b
     H.assert_prd_equal(ga["results"], gb["results"], what)
@@ -194,6 +218,8 @@ def main():
                 against_oracle(spec, a)
             if seed % 4 == 0:
                 pulses_on_one_handle(spec, seed)
+            if seed % 3 == 0:
+                dealt_parts(spec, seed, a)
         except Exception as e:
             print("FAILED seed %d (%s, aimed %s, W=%d, refl=%d, refr=%s): %r" % (seed, place, aim, spec["W"], spec["max_refl"], "max_refr" in spec, e), flush=True)
             raise
