@@ -383,7 +383,7 @@ void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlo
         std::vector<InFlight> fly; size_t done = 0;                            // fly[k] for pulse k; finished up to `done`
         std::vector<Stage1> st1; size_t done2 = 0;                             // staged finish: st1[k] once pulse k's stage 1 has run; stage 2 done up to `done2`
         const unsigned lanes = split ? F : S * F;                              // pulses in flight
-        bool dealt = false;
+        bool dealt = false; uint32_t deal_tile = RTS_PLAN_TILE;
         for (unsigned k = 0; k < pulseCount; k++) {
             InFlight fl;
             if (split && !dealt && opt.deal_after && k == opt.deal_after) {
@@ -391,15 +391,16 @@ void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlo
                 // No pulse may be in flight on a handle whose list changes: the pipeline is drained first.
                 while (done < fly.size()) { finish_pulse(fly[done].parts, fly[done].time_t); done++; }
                 const uint32_t n_rec = (uint32_t)((launchTotal + 63) / 64);
-                std::vector<uint32_t> table(n_rec, 0u), mine(n_rec), part_of((size_t)((launchTotal + RTS_PLAN_TILE - 1) / RTS_PLAN_TILE));
+                deal_tile = RTS_PLAN_TILE; while (deal_tile > 64u && (launchTotal + deal_tile - 1) / deal_tile < 8ull * S) deal_tile /= 2u;      // (a small lattice: finer tiles, so that every set gets some)
+                std::vector<uint32_t> table(n_rec, 0u), mine(n_rec), part_of((size_t)((launchTotal + deal_tile - 1) / deal_tile));
                 for (unsigned s = 0; s < S; s++) for (unsigned f = 0; f < F; f++) {     // (sets: disjoint parts; slots of a set: the same part, pulse after pulse)
                     check(rts_tile_records_get(H(s, f), mine.data(), n_rec), "rts_tile_records_get");
                     for (uint32_t i = 0; i < n_rec; i++) if (mine[i] > table[i]) table[i] = mine[i];
                 }
-                check(rts_deal_tiles(table.data(), n_rec, launchTotal, RTS_PLAN_TILE, S, part_of.data(), nullptr), "rts_deal_tiles");
+                check(rts_deal_tiles(table.data(), n_rec, launchTotal, deal_tile, S, part_of.data(), nullptr), "rts_deal_tiles");
                 for (unsigned s = 0; s < S; s++) {
                     std::vector<uint32_t> ids; for (uint32_t t = 0; t < part_of.size(); t++) if (part_of[t] == s) ids.push_back(t);
-                    for (unsigned f = 0; f < F; f++) { check(rts_tile_records_set(H(s, f), table.data(), n_rec), "rts_tile_records_set"); check(rts_set_tile_list(H(s, f), RTS_PLAN_TILE, ids.data(), (uint32_t)ids.size()), "rts_set_tile_list"); }
+                    for (unsigned f = 0; f < F; f++) { check(rts_tile_records_set(H(s, f), table.data(), n_rec), "rts_tile_records_set"); check(rts_set_tile_list(H(s, f), deal_tile, ids.data(), (uint32_t)ids.size()), "rts_set_tile_list"); }
                 }
                 dealt = true;
             }
@@ -408,7 +409,7 @@ void run(typename Tr::World* world, unsigned int MaxThreads, unsigned int MaxBlo
                 for (unsigned s = 0; s < S; s++) {
                     RtsPlanItem item{}; uint32_t n_items = 0;
                     check(rts_plan_cpi(launchTotal, 1, s, S, RTS_SHARD_RAYS, 0, 0, &item, 1, &n_items), "rts_plan_cpi");
-                    if (dealt) { item.interleave_tile = RTS_PLAN_TILE; item.interleave_parts = RTS_INTERLEAVE_LIST; item.interleave_part = 0; }
+                    if (dealt) { item.interleave_tile = deal_tile; item.interleave_parts = RTS_INTERLEAVE_LIST; item.interleave_part = 0; }
                     fl.time_t = begin_pulse(k, H(s, f), item); fl.parts.push_back(H(s, f));
                 }
             } else {                                                           // whole pulse on the next (set, slot) in turn

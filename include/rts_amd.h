@@ -371,7 +371,8 @@ int rts_plan_cpi(uint64_t total_rays, uint32_t n_pulses, uint32_t rank, uint32_t
  *                          launch indices (a multiple of 64) in descending cost, each to the worker with the least cost so far;
  *                          tiles without a record are dealt round-robin.  part_of_tile[ceil(total_rays / tile)] <- worker
  *   rts_set_tile_list      the plan tiles (ascending, unique, < ceil(range / tile)) the handle's launches with
- *                          interleave_parts == RTS_INTERLEAVE_LIST trace; n_ids == 0 forgets the list */
+ *                          interleave_parts == RTS_INTERLEAVE_LIST trace; n_ids == 0 is an EMPTY list (a worker that was dealt nothing:
+ *                          its launches trace no launch index and return empty sets); tile == 0 forgets the list */
 int rts_tile_records_get(RtsHandle h, uint32_t* records, uint32_t n);
 int rts_tile_records_set(RtsHandle h, const uint32_t* records, uint32_t n);
 int rts_deal_tiles(const uint32_t* records, uint32_t n_records, uint64_t total_rays, uint32_t tile, uint32_t parts, uint32_t* part_of_tile, uint64_t* cost_of_part /* [parts] or NULL */);

@@ -206,7 +206,8 @@ class Tracer:
         check(L.lib().rts_tile_records_set(self.h, ptr(r), r.shape[0]))
 
     def set_tile_list(self, tile, tile_ids):
-        """the plan tiles (of `tile` launch indices, ascending) that launches with interleave=(tile, INTERLEAVE_LIST, 0) trace"""
+        """the plan tiles (of `tile` launch indices, ascending) that launches with interleave=(tile, INTERLEAVE_LIST, 0) trace; no ids: an
+        empty list (such launches trace nothing); tile = 0: no list any more"""
         ids = np.ascontiguousarray(tile_ids, np.uint32)
         check(L.lib().rts_set_tile_list(self.h, tile, ptr(ids) if ids.shape[0] else None, ids.shape[0]))
 

@@ -143,7 +143,7 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     c->gate = new RtsGate(); c->gate->refs = 1; c->gate->device = p->device;
     e = hipStreamCreateWithPriority(&c->gate->tstream, hipStreamNonBlocking, prio_low);
     if (e != hipSuccess) { delete c->gate; (void)hipStreamDestroy(c->stream); delete c; rts_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return RTS_ERR_HIP; }
-    c->tstream = c->gate->tstream;
+    c->tstream = c->gate->tstream; c->tstream_now = c->tstream;
     e = hipEventCreateWithFlags(&c->ev_spec, hipEventDisableTiming); if (e != hipSuccess) { delete c; rts_set_error("hipEventCreate: %s", hipGetErrorString(e)); return RTS_ERR_HIP; }
     for (int i = 0; i < 2; i++) { e = hipEventCreateWithFlags(&c->ev_coop[i], hipEventDisableTiming); if (e != hipSuccess) { delete c; rts_set_error("hipEventCreate: %s", hipGetErrorString(e)); return RTS_ERR_HIP; } }
     for (int i = 0; i < 9; i++) { e = hipEventCreate(&c->ev[i]); if (e != hipSuccess) { delete c; rts_set_error("hipEventCreate: %s", hipGetErrorString(e)); return RTS_ERR_HIP; } }
@@ -171,6 +171,7 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     { const char* e = getenv("RTS_PLACE_FUSED"); if (e) c->place_fused = atoi(e) != 0; }
     { const char* e = getenv("RTS_TILE_SORT"); if (e) c->tile_bucket_order = strcmp(e, "radix") != 0; }
     { const char* e = getenv("RTS_XCD_AFFINE"); if (e) c->xcd_affine = e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2); }
+    { const char* e = getenv("RTS_TRACE_OWN_STREAM"); if (e) c->trace_own_stream = atoi(e) != 0; }
     { const char* e = getenv("RTS_SPEC_STREAM"); if (e) c->spec_on_trace_stream = strcmp(e, "trace") == 0; }
     { const char* e = getenv("RTS_SPECULATE"); if (e) c->spec_enabled = atoi(e) != 0; }
     { const char* e = getenv("RTS_POST_SMALL"); if (e) c->post_small = atoi(e) != 0; }
@@ -262,7 +263,7 @@ extern "C" int rts_link_handles(RtsHandle a, RtsHandle b)
     RTS_HIP(hipSetDevice(a->device));
     RTS_HIP(hipStreamSynchronize(joiner->tstream));
     (void)hipStreamDestroy(joiner->gate->tstream); delete joiner->gate;
-    joiner->gate = host->gate; joiner->gate->refs++; joiner->tstream = joiner->gate->tstream;
+    joiner->gate = host->gate; joiner->gate->refs++; joiner->tstream = joiner->gate->tstream; joiner->tstream_now = joiner->tstream;
     return RTS_OK;
 }
 
@@ -660,7 +661,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     uint32_t il_tile = 0, il_parts = 0, il_part = 0;
     const bool il_list = p->interleave_parts == RTS_INTERLEAVE_LIST;      // the tiles dealt to this handle (rts_set_tile_list)
     if (il_list) {
-        if (c->il_list_n == 0 || p->interleave_tile != c->il_list_tile) { rts_set_error("rts_trace_pulse: RTS_INTERLEAVE_LIST with tile %u, but the handle's tile list has %u tiles of %u launch indices (rts_set_tile_list)", p->interleave_tile, c->il_list_n, c->il_list_tile); return RTS_ERR_INVALID; }
+        if (c->il_list_tile == 0 || p->interleave_tile != c->il_list_tile) { rts_set_error("rts_trace_pulse: RTS_INTERLEAVE_LIST with tile %u, but the handle's tile list has %u tiles of %u launch indices (rts_set_tile_list)", p->interleave_tile, c->il_list_n, c->il_list_tile); return RTS_ERR_INVALID; }
         il_tile = c->il_list_tile; il_parts = RTS_INTERLEAVE_LIST; il_part = c->il_list_gen;
     } else if (p->interleave_parts > 1) {
         il_tile = p->interleave_tile; il_parts = p->interleave_parts; il_part = p->interleave_part;
@@ -704,10 +705,13 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     // ---- per-pulse buffers
     if (il_list) {           // every listed tile is whole, except the last tile of the range when it is listed (the list is ascending: it is the last entry)
         const uint64_t range_tiles = (count + il_tile - 1) / il_tile;
-        if (c->il_list_last >= range_tiles) { rts_set_error("rts_trace_pulse: the handle's tile list names tile %u, the range has %llu tiles of %u launch indices", c->il_list_last, (unsigned long long)range_tiles, il_tile); return RTS_ERR_INVALID; }
-        uint64_t cnt = (uint64_t)c->il_list_n * il_tile;
-        if (c->il_list_last == range_tiles - 1) cnt -= range_tiles * il_tile - count;
-        count = cnt;
+        if (c->il_list_n == 0) count = 0;
+        else if (c->il_list_last >= range_tiles) { rts_set_error("rts_trace_pulse: the handle's tile list names tile %u, the range has %llu tiles of %u launch indices", c->il_list_last, (unsigned long long)range_tiles, il_tile); return RTS_ERR_INVALID; }
+        else {
+            uint64_t cnt = (uint64_t)c->il_list_n * il_tile;
+            if (c->il_list_last == range_tiles - 1) cnt -= range_tiles * il_tile - count;
+            count = cnt;
+        }
     } else if (il_parts > 1) {      // number of launch indices of the range that fall into this part's tiles
         const uint64_t stride = (uint64_t)il_tile * il_parts, full = count / stride, rem = count % stride;
         const uint64_t lo = (uint64_t)il_part * il_tile;
@@ -817,9 +821,15 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     lt.lap(3);
     // ---- trace
     RTS_STAGE(c, "pre-trace");
-    RTS_HIP(hipEventRecord(c->ev[8], st));                       // scene + per-pulse buffers of this handle are ready
-    RTS_HIP(hipStreamWaitEvent(c->tstream, c->ev[8], 0));
-    RTS_HIP(hipEventRecord(c->ev[2], c->tstream));
+    // The trace kernel's stream: the handle's low-priority trace stream when other pulses share the GPU (their short kernels then get
+    // in beside it), the handle's OWN stream when none does -- a pulse on its own is one dependent chain, and every hop between two
+    // streams costs it 17-25 us of event hand-over (profiles/r04_inflight1_pulse_timeline.log: two hops per pulse)
+    c->tstream_now = (c->trace_own_stream && !shared_gpu && c->gate->refs.load() == 1) ? st : c->tstream;
+    if (c->tstream_now != st) {
+        RTS_HIP(hipEventRecord(c->ev[8], st));                   // scene + per-pulse buffers of this handle are ready
+        RTS_HIP(hipStreamWaitEvent(c->tstream_now, c->ev[8], 0));
+    }
+    RTS_HIP(hipEventRecord(c->ev[2], c->tstream_now));
     // the cooperative kernel (tiles at the head of the cost order, one launch index per wave): its grid follows the head count
     // of the handle's previous order build (the count of THIS build is on the device; a grid too small or too large only costs
     // balance, every unit is drawn from a queue); it came home with that launch's counters
@@ -837,8 +847,8 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     int rc = rts_trace_launch(c, a, count_trav, coop_grid);
     if (rc != RTS_OK) return rc;
     RTS_STAGE(c, "k_trace");
-    RTS_HIP(hipEventRecord(c->ev[3], c->tstream));
-    RTS_HIP(hipStreamWaitEvent(st, c->ev[3], 0));                // everything later on this handle's stream follows its trace
+    RTS_HIP(hipEventRecord(c->ev[3], c->tstream_now));
+    if (c->tstream_now != st) RTS_HIP(hipStreamWaitEvent(st, c->ev[3], 0));      // everything later on this handle's stream follows its trace
     lt.lap(4);
     // (the eight counters were written into the pinned block by k_sum_counters itself: no copy)
     c->pulse_open = true; g_open_pulses[c->device & 63]++;
@@ -1116,10 +1126,10 @@ extern "C" int rts_trace_pulse_end_uniform(RtsHandle c, const double* rcs_per_ta
     // ... on the TRACE stream, behind the trace kernel: enqueued on the handle's other stream -- which waits for the trace through
     // an event -- every launch call of the chain blocked (0.22 ms per pulse in the submitting thread)
     int rc;
-    if (c->spec_on_trace_stream) {
-        hipStream_t own = c->stream; c->stream = c->tstream;
+    if (c->spec_on_trace_stream && c->tstream_now != c->stream) {
+        hipStream_t own = c->stream; c->stream = c->tstream_now;
         rc = rts_post_chain(c);
-        RTS_HIP(hipEventRecord(c->ev_spec, c->tstream)); c->stream = own;
+        RTS_HIP(hipEventRecord(c->ev_spec, c->tstream_now)); c->stream = own;
         RTS_HIP(hipStreamWaitEvent(c->stream, c->ev_spec, 0));          // (what the handle enqueues next on its own stream comes after the chain)
     } else rc = rts_post_chain(c);                                      // (the handle's own stream already waits for the trace: rts_trace_pulse_begin)
     c->recv_dev = nullptr; c->n_recv = 0;
@@ -1358,8 +1368,9 @@ extern "C" int rts_set_tile_list(RtsHandle c, uint32_t tile, const uint32_t* til
     if (c->spec_pending) { int rc_ = rts_spec_resolve(c); if (rc_ != RTS_OK) return rc_; }
     // the cost records of the last launch are indexed through the list in force: into the history before it goes
     { int rc = rts_tile_costs_flush(c); if (rc != RTS_OK) return rc; }
-    if (n_ids == 0) { c->il_list_n = 0; c->il_list_tile = 0; c->il_list_gen++; return RTS_OK; }
-    if (!tile_ids || tile == 0 || tile % RTS_WTILE != 0) { rts_set_error("rts_set_tile_list: tile must be a positive multiple of %d launch indices (got %u)", RTS_WTILE, tile); return RTS_ERR_INVALID; }
+    if (tile == 0) { c->il_list_n = 0; c->il_list_tile = 0; c->il_list_gen++; c->tile_last_valid = false; return RTS_OK; }      // no list any more
+    if ((n_ids && !tile_ids) || tile % RTS_WTILE != 0) { rts_set_error("rts_set_tile_list: tile must be a positive multiple of %d launch indices (got %u)", RTS_WTILE, tile); return RTS_ERR_INVALID; }
+    if (n_ids == 0) { c->il_list_n = 0; c->il_list_tile = tile; c->il_list_last = 0; c->il_list_gen++; c->tile_last_valid = false; return RTS_OK; }      // an EMPTY list: this worker was dealt nothing, its launches trace no launch index
     for (uint32_t k = 1; k < n_ids; k++) if (tile_ids[k] <= tile_ids[k - 1]) { rts_set_error("rts_set_tile_list: tile ids must be ascending and unique (entry %u: %u after %u)", k, tile_ids[k], tile_ids[k - 1]); return RTS_ERR_INVALID; }
     const uint64_t total = (uint64_t)c->params.width * c->params.width * c->params.width;
     if ((uint64_t)tile_ids[n_ids - 1] * tile >= total) { rts_set_error("rts_set_tile_list: tile %u of %u launch indices lies beyond W^3 = %llu", tile_ids[n_ids - 1], tile, (unsigned long long)total); return RTS_ERR_INVALID; }

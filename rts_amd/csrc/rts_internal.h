@@ -345,6 +345,7 @@ struct RtsContext {
     uint32_t post_prio = 3;             // s_setprio of k_post_all's waves (RTS_POST_PRIO = 0 .. 3)
     bool post_one = true;               // rts_trace_pulse_end_uniform: ONE kernel for order + expand + finalise + cube + aggregation of a small received set (RTS_POST_ONE=0: seven)
     bool post_small = true;             // received sets of up to 4096 rays are ordered / finished by single blocks (RTS_POST_SMALL=0: the general chain)
+    hipStream_t tstream_now = nullptr; bool trace_own_stream = true;      // the stream this pulse's trace kernel went to (rts_trace_pulse_begin; RTS_TRACE_OWN_STREAM=0: always the trace stream)
     hipEvent_t ev_spec = nullptr; uint32_t spec_cap = RTS_SMALL_CAP64; bool spec_on_trace_stream = false;      // (RTS_SPEC_STREAM=trace: the speculative chain behind the trace kernel on ITS stream)
     RtsSpecParams spec; bool spec_pending = false, spec_enabled = true;      // rts_trace_pulse_end_uniform: parameters of the chain; a chain enqueued on the device-side count awaits its resolution (RTS_SPECULATE=0: never)
     const unsigned long long* recv_dev = nullptr;                           // != nullptr while such a chain is being enqueued: its kernels take the received count from here

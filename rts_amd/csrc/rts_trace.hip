@@ -1211,12 +1211,12 @@ int rts_trace_launch(RtsContext* c, const RtsTraceArgs& a_in, bool count_travers
     a.done_ctr = c->sum_in_kernel ? a.tile_ctr + RTS_OFF_HEAD + 3 : nullptr;      // (the pad word behind the head words: zeroed with them)
     a.n_blocks_all = a.total_threads / RTS_BLOCK + coop_grid; a.host_cnt = c->pin_dev->cnt;
     if (a.n_rays == 0) {                                            // nothing to trace (an interleaved part without launch indices): the counters still go home, as zeros
-        k_sum_counters<<<1, 256, 0, c->tstream>>>(a.block_counters, 0u, a.counters, nullptr, c->pin_dev->cnt);
+        k_sum_counters<<<1, 256, 0, c->tstream_now>>>(a.block_counters, 0u, a.counters, nullptr, c->pin_dev->cnt);
         RTS_HIP(hipGetLastError());
         return RTS_OK;
     }
     const unsigned grid = a.total_threads / RTS_BLOCK;
-    hipStream_t st = c->tstream;
+    hipStream_t st = c->tstream_now;
     if (count_traversal) RTS_HIP(hipMemsetAsync(a.block_counters, 0xff, sizeof(unsigned long long) * 8 * ((size_t)grid + coop_grid), st));      // poison: every block must write its row
     if (coop_grid) {
         if (!c->cstream) { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); RTS_HIP(hipStreamCreateWithPriority(&c->cstream, hipStreamNonBlocking, lo)); }

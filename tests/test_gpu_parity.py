@@ -802,7 +802,10 @@ def test_dealt_tile_lists_equal_whole(rts, scenes):
     with pytest.raises(Exception): tr.set_tile_list(100, np.array([0, 1], np.uint32))                # not a multiple of 64
     with pytest.raises(Exception): tr.set_tile_list(64, np.array([3, 3], np.uint32))                 # not ascending
     with pytest.raises(Exception): tr.set_tile_list(64, np.array([(n + 63) // 64], np.uint32))       # beyond W^3
-    tr.set_tile_list(64, np.zeros(0, np.uint32))
+    tr.set_tile_list(64, np.zeros(0, np.uint32))                                                     # an EMPTY list: a worker that was dealt nothing traces nothing
+    _, st = H.gpu_trace(rts, spec, tr=tr, interleave=(64, api.INTERLEAVE_LIST, 0))
+    assert st["rays"] == 0 and st["segments"] == 0 and len(tr.received()["slots"]) == 0
+    tr.set_tile_list(0, np.zeros(0, np.uint32))                                                      # no list any more
     with pytest.raises(Exception): H.gpu_trace(rts, spec, tr=tr, interleave=(64, api.INTERLEAVE_LIST, 0))
     _, st = H.gpu_trace(rts, spec, tr=tr)
     assert st["rays"] == n and st["segments"] == st_whole["segments"]

@@ -44,7 +44,7 @@ for mode in ("interleaved", "dealt"):
         if mode == "dealt":
             tr.set_tile_list(tile, np.flatnonzero(part_of == r).astype(np.uint32)); il = (tile, api.INTERLEAVE_LIST, 0)
         else:
-            tr.set_tile_list(tile, np.zeros(0, np.uint32)); il = (tile, parts, r)
+            tr.set_tile_list(0, np.zeros(0, np.uint32)); il = (tile, parts, r)
         ms = []
         for k in range(launches):
             st = tr.trace(tx["origin"], tx["span"], tx["dir"], motion(6 + k), ray_first=0, ray_count=n, interleave=il)
