@@ -18,7 +18,10 @@ aggregation into the pulse's responses.  A "ray" in Mrays/s is one traced segmen
 or bounce).  Pulses are independent, so each GPU keeps --inflight of them in flight on as many handles.  All of that is
 inside the timed region; ms_per_step is wall time / pulses.
 
-Sharding over N ranks (--shard): "pulses" (default) deals the K pulses of the interval to the ranks whole, left-over
+N > 1 ranks (one process per GPU): WEAK scaling by default -- every rank runs --steps pulses, the interval is N x steps pulses
+(pulses are independent, ray_tracer.cpp:843; no collective in the data path), a step = one pulse on every rank, value = the
+segments all ranks traced / the slowest rank's time; --scaling strong deals ONE interval of --steps pulses to the ranks.
+Sharding over N ranks (--shard): "pulses" (default) deals the pulses of the interval to the ranks whole, left-over
 pulses in interleaved tiles (rts_plan_cpi); "rays" splits EVERY pulse over all ranks in interleaved 4096-index tiles.
 Either way the per-(receiver, path) group tables are exchanged once per interval (one all-gather over RCCL) and the
 complex return cube is summed once (one all-reduce), both inside the timed region.
@@ -178,6 +181,7 @@ def main():
     ap.add_argument("--tx", default="0", choices=["0", "1", "both"], help="c4: which of configs[3]'s two transmitters; both = the first half of the interval's pulses from transmitter 0, the second half from transmitter 1 (the reference's transmitter loop is the outer one, ray_tracer.cpp:806)")
     ap.add_argument("--as-rank", default="", help="debug, one process: 'r/N' runs the plan rank r of N ranks would run (with --shard rays: its part of EVERY pulse), without a process group -- one GPU's share of a ray-sharded interval at the pipelined rate, every r in turn gives the critical path of an N-GPU run; value / ms_per_step are that rank's alone")
     ap.add_argument("--deal", default="interleave", choices=["interleave", "cost"], help="--shard rays: 'cost' = after the warm-up pulses (traced as interleaved parts) the ranks exchange what every tile cost the rank that traced it (ONE all-reduce of a uint32 per 64 launch indices, outside the timed interval: it belongs to the previous interval), adopt the merged table as their tile history and trace the timed interval's pulses as tile lists dealt longest-first from it (rts_deal_tiles, rts_set_tile_list) instead of the static interleave.  With --as-rank the table comes from two whole pulses traced by this process (standing in for the other ranks)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="N > 1: 'weak' (default) = every rank runs --steps pulses, the interval is N x steps pulses (a step = one pulse on every rank; value = what all ranks traced / time; per-GPU work fixed as N grows -- pulses are independent, ray_tracer.cpp:843, and there is no collective in the data path); 'strong' = ONE interval of --steps pulses dealt to the ranks (a 20-pulse interval over 8 ranks is 2-3 pulses per rank: pipeline fill and drain, not scaling)")
     ap.add_argument("--shard", default="pulses", choices=["pulses", "rays"], help="N > 1: deal whole pulses to the ranks, or split every pulse over all ranks (interleaved tiles)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks")
     args = ap.parse_args()
@@ -258,7 +262,9 @@ def main():
     if args.tx == "1":
         tx = spec["tx_list"][1]
     two_tx = args.tx == "both"
-    half = (args.steps + 1) // 2                                  # --tx both: pulses [0, half) of transmitter 0, then [0, steps - half) of transmitter 1
+    n_int = args.steps * (world if args.scaling == "weak" else 1)     # pulses of the timed interval (weak scaling: --steps per rank) ...
+    n_warm = args.warmup * (world if args.scaling == "weak" else 1)   # ... and of the warm-up
+    half = (n_int + 1) // 2                                       # --tx both: pulses [0, half) of transmitter 0, then [0, n_int - half) of transmitter 1
 
     def tx_of(k_rel, motion):
         """transmitter of the interval's k_rel-th pulse; a configuration with tx_track aims the boresight at the (first) target's
@@ -293,7 +299,7 @@ def main():
     n_bins = 1024
     r0 = 2.0 * float(np.linalg.norm(np.asarray(tx["origin"], np.float64) - np.asarray(spec["motion"][0]["position"], np.float64)))
     cube_t0 = (r0 - 150.0) / spec["c"]; cube_dt = 300.0 / spec["c"] / n_bins
-    cube = torch.zeros((len(spec["rx"]), max(args.steps, args.warmup, 1), n_bins), dtype=torch.complex128, device="cuda")
+    cube = torch.zeros((len(spec["rx"]), max(n_int, n_warm, 1), n_bins), dtype=torch.complex128, device="cuda")
     for t in trs:                                              # every pulse owns one row of the cube, so the handles can share it
         t.cube_attach(cube.shape[0], cube.shape[1], n_bins, cube_t0, cube_dt, device_ptr=cube.data_ptr())
     n_fft = 1 << max(int(cube.shape[1]) - 1, 1).bit_length()  # range-Doppler map: zero-padded power-of-two transform over the pulse axis (rts_cube_doppler)
@@ -416,8 +422,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.warmup:
-        run_cpi(0, args.warmup)
+    if n_warm:
+        run_cpi(0, n_warm)
     if args.deal == "cost" and args.shard == "rays" and plan_world > 1:
         if args.as_rank:                                      # one process: two whole pulses stand in for what the other ranks measured
             m0 = pulse_motion(spec, 0); x0 = tx_of(0, m0)
@@ -430,8 +436,8 @@ def main():
         for t in trs:
             t.tile_records_set(table); t.set_tile_list(tile_, ids_)
         dealt.update(tile=tile_, cost=[float(x) for x in cost_ / max(float(cost_.mean()), 1.0)], tiles_of_this_rank=int(ids_.shape[0]))
-        run_cpi(args.warmup, min(args.warmup, 2 * len(trs)))  # (every handle's first launch over its list: the cooperative stream, the order build of a new shape)
-    prepared = prepare_cpi(args.warmup, args.steps)
+        run_cpi(n_warm, min(n_warm, 2 * len(trs)))  # (every handle's first launch over its list: the cooperative stream, the order build of a new shape)
+    prepared = prepare_cpi(n_warm, n_int)
     # The harness is Python: its cyclic garbage collector, once a few thousand ctypes / numpy objects have been allocated by the
     # loop, makes full passes over everything torch imported (~40 ms each) -- measured as 0.15 ms per pulse in trace_begin at 256
     # pulses, none at 64 (gpurun_out r04h).  Not the product's time: collected once here, then off for the timed interval.
@@ -441,11 +447,11 @@ def main():
         gc.disable()
     sync()
     t0 = time.perf_counter()
-    acc, resp = run_cpi(args.warmup, args.steps, prepared)
+    acc, resp = run_cpi(n_warm, n_int, prepared)
     sync()
     dt = time.perf_counter() - t0
     gc.enable()
-    assert len(resp) == args.steps, "every pulse of the interval must come back with its responses"
+    assert len(resp) == n_int, "every pulse of the interval must come back with its responses"
     # range-Doppler map of the interval (slow-time FFT of the summed cube): a check of the dense product, outside the timed
     # region -- the hot path ends with the per-pulse responses and the (all-reduced) cube
     # (the transform itself ran inside the timed region, in the interval's tail: rts_cube_doppler; here it is checked against torch.fft)
@@ -557,18 +563,18 @@ def main():
         out = {
             "metric": "Mrays/s (primary+bounces) & ms/pulse, 100k-tri scene",
             "value": seg_all / dt / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[%d]%s: %s, 1 Tx / %d Rx, W=%d (%d launch indices/pulse), maxRefl=%d, target moves every pulse (re-placed on the device per pulse; static target-space BVH4)"
                                    % ({"c3": 2, "c3ecef": 2, "c3ico": 2, "c4": 3, "c5": 4}.get(args.config, 1), " at Earth-centred coordinates" if args.config == "c3ecef" else (" (both transmitters in turn: pulses [0, %d) from Tx 0, [%d, %d) from Tx 1; a receiver's noise temperature grows by the signal's once per transmitter, ray_tracer.cpp:829 -- host side, the SOARS adapter's)" % (half, half, args.steps) if two_tx else (" -- NOT a BASELINE configuration: the scene of the C++ boundary benchmark (tests/adapter/adapter_bench.cpp)" if args.config == "sphere6" else (" (target re-rotated and translated every pulse, ray_tracer.cpp:993-1014; the transmitter's boresight tracks it)" if args.config == "c5" else ""))), spec["name"], len(spec["rx"]), W, total, spec["max_refl"]),
-                       "rays_per_pulse": total, "segments_per_pulse": seg_all / args.steps, "received_per_pulse": received_all / args.steps,
-                       "hit_fraction": hit_fraction, "bounding_sphere_fraction": sphere_fraction, "primary_Mrays_per_s": total * args.steps / dt / 1e6,
-                       "walked_segments_per_pulse": walked_per_pulse, "walked_Mrays_per_s": walked_per_pulse * (seg_all / max(seg_serial * args.steps, 1)) * args.steps / dt / 1e6,
+                       "rays_per_pulse": total, "pulses_in_the_interval": n_int, "segments_per_pulse": seg_all / max(n_int, 1), "received_per_pulse": received_all / max(n_int, 1),
+                       "hit_fraction": hit_fraction, "bounding_sphere_fraction": sphere_fraction, "primary_Mrays_per_s": total * n_int / dt / 1e6,
+                       "walked_segments_per_pulse": walked_per_pulse, "walked_Mrays_per_s": walked_per_pulse * (seg_all / max(seg_serial * n_int, 1)) * n_int / dt / 1e6,
                        "walked_note": "segments that entered a target's hierarchy (counting build, one pulse); the rest of segments_per_pulse are primaries the conservative pre-filter or the bounding spheres cleared -- counted as rtTrace calls (SURVEY 8d), but bulk culling, not traversal",
                        "dense_control_Gseg_per_s": (dense or {}).get("Gseg_per_s"),
                        "return_cube": "complex128 [%d rx][%d pulses][%d bins], all-reduced once per interval, then %d-point slow-time FFT in the library (rts_cube_doppler, inside the timed region); range-Doppler peak %.6e, max deviation from torch.fft %.1e (relative)" % (cube.shape[0], cube.shape[1], n_bins, n_fft, range_doppler_peak, range_doppler_err or 0.0),
                        "as_rank": args.as_rank or None, "deal": (dict(dealt, how="tiles dealt longest-first from the cost records of the warm-up interval (one all-reduce), rts_deal_tiles") if dealt else "static interleave") if args.shard == "rays" and plan_world > 1 else None,
-                       "sharding": ("%d-pulse interval over %d ranks, --shard %s: " % (args.steps, world, args.shard)) + ("every pulse split over all ranks in interleaved 4096-index tiles" if args.shard == "rays" else "whole pulses, left-over pulses in interleaved 4096-index tiles") + "; one group-table all-gather + one cube all-reduce per interval",
+                       "sharding": ("%d-pulse interval over %d ranks (--scaling %s: %s), --shard %s: " % (n_int, world, args.scaling, "--steps pulses per rank" if args.scaling == "weak" else "--steps pulses in all", args.shard)) + ("every pulse split over all ranks in interleaved 4096-index tiles" if args.shard == "rays" else "whole pulses, left-over pulses in interleaved 4096-index tiles") + "; one group-table all-gather + one cube all-reduce per interval",
                        "host_numa_node": numa_node, "post_processing_call": "rts_trace_pulse_end_uniform" if ((args.fused_post or len(trs) == 1) and hasattr(rts_amd._lib.lib(), "rts_trace_pulse_end_uniform")) else "rts_trace_pulse_end + rts_finalise_uniform + rts_cube_accumulate + rts_aggregate", "pulses_in_flight": len(trs), "linked": bool(args.link), "scene_setup_s": scene_setup_s,
                        "interval_tail_ms_rank0": acc["tail_ms"],
                        "host_ms_per_pulse_rank0": {k: v / max(acc["launches"], 1) for k, v in acc["host_ms"].items()},
