@@ -744,7 +744,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     const bool pre_filter = c->use_pmask && !c->pre_dense;           // (a launch where most rays hit pays for the filter and skips nothing)
     fill_mask_frame(lc, pre_filter && c->scene->n_prims > 0);
     for (int k = 0; k < 3; k++) { lc.f_bs[k] = (float)(&lc.bsx)[k]; lc.f_st[k] = (float)(&lc.stx)[k]; }
-    for (int k = 0; k < 9; k++) { lc.f_rot[k] = (float)lc.rot[k]; lc.f_rot1[k] = (float)lc.rot1[k]; }
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) lc.f_m[3 * i + j] = (float)(lc.rot1[3 * i] * lc.rot[j] + lc.rot1[3 * i + 1] * lc.rot[3 + j] + lc.rot1[3 * i + 2] * lc.rot[6 + j]);
     lt.lap(0);
     // ---- the pulse's parameters in ONE upload: launch constants, and -- when a target moved -- the placements behind them
     c->pin->lc = lc;

@@ -144,8 +144,9 @@ struct RtsLaunchConsts {
     uint32_t il_tile, il_parts, il_part, pad2;     // interleaved tiles (il_parts <= 1: contiguous)
     const uint32_t* il_list;        // != nullptr: local tile j of il_tile launch indices is tile il_list[j] of the range (rts_set_tile_list: tiles DEALT to this launch, ascending) instead of j * il_parts + il_part
     RtsMaskFrame mask;              // primary-ray mask frame (n = 0: no mask this launch)
-    // f32 copies for the primary-ray PRE-FILTER (rts_trace.hip): beamStart, lattice step, Rot, Rot1
-    float f_bs[3], f_st[3], f_rot[9], f_rot1[9];
+    // f32 constants of the primary-ray PRE-FILTER (rts_trace.hip): beamStart, lattice step, and Rot1 * Rot in ONE matrix -- the two
+    // normalisations between them (ray_tracer.cu:170, 182) only scale, so the direction is Rot1 Rot (bs + st l) up to its length
+    float f_bs[3], f_st[3], f_m[9], f_pad;
 };
 static_assert(sizeof(RtsLaunchConsts) % 8 == 0, "launch constants are copied to LDS dword by dword");
 

@@ -548,17 +548,17 @@ __device__ __forceinline__ void rts_write_back(const RtsTraceArgs& a, const RtsU
 __device__ __forceinline__ void rts_prefilter(const RtsLaunchConsts& lc, const uint32_t slot, const bool mask_on, const uint32_t* __restrict__ pmask, const uint32_t n_rx,
                                               const float (*rxp)[6], bool& may_target, bool& may_rx)
 {
-    // ray_generation in f32 (same tree, f32 constants): lattice point, normalise, Rot, normalise, Rot1
+    // ray_generation in f32: lattice point, ONE matrix (Rot1 Rot: the reference's two normalisations in between only scale), normalise.
+    // Good to ~2e-7 rad; the mask's margin is a whole cell (>= 1e-5), the receivers' radii are widened by 1 %
     uint32_t lx, ly, lz; rts_lattice_coords(lc, slot, lx, ly, lz);
-    float vx = __builtin_fmaf(lc.f_st[0], (float)lx, lc.f_bs[0]), vy = __builtin_fmaf(lc.f_st[1], (float)ly, lc.f_bs[1]), vz = __builtin_fmaf(lc.f_st[2], (float)lz, lc.f_bs[2]);
-    float inv = __frsqrt_rn(vx*vx + vy*vy + vz*vz); vx *= inv; vy *= inv; vz *= inv;
-    float rx_ = lc.f_rot[0]*vx + lc.f_rot[1]*vy + lc.f_rot[2]*vz, ry_ = lc.f_rot[3]*vx + lc.f_rot[4]*vy + lc.f_rot[5]*vz, rz_ = lc.f_rot[6]*vx + lc.f_rot[7]*vy + lc.f_rot[8]*vz;
-    inv = __frsqrt_rn(rx_*rx_ + ry_*ry_ + rz_*rz_); rx_ *= inv; ry_ *= inv; rz_ *= inv;
-    const float dx = lc.f_rot1[0]*rx_ + lc.f_rot1[1]*ry_ + lc.f_rot1[2]*rz_, dy = lc.f_rot1[3]*rx_ + lc.f_rot1[4]*ry_ + lc.f_rot1[5]*rz_, dz = lc.f_rot1[6]*rx_ + lc.f_rot1[7]*ry_ + lc.f_rot1[8]*rz_;
+    const float vx = __builtin_fmaf(lc.f_st[0], (float)lx, lc.f_bs[0]), vy = __builtin_fmaf(lc.f_st[1], (float)ly, lc.f_bs[1]), vz = __builtin_fmaf(lc.f_st[2], (float)lz, lc.f_bs[2]);
+    float dx = lc.f_m[0]*vx + lc.f_m[1]*vy + lc.f_m[2]*vz, dy = lc.f_m[3]*vx + lc.f_m[4]*vy + lc.f_m[5]*vz, dz = lc.f_m[6]*vx + lc.f_m[7]*vy + lc.f_m[8]*vz;
+    const float inv = __frsqrt_rn(dx*dx + dy*dy + dz*dz); dx *= inv; dy *= inv; dz *= inv;
     if (mask_on) {                                       // is any triangle's projection near this direction? (RtsMaskFrame)
         const RtsMaskFrame& mf = lc.mask;
         const float w = dx * mf.bx + dy * mf.by + dz * mf.bz;
-        const float fu = ((dx * mf.ux + dy * mf.uy + dz * mf.uz) / w - mf.u0) * mf.inv_du, fv = ((dx * mf.vx + dy * mf.vy + dz * mf.vz) / w - mf.v0) * mf.inv_dv;
+        const float iw = __builtin_amdgcn_rcpf(w);          // (v_rcp_f32, 1 ulp: 1e-7 of a coordinate that is compared with cells of >= 1e-5 after a one-cell margin; two IEEE divisions were ~20 instructions)
+        const float fu = ((dx * mf.ux + dy * mf.uy + dz * mf.uz) * iw - mf.u0) * mf.inv_du, fv = ((dx * mf.vx + dy * mf.vy + dz * mf.vz) * iw - mf.v0) * mf.inv_dv;
         if (w > 0.0f && fu >= 0.0f && fv >= 0.0f && fu < (float)mf.n && fv < (float)mf.n) {
             const uint32_t cell = (uint32_t)fv * mf.n + (uint32_t)fu;
             may_target = ((pmask[cell >> 5] >> (cell & 31u)) & 1u) != 0u;
