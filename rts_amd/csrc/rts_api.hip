@@ -176,6 +176,7 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     { const char* e = getenv("RTS_SPECULATE"); if (e) c->spec_enabled = atoi(e) != 0; }
     { const char* e = getenv("RTS_POST_SMALL"); if (e) c->post_small = atoi(e) != 0; }
     { const char* e = getenv("RTS_POST_ONE"); if (e) c->post_one = atoi(e) != 0; }
+    { const char* e = getenv("RTS_POST_ONE_MAX"); if (e) c->post_one_max = (uint64_t)strtoull(e, nullptr, 10); }
     { const char* e = getenv("RTS_POST_PRIO"); if (e) c->post_prio = (uint32_t)std::min(3, std::max(0, atoi(e))); }
     { const char* e = getenv("RTS_ASYNC_IDLE0"); if (e) c->async_idle0 = (uint32_t)std::min(64, std::max(0, atoi(e))); }
     { const char* e = getenv("RTS_ASYNC_IDLE1"); if (e) c->async_idle1 = (uint32_t)std::min(64, std::max(1, atoi(e))); }
@@ -1048,7 +1049,10 @@ static int rts_post_chain(RtsContext* c, bool ordered = false)      // ordered: 
     hipStream_t st = c->stream;
     const bool keep_all = (c->params.flags & RTS_FLAG_KEEP_ALL_RAYS) != 0;
     int rc = RTS_OK;
-    if (!ordered && q.mode == 0 && c->recv_dev && c->post_one && c->post_small && !keep_all && !c->mirror.want && c->n_recv <= c->spec_cap) {
+    // (one block does in 150 us what seven launches -- four of them many blocks wide -- do in 92 us + six launch gaps for BASELINE configs[2]'s
+    // ~1 900 received rays; for a few hundred rays it is the other way round: sequential pulses, one kernel against seven, C3 1.025 / 0.980 ms,
+    // C2 (400 rays) 0.339 / 0.354, configs[4] (100) 0.955 / 0.978, profiles/r04_post_one_ab.log -- so the choice follows the handle's last count)
+    if (!ordered && q.mode == 0 && c->recv_dev && c->post_one && c->recv_hint_valid && c->recv_hint <= c->post_one_max && c->post_small && !keep_all && !c->mirror.want && c->n_recv <= c->spec_cap) {
         // the speculative chain as ONE kernel (rts_post.hip: k_post_all): sized for the capacity, the count from the device
         RTS_HIP(hipEventRecord(c->ev[4], st)); RTS_HIP(hipEventRecord(c->ev[5], st)); RTS_HIP(hipEventRecord(c->ev[6], st));
         c->agg_pending.valid = false; c->groups.clear();
@@ -1082,6 +1086,7 @@ static int rts_spec_resolve(RtsContext* c)
     RTS_HIP(rts_stream_wait(c, c->stream));
     if (cnt[6]) { rts_set_error("rts_trace_pulse: traversal stack overflow / malformed BVH guard tripped on %llu waves", cnt[6]); return RTS_ERR_HIP; }
     c->n_recv = cnt[0]; c->n_head_hint = (uint32_t)cnt[7];
+    c->recv_hint = cnt[0]; c->recv_hint_valid = true;                   // (the next pulse's choices -- speculate at all, one kernel or seven -- follow THIS pulse's count, not the handle's first)
     rts_pulse_account(c, cnt);
     if (c->n_recv > c->spec_cap) {                                      // more rays than the speculative chain was sized for: it did nothing; the ordinary chain now
         c->agg_pending.valid = false;

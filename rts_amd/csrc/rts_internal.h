@@ -344,6 +344,7 @@ struct RtsContext {
     bool tile_bucket_order = true;      // tile order by counting bins instead of a radix sort (RTS_TILE_SORT=radix: the sort)
     int xcd_affine = 0; bool xcd_affine_now = false; uint32_t xcd_bnd_tiles = 0; DevBuf<uint32_t> d_xcd;      // XCD-affine sub-orders of the ORDINARY kernel (RTS_XCD_AFFINE = 0, the default / 1 / auto; rts_post.hip: rts_tile_order_build) -- measured slower, DESIGN.md section 5
     uint32_t post_prio = 3;             // s_setprio of k_post_all's waves (RTS_POST_PRIO = 0 .. 3)
+    uint64_t post_one_max = 1024;       // ... when the handle's previous pulse received at most this many rays (RTS_POST_ONE_MAX); above it the seven launches are faster
     bool post_one = true;               // rts_trace_pulse_end_uniform: ONE kernel for order + expand + finalise + cube + aggregation of a small received set (RTS_POST_ONE=0: seven)
     bool post_small = true;             // received sets of up to 4096 rays are ordered / finished by single blocks (RTS_POST_SMALL=0: the general chain)
     hipStream_t tstream_now = nullptr; bool trace_own_stream = true;      // the stream this pulse's trace kernel went to (rts_trace_pulse_begin; RTS_TRACE_OWN_STREAM=0: always the trace stream)
