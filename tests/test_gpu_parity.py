@@ -798,6 +798,20 @@ def test_dealt_tile_lists_equal_whole(rts, scenes):
         mo, wo = np.argsort(merged["min_ray"]), np.argsort(g_whole["min_ray"])         # (the order of a group table is not part of the contract: responses are emitted by representative ray)
         assert np.array_equal(merged["min_ray"][mo], g_whole["min_ray"][wo]) and np.array_equal(merged["n"][mo], g_whole["n"][wo])
         np.testing.assert_allclose(merged["sum_sqrt_power"][mo], g_whole["sum_sqrt_power"][wo], rtol=1e-12)
+    # a list inside a SUB-RANGE of the lattice (ragged: the range neither starts at 0 nor ends on a tile boundary): tile t of the list is
+    # launch indices [first + t tile, first + (t + 1) tile) cut at the range's end
+    first, count, tile = 3 * 4096 + 64, n // 2 + 37, 256
+    n_plan = (count + tile - 1) // tile
+    ids = np.sort(rng.choice(n_plan, n_plan // 3, replace=False)).astype(np.uint32)
+    if ids[-1] != n_plan - 1: ids = np.append(ids, np.uint32(n_plan - 1))          # (the partial last tile of the range included)
+    tr.set_tile_list(tile, ids)
+    _, st = H.gpu_trace(rts, spec, tr=tr, ray_first=first, ray_count=count, interleave=(tile, api.INTERLEAVE_LIST, 0))
+    assert st["rays"] == int(sum(min(tile, count - int(i) * tile) for i in ids))
+    got = tr.received()
+    rel = whole["slots"].astype(np.int64) - first
+    keep = (rel >= 0) & (rel < count) & np.isin(np.clip(rel, 0, None) // tile, ids.astype(np.int64))
+    assert np.array_equal(got["slots"], whole["slots"][keep]) and np.array_equal(got["path"], whole["path"][keep])
+    H.assert_prd_equal(got["results"], whole["results"][keep], "a dealt list inside a sub-range")
     # a list is refused where it cannot be right, and forgotten on request
     with pytest.raises(Exception): tr.set_tile_list(100, np.array([0, 1], np.uint32))                # not a multiple of 64
     with pytest.raises(Exception): tr.set_tile_list(64, np.array([3, 3], np.uint32))                 # not ascending
