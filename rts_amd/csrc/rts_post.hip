@@ -297,49 +297,59 @@ __global__ void __launch_bounds__(256) k_tile_bucket_scatter(const uint32_t* __r
 // scans the 1 024 bins for itself instead of waiting for a one-block scan kernel.  The head decision needs the launch's balanced
 // time -- the SUM of the costs, a grid-wide quantity: the sum of the launch BEFORE (persist[0..1], written by the previous
 // build's scatter) stands in for it; pulses of an interval look alike, and only the schedule depends on it.
+// `per`: wave tiles per THREAD (1 up to 2^18 tiles).  Every block ends with one atomic on the launch's cost sum and one per non-empty bin;
+// most tiles of a pulse are dead and share ONE bin, so those are same-address atomics, ~12 ns apiece at the L2: BASELINE configs[3]'s
+// 1.57 M tiles in 6 136 blocks of 256 spent 145 us per kernel on them (configs[2]'s 616 blocks: 10 us).  Fatter blocks: never more than 1 024.
 __global__ void k_tile_merge_keys(uint32_t* __restrict__ cost, RtsTileShape cur, uint32_t* __restrict__ hist, uint32_t n_hist, unsigned long long* __restrict__ head_sum,
-                                  const unsigned long long* __restrict__ sum_before, uint32_t* __restrict__ head_count, RtsHeadRule rule, uint32_t* __restrict__ key, uint32_t* __restrict__ bucket_hist)
+                                  const unsigned long long* __restrict__ sum_before, uint32_t* __restrict__ head_count, RtsHeadRule rule, uint32_t* __restrict__ key, uint32_t* __restrict__ bucket_hist,
+                                  uint32_t per)
 {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t is_head = 0, bucket = 0; unsigned long long v64 = 0;
-    if (j < cur.n_tiles) {
-        const uint32_t v = cost[j], g = tile_global(cur, j);
-        if (v && g < n_hist) hist[g] = v;
-        cost[j] = 0u;
-        uint32_t est = v ? v : (g < n_hist ? hist[g] : 0u);
-        v64 = v & 0x3fffffffu;
-        const uint32_t c = est & 0x3fffffffu;
-        if (head_count && rule.frac > 0.0) {
-            const double balanced = (double)sum_before[0] / (double)(rule.resident_waves ? rule.resident_waves : 1u);
-            double thr = rule.frac * balanced; if (thr < (double)rule.floor_cost) thr = (double)rule.floor_cost;
-            double thr_big = rule.big * balanced; if (thr_big < (double)rule.floor_cost) thr_big = (double)rule.floor_cost;
-            is_head = rts_head_rule(est, (double)c, balanced, thr, thr_big, rule) ? 1u : 0u;
-        }
-        bucket = (is_head ? 0u : RTS_TILE_BUCKETS / 2u) + (RTS_TILE_BUCKETS / 2u - 1u) - min((uint32_t)(__log2f((float)c + 1.0f) * 16.0f), RTS_TILE_BUCKETS / 2u - 1u);
-        key[j] = bucket;
-    }
     __shared__ unsigned long long s_part[4];
     __shared__ uint32_t s_cnt[RTS_TILE_BUCKETS];
     for (uint32_t b = threadIdx.x; b < RTS_TILE_BUCKETS; b += blockDim.x) s_cnt[b] = 0u;
+    __syncthreads();
+    unsigned long long v64 = 0; uint32_t n_head_wave = 0;
+    for (uint32_t it = 0; it < per; it++) {
+        const uint32_t j = (blockIdx.x * per + it) * blockDim.x + threadIdx.x;
+        uint32_t is_head = 0;
+        if (j < cur.n_tiles) {
+            const uint32_t v = cost[j], g = tile_global(cur, j);
+            if (v && g < n_hist) hist[g] = v;
+            cost[j] = 0u;
+            uint32_t est = v ? v : (g < n_hist ? hist[g] : 0u);
+            v64 += v & 0x3fffffffu;
+            const uint32_t c = est & 0x3fffffffu;
+            if (head_count && rule.frac > 0.0) {
+                const double balanced = (double)sum_before[0] / (double)(rule.resident_waves ? rule.resident_waves : 1u);
+                double thr = rule.frac * balanced; if (thr < (double)rule.floor_cost) thr = (double)rule.floor_cost;
+                double thr_big = rule.big * balanced; if (thr_big < (double)rule.floor_cost) thr_big = (double)rule.floor_cost;
+                is_head = rts_head_rule(est, (double)c, balanced, thr, thr_big, rule) ? 1u : 0u;
+            }
+            const uint32_t bucket = (is_head ? 0u : RTS_TILE_BUCKETS / 2u) + (RTS_TILE_BUCKETS / 2u - 1u) - min((uint32_t)(__log2f((float)c + 1.0f) * 16.0f), RTS_TILE_BUCKETS / 2u - 1u);
+            key[j] = bucket;
+            atomicAdd(&s_cnt[bucket], 1u);
+        }
+        if (head_count) n_head_wave += (uint32_t)__popcll(__ballot(is_head != 0));      // (uniform per wave)
+    }
     for (int o = 32; o > 0; o >>= 1) v64 += __shfl_down(v64, o);
     if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v64;
-    if (head_count) { const unsigned long long m = __ballot(is_head != 0); if ((threadIdx.x & 63) == 0 && m) atomicAdd(head_count, (uint32_t)__popcll(m)); }
+    if (head_count && (threadIdx.x & 63) == 0 && n_head_wave) atomicAdd(head_count, n_head_wave);
     __syncthreads();
     if (threadIdx.x == 0 && head_sum) { const unsigned long long t = s_part[0] + s_part[1] + s_part[2] + s_part[3]; if (t) atomicAdd(head_sum, t); }
-    if (j < cur.n_tiles) atomicAdd(&s_cnt[bucket], 1u);
-    __syncthreads();
     for (uint32_t b = threadIdx.x; b < RTS_TILE_BUCKETS; b += blockDim.x) if (s_cnt[b]) atomicAdd(&bucket_hist[b], s_cnt[b]);
 }
-// scatter with the bins' scan inside every block: hist = the bins' COUNTS (left untouched), taken = zeroed reservation counters
+// scatter with the bins' scan inside every block: hist = the bins' COUNTS (left untouched), taken = zeroed reservation counters.  Two passes over the
+// block's `per` x 256 tiles: count per bin, reserve each bin's share with ONE atomic, then rank inside it (the order inside a bin is free)
 __global__ void __launch_bounds__(256) k_tile_scan_scatter(const uint32_t* __restrict__ bucket_of, uint32_t n, const uint32_t* __restrict__ hist, uint32_t* __restrict__ taken, uint32_t* __restrict__ order,
-                                                           const unsigned long long* __restrict__ head_sum, unsigned long long* __restrict__ sum_persist)
+                                                           const unsigned long long* __restrict__ head_sum, unsigned long long* __restrict__ sum_persist, uint32_t per)
 {
-    __shared__ uint32_t s_cnt[RTS_TILE_BUCKETS], s_base[RTS_TILE_BUCKETS], s_wave[4];
-    const uint32_t t = threadIdx.x, j = blockIdx.x * blockDim.x + t;
+    __shared__ uint32_t s_cnt[RTS_TILE_BUCKETS], s_base[RTS_TILE_BUCKETS], s_rank[RTS_TILE_BUCKETS], s_wave[4];
+    const uint32_t t = threadIdx.x;
     if (blockIdx.x == 0 && t == 0 && sum_persist) sum_persist[0] = head_sum[0];      // (complete: the keys kernel is over) the next build's "sum of the launch before"
     static_assert(RTS_TILE_BUCKETS == 4 * 256, "four bins per thread");
     const uint32_t h0 = hist[4 * t], h1 = hist[4 * t + 1], h2 = hist[4 * t + 2], h3 = hist[4 * t + 3];
     s_cnt[4 * t] = 0u; s_cnt[4 * t + 1] = 0u; s_cnt[4 * t + 2] = 0u; s_cnt[4 * t + 3] = 0u;
+    s_rank[4 * t] = 0u; s_rank[4 * t + 1] = 0u; s_rank[4 * t + 2] = 0u; s_rank[4 * t + 3] = 0u;
     uint32_t x = h0 + h1 + h2 + h3;                              // inclusive scan of the threads' sums: wave shuffle, then the four waves
     for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if ((t & 63u) >= (uint32_t)o) x += y; }
     if ((t & 63u) == 63u) s_wave[t >> 6] = x;
@@ -348,12 +358,11 @@ __global__ void __launch_bounds__(256) k_tile_scan_scatter(const uint32_t* __res
     for (uint32_t w = 0; w < (t >> 6); w++) before += s_wave[w];
     s_base[4 * t] = before; s_base[4 * t + 1] = before + h0; s_base[4 * t + 2] = before + h0 + h1; s_base[4 * t + 3] = before + h0 + h1 + h2;
     __syncthreads();
-    uint32_t b = 0, r = 0;
-    if (j < n) { b = bucket_of[j]; r = atomicAdd(&s_cnt[b], 1u); }
+    for (uint32_t it = 0; it < per; it++) { const uint32_t j = (blockIdx.x * per + it) * blockDim.x + t; if (j < n) atomicAdd(&s_cnt[bucket_of[j]], 1u); }
     __syncthreads();
     for (uint32_t q = t; q < RTS_TILE_BUCKETS; q += blockDim.x) if (s_cnt[q]) s_base[q] += atomicAdd(&taken[q], s_cnt[q]);
     __syncthreads();
-    if (j < n) order[s_base[b] + r] = j;
+    for (uint32_t it = 0; it < per; it++) { const uint32_t j = (blockIdx.x * per + it) * blockDim.x + t; if (j < n) { const uint32_t b = bucket_of[j]; order[s_base[b] + atomicAdd(&s_rank[b], 1u)] = j; } }
 }
 
 // ---- the history as a table other workers can use (rts_tile_records_get / _set: ray sharding dealt by last-seen cost)
@@ -427,8 +436,9 @@ int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_vali
         const RtsHeadRule rule2 = {c->coop_frac, c->coop_big_now, c->coop_mid, c->coop_floor, resident_waves};
         RTS_HIP(c->d_tile_key.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_order.reserve(n_tiles_cur)); RTS_HIP(c->d_xcd.reserve(64));
         unsigned long long* persist = reinterpret_cast<unsigned long long*>(c->d_xcd.p + 32);
-        k_tile_merge_keys<<<blocks_for(n_tiles_cur, 256), 256, 0, st>>>(c->d_tile_cost.p, cur2, c->d_tile_hist.p, n_hist, reinterpret_cast<unsigned long long*>(head), persist, head ? head + 2 : nullptr, rule2, c->d_tile_key.p, bins);
-        k_tile_scan_scatter<<<blocks_for(n_tiles_cur, 256), 256, 0, st>>>(c->d_tile_key.p, n_tiles_cur, bins, c->d_tile_ctr.p + RTS_OFF_COARSE, c->d_tile_order.p, reinterpret_cast<const unsigned long long*>(head), head ? persist : nullptr);
+        const uint32_t per = (n_tiles_cur + (256u << 10) - 1u) / (256u << 10), fat = blocks_for(n_tiles_cur, 256u * per);      // at most 1 024 blocks
+        k_tile_merge_keys<<<fat, 256, 0, st>>>(c->d_tile_cost.p, cur2, c->d_tile_hist.p, n_hist, reinterpret_cast<unsigned long long*>(head), persist, head ? head + 2 : nullptr, rule2, c->d_tile_key.p, bins, per);
+        k_tile_scan_scatter<<<fat, 256, 0, st>>>(c->d_tile_key.p, n_tiles_cur, bins, c->d_tile_ctr.p + RTS_OFF_COARSE, c->d_tile_order.p, reinterpret_cast<const unsigned long long*>(head), head ? persist : nullptr, per);
         RTS_HIP(hipGetLastError());
         return RTS_OK;
     }
