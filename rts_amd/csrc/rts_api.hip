@@ -886,7 +886,6 @@ extern "C" int rts_trace_pulse_end(RtsHandle c)
     c->pulse_open = false; g_open_pulses[c->device & 63]--;
     hipStream_t st = c->stream;
     const bool keep_all = (c->params.flags & RTS_FLAG_KEEP_ALL_RAYS) != 0;
-    const uint32_t n = c->n_rays;
     unsigned long long* cnt = c->pin->cnt;
     RTS_HIP(rts_stream_wait(c, st));                // the one host sync of the launch: the received count sizes what follows
     if (cnt[13]) { rts_set_error("rts_trace_pulse: %llu counter rows of the launch were never written by their blocks (counting build)", cnt[13]); return RTS_ERR_HIP; }
