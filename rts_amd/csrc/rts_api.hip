@@ -225,7 +225,7 @@ extern "C" int rts_destroy(RtsHandle c)
     c->d_verts_world.release(); c->d_normals_world.release();
     c->d_params.release();
     c->d_leaves.release(); c->d_sort_tmp.release(); c->d_rx.release(); c->d_recv.release(); c->d_all.release();
-    c->d_block_counters.release(); c->d_timeline.release(); c->d_tile_cost.release(); c->d_tile_key.release(); c->d_tile_key_sorted.release(); c->d_tile_id.release(); c->d_tile_order.release(); c->d_tile_hist.release(); c->d_tile_ctr.release(); c->d_dir_hist.release(); c->d_pmask.release(); c->d_child.release(); c->d_rk64.release(); c->d_rk64_sorted.release(); c->d_hit_prim.release(); c->d_hit_t.release(); c->d_stack_ovf.release();
+    c->d_block_counters.release(); c->d_timeline.release(); c->d_tile_cost.release(); c->d_tile_key.release(); c->d_tile_key_sorted.release(); c->d_tile_id.release(); c->d_tile_order.release(); c->d_tile_hist.release(); c->d_tile_ctr.release(); c->d_dir_hist.release(); c->d_pmask.release(); c->d_child.release(); c->d_rk64.release(); c->d_rk64_sorted.release(); c->d_hit_prim.release(); c->d_hit_t.release(); c->d_stack_ovf.release(); c->d_il_list.release(); c->d_rec_tmp.release();
     c->d_xcd.release();
     c->d_rk.release(); c->d_rk_sorted.release(); c->d_ri.release(); c->d_ri_sorted.release(); c->d_rx_rays.release(); c->d_rx_paths.release();
     c->d_rx_angles.release(); c->d_rx_slots.release(); c->d_all_rays.release(); c->d_all_paths.release(); c->d_all_angles.release();

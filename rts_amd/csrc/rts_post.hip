@@ -1392,7 +1392,6 @@ int rts_aggregate_device(RtsContext* c, int32_t max_path, int32_t max_rx, const 
         RTS_HIP(hipGetLastError());
     }
     // group table to the host: count + the first AGG_SPEC groups speculatively in one batch (pinned), rest on demand
-    RtsPinned* pin = c->pin;
     const uint32_t spec = std::min<uint32_t>(R, RTS_PIN_GROUPS);
     // (written by ONE kernel straight into the pinned block -- five small device-to-host copies per pulse before)
     k_agg_export<<<blocks_for(spec, 256), 256, 0, st>>>(d_G, gsum, c->d_gmin.p, c->d_gkey.p, d_rows ? c->d_grow.p : nullptr, spec, &c->pin_dev->G, c->pin_dev->gsum, c->pin_dev->gmin, c->pin_dev->gkey, c->pin_dev->grow);
