@@ -411,7 +411,8 @@ def test_product_trace_kernels_use_no_scratch():
             assert scratch <= 16 and vspill <= 3, (name, scratch, vspill)
         coop = flags[3]; refr = flags[2]
         if coop:
-            assert lds * 3 <= 160 * 1024 and occ >= 2, (name, lds, occ)      # the cooperative kernel: three blocks per CU
+            assert lds * 3 <= 160 * 1024 and occ >= (2 if refr else 3), (name, lds, occ)      # the cooperative kernel: three blocks per CU -- and three waves per SIMD: at 169 registers (one above
+                                                                                              # 168 = 512 / 3 in granules of 8) it ran at TWO for most of round 4, unnoticed; __launch_bounds__ now says 3
         else:
             assert lds * 4 <= 160 * 1024 and occ >= (2 if refr else 4), (name, lds, occ)      # four blocks of four waves per CU
         body = isa[isa.index("\n" + name + ":"):]
