@@ -859,7 +859,7 @@ __device__ __forceinline__ void rts_sum_counters_body(const uint32_t t, unsigned
 // kernel then starts at position n_head of the order.  A kernel of its own because the shared walk needs ~40 registers more
 // than the 128 the ordinary kernel is held to (four waves per SIMD).
 template <bool COUNT, bool KEEP_ALL, bool REFR, bool COOP, bool ASYNC = false, bool AFFINE = false>
-__global__ void __launch_bounds__(RTS_BLOCK, REFR ? 2 : (COOP ? 3 : 4)) k_trace(const RtsTraceArgs a)
+__global__ void __launch_bounds__(RTS_BLOCK, (REFR && COOP) ? 2 : ((REFR || COOP) ? 3 : 4)) k_trace(const RtsTraceArgs a)
 {
     __shared__ __attribute__((aligned(16))) int32_t s_stack[RTS_STACK_LDS * RTS_BLOCK];
     const uint32_t tid = threadIdx.x;
