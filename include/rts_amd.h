@@ -141,7 +141,8 @@ typedef struct RtsStats {
     uint64_t walked_segments;    /* segments that entered a target's hierarchy at all -- the rest were cleared by the primary-ray
                                     pre-filter or by the targets' bounding spheres (RTS_FLAG_COUNT_TRAVERSAL only)              */
     uint32_t coop_tiles;         /* wave tiles of this launch traced as cooperative units (one launch index per wave)           */
-    uint32_t reserved;
+    uint32_t cost_records_dropped;/* tiles whose duration read as nonsense and left no cost record (never, since the records are
+                                    taken on the constant-rate counter; counted, not assumed)                                    */
 } RtsStats;
 
 /* One aggregated return: what ray_tracer.cpp:1301-1321 turns into an InterpPoint/Response. */
@@ -192,6 +193,8 @@ typedef struct RtsSceneInfo {
     uint64_t shared_device_bytes;/* device memory of the shared, immutable part                              */
     uint64_t handle_device_bytes;/* device memory of this handle's placement of it (leaf records, world-space
                                     vertices and normals); per-launch buffers (rts_reserve) not included       */
+    uint64_t version_bytes;      /* of shared_device_bytes: the eight octant versions of the node records (0: the
+                                    scene has none -- RTS_NODE_VERSIONS=0, or too large for them)               */
 } RtsSceneInfo;
 int rts_scene_info(RtsHandle h, RtsSceneInfo* out);
 

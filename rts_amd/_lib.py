@@ -76,14 +76,14 @@ RTS_SHARD_PULSES, RTS_SHARD_RAYS = 0, 1
 class RtsSceneInfo(C.Structure):
     _fields_ = [("n_targets", C.c_uint32), ("n_prims", C.c_uint32), ("n_nodes", C.c_uint32), ("n_leaves", C.c_uint32),
                 ("handles_sharing", C.c_uint32), ("builder", C.c_uint32), ("build_ms", C.c_double),
-                ("shared_device_bytes", C.c_uint64), ("handle_device_bytes", C.c_uint64)]
+                ("shared_device_bytes", C.c_uint64), ("handle_device_bytes", C.c_uint64), ("version_bytes", C.c_uint64)]
 
 
 class RtsStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("segments", C.c_uint64), ("shaded", C.c_uint64), ("received", C.c_uint64),
                 ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64), ("n_prims", C.c_uint32), ("n_nodes", C.c_uint32),
                 ("ms_scene", C.c_float), ("ms_trace", C.c_float), ("ms_compact", C.c_float), ("ms_aggregate", C.c_float),
-                ("bvh_rebuilt", C.c_uint32), ("stack_overflows", C.c_uint32), ("walked_segments", C.c_uint64), ("coop_tiles", C.c_uint32), ("reserved", C.c_uint32)]
+                ("bvh_rebuilt", C.c_uint32), ("stack_overflows", C.c_uint32), ("walked_segments", C.c_uint64), ("coop_tiles", C.c_uint32), ("cost_records_dropped", C.c_uint32)]
 
 
 RESPONSE_DTYPE = np.dtype([("ray", "<u8"), ("rx", "<i4"), ("n", "<u4"), ("power", "<f8"), ("delay", "<f8"),

@@ -80,6 +80,46 @@ __global__ void k_children_to_prims(RtsNode4* __restrict__ nodes, uint32_t n, co
     for (int k = 0; k < 4; k++) { const int32_t ch = nodes[i].child[k]; nodes[i].pad[k] = ch; if (ch < 0) nodes[i].child[k] = ~(int32_t)leaf_prim[~ch]; }
 }
 
+// OCTANT VERSIONS of the node records (round 5; RtsScene::d_nodes4v, [node][octant]).  A ray's octant in a target's frame -- the
+// signs of its direction there -- is fixed for a whole walk, and two things the node step used to work out per visit depend on
+// nothing else: which plane of a child's slab the ray enters through (low when it runs towards +axis, high towards -axis: the
+// role fetch formed six per-lane addresses for that) and a good front-to-back order of the four children (the step sorted the
+// four entry distances: 5 compares + 20 selects).  Both are baked here, once per scene: version o of a node holds, per child
+// slot, [entry planes x y z | exit planes x y z | child: ~primitive, or 8 x node + o = the child's record of the same octant], the slots in ascending order of the children's position along the
+// octant's diagonal (key_mode 1, the default: the box's centre; 0: its entry corner), unused slots (degenerate box, never entered) last.
+// The trace kernel reads the record of (node, octant) straight through and visits the open children in slot order.
+// Eight times the node bytes (BASELINE configs[2]: 18 -> 145 MB, configs[3]: 185 MB -> 1.5 GB of 288 GB), of which a walk
+// touches one version only.
+__global__ void k_node_versions(const RtsNode4* __restrict__ nodes, uint32_t n, RtsNode4* __restrict__ out, int key_mode)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (node, octant)
+    if (g >= n * 8u) return;
+    const uint32_t i = g >> 3, o = g & 7u;
+    const RtsNode4 nd = nodes[i];
+    const bool mx = (o & 1u) != 0u, my = (o & 2u) != 0u, mz = (o & 4u) != 0u;      // the ray runs towards -x / -y / -z
+    float key[4]; int ord[4];
+    for (int k = 0; k < 4; k++) {
+        const float ex = mx ? -nd.hix[k] : nd.lox[k], ey = my ? -nd.hiy[k] : nd.loy[k], ez = mz ? -nd.hiz[k] : nd.loz[k];      // entry corner, along the diagonal
+        const float cx = 0.5f * (nd.lox[k] + nd.hix[k]), cy = 0.5f * (nd.loy[k] + nd.hiy[k]), cz = 0.5f * (nd.loz[k] + nd.hiz[k]);
+        const float kc = key_mode == 1 ? ((mx ? -cx : cx) + (my ? -cy : cy) + (mz ? -cz : cz)) : (ex + ey + ez);
+        key[k] = nd.child[k] == 0x7fffffff ? __builtin_inff() : kc;
+        ord[k] = k;
+    }
+    for (int a = 1; a < 4; a++)                                     // stable insertion sort of four
+        for (int b = a; b > 0 && key[ord[b]] < key[ord[b - 1]]; b--) { const int t = ord[b]; ord[b] = ord[b - 1]; ord[b - 1] = t; }
+    RtsNode4 v;
+    for (int j = 0; j < 4; j++) {
+        const int k = ord[j];
+        v.lox[j] = mx ? nd.hix[k] : nd.lox[k]; v.hix[j] = mx ? nd.lox[k] : nd.hix[k];      // lo* <- entry planes, hi* <- exit planes
+        v.loy[j] = my ? nd.hiy[k] : nd.loy[k]; v.hiy[j] = my ? nd.loy[k] : nd.hiy[k];
+        v.loz[j] = mz ? nd.hiz[k] : nd.loz[k]; v.hiz[j] = mz ? nd.loz[k] : nd.hiz[k];
+        const int32_t ch = nd.child[k];
+        v.child[j] = (ch >= 0 && ch != 0x7fffffff) ? (int32_t)(((uint32_t)ch << 3) | o) : ch;      // a node child: the index of ITS record of this octant (a walk never changes octant)
+        v.pad[j] = nd.pad[k];
+    }
+    out[g] = v;
+}
+
 // The two waits of a pulse (its trace, its post-processing): a thread blocked in hipStreamSynchronize lets its core fall
 // asleep, and every wake-up -- two per pulse, each in front of work the GPU is waiting for -- costs tens of microseconds on
 // the hosts of this pool (the C++ adapter's loop ran 0.44 ms per pulse right after a second of host-side hierarchy build had
@@ -165,6 +205,7 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     { const char* e = getenv("RTS_COOP_FRAC"); if (e) { const double v = atof(e); if (v >= 0) c->coop_frac = v; } }                  // 0: no cooperative units; tests: tiny values put every tile at the head
     { const char* e = getenv("RTS_COOP_FLOOR"); if (e) c->coop_floor = (uint32_t)std::max(0, atoi(e)); }
     c->debug_coop = getenv("RTS_DEBUG_COOP") != nullptr;
+    { const char* e = getenv("RTS_WALK_VERSIONS"); if (e) c->node_versions = e[0] != '0'; }      // (per handle: RTS_NODE_VERSIONS decides whether the scene HAS versions, this whether the handle walks them)
     { const char* e = getenv("RTS_SUM_IN_KERNEL"); if (e) c->sum_in_kernel = atoi(e) != 0; }
     { const char* e = getenv("RTS_SPIN_WAIT"); if (e) c->spin_wait = atoi(e) != 0; }
     { const char* e = getenv("RTS_ORDER_FUSED"); if (e) c->order_fused = atoi(e) != 0; }
@@ -398,6 +439,19 @@ extern "C" int rts_set_scene(RtsHandle c, const RtsMesh* meshes, uint32_t n_targ
     // the record's unused words for rts_get_bvh.  A third of the per-pulse leaf refresh and of the leaf bytes on C3 (300 k slots
     // for 100 k triangles), and of the 240 MB per handle on BASELINE configs[3].
     if (ns->n_nodes) { k_children_to_prims<<<(ns->n_nodes + 255) / 256, 256, 0, c->stream>>>(ns->d_nodes4.p, ns->n_nodes, ns->d_leaf_prim.p); RTS_HIP(hipGetLastError()); RTS_HIP(hipStreamSynchronize(c->stream)); }
+    {   // the octant versions of the node records (k_node_versions): RTS_NODE_VERSIONS=0: none; they need 1 KB per node -- a scene whose
+        // versions would not fit a quarter of the device's free memory goes without (the kernel then walks d_nodes4 as before)
+        const char* e = getenv("RTS_NODE_VERSIONS"); const bool want = !(e && e[0] == '0');
+        const char* km = getenv("RTS_VERSION_KEY"); const int key_mode = (km && strcmp(km, "corner") == 0) ? 0 : 1;      // (measured, profiles/r05a_versions_ab.log: by centre the dense control visits 5.9 % more nodes than the sorted walk, by entry corner 9.6 %)
+        size_t free_b = 0, total_b = 0; (void)hipMemGetInfo(&free_b, &total_b);
+        const size_t need = (size_t)ns->n_nodes * 8 * sizeof(RtsNode4);
+        if (want && ns->n_nodes && ns->n_nodes < (1u << 28) && need < free_b / 4) {
+            if (ns->d_nodes4v.reserve((size_t)ns->n_nodes * 8) == hipSuccess) {
+                k_node_versions<<<(ns->n_nodes * 8u + 255u) / 256u, 256, 0, c->stream>>>(ns->d_nodes4.p, ns->n_nodes, ns->d_nodes4v.p, key_mode);
+                RTS_HIP(hipGetLastError()); RTS_HIP(hipStreamSynchronize(c->stream));
+            } else (void)hipGetLastError();
+        }
+    }
     ns->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build0).count();
 
     // ---- swap it in
@@ -451,7 +505,7 @@ extern "C" int rts_scene_info(RtsHandle c, RtsSceneInfo* out)
     memset(out, 0, sizeof(*out));
     out->n_targets = (uint32_t)sc->meshes.size(); out->n_prims = sc->n_prims; out->n_nodes = sc->n_nodes; out->n_leaves = sc->n_leaves;
     out->handles_sharing = (uint32_t)sc->refs.load(); out->builder = sc->builder; out->build_ms = sc->build_ms;
-    out->shared_device_bytes = sc->device_bytes();
+    out->shared_device_bytes = sc->device_bytes(); out->version_bytes = sc->d_nodes4v.cap * sizeof(RtsNode4);
     out->handle_device_bytes = c->d_leaves.cap * sizeof(RtsLeafTri) + c->d_verts_world.cap * 8 + c->d_normals_world.cap * 8 + c->d_params.cap;
     return RTS_OK;
 }
@@ -784,7 +838,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
         RTS_HIP(hipMemsetAsync(c->d_hit_t.p, 0, sizeof(float) * (size_t)n * (c->params.max_refl + 1), st));
     }
     a.pmask = lc.mask.n ? pmask : nullptr; a.pre_filter = pre_filter ? 1u : 0u;
-    a.nodes4 = c->scene->d_nodes4.p; a.stack_lds = c->stack_lds; a.leaves = c->d_leaves.p; a.tri_nidx = c->scene->d_tri_nidx.p; a.normals = c->d_normals_world.p;
+    a.nodes4 = c->scene->d_nodes4.p; a.nodes4v = (c->node_versions && !c->async_idle0) ? c->scene->d_nodes4v.p : nullptr; a.stack_lds = c->stack_lds; a.leaves = c->d_leaves.p; a.tri_nidx = c->scene->d_tri_nidx.p; a.normals = c->d_normals_world.p;
     a.targets = c->p_targets; a.rx = c->d_rx.p;
     a.recv_records = c->d_recv.p; a.all_records = c->d_all.p; a.counters = c->p_counters; a.block_counters = c->d_block_counters.p; a.dir_hist = c->d_dir_hist.p;
     a.hit_prim = c->d_hit_prim.p; a.hit_t = c->d_hit_t.p; a.stack_ovf = c->d_stack_ovf.p; a.child = c->d_child.p;
@@ -871,7 +925,8 @@ static void rts_pulse_account(RtsContext* c, const unsigned long long* cnt)
     RtsStats& s = c->stats;
     s.rays = n; s.segments = cnt[1]; s.shaded = cnt[2]; s.received = cnt[0]; s.node_visits = cnt[3]; s.tri_tests = cnt[4]; s.stack_overflows = (uint32_t)cnt[5];
     s.n_prims = c->scene->n_prims; s.n_nodes = c->scene->n_nodes;
-    s.walked_segments = cnt[11]; s.reserved = 0;
+    s.walked_segments = cnt[11]; s.cost_records_dropped = (uint32_t)cnt[12];
+    if (c->debug_coop && (cnt[12] || cnt[14])) fprintf(stderr, "[rts] clocks: %llu cost records dropped; shader clock ran backwards on %llu tiles (XCC mask 0x%llx)\n", cnt[12], cnt[14], cnt[15]);
     s.coop_tiles = c->last_coop_grid ? (uint32_t)std::min<unsigned long long>(std::min<unsigned long long>(cnt[7], (n + RTS_WTILE - 1) / RTS_WTILE), 16384ull) : 0u;      // (the bounds k_trace applies to the order's head count)
     c->pre_dense = 2 * s.shaded > (uint64_t)n;                      // next launch of this handle: pre-filter only if most launch indices hit nothing
     s.ms_scene = s.ms_trace = s.ms_compact = s.ms_aggregate = 0;
@@ -1083,6 +1138,7 @@ static int rts_spec_resolve(RtsContext* c)
     RTS_HIP(hipSetDevice(c->device));
     const unsigned long long* cnt = c->pin->cnt;
     RTS_HIP(rts_stream_wait(c, c->stream));
+    if (cnt[13]) { rts_set_error("rts_trace_pulse: %llu counter rows of the launch were never written by their blocks (counting build)", cnt[13]); return RTS_ERR_HIP; }      // (as rts_trace_pulse_end does: ADVICE r4)
     if (cnt[6]) { rts_set_error("rts_trace_pulse: traversal stack overflow / malformed BVH guard tripped on %llu waves", cnt[6]); return RTS_ERR_HIP; }
     c->n_recv = cnt[0]; c->n_head_hint = (uint32_t)cnt[7];
     c->recv_hint = cnt[0]; c->recv_hint_valid = true;                   // (the next pulse's choices -- speculate at all, one kernel or seven -- follow THIS pulse's count, not the handle's first)

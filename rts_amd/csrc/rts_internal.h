@@ -160,6 +160,7 @@ struct RtsTraceArgs {
     RtsChildState* child;           // [2][grid threads] (refraction only)
     // scene
     const RtsNode4* nodes4;
+    const RtsNode4* nodes4v;        // != null: the eight OCTANT VERSIONS of every node record, [node][octant] (k_node_versions, rts_api.hip): the ordinary kernel walks these
     const RtsLeafTri* leaves;
     const uint32_t* tri_nidx;       // [n_prims][3] indices into normals
     const double* normals;          // world-space normals [.][3]
@@ -177,7 +178,7 @@ struct RtsTraceArgs {
     uint32_t total_threads;         // threads of the ordinary kernel's grid
     uint32_t slab_threads;          // row length of the per-thread slabs (stack_ovf, child): total_threads + the cooperative kernel's threads
     const uint32_t* tile_order;     // [wave tiles] tile ids in descending order of the cost last seen by the handle (null: identity)
-    uint32_t* tile_cost;            // [wave tiles] out: duration of the tile (shader clocks >> 6, + 1)
+    uint32_t* tile_cost;            // [wave tiles] out: duration of the tile (units of 8/3 ticks of the 100 MHz counter = 64 shader clocks at 2.4 GHz, + 1)
     uint32_t* tile_ctr;             // the zero block: draw counters (element s * RTS_TILE_CTR_STRIDE; the cooperative kernel's at RTS_OFF_CTR_COOP), zero at launch
     uint32_t coop_spread;           // 1, 2, 4 or 8: XCD lists a head tile's 64 cooperative units are dealt to (rts_trace.hip)
     const uint32_t* xcd_seg;        // != null: XCD-affine sub-orders -- [RTS_XCD + 1] first position of each band's segment in tile_order (the last entry: its end)
@@ -249,13 +250,14 @@ struct RtsScene {
     DevBuf<double> d_verts_local, d_normals_local;
     std::vector<RtsBlasInfo> blas; uint32_t n_nodes = 0, n_leaves = 0;
     DevBuf<RtsNode4> d_nodes4; DevBuf<uint32_t> d_leaf_prim;
+    DevBuf<RtsNode4> d_nodes4v;     // [n_nodes][8] octant versions of d_nodes4 (empty: none -- RTS_NODE_VERSIONS=0, or the scene too large for them)
     double build_ms = 0; uint32_t builder = 0;     // how long the hierarchy build took, and where it ran (0 host SAH, 1 device LBVH)
     size_t device_bytes() const {
         return d_tri_vidx.cap * 4 + d_tri_nidx.cap * 4 + d_vert_targ.cap * 4 + d_norm_targ.cap * 4 + d_prim_targ.cap * 4 + d_verts_local.cap * 8 +
-               d_normals_local.cap * 8 + d_nodes4.cap * sizeof(RtsNode4) + d_leaf_prim.cap * 4;
+               d_normals_local.cap * 8 + (d_nodes4.cap + d_nodes4v.cap) * sizeof(RtsNode4) + d_leaf_prim.cap * 4;
     }
     void release() { d_tri_vidx.release(); d_tri_nidx.release(); d_vert_targ.release(); d_norm_targ.release(); d_prim_targ.release();
-                     d_verts_local.release(); d_normals_local.release(); d_nodes4.release(); d_leaf_prim.release(); }
+                     d_verts_local.release(); d_normals_local.release(); d_nodes4.release(); d_nodes4v.release(); d_leaf_prim.release(); }
 };
 
 #define RTS_SMALL_CAP32 4096u         // received rays the one-block ordering kernels take with 32-bit sort keys (rts_post.hip) ...
@@ -335,6 +337,7 @@ struct RtsContext {
     DevBuf<double> d_gsum; DevBuf<uint32_t> d_gmin; DevBuf<uint64_t> d_gkey; DevBuf<uint32_t> d_gcount; DevBuf<uint64_t> d_grow; DevBuf<int32_t> d_gpath;
     DevBuf<double> d_delay, d_phase; DevBuf<int32_t> d_pathmatch; DevBuf<double> d_rcs;
     std::vector<RtsGroup> groups; bool agg_valid = false; uint64_t recv_index_base = 0;
+    bool node_versions = true;          // the ordinary trace kernel walks the octant versions of the node records when the scene has them (RTS_NODE_VERSIONS=0: the role fetch + sorting network)
     bool debug_coop = false;            // RTS_DEBUG_COOP: one line per launch on stderr (grids, head hint, thresholds)
     bool sum_in_kernel = false;         // the launch's last block sums the block counters (RTS_SUM_IN_KERNEL=1) instead of k_sum_counters -- measured SLOWER, off: the ticket's
                                         // release / acquire fences (one per block) write back and invalidate L2, and the post-processing behind the trace took 0.40 instead of 0.34 ms

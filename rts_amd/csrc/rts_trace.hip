@@ -78,6 +78,9 @@ __device__ __forceinline__ RtsSlabRay rts_slab_setup(const dvec3& o, const dvec3
 // the backend does not track vector-memory loads issued from inline asm and the hardware has no interlock on a VGPR with a
 // load in flight, so nothing the compiler might place (a copy, a spill of q0..q6) may come between the loads and the wait.
 typedef unsigned int rts_u32x4 __attribute__((ext_vector_type(4)));
+// byte address of an LDS word for ds_* instructions written by hand
+typedef __attribute__((address_space(3))) int32_t rts_lds_i32;
+__device__ __forceinline__ uint32_t rts_lds_addr(int32_t* p) { return (uint32_t)(uintptr_t)(rts_lds_i32*)p; }
 // Loads: q0..q2 <- N planes x, y, z (record + 0 / 16 / 32 + offset), q3..q5 <- F planes (record + 0 / 16 / 32 + 48 - offset),
 // q6 <- the child ids (record + 96); q5, q6 for the lanes at nodes only.  A lane at a leaf reads its record straight through
 // (offsets 0: nm = 0).
@@ -164,12 +167,26 @@ __device__ __attribute__((noinline)) int rts_stack_below_spilled(int from_lds, i
 // child boxes / the triangle, update the stack and the closest hit.
 #define RTS_STACK_SENTINEL 0x7fffffff
 #define RTS_SEG_ONE 0x00400001u      // one traced segment in the per-lane LDS counter: launch total (bits 0-21) and current tile (bits 22-31)
-template <bool COUNT, bool ROLES = true>      // ROLES: the fetch delivers entry / exit planes (lr by role); else low / high planes (lr by plane, rts_slab_by_plane)
+// MODE (how a node record reaches the lane, and in which order its children are visited):
+//   RTS_WALK_ROLES     the role fetch above (entry / exit planes by per-axis address offsets), children sorted by entry distance;
+//   RTS_WALK_PLANES    the record read straight through (low / high planes; lr by plane, rts_slab_by_plane), children sorted -- the cooperative kernel's;
+//   RTS_WALK_VERSIONS  the record of the ray's OCTANT (a.nodes4v: eight versions per node, written once per scene by k_node_versions,
+//                      rts_api.hip) read straight through: its planes are already entry / exit planes for every ray of that octant and its
+//                      children are already in front-to-back order along the octant's diagonal -- no address arithmetic per axis, no
+//                      sorting network (5 compares + 20 selects of the node step), no +inf selects.  The ORDER only decides what gets
+//                      pruned, never the result: every child whose slab interval is open is visited in either scheme, and the closest hit
+//                      is the minimum over (f32 t, primitive id) whatever the order.
+#define RTS_WALK_ROLES 0
+#define RTS_WALK_PLANES 1
+#define RTS_WALK_VERSIONS 2
+template <bool COUNT, int MODE = RTS_WALK_ROLES>
 __device__ __forceinline__ void rts_walk_step(const RtsTraceArgs& a, int32_t* s_stack, uint32_t tid, uint32_t gtid, int lds_cap, uint32_t* n_spill_lds,
                                               int& node, int& sp, const RtsSlabRay& lr, const dvec3& prev, const dvec3& dir, float tmin,
                                               float& best_t, int& best_leaf, uint32_t& best_prim, float& t_prune,
                                               uint32_t& n_nodes, uint32_t& n_tris, bool& hard_overflow)
 {
+    constexpr bool ROLES = MODE != RTS_WALK_PLANES;      // lr holds the constants by role (entry / exit)
+    constexpr bool VERS = MODE == RTS_WALK_VERSIONS;
     const bool deep = __any(sp + 4 > lds_cap);                  // wave-uniform: some lane is about to leave the LDS part
     int below = s_stack[min(sp - 1, lds_cap - 1) * RTS_BLOCK + tid];      // (always an LDS read: a second, global source here made the compiler fold both into one FLAT load)
     if (deep) below = rts_stack_below_spilled(below, sp, lds_cap, a.stack_ovf, a.slab_threads, gtid);
@@ -178,9 +195,10 @@ __device__ __forceinline__ void rts_walk_step(const RtsTraceArgs& a, int32_t* s_
     // issued together at the top of the step, so a wave whose lanes are at nodes AND at leaves waits for
     // ONE memory round trip (as if / else bodies the leaf loads could only be issued after the node body).
     const bool at_node = node >= 0;
-    const void* rp = at_node ? static_cast<const void*>(a.nodes4 + node) : static_cast<const void*>(a.leaves + ~node);
+    // (VERS: a node id IS the index of its record in a.nodes4v -- 8 node + octant; the children a version names carry that version's octant)
+    const void* rp = at_node ? static_cast<const void*>(VERS ? a.nodes4v + node : a.nodes4 + node) : static_cast<const void*>(a.leaves + ~node);
     rts_u32x4 q0, q1, q2, q3, q4, q5, q6;
-    if (ROLES) rts_fetch_record(rp, node, at_node ? 48u : 0u, lr.iNx, lr.iNy, lr.iNz, q0, q1, q2, q3, q4, q5, q6);
+    if (MODE == RTS_WALK_ROLES) rts_fetch_record(rp, node, at_node ? 48u : 0u, lr.iNx, lr.iNy, lr.iNz, q0, q1, q2, q3, q4, q5, q6);
     else rts_fetch_record_plain(rp, node, q0, q1, q2, q3, q4, q5, q6);
     if (at_node) {
         // BVH4 node: six dwordx4 planes (lo/hi x,y,z of the four children) + the four child ids
@@ -191,16 +209,65 @@ __device__ __forceinline__ void rts_walk_step(const RtsTraceArgs& a, int32_t* s_
         const int4 CH = make_int4((int)q6.x, (int)q6.y, (int)q6.z, (int)q6.w);
         if (COUNT) n_nodes++;
         const float INF = __builtin_inff();
-#define RTS_CHILD(k, dk) float dk; { \
+#define RTS_CHILD(k, dk) float dk, tn##dk, tf##dk; { \
             const float nx = __builtin_fmaf(NX.k, lr.iNx, lr.cNx), fx = __builtin_fmaf(FX.k, lr.iFx, lr.cFx); \
             const float ny = __builtin_fmaf(NY.k, lr.iNy, lr.cNy), fy = __builtin_fmaf(FY.k, lr.iFy, lr.cFy); \
             const float nz = __builtin_fmaf(NZ.k, lr.iNz, lr.cNz), fz = __builtin_fmaf(FZ.k, lr.iFz, lr.cFz); \
             const float tn = ROLES ? fmaxf(fmaxf(fmaxf(nx, ny), nz), 0.0f) : fmaxf(fmaxf(fminf(nx, fx), fminf(ny, fy)), fmaxf(fminf(nz, fz), 0.0f)); \
             const float tf = ROLES ? fminf(fminf(fminf(fx, fy), fz), t_prune) : fminf(fminf(fmaxf(nx, fx), fmaxf(ny, fy)), fminf(fmaxf(nz, fz), t_prune)); \
-            dk = (tn <= tf) ? tn : INF; }
+            tn##dk = tn; tf##dk = tf; dk = VERS ? 0.0f : ((tn <= tf) ? tn : INF); }
         RTS_CHILD(x, d0) RTS_CHILD(y, d1) RTS_CHILD(z, d2) RTS_CHILD(w, d3)
 #undef RTS_CHILD
         int c0 = CH.x, c1 = CH.y, c2 = CH.z, c3 = CH.w;
+        if (VERS) {
+            // children 0 .. 3 are in visiting order already: push the open ones last-first, go on with the first open one (which
+            // need not be child 0: the open children are no prefix of an order that was fixed before the ray was known)
+            if (!deep) {
+                // per child: store it at the top, then  open = tn <= tf (VCC);  top = open ? child : top;  sp += open (carry in) -- four
+                // vector instructions and one LDS store, the compare's mask never leaves VCC (as C++ the compiler forms all four masks
+                // first: eight more scalar registers live through the step, and 0 / 1 selects + adds for the stack pointer).  Child 0:
+                // node = open ? child 0 : top;  sp += open - 1 (closed: the top of the stack -- the entry just pushed, or `below`).
+                // (the LDS stores of one wave complete in order: the next step's read of `below` sees them)
+                uint32_t ad_; int top_, nd_;
+                asm volatile("v_lshl_add_u32 %[ad], %[sp], 10, %[base]\n\t"
+                             "ds_write_b32 %[ad], %[c3]\n\t"
+                             "v_cmp_le_f32 vcc, %[n3], %[f3]\n\t"
+                             "v_cndmask_b32 %[top], %[below], %[c3], vcc\n\t"
+                             "v_addc_co_u32 %[sp], vcc, 0, %[sp], vcc\n\t"
+                             "v_lshl_add_u32 %[ad], %[sp], 10, %[base]\n\t"
+                             "ds_write_b32 %[ad], %[c2]\n\t"
+                             "v_cmp_le_f32 vcc, %[n2], %[f2]\n\t"
+                             "v_cndmask_b32 %[top], %[top], %[c2], vcc\n\t"
+                             "v_addc_co_u32 %[sp], vcc, 0, %[sp], vcc\n\t"
+                             "v_lshl_add_u32 %[ad], %[sp], 10, %[base]\n\t"
+                             "ds_write_b32 %[ad], %[c1]\n\t"
+                             "v_cmp_le_f32 vcc, %[n1], %[f1]\n\t"
+                             "v_cndmask_b32 %[top], %[top], %[c1], vcc\n\t"
+                             "v_addc_co_u32 %[sp], vcc, 0, %[sp], vcc\n\t"
+                             "v_cmp_le_f32 vcc, %[n0], %[f0]\n\t"
+                             "v_cndmask_b32 %[nd], %[top], %[c0], vcc\n\t"
+                             "v_addc_co_u32 %[sp], vcc, -1, %[sp], vcc"
+                             : [sp] "+v"(sp), [top] "=&v"(top_), [ad] "=&v"(ad_), [nd] "=v"(nd_)
+                             : [base] "v"(rts_lds_addr(s_stack + tid)), [below] "v"(below), [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [c3] "v"(c3),
+                               [n0] "v"(tnd0), [f0] "v"(tfd0), [n1] "v"(tnd1), [f1] "v"(tfd1), [n2] "v"(tnd2), [f2] "v"(tfd2), [n3] "v"(tnd3), [f3] "v"(tfd3)
+                             : "vcc", "memory");
+                node = nd_;
+            } else {
+                // (the compares at their uses: formed ahead of the branch, the four masks were eight scalar registers live through the step)
+#define RTS_PUSH(cv) { if (sp < lds_cap) s_stack[sp * RTS_BLOCK + tid] = (cv); \
+                       else if (sp < lds_cap + RTS_STACK_OVF) { a.stack_ovf[(size_t)(sp - lds_cap) * a.slab_threads + gtid] = (cv); atomicAdd(n_spill_lds, 1u); } \
+                       else hard_overflow = true; \
+                       if (sp < lds_cap + RTS_STACK_OVF) sp++; }
+                int top = below;
+                if (tnd3 <= tfd3) { RTS_PUSH(c3) top = c3; }
+                if (tnd2 <= tfd2) { RTS_PUSH(c2) top = c2; }
+                if (tnd1 <= tfd1) { RTS_PUSH(c1) top = c1; }
+#undef RTS_PUSH
+                if (tnd0 <= tfd0) node = c0;
+                else { node = top; sp--; }
+            }
+            return;
+        }
         // sort the four (distance, child) pairs ascending (5 compare-exchanges); misses carry +inf
         // (measured, not kept: the compare into an SGPR pair and four VOP3 selects written by hand, because a probe --
         // tools/cndmask_probe.hip -- shows v_cndmask_b32 reading VCC at ~22 cycles each when several follow one compare, against
@@ -292,7 +359,7 @@ __device__ __forceinline__ void rts_walk_coop(const RtsTraceArgs& a, int32_t* s_
         bool improved = false;
         if (node != SENTINEL) {
             const float before = t_prune;
-            rts_walk_step<COUNT, false>(a, s_stack, tid, gtid, lds_cap, n_spill_lds, node, sp, lp, prev, dir, tmin, best_t, best_leaf, best_prim, t_prune, n_nodes, n_tris, hard_overflow);
+            rts_walk_step<COUNT, RTS_WALK_PLANES>(a, s_stack, tid, gtid, lds_cap, n_spill_lds, node, sp, lp, prev, dir, tmin, best_t, best_leaf, best_prim, t_prune, n_nodes, n_tris, hard_overflow);
             improved = t_prune != before;
         }
         if (__any(improved)) t_prune = rts_wave_min_f32(t_prune);
@@ -591,7 +658,7 @@ __device__ __forceinline__ void rts_primary_setup(const RtsTraceArgs& a, const R
     rayLength = 0; power = 0; doppler = 0;
 }
 
-template <bool COUNT, bool KEEP_ALL, bool REFR, bool COOP>
+template <bool COUNT, bool KEEP_ALL, bool REFR, bool COOP, bool VERS = false>
 __device__ __forceinline__ void rts_trace_unit(const RtsTraceArgs& a, const RtsLaunchConsts& lc, const RtsUnitLds& L_, const uint32_t tid, const uint32_t gtid, const uint32_t lane,
                                                const uint32_t slot, const bool pre_on, const bool mask_on, const uint32_t D, const uint32_t max_refr, const dvec3& origin,
                                                uint32_t& n_nodes, uint32_t& n_tris, bool& hard_overflow, unsigned long long (&lane_stats)[4],
@@ -658,6 +725,9 @@ __device__ __forceinline__ void rts_trace_unit(const RtsTraceArgs& a, const RtsL
                     const dvec3 ol = mk3(TG.rinv[0]*q.x + TG.rinv[1]*q.y + TG.rinv[2]*q.z, TG.rinv[3]*q.x + TG.rinv[4]*q.y + TG.rinv[5]*q.z, TG.rinv[6]*q.x + TG.rinv[7]*q.y + TG.rinv[8]*q.z);
                     const dvec3 dl = mk3(TG.rinv[0]*dir.x + TG.rinv[1]*dir.y + TG.rinv[2]*dir.z, TG.rinv[3]*dir.x + TG.rinv[4]*dir.y + TG.rinv[5]*dir.z, TG.rinv[6]*dir.x + TG.rinv[7]*dir.y + TG.rinv[8]*dir.z);
                     const RtsSlabRay lr = rts_slab_setup(ol, dl, TG.ew);
+                    // (VERS) the ray's octant in the target's frame: bit k = the ray runs towards -axis k = the sign of its entry reciprocal,
+                    // the rule by which the role fetch picks the entry plane (a dropped axis has iN = +0: either plane will do)
+                    const uint32_t oct = VERS ? ((__float_as_uint(lr.iNx) >> 31) | ((__float_as_uint(lr.iNy) >> 31) << 1) | ((__float_as_uint(lr.iNz) >> 31) << 2)) : 0u;
                     // Traversal stack: entry e of lane `tid` lives at s_stack[e * RTS_BLOCK + tid] for e < stack_lds and in the
                     // global slab above that.  Entry 0 holds a sentinel, so "pop" never needs an emptiness test and the walk
                     // ends when the sentinel comes off.  The common step is branch free: the entry a lane falls back to
@@ -672,12 +742,13 @@ __device__ __forceinline__ void rts_trace_unit(const RtsTraceArgs& a, const RtsL
                     } else {
                         s_stack[tid] = SENTINEL;
                         int sp = 1;
-                        int node = TG.root;
+                        int node = VERS ? (int)(((uint32_t)TG.root << 3) | oct) : TG.root;
                         uint32_t wave_steps = 0;                                     // (wave-uniform: a scalar register; the per-lane count is the counting build's)
                         while (node != SENTINEL) {
-                            if (++wave_steps > (1u << 24)) { hard_overflow = true; break; }   // malformed tree guard: every wave must drain
+                            wave_steps = __builtin_amdgcn_readfirstlane(wave_steps) + 1u;      // (uniform by construction; said so, or the count lives in a vector register of the walk)
+                            if (wave_steps > (1u << 24)) { hard_overflow = true; break; }   // malformed tree guard: every wave must drain
                             if (COUNT) steps++;
-                            rts_walk_step<COUNT>(a, s_stack, tid, gtid, lds_cap, &s_n[2 * RTS_BLOCK + tid], node, sp, lr, prev, dir, tmin, best_t, best_leaf, best_prim, t_prune,
+                            rts_walk_step<COUNT, VERS ? RTS_WALK_VERSIONS : RTS_WALK_ROLES>(a, s_stack, tid, gtid, lds_cap, &s_n[2 * RTS_BLOCK + tid], node, sp, lr, prev, dir, tmin, best_t, best_leaf, best_prim, t_prune,
                                                  n_nodes, n_tris, hard_overflow);
                         }
                         // the tile's walk statistics (LONG WALKS flag, k_trace): iterations the wave spent in this walk -- its slowest lane's;
@@ -706,6 +777,9 @@ __device__ __forceinline__ void rts_trace_unit(const RtsTraceArgs& a, const RtsL
         rts_write_back<KEEP_ALL, COOP>(a, L_, tid, lane, slot, chain, S, pending, refr_code0);
       }   // chain
 }
+
+// a duration on the constant-rate counter (100 MHz ticks) in the unit of the tile-cost records: 64 shader clocks at 2.4 GHz = 8/3 ticks (k_trace)
+#define RTS_COST_UNITS(ticks) (((unsigned long long)(ticks) * 3ULL) >> 3)
 
 // ASYNCHRONOUS BOUNCES (the north star's "wave-level ballot / compaction of active rays"): the same launch
 // index per lane, but the lanes of a wave no longer move from segment to segment in lock step.  In rts_trace_unit a wave walks
@@ -799,7 +873,7 @@ __device__ __forceinline__ void rts_trace_unit_async(const RtsTraceArgs& a, cons
             lr = rts_slab_setup(ol, dl, TG.ew);
         }
         const float tmin = (st & (1u << 9)) ? SCENE_EPS : SCENE_EPS_R;
-        const uint32_t age = (uint32_t)((unsigned long long)(clock64() - tile_t0) >> 6);           // (s_memtime: wave-uniform)
+        const uint32_t age = (uint32_t)RTS_COST_UNITS(wall_clock64() - tile_t0);                 // (s_memrealtime: wave-uniform)
         const uint32_t idle_limit = age >= a.async_age ? a.async_idle1 : a.async_idle0;
         // ---------------------------------------------------------------- walk
         for (;;) {
@@ -825,7 +899,7 @@ __device__ __forceinline__ void rts_sum_counters_body(const uint32_t t, unsigned
 #define RTS_LD64(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
     if (t == 7) { const unsigned long long h = head_count ? (unsigned long long)__hip_atomic_load(head_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL; counters[7] = h; host_cnt[7] = h; }     // the order's head count travels home with the counters (sizes the next cooperative grid)
     if (t == 0) host_cnt[0] = RTS_LD64(&counters[0]);                          // received rays (appended by the trace kernels)
-    if (t >= 8 && t <= 11) host_cnt[t] = RTS_LD64(&counters[t]);               // lane statistics and walked segments of the counting build
+    if ((t >= 8 && t <= 12) || t == 14 || t == 15) host_cnt[t] = RTS_LD64(&counters[t]);      // lane statistics and walked segments of the counting build; [12] cost records dropped, [14] / [15] tiles / XCCs on which the shader clock ran backwards
     const unsigned int k = t & 7u, lane = t >> 3;                              // 32 partial sums per counter
     unsigned long long v = 0;
     // (counting builds poison the rows before the launch -- rts_trace_launch -- : a row no block wrote is COUNTED, counters[13], instead
@@ -858,7 +932,7 @@ __device__ __forceinline__ void rts_sum_counters_body(const uint32_t t, unsigned
 // history): it traces the 64 n_head launch indices of the tiles at the head of the cost order, one per wave; the ordinary
 // kernel then starts at position n_head of the order.  A kernel of its own because the shared walk needs ~40 registers more
 // than the 128 the ordinary kernel is held to (four waves per SIMD).
-template <bool COUNT, bool KEEP_ALL, bool REFR, bool COOP, bool ASYNC = false, bool AFFINE = false>
+template <bool COUNT, bool KEEP_ALL, bool REFR, bool COOP, bool ASYNC = false, bool AFFINE = false, bool VERS = false>
 __global__ void __launch_bounds__(RTS_BLOCK, (REFR && COOP) ? 2 : ((REFR || COOP) ? 3 : 4)) k_trace(const RtsTraceArgs a)
 {
     __shared__ __attribute__((aligned(16))) int32_t s_stack[RTS_STACK_LDS * RTS_BLOCK];
@@ -1069,16 +1143,27 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR && COOP) ? 2 : ((REFR || COOP
           }
           pre = 1u | (pre_target ? 2u : 0u) | (pre_rx ? 4u : 0u);
       }
-      const long long tile_t0 = clock64();
+      // Tile durations on the CONSTANT-RATE counter (wall_clock64 = s_memrealtime, 100 MHz), scaled to the old unit -- 64 shader clocks at
+      // 2.4 GHz = 26.7 ns = 8/3 ticks -- so that every threshold kept its meaning (RTS_COST_UNITS).  Rounds 2-4 timed tiles with clock64()
+      // (s_memtime, the shader clock counter), and on gfx950 that counter does not only tick: with three BASELINE configs[3] pulses in flight
+      // about one launch in fifteen had ~1 000 tiles -- all those open at one instant -- whose end read EARLIER than their start
+      // (profiles/r04_c4_cost_glitch.log).  The counting build still reads both and counts the tiles on which the shader clock ran
+      // backwards while the constant-rate one did not, with the XCCs they ran on (counters[14], [15]; RtsStats / RTS_DEBUG_COOP).
+      const long long tile_t0 = wall_clock64();
+      const long long tile_s0 = COUNT ? clock64() : 0;
       if (!COOP) atomicAnd(&s_n[tid], 0x003fffffu);              // (ds_and_b32: the tile's own segment count starts at zero; a register for it would be the 129th)
       if (!COOP && !ASYNC && lane == 0) { const uint32_t z_ = RTS_OPAQUE_S(0u); s_walk[2u * wave_u] = z_; s_walk[2u * wave_u + 1u] = z_; }      // (an opaque zero: hoisted out of the tile loop as a register pair the constant was parked in SCRATCH and reloaded per tile)
       const unsigned long long tl_tile = (COUNT && a.timeline && lane == 0) ? wall_clock64() : 0ULL;
       if (slot < a.n_rays) {
           if (ASYNC) rts_trace_unit_async<COUNT, KEEP_ALL>(a, lc, ul, tid, gtid, lane, slot, pre_on, mask_on, D, origin, tile_t0, n_nodes, n_tris, hard_overflow, lane_stats);
-          else rts_trace_unit<COUNT, KEEP_ALL, REFR, COOP>(a, lc, ul, tid, gtid, lane, slot, pre_on, mask_on, D, max_refr, origin, n_nodes, n_tris, hard_overflow, lane_stats, pre);
+          else rts_trace_unit<COUNT, KEEP_ALL, REFR, COOP, VERS>(a, lc, ul, tid, gtid, lane, slot, pre_on, mask_on, D, max_refr, origin, n_nodes, n_tris, hard_overflow, lane_stats, pre);
       }   // slot < n_rays
       // (the segment count of the tile is only formed for tiles long enough to matter: an all-miss tile is ~100 instructions)
-      const unsigned long long dt = (unsigned long long)(clock64() - tile_t0) >> 6;             // (s_memtime: wave-uniform)
+      const unsigned long long dt = RTS_COST_UNITS(wall_clock64() - tile_t0);                     // (s_memrealtime: wave-uniform)
+      if (COUNT && !COOP && lane == 0 && clock64() - tile_s0 < 0) {                               // the shader clock ran backwards over this tile
+          uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+          atomicAdd(&a.counters[14], 1ULL); atomicOr(&a.counters[15], 1ULL << (xcc & 7u));
+      }
       bool long_walks = false, longish_walks = false;
       if (!COOP && !ASYNC && a.tile_cost && dt >= a.coop_min_cost) {      // (the asynchronous-bounce experiment keeps no walk statistics: it flags nothing)
           // LONG WALKS: the tile's bounce rounds took a.coop_walk_steps walk iterations of the wave on average -- rays that graze along a surface
@@ -1103,6 +1188,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR && COOP) ? 2 : ((REFR || COOP
           // clamped to the field's maximum they made the launch's cost sum 1 000 x too large, the head rule of the handle's next order
           // found no tile above half THAT balanced time, and a BASELINE configs[3] pulse went without its cooperative kernel: 13 ms
           // instead of 8.5, profiles/r04_c4_cost_glitch.log.  Such a tile leaves no record; the history keeps what it had.)
+          if (a.tile_cost && dt >= (1ULL << 26)) atomicAdd(&a.counters[12], 1ULL);      // (cannot happen on the constant-rate counter; counted -- RtsStats::cost_records_dropped -- instead of assumed)
           if (a.tile_cost && dt < (1ULL << 26)) {
               if (COOP) { atomicAdd(&a.tile_cost[tile], (unsigned int)(dt > 0x00fffffeULL ? 0x00fffffeULL : dt) + 1u); if ((vpos & 63u) == 0u) atomicOr(&a.tile_cost[tile], 0x80000000u); }
               else a.tile_cost[tile] = ((unsigned int)(dt > 0x3ffffffeULL ? 0x3ffffffeULL : dt) + 1u) | (long_walks ? 0x80000000u : 0u) | (longish_walks ? 0x40000000u : 0u);
@@ -1184,6 +1270,19 @@ static void rts_trace_dispatch(const RtsTraceArgs& a, bool count_traversal, unsi
             case 1: k_trace<true, false, false, false, true><<<grid, RTS_BLOCK, 0, st>>>(a); break;
             case 2: k_trace<false, true, false, false, true><<<grid, RTS_BLOCK, 0, st>>>(a); break;
             default: k_trace<true, true, false, false, true><<<grid, RTS_BLOCK, 0, st>>>(a); break;
+        }
+        return;
+    }
+    if (!COOP && a.nodes4v) {                                    // octant versions of the node records (ordinary lock-step kernel)
+        switch (sel) {
+            case 0: k_trace<false, false, false, false, false, false, true><<<grid, RTS_BLOCK, 0, st>>>(a); break;
+            case 1: k_trace<true, false, false, false, false, false, true><<<grid, RTS_BLOCK, 0, st>>>(a); break;
+            case 2: k_trace<false, true, false, false, false, false, true><<<grid, RTS_BLOCK, 0, st>>>(a); break;
+            case 3: k_trace<true, true, false, false, false, false, true><<<grid, RTS_BLOCK, 0, st>>>(a); break;
+            case 4: k_trace<false, false, true, false, false, false, true><<<grid, RTS_BLOCK, 0, st>>>(a); break;
+            case 5: k_trace<true, false, true, false, false, false, true><<<grid, RTS_BLOCK, 0, st>>>(a); break;
+            case 6: k_trace<false, true, true, false, false, false, true><<<grid, RTS_BLOCK, 0, st>>>(a); break;
+            default: k_trace<true, true, true, false, false, false, true><<<grid, RTS_BLOCK, 0, st>>>(a); break;
         }
         return;
     }

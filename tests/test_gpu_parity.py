@@ -1214,6 +1214,67 @@ def test_cooperative_units_are_invisible(rts, oracle, scenes, monkeypatch):
         # triangles than ... nothing is guaranteed either way; what IS: both found the same closest hits (above)
 
 
+def test_octant_versions_are_invisible(rts, oracle, scenes, monkeypatch):
+    """round 5: the ordinary trace kernel walks the OCTANT VERSIONS of the node records (k_node_versions, rts_api.hip: per node eight
+    records whose planes are entry / exit planes for a ray of that octant and whose children sit in front-to-back order along the
+    octant's diagonal -- no sorting network, no per-axis fetch addresses; k_trace<.., VERS>).  The visiting ORDER only decides what
+    is pruned: every output buffer must be the same bits with the versions walked (the default) and with the role fetch + sorted
+    children (RTS_WALK_VERSIONS=0) -- KEEP_ALL + counting builds and the product build, refraction, the LDS stack cut to 3 entries
+    (the versions' deep-stack branch), Earth-centred coordinates, both sort keys of the versions (centre, the default / entry corner), a rotated
+    target (the octant is taken in the TARGET's frame); and the versions' launch against the oracle's brute force"""
+    import math
+    c3 = scenes.config3(W=56, detail=0.3, rx_radius=300.0)
+    multi = scenes.config_multi(W=44)
+    refr = dict(scenes.config_multi(W=42, max_refl=2), max_refr=1)
+    refr["meshes"] = [dict(m, refl_coeff=0.6, refr_index=1.5) for m in refr["meshes"]]
+    refr["rx"] = refr["rx"] + [scenes._rx_at((200.0, 0.0, 0.0), (0, 0, 0), 90.0, 2.6)]
+    yaw = 0.9; cy, sy = math.cos(yaw), math.sin(yaw)
+    turned = dict(c3, motion=[dict(m, rotation=(cy, -sy, 0.0, sy, cy, 0.0, 0.0, 0.0, 1.0)) for m in c3["motion"]])
+    cases = [("c3", c3, {}), ("c3 ecef", scenes.translate(c3, scenes.ecef_offset(lat=math.pi / 2)), {}), ("multi", multi, {}), ("refraction", refr, {}),
+             ("c3 short stack", c3, {"RTS_STACK_LDS_DEBUG": "3"}), ("miss branches", scenes.config_miss_branches(W=44), {}),
+             ("c3 corner key", c3, {"RTS_VERSION_KEY": "corner"}), ("c3 turned", turned, {})]
+    for name, spec, env in cases:
+        n = spec["W"] ** 3
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("RTS_WALK_VERSIONS", mode)
+            tr = H.gpu_tracer(rts, spec, keep_all=True, count_traversal=True)
+            tp = H.gpu_tracer(rts, spec)                                        # the product build
+            assert tr.scene_info()["version_bytes"] > 0, name                   # (the scene HAS versions either way: the handle decides whether to walk them)
+            for rep in range(2):                                                # (the second launch has a cost order)
+                _, st = H.gpu_trace(rts, spec, tr=tr); _, sp = H.gpu_trace(rts, spec, tr=tp)
+            out[mode] = (tr.all_rays(n * (spec["max_refl"] + 3 if spec.get("max_refr", 0) else 1)), tr.received(), st, tp.received(), sp)
+            tr.close(); tp.close()
+        for k in env:
+            monkeypatch.delenv(k)
+        (a, ra, sa, pa, spa), (b, rb, sb, pb, spb) = out["0"], out["1"]
+        if name == "c3":
+            c3_received = pb
+        _all_equal(a, b, name)
+        for x, y, what in ((ra, rb, "counting build"), (pa, pb, "product build"), (ra, pb, "product vs counting")):
+            assert np.array_equal(x["slots"], y["slots"]) and np.array_equal(x["path"], y["path"]), (name, what)
+            H.assert_prd_equal(x["results"], y["results"], "%s (received, %s)" % (name, what))
+            assert x["rcs_angle"].tobytes() == y["rcs_angle"].tobytes(), (name, what)
+        assert (sa["segments"], sa["shaded"], sa["received"], sa["walked_segments"]) == (sb["segments"], sb["shaded"], sb["received"], sb["walked_segments"]), name
+        assert (spa["segments"], spa["shaded"], spa["received"]) == (spb["segments"], spb["shaded"], spb["received"]) == (sb["segments"], sb["shaded"], sb["received"]), name
+        assert sa["received"] > 0 and sb["tri_tests"] >= sb["shaded"] > 0, name
+        # the fixed order prunes a little less well than the sorted one: a few per cent more node visits are the price of the step
+        assert sb["node_visits"] <= 1.25 * sa["node_visits"] and sb["tri_tests"] <= 1.25 * sa["tri_tests"], (name, sa["node_visits"], sb["node_visits"], sa["tri_tests"], sb["tri_tests"])
+        if name in ("multi", "refraction", "c3 turned"):
+            rows = spec["max_refl"] + 3 if spec.get("max_refr", 0) else 1
+            o = H.oracle_trace(oracle, spec, use_bvh=False, threads=8)
+            H.compare_full(o, b, n * rows)
+            assert sb["segments"] == o["counters"]["segments"] and sb["shaded"] == o["counters"]["shaded"], name
+    monkeypatch.setenv("RTS_NODE_VERSIONS", "0")                           # a scene WITHOUT versions: the handle walks the plain records
+    tr = H.gpu_tracer(rts, c3)
+    assert tr.scene_info()["version_bytes"] == 0
+    _, st = H.gpu_trace(rts, c3, tr=tr)
+    H.assert_prd_equal(tr.received()["results"], c3_received["results"], "a scene built without versions")
+    tr.close()
+
+
 def test_small_received_sets_one_block_path_is_invisible(rts, scenes, monkeypatch):
     """up to 4 096 received rays (2 048 where a sort key needs 64 bits) the ordering of the received set and the aggregation run as single-block kernels
     (k_recv_order_small, k_agg_order_small, k_agg_finish_small) instead of the chain of device-wide sorts and scans
@@ -1331,6 +1392,7 @@ def test_xcd_affine_sub_orders_are_invisible(rts, oracle, scenes, monkeypatch):
     c3 = scenes.config3(W=80, detail=0.3, rx_radius=300.0)
     tx = c3["tx"]; n_all = c3["W"] ** 3
     out = {}
+    monkeypatch.setenv("RTS_WALK_VERSIONS", "0")      # (the experiment exists for the sorted walk only; the counts below are compared step for step)
     for mode in ("0", "1"):
         monkeypatch.setenv("RTS_XCD_AFFINE", mode)
         for count in (False, True):
@@ -1483,6 +1545,7 @@ def test_asynchronous_bounces_are_invisible(rts, scenes, monkeypatch):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         out = {}
+        monkeypatch.setenv("RTS_WALK_VERSIONS", "0")      # (the asynchronous schedule exists for the sorted walk only; its counts are compared step for step with the lock-step kernel's)
         for mode in ("0", "64", "8", "1"):
             monkeypatch.setenv("RTS_ASYNC_IDLE0", mode); monkeypatch.setenv("RTS_ASYNC_IDLE1", "1" if mode == "64" else mode if mode != "0" else "1"); monkeypatch.setenv("RTS_ASYNC_AGE", "40")
             tr = H.gpu_tracer(rts, spec, keep_all=True, count_traversal=True)

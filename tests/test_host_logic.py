@@ -402,8 +402,8 @@ def test_product_trace_kernels_use_no_scratch():
         seen += 1
         scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1)); vspill = int(re.search(r"VGPRs Spill: (\d+)", b).group(1))
         lds = int(re.search(r"LDS Size \[bytes/block\]: (\d+)", b).group(1)); occ = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1))
-        flags = [q == "1" for q in re.findall(r"Lb([01])", name.split("EEv")[0])]      # k_trace<COUNT, KEEP_ALL, REFR, COOP, ASYNC, AFFINE>
-        assert len(flags) == 6, name
+        flags = [q == "1" for q in re.findall(r"Lb([01])", name.split("EEv")[0])]      # k_trace<COUNT, KEEP_ALL, REFR, COOP, ASYNC, AFFINE, VERS>
+        assert len(flags) == 7, name
         async_k = flags[4]
         if async_k:
             assert scratch <= 64 and vspill <= 16, (name, scratch, vspill)
@@ -441,7 +441,7 @@ def test_product_trace_kernels_use_no_scratch():
                 else:
                     assert not in_loop, (name, t)
         assert fetch_blocks >= 1 and asm_loads == 0, (name, fetch_blocks, asm_loads)     # every asm load group ends in its own wait
-    assert seen == 11      # 4 ordinary + 4 cooperative + 2 asynchronous + 1 XCD-affine product instantiations
+    assert seen == 15      # 4 ordinary (role fetch) + 4 ordinary (octant versions) + 4 cooperative + 2 asynchronous + 1 XCD-affine product instantiations
 
 
 def test_fuzz_generator_versions_are_frozen(rts):

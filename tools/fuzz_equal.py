@@ -208,6 +208,10 @@ def main():
             d = run(spec, device_build=False, pre_filter=False)
             os.environ.pop("RTS_SPLIT_BUDGET", None)
             same(a, b, "seed %d: pre-filter on / off" % seed)
+            os.environ["RTS_WALK_VERSIONS"] = "0"                    # round 5: the default walks the octant versions of the node records; here the role fetch + sorted children
+            g = run(spec); g2 = run(spec, device_build=False, pre_filter=False) if seed % 2 else run(spec, count_traversal=True)
+            os.environ.pop("RTS_WALK_VERSIONS", None)
+            same(a, g, "seed %d: octant versions / sorted walk" % seed); same(a, g2, "seed %d: octant versions / sorted walk (second way)" % seed)
             e = run(spec, count_traversal=True); f = run(spec, count_traversal=True, pre_filter=False)     # counting builds: is the filter doing anything?
             same(a, e, "seed %d: counting build" % seed); same(a, f, "seed %d: counting build, no pre-filter" % seed)
             assert e[2]["tri_tests"] <= f[2]["tri_tests"] and e[2]["node_visits"] <= f[2]["node_visits"], (seed, e[2], f[2])       # (the filter only ever REMOVES visits)
