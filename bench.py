@@ -18,13 +18,20 @@ aggregation into the pulse's responses.  A "ray" in Mrays/s is one traced segmen
 or bounce).  Pulses are independent, so each GPU keeps --inflight of them in flight on as many handles.  All of that is
 inside the timed region; ms_per_step is wall time / pulses.
 
-N > 1 ranks (one process per GPU): WEAK scaling by default -- every rank runs --steps pulses, the interval is N x steps pulses
-(pulses are independent, ray_tracer.cpp:843; no collective in the data path), a step = one pulse on every rank, value = the
-segments all ranks traced / the slowest rank's time; --scaling strong deals ONE interval of --steps pulses to the ranks.
-Sharding over N ranks (--shard): "pulses" (default) deals the pulses of the interval to the ranks whole, left-over
-pulses in interleaved tiles (rts_plan_cpi); "rays" splits EVERY pulse over all ranks in interleaved 4096-index tiles.
-Either way the per-(receiver, path) group tables are exchanged once per interval (one all-gather over RCCL) and the
-complex return cube is summed once (one all-reduce), both inside the timed region.
+N > 1 ranks (one process per GPU): STRONG scaling is the line's `value` -- ONE interval of --steps pulses shared by the N ranks
+(BASELINE.json's north star: "rays shard ... RCCL reduce ... strong-scaling efficiency"), `ms_per_step` = the interval's wall time /
+--steps.  How it is shared (--shard auto): every pulse split over all ranks by RAYS (tiles dealt longest-first from the cost records
+of the warm-up interval, rts_deal_tiles; interleaved 4096-index tiles until there are records) when the ranks would otherwise get
+fewer than 4 x --inflight whole pulses each AND a rank's part of a pulse is at least 4 M launch indices; else whole PULSES are dealt
+(left-over pulses in interleaved tiles, rts_plan_cpi).  The second condition is this file's, not VERDICT r4's: an eighth of a
+configs[2] pulse is 0.08 ms of tracing against a 0.07 ms empty launch and ~15 launches around it, so ray-sharding THAT workload
+measures launch overhead -- its pulses are dealt whole, and a rank's two or three of them overlap in flight.
+Either way the per-(receiver, path) group tables are exchanged once per interval (one all-gather over RCCL) and the complex return
+cube is summed once (one all-reduce), both inside the timed region.  The same job then measures, outside that region and reported
+as secondary blocks: `weak` -- every rank --steps whole pulses (an N x steps interval; per-GPU work as at N = 1, no collective in the
+data path) -- and `n1` -- rank 0 ALONE tracing the strong interval's --steps pulses while the others wait at a barrier --, from
+which `efficiency_vs_n1` = value / (N x n1.value): the line is self-contained.  (--scaling weak makes the weak interval the
+headline, as round 4 did.)
 
 roofline: the trace kernel moves ~150 MB of HBM per launch against >10 GB of cache-served traversal bytes, so HBM is not
 its bound (reported as secondary fields).  What binds is instruction issue: `bound` names the busier of the two per-CU
@@ -180,12 +187,17 @@ def main():
     ap.add_argument("--config", default="c3", choices=["c2", "c2file", "c3", "c3ecef", "c3ico", "c4", "c5", "sphere6"], help="c3 = BASELINE configs[2] (the metric's workload); c4 = configs[3]'s scene and size (100 M launch indices per pulse: give --steps 32; --tx both: its two transmitters in turn); c5 = configs[4]: the C3 airframe re-rotated AND translated every pulse, 1024-pulse interval (give --steps 1024), the transmitter tracking it; sphere6 = the scene of the C++ boundary benchmark (tests/adapter/adapter_bench.cpp)")
     ap.add_argument("--tx", default="0", choices=["0", "1", "both"], help="c4: which of configs[3]'s two transmitters; both = the first half of the interval's pulses from transmitter 0, the second half from transmitter 1 (the reference's transmitter loop is the outer one, ray_tracer.cpp:806)")
     ap.add_argument("--as-rank", default="", help="debug, one process: 'r/N' runs the plan rank r of N ranks would run (with --shard rays: its part of EVERY pulse), without a process group -- one GPU's share of a ray-sharded interval at the pipelined rate, every r in turn gives the critical path of an N-GPU run; value / ms_per_step are that rank's alone")
-    ap.add_argument("--deal", default="interleave", choices=["interleave", "cost"], help="--shard rays: 'cost' = after the warm-up pulses (traced as interleaved parts) the ranks exchange what every tile cost the rank that traced it (ONE all-reduce of a uint32 per 64 launch indices, outside the timed interval: it belongs to the previous interval), adopt the merged table as their tile history and trace the timed interval's pulses as tile lists dealt longest-first from it (rts_deal_tiles, rts_set_tile_list) instead of the static interleave.  With --as-rank the table comes from two whole pulses traced by this process (standing in for the other ranks)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="N > 1: 'weak' (default) = every rank runs --steps pulses, the interval is N x steps pulses (a step = one pulse on every rank; value = what all ranks traced / time; per-GPU work fixed as N grows -- pulses are independent, ray_tracer.cpp:843, and there is no collective in the data path); 'strong' = ONE interval of --steps pulses dealt to the ranks (a 20-pulse interval over 8 ranks is 2-3 pulses per rank: pipeline fill and drain, not scaling)")
-    ap.add_argument("--shard", default="pulses", choices=["pulses", "rays"], help="N > 1: deal whole pulses to the ranks, or split every pulse over all ranks (interleaved tiles)")
+    ap.add_argument("--deal", default="auto", choices=["auto", "interleave", "cost"], help="auto = cost for a multi-rank job, interleave with --as-rank.  --shard rays: 'cost' = after the warm-up pulses (traced as interleaved parts) the ranks exchange what every tile cost the rank that traced it (ONE all-reduce of a uint32 per 64 launch indices, outside the timed interval: it belongs to the previous interval), adopt the merged table as their tile history and trace the timed interval's pulses as tile lists dealt longest-first from it (rts_deal_tiles, rts_set_tile_list) instead of the static interleave.  With --as-rank the table comes from two whole pulses traced by this process (standing in for the other ranks)")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"], help="N > 1: which interval is the line's value.  'strong' (default, the north star's) = ONE interval of --steps pulses shared by the ranks; 'weak' = every rank runs --steps pulses, the interval is N x steps pulses (per-GPU work fixed as N grows -- pulses are independent, ray_tracer.cpp:843, and there is no collective in the data path).  The other one, and rank 0 alone on the strong interval, are measured by the same job and reported as secondary blocks")
+    ap.add_argument("--shard", default="auto", choices=["auto", "pulses", "rays"], help="N > 1, the strong interval: deal whole pulses to the ranks, or split every pulse over all ranks; auto: rays when a rank would get fewer than 4 x --inflight whole pulses and its part of a pulse is >= 4 M launch indices (see the top of this file)")
+    ap.add_argument("--no-secondary", action="store_true", help="N > 1: skip the secondary intervals (weak / strong counterpart and rank 0 alone)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks")
     args = ap.parse_args()
 
+    # stdout carries the JSON line and nothing else: whatever a library prints there (RCCL's version banner under torch.distributed.run
+    # made profiles/r04_bench_rccl_world1.json unparsable) goes to stderr from here on; the line is written to the saved descriptor
+    sys.stdout.flush()
+    real_stdout = os.dup(1); os.dup2(2, 1)
     import torch
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -262,14 +274,32 @@ def main():
     if args.tx == "1":
         tx = spec["tx_list"][1]
     two_tx = args.tx == "both"
-    n_int = args.steps * (world if args.scaling == "weak" else 1)     # pulses of the timed interval (weak scaling: --steps per rank) ...
-    n_warm = args.warmup * (world if args.scaling == "weak" else 1)   # ... and of the warm-up
-    half = (n_int + 1) // 2                                       # --tx both: pulses [0, half) of transmitter 0, then [0, n_int - half) of transmitter 1
+    plan_rank, plan_world = (int(args.as_rank.split("/")[0]), int(args.as_rank.split("/")[1])) if args.as_rank else (rank, world)
+    if args.as_rank and (world != 1 or not 0 <= plan_rank < plan_world or args.shard == "pulses"):
+        raise SystemExit("--as-rank r/N needs a single process, 0 <= r < N and --shard rays")
+    RAY_SHARD_MIN = 4_000_000                                     # launch indices of a rank's part of a pulse below which ray sharding measures launch overhead (top of this file)
+
+    def resolve_shard(n_pulses, w):
+        if args.as_rank:
+            return "rays"
+        if args.shard != "auto":
+            return args.shard
+        return "rays" if (w > 1 and n_pulses < 4 * max(args.inflight, 1) * w and total // w >= RAY_SHARD_MIN) else "pulses"
+
+    # the interval being run: the closures below read it (strong / weak / rank 0 alone differ in these five things only)
+    cur = dict(n_int=args.steps * (world if (args.scaling == "weak" and world > 1) else 1), n_warm=args.warmup * (world if (args.scaling == "weak" and world > 1) else 1),
+               rank=plan_rank, world=plan_world, shard=None, collectives=True)
+    cur["shard"] = resolve_shard(cur["n_int"], plan_world) if args.scaling == "strong" or args.as_rank else ("pulses" if args.shard == "auto" else args.shard)
+    deal_mode = args.deal if args.deal != "auto" else ("interleave" if args.as_rank else "cost")
+    n_int, n_warm = cur["n_int"], cur["n_warm"]
+
+    def half_of():
+        return (cur["n_int"] + 1) // 2                            # --tx both: pulses [0, half) of transmitter 0, then [0, n_int - half) of transmitter 1
 
     def tx_of(k_rel, motion):
         """transmitter of the interval's k_rel-th pulse; a configuration with tx_track aims the boresight at the (first) target's
         position of that pulse (the reference reads the transmitter's rotation per pulse, ray_tracer.cpp:888)"""
-        t = tx if not two_tx else spec["tx_list"][0 if k_rel < half else 1]
+        t = tx if not two_tx else spec["tx_list"][0 if k_rel < half_of() else 1]
         if spec.get("tx_track"):
             d = np.asarray(motion[0]["position"], np.float64) - np.asarray(t["origin"], np.float64)
             t = dict(t, dir=(math.atan2(d[1], d[0]), math.atan2(d[2], math.hypot(d[0], d[1]))))
@@ -277,13 +307,13 @@ def main():
 
     def pulse_of(k_rel):
         """pulse number (placement) of the interval's k_rel-th pulse: with two transmitters each runs through the same pulses"""
-        return k_rel if not two_tx or k_rel < half else k_rel - half
+        return k_rel if not two_tx or k_rel < half_of() else k_rel - half_of()
 
     # --inflight handles take the pulses in turn; they SHARE one copy of the immutable scene (hierarchy built once)
     trs = []
     t_scene0 = time.perf_counter()
     for i in range(max(args.inflight, 1)):
-        t = api.Tracer(W, spec["max_refl"], 0, spec["smooth"], device=local_rank)
+        t = api.Tracer(W, spec["max_refl"], 0, spec["smooth"], device=local_rank, count_traversal=bool(os.environ.get("RTS_BENCH_COUNT")))      # (RTS_BENCH_COUNT=1: the counting build in the pipelined loop -- diagnostics, e.g. RTS_DEBUG_COOP's clock check)
         if i == 0:
             t.set_scene(spec["meshes"])
         else:
@@ -299,26 +329,34 @@ def main():
     n_bins = 1024
     r0 = 2.0 * float(np.linalg.norm(np.asarray(tx["origin"], np.float64) - np.asarray(spec["motion"][0]["position"], np.float64)))
     cube_t0 = (r0 - 150.0) / spec["c"]; cube_dt = 300.0 / spec["c"] / n_bins
-    cube = torch.zeros((len(spec["rx"]), max(n_int, n_warm, 1), n_bins), dtype=torch.complex128, device="cuda")
-    for t in trs:                                              # every pulse owns one row of the cube, so the handles can share it
-        t.cube_attach(cube.shape[0], cube.shape[1], n_bins, cube_t0, cube_dt, device_ptr=cube.data_ptr())
-    n_fft = 1 << max(int(cube.shape[1]) - 1, 1).bit_length()  # range-Doppler map: zero-padded power-of-two transform over the pulse axis (rts_cube_doppler)
     has_dop = hasattr(rts_amd._lib.lib(), "rts_cube_doppler")     # (an older library named by RTS_AMD_LIB, A/B runs: torch.fft then, outside the timed region)
-    dop = torch.zeros((cube.shape[0], n_fft, n_bins), dtype=torch.complex128, device="cuda") if (n_fft <= 4096 and has_dop) else None
+    cubes = {}                                                 # one cube per interval LENGTH this job runs (strong: --steps rows, weak: N x steps): the all-reduce and the transform of an interval move its own rows only
+    cube = dop = None; n_fft = 0
 
-    plan_rank, plan_world = (int(args.as_rank.split("/")[0]), int(args.as_rank.split("/")[1])) if args.as_rank else (rank, world)
-    if args.as_rank and (world != 1 or not 0 <= plan_rank < plan_world or args.shard != "rays"):
-        raise SystemExit("--as-rank r/N needs a single process, 0 <= r < N and --shard rays")
+    def attach_cube(rows):
+        """the return cube [rx][rows][bins] of an interval of `rows` pulses, attached to every handle (each pulse owns one row, so the handles share it), and its
+        range-Doppler map: zero-padded power-of-two transform over the pulse axis (rts_cube_doppler)"""
+        nonlocal cube, dop, n_fft
+        rows = max(int(rows), 1)
+        if rows not in cubes:
+            c_ = torch.zeros((len(spec["rx"]), rows, n_bins), dtype=torch.complex128, device="cuda")
+            nf = 1 << max(rows - 1, 1).bit_length()
+            d_ = torch.zeros((c_.shape[0], nf, n_bins), dtype=torch.complex128, device="cuda") if (nf <= 4096 and has_dop) else None
+            cubes[rows] = (c_, d_, nf)
+        cube, dop, n_fft = cubes[rows]
+        for t in trs:
+            t.cube_attach(cube.shape[0], cube.shape[1], n_bins, cube_t0, cube_dt, device_ptr=cube.data_ptr())
+    attach_cube(max(n_int, n_warm))
 
     dealt = {}                                               # --deal cost: {"tile": launch indices per plan tile, "cost": every rank's share by the records} once the tile lists are set
 
     def plan(n_pulses):
         if dealt:
             return [(k, 0, total, (dealt["tile"], api.INTERLEAVE_LIST, 0)) for k in range(n_pulses)]
-        if args.shard == "rays" and plan_world > 1:
-            p = multigpu.plan_rays(total, n_pulses, plan_rank, plan_world)
+        if cur["shard"] == "rays" and cur["world"] > 1:
+            p = multigpu.plan_rays(total, n_pulses, cur["rank"], cur["world"])
         else:
-            p = multigpu.plan_cpi(total, n_pulses, plan_rank, plan_world)
+            p = multigpu.plan_cpi(total, n_pulses, cur["rank"], cur["world"])
         return multigpu.refine_plan(p, len(trs))
 
     def prepare_cpi(k0, n_pulses):
@@ -400,11 +438,12 @@ def main():
         while posted:
             collect(*posted.pop(0))
         t_a = time.perf_counter()
-        allp = multigpu.exchange_parts(parts, dist, torch)    # ONE exchange per CPI (RCCL all-gather), inside the timed region
+        cdist = dist if cur["collectives"] else None           # (rank 0 alone on the strong interval: no collective)
+        allp = multigpu.exchange_parts(parts, cdist, torch)   # ONE exchange per CPI (RCCL all-gather), inside the timed region
         t_b = time.perf_counter()
         resp = multigpu.merge_cpi(allp, spec["max_refl"])
         t_c = time.perf_counter()
-        if dist is not None:                                  # dense per-receiver return buffers: sum over the ranks
+        if cdist is not None:                                 # dense per-receiver return buffers: sum over the ranks
             if args.backend == "nccl":
                 dist.all_reduce(torch.view_as_real(cube), op=dist.ReduceOp.SUM)
             else:
@@ -422,36 +461,70 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if n_warm:
-        run_cpi(0, n_warm)
-    if args.deal == "cost" and args.shard == "rays" and plan_world > 1:
-        if args.as_rank:                                      # one process: two whole pulses stand in for what the other ranks measured
-            m0 = pulse_motion(spec, 0); x0 = tx_of(0, m0)
-            for _ in range(2):
-                trs[0].trace(x0["origin"], x0["span"], x0["dir"], m0, ray_first=0, ray_count=total)
-            table = trs[0].tile_records_get()
-        else:
-            table = multigpu.exchange_tile_records([t.tile_records_get() for t in trs], dist, torch)
-        tile_, ids_, cost_ = multigpu.dealt_tiles(table, total, plan_rank, plan_world)
-        for t in trs:
-            t.tile_records_set(table); t.set_tile_list(tile_, ids_)
-        dealt.update(tile=tile_, cost=[float(x) for x in cost_ / max(float(cost_.mean()), 1.0)], tiles_of_this_rank=int(ids_.shape[0]))
-        run_cpi(n_warm, min(n_warm, 2 * len(trs)))  # (every handle's first launch over its list: the cooperative stream, the order build of a new shape)
-    prepared = prepare_cpi(n_warm, n_int)
-    # The harness is Python: its cyclic garbage collector, once a few thousand ctypes / numpy objects have been allocated by the
-    # loop, makes full passes over everything torch imported (~40 ms each) -- measured as 0.15 ms per pulse in trace_begin at 256
-    # pulses, none at 64 (gpurun_out r04h).  Not the product's time: collected once here, then off for the timed interval.
     import gc
-    gc.collect()
-    if not os.environ.get("RTS_BENCH_GC"):                 # (RTS_BENCH_GC=1: leave the collector on -- the control run of profiles/r04_fresh_processes_gc.log)
-        gc.disable()
-    sync()
-    t0 = time.perf_counter()
-    acc, resp = run_cpi(n_warm, n_int, prepared)
-    sync()
-    dt = time.perf_counter() - t0
-    gc.enable()
-    assert len(resp) == n_int, "every pulse of the interval must come back with its responses"
+
+    def clear_deal():
+        if dealt:
+            for t in trs:
+                t.set_tile_list(0, np.zeros(0, np.uint32))
+            dealt.clear()
+
+    def timed_interval(n_int_, n_warm_, shard_, rank_, world_, collectives_=True, participate=True):
+        """warm-up + ONE timed interval under the given sharding; returns (acc, resp, seconds) -- seconds = the slowest rank's when the
+        interval uses the process group.  participate = False: this rank only keeps the barriers (rank 0 traces alone)."""
+        clear_deal()
+        cur.update(n_int=n_int_, n_warm=n_warm_, shard=shard_, rank=rank_, world=world_, collectives=collectives_)
+        attach_cube(max(n_int_, n_warm_))
+        acc_ = resp_ = None; dt_ = 0.0
+        if participate:
+            if n_warm_:
+                run_cpi(0, n_warm_)
+            if deal_mode == "cost" and shard_ == "rays" and world_ > 1:
+                if args.as_rank or not collectives_:                  # one process: two whole pulses stand in for what the other ranks measured
+                    m0 = pulse_motion(spec, 0); x0 = tx_of(0, m0)
+                    for _ in range(2):
+                        trs[0].trace(x0["origin"], x0["span"], x0["dir"], m0, ray_first=0, ray_count=total)
+                    table = trs[0].tile_records_get()
+                else:
+                    table = multigpu.exchange_tile_records([t.tile_records_get() for t in trs], dist, torch)
+                tile_, ids_, cost_ = multigpu.dealt_tiles(table, total, rank_, world_)
+                for t in trs:
+                    t.tile_records_set(table); t.set_tile_list(tile_, ids_)
+                dealt.update(tile=tile_, cost=[float(x) for x in cost_ / max(float(cost_.mean()), 1.0)], tiles_of_this_rank=int(ids_.shape[0]))
+                run_cpi(n_warm_, min(n_warm_, 2 * len(trs)))  # (every handle's first launch over its list: the cooperative stream, the order build of a new shape)
+            prepared = prepare_cpi(n_warm_, n_int_)
+            # The harness is Python: its cyclic garbage collector, once a few thousand ctypes / numpy objects have been allocated by the
+            # loop, makes full passes over everything torch imported (~40 ms each) -- measured as 0.15 ms per pulse in trace_begin at 256
+            # pulses, none at 64 (gpurun_out r04h).  Not the product's time: collected once here, then off for the timed interval.
+            gc.collect()
+            if not os.environ.get("RTS_BENCH_GC"):             # (RTS_BENCH_GC=1: leave the collector on -- the control run of profiles/r04_fresh_processes_gc.log)
+                gc.disable()
+        sync()
+        t0 = time.perf_counter()
+        if participate:
+            acc_, resp_ = run_cpi(n_warm_, n_int_, prepared)
+        sync()
+        dt_ = time.perf_counter() - t0
+        gc.enable()
+        if participate:
+            assert len(resp_) == n_int_, "every pulse of the interval must come back with its responses"
+        if dist is not None and collectives_:
+            rdev = "cuda" if args.backend == "nccl" else "cpu"
+            tt = torch.tensor([dt_], dtype=torch.float64, device=rdev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt_ = float(tt.item())
+        return acc_, resp_, dt_
+
+    def job_sums(acc_):
+        """(segments, shaded, received) over all ranks"""
+        v = [acc_["segments"], acc_["shaded"], acc_["received"]]
+        if dist is None:
+            return v
+        rdev = "cuda" if args.backend == "nccl" else "cpu"
+        ss = torch.tensor(v, dtype=torch.float64, device=rdev); dist.all_reduce(ss, op=dist.ReduceOp.SUM)
+        return [int(x) for x in ss.tolist()]
+
+    # ---- the line's interval
+    acc, resp, dt = timed_interval(n_int, n_warm, cur["shard"], plan_rank, plan_world)
+    headline = dict(scaling=args.scaling, shard=cur["shard"], n_int=n_int, deal=dict(dealt) if dealt else None)
     # range-Doppler map of the interval (slow-time FFT of the summed cube): a check of the dense product, outside the timed
     # region -- the hot path ends with the per-pulse responses and the (all-reduced) cube
     # (the transform itself ran inside the timed region, in the interval's tail: rts_cube_doppler; here it is checked against torch.fft)
@@ -459,17 +532,28 @@ def main():
     range_doppler_peak = float((dop if dop is not None else ref_rd).abs().max().item()) if args.steps > 0 else 0.0
     range_doppler_err = float((dop - ref_rd).abs().max().item() / max(float(ref_rd.abs().max().item()), 1e-300)) if dop is not None else None
     assert range_doppler_err is None or range_doppler_err < 1e-9, "rts_cube_doppler disagrees with torch.fft (%g)" % range_doppler_err
+    cube_desc = "complex128 [%d rx][%d pulses][%d bins], all-reduced once per interval, then %d-point slow-time FFT in the library (rts_cube_doppler, inside the timed region); range-Doppler peak %.6e, max deviation from torch.fft %.1e (relative)" % (cube.shape[0], cube.shape[1], n_bins, n_fft, range_doppler_peak, range_doppler_err or 0.0)
     seg = acc["segments"]; ms_trace = acc["ms_trace"]; ms_scene = acc["ms_scene"]; ms_post = acc["ms_post"]
     shaded = acc["shaded"]; received = acc["received"]; launches = max(acc["launches"], 1)
+    seg_all, shaded_all, received_all = job_sums(acc)              # whole-job aggregates (dt is already the slowest rank's)
 
-    # whole-job aggregates: max time over ranks, sum of segments
-    if dist is not None:
-        rdev = "cuda" if args.backend == "nccl" else "cpu"
-        tt = torch.tensor([dt], dtype=torch.float64, device=rdev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
-        ss = torch.tensor([seg, shaded, received], dtype=torch.float64, device=rdev); dist.all_reduce(ss, op=dist.ReduceOp.SUM)
-        seg_all, shaded_all, received_all = [int(x) for x in ss.tolist()]
-    else:
-        seg_all, shaded_all, received_all = seg, shaded, received
+    # ---- secondary intervals of a multi-rank job: the other scaling mode, and rank 0 alone on the strong interval
+    secondary = {}
+    if world > 1 and not args.no_secondary and not args.as_rank:
+        other = "weak" if args.scaling == "strong" else "strong"
+        o_int = args.steps * (world if other == "weak" else 1); o_warm = min(args.warmup, 2 * len(trs)) * (world if other == "weak" else 1)
+        o_shard = "pulses" if other == "weak" else resolve_shard(o_int, world)
+        acc_o, _, dt_o = timed_interval(o_int, o_warm, o_shard, rank, world)
+        seg_o = job_sums(acc_o)[0]
+        secondary[other] = dict(value=seg_o / dt_o / 1e6, unit="Mrays/s", ms_per_step=dt_o / args.steps * 1e3, ms_per_pulse_of_the_interval=dt_o / o_int * 1e3, pulses_in_the_interval=o_int, shard=o_shard,
+                                note=("every rank traces --steps whole pulses; ms_per_step = wall time / --steps (one pulse on every rank)" if other == "weak" else "ONE interval of --steps pulses shared by the ranks"))
+        acc_1, _, dt_1 = timed_interval(args.steps, min(args.warmup, 2 * len(trs)), "pulses", 0, 1, collectives_=False, participate=(rank == 0))
+        if rank == 0:
+            n1_value = acc_1["segments"] / dt_1 / 1e6
+            secondary["n1"] = dict(value=n1_value, unit="Mrays/s", ms_per_step=dt_1 / args.steps * 1e3,
+                                   note="rank 0 alone, the strong interval's --steps pulses, in this job after the timed region (the other ranks wait at the barrier)")
+            strong_value = (seg_all / dt / 1e6) if args.scaling == "strong" else secondary["strong"]["value"]
+            secondary["efficiency_vs_n1"] = strong_value / (world * n1_value)
 
     if rank == 0:
         # ---- un-timed measurements behind the roofline block (rank 0, after the timed region)
@@ -563,7 +647,7 @@ def main():
         out = {
             "metric": "Mrays/s (primary+bounces) & ms/pulse, 100k-tri scene",
             "value": seg_all / dt / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling if world > 1 else "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[%d]%s: %s, 1 Tx / %d Rx, W=%d (%d launch indices/pulse), maxRefl=%d, target moves every pulse (re-placed on the device per pulse; static target-space BVH4)"
                                    % ({"c3": 2, "c3ecef": 2, "c3ico": 2, "c4": 3, "c5": 4}.get(args.config, 1), " at Earth-centred coordinates" if args.config == "c3ecef" else (" (both transmitters in turn: pulses [0, %d) from Tx 0, [%d, %d) from Tx 1; a receiver's noise temperature grows by the signal's once per transmitter, ray_tracer.cpp:829 -- host side, the SOARS adapter's)" % (half, half, args.steps) if two_tx else (" -- NOT a BASELINE configuration: the scene of the C++ boundary benchmark (tests/adapter/adapter_bench.cpp)" if args.config == "sphere6" else (" (target re-rotated and translated every pulse, ray_tracer.cpp:993-1014; the transmitter's boresight tracks it)" if args.config == "c5" else ""))), spec["name"], len(spec["rx"]), W, total, spec["max_refl"]),
@@ -572,20 +656,23 @@ def main():
                        "walked_segments_per_pulse": walked_per_pulse, "walked_Mrays_per_s": walked_per_pulse * (seg_all / max(seg_serial * n_int, 1)) * n_int / dt / 1e6,
                        "walked_note": "segments that entered a target's hierarchy (counting build, one pulse); the rest of segments_per_pulse are primaries the conservative pre-filter or the bounding spheres cleared -- counted as rtTrace calls (SURVEY 8d), but bulk culling, not traversal",
                        "dense_control_Gseg_per_s": (dense or {}).get("Gseg_per_s"),
-                       "return_cube": "complex128 [%d rx][%d pulses][%d bins], all-reduced once per interval, then %d-point slow-time FFT in the library (rts_cube_doppler, inside the timed region); range-Doppler peak %.6e, max deviation from torch.fft %.1e (relative)" % (cube.shape[0], cube.shape[1], n_bins, n_fft, range_doppler_peak, range_doppler_err or 0.0),
-                       "as_rank": args.as_rank or None, "deal": (dict(dealt, how="tiles dealt longest-first from the cost records of the warm-up interval (one all-reduce), rts_deal_tiles") if dealt else "static interleave") if args.shard == "rays" and plan_world > 1 else None,
-                       "sharding": ("%d-pulse interval over %d ranks (--scaling %s: %s), --shard %s: " % (n_int, world, args.scaling, "--steps pulses per rank" if args.scaling == "weak" else "--steps pulses in all", args.shard)) + ("every pulse split over all ranks in interleaved 4096-index tiles" if args.shard == "rays" else "whole pulses, left-over pulses in interleaved 4096-index tiles") + "; one group-table all-gather + one cube all-reduce per interval",
+                       "return_cube": cube_desc,
+                       "as_rank": args.as_rank or None, "deal": (dict(headline["deal"], how="tiles dealt longest-first from the cost records of the warm-up interval (one all-reduce), rts_deal_tiles") if headline["deal"] else "static interleave") if headline["shard"] == "rays" and plan_world > 1 else None,
+                       "sharding": ("%d-pulse interval over %d ranks (--scaling %s: %s), --shard %s -> %s: " % (n_int, world, args.scaling, "--steps pulses per rank" if args.scaling == "weak" else "--steps pulses in all", args.shard, headline["shard"])) + ("every pulse split over all ranks, tiles of 4096 launch indices %s" % ("dealt longest-first from the warm-up interval's cost records" if headline["deal"] else "interleaved") if headline["shard"] == "rays" else "whole pulses, left-over pulses in interleaved 4096-index tiles") + "; one group-table all-gather + one cube all-reduce per interval",
+                       "ms_per_pulse_of_the_interval": dt / max(n_int, 1) * 1e3,
                        "host_numa_node": numa_node, "post_processing_call": "rts_trace_pulse_end_uniform" if ((args.fused_post or len(trs) == 1) and hasattr(rts_amd._lib.lib(), "rts_trace_pulse_end_uniform")) else "rts_trace_pulse_end + rts_finalise_uniform + rts_cube_accumulate + rts_aggregate", "pulses_in_flight": len(trs), "linked": bool(args.link), "scene_setup_s": scene_setup_s,
                        "interval_tail_ms_rank0": acc["tail_ms"],
                        "host_ms_per_pulse_rank0": {k: v / max(acc["launches"], 1) for k, v in acc["host_ms"].items()},
                        "stage_ms_per_launch_rank0": {"scene_placement": ms_scene / launches, "trace": ms_trace / launches, "order+finalise+aggregate": ms_post / launches}},
             "roofline": roof,
         }
+        out.update(secondary)                                       # N > 1: "weak" (or "strong"), "n1", "efficiency_vs_n1"
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(spec)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())     # the ONE line of this process's real stdout (everything else went to stderr, see main)
     if api._PY_LAP:
         print("python side of trace_begin, us per call:", {k: round(v / max(api._PY_LAP["n"], 1) * 1e6, 1) for k, v in api._PY_LAP.items() if k != "n"}, file=sys.stderr)
     for t in trs:

@@ -205,6 +205,8 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     { const char* e = getenv("RTS_COOP_FRAC"); if (e) { const double v = atof(e); if (v >= 0) c->coop_frac = v; } }                  // 0: no cooperative units; tests: tiny values put every tile at the head
     { const char* e = getenv("RTS_COOP_FLOOR"); if (e) c->coop_floor = (uint32_t)std::max(0, atoi(e)); }
     c->debug_coop = getenv("RTS_DEBUG_COOP") != nullptr;
+    { const char* e = getenv("RTS_RX_WINDOW_SCREEN"); if (e) c->rx_window_screen = e[0] != '0'; }
+    { const char* e = getenv("RTS_DEAD_BATCH"); if (e) c->batch_dead = strcmp(e, "all") == 0 ? 2 : (e[0] != '0' ? 1 : 0); }      // dead-tile batches of the trace kernel: 0 never, 1 the order's dead part (default), all: every position is screened tile-wise first (tests)
     { const char* e = getenv("RTS_WALK_VERSIONS"); if (e) c->node_versions = e[0] != '0'; }      // (per handle: RTS_NODE_VERSIONS decides whether the scene HAS versions, this whether the handle walks them)
     { const char* e = getenv("RTS_SUM_IN_KERNEL"); if (e) c->sum_in_kernel = atoi(e) != 0; }
     { const char* e = getenv("RTS_SPIN_WAIT"); if (e) c->spin_wait = atoi(e) != 0; }
@@ -847,6 +849,8 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
         const uint32_t n_tiles = (n + RTS_WTILE - 1) / RTS_WTILE;
         const uint64_t sig[4] = {n, first, ((uint64_t)il_parts << 32) | il_tile, il_part};
         const bool aligned = first % RTS_WTILE == 0 && (il_parts <= 1 || il_tile % RTS_WTILE == 0);
+        a.rx_window_screen = c->rx_window_screen ? 1u : 0u;
+        a.batch_dead = aligned ? (uint32_t)c->batch_dead : 0u;      // (a wave tile must be 64 CONSECUTIVE launch indices for the tile-level screen: rts_tile_maybe)
         const uint32_t n_hist = (uint32_t)((total + RTS_WTILE - 1) / RTS_WTILE);
         RTS_HIP(c->d_tile_ctr.reserve(RTS_ZERO_WORDS + RTS_MASK_WORDS + 64)); c->p_counters = reinterpret_cast<unsigned long long*>(c->d_tile_ctr.p + RTS_OFF_COUNTERS); a.counters = c->p_counters;
         a.tile_ctr = c->d_tile_ctr.p;
@@ -860,6 +864,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
                 int rc = rts_tile_order_build(c, c->tile_cost_sig, c->tile_cost_pending, sig, n_tiles, grid * (RTS_BLOCK / RTS_WTILE)); if (rc != RTS_OK) return rc;
                 a.xcd_seg = c->xcd_affine_now ? c->d_xcd.p : nullptr;
                 a.tile_order = c->d_tile_order.p; a.tile_head = c->coop_frac > 0.0 ? c->d_tile_ctr.p + RTS_OFF_HEAD + 2 : nullptr; a.tile_head_all = a.tile_head; c->tile_hist_any = true;
+                a.tile_live = c->d_tile_ctr.p + RTS_OFF_LIVE;      // (written by the order build when it counts bins; else it stays at the fill's 0 = unknown)
             }
             const bool merged_all = c->tile_cost_pending && (c->tile_cost_sig[0] + RTS_WTILE - 1) / RTS_WTILE >= n_tiles && c->d_tile_cost.cap >= n_tiles;      // k_tile_merge read AND cleared the records
             RTS_HIP(c->d_tile_cost.reserve(n_tiles));
@@ -950,7 +955,8 @@ extern "C" int rts_trace_pulse_end(RtsHandle c)
         unsigned long long sums[2] = {0, 0};
         (void)hipMemcpy(&sums[0], c->d_xcd.p + 32, sizeof(unsigned long long), hipMemcpyDeviceToHost);
         (void)hipMemcpy(&sums[1], c->d_tile_ctr.p + RTS_OFF_HEAD, sizeof(unsigned long long), hipMemcpyDeviceToHost);
-        fprintf(stderr, "[rts] end: handle %p head count %llu coop grid %u | cost sum persisted %llu, this build's %llu\n", (void*)c, cnt[7], c->last_coop_grid, sums[0], sums[1]);
+        uint32_t live_w = 0; (void)hipMemcpy(&live_w, c->d_tile_ctr.p + RTS_OFF_LIVE, sizeof(uint32_t), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[rts] end: handle %p head count %llu coop grid %u | cost sum persisted %llu, this build's %llu | live word %u of %u tiles\n", (void*)c, cnt[7], c->last_coop_grid, sums[0], sums[1], live_w, (c->n_rays + RTS_WTILE - 1) / RTS_WTILE);
         if (c->tile_cost_pending && c->d_tile_cost.p) {          // the cost records this launch wrote (merged by the next order build)
             const uint32_t nt = (uint32_t)((c->tile_cost_sig[0] + RTS_WTILE - 1) / RTS_WTILE);
             std::vector<uint32_t> h(nt);

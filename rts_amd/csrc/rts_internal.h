@@ -92,7 +92,8 @@ static_assert(sizeof(RtsChildState) == 128, "child state size");
 // sum lo, hi, head count, ticket | the launch's 16 u64 counters | the order's bins | the coarse cost cells]
 #define RTS_OFF_CTR_COOP (RTS_TILE_CTRS_LAYOUT * RTS_TILE_CTR_STRIDE)
 #define RTS_OFF_HEAD (2 * RTS_TILE_CTRS_LAYOUT * RTS_TILE_CTR_STRIDE)
-#define RTS_OFF_COUNTERS (RTS_OFF_HEAD + 4)
+#define RTS_OFF_LIVE (RTS_OFF_HEAD + 4)       // 1 + the number of tiles at the front of this launch's order that cost more than a dead tile (0: unknown) -- written by the order build (rts_post.hip)
+#define RTS_OFF_COUNTERS (RTS_OFF_HEAD + 8)
 #define RTS_OFF_BINS (RTS_OFF_COUNTERS + 32)
 #define RTS_OFF_COARSE (RTS_OFF_BINS + RTS_TILE_BUCKETS)
 #define RTS_ZERO_WORDS (RTS_OFF_COARSE + RTS_COARSE_CELLS)
@@ -184,6 +185,9 @@ struct RtsTraceArgs {
     const uint32_t* xcd_seg;        // != null: XCD-affine sub-orders -- [RTS_XCD + 1] first position of each band's segment in tile_order (the last entry: its end)
     const uint32_t* tile_head;      // [1] number of tiles at the head of tile_order that are traced as 64 cooperative units (null: none)
     const uint32_t* tile_head_all;  // the same word whether or not this launch has a cooperative kernel (read back with the counters)
+    const uint32_t* tile_live;      // != null: [1 + tiles at the front of tile_order that cost more than a dead tile last time] (0: unknown); the order behind them is drawn 64 tiles at a time, one LANE per tile (k_trace: dead-tile batches)
+    uint32_t rx_window_screen;      // 1: the pre-filter also asks whether a crossing of a capture sphere can lie in the receiver's angular window (RTS_RX_WINDOW_SCREEN=0: only whether the sphere is reached)
+    uint32_t batch_dead;            // 0: never batch; 1: batch the order's dead region (needs tile_live); 2: every position goes through the tile-level test first (RTS_DEAD_BATCH=all: tests)
     uint32_t* done_ctr; uint32_t n_blocks_all; unsigned long long* host_cnt;      // the last block of the launch (ticket from done_ctr, zero at launch) sums the block counters and writes them home
     uint32_t async_idle0, async_idle1, async_age;   // asynchronous bounces (rts_trace_unit_async): idle-lane limit of a walk phase for young / old tiles (0: lock-step kernel), age in cost units
     uint32_t coop_walk_steps_lo;    // ... bit 30 of the record: >= this many (LONGISH WALKS; the head rule asks more of such a tile's cost, rts_post.hip)
@@ -337,6 +341,8 @@ struct RtsContext {
     DevBuf<double> d_gsum; DevBuf<uint32_t> d_gmin; DevBuf<uint64_t> d_gkey; DevBuf<uint32_t> d_gcount; DevBuf<uint64_t> d_grow; DevBuf<int32_t> d_gpath;
     DevBuf<double> d_delay, d_phase; DevBuf<int32_t> d_pathmatch; DevBuf<double> d_rcs;
     std::vector<RtsGroup> groups; bool agg_valid = false; uint64_t recv_index_base = 0;
+    bool rx_window_screen = true;       // RTS_RX_WINDOW_SCREEN
+    int batch_dead = 1;                 // dead-tile batches of the trace kernel (RTS_DEAD_BATCH = 0 / 1 / all)
     bool node_versions = true;          // the ordinary trace kernel walks the octant versions of the node records when the scene has them (RTS_NODE_VERSIONS=0: the role fetch + sorting network)
     bool debug_coop = false;            // RTS_DEBUG_COOP: one line per launch on stderr (grids, head hint, thresholds)
     bool sum_in_kernel = false;         // the launch's last block sums the block counters (RTS_SUM_IN_KERNEL=1) instead of k_sum_counters -- measured SLOWER, off: the ticket's

@@ -219,7 +219,7 @@ __global__ void k_tile_keys(const uint32_t* __restrict__ hist, uint32_t n_hist, 
         // bucket of the counting order (bucket_hist != nullptr): the head of the order in the first half of the bins, the rest in
         // the second, each by descending cost in steps of 1/16 octave -- finer than a tile's cost repeats from pulse to pulse
         // (the head is ordered too: its longest cooperative unit has to start first)
-        bucket = (is_head ? 0u : RTS_TILE_BUCKETS / 2u) + (RTS_TILE_BUCKETS / 2u - 1u) - min((uint32_t)(__log2f((float)cost + 1.0f) * 16.0f), RTS_TILE_BUCKETS / 2u - 1u);
+        bucket = (is_head ? 0u : RTS_TILE_BUCKETS / 2u) + (RTS_TILE_BUCKETS / 2u - 1u) - (cost <= 1u ? 16u * cost : min((uint32_t)(__log2f((float)cost + 1.0f) * 16.0f), RTS_TILE_BUCKETS / 2u - 1u));      // (cost 1, a dead tile: RTS_DEAD_BIN, said exactly)
         if (affine) {
             // XCD-affine sub-orders: [64 head bins, half octaves | RTS_XCD bands x 120 bins, quarter octaves]; band = the contiguous range
             // of local tile indices (a slab of the lattice) that held an eighth of the cost of the launch before last (bnd: written by
@@ -253,7 +253,10 @@ __global__ void k_tile_keys(const uint32_t* __restrict__ hist, uint32_t n_hist, 
 // xcd != null (XCD-affine sub-orders): xcd[0 .. RTS_XCD] <- first order position of each band's segment (the last entry: the number of
 // tiles), and xcd[16 .. 16 + RTS_XCD] <- the bands of the NEXT build: local tile indices at which the cost cells of the launch just
 // merged (coarse) reach 1/8, 2/8, ... of their sum
-__global__ void __launch_bounds__(RTS_TILE_BUCKETS) k_tile_bucket_scan(uint32_t* __restrict__ hist, uint32_t* __restrict__ xcd, const uint32_t* __restrict__ coarse, uint32_t n_tiles)
+// The bin of a DEAD tile (cost record 1: every launch index cleared by the pre-filter, k_trace): everything in front of it in the order cost more.
+// Its first position + 1 goes to `live` (the trace kernel draws the order behind it 64 tiles at a time, one lane per tile).
+#define RTS_DEAD_BIN (RTS_TILE_BUCKETS / 2u + (RTS_TILE_BUCKETS / 2u - 1u) - 16u)       // (is_head ? 0 : 512) + 511 - min(log2(1 + 1) * 16, 511)
+__global__ void __launch_bounds__(RTS_TILE_BUCKETS) k_tile_bucket_scan(uint32_t* __restrict__ hist, uint32_t* __restrict__ xcd, const uint32_t* __restrict__ coarse, uint32_t n_tiles, uint32_t* __restrict__ live)
 {
     __shared__ uint32_t s[2][RTS_TILE_BUCKETS];
     const uint32_t t = threadIdx.x, v = hist[t];
@@ -261,6 +264,7 @@ __global__ void __launch_bounds__(RTS_TILE_BUCKETS) k_tile_bucket_scan(uint32_t*
     int cur = 0;
     for (uint32_t off = 1; off < RTS_TILE_BUCKETS; off <<= 1) { uint32_t x = s[cur][t]; if (t >= off) x += s[cur][t - off]; s[cur ^ 1][t] = x; cur ^= 1; __syncthreads(); }
     hist[t] = s[cur][t] - v;                                                   // exclusive: first position of the bin
+    if (live && t == RTS_DEAD_BIN) live[0] = s[cur][t] - v + 1u;
     if (!xcd) return;                                                          // (uniform)
     if (t >= 64u && (t - 64u) % 120u == 0u && (t - 64u) / 120u < RTS_XCD) xcd[(t - 64u) / 120u] = s[cur][t] - v;
     if (t == 0) xcd[RTS_XCD] = s[cur][RTS_TILE_BUCKETS - 1];
@@ -325,7 +329,7 @@ __global__ void k_tile_merge_keys(uint32_t* __restrict__ cost, RtsTileShape cur,
                 double thr_big = rule.big * balanced; if (thr_big < (double)rule.floor_cost) thr_big = (double)rule.floor_cost;
                 is_head = rts_head_rule(est, (double)c, balanced, thr, thr_big, rule) ? 1u : 0u;
             }
-            const uint32_t bucket = (is_head ? 0u : RTS_TILE_BUCKETS / 2u) + (RTS_TILE_BUCKETS / 2u - 1u) - min((uint32_t)(__log2f((float)c + 1.0f) * 16.0f), RTS_TILE_BUCKETS / 2u - 1u);
+            const uint32_t bucket = (is_head ? 0u : RTS_TILE_BUCKETS / 2u) + (RTS_TILE_BUCKETS / 2u - 1u) - (c <= 1u ? 16u * c : min((uint32_t)(__log2f((float)c + 1.0f) * 16.0f), RTS_TILE_BUCKETS / 2u - 1u));      // (cost 1, a dead tile: RTS_DEAD_BIN, said exactly)
             key[j] = bucket;
             atomicAdd(&s_cnt[bucket], 1u);
         }
@@ -341,7 +345,7 @@ __global__ void k_tile_merge_keys(uint32_t* __restrict__ cost, RtsTileShape cur,
 // scatter with the bins' scan inside every block: hist = the bins' COUNTS (left untouched), taken = zeroed reservation counters.  Two passes over the
 // block's `per` x 256 tiles: count per bin, reserve each bin's share with ONE atomic, then rank inside it (the order inside a bin is free)
 __global__ void __launch_bounds__(256) k_tile_scan_scatter(const uint32_t* __restrict__ bucket_of, uint32_t n, const uint32_t* __restrict__ hist, uint32_t* __restrict__ taken, uint32_t* __restrict__ order,
-                                                           const unsigned long long* __restrict__ head_sum, unsigned long long* __restrict__ sum_persist, uint32_t per)
+                                                           const unsigned long long* __restrict__ head_sum, unsigned long long* __restrict__ sum_persist, uint32_t per, uint32_t* __restrict__ live)
 {
     __shared__ uint32_t s_cnt[RTS_TILE_BUCKETS], s_base[RTS_TILE_BUCKETS], s_rank[RTS_TILE_BUCKETS], s_wave[4];
     const uint32_t t = threadIdx.x;
@@ -358,6 +362,7 @@ __global__ void __launch_bounds__(256) k_tile_scan_scatter(const uint32_t* __res
     for (uint32_t w = 0; w < (t >> 6); w++) before += s_wave[w];
     s_base[4 * t] = before; s_base[4 * t + 1] = before + h0; s_base[4 * t + 2] = before + h0 + h1; s_base[4 * t + 3] = before + h0 + h1 + h2;
     __syncthreads();
+    if (live && blockIdx.x == 0 && t == 0) live[0] = s_base[RTS_DEAD_BIN] + 1u;      // first position of the dead tiles' bin (+ 1: 0 means unknown)
     for (uint32_t it = 0; it < per; it++) { const uint32_t j = (blockIdx.x * per + it) * blockDim.x + t; if (j < n) atomicAdd(&s_cnt[bucket_of[j]], 1u); }
     __syncthreads();
     for (uint32_t q = t; q < RTS_TILE_BUCKETS; q += blockDim.x) if (s_cnt[q]) s_base[q] += atomicAdd(&taken[q], s_cnt[q]);
@@ -438,7 +443,7 @@ int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_vali
         unsigned long long* persist = reinterpret_cast<unsigned long long*>(c->d_xcd.p + 32);
         const uint32_t per = (n_tiles_cur + (256u << 10) - 1u) / (256u << 10), fat = blocks_for(n_tiles_cur, 256u * per);      // at most 1 024 blocks
         k_tile_merge_keys<<<fat, 256, 0, st>>>(c->d_tile_cost.p, cur2, c->d_tile_hist.p, n_hist, reinterpret_cast<unsigned long long*>(head), persist, head ? head + 2 : nullptr, rule2, c->d_tile_key.p, bins, per);
-        k_tile_scan_scatter<<<fat, 256, 0, st>>>(c->d_tile_key.p, n_tiles_cur, bins, c->d_tile_ctr.p + RTS_OFF_COARSE, c->d_tile_order.p, reinterpret_cast<const unsigned long long*>(head), head ? persist : nullptr, per);
+        k_tile_scan_scatter<<<fat, 256, 0, st>>>(c->d_tile_key.p, n_tiles_cur, bins, c->d_tile_ctr.p + RTS_OFF_COARSE, c->d_tile_order.p, reinterpret_cast<const unsigned long long*>(head), head ? persist : nullptr, per, c->d_tile_ctr.p + RTS_OFF_LIVE);
         RTS_HIP(hipGetLastError());
         return RTS_OK;
     }
@@ -454,7 +459,7 @@ int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_vali
     k_tile_keys<<<blocks_for(n_tiles_cur, 256), 256, 0, st>>>(c->d_tile_hist.p, n_hist, cur, c->d_tile_key.p, c->d_tile_id.p, reinterpret_cast<const unsigned long long*>(head), head ? head + 2 : nullptr, rule, bins,
                                                               affine ? 1 : 0, bnd);
     if (bins) {
-        k_tile_bucket_scan<<<1, RTS_TILE_BUCKETS, 0, st>>>(bins, affine ? c->d_xcd.p : nullptr, coarse, n_tiles_cur);
+        k_tile_bucket_scan<<<1, RTS_TILE_BUCKETS, 0, st>>>(bins, affine ? c->d_xcd.p : nullptr, coarse, n_tiles_cur, affine ? nullptr : c->d_tile_ctr.p + RTS_OFF_LIVE);      // (the affine keys use other bins)
         if (affine) c->xcd_bnd_tiles = merged ? n_tiles_cur : 0u;               // (bands from a launch of another shape are not used)
         k_tile_bucket_scatter<<<blocks_for(n_tiles_cur, 256), 256, 0, st>>>(c->d_tile_key.p, n_tiles_cur, bins, c->d_tile_order.p);
         RTS_HIP(hipGetLastError());

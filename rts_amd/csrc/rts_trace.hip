@@ -386,7 +386,22 @@ __device__ __forceinline__ void rts_walk_coop(const RtsTraceArgs& a, int32_t* s_
 //                  occupies ONE wave for 7-13 ms of a launch whose balanced time is 7.8 ms; as 64 cooperative units it is
 //                  spread over 64 waves that finish each ray in a few hundred wave steps.
 // The two share every expression of the payload arithmetic (same code, same operand order): results are bit-identical.
-struct RtsUnitLds { int32_t* stack; int32_t* exch; double* first; unsigned long long* path; uint32_t* n; const RtsRxDev* rx; const float (*rxp)[6]; uint32_t* lane_scratch; uint32_t* walk; };      // walk: per wave [walk iterations of the tile, walks]
+// rows of k_trace's s_rxp: the receivers' pre-filter constants (rts_rx_maybe)
+#define RTS_RXP_QQW 3          // |q|^2 (1 + 1e-6)
+#define RTS_RXP_R2W 4          // widened radius^2
+#define RTS_RXP_QN 5           // |q|
+#define RTS_RXP_QQ 6           // |q|^2
+#define RTS_RXP_R2 7           // radius^2
+#define RTS_RXP_E2 8           // error bound of s^2
+#define RTS_RXP_CT 9           // cos, sin of the window's centre azimuth
+#define RTS_RXP_ST 10
+#define RTS_RXP_CH 11          // cos of its half span
+#define RTS_RXP_SLO 12         // r sin(min phi), r sin(max phi)
+#define RTS_RXP_SHI 13
+#define RTS_RXP_OK 14          // 1: the window screen applies
+#define RTS_RXP_RW 15          // sqrt(widened radius^2) (1 + 1e-6)
+#define RTS_RXP_N 16
+struct RtsUnitLds { int32_t* stack; int32_t* exch; double* first; unsigned long long* path; uint32_t* n; const RtsRxDev* rx; const float (*rxp)[RTS_RXP_N]; uint32_t* lane_scratch; uint32_t* walk; };      // walk: per wave [walk iterations of the tile, walks]
 // The payload of one ray chain between its segments (PerRayData fields that the walk does not touch but the shading does;
 // the first hit point, the path words and the counters live in LDS, RtsUnitLds).
 struct RtsRay { dvec3 dir, prev; double rayLength, power, doppler, refx, refy; uint32_t reflDepth, refrDepth; int received; bool end, chain_start; };
@@ -610,10 +625,64 @@ __device__ __forceinline__ void rts_write_back(const RtsTraceArgs& a, const RtsU
     }
 }
 
+// Can a PRIMARY ray of (unit, f32) direction d -- or, delta > 0, any primary ray within the angle delta of it -- be CAPTURED by the receiver whose
+// constants are K (k_trace's s_rxp row; RTS_RXP_*)?  Two conservative questions, both in f32:
+//  (1) can it come within the widened radius of the capture sphere at all (round 2; the widening covers the f32 arithmetic here and the
+//      reference's own cancelling quadratic, k_trace);
+//  (2) round 5 -- if it does cross the sphere: can either crossing point lie inside the receiver's angular capture window
+//      (ray_tracer.cu:326-375)?  A monostatic radar's capture sphere sits right in front of the antenna and EVERY ray of the beam crosses it
+//      (so do all of BASELINE configs[3]'s: its transmitter is 112 m from the centre of an 80 m sphere); the window, which looks back at the
+//      receiver, excludes them -- but only the exact f64 miss program knew, at ~500 instructions per receiver and ray.  Here: the
+//      crossing points p = t d - q for t = b -+ s (b = q.d, s^2 = b^2 - (|q|^2 - r^2)) and two inequalities without an arctangent --
+//      the azimuth test as a cosine against the window's centre direction, the elevation test as p_z against r sin(min / max phi).
+//      Error budget (e2, ep below; derivation in DESIGN.md section 4): the reference's roots differ from geometry by eC / (2 s) along the
+//      ray, eC <= 1e-14 (|o|^2 + |c|^2) the rounding of its constant term; this arithmetic's s^2 is off by <= 2e-6 |q|^2 + 1e-6 r^2 (f32 q, the
+//      pre-filter's direction good to 3e-7 rad); a point error ep turns the azimuth by <= 1.1 ep / rho (rho = the point's distance from the
+//      sphere's polar axis) and moves p_z by ep.  Near-tangent rays (s^2 < 16 e2), points near the polar axis (ep > rho / 4), windows that
+//      reach over a pole or span >= 3 rad in azimuth (RTS_RXP_OK = 0): "maybe".  A root is ignored when it is certainly below the
+//      reference's t > SCENE_EPS (the transmitter ON the sphere: the monostatic case).
+//      delta > 0: every ray of the bundle lies within delta of d; its b differs by <= |q| delta, its roots by dt = |q| delta (1 + (2 |b| +
+//      |q| delta) / (1.7 s)), its crossing points by dt + |t| delta (valid while the bundle's smallest s^2 >= s^2 / 2, else "maybe").
+__device__ __forceinline__ bool rts_rx_maybe(const float* K, const float dx, const float dy, const float dz, const float dd, const float delta)
+{
+    const float qx = K[0], qy = K[1], qz = K[2], qn = K[RTS_RXP_QN];
+    const float b = qx*dx + qy*dy + qz*dz;
+    const float R = K[RTS_RXP_RW] + qn * delta, r2w = delta > 0.0f ? R * R : K[RTS_RXP_R2W];
+    const bool inside = K[RTS_RXP_QQW] <= K[RTS_RXP_R2W] * 1.01f;                                   // the transmitter is inside the (widened) sphere
+    const bool ahead = b > -(1.0e-3f + delta) * qn && (b*b - (K[RTS_RXP_QQW] - r2w) * dd) >= 0.0f;
+    if (!(inside || ahead)) return false;                        // (1) it cannot reach the sphere
+    if (K[RTS_RXP_OK] == 0.0f) return true;
+    // (2) the crossing points against the window
+    const float e2 = K[RTS_RXP_E2], s2 = b*b - (K[RTS_RXP_QQ] - K[RTS_RXP_R2]);
+    if (!(s2 >= 16.0f * e2)) return true;                        // near-tangent (or not a number): the roots are not known well enough
+    const float s = __builtin_sqrtf(s2);
+    float dt = 0.0f;
+    if (delta > 0.0f) {
+        const float qd = qn * delta;
+        if (!(s2 - qd * (2.2f * fabsf(b) + qd) >= 0.5f * s2)) return true;      // the bundle comes too close to tangency
+        dt = qd * (1.0f + (2.0f * fabsf(b) + qd) / (1.7f * s));
+    }
+    const float et = 0.75f * e2 / s + 1.0e-6f * qn;
+    bool maybe = false;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const float t = k == 0 ? b - s : b + s;
+        if (t + et + dt < 0.004999f) continue;                   // certainly not a valid root (ray_tracer.cu:314: t >= 0, rayLength + t > SCENE_EPS)
+        const float px = __builtin_fmaf(t, dx, -qx), py = __builtin_fmaf(t, dy, -qy), pz = __builtin_fmaf(t, dz, -qz);
+        const float ep = et + dt + (fabsf(t) + qn) * (2.0e-6f + delta);
+        const float rho = __builtin_sqrtf(px*px + py*py);
+        if (!(ep <= 0.25f * rho)) { maybe = true; continue; }    // near the polar axis: the azimuth is not known
+        const bool az_out = (px * K[RTS_RXP_CT] + py * K[RTS_RXP_ST]) < rho * (K[RTS_RXP_CH] - 1.1f * ep / rho - 2.0e-6f);
+        const bool el_out = pz < K[RTS_RXP_SLO] - 2.0f * ep - 2.0e-6f * qn || pz > K[RTS_RXP_SHI] + 2.0f * ep + 2.0e-6f * qn;
+        maybe = maybe || !(az_out || el_out);
+    }
+    return maybe;
+}
+
 // The conservative f32 pre-filter of a primary ray: can it meet any triangle's projection (the pulse's direction bitmap,
 // RtsMaskFrame) / come within the widened radius of a receiver sphere?  rxp: the receivers' constants (k_trace's s_rxp).
 __device__ __forceinline__ void rts_prefilter(const RtsLaunchConsts& lc, const uint32_t slot, const bool mask_on, const uint32_t* __restrict__ pmask, const uint32_t n_rx,
-                                              const float (*rxp)[6], bool& may_target, bool& may_rx)
+                                              const float (*rxp)[RTS_RXP_N], bool& may_target, bool& may_rx)
 {
     // ray_generation in f32: lattice point, ONE matrix (Rot1 Rot: the reference's two normalisations in between only scale), normalise.
     // Good to ~2e-7 rad; the mask's margin is a whole cell (>= 1e-5), the receivers' radii are widened by 1 %
@@ -633,13 +702,82 @@ __device__ __forceinline__ void rts_prefilter(const RtsLaunchConsts& lc, const u
     }
     may_rx = false;
     const float dd = dx*dx + dy*dy + dz*dz;
-    for (uint32_t Rx_i = 0; Rx_i < n_rx; Rx_i++) {    // can the ray come within the widened radius of this receiver's sphere?
-        const float qx = rxp[Rx_i][0], qy = rxp[Rx_i][1], qz = rxp[Rx_i][2], qq = rxp[Rx_i][3], r2w = rxp[Rx_i][4], qn = rxp[Rx_i][5];
-        const float b = qx*dx + qy*dy + qz*dz;
-        const bool inside = qq <= r2w * 1.01f;
-        const bool ahead = b > -1.0e-3f * qn && (b*b - (qq - r2w) * dd) >= 0.0f;
-        may_rx = may_rx || inside || ahead;
+    for (uint32_t Rx_i = 0; Rx_i < n_rx; Rx_i++) may_rx = may_rx || rts_rx_maybe(rxp[Rx_i], dx, dy, dz, dd, 0.0f);      // can this receiver capture the ray?
+}
+
+// The pre-filter's question asked of a whole ROW SEGMENT of the launch lattice -- launch indices lx_a .. lx_b of row (ly, lz) -- by ONE lane:
+// can ANY of its primary rays meet a triangle's projection or come within the widened radius of a receiver sphere?  (Dead-tile batches
+// of k_trace: most wave tiles of a pulse are dead, and a wave spent ~1.5 us on each -- a dependent chain of the order's load, 64 per-lane
+// filters, the mask load, a ballot -- to learn it.)  Conservative with respect to the per-ray filter's own arithmetic:
+//  * the un-normalised direction is LINEAR in lx, d(lx) = M (bs + st (lx, ly, lz)), so the rays of the segment lie in one plane through the
+//    transmitter, on the great-circle arc between the two end rays;
+//  * the mask coordinates fu, fv are ratios of linear functions of lx with the same denominator w = d . b: where w > 0 at both ends it is
+//    positive in between and (fu, fv) runs along the STRAIGHT segment between the end rays' points (a projective map of the lattice row),
+//    monotonically.  The cells that segment passes through are tested; the mask's one-cell margin covers the f32 rounding of the ends
+//    exactly as it covers a single ray's.  An end outside the mask's frame, w <= 0, or a segment of more than 96 cells: "maybe";
+//  * a ray that passes within R of a receiver's centre q does so at an angle asin(R / |q|) from q's direction; every ray of the segment is
+//    within delta = angle(end a, end b) of end a, so end a passes within R + |q| delta: the per-ray test at end a with that radius (and the
+//    "pointing away" bound relaxed by delta).  delta <= 1.6 x the chord of the normalised ends (+ 4e-6 for their f32 rounding).
+__device__ __forceinline__ bool rts_segment_maybe(const RtsLaunchConsts& lc, const uint32_t lx_a, const uint32_t lx_b, const uint32_t ly, const uint32_t lz, const bool has_prims, const bool mask_on,
+                                                  const uint32_t* __restrict__ pmask, const uint32_t n_rx, const float (*rxp)[RTS_RXP_N])
+{
+    const float vy = __builtin_fmaf(lc.f_st[1], (float)ly, lc.f_bs[1]), vz = __builtin_fmaf(lc.f_st[2], (float)lz, lc.f_bs[2]);
+    const float vxa = __builtin_fmaf(lc.f_st[0], (float)lx_a, lc.f_bs[0]), vxb = __builtin_fmaf(lc.f_st[0], (float)lx_b, lc.f_bs[0]);
+    float ax = lc.f_m[0]*vxa + lc.f_m[1]*vy + lc.f_m[2]*vz, ay = lc.f_m[3]*vxa + lc.f_m[4]*vy + lc.f_m[5]*vz, az = lc.f_m[6]*vxa + lc.f_m[7]*vy + lc.f_m[8]*vz;
+    float bx = lc.f_m[0]*vxb + lc.f_m[1]*vy + lc.f_m[2]*vz, by = lc.f_m[3]*vxb + lc.f_m[4]*vy + lc.f_m[5]*vz, bz = lc.f_m[6]*vxb + lc.f_m[7]*vy + lc.f_m[8]*vz;
+    { const float ia = __frsqrt_rn(ax*ax + ay*ay + az*az), ib = __frsqrt_rn(bx*bx + by*by + bz*bz); ax *= ia; ay *= ia; az *= ia; bx *= ib; by *= ib; bz *= ib; }
+    if (has_prims) {
+        if (!mask_on) return true;
+        const RtsMaskFrame& mf = lc.mask;
+        const float wa = ax * mf.bx + ay * mf.by + az * mf.bz, wb = bx * mf.bx + by * mf.by + bz * mf.bz;
+        if (!(wa > 0.0f && wb > 0.0f)) return true;
+        const float iwa = __builtin_amdgcn_rcpf(wa), iwb = __builtin_amdgcn_rcpf(wb);
+        const float fua = ((ax * mf.ux + ay * mf.uy + az * mf.uz) * iwa - mf.u0) * mf.inv_du, fva = ((ax * mf.vx + ay * mf.vy + az * mf.vz) * iwa - mf.v0) * mf.inv_dv;
+        const float fub = ((bx * mf.ux + by * mf.uy + bz * mf.uz) * iwb - mf.u0) * mf.inv_du, fvb = ((bx * mf.vx + by * mf.vy + bz * mf.vz) * iwb - mf.v0) * mf.inv_dv;
+        const float ulo = fminf(fua, fub), uhi = fmaxf(fua, fub), vlo = fminf(fva, fvb), vhi = fmaxf(fva, fvb);
+        if (!(ulo >= 0.0f && vlo >= 0.0f && uhi < (float)mf.n && vhi < (float)mf.n)) return true;      // (an end outside the frame -- or not a number -- : the per-ray filter says "maybe" there)
+        // The rays' mask points lie ON the straight segment between the two ends' (a projective map takes the lattice row to a line):
+        // along the range axis of the lattice that is up to ~16 cells at the beam's edge, mostly radial -- its bounding box would be
+        // hundreds of cells.  The segment is walked column by column along its major axis; per column the cells its part of the segment
+        // passes through, widened by 1/32 cell for the rounding of this interpolation (the rays' own rounding is the mask's one-cell margin's).
+        const bool major_u = (uhi - ulo) >= (vhi - vlo);
+        float a0 = major_u ? fua : fva, a1 = major_u ? fub : fvb, b0 = major_u ? fva : fua, b1 = major_u ? fvb : fub;
+        if (a0 > a1) { const float t0 = a0; a0 = a1; a1 = t0; const float t1 = b0; b0 = b1; b1 = t1; }
+        const uint32_t c0 = (uint32_t)a0, c1 = (uint32_t)a1;
+        if (c1 - c0 > 96u) return true;                               // (a segment across a tenth of the beam: not a tile of nearly parallel rays)
+        const float slope = (a1 - a0) > 1.0e-6f ? (b1 - b0) / (a1 - a0) : 0.0f;
+        const float nmax = (float)(mf.n - 1u);
+        uint32_t found = 0u;
+        for (uint32_t c = c0; c <= c1; c++) {
+            const float la = fmaxf(a0, (float)c), ha = fminf(a1, (float)(c + 1u));
+            const float bl = b0 + slope * (la - a0), bh = b0 + slope * (ha - a0);
+            const uint32_t r0 = (uint32_t)fminf(fmaxf(fminf(bl, bh) - 0.03125f, 0.0f), nmax), r1 = (uint32_t)fminf(fmaxf(fmaxf(bl, bh) + 0.03125f, 0.0f), nmax);
+            for (uint32_t r = r0; r <= r1; r++) { const uint32_t cell = major_u ? r * mf.n + c : c * mf.n + r; found |= pmask[cell >> 5] >> (cell & 31u); }
+        }
+        if (found & 1u) return true;
     }
+    const float ex = ax - bx, ey = ay - by, ez = az - bz;
+    const float delta = 1.6f * __builtin_sqrtf(ex*ex + ey*ey + ez*ez) + 4.0e-6f;
+    const float dd = ax*ax + ay*ay + az*az;
+    for (uint32_t Rx_i = 0; Rx_i < n_rx; Rx_i++) if (rts_rx_maybe(rxp[Rx_i], ax, ay, az, dd, delta)) return true;      // (end a stands for the bundle: every ray is within delta of it)
+    return false;
+}
+// ... of a WAVE TILE: 64 consecutive launch indices (aligned launches only: consecutive GLOBAL indices) = one row segment, or the end of one
+// row and the start of the next (W >= 64)
+__device__ __forceinline__ bool rts_tile_maybe(const RtsLaunchConsts& lc, const uint32_t tile, const uint32_t n_rays, const bool has_prims, const bool mask_on, const uint32_t* __restrict__ pmask,
+                                               const uint32_t n_rx, const float (*rxp)[RTS_RXP_N])
+{
+    const uint32_t s0 = tile * 64u, s1 = min(s0 + 63u, n_rays - 1u);
+    uint32_t lx0, ly0, lz0, lx1, ly1, lz1;
+    rts_lattice_coords(lc, s0, lx0, ly0, lz0); rts_lattice_coords(lc, s1, lx1, ly1, lz1);
+    const bool one_row = ly0 == ly1 && lz0 == lz1;
+    if (one_row && lx1 < lx0) return true;                            // (cannot be: said for safety)
+    // (ONE inlined copy of the segment test, run once or twice: inlined at two call sites its loop-invariant addresses were hoisted into
+    // vector registers of the tile loop -- and from there into scratch)
+    bool maybe = false;
+    for (uint32_t seg = 0; seg < (one_row ? 1u : 2u) && !maybe; seg++)
+        maybe = rts_segment_maybe(lc, seg == 0u ? lx0 : 0u, (seg == 0u && !one_row) ? lc.W - 1u : lx1, seg == 0u ? ly0 : ly1, seg == 0u ? lz0 : lz1, has_prims, mask_on, pmask, n_rx, rxp);
+    return maybe;
 }
 
 // ray_generation + payload of a launch index (ray_tracer.cu:144-224), with the conservative f32 pre-filter of primary rays:
@@ -647,7 +785,7 @@ __device__ __forceinline__ void rts_prefilter(const RtsLaunchConsts& lc, const u
 __device__ __forceinline__ void rts_primary_setup(const RtsTraceArgs& a, const RtsLaunchConsts& lc, const RtsUnitLds& L_, const uint32_t tid, const uint32_t slot, const bool pre_on,
                                                   const bool mask_on, const dvec3& origin, RtsRay& S, bool& may_target, bool& may_rx, const bool pre_done = false)
 {
-    double* const s_first = L_.first; unsigned long long* const s_path = L_.path; const float (*const s_rxp)[6] = L_.rxp;
+    double* const s_first = L_.first; unsigned long long* const s_path = L_.path; const float (*const s_rxp)[RTS_RXP_N] = L_.rxp;
     dvec3& dir = S.dir; dvec3& prev = S.prev; double& rayLength = S.rayLength; double& power = S.power; double& doppler = S.doppler;
     // ------------------------------------------------------------ ray_generation + payload, ray_tracer.cu:144-224
     if (pre_on && !pre_done) rts_prefilter(lc, slot, mask_on, a.pmask, a.n_rx, s_rxp, may_target, may_rx);
@@ -972,13 +1110,25 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR && COOP) ? 2 : ((REFR || COOP
     // cancel catastrophically -- terms of 4e13 m^2, rounded a dozen times: the sphere it tests is up to ~0.05 m^2 larger or
     // smaller in r^2 than the one it was given (found by tools/fuzz_equal.py: a 0.86 m sphere 3.7 m from the transmitter
     // captured 32 rays the geometric filter had excluded).  + 1e-14 (|o|^2 + |c|^2): 45 ulps of the largest term.
-    __shared__ float s_rxp[RTS_RX_LDS][6];
+    __shared__ float s_rxp[RTS_RX_LDS][RTS_RXP_N];
     if (tid < RTS_RX_LDS && tid < a.n_rx) {
         const RtsRxDev r = s_rx[tid];
         const double qx = r.cx - lc.ox, qy = r.cy - lc.oy, qz = r.cz - lc.oz, qq = qx*qx + qy*qy + qz*qz;
-        s_rxp[tid][0] = (float)qx; s_rxp[tid][1] = (float)qy; s_rxp[tid][2] = (float)qz; s_rxp[tid][3] = (float)qq * 1.000001f;
-        s_rxp[tid][4] = (float)(r.radius * r.radius * 1.001 + 1.0e-5 * qq + 1.0e-6 + 1.0e-14 * (lc.ox*lc.ox + lc.oy*lc.oy + lc.oz*lc.oz + r.cx*r.cx + r.cy*r.cy + r.cz*r.cz));
-        s_rxp[tid][5] = (float)sqrt(qq);
+        const double w2 = lc.ox*lc.ox + lc.oy*lc.oy + lc.oz*lc.oz + r.cx*r.cx + r.cy*r.cy + r.cz*r.cz;
+        const double r2wd = r.radius * r.radius * 1.001 + 1.0e-5 * qq + 1.0e-6 + 1.0e-14 * w2;
+        s_rxp[tid][0] = (float)qx; s_rxp[tid][1] = (float)qy; s_rxp[tid][2] = (float)qz; s_rxp[tid][RTS_RXP_QQW] = (float)qq * 1.000001f;
+        s_rxp[tid][RTS_RXP_R2W] = (float)r2wd;
+        s_rxp[tid][RTS_RXP_QN] = (float)sqrt(qq);
+        // the window screen's constants (rts_rx_maybe): window = (minTheta, maxTheta) x (minPhi, maxPhi), ray_tracer.cu:343-375; applicable when it does not
+        // reach over a pole (the reference then tests a second, mirrored window) and spans < 3 rad in azimuth (angle_in_range rejects spans >= pi)
+        const double th_c = 0.5 * (r.minTheta + r.maxTheta), th_h = 0.5 * (r.maxTheta - r.minTheta);
+        const bool ok = r.minPhi >= -RTS_PI / 2 && r.maxPhi <= RTS_PI / 2 && r.minPhi < r.maxPhi && th_h > 0.0 && th_h < 1.5 && r.radius > 0.0 && isfinite(th_c) && isfinite(qq);
+        s_rxp[tid][RTS_RXP_QQ] = (float)qq; s_rxp[tid][RTS_RXP_R2] = (float)(r.radius * r.radius);
+        s_rxp[tid][RTS_RXP_E2] = (float)(2.0e-6 * qq + 1.0e-6 * r.radius * r.radius + 1.0e-14 * w2 + 1.0e-12);
+        s_rxp[tid][RTS_RXP_CT] = (float)cos(th_c); s_rxp[tid][RTS_RXP_ST] = (float)sin(th_c); s_rxp[tid][RTS_RXP_CH] = (float)cos(th_h);
+        s_rxp[tid][RTS_RXP_SLO] = (float)(r.radius * sin(r.minPhi)); s_rxp[tid][RTS_RXP_SHI] = (float)(r.radius * sin(r.maxPhi));
+        s_rxp[tid][RTS_RXP_OK] = (ok && a.rx_window_screen) ? 1.0f : 0.0f;
+        s_rxp[tid][RTS_RXP_RW] = (float)(sqrt(r2wd) * 1.000001);
     }
     __syncthreads();
     uint32_t n_nodes = 0, n_tris = 0;                            // counting build only (per lane and launch: far below 2^32)
@@ -1061,9 +1211,35 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR && COOP) ? 2 : ((REFR || COOP
         coop_len = RTS_COOP_LEN(coop_x);
     }
     const uint32_t S = (AFFINE || COOP) ? (uint32_t)RTS_SEG_STRIPES : (uint32_t)RTS_TILE_CTRS;      // stripes of a segment
-#define RTS_LSTRIPE (AFFINE ? (RTS_OPAQUE_S(stripe) & (RTS_SEG_STRIPES - 1u)) : (COOP ? (stripe & (RTS_SEG_STRIPES - 1u)) : stripe))
+#define RTS_LSTRIPE (AFFINE ? (RTS_OPAQUE_S(stripe) & (RTS_SEG_STRIPES - 1u)) : (COOP ? (stripe & (RTS_SEG_STRIPES - 1u)) : RTS_OPAQUE_S(stripe)))      // (opaque: the draw counter's ADDRESS is formed at each draw -- hoisted, it is a vector register pair of the tile loop)
     const uint32_t per_stripe_all = (n_units + RTS_TILE_CTRS - 1u) / RTS_TILE_CTRS;
-    const uint32_t single_draws_all = per_stripe_all >= 1024u ? per_stripe_all / 4u : per_stripe_all;      // (short queues: one tile per draw throughout)
+    // DEAD-TILE BATCHES (round 5).  Most wave tiles of a pulse are DEAD -- the pre-filter clears all 64 launch indices: 84 % of BASELINE
+    // configs[2]'s tiles -- and the cost order keeps them at its end (cost record 1).  That part of the order is drawn 64 positions at
+    // a time and every LANE asks the pre-filter's question of one whole tile (rts_tile_maybe: the tile's rays are a row segment of the
+    // lattice, its two end rays bound what all of them can reach): the tiles that are still dead are accounted for by their lanes --
+    // 64 segments counted, cost record 1 -- and the few that have come to life are traced by the wave one after the other, as any
+    // tile is.  k_dead = the stripe's first position in the dead part (a.tile_live: written by the order build), 0 with
+    // a.batch_dead == 2 (every position is screened that way first: tests).  Ordinary lock-step kernel of aligned launches only.
+    // (the schedule's three numbers and a batch's mask of live positions live in LDS, one row per wave, and are read once per DRAW: as
+    // scalars of the kernel they were live through every tile's bounce loops -- 30 more scalar spills, and the pending draw in scratch)
+    constexpr bool BATCHABLE = !COOP && !ASYNC && !AFFINE && !KEEP_ALL;
+    __shared__ uint32_t s_sched[(RTS_BLOCK / 64) * 8];      // per wave: [0] single draws, [1] draws of four, [2] k_dead, [3] [4] live mask of the batch in hand
+#define RTS_SCHED(k) s_sched[RTS_OPAQUE_S(wave_u) * 8u + (k)]
+    const uint32_t single_draws_nobatch = per_stripe_all >= 1024u ? per_stripe_all / 4u : per_stripe_all;      // (short queues: one tile per draw throughout)
+    if (BATCHABLE) {
+        uint32_t k_dead = per_stripe_all;
+        if (a.batch_dead != 0u && pre_on && lc.W >= 64u) {
+            if (a.batch_dead == 2u) k_dead = 0u;
+            else if (a.tile_live && a.tile_order) {
+                const uint32_t lv = __builtin_amdgcn_readfirstlane(a.tile_live[0]);          // 1 + tiles at the front of the order that cost more than a dead one (0: unknown)
+                if (lv) { const uint32_t v_dead = lv - 1u > n_head ? lv - 1u - n_head : 0u; k_dead = min(per_stripe_all, v_dead > stripe ? (v_dead - stripe + RTS_TILE_CTRS - 1u) / RTS_TILE_CTRS : 0u); }
+            }
+        }
+        // draws of a stripe: positions [0, s1) one per draw, [s1, k_dead) four per draw (n2 draws), [k_dead, ..) 64 per draw
+        const uint32_t s1 = min(single_draws_nobatch, k_dead);
+        if (lane == 0) { RTS_SCHED(0) = s1; RTS_SCHED(1) = (k_dead - s1 + 3u) / 4u; RTS_SCHED(2) = k_dead; }
+    }
+    const uint32_t single_draws_all = single_draws_nobatch;
     // The pending draw is held in a register of lane 0 (so that its latency hides behind the tiles traced meanwhile) -- except
     // in the counting builds, which are short of registers: there the allocator spilled it to scratch and launches lost whole
     // tiles' worth of counters from run to run, until it was moved to LDS.  What the ISA of that build shows (round 3,
@@ -1084,9 +1260,11 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR && COOP) ? 2 : ((REFR || COOP
     for (;;) {
       const uint32_t draw = __builtin_amdgcn_readfirstlane(AFFINE ? s_draw[RTS_OPAQUE_S(wave_u)] : (COUNT ? s_draw[wave_u] : draw_next));      // (AFFINE: in LDS like the counting builds' -- the kernel has no register for it across the tile loop, see above)
       const uint32_t per_stripe = AFFINE ? __builtin_amdgcn_readfirstlane(RTS_Q(3)) : (COOP ? (coop_len * (64u / coop_P) + RTS_SEG_STRIPES - 1u) / RTS_SEG_STRIPES : per_stripe_all);
-      const uint32_t single_draws = AFFINE ? __builtin_amdgcn_readfirstlane(RTS_Q(4)) : (COOP ? per_stripe : single_draws_all);      // (COOP: one unit per draw -- units are long)
-      const uint32_t k0 = draw < single_draws ? draw : single_draws + 4u * (draw - single_draws);
-      const uint32_t kn = draw < single_draws ? 1u : 4u;
+      const uint32_t single_draws = AFFINE ? __builtin_amdgcn_readfirstlane(RTS_Q(4)) : (COOP ? per_stripe : (BATCHABLE ? __builtin_amdgcn_readfirstlane(RTS_SCHED(0)) : single_draws_all));      // (COOP: one unit per draw -- units are long)
+      const uint32_t four_draws = BATCHABLE ? __builtin_amdgcn_readfirstlane(RTS_SCHED(1)) : 0u, k_dead = BATCHABLE ? __builtin_amdgcn_readfirstlane(RTS_SCHED(2)) : 0u;
+      const bool batch = BATCHABLE && draw >= single_draws + four_draws;      // (uniform) a batch of 64 positions of the order's dead part
+      const uint32_t k0 = draw < single_draws ? draw : (batch ? k_dead + 64u * (draw - single_draws - four_draws) : single_draws + 4u * (draw - single_draws));
+      const uint32_t kn = draw < single_draws ? 1u : (batch ? 64u : (BATCHABLE ? min(4u, k_dead - k0) : 4u));
       if (k0 >= per_stripe) {
           if (COOP) {                                                       // this XCD's list is empty: the next XCD's
               if (++coop_sweep >= RTS_XCD) break;
@@ -1112,8 +1290,32 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR && COOP) ? 2 : ((REFR || COOP
       // expensive tile for as long as this one takes -- the launch then ends with that tile, traced alone)
       const bool ahead = draw >= single_draws;
       if (ahead && lane == 0) RTS_DRAW()
+     // a batch: lane j screens the tile at position k0 + j; what is left of it are the positions whose tiles may have come to life
+     if (BATCHABLE && batch) {
+         const uint64_t vl = (uint64_t)(k0 + lane) * S + RTS_LSTRIPE;
+         bool maybe = false;
+         if (k0 + lane < per_stripe && vl < seg_len) {
+             const uint32_t tp = (uint32_t)vl + n_head;
+             const uint32_t tj = a.tile_order ? a.tile_order[tp] : ((tp & 1u) ? (n_tiles - 1u) / 2u + (tp + 1u) / 2u : (n_tiles - 1u) / 2u - tp / 2u);
+             const uint32_t* pm_ = a.pmask; asm volatile("" : "+s"(pm_));      // (opaque: addresses derived from it stay inside the batch)
+             maybe = rts_tile_maybe(lc, tj, a.n_rays, a.n_prims > 0, mask_on, pm_, a.n_rx, s_rxp);
+             if (!maybe) {                                             // still dead: its launch indices' one segment each, and its cost record
+                 atomicAdd(&s_n[tid], min(64u, a.n_rays - tj * 64u));
+                 if (a.tile_cost) a.tile_cost[tj] = 1u;
+             }
+         }
+         const unsigned long long live_m = __ballot(maybe);
+         if (lane == 0) { RTS_SCHED(3) = (uint32_t)live_m; RTS_SCHED(4) = (uint32_t)(live_m >> 32); }
+     }
      for (uint32_t kb = 0; kb < kn; kb++) {
-      const uint64_t vloc64 = (uint64_t)(k0 + kb) * S + RTS_LSTRIPE;      // position inside the segment
+      uint32_t kq = kb;
+      if (BATCHABLE && kn == 64u) {                                    // (a batch: the next position whose tile may have come to life)
+          const uint32_t m_lo = __builtin_amdgcn_readfirstlane(RTS_SCHED(3)), m_hi = __builtin_amdgcn_readfirstlane(RTS_SCHED(4));
+          if ((m_lo | m_hi) == 0u) break;
+          kq = m_lo ? (uint32_t)__builtin_ctz(m_lo) : 32u + (uint32_t)__builtin_ctz(m_hi);
+          if (lane == 0) { if (m_lo) RTS_SCHED(3) = m_lo & (m_lo - 1u); else RTS_SCHED(4) = m_hi & (m_hi - 1u); }
+      }
+      const uint64_t vloc64 = (uint64_t)(k0 + kq) * S + RTS_LSTRIPE;      // position inside the segment
       if (vloc64 >= seg_len) break;
       // (COOP: unit u of list x: head tile h = x mod G + G (u / (64 / P)), ray c + P (u mod (64 / P)) with c = ((x - h) mod 8) / G;
       // vpos = 64 x head tile + ray, as before)

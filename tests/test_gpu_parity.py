@@ -1275,6 +1275,121 @@ def test_octant_versions_are_invisible(rts, oracle, scenes, monkeypatch):
     tr.close()
 
 
+def test_dead_tile_batches_are_invisible(rts, oracle, scenes, monkeypatch):
+    """round 5: the part of the cost order that holds the DEAD wave tiles (all 64 launch indices cleared by the pre-filter) is drawn 64
+    positions at a time and one LANE screens one whole tile (rts_tile_maybe: the tile's rays are a row segment of the lattice, its end
+    rays bound what any of them can reach) -- conservative, so nothing observable may change: RTS_DEAD_BATCH=0 (every tile by the wave),
+    1 (the default: the order's dead part) and `all` (EVERY position screened tile-wise first, from the handle's first launch on)
+    must give the same received set, segment and hit counts and cost-record table, pulse after pulse on one handle while the target
+    moves through the beam (tiles die and come to life), for whole pulses, an interleaved part and a dealt tile list, with receivers
+    in the beam (direct rays), at Earth-centred coordinates, W = 70 / 81 (rows that straddle wave tiles); product and counting builds;
+    and the `all` launch against the oracle's brute force.  (rx_radius 120: at 300 the transmitter sits INSIDE two capture spheres, every primary ray may be
+    captured and no tile is dead)"""
+    import math
+    monkeypatch.setenv("RTS_GRID_MULT", "1")                               # 256 blocks: a cost order exists from ~65 k launch indices on
+    c3 = scenes.config3(W=81, detail=0.3, rx_radius=120.0); c3["tx"] = dict(c3["tx"], span=(0.08, 0.07, c3["tx"]["span"][2]))      # (a beam wider than the airframe: dead tiles around it)
+    direct = dict(c3, rx=c3["rx"] + [scenes._rx_at((1500.0, 20.0, 5.0), (-1000.0, 0, 0), 60.0, 2.6), scenes._rx_at((-100.0, -10.0, 0.0), (-1000.0, 0, 0), 5.0, 2.6)])      # in the beam behind / in front of the target: direct rays
+    wide = dict(scenes.config3(W=70, detail=0.3, rx_radius=120.0)); wide["tx"] = dict(wide["tx"], span=tuple(3.0 * x for x in wide["tx"]["span"][:2]) + (wide["tx"]["span"][2],))
+    cases = [("c3", c3), ("c3 ecef", scenes.translate(c3, scenes.ecef_offset(lat=math.pi / 2))), ("direct rays", direct), ("wide beam", wide)]
+    for name, spec in cases:
+        tx = spec["tx"]; n_all = spec["W"] ** 3
+        out = {}
+        for mode in ("0", "1", "all"):
+            monkeypatch.setenv("RTS_DEAD_BATCH", mode)
+            for count in (False, True):
+                tr = rts.Tracer(spec["W"], spec["max_refl"], 0, spec["smooth"], count_traversal=count)
+                tr.set_scene(spec["meshes"]); tr.set_receivers(spec["rx"])
+                res = []
+                for k in range(6):
+                    mo = [dict(m, position=tuple(np.add(m["position"], (0.5 * k, 4.0 * k, -2.5 * k)))) for m in spec["motion"]]      # across the beam: tiles die and come to life
+                    il = (4096, 2, 1) if k == 3 else None
+                    if k == 4:
+                        tr.set_tile_list(4096, np.arange(0, (n_all + 4095) // 4096, 3, dtype=np.uint32)); il = (4096, rts.INTERLEAVE_LIST, 0)
+                    st = tr.trace(tx["origin"], tx["span"], tx["dir"], mo, ray_first=0, ray_count=n_all, interleave=il)
+                    res.append((st, tr.received(), tr.tile_records_get() & 0x3fffffff))
+                out[(mode, count)] = res
+                tr.close()
+        for count in (False, True):
+            for mode in ("1", "all"):
+                for k, ((sa, ra, ta), (sb, rb, tb)) in enumerate(zip(out[("0", count)], out[(mode, count)])):
+                    for f in ("rays", "segments", "shaded", "received") + (("node_visits", "tri_tests", "walked_segments") if count else ()):
+                        assert sa[f] == sb[f], (name, mode, count, k, f, sa[f], sb[f])
+                    H.assert_prd_equal(ra["results"], rb["results"], "%s: batches %s, pulse %d" % (name, mode, k))
+                    assert np.array_equal(ra["slots"], rb["slots"]) and np.array_equal(ra["path"], rb["path"]) and ra["rcs_angle"].tobytes() == rb["rcs_angle"].tobytes()
+                    assert np.array_equal(ta == 1, tb == 1) and np.array_equal(ta == 0, tb == 0), (name, mode, count, k)      # the same tiles are dead, the same have no record
+        st, rec, _ = out[("all", False)][5]
+        assert st["rays"] == n_all and st["received"] > 20, (name, st["received"])
+        assert (out[("0", False)][2][2] == 1).sum() > 0.2 * len(out[("0", False)][2][2]), name      # (there ARE dead tiles to batch; the transmitter is outside every capture sphere)
+        if name in ("c3", "direct rays"):
+            mo = [dict(m, position=tuple(np.add(m["position"], (0.5 * 5, 4.0 * 5, -2.5 * 5)))) for m in spec["motion"]]
+            idx = rec["slots"][:: max(len(rec["slots"]) // 300, 1)].astype(np.int64)
+            sc = H.oracle_scene(oracle, spec, mo)
+            for i in idx[:300]:
+                o = sc.trace(tx["origin"], tx["span"], tx["dir"], spec["W"], spec["max_refl"], 0, spec["smooth"], ray_first=int(i), ray_stride=1, n_rays=1, use_bvh=False)
+                j = int(np.searchsorted(rec["slots"], i))
+                H.assert_prd_equal(o["results"][:1], rec["results"][j:j + 1], "launch index %d against the brute-force oracle" % i)
+
+
+def test_receiver_window_screen_is_invisible(rts, oracle, scenes, monkeypatch):
+    """round 5: the pre-filter also asks whether a primary ray that CROSSES a capture sphere can have a crossing point inside the receiver's
+    angular window (rts_rx_maybe: f32, no arctangent, an explicit error budget) -- a monostatic radar's sphere touches the transmitter
+    and every ray of the beam crosses it.  Conservative or wrong: with the screen (default) and without (RTS_RX_WINDOW_SCREEN=0) every
+    output buffer must hold the same bits, and the screened launch is held against the oracle's brute force ray by ray.  Scenes: the
+    monostatic sphere (transmitter ON it, a hair inside, a hair outside), the transmitter well inside, spheres ahead in the beam at
+    several impact parameters; for each a sweep of windows whose azimuth / elevation EDGE passes through the boresight ray's crossing
+    points (from well clear on one side to well clear on the other, in steps down to 1e-4 rad), narrow and wide windows; origin-centred
+    and Earth-centred (where the reference's own quadratic is off by centimetres); also with dead-tile batches screening whole tiles"""
+    import math
+    base = scenes.config_multi(W=26, max_refl=2)
+    tx = dict(origin=(-200.0, 3.0, -2.0), span=(0.10, 0.08, 0.05), dir=(0.02, -0.015))
+    o = np.asarray(tx["origin"]); az, el = tx["dir"]
+    bore = np.array([math.cos(az) * math.cos(el), math.sin(az) * math.cos(el), math.sin(el)])
+    side = np.cross(bore, (0.0, 0.0, 1.0)); side /= np.linalg.norm(side)
+    spheres = [("monostatic", o + 12.0 * bore, 12.0), ("a hair inside", o + 12.0 * bore * (1 - 2e-4), 12.0), ("a hair outside", o + 12.0 * bore * (1 + 2e-4), 12.0),
+               ("inside", o + 3.0 * bore + 2.0 * side, 12.0), ("ahead, central", o + 60.0 * bore, 9.0), ("ahead, off axis", o + 80.0 * bore + 2.5 * side, 4.0),
+               ("ahead, grazing", o + 50.0 * bore + 5.6 * side, 4.0)]
+    rng = np.random.default_rng(5)
+    n_checked = 0; n_received_direct = 0
+    for ecef in (False, True):
+        for name, c, r in spheres:
+            m = o - c; b = float(-m @ bore); disc = b * b - float(m @ m - r * r)
+            pts = [m + (b + sg * math.sqrt(max(disc, 0.0))) * bore for sg in (-1.0, 1.0)] if disc > 0 else [m / max(np.linalg.norm(m), 1e-9) * r]
+            rxs = []
+            for pnt in pts:
+                th = math.atan2(pnt[1], pnt[0]); ph = math.asin(max(-1.0, min(1.0, pnt[2] / np.linalg.norm(pnt))))
+                for hw in (0.02, 0.4, 1.2):
+                    for edge in (-3e-2, -1e-3, -1e-4, 0.0, 1e-4, 1e-3, 3e-2):
+                        rxs.append(scenes.rx_window(tuple(c), r, (th + edge, th + edge + 2 * hw), (max(ph - hw, -1.57), min(ph + hw, 1.57))))     # azimuth edge at the point
+                        rxs.append(scenes.rx_window(tuple(c), r, (th - hw, th + hw), (max(min(ph + edge, 1.5), -1.57), min(ph + edge + 2 * hw, 1.57))))   # elevation edge at the point
+            order = rng.permutation(len(rxs))
+            for g in range(0, min(len(rxs), 42), 14):                 # 14 receivers per launch (<= 16: the pre-filter is on), three launches of a random half of the sweep
+                spec = dict(base, name="window-%s" % name, tx=tx, rx=[rxs[i] for i in order[g:g + 14]])
+                if ecef:
+                    spec = scenes.translate(spec, scenes.ecef_offset(lat=0.7, lon=-2.0))
+                n = spec["W"] ** 3
+                out = {}
+                for mode in ("0", "1", "batch"):
+                    monkeypatch.setenv("RTS_RX_WINDOW_SCREEN", "0" if mode == "0" else "1")
+                    monkeypatch.setenv("RTS_DEAD_BATCH", "all" if mode == "batch" else "0")
+                    if mode == "batch":
+                        tp = H.gpu_tracer(rts, spec); _, sp_ = H.gpu_trace(rts, spec, tr=tp); out[mode] = (None, tp.received(), sp_); tp.close()
+                    else:
+                        tr, st = H.gpu_trace(rts, spec); out[mode] = (tr.all_rays(n), tr.received(), st); tr.close()
+                (a, ra, sa), (b_, rb, sb), (_, rc, sc) = out["0"], out["1"], out["batch"]
+                _all_equal(a, b_, "%s%s, group %d" % (name, " ecef" if ecef else "", g))
+                for x in (rb, rc):
+                    assert np.array_equal(ra["slots"], x["slots"]) and np.array_equal(ra["path"], x["path"]), (name, ecef, g)
+                    H.assert_prd_equal(ra["results"], x["results"], "%s (received)" % name)
+                assert (sa["segments"], sa["shaded"], sa["received"]) == (sb["segments"], sb["shaded"], sb["received"]) == (sc["segments"], sc["shaded"], sc["received"]), (name, ecef, g)
+                n_received_direct += int(((rb["results"]["reflDepth"] == 0) & (rb["results"]["received"] >= 0)).sum())
+                if g == 0:                                             # the screened launch against the oracle, every launch index
+                    oo = H.oracle_trace(oracle, spec, use_bvh=False, threads=8)
+                    H.compare_full(oo, b_, n)
+                    n_checked += 1
+    assert n_checked == 14 and n_received_direct > 1000                # (the sweeps DO capture direct rays: the screen is not vacuously "never")
+    monkeypatch.delenv("RTS_RX_WINDOW_SCREEN"); monkeypatch.delenv("RTS_DEAD_BATCH")
+
+
 def test_small_received_sets_one_block_path_is_invisible(rts, scenes, monkeypatch):
     """up to 4 096 received rays (2 048 where a sort key needs 64 bits) the ordering of the received set and the aggregation run as single-block kernels
     (k_recv_order_small, k_agg_order_small, k_agg_finish_small) instead of the chain of device-wide sorts and scans

@@ -48,9 +48,11 @@ def soup(rng, n_reg, n_sliver, n_fan, scale):
     return dict(tris=t, verts=v, normals=nrm, refl_coeff=float(rng.choice([0.8, -0.6, 1.0, 0.3])), refr_index=float(rng.choice([1.0, 1.3, 2.0])))
 
 
-def random_scene(seed, version=3, big=False):
+def random_scene(seed, version=4, big=False):
     """versions 1, 2: the generator as it was when the regression seeds of tests/test_gpu_parity.py were found (1: as first
-    written; 2: + the scenes biased towards an active pre-filter; 3: + many targets / receivers, NaN vertices, W = 1, deep chains)"""
+    written; 2: + the scenes biased towards an active pre-filter; 3: + many targets / receivers, NaN vertices, W = 1, deep chains;
+    4 (round 5): + receivers the pre-filter's WINDOW screen has to judge -- capture spheres the beam crosses, the transmitter on or near their
+    surface (a monostatic radar's), windows narrow enough for the screen to apply and aimed so that their EDGES pass near the crossing points)"""
     rng = np.random.default_rng(seed)
     v2 = version >= 3; friendly = version >= 2
     place = rng.choice(["origin", "far", "ecef"])
@@ -96,6 +98,32 @@ def random_scene(seed, version=3, big=False):
         else:
             c = off + rng.normal(0, 1.0, 3) * dist * rng.uniform(0.2, 2.0); r = float(dist * 10 ** rng.uniform(-2, -0.3))
         th0 = rng.uniform(-3.2, 3.2); ph0 = rng.uniform(-1.6, 1.6)
+        if version >= 4 and rng.random() < 0.6:
+            # a sphere in the path of the boresight ray, and a window whose edge lies near one of that ray's crossing points
+            bore = np.array([math.cos(az) * math.cos(el), math.sin(az) * math.cos(el), math.sin(el)])
+            how = rng.random()
+            r = float(10 ** rng.uniform(-0.5, 2.5) * scale)
+            if how < 0.35:                                             # monostatic: the sphere touches the transmitter (ray_tracer.cpp:903-905)
+                c = np.asarray(origin) + r * bore * (1.0 + (rng.normal(0, 1e-3) if rng.random() < 0.5 else 0.0)) + (rng.normal(0, 0.05 * r, 3) if rng.random() < 0.3 else 0.0)
+            elif how < 0.55:                                           # the transmitter inside
+                c = np.asarray(origin) + rng.normal(0, 1.0, 3) * r * rng.uniform(0.0, 0.6)
+            else:                                                      # ahead, crossed by (part of) the beam at any impact parameter
+                perp = np.cross(bore, rng.normal(0, 1, 3)); perp /= max(np.linalg.norm(perp), 1e-12)
+                c = np.asarray(origin) + bore * (r + dist * rng.uniform(0.01, 1.5)) + perp * r * rng.uniform(0.0, 1.2)
+            m = np.asarray(origin) - c; b = float(-m @ bore); disc = b * b - float(m @ m - r * r)
+            if disc > 0:
+                t = b + math.sqrt(disc) * (1.0 if (rng.random() < 0.5 or b - math.sqrt(disc) <= 0) else -1.0)
+                pnt = m + t * bore
+                th0 = math.atan2(pnt[1], pnt[0]); ph0 = math.asin(max(-1.0, min(1.0, pnt[2] / max(np.linalg.norm(pnt), 1e-300))))
+            hw_t = 10 ** rng.uniform(-2.0, 0.15); hw_p = 10 ** rng.uniform(-2.0, -0.1)
+            th0 += hw_t * rng.choice([0.0, 0.9, 1.0, 1.1, -0.9, -1.0, -1.1, 2.0]) + rng.normal(0, 0.02 * hw_t)      # the window's edge at / near the crossing point
+            ph0 += hw_p * rng.choice([0.0, 0.9, 1.0, 1.1, -0.9, -1.0, -1.1, 2.0]) + rng.normal(0, 0.02 * hw_p)
+            lo_p, hi_p = ph0 - hw_p, ph0 + hw_p
+            if rng.random() < 0.8:
+                lo_p, hi_p = max(lo_p, -math.pi / 2), min(hi_p, math.pi / 2)                               # (within the poles: the screen applies)
+            if hi_p > lo_p:
+                rx.append(scenes.rx_window(tuple(c), r, (th0 - hw_t, th0 + hw_t), (lo_p, hi_p)))
+                continue
         rx.append(scenes.rx_window(tuple(c), r, (th0 - rng.uniform(0.1, 3.2), th0 + rng.uniform(0.1, 3.2)), (ph0 - rng.uniform(0.1, 1.7), ph0 + rng.uniform(0.1, 1.7))))
     refr = rng.random() < 0.2
     W = int(rng.integers(6, 24 if refr else 41))
@@ -208,6 +236,10 @@ def main():
             d = run(spec, device_build=False, pre_filter=False)
             os.environ.pop("RTS_SPLIT_BUDGET", None)
             same(a, b, "seed %d: pre-filter on / off" % seed)
+            os.environ["RTS_RX_WINDOW_SCREEN"] = "0"                  # round 5: the pre-filter without its window screen (it then only asks whether a capture sphere is reached)
+            h = run(spec)
+            os.environ.pop("RTS_RX_WINDOW_SCREEN", None)
+            same(a, h, "seed %d: receiver window screen on / off" % seed)
             os.environ["RTS_WALK_VERSIONS"] = "0"                    # round 5: the default walks the octant versions of the node records; here the role fetch + sorted children
             g = run(spec); g2 = run(spec, device_build=False, pre_filter=False) if seed % 2 else run(spec, count_traversal=True)
             os.environ.pop("RTS_WALK_VERSIONS", None)

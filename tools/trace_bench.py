@@ -22,9 +22,13 @@ spec = {"c2": lambda: scenes.config2(rx_radius=200.0), "c3": lambda: scenes.conf
         "c3norx": lambda: scenes.config3(rx_radius=50.0), "c3empty": lambda: scenes.config3(rx_radius=50.0), "c3narrow": lambda: scenes.config3(rx_radius=50.0),
         "c3ecef": lambda: scenes.translate(scenes.config3(rx_radius=50.0), scenes.ecef_offset(lat=math.pi / 2)),
         "c3narrowecef": lambda: scenes.translate(scenes.config3(rx_radius=50.0), scenes.ecef_offset(lat=math.pi / 2)),
-        "c4s": lambda: scenes.config4(W=232), "c4": lambda: scenes.config4(), "c5": lambda: scenes.config5()}[which]()
+        "c4s": lambda: scenes.config4(W=232), "c4": lambda: scenes.config4(), "c4empty": lambda: scenes.config4(), "c4norx": lambda: scenes.config4(), "c5": lambda: scenes.config5()}[which]()
 if which == "c3nomesh":
     spec["meshes"] = []; spec["motion"] = []
+if which == "c4empty":
+    spec["meshes"] = []; spec["motion"] = []; spec["rx"] = []
+if which == "c4norx":
+    spec["rx"] = []
 if which == "c3empty":
     spec["meshes"] = []; spec["motion"] = []; spec["rx"] = []
 if which == "c3norx":
