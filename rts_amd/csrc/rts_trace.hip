@@ -1255,10 +1255,10 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR && COOP) ? 2 : ((REFR || COOP
     // unproven.  Product builds reload nothing from scratch (tests/test_host_logic.py checks the ISA).
     __shared__ uint32_t s_draw[RTS_BLOCK / 64];
     uint32_t draw_next = 0;
-#define RTS_DRAW() { const uint32_t dv_ = atomicAdd(&a.tile_ctr[(COOP ? RTS_OFF_CTR_COOP : 0) + ((AFFINE ? RTS_Q(0) * S : (COOP ? coop_x * S : 0u)) + RTS_LSTRIPE) * RTS_TILE_CTR_STRIDE], 1u); if (AFFINE) s_draw[RTS_OPAQUE_S(wave_u)] = dv_; else if (COUNT) s_draw[wave_u] = dv_; else draw_next = dv_; }
+#define RTS_DRAW() { const uint32_t dv_ = atomicAdd(&a.tile_ctr[(COOP ? RTS_OFF_CTR_COOP : 0) + ((AFFINE ? RTS_Q(0) * S : (COOP ? coop_x * S : 0u)) + RTS_LSTRIPE) * RTS_TILE_CTR_STRIDE], 1u); if (AFFINE) s_draw[RTS_OPAQUE_S(wave_u)] = dv_; else if (COUNT || KEEP_ALL) s_draw[wave_u] = dv_; else draw_next = dv_; }
     if (lane == 0) RTS_DRAW()
     for (;;) {
-      const uint32_t draw = __builtin_amdgcn_readfirstlane(AFFINE ? s_draw[RTS_OPAQUE_S(wave_u)] : (COUNT ? s_draw[wave_u] : draw_next));      // (AFFINE: in LDS like the counting builds' -- the kernel has no register for it across the tile loop, see above)
+      const uint32_t draw = __builtin_amdgcn_readfirstlane(AFFINE ? s_draw[RTS_OPAQUE_S(wave_u)] : ((COUNT || KEEP_ALL) ? s_draw[wave_u] : draw_next));      // (KEEP_ALL builds -- tests -- keep it in LDS too: their refraction instantiation parked it in scratch inside the tile loop)      // (AFFINE: in LDS like the counting builds' -- the kernel has no register for it across the tile loop, see above)
       const uint32_t per_stripe = AFFINE ? __builtin_amdgcn_readfirstlane(RTS_Q(3)) : (COOP ? (coop_len * (64u / coop_P) + RTS_SEG_STRIPES - 1u) / RTS_SEG_STRIPES : per_stripe_all);
       const uint32_t single_draws = AFFINE ? __builtin_amdgcn_readfirstlane(RTS_Q(4)) : (COOP ? per_stripe : (BATCHABLE ? __builtin_amdgcn_readfirstlane(RTS_SCHED(0)) : single_draws_all));      // (COOP: one unit per draw -- units are long)
       const uint32_t four_draws = BATCHABLE ? __builtin_amdgcn_readfirstlane(RTS_SCHED(1)) : 0u, k_dead = BATCHABLE ? __builtin_amdgcn_readfirstlane(RTS_SCHED(2)) : 0u;
