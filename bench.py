@@ -125,10 +125,17 @@ def cpu_baseline(spec, seconds_target=12.0):
     whole pulses of the same workload, repeated until ~seconds_target of CPU work.  kind = "port": the reference has no CPU
     path and cannot be built here."""
     os.environ["RTS_ORACLE_NATIVE"] = "1"
+    os.environ["RTS_ORACLE_PIN"] = "1"                     # one worker per hardware thread, pinned (oracle/rts_oracle.cpp: orc_trace)
     from oracle import oracle as O
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import helpers as H
-    threads = os.cpu_count() or 1
+    # every hardware thread of the machine: the GPU loop above bound this process to the GPU's NUMA node -- half the host on the two-socket boxes of
+    # this pool, where 256 unpinned threads then shared 128 hardware threads and a pulse took 498-749 ms from run to run (VERDICT r4, weak 10)
+    try:
+        os.sched_setaffinity(0, range(os.cpu_count() or 1))
+    except OSError:
+        pass
+    threads = len(os.sched_getaffinity(0)) or 1
     sc = H.oracle_scene(O, spec, pulse_motion(spec, 0))
     tx = spec["tx"]; W = spec["W"]; total = W ** 3
     n = 20000
@@ -150,7 +157,7 @@ def cpu_baseline(spec, seconds_target=12.0):
         what = "%d whole pulses (%d launch indices each): best %.1f, median %.1f, worst %.1f ms per pulse" % (reps, total, best * 1e3, float(np.median(times)) * 1e3, max(times) * 1e3)
         dt = time.time() - t0
         return dict(value=seg_pulse / best / 1e6, unit="Mrays/s", cores=threads, kind="port", cpu=cpu_model(), mean_value=seg / dt / 1e6,
-                    spread=dict(best_ms=best * 1e3, median_ms=float(np.median(times)) * 1e3, worst_ms=max(times) * 1e3, pulses=reps),
+                    spread=dict(best_ms=best * 1e3, median_ms=float(np.median(times)) * 1e3, worst_ms=max(times) * 1e3, pulses=reps, worst_over_best=max(times) / best, threads_pinned=True),
                     sample="%s (value = best of %d; mean %.1f Mrays/s): %d segments in %.1f s; oracle/rts_oracle.cpp in BVH mode, g++ -O3 -march=native -ffp-contract=off, %d threads on %s"
                            % (what, reps, seg / dt / 1e6, seg, dt, threads, cpu_model()))
     else:                                                  # a strided sample of one pulse
@@ -186,7 +193,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=3, help="pulses in flight per GPU; 1 = strictly sequential pulses")
     ap.add_argument("--config", default="c3", choices=["c2", "c2file", "c3", "c3ecef", "c3ico", "c4", "c5", "sphere6"], help="c3 = BASELINE configs[2] (the metric's workload); c4 = configs[3]'s scene and size (100 M launch indices per pulse: give --steps 32; --tx both: its two transmitters in turn); c5 = configs[4]: the C3 airframe re-rotated AND translated every pulse, 1024-pulse interval (give --steps 1024), the transmitter tracking it; sphere6 = the scene of the C++ boundary benchmark (tests/adapter/adapter_bench.cpp)")
     ap.add_argument("--tx", default="0", choices=["0", "1", "both"], help="c4: which of configs[3]'s two transmitters; both = the first half of the interval's pulses from transmitter 0, the second half from transmitter 1 (the reference's transmitter loop is the outer one, ray_tracer.cpp:806)")
-    ap.add_argument("--as-rank", default="", help="debug, one process: 'r/N' runs the plan rank r of N ranks would run (with --shard rays: its part of EVERY pulse), without a process group -- one GPU's share of a ray-sharded interval at the pipelined rate, every r in turn gives the critical path of an N-GPU run; value / ms_per_step are that rank's alone")
+    ap.add_argument("--as-rank", default="", help="debug, one process: 'r/N' runs the plan rank r of N ranks would run (--shard rays, the default here: its part of EVERY pulse; --shard pulses: its whole pulses and its parts of the left-over ones), without a process group -- one GPU's share of a ray-sharded interval at the pipelined rate, every r in turn gives the critical path of an N-GPU run; value / ms_per_step are that rank's alone")
     ap.add_argument("--deal", default="auto", choices=["auto", "interleave", "cost"], help="auto = cost for a multi-rank job, interleave with --as-rank.  --shard rays: 'cost' = after the warm-up pulses (traced as interleaved parts) the ranks exchange what every tile cost the rank that traced it (ONE all-reduce of a uint32 per 64 launch indices, outside the timed interval: it belongs to the previous interval), adopt the merged table as their tile history and trace the timed interval's pulses as tile lists dealt longest-first from it (rts_deal_tiles, rts_set_tile_list) instead of the static interleave.  With --as-rank the table comes from two whole pulses traced by this process (standing in for the other ranks)")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"], help="N > 1: which interval is the line's value.  'strong' (default, the north star's) = ONE interval of --steps pulses shared by the ranks; 'weak' = every rank runs --steps pulses, the interval is N x steps pulses (per-GPU work fixed as N grows -- pulses are independent, ray_tracer.cpp:843, and there is no collective in the data path).  The other one, and rank 0 alone on the strong interval, are measured by the same job and reported as secondary blocks")
     ap.add_argument("--shard", default="auto", choices=["auto", "pulses", "rays"], help="N > 1, the strong interval: deal whole pulses to the ranks, or split every pulse over all ranks; auto: rays when a rank would get fewer than 4 x --inflight whole pulses and its part of a pulse is >= 4 M launch indices (see the top of this file)")
@@ -275,15 +282,15 @@ def main():
         tx = spec["tx_list"][1]
     two_tx = args.tx == "both"
     plan_rank, plan_world = (int(args.as_rank.split("/")[0]), int(args.as_rank.split("/")[1])) if args.as_rank else (rank, world)
-    if args.as_rank and (world != 1 or not 0 <= plan_rank < plan_world or args.shard == "pulses"):
-        raise SystemExit("--as-rank r/N needs a single process, 0 <= r < N and --shard rays")
+    if args.as_rank and (world != 1 or not 0 <= plan_rank < plan_world):
+        raise SystemExit("--as-rank r/N needs a single process and 0 <= r < N")
     RAY_SHARD_MIN = 4_000_000                                     # launch indices of a rank's part of a pulse below which ray sharding measures launch overhead (top of this file)
 
     def resolve_shard(n_pulses, w):
-        if args.as_rank:
-            return "rays"
         if args.shard != "auto":
             return args.shard
+        if args.as_rank:
+            return "rays"
         return "rays" if (w > 1 and n_pulses < 4 * max(args.inflight, 1) * w and total // w >= RAY_SHARD_MIN) else "pulses"
 
     # the interval being run: the closures below read it (strong / weak / rank 0 alone differ in these five things only)
@@ -474,7 +481,7 @@ def main():
         interval uses the process group.  participate = False: this rank only keeps the barriers (rank 0 traces alone)."""
         clear_deal()
         cur.update(n_int=n_int_, n_warm=n_warm_, shard=shard_, rank=rank_, world=world_, collectives=collectives_)
-        attach_cube(max(n_int_, n_warm_))
+        attach_cube(max(n_int_, n_warm_, 3 * len(trs)))
         acc_ = resp_ = None; dt_ = 0.0
         if participate:
             if n_warm_:
@@ -491,7 +498,7 @@ def main():
                 for t in trs:
                     t.tile_records_set(table); t.set_tile_list(tile_, ids_)
                 dealt.update(tile=tile_, cost=[float(x) for x in cost_ / max(float(cost_.mean()), 1.0)], tiles_of_this_rank=int(ids_.shape[0]))
-                run_cpi(n_warm_, min(n_warm_, 2 * len(trs)))  # (every handle's first launch over its list: the cooperative stream, the order build of a new shape)
+                run_cpi(n_warm_, 3 * len(trs))                # (every handle's first launches over its list: the order build of a new shape, then the cooperative kernel's grid from the head count of the launch before -- three launches per handle until the schedule is the one the interval runs with)
             prepared = prepare_cpi(n_warm_, n_int_)
             # The harness is Python: its cyclic garbage collector, once a few thousand ctypes / numpy objects have been allocated by the
             # loop, makes full passes over everything torch imported (~40 ms each) -- measured as 0.15 ms per pulse in trace_begin at 256
@@ -507,7 +514,8 @@ def main():
         dt_ = time.perf_counter() - t0
         gc.enable()
         if participate:
-            assert len(resp_) == n_int_, "every pulse of the interval must come back with its responses"
+            expected = n_int_ if not args.as_rank else len({it[0] for it in prepared[0]})      # (--as-rank: one process stands for one rank, it sees the pulses of that rank's plan only)
+            assert len(resp_) == expected, "every pulse of the interval must come back with its responses"
         if dist is not None and collectives_:
             rdev = "cuda" if args.backend == "nccl" else "cpu"
             tt = torch.tensor([dt_], dtype=torch.float64, device=rdev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt_ = float(tt.item())

@@ -231,6 +231,7 @@ int rts_get_stats(RtsHandle h, RtsStats* out);
 /* Lane statistics of the last launch's traversal (counting build, RTS_FLAG_COUNT_TRAVERSAL): out3[0] walk iterations issued x 64
  * lanes, out3[1] the part issued to lanes that took part in their tile's bounce round, out3[2] walk steps actually taken. */
 int rts_get_lane_stats(RtsHandle h, uint64_t* out3);
+int rts_get_walk_stats(RtsHandle h, uint64_t* out, uint32_t n);   /* out[0..2] as rts_get_lane_stats; [3] segments that walked; [4] lane-steps issued to lanes that are in a bounce round but never started a walk in it (counting builds) */
 int rts_received_count(RtsHandle h, uint64_t* count);
 int rts_get_received(RtsHandle h, struct PerRayData* rays, int32_t* paths, double* rcs_angles, uint64_t* slots,
                      uint64_t capacity);
@@ -249,7 +250,9 @@ int rts_get_received(RtsHandle h, struct PerRayData* rays, int32_t* paths, doubl
  * rays (1 536 with refraction chains), otherwise it only marks the pulse and the first accessor's (blocking) rts_trace_pulse_end
  * feeds the mirror.  Either way the views equal rts_get_received / rts_get_aggregated bit for bit; sets beyond the mirror
  * (4 096 rays, or what the handle has seen) are served by copies.  View pointers stay valid until the handle's next
- * rts_trace_pulse_begin; rts_received_view's records are the set AS RECEIVED even after rts_finalise_values / rts_aggregate. */
+ * rts_trace_pulse_begin and keep their content: rts_received_view's records are the set as it was at the pulse's FIRST call of it --
+ * AS RECEIVED when that call precedes rts_finalise_values (the adapter's order) -- whatever rts_finalise_values / rts_aggregate /
+ * rts_aggregated_view do afterwards, also for sets beyond the mirror's capacity (served from copies made once per pulse). */
 int rts_received_prefetch(RtsHandle h);
 int rts_received_view(RtsHandle h, const struct PerRayData** rays, const int32_t** paths, const double** rcs_angles, const uint64_t** slots,
                       uint64_t* count);
@@ -372,7 +375,7 @@ int rts_plan_cpi(uint64_t total_rays, uint32_t n_pulses, uint32_t rank, uint32_t
  *                          the cooperative kernel's head tiles -- from what ANY worker measured
  *   rts_deal_tiles         host code, deterministic (every worker computes the same map from the same table): plan tiles of `tile`
  *                          launch indices (a multiple of 64) in descending cost, each to the worker with the least cost so far;
- *                          tiles without a record are dealt round-robin.  part_of_tile[ceil(total_rays / tile)] <- worker
+ *                          tiles without a record are then dealt by COUNT (ascending, each to the worker holding the fewest tiles).  part_of_tile[ceil(total_rays / tile)] <- worker
  *   rts_set_tile_list      the plan tiles (ascending, unique, < ceil(range / tile)) the handle's launches with
  *                          interleave_parts == RTS_INTERLEAVE_LIST trace; n_ids == 0 is an EMPTY list (a worker that was dealt nothing:
  *                          its launches trace no launch index and return empty sets); tile == 0 forgets the list */

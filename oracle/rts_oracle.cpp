@@ -53,6 +53,8 @@
 #include <set>
 #include <string>
 #include <thread>
+#include <pthread.h>
+#include <sched.h>
 #include <vector>
 
 // ------------------------------------------------------------------ ray_tracer.h:9-28
@@ -785,9 +787,14 @@ int orc_trace(void* s, const OPulse* p, uint64_t ray_first, uint64_t ray_stride,
         for (uint64_t i = r0*D; i < r1*D; i++) { targ_intersect[i] = -1; rcs_angle[2*i] = -1000000; rcs_angle[2*i+1] = -1000000; }
     };
     std::vector<OTraceCtx> ctxs(n_threads);
+    // RTS_ORACLE_PIN=1 (the timed CPU baseline of bench.py): worker t runs on the t-th CPU of the process's affinity mask -- one thread per
+    // hardware thread, no migration -- so that a pulse's time does not depend on where the scheduler happened to put 256 fresh threads
+    std::vector<int> pin_cpus;
+    if (const char* e = getenv("RTS_ORACLE_PIN")) if (e[0] == '1') { cpu_set_t m; CPU_ZERO(&m); if (sched_getaffinity(0, sizeof(m), &m) == 0) for (int k = 0; k < CPU_SETSIZE; k++) if (CPU_ISSET(k, &m)) pin_cpus.push_back(k); }
     const uint64_t CHUNK = 2048;                                   // launch indices per work unit, handed out dynamically:
     std::atomic<uint64_t> next_fill(0), next_ray(0), filled(0);    // rays that hit cluster in launch-index space
     auto worker = [&](int tid) {
+        if (!pin_cpus.empty() && n_threads > 1) { cpu_set_t m; CPU_ZERO(&m); CPU_SET(pin_cpus[(size_t)tid % pin_cpus.size()], &m); (void)pthread_setaffinity_np(pthread_self(), sizeof(m), &m); }
         OTraceCtx& cx = ctxs[tid];
         cx.sc = sc; cx.p = p; cx.d_maxReflDepth = p->maxRefl + 1; cx.d_maxRefrDepth = p->maxRefr; cx.depthTotal = D;
         cx.stride = n_rays; cx.useBvh = use_bvh != 0; cx.results = results; cx.targ_intersect = targ_intersect; cx.rcs_angle = (d2*)rcs_angle;

@@ -153,7 +153,7 @@ EXPORTS = ["rts_create", "rts_destroy", "rts_last_error", "rts_device_count", "r
            "rts_finalise_uniform", "rts_trace_pulse_end_uniform", "rts_aggregate", "rts_group_count", "rts_get_groups", "rts_get_aggregated",
            "rts_merge_groups", "rts_groups_to_responses", "rts_kernel_wrapper", "rts_vertex_rotation",
            "rts_rotation_matrix", "rts_rect_mesh", "rts_sphere_mesh", "rts_file_mesh", "rts_rx_sphere", "rts_get_bvh",
-           "rts_build_id", "rts_bind_host_to_device", "rts_get_lane_stats", "rts_self_test_math", "rts_cube_attach", "rts_cube_accumulate", "rts_cube_get", "rts_cube_accumulate_paths", "rts_cube_doppler", "rts_cube_doppler_get", "rts_plan_cpi", "rts_cube_reduce", "rts_kernel_wrapper_on",
+           "rts_build_id", "rts_bind_host_to_device", "rts_get_lane_stats", "rts_get_walk_stats", "rts_self_test_math", "rts_cube_attach", "rts_cube_accumulate", "rts_cube_get", "rts_cube_accumulate_paths", "rts_cube_doppler", "rts_cube_doppler_get", "rts_plan_cpi", "rts_cube_reduce", "rts_kernel_wrapper_on",
            "rts_received_prefetch", "rts_received_view", "rts_finalise_values", "rts_aggregated_view", "rts_build_hierarchy_host",
            "rts_tile_records_get", "rts_tile_records_set", "rts_deal_tiles", "rts_set_tile_list"]
 
@@ -209,7 +209,7 @@ def lib():
         "rts_get_bvh": [vp, vp, vp, vp, u32, u32, vp],
         "rts_cube_attach": [vp, C.POINTER(RtsCubeParams), vp],
         "rts_cube_accumulate": [vp, u32, dbl, dbl],
-        "rts_cube_get": [vp, vp, u64], "rts_get_lane_stats": [vp, vp], "rts_bind_host_to_device": [C.c_int, C.POINTER(C.c_int)],
+        "rts_cube_get": [vp, vp, u64], "rts_get_lane_stats": [vp, vp], "rts_get_walk_stats": [vp, vp, C.c_uint32], "rts_bind_host_to_device": [C.c_int, C.POINTER(C.c_int)],
         "rts_cube_accumulate_paths": [vp, u32], "rts_cube_doppler": [vp, u32, vp], "rts_cube_doppler_get": [vp, vp, u64],
         "rts_plan_cpi": [u64, u32, u32, u32, u32, u32, u32, vp, u32, C.POINTER(u32)],
         "rts_cube_reduce": [vp, u32, C.c_int],

@@ -728,7 +728,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     const uint32_t n_targets = (uint32_t)c->scene->meshes.size();
     hipStream_t st = c->stream;
     c->agg_valid = false; c->agg_pending.valid = false; c->n_recv = 0;
-    c->mirror.want = false; c->mirror.recv_valid = false; c->mirror.agg_valid = false;
+    c->mirror.want = false; c->mirror.recv_valid = false; c->mirror.agg_valid = false; c->v_recv_have = 0;
 
     // ---- scene placement: only when a target actually moved
     RTS_HIP(hipEventRecord(c->ev[0], st));
@@ -931,7 +931,7 @@ static void rts_pulse_account(RtsContext* c, const unsigned long long* cnt)
     s.rays = n; s.segments = cnt[1]; s.shaded = cnt[2]; s.received = cnt[0]; s.node_visits = cnt[3]; s.tri_tests = cnt[4]; s.stack_overflows = (uint32_t)cnt[5];
     s.n_prims = c->scene->n_prims; s.n_nodes = c->scene->n_nodes;
     s.walked_segments = cnt[11]; s.cost_records_dropped = (uint32_t)cnt[12];
-    if (c->debug_coop && (cnt[12] || cnt[14])) fprintf(stderr, "[rts] clocks: %llu cost records dropped; shader clock ran backwards on %llu tiles (XCC mask 0x%llx)\n", cnt[12], cnt[14], cnt[15]);
+    if (c->debug_coop && (cnt[12] || cnt[14])) fprintf(stderr, "[rts] clocks: %llu cost records dropped; shader clock ran backwards on %llu tiles (XCC mask 0x%llx)\n", cnt[12], cnt[14] & 0x00ffffffffffffffULL, cnt[14] >> 56);
     s.coop_tiles = c->last_coop_grid ? (uint32_t)std::min<unsigned long long>(std::min<unsigned long long>(cnt[7], (n + RTS_WTILE - 1) / RTS_WTILE), 16384ull) : 0u;      // (the bounds k_trace applies to the order's head count)
     c->pre_dense = 2 * s.shaded > (uint64_t)n;                      // next launch of this handle: pre-filter only if most launch indices hit nothing
     s.ms_scene = s.ms_trace = s.ms_compact = s.ms_aggregate = 0;
@@ -1009,6 +1009,19 @@ extern "C" int rts_get_lane_stats(RtsHandle c, uint64_t* out3)
     return RTS_OK;
 }
 
+// ... and the split VERDICT r4 #3 asked for: out[0..2] as rts_get_lane_stats, out[3] segments that walked at all, out[4] lane-steps issued to
+// lanes that are in their tile's bounce round but never started a walk in it (a primary the pre-filter or every bounding sphere cleared, in a
+// tile other lanes of which walk): out[4] / out[0] is what packing live launch indices of several tiles into dense waves could recover at most;
+// (out[1] - out[2] - out[4]) / out[0] what waiting for the round's slowest WALKING lane costs.  n: capacity of out (<= 5 values are written).
+extern "C" int rts_get_walk_stats(RtsHandle c, uint64_t* out, uint32_t n)
+{
+    if (!c || !out) { rts_set_error("rts_get_walk_stats: null argument"); return RTS_ERR_INVALID; }
+    CHECK_CLOSED(c);
+    const int src[5] = {8, 9, 10, 11, 15};
+    for (uint32_t k = 0; k < n && k < 5u; k++) out[k] = c->pin->cnt[src[k]];
+    return RTS_OK;
+}
+
 extern "C" int rts_received_count(RtsHandle c, uint64_t* count)
 {
     if (!c || !count) { rts_set_error("rts_received_count: null argument"); return RTS_ERR_INVALID; }
@@ -1059,7 +1072,7 @@ extern "C" int rts_finalise_uniform(RtsHandle c, const double* rcs_per_target, d
     int rc = rts_post_finalise(c, rcs_per_target, wavelength, gt, gr, carrier, cspeed); if (rc != RTS_OK) return rc;
     RTS_HIP(hipEventRecord(c->ev[7], c->stream));
     c->fin_timed = true; c->stats_pending = true;
-    c->agg_valid = false; c->mirror.recv_valid = false;
+    c->agg_valid = false;      // (the mirror keeps the set AS RECEIVED for the rest of the pulse: rts_received_view)
     return RTS_OK;
 }
 
@@ -1079,7 +1092,7 @@ static int rts_aggregate_impl(RtsContext* c, double cspeed, double carrier, uint
                                   c->d_delay.p, c->d_phase.p, c->d_pathmatch.p, &c->groups, nullptr, nullptr, nullptr, INT32_MAX, use_rows ? c->d_rx_slots.p : nullptr);
     c->agg_delay_in = true;
     if (rc != RTS_OK) return rc;
-    c->mirror.recv_valid = false;                                       // (the rays' power / Doppler are the group values now: the mirror holds the set as it was received)
+    // (the rays' power / Doppler on the device are the group values now; the mirror still holds the set as it was received, and rts_received_view keeps serving it)
     if (c->mirror.want) { rc = rts_post_mirror_aggregated(c); if (rc != RTS_OK) return rc; }
     RTS_HIP(hipEventRecord(c->ev[7], c->stream));
     c->agg_timed = true; c->stats_pending = true;
@@ -1118,7 +1131,7 @@ static int rts_post_chain(RtsContext* c, bool ordered = false)      // ordered: 
         c->agg_pending.valid = false; c->groups.clear();
         rc = rts_post_all_small(c, (uint32_t)c->n_recv, q, true); if (rc != RTS_OK) return rc;
         RTS_HIP(hipEventRecord(c->ev[7], st));
-        c->fin_timed = true; c->agg_timed = true; c->stats_pending = true; c->agg_valid = true; c->mirror.recv_valid = false;
+        c->fin_timed = true; c->agg_timed = true; c->stats_pending = true; c->agg_valid = true;
         return RTS_OK;
     }
     if (!ordered) {
@@ -1246,11 +1259,14 @@ extern "C" int rts_received_view(RtsHandle c, const PerRayData** rays, const int
         if (rcs_angles) *rcs_angles = (const double*)(m.host + m.o_angles); if (slots) *slots = (const uint64_t*)(m.host + m.o_slots);
         return RTS_OK;
     }
-    // no mirror of this set (not asked for, or larger than the mirror): copies into storage the handle keeps
-    if (rays) { c->v_rays.resize(R); RTS_HIP(hipMemcpy(c->v_rays.data(), c->d_rx_rays.p, sizeof(PerRayData) * R, hipMemcpyDeviceToHost)); *rays = c->v_rays.data(); }
-    if (paths && D) { c->v_paths.resize(R * D); RTS_HIP(hipMemcpy(c->v_paths.data(), c->d_rx_paths.p, sizeof(int32_t) * R * D, hipMemcpyDeviceToHost)); *paths = c->v_paths.data(); }
-    if (rcs_angles && D) { c->v_angles.resize(2 * R * D); RTS_HIP(hipMemcpy(c->v_angles.data(), c->d_rx_angles.p, sizeof(double) * 2 * R * D, hipMemcpyDeviceToHost)); *rcs_angles = c->v_angles.data(); }
-    if (slots) { c->v_slots.resize(R); RTS_HIP(hipMemcpy(c->v_slots.data(), c->d_rx_slots.p, sizeof(uint64_t) * R, hipMemcpyDeviceToHost)); *slots = c->v_slots.data(); }
+    // no mirror of this set (not asked for, or larger than the mirror): copies into storage the handle keeps.  Each array is read from the
+    // device ONCE per pulse (v_recv_have): pointers handed out earlier stay valid and keep their content -- the records as they were at the
+    // pulse's first call, i.e. AS RECEIVED when that call came before rts_finalise_values (a second call used to re-read records
+    // the finalisation had changed, and rts_aggregated_view's fallback overwrote them with group values)
+    if (rays) { if (!(c->v_recv_have & 1u)) { c->v_rays.resize(R); RTS_HIP(hipMemcpy(c->v_rays.data(), c->d_rx_rays.p, sizeof(PerRayData) * R, hipMemcpyDeviceToHost)); c->v_recv_have |= 1u; } *rays = c->v_rays.data(); }
+    if (paths && D) { if (!(c->v_recv_have & 2u)) { c->v_paths.resize(R * D); RTS_HIP(hipMemcpy(c->v_paths.data(), c->d_rx_paths.p, sizeof(int32_t) * R * D, hipMemcpyDeviceToHost)); c->v_recv_have |= 2u; } *paths = c->v_paths.data(); }
+    if (rcs_angles && D) { if (!(c->v_recv_have & 4u)) { c->v_angles.resize(2 * R * D); RTS_HIP(hipMemcpy(c->v_angles.data(), c->d_rx_angles.p, sizeof(double) * 2 * R * D, hipMemcpyDeviceToHost)); c->v_recv_have |= 4u; } *rcs_angles = c->v_angles.data(); }
+    if (slots) { if (!(c->v_recv_have & 8u)) { c->v_slots.resize(R); RTS_HIP(hipMemcpy(c->v_slots.data(), c->d_rx_slots.p, sizeof(uint64_t) * R, hipMemcpyDeviceToHost)); c->v_recv_have |= 8u; } *slots = c->v_slots.data(); }
     return RTS_OK;
 }
 
@@ -1281,7 +1297,7 @@ extern "C" int rts_finalise_values(RtsHandle c, const double* power, const doubl
     }
     RTS_HIP(hipEventRecord(c->ev[7], c->stream));
     c->fin_timed = true; c->stats_pending = true;
-    c->agg_valid = false; c->mirror.recv_valid = false;
+    c->agg_valid = false;      // (the mirror keeps the set AS RECEIVED for the rest of the pulse: rts_received_view)
     return RTS_OK;
 }
 
@@ -1306,9 +1322,9 @@ extern "C" int rts_aggregated_view(RtsHandle c, const double** power, const doub
         return RTS_OK;
     }
     if (power || doppler) {
-        c->v_rays.resize(R); RTS_HIP(hipMemcpy(c->v_rays.data(), c->d_rx_rays.p, sizeof(PerRayData) * R, hipMemcpyDeviceToHost));
+        c->v_agg_rays.resize(R); RTS_HIP(hipMemcpy(c->v_agg_rays.data(), c->d_rx_rays.p, sizeof(PerRayData) * R, hipMemcpyDeviceToHost));      // (scratch of its own: rts_received_view's records stay as they were)
         c->v_apower.resize(R); c->v_adoppler.resize(R);
-        for (uint64_t i = 0; i < R; i++) { c->v_apower[i] = c->v_rays[i].power; c->v_adoppler[i] = c->v_rays[i].doppler; }
+        for (uint64_t i = 0; i < R; i++) { c->v_apower[i] = c->v_agg_rays[i].power; c->v_adoppler[i] = c->v_agg_rays[i].doppler; }
         if (power) *power = c->v_apower.data(); if (doppler) *doppler = c->v_adoppler.data();
     }
     if (delay) { c->v_adelay.resize(R); RTS_HIP(hipMemcpy(c->v_adelay.data(), c->d_delay.p, sizeof(double) * R, hipMemcpyDeviceToHost)); *delay = c->v_adelay.data(); }
@@ -1488,23 +1504,35 @@ extern "C" int rts_deal_tiles(const uint32_t* records, uint32_t n_records, uint6
     for (uint32_t t = 0; t < n_plan; t++) {
         uint64_t v = 0; const uint64_t w0 = (uint64_t)t * per, w1 = std::min<uint64_t>(w0 + per, n_records);
         for (uint64_t w = w0; w < w1; w++) v += records[w] & 0x3fffffffu;
-        cost[t] = v ? v : 1;                                       // (a tile nobody traced yet: dealt like the cheapest, so that the COUNTS balance too)
+        cost[t] = v;                                               // 0: a tile nobody traced yet
     }
-    std::vector<uint32_t> order(n_plan);
-    for (uint32_t t = 0; t < n_plan; t++) order[t] = t;
+    std::vector<uint32_t> order; order.reserve(n_plan);
+    for (uint32_t t = 0; t < n_plan; t++) if (cost[t]) order.push_back(t);
     std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
-    // min-heap of (load, worker)
+    // the tiles WITH a record: longest first, each to the worker with the least cost so far -- min-heap of (load, worker)
     std::vector<std::pair<uint64_t, uint32_t>> heap(parts);
     for (uint32_t r = 0; r < parts; r++) heap[r] = {0, r};
     auto cmp = [](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& b) { return a > b; };
     std::make_heap(heap.begin(), heap.end(), cmp);
-    for (uint32_t k = 0; k < n_plan; k++) {
+    std::vector<uint64_t> n_of(parts, 0);
+    for (uint32_t k = 0; k < (uint32_t)order.size(); k++) {
         std::pop_heap(heap.begin(), heap.end(), cmp);
         std::pair<uint64_t, uint32_t>& top = heap.back();
-        part_of_tile[order[k]] = top.second; top.first += cost[order[k]];
+        part_of_tile[order[k]] = top.second; top.first += cost[order[k]]; n_of[top.second]++;
         std::push_heap(heap.begin(), heap.end(), cmp);
     }
-    if (cost_of_part) for (const auto& h : heap) cost_of_part[h.second] = h.first;
+    std::vector<uint64_t> load(parts, 0);
+    for (const auto& h : heap) load[h.second] = h.first;
+    // the tiles WITHOUT a record (the first interval, a partial table, records a launch dropped): nothing is known about their cost, so their
+    // COUNT is balanced -- in ascending tile order, each to the worker holding the fewest tiles so far (as cost-1 entries of the
+    // heap above they all went to the lightest workers: 64 tiles, records {500, 100, 50}, three workers: 0 / ~6 / ~55 of the 61)
+    for (uint32_t t = 0; t < n_plan; t++) {
+        if (cost[t]) continue;
+        uint32_t best = 0;
+        for (uint32_t r = 1; r < parts; r++) if (n_of[r] < n_of[best]) best = r;
+        part_of_tile[t] = best; n_of[best]++; load[best] += 1;
+    }
+    if (cost_of_part) for (uint32_t r = 0; r < parts; r++) cost_of_part[r] = load[r];
     return RTS_OK;
 }
 

@@ -310,7 +310,9 @@ struct RtsContext {
     DevBuf<RtsEndRecord> d_recv, d_all; DevBuf<unsigned long long> d_block_counters, d_timeline; unsigned long long* p_counters = nullptr;      // (the 16 counters live behind the draw counters: one fill zeroes both)
     DevBuf<uint32_t> d_tile_cost, d_tile_key, d_tile_key_sorted, d_tile_id, d_tile_order, d_tile_hist, d_tile_ctr;
     uint32_t coop_floor = 7500;         // ... more than this many cost units (shader clocks >> 6; 7 500 = 0.2 ms of one wave) (RTS_COOP_FLOOR)
-    uint32_t coop_walk_steps_lo = 400; double coop_mid = 3.0;      // LONGISH WALKS (RTS_COOP_STEPS_LO) go to the head only if the tile cost more than coop_mid x the balanced time (RTS_COOP_MID; 0: never)
+    uint32_t coop_walk_steps_lo = 400; double coop_mid = 1.5;      // LONGISH WALKS (RTS_COOP_STEPS_LO) go to the head only if the tile cost more than coop_mid x the balanced time (RTS_COOP_MID; 0: never).  3 in round 4;
+                                        // re-scanned in round 5, when the dead work had left the balanced time and the cooperative records had stopped flip-flopping (rts_record_to_keep): 1.5 takes a lone
+                                        // BASELINE configs[3] launch from 7.4 to 4.75 ms and the pipelined pulse from 5.23 to 5.06, configs[2] / [4] / [1] do not move (profiles/r05c_coop_mid_scan.log)
     uint32_t coop_walk_steps = 1000;     // ... and whose bounce rounds took at least this many walk iterations each, on average (RTS_COOP_STEPS; 0: every tile above the floor is flagged) --
                                         // counted by the kernel, so neither other pulses sharing the GPU nor a launch that is all tail move it
     double coop_big_part = 1.5, coop_big_now = 0.0;      // coop_big for a launch that is a PART of a pulse (interleaved or dealt tiles) on a GPU no other pulse shares (RTS_COOP_BIG_PART; 0: off) -- one
@@ -364,6 +366,7 @@ struct RtsContext {
     RtsAggPending agg_pending;          // the group table of the last rts_aggregate is still on its way (rts_aggregate_fetch reads it)
     RtsHostMirror mirror;               // rts_received_prefetch / rts_received_view / rts_finalise_values / rts_aggregated_view
     std::vector<PerRayData> v_rays; std::vector<int32_t> v_paths; std::vector<double> v_angles, v_apower, v_adoppler, v_adelay, v_aphase; std::vector<uint64_t> v_slots; std::vector<int32_t> v_apm;      // the views' fallback storage (sets beyond the mirror's capacity)
+    std::vector<PerRayData> v_agg_rays; unsigned v_recv_have = 0;      // rts_aggregated_view's own scratch (never the received view's storage); bits: which of v_rays / v_paths / v_angles / v_slots hold THIS pulse's set already
     RtsRxDev* pin_rx = nullptr; uint32_t pin_rx_cap = 0; std::vector<RtsRxDev> rx_host;      // receivers: last values set (an unchanged set is not uploaded again) and the pinned staging of the asynchronous upload
     RtsCubeParams cube_params; double* cube = nullptr; DevBuf<double> d_cube_own; bool cube_set = false;
     DevBuf<double> d_doppler_own; double* doppler = nullptr; uint32_t doppler_n = 0;       // slow-time transform of the cube (rts_cube_doppler)

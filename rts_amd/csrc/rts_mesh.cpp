@@ -167,8 +167,8 @@ extern "C" int rts_file_mesh(const char* v_file, const char* n_file, float yaw, 
     // The reference's loop tests fscanf() == EOF only (:459-476): a line that yields fewer than its nine numbers -- a missing
     // comma, a word where a number belongs -- leaves the remaining coordinates at whatever the vector held (zeros) and the
     // stream wherever the match failed, i.e. a silently wrong mesh (NaN normals downstream).  A C-ABI that promises status codes
-    // reports it: RTS_ERR_IO naming the file and the 1-based triangle (line) that did not parse.  Well-formed files -- the only
-    // ones whose result the reference defines -- read exactly as there.
+    // reports it: RTS_ERR_IO naming the file and the 1-based triangle (line) that did not parse.  Every file the reference reads
+    // correctly -- nine numbers per line, with or without the final comma -- reads exactly as there.
     // (line by line: a line with too few numbers must not borrow the next line's -- fscanf's white space crosses line ends)
     auto read9 = [&](FILE* f, double* dst, uint32_t* bad_line, int* got) -> bool {
         char* line = nullptr; size_t cap = 0; bool ok = true;
@@ -176,10 +176,11 @@ extern "C" int rts_file_mesh(const char* v_file, const char* n_file, float yaw, 
             double* p = dst + 9*(size_t)i;
             int n = EOF, used = -1;
             if (getline(&line, &cap, f) >= 0) {
-                n = sscanf(line, "%lf %lf %lf, %lf %lf %lf, %lf %lf %lf,%n", p, p+1, p+2, p+3, p+4, p+5, p+6, p+7, p+8, &used);
+                n = sscanf(line, "%lf %lf %lf, %lf %lf %lf, %lf %lf %lf%n", p, p+1, p+2, p+3, p+4, p+5, p+6, p+7, p+8, &used);
                 if (n == EOF) n = 0;                                   // (an empty line)
-                if (n == 9 && used < 0) n = 8;                         // the closing comma is missing
-                if (n == 9) for (const char* q = line + used; *q; q++) if (!isspace((unsigned char)*q)) { n = 10; break; }      // something behind it
+                // behind the ninth number: the closing comma -- or nothing: the reference's fscanf has matched its nine conversions by then and
+                // returns 9 with or without it (ray_tracer.cpp:461), and goes on with the next line either way -- and white space only
+                if (n == 9) { const char* q = line + used; while (isspace((unsigned char)*q)) q++; if (*q == ',') q++; for (; *q; q++) if (!isspace((unsigned char)*q)) { n = 10; break; } }
             }
             if (n != 9) { *bad_line = i + 1; *got = n; ok = false; }
         }

@@ -146,7 +146,7 @@ __device__ __forceinline__ uint32_t tile_global(const RtsTileShape& s, uint32_t 
 struct RtsHeadRule { double frac, big, mid; uint32_t floor_cost, resident_waves; };
 // A tile goes to the head of the order -- to the cooperative kernel -- if its cost record says
 //   LONG WALKS (bit 31: >= coop_walk_steps walk iterations per bounce round, 1 000) and it cost more than frac x the launch's balanced time; or
-//   LONGISH WALKS (bit 30: >= coop_walk_steps_lo, 400) and it cost more than mid x the balanced time (3: alone it would triple the
+//   LONGISH WALKS (bit 30: >= coop_walk_steps_lo, 400) and it cost more than mid x the balanced time (1.5 since round 5; 3 before: alone it would triple the
 //   launch -- a launch that consists of its tail, e.g. one GPU's eighth of a BASELINE configs[3] pulse, where the ~5 x more work of
 //   64 units with short walks is free because the chip is idle; in a launch that is busy throughout the same tile stays where it is:
 //   BASELINE configs[4] lost 9 % when such tiles were made cooperative, profiles/r04_coop_steps_scan.log); or
@@ -157,6 +157,20 @@ __device__ __forceinline__ bool rts_head_rule(const uint32_t est, const double c
     return ((est >> 31) && cost > thr) || (rule.mid > 0.0 && ((est >> 30) & 1u) && balanced > 0.0 && cost > thr_mid) || (rule.big > 0.0 && balanced > 0.0 && cost > thr_big);
 }
 
+// A record left by the COOPERATIVE kernel (bit 31 without bit 30: the ordinary kernel never writes that -- its LONG WALKS imply LONGISH) is the sum
+// of the tile's 64 units' wave time, and that is NOT "at least what the tile costs one wave" (round 3's assumption): a tile with one straggling
+// ray of 6 ms is walked by 64 lanes in 0.1 ms, its units sum to less than the head rule's threshold, the next launch hands it back to the
+// ordinary kernel -- 6 ms again, one wave, the launch's tail -- and the launch after that makes it cooperative again (BASELINE configs[3] with
+// longish tiles admitted: lone launches 5.0 / 6.1 / 5.0 / 6.1 ms, the ordinary kernel 4.0 / 5.9, profiles/r05c_c4_tail_scan.log).  Such a record keeps
+// the larger of its own cost and 0.95 x what the history held: a tile stays at the head while it deserves to (its last ordinary cost decays over
+// ~20 launches) and one that has become cheap -- the target moved on -- leaves it.  The LAUNCH's cost sum takes what was measured.
+__device__ __forceinline__ uint32_t rts_record_to_keep(const uint32_t v, const uint32_t old)
+{
+    if ((v >> 30) != 2u) return v;
+    const uint32_t keep = (uint32_t)(0.95f * (float)(old & 0x3fffffffu));
+    return 0x80000000u | max(v & 0x3fffffffu, keep);
+}
+
 // fold the costs measured by the previous launch into the history
 __global__ void k_tile_merge(uint32_t* __restrict__ cost, RtsTileShape prev, uint32_t* __restrict__ hist, uint32_t n_hist, unsigned long long* __restrict__ head_sum, uint32_t* __restrict__ coarse)
 {
@@ -164,7 +178,7 @@ __global__ void k_tile_merge(uint32_t* __restrict__ cost, RtsTileShape prev, uin
     unsigned long long v64 = 0;
     if (j < prev.n_tiles) {
         const uint32_t v = cost[j], g = tile_global(prev, j);
-        if (v && g < n_hist) hist[g] = v;
+        if (v && g < n_hist) hist[g] = rts_record_to_keep(v, hist[g]);
         v64 = v & 0x3fffffffu;
         cost[j] = 0u;                                                          // (ready for the coming launch: no fill of its own)
     }
@@ -318,9 +332,10 @@ __global__ void k_tile_merge_keys(uint32_t* __restrict__ cost, RtsTileShape cur,
         uint32_t is_head = 0;
         if (j < cur.n_tiles) {
             const uint32_t v = cost[j], g = tile_global(cur, j);
-            if (v && g < n_hist) hist[g] = v;
+            const uint32_t vk = (v && g < n_hist) ? rts_record_to_keep(v, hist[g]) : v;
+            if (v && g < n_hist) hist[g] = vk;
             cost[j] = 0u;
-            uint32_t est = v ? v : (g < n_hist ? hist[g] : 0u);
+            uint32_t est = v ? vk : (g < n_hist ? hist[g] : 0u);
             v64 += v & 0x3fffffffu;
             const uint32_t c = est & 0x3fffffffu;
             if (head_count && rule.frac > 0.0) {
@@ -430,7 +445,7 @@ int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_vali
                                            s.n_tiles = (uint32_t)((sig[0] + RTS_WTILE - 1) / RTS_WTILE); s.il_list = s.il_parts == RTS_INTERLEAVE_LIST ? c->d_il_list.p : nullptr; return s; };
     uint32_t* head = c->coop_frac > 0.0 ? c->d_tile_ctr.p + RTS_OFF_HEAD : nullptr;      // [sum lo, sum hi, count, pad]: zeroed with the draw counters
     uint32_t* bins = c->tile_bucket_order ? c->d_tile_ctr.p + RTS_OFF_BINS : nullptr;      // zeroed with the draw counters
-    // XCD-AFFINE sub-orders (RtsContext::xcd_affine: 0 never, 1 whenever there is a counting order, 2 -- the default -- for launches of
+    // XCD-AFFINE sub-orders (RtsContext::xcd_affine: 0 never -- the default: measured slower, DESIGN.md section 5 --, 1 whenever there is a counting order, 2 for launches of
     // >= 2^18 wave tiles, i.e. BASELINE configs[3]'s 100 M launch indices, whose scene is a hundred times an XCD's L2)
     const bool affine = bins != nullptr && (c->xcd_affine == 1 || (c->xcd_affine == 2 && n_tiles_cur >= (1u << 18)));
     c->xcd_affine_now = affine;

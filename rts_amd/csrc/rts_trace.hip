@@ -762,21 +762,24 @@ __device__ __forceinline__ bool rts_segment_maybe(const RtsLaunchConsts& lc, con
     for (uint32_t Rx_i = 0; Rx_i < n_rx; Rx_i++) if (rts_rx_maybe(rxp[Rx_i], ax, ay, az, dd, delta)) return true;      // (end a stands for the bundle: every ray is within delta of it)
     return false;
 }
-// ... of a WAVE TILE: 64 consecutive launch indices (aligned launches only: consecutive GLOBAL indices) = one row segment, or the end of one
-// row and the start of the next (W >= 64)
+// ... of a WAVE TILE: 64 consecutive launch indices (aligned launches only: consecutive GLOBAL indices) = one row segment of the lattice, or
+// the end of one row and the start of the next -- or, W < 64, several whole rows: the segments are taken one after the other
+// (ONE inlined copy of the segment test in a loop: inlined at two call sites its loop-invariant addresses were hoisted into vector
+// registers of the tile loop -- and from there into scratch)
 __device__ __forceinline__ bool rts_tile_maybe(const RtsLaunchConsts& lc, const uint32_t tile, const uint32_t n_rays, const bool has_prims, const bool mask_on, const uint32_t* __restrict__ pmask,
                                                const uint32_t n_rx, const float (*rxp)[RTS_RXP_N])
 {
     const uint32_t s0 = tile * 64u, s1 = min(s0 + 63u, n_rays - 1u);
-    uint32_t lx0, ly0, lz0, lx1, ly1, lz1;
-    rts_lattice_coords(lc, s0, lx0, ly0, lz0); rts_lattice_coords(lc, s1, lx1, ly1, lz1);
-    const bool one_row = ly0 == ly1 && lz0 == lz1;
-    if (one_row && lx1 < lx0) return true;                            // (cannot be: said for safety)
-    // (ONE inlined copy of the segment test, run once or twice: inlined at two call sites its loop-invariant addresses were hoisted into
-    // vector registers of the tile loop -- and from there into scratch)
+    uint32_t lx, ly, lz;
+    rts_lattice_coords(lc, s0, lx, ly, lz);
+    uint32_t left = s1 - s0 + 1u;
     bool maybe = false;
-    for (uint32_t seg = 0; seg < (one_row ? 1u : 2u) && !maybe; seg++)
-        maybe = rts_segment_maybe(lc, seg == 0u ? lx0 : 0u, (seg == 0u && !one_row) ? lc.W - 1u : lx1, seg == 0u ? ly0 : ly1, seg == 0u ? lz0 : lz1, has_prims, mask_on, pmask, n_rx, rxp);
+    while (left != 0u && !maybe) {
+        const uint32_t n = min(left, lc.W - lx);
+        maybe = rts_segment_maybe(lc, lx, lx + n - 1u, ly, lz, has_prims, mask_on, pmask, n_rx, rxp);
+        left -= n; lx = 0u;
+        if (++ly == lc.W) { ly = 0u; lz++; }
+    }
     return maybe;
 }
 
@@ -799,7 +802,7 @@ __device__ __forceinline__ void rts_primary_setup(const RtsTraceArgs& a, const R
 template <bool COUNT, bool KEEP_ALL, bool REFR, bool COOP, bool VERS = false>
 __device__ __forceinline__ void rts_trace_unit(const RtsTraceArgs& a, const RtsLaunchConsts& lc, const RtsUnitLds& L_, const uint32_t tid, const uint32_t gtid, const uint32_t lane,
                                                const uint32_t slot, const bool pre_on, const bool mask_on, const uint32_t D, const uint32_t max_refr, const dvec3& origin,
-                                               uint32_t& n_nodes, uint32_t& n_tris, bool& hard_overflow, unsigned long long (&lane_stats)[4],
+                                               uint32_t& n_nodes, uint32_t& n_tris, bool& hard_overflow, unsigned long long (&lane_stats)[5],
                                                const uint32_t pre = 0u)      // pre: bit 0 = k_trace ran the pre-filter already, bits 1 / 2 = its may_target / may_rx
 {
       int32_t* const s_stack = L_.stack; int32_t* const s_exch = L_.exch; double* const s_first = L_.first; unsigned long long* const s_path = L_.path; uint32_t* const s_n = L_.n;
@@ -907,6 +910,7 @@ __device__ __forceinline__ void rts_trace_unit(const RtsTraceArgs& a, const RtsL
                 const uint32_t smax = ls[0], ssum = ls[1];
                 lane_stats[0] += 64ull * smax; lane_stats[1] += (unsigned long long)__popcll(act) * smax; lane_stats[2] += ssum;
                 lane_stats[3] += (unsigned long long)__popcll(__ballot(steps > 0u));      // segments that walked at all (the others: cleared by the pre-filter or by every target's bounding sphere)
+                lane_stats[4] += (unsigned long long)__popcll(__ballot(steps == 0u)) * smax;      // lane-steps issued to lanes that are in the round but NEVER STARTED a walk in it -- what packing the live launch indices of several tiles into dense waves could recover
             }
             if (COUNT && COOP && steps) lane_stats[3] += 1ull;
             if (!rts_shade<KEEP_ALL, REFR, COOP>(a, L_, tid, gtid, lane, slot, chain, D, max_refr, origin, primary, may_rx, best_t, best_leaf, best_prim, tmin, S, pending, refr_code0)) break;
@@ -935,7 +939,7 @@ __device__ __forceinline__ void rts_trace_unit(const RtsTraceArgs& a, const RtsL
 template <bool COUNT, bool KEEP_ALL>
 __device__ __forceinline__ void rts_trace_unit_async(const RtsTraceArgs& a, const RtsLaunchConsts& lc, const RtsUnitLds& L_, const uint32_t tid, const uint32_t gtid, const uint32_t lane,
                                                      const uint32_t slot_in, const bool pre_on, const bool mask_on, const uint32_t D, const dvec3& origin, const long long tile_t0,
-                                                     uint32_t& n_nodes, uint32_t& n_tris, bool& hard_overflow, unsigned long long (&lane_stats)[4])
+                                                     uint32_t& n_nodes, uint32_t& n_tris, bool& hard_overflow, unsigned long long (&lane_stats)[5])
 {
     int32_t* const s_stack = L_.stack; uint32_t* const s_n = L_.n;
     const int SENTINEL = RTS_STACK_SENTINEL;
@@ -1037,7 +1041,7 @@ __device__ __forceinline__ void rts_sum_counters_body(const uint32_t t, unsigned
 #define RTS_LD64(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
     if (t == 7) { const unsigned long long h = head_count ? (unsigned long long)__hip_atomic_load(head_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL; counters[7] = h; host_cnt[7] = h; }     // the order's head count travels home with the counters (sizes the next cooperative grid)
     if (t == 0) host_cnt[0] = RTS_LD64(&counters[0]);                          // received rays (appended by the trace kernels)
-    if ((t >= 8 && t <= 12) || t == 14 || t == 15) host_cnt[t] = RTS_LD64(&counters[t]);      // lane statistics and walked segments of the counting build; [12] cost records dropped, [14] / [15] tiles / XCCs on which the shader clock ran backwards
+    if ((t >= 8 && t <= 12) || t == 14 || t == 15) host_cnt[t] = RTS_LD64(&counters[t]);      // lane statistics and walked segments of the counting build; [12] cost records dropped, [14] tiles (| XCC mask << 56) on which the shader clock ran backwards, [15] never-started lane-steps
     const unsigned int k = t & 7u, lane = t >> 3;                              // 32 partial sums per counter
     unsigned long long v = 0;
     // (counting builds poison the rows before the launch -- rts_trace_launch -- : a row no block wrote is COUNTED, counters[13], instead
@@ -1168,7 +1172,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR && COOP) ? 2 : ((REFR || COOP
     __shared__ uint32_t s_lane_scratch[COUNT ? 2 * (RTS_BLOCK / 64) : 1];      // (counting build: per-wave max / sum of a round's walk steps)
     __shared__ uint32_t s_walk[ASYNC ? 1 : 2 * (RTS_BLOCK / 64)];           // per wave: walk iterations of the current tile (each walk's slowest lane), walks
     const RtsUnitLds ul = {s_stack, s_exch, s_first, s_path, s_n, s_rx, s_rxp, s_lane_scratch, s_walk};
-    unsigned long long lane_stats[4] = {0ull, 0ull, 0ull, 0ull};
+    unsigned long long lane_stats[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
     // XCD-AFFINE SUB-ORDERS (a.xcd_seg, big launches; ordinary kernel only): the order behind the head is cut into one segment per XCD
     // -- a band of the lattice that held an eighth of the cost last seen, longest tiles first inside it -- so that the ~500 waves of
     // an XCD trace neighbouring tiles at the same time and its 4 MB of L2 serves ONE part of a scene that is a hundred times that
@@ -1228,7 +1232,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR && COOP) ? 2 : ((REFR || COOP
     const uint32_t single_draws_nobatch = per_stripe_all >= 1024u ? per_stripe_all / 4u : per_stripe_all;      // (short queues: one tile per draw throughout)
     if (BATCHABLE) {
         uint32_t k_dead = per_stripe_all;
-        if (a.batch_dead != 0u && pre_on && lc.W >= 64u) {
+        if (a.batch_dead != 0u && pre_on) {
             if (a.batch_dead == 2u) k_dead = 0u;
             else if (a.tile_live && a.tile_order) {
                 const uint32_t lv = __builtin_amdgcn_readfirstlane(a.tile_live[0]);          // 1 + tiles at the front of the order that cost more than a dead one (0: unknown)
@@ -1350,7 +1354,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR && COOP) ? 2 : ((REFR || COOP
       // (s_memtime, the shader clock counter), and on gfx950 that counter does not only tick: with three BASELINE configs[3] pulses in flight
       // about one launch in fifteen had ~1 000 tiles -- all those open at one instant -- whose end read EARLIER than their start
       // (profiles/r04_c4_cost_glitch.log).  The counting build still reads both and counts the tiles on which the shader clock ran
-      // backwards while the constant-rate one did not, with the XCCs they ran on (counters[14], [15]; RtsStats / RTS_DEBUG_COOP).
+      // backwards while the constant-rate one did not, with the XCCs they ran on (counters[14]; RTS_DEBUG_COOP).
       const long long tile_t0 = wall_clock64();
       const long long tile_s0 = COUNT ? clock64() : 0;
       if (!COOP) atomicAnd(&s_n[tid], 0x003fffffu);              // (ds_and_b32: the tile's own segment count starts at zero; a register for it would be the 129th)
@@ -1364,7 +1368,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR && COOP) ? 2 : ((REFR || COOP
       const unsigned long long dt = RTS_COST_UNITS(wall_clock64() - tile_t0);                     // (s_memrealtime: wave-uniform)
       if (COUNT && !COOP && lane == 0 && clock64() - tile_s0 < 0) {                               // the shader clock ran backwards over this tile
           uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-          atomicAdd(&a.counters[14], 1ULL); atomicOr(&a.counters[15], 1ULL << (xcc & 7u));
+          atomicAdd(&a.counters[14], 1ULL); atomicOr(&a.counters[14], 1ULL << (56u + (xcc & 7u)));      // (count in the low bits, the XCCs' mask in bits 56-63)
       }
       bool long_walks = false, longish_walks = false;
       if (!COOP && !ASYNC && a.tile_cost && dt >= a.coop_min_cost) {      // (the asynchronous-bounce experiment keeps no walk statistics: it flags nothing)
@@ -1407,6 +1411,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR && COOP) ? 2 : ((REFR || COOP
     // wave on the same two addresses -- 32 k same-line L2 atomics -- cost a fixed ~0.35 ms at the tail of every launch.)
     if (COUNT && !COOP && lane == 0 && lane_stats[0]) { atomicAdd(&a.counters[8], lane_stats[0]); atomicAdd(&a.counters[9], lane_stats[1]); atomicAdd(&a.counters[10], lane_stats[2]); }
     if (COUNT && lane == 0 && lane_stats[3]) atomicAdd(&a.counters[11], lane_stats[3]);
+    if (COUNT && !COOP && lane == 0 && lane_stats[4]) atomicAdd(&a.counters[15], lane_stats[4]);
     // (the thread index is re-formed here from the wave's number -- scalar, kept since the start -- and the lane number instead of
     // being carried through the kernel: the allocator, at its 128-register limit, otherwise parks threadIdx.x in scratch in the
     // prologue and reloads it here)

@@ -1287,6 +1287,8 @@ def test_dead_tile_batches_are_invisible(rts, oracle, scenes, monkeypatch):
     captured and no tile is dead)"""
     import math
     monkeypatch.setenv("RTS_GRID_MULT", "1")                               # 256 blocks: a cost order exists from ~65 k launch indices on
+    monkeypatch.setenv("RTS_COOP_FRAC", "0")                               # (no cooperative kernel: which tiles it takes follows measured TIMES, and a tile it traces as 64 units leaves the sum of their
+                                                                           # durations as its record even when every one of its rays is dead -- the record tables below are compared entry by entry)
     c3 = scenes.config3(W=81, detail=0.3, rx_radius=120.0); c3["tx"] = dict(c3["tx"], span=(0.08, 0.07, c3["tx"]["span"][2]))      # (a beam wider than the airframe: dead tiles around it)
     direct = dict(c3, rx=c3["rx"] + [scenes._rx_at((1500.0, 20.0, 5.0), (-1000.0, 0, 0), 60.0, 2.6), scenes._rx_at((-100.0, -10.0, 0.0), (-1000.0, 0, 0), 5.0, 2.6)])      # in the beam behind / in front of the target: direct rays
     wide = dict(scenes.config3(W=70, detail=0.3, rx_radius=120.0)); wide["tx"] = dict(wide["tx"], span=tuple(3.0 * x for x in wide["tx"]["span"][:2]) + (wide["tx"]["span"][2],))
@@ -1596,6 +1598,11 @@ def test_host_mirror_equals_the_copy_calls(rts, scenes, monkeypatch):
             agg = tr.aggregated_view()
             assert agg["power"].tobytes() == wagg["results"]["power"].tobytes() and agg["doppler"].tobytes() == wagg["results"]["doppler"].tobytes(), (spec, k)
             assert agg["delay"].tobytes() == wagg["delay"].tobytes() and agg["phase"].tobytes() == wagg["phase"].tobytes() and np.array_equal(agg["pathMatch"], wagg["pathMatch"]), (spec, k)
+            # a SECOND view after finalise + aggregate + aggregated view: still the records AS RECEIVED (rts_amd.h), also for a set beyond the
+            # mirror's 4 096 rows, which is served from copies -- made once per pulse, in storage rts_aggregated_view does not touch
+            rec2 = tr.received_view()
+            H.assert_prd_equal(rec2["results"], wrec["results"], "received records, second view (%s, pulse %d, %d rays)" % (spec, k, len(wrec["results"])))
+            assert np.array_equal(rec2["path"], wrec["path"]) and np.array_equal(rec2["slots"], wrec["slots"]) and rec2["rcs_angle"].tobytes() == wrec["rcs_angle"].tobytes(), (spec, k)
             again = tr.received()                       # the copy call after the aggregation: the rays carry the group values now (as after rs::kernel_wrapper)
             assert again["results"]["power"].tobytes() == wagg["results"]["power"].tobytes(), (spec, k)
         tr.close()

@@ -16,9 +16,9 @@ for name in (sys.argv[1:] or ["c3", "c2", "c3narrow", "c3ecef", "c3narrowecef"])
     tx = spec["tx"]
     st = tr.trace(tx["origin"], tx["span"], tx["dir"], spec["motion"])
     import ctypes as C
-    ls = (C.c_uint64 * 3)(); rts_amd._lib.check(rts_amd._lib.lib().rts_get_lane_stats(tr.h, ls))
-    issued, alive, useful = [float(x) for x in ls]
-    print("%-9s segs %d  nodes/seg %.2f  tri/seg %.2f  shaded/seg %.3f  trace %.3f ms | walk lane-steps: issued %.3e, to lanes in the round %.1f %%, taken %.1f %%  (lanes out of the round %.1f %%, waiting for the round's slowest %.1f %%)" %
+    ls = (C.c_uint64 * 5)(); rts_amd._lib.check(rts_amd._lib.lib().rts_get_walk_stats(tr.h, ls, 5))
+    issued, alive, useful, _walked, never = [float(x) for x in ls]
+    print("%-9s segs %d  nodes/seg %.2f  tri/seg %.2f  shaded/seg %.3f  trace %.3f ms | walk lane-steps: issued %.3e, to lanes in the round %.1f %%, taken %.1f %%  (lanes out of the round %.1f %%, waiting for the round's slowest %.1f %% -- of which lanes that never started a walk in the round %.1f %%, lanes whose walk was shorter %.1f %%)" %
           (name, st["segments"], st["node_visits"] / st["segments"], st["tri_tests"] / st["segments"], st["shaded"] / st["segments"], st["ms_trace"],
-           issued, 100 * alive / max(issued, 1), 100 * useful / max(issued, 1), 100 * (1 - alive / max(issued, 1)), 100 * (alive - useful) / max(issued, 1)))
+           issued, 100 * alive / max(issued, 1), 100 * useful / max(issued, 1), 100 * (1 - alive / max(issued, 1)), 100 * (alive - useful) / max(issued, 1), 100 * never / max(issued, 1), 100 * (alive - useful - never) / max(issued, 1)))
     tr.close()
