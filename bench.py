@@ -20,12 +20,13 @@ inside the timed region; ms_per_step is wall time / pulses.
 
 N > 1 ranks (one process per GPU): STRONG scaling is the line's `value` -- ONE interval of --steps pulses shared by the N ranks
 (BASELINE.json's north star: "rays shard ... RCCL reduce ... strong-scaling efficiency"), `ms_per_step` = the interval's wall time /
---steps.  How it is shared (--shard auto): every pulse split over all ranks by RAYS (tiles dealt longest-first from the cost records
-of the warm-up interval, rts_deal_tiles; interleaved 4096-index tiles until there are records) when the ranks would otherwise get
-fewer than 4 x --inflight whole pulses each AND a rank's part of a pulse is at least 4 M launch indices; else whole PULSES are dealt
-(left-over pulses in interleaved tiles, rts_plan_cpi).  The second condition is this file's, not VERDICT r4's: an eighth of a
-configs[2] pulse is 0.08 ms of tracing against a 0.07 ms empty launch and ~15 launches around it, so ray-sharding THAT workload
-measures launch overhead -- its pulses are dealt whole, and a rank's two or three of them overlap in flight.
+--steps.  How it is shared (--shard auto): WHOLE pulses in contiguous runs, the first K mod N ranks one pulse more (rts_plan_cpi, RTS_SHARD_PULSES_WHOLE),
+whenever the interval has at least as many pulses as there are ranks; with FEWER pulses than ranks -- the latency of single pulses -- every pulse
+is split over all ranks by RAYS (tiles dealt longest-first from the cost records of the warm-up interval, rts_deal_tiles) when a rank's part is at
+least 4 M launch indices, else over groups of ranks.  This is measured, not VERDICT r4's rule ("rays below 4 x --inflight pulses per rank"): one GPU
+running each rank's plan of a 20-pulse interval in turn (profiles/r05d_as_rank_pulses_*.log) took 3.3-3.7 ms per rank with left-over pulses split and
+12-14 ms ray-sharded on configs[2] (11.9 ms on one GPU), 34-45 / 30-68 ms on configs[3] (110 ms): a part of a pulse is a launch of another shape
+whose tile schedule starts from nothing, and an eighth of a configs[2] pulse is 0.08 ms of tracing against a 0.07 ms empty launch.
 Either way the per-(receiver, path) group tables are exchanged once per interval (one all-gather over RCCL) and the complex return
 cube is summed once (one all-reduce), both inside the timed region.  The same job then measures, outside that region and reported
 as secondary blocks: `weak` -- every rank --steps whole pulses (an N x steps interval; per-GPU work as at N = 1, no collective in the
@@ -196,7 +197,7 @@ def main():
     ap.add_argument("--as-rank", default="", help="debug, one process: 'r/N' runs the plan rank r of N ranks would run (--shard rays, the default here: its part of EVERY pulse; --shard pulses: its whole pulses and its parts of the left-over ones), without a process group -- one GPU's share of a ray-sharded interval at the pipelined rate, every r in turn gives the critical path of an N-GPU run; value / ms_per_step are that rank's alone")
     ap.add_argument("--deal", default="auto", choices=["auto", "interleave", "cost"], help="auto = cost for a multi-rank job, interleave with --as-rank.  --shard rays: 'cost' = after the warm-up pulses (traced as interleaved parts) the ranks exchange what every tile cost the rank that traced it (ONE all-reduce of a uint32 per 64 launch indices, outside the timed interval: it belongs to the previous interval), adopt the merged table as their tile history and trace the timed interval's pulses as tile lists dealt longest-first from it (rts_deal_tiles, rts_set_tile_list) instead of the static interleave.  With --as-rank the table comes from two whole pulses traced by this process (standing in for the other ranks)")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"], help="N > 1: which interval is the line's value.  'strong' (default, the north star's) = ONE interval of --steps pulses shared by the ranks; 'weak' = every rank runs --steps pulses, the interval is N x steps pulses (per-GPU work fixed as N grows -- pulses are independent, ray_tracer.cpp:843, and there is no collective in the data path).  The other one, and rank 0 alone on the strong interval, are measured by the same job and reported as secondary blocks")
-    ap.add_argument("--shard", default="auto", choices=["auto", "pulses", "rays"], help="N > 1, the strong interval: deal whole pulses to the ranks, or split every pulse over all ranks; auto: rays when a rank would get fewer than 4 x --inflight whole pulses and its part of a pulse is >= 4 M launch indices (see the top of this file)")
+    ap.add_argument("--shard", default="auto", choices=["auto", "pulses", "whole", "rays"], help="N > 1, the strong interval: 'whole' = whole pulses only, contiguous runs, some ranks one pulse more; 'pulses' = whole pulses and each left-over pulse split over a group of ranks; 'rays' = every pulse split over all ranks (tiles dealt by cost).  auto: see the top of this file")
     ap.add_argument("--no-secondary", action="store_true", help="N > 1: skip the secondary intervals (weak / strong counterpart and rank 0 alone)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks")
     args = ap.parse_args()
@@ -291,12 +292,14 @@ def main():
             return args.shard
         if args.as_rank:
             return "rays"
-        return "rays" if (w > 1 and n_pulses < 4 * max(args.inflight, 1) * w and total // w >= RAY_SHARD_MIN) else "pulses"
+        if w > 1 and n_pulses < w:                             # fewer pulses than ranks -- the latency of single pulses: every pulse split over all ranks by rays when the parts are big enough, else over groups of ranks
+            return "rays" if total // w >= RAY_SHARD_MIN else "pulses"
+        return "whole"
 
     # the interval being run: the closures below read it (strong / weak / rank 0 alone differ in these five things only)
     cur = dict(n_int=args.steps * (world if (args.scaling == "weak" and world > 1) else 1), n_warm=args.warmup * (world if (args.scaling == "weak" and world > 1) else 1),
                rank=plan_rank, world=plan_world, shard=None, collectives=True)
-    cur["shard"] = resolve_shard(cur["n_int"], plan_world) if args.scaling == "strong" or args.as_rank else ("pulses" if args.shard == "auto" else args.shard)
+    cur["shard"] = resolve_shard(cur["n_int"], plan_world) if args.scaling == "strong" or args.as_rank else ("whole" if args.shard == "auto" else args.shard)
     deal_mode = args.deal if args.deal != "auto" else ("interleave" if args.as_rank else "cost")
     n_int, n_warm = cur["n_int"], cur["n_warm"]
 
@@ -362,6 +365,8 @@ def main():
             return [(k, 0, total, (dealt["tile"], api.INTERLEAVE_LIST, 0)) for k in range(n_pulses)]
         if cur["shard"] == "rays" and cur["world"] > 1:
             p = multigpu.plan_rays(total, n_pulses, cur["rank"], cur["world"])
+        elif cur["shard"] == "whole":
+            return multigpu.plan_whole(total, n_pulses, cur["rank"], cur["world"])      # (never refined: a rank with fewer pulses than handles leaves a handle idle rather than trace parts)
         else:
             p = multigpu.plan_cpi(total, n_pulses, cur["rank"], cur["world"])
         return multigpu.refine_plan(p, len(trs))
@@ -550,12 +555,12 @@ def main():
     if world > 1 and not args.no_secondary and not args.as_rank:
         other = "weak" if args.scaling == "strong" else "strong"
         o_int = args.steps * (world if other == "weak" else 1); o_warm = min(args.warmup, 2 * len(trs)) * (world if other == "weak" else 1)
-        o_shard = "pulses" if other == "weak" else resolve_shard(o_int, world)
+        o_shard = "whole" if other == "weak" else resolve_shard(o_int, world)
         acc_o, _, dt_o = timed_interval(o_int, o_warm, o_shard, rank, world)
         seg_o = job_sums(acc_o)[0]
         secondary[other] = dict(value=seg_o / dt_o / 1e6, unit="Mrays/s", ms_per_step=dt_o / args.steps * 1e3, ms_per_pulse_of_the_interval=dt_o / o_int * 1e3, pulses_in_the_interval=o_int, shard=o_shard,
                                 note=("every rank traces --steps whole pulses; ms_per_step = wall time / --steps (one pulse on every rank)" if other == "weak" else "ONE interval of --steps pulses shared by the ranks"))
-        acc_1, _, dt_1 = timed_interval(args.steps, min(args.warmup, 2 * len(trs)), "pulses", 0, 1, collectives_=False, participate=(rank == 0))
+        acc_1, _, dt_1 = timed_interval(args.steps, min(args.warmup, 2 * len(trs)), "whole", 0, 1, collectives_=False, participate=(rank == 0))
         if rank == 0:
             n1_value = acc_1["segments"] / dt_1 / 1e6
             secondary["n1"] = dict(value=n1_value, unit="Mrays/s", ms_per_step=dt_1 / args.steps * 1e3,
@@ -666,7 +671,7 @@ def main():
                        "dense_control_Gseg_per_s": (dense or {}).get("Gseg_per_s"),
                        "return_cube": cube_desc,
                        "as_rank": args.as_rank or None, "deal": (dict(headline["deal"], how="tiles dealt longest-first from the cost records of the warm-up interval (one all-reduce), rts_deal_tiles") if headline["deal"] else "static interleave") if headline["shard"] == "rays" and plan_world > 1 else None,
-                       "sharding": ("%d-pulse interval over %d ranks (--scaling %s: %s), --shard %s -> %s: " % (n_int, world, args.scaling, "--steps pulses per rank" if args.scaling == "weak" else "--steps pulses in all", args.shard, headline["shard"])) + ("every pulse split over all ranks, tiles of 4096 launch indices %s" % ("dealt longest-first from the warm-up interval's cost records" if headline["deal"] else "interleaved") if headline["shard"] == "rays" else "whole pulses, left-over pulses in interleaved 4096-index tiles") + "; one group-table all-gather + one cube all-reduce per interval",
+                       "sharding": ("%d-pulse interval over %d ranks (--scaling %s: %s), --shard %s -> %s: " % (n_int, world, args.scaling, "--steps pulses per rank" if args.scaling == "weak" else "--steps pulses in all", args.shard, headline["shard"])) + ("every pulse split over all ranks, tiles of 4096 launch indices %s" % ("dealt longest-first from the warm-up interval's cost records" if headline["deal"] else "interleaved") if headline["shard"] == "rays" else ("whole pulses only (contiguous runs, some ranks one pulse more)" if headline["shard"] == "whole" else "whole pulses, left-over pulses in interleaved 4096-index tiles")) + "; one group-table all-gather + one cube all-reduce per interval",
                        "ms_per_pulse_of_the_interval": dt / max(n_int, 1) * 1e3,
                        "host_numa_node": numa_node, "post_processing_call": "rts_trace_pulse_end_uniform" if ((args.fused_post or len(trs) == 1) and hasattr(rts_amd._lib.lib(), "rts_trace_pulse_end_uniform")) else "rts_trace_pulse_end + rts_finalise_uniform + rts_cube_accumulate + rts_aggregate", "pulses_in_flight": len(trs), "linked": bool(args.link), "scene_setup_s": scene_setup_s,
                        "interval_tail_ms_rank0": acc["tail_ms"],

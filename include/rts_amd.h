@@ -348,6 +348,9 @@ int rts_cube_doppler_get(RtsHandle h, double* host_out, uint64_t capacity_double
  *                     group of consecutive workers in interleaved tiles (RtsPulse.interleave_*)
  *   RTS_SHARD_RAYS    every pulse is split over all workers in interleaved tiles (work per worker independent of how
  *                     n_pulses divides by world)
+ *   RTS_SHARD_PULSES_WHOLE  whole pulses only, contiguous runs, the first n_pulses % world workers one pulse more (a part of a pulse
+ *                     is a launch of another shape whose schedule starts from nothing: on short intervals of small pulses that costs
+ *                     more than one pulse of imbalance); with fewer pulses than workers: as RTS_SHARD_PULSES
  * min_items > 1 splits items further (part p of P -> parts p and p + P of 2 P) until the worker owns that many, so that
  * it can keep min_items pulses (or parts) in flight.  Parts of one pulse are merged again through their group tables
  * (rts_aggregate with RTS_BASE_USE_ROWS, rts_merge_groups) or through their received sets ordered by RtsResponse.ray /
@@ -359,6 +362,7 @@ typedef struct RtsPlanItem {
 } RtsPlanItem;
 #define RTS_SHARD_PULSES 0u
 #define RTS_SHARD_RAYS 1u
+#define RTS_SHARD_PULSES_WHOLE 2u
 #define RTS_PLAN_TILE 4096u      /* default launch indices per interleaved tile (a multiple of 64 keeps the tile-cost history) */
 int rts_plan_cpi(uint64_t total_rays, uint32_t n_pulses, uint32_t rank, uint32_t world, uint32_t mode, uint32_t min_items,
                  uint32_t tile /* launch indices per interleaved tile; 0 = RTS_PLAN_TILE */, RtsPlanItem* out, uint32_t capacity,

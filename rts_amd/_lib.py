@@ -70,7 +70,7 @@ class RtsPlanItem(C.Structure):
                 ("ray_first", C.c_uint64), ("ray_count", C.c_uint64)]
 
 
-RTS_SHARD_PULSES, RTS_SHARD_RAYS = 0, 1
+RTS_SHARD_PULSES, RTS_SHARD_RAYS, RTS_SHARD_PULSES_WHOLE = 0, 1, 2
 
 
 class RtsSceneInfo(C.Structure):

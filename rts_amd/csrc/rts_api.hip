@@ -205,6 +205,8 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     { const char* e = getenv("RTS_COOP_FRAC"); if (e) { const double v = atof(e); if (v >= 0) c->coop_frac = v; } }                  // 0: no cooperative units; tests: tiny values put every tile at the head
     { const char* e = getenv("RTS_COOP_FLOOR"); if (e) c->coop_floor = (uint32_t)std::max(0, atoi(e)); }
     c->debug_coop = getenv("RTS_DEBUG_COOP") != nullptr;
+    c->hist = new RtsTileHist();
+    { const char* e = getenv("RTS_SHARE_HISTORY"); if (e) c->share_history = e[0] != '0'; }
     { const char* e = getenv("RTS_RX_WINDOW_SCREEN"); if (e) c->rx_window_screen = e[0] != '0'; }
     { const char* e = getenv("RTS_DEAD_BATCH"); if (e) c->batch_dead = strcmp(e, "all") == 0 ? 2 : (e[0] != '0' ? 1 : 0); }      // dead-tile batches of the trace kernel: 0 never, 1 the order's dead part (default), all: every position is screened tile-wise first (tests)
     { const char* e = getenv("RTS_WALK_VERSIONS"); if (e) c->node_versions = e[0] != '0'; }      // (per handle: RTS_NODE_VERSIONS decides whether the scene HAS versions, this whether the handle walks them)
@@ -249,6 +251,7 @@ struct RtsLapTimer {
 // pulses begun and not yet ended, per device: a trace launch that will share the GPU with another pulse's kernels leaves block
 // slots free for them (RtsContext::grid_spare), a lone pulse takes the whole chip
 static std::atomic<int> g_open_pulses[64];
+static std::mutex g_hist_mu;      // (re)allocation of a shared tile-cost history (RtsTileHist)
 
 extern "C" int rts_destroy(RtsHandle c)
 {
@@ -265,10 +268,12 @@ extern "C" int rts_destroy(RtsHandle c)
     rts_comm_cache_forget(c);
     if (c->scene && --c->scene->refs == 0) { c->scene->release(); delete c->scene; }
     c->scene = nullptr;
+    if (c->hist && --c->hist->refs == 0) { c->hist->d.release(); delete c->hist; }
+    c->hist = nullptr;
     c->d_verts_world.release(); c->d_normals_world.release();
     c->d_params.release();
     c->d_leaves.release(); c->d_sort_tmp.release(); c->d_rx.release(); c->d_recv.release(); c->d_all.release();
-    c->d_block_counters.release(); c->d_timeline.release(); c->d_tile_cost.release(); c->d_tile_key.release(); c->d_tile_key_sorted.release(); c->d_tile_id.release(); c->d_tile_order.release(); c->d_tile_hist.release(); c->d_tile_ctr.release(); c->d_dir_hist.release(); c->d_pmask.release(); c->d_child.release(); c->d_rk64.release(); c->d_rk64_sorted.release(); c->d_hit_prim.release(); c->d_hit_t.release(); c->d_stack_ovf.release(); c->d_il_list.release(); c->d_rec_tmp.release();
+    c->d_block_counters.release(); c->d_timeline.release(); c->d_tile_cost.release(); c->d_tile_key.release(); c->d_tile_key_sorted.release(); c->d_tile_id.release(); c->d_tile_order.release(); c->d_tile_ctr.release(); c->d_dir_hist.release(); c->d_pmask.release(); c->d_child.release(); c->d_rk64.release(); c->d_rk64_sorted.release(); c->d_hit_prim.release(); c->d_hit_t.release(); c->d_stack_ovf.release(); c->d_il_list.release(); c->d_rec_tmp.release();
     c->d_xcd.release();
     c->d_rk.release(); c->d_rk_sorted.release(); c->d_ri.release(); c->d_ri_sorted.release(); c->d_rx_rays.release(); c->d_rx_paths.release();
     c->d_rx_angles.release(); c->d_rx_slots.release(); c->d_all_rays.release(); c->d_all_paths.release(); c->d_all_angles.release();
@@ -477,7 +482,8 @@ static int rts_attach_scene(RtsContext* c)
         c->rcs_uploaded = false;
     }
     c->verts_world_valid = false; c->order_sum_valid = false;
-    c->motion.assign(n_targets, RtsTargetMotion{}); c->motion_valid = false; c->bvh_valid = false; c->tile_hist_n = 0; c->tile_hist_any = false; c->tile_cost_pending = false; c->tile_last_valid = false;
+    if (c->hist->refs.load() > 1) { c->hist->refs--; c->hist = new RtsTileHist(); }      // (a handle that leaves a shared scene leaves the shared history)
+    c->motion.assign(n_targets, RtsTargetMotion{}); c->motion_valid = false; c->bvh_valid = false; c->hist->n = 0; c->hist->any = false; c->hist->head_hint_valid = false; c->tile_cost_pending = false; c->tile_last_valid = false;
     return RTS_OK;
 }
 
@@ -497,7 +503,12 @@ extern "C" int rts_share_scene(RtsHandle dst, RtsHandle src)
     if (dst->scene == src->scene) return RTS_OK;
     if (--dst->scene->refs == 0) { dst->scene->release(); delete dst->scene; }
     dst->scene = src->scene; dst->scene->refs++;
-    return rts_attach_scene(dst);
+    { int rc = rts_attach_scene(dst); if (rc != RTS_OK) return rc; }
+    if (dst->share_history && src->share_history && dst->params.width == src->params.width) {      // ... and the tile-cost history of the scene's handles (RtsTileHist)
+        if (--dst->hist->refs == 0) { dst->hist->d.release(); delete dst->hist; }
+        dst->hist = src->hist; dst->hist->refs++;
+    }
+    return RTS_OK;
 }
 
 extern "C" int rts_scene_info(RtsHandle c, RtsSceneInfo* out)
@@ -682,9 +693,10 @@ extern "C" int rts_reserve(RtsHandle c, uint64_t n_rays)
     const size_t n_tiles = (size_t)((n + RTS_WTILE - 1) / RTS_WTILE), n_hist = (size_t)((W3 + RTS_WTILE - 1) / RTS_WTILE);
     RTS_HIP(c->d_tile_ctr.reserve(RTS_ZERO_WORDS + RTS_MASK_WORDS + 64)); c->p_counters = reinterpret_cast<unsigned long long*>(c->d_tile_ctr.p + RTS_OFF_COUNTERS); RTS_HIP(c->d_tile_cost.reserve(n_tiles)); RTS_HIP(c->d_tile_key.reserve(n_tiles)); RTS_HIP(c->d_tile_key_sorted.reserve(n_tiles));
     RTS_HIP(c->d_tile_id.reserve(n_tiles)); RTS_HIP(c->d_tile_order.reserve(n_tiles));
-    if (c->tile_hist_n != (uint32_t)n_hist) {
-        RTS_HIP(c->d_tile_hist.reserve(n_hist)); RTS_HIP(hipMemsetAsync(c->d_tile_hist.p, 0, sizeof(uint32_t) * n_hist, c->stream));
-        c->tile_hist_n = (uint32_t)n_hist; c->tile_hist_any = false; c->tile_cost_pending = false;
+    if (c->hist->n != (uint32_t)n_hist) {
+        std::lock_guard<std::mutex> lk(g_hist_mu);      // (handles that share the history may be driven from different threads)
+        RTS_HIP(hipDeviceSynchronize()); RTS_HIP(c->hist->d.reserve(n_hist)); RTS_HIP(hipMemset(c->hist->d.p, 0, sizeof(uint32_t) * n_hist));      // (blocking: the table may be shared with handles on other streams)
+        c->hist->n = (uint32_t)n_hist; c->hist->any = false; c->tile_cost_pending = false;
     }
     if (c->params.flags & RTS_FLAG_KEEP_ALL_RAYS) { RTS_HIP(c->d_all.reserve((size_t)n * chains + 1)); RTS_HIP(c->d_hit_prim.reserve((size_t)n * H + 1)); RTS_HIP(c->d_hit_t.reserve((size_t)n * H + 1)); }
     // touch the two slabs the trace kernel writes sparsely, so that their pages exist before the first launch
@@ -855,15 +867,16 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
         RTS_HIP(c->d_tile_ctr.reserve(RTS_ZERO_WORDS + RTS_MASK_WORDS + 64)); c->p_counters = reinterpret_cast<unsigned long long*>(c->d_tile_ctr.p + RTS_OFF_COUNTERS); a.counters = c->p_counters;
         a.tile_ctr = c->d_tile_ctr.p;
         if (lpt && aligned && n_tiles > grid * (RTS_BLOCK / RTS_WTILE)) {
-            if (c->tile_hist_n != n_hist) {
-                RTS_HIP(c->d_tile_hist.reserve(n_hist)); RTS_HIP(hipMemsetAsync(c->d_tile_hist.p, 0, sizeof(uint32_t) * n_hist, st));
-                c->tile_hist_n = n_hist; c->tile_hist_any = false; c->tile_cost_pending = false;
+            if (c->hist->n != n_hist) {
+                std::lock_guard<std::mutex> lk(g_hist_mu);
+                RTS_HIP(hipDeviceSynchronize()); RTS_HIP(c->hist->d.reserve(n_hist)); RTS_HIP(hipMemset(c->hist->d.p, 0, sizeof(uint32_t) * n_hist));      // (blocking, once: the table may be shared with handles on other streams)
+                c->hist->n = n_hist; c->hist->any = false; c->tile_cost_pending = false;
             }
-            if (c->tile_cost_pending || c->tile_hist_any) {
+            if (c->tile_cost_pending || c->hist->any) {
                 c->coop_big_now = (il_parts > 1 && !shared_gpu && c->coop_big_part > c->coop_big) ? c->coop_big_part : c->coop_big;
                 int rc = rts_tile_order_build(c, c->tile_cost_sig, c->tile_cost_pending, sig, n_tiles, grid * (RTS_BLOCK / RTS_WTILE)); if (rc != RTS_OK) return rc;
                 a.xcd_seg = c->xcd_affine_now ? c->d_xcd.p : nullptr;
-                a.tile_order = c->d_tile_order.p; a.tile_head = c->coop_frac > 0.0 ? c->d_tile_ctr.p + RTS_OFF_HEAD + 2 : nullptr; a.tile_head_all = a.tile_head; c->tile_hist_any = true;
+                a.tile_order = c->d_tile_order.p; a.tile_head = c->coop_frac > 0.0 ? c->d_tile_ctr.p + RTS_OFF_HEAD + 2 : nullptr; a.tile_head_all = a.tile_head; c->hist->any = true;
                 a.tile_live = c->d_tile_ctr.p + RTS_OFF_LIVE;      // (written by the order build when it counts bins; else it stays at the fill's 0 = unknown)
             }
             const bool merged_all = c->tile_cost_pending && (c->tile_cost_sig[0] + RTS_WTILE - 1) / RTS_WTILE >= n_tiles && c->d_tile_cost.cap >= n_tiles;      // k_tile_merge read AND cleared the records
@@ -897,6 +910,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     // who traces the head of the order): no head last time -> none now, and the ordinary kernel traces every tile.
     unsigned coop_grid = 0;
     if (a.tile_head) {
+        if (c->hist->head_hint_valid) c->n_head_hint = c->hist->head_hint;      // (the latest head count of ANY handle that shares the history)
         const uint64_t units = 64ULL * c->n_head_hint;
         if (units == 0) a.tile_head = nullptr;
         else coop_grid = (unsigned)std::min<uint64_t>(c->coop_grid_max, std::max<uint64_t>(16, (units + 3) / 4));
@@ -950,7 +964,7 @@ extern "C" int rts_trace_pulse_end(RtsHandle c)
     RTS_HIP(rts_stream_wait(c, st));                // the one host sync of the launch: the received count sizes what follows
     if (cnt[13]) { rts_set_error("rts_trace_pulse: %llu counter rows of the launch were never written by their blocks (counting build)", cnt[13]); return RTS_ERR_HIP; }
     if (cnt[6]) { rts_set_error("rts_trace_pulse: traversal stack overflow / malformed BVH guard tripped on %llu waves", cnt[6]); return RTS_ERR_HIP; }
-    c->n_recv = cnt[0]; c->n_head_hint = (uint32_t)cnt[7];
+    c->n_recv = cnt[0]; c->n_head_hint = (uint32_t)cnt[7]; c->hist->head_hint = c->n_head_hint; c->hist->head_hint_valid = true;
     if (c->debug_coop && c->d_xcd.p && c->d_tile_ctr.p) {      // debug: what the head rule of this launch's order build saw (blocking read-backs)
         unsigned long long sums[2] = {0, 0};
         (void)hipMemcpy(&sums[0], c->d_xcd.p + 32, sizeof(unsigned long long), hipMemcpyDeviceToHost);
@@ -1159,7 +1173,7 @@ static int rts_spec_resolve(RtsContext* c)
     RTS_HIP(rts_stream_wait(c, c->stream));
     if (cnt[13]) { rts_set_error("rts_trace_pulse: %llu counter rows of the launch were never written by their blocks (counting build)", cnt[13]); return RTS_ERR_HIP; }      // (as rts_trace_pulse_end does: ADVICE r4)
     if (cnt[6]) { rts_set_error("rts_trace_pulse: traversal stack overflow / malformed BVH guard tripped on %llu waves", cnt[6]); return RTS_ERR_HIP; }
-    c->n_recv = cnt[0]; c->n_head_hint = (uint32_t)cnt[7];
+    c->n_recv = cnt[0]; c->n_head_hint = (uint32_t)cnt[7]; c->hist->head_hint = c->n_head_hint; c->hist->head_hint_valid = true;
     c->recv_hint = cnt[0]; c->recv_hint_valid = true;                   // (the next pulse's choices -- speculate at all, one kernel or seven -- follow THIS pulse's count, not the handle's first)
     rts_pulse_account(c, cnt);
     if (c->n_recv > c->spec_cap) {                                      // more rays than the speculative chain was sized for: it did nothing; the ordinary chain now
@@ -1486,9 +1500,9 @@ extern "C" int rts_tile_records_set(RtsHandle c, const uint32_t* records, uint32
     const uint64_t total = (uint64_t)c->params.width * c->params.width * c->params.width;
     if (!records || n != (uint32_t)((total + RTS_WTILE - 1) / RTS_WTILE)) { rts_set_error("rts_tile_records_set: n must be ceil(W^3 / %d) = %llu", RTS_WTILE, (unsigned long long)((total + RTS_WTILE - 1) / RTS_WTILE)); return RTS_ERR_INVALID; }
     RTS_HIP(hipStreamSynchronize(c->stream));
-    RTS_HIP(c->d_tile_hist.reserve(n));
-    RTS_HIP(hipMemcpy(c->d_tile_hist.p, records, sizeof(uint32_t) * n, hipMemcpyHostToDevice));
-    c->tile_hist_n = n; c->tile_hist_any = true; c->tile_cost_pending = false; c->order_sum_valid = false;      // (records of the last launch not merged yet are superseded)
+    RTS_HIP(c->hist->d.reserve(n));
+    RTS_HIP(hipMemcpy(c->hist->d.p, records, sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+    c->hist->n = n; c->hist->any = true; c->tile_cost_pending = false; c->order_sum_valid = false;      // (records of the last launch not merged yet are superseded)
     return RTS_OK;
 }
 
@@ -1547,12 +1561,19 @@ extern "C" int rts_plan_cpi(uint64_t total_rays, uint32_t n_pulses, uint32_t ran
                             uint32_t tile, RtsPlanItem* out, uint32_t capacity, uint32_t* n_out)
 {
     if (tile == 0) tile = RTS_PLAN_TILE;
-    if (!n_out || world == 0 || rank >= world || mode > RTS_SHARD_RAYS) { rts_set_error("rts_plan_cpi: bad argument (rank %u of %u, mode %u)", rank, world, mode); return RTS_ERR_INVALID; }
+    if (!n_out || world == 0 || rank >= world || mode > RTS_SHARD_PULSES_WHOLE) { rts_set_error("rts_plan_cpi: bad argument (rank %u of %u, mode %u)", rank, world, mode); return RTS_ERR_INVALID; }
     std::vector<RtsPlanItem> plan;
     auto item = [&](uint32_t pulse, uint32_t parts, uint32_t part) { RtsPlanItem it; memset(&it, 0, sizeof(it)); it.pulse = pulse; it.ray_first = 0; it.ray_count = total_rays;
                                                                      if (parts > 1) { it.interleave_tile = tile; it.interleave_parts = parts; it.interleave_part = part; } return it; };
     if (mode == RTS_SHARD_RAYS) {
         for (uint32_t k = 0; k < n_pulses; k++) plan.push_back(item(k, world, rank));
+    } else if (mode == RTS_SHARD_PULSES_WHOLE && n_pulses >= world) {
+        // whole pulses only, in contiguous runs (a handle's consecutive pulses are consecutive in time: its cost history fits): the first
+        // n_pulses % world workers trace one pulse more.  A part of a pulse is a launch of another SHAPE -- its tile order starts from nothing,
+        // and on a short interval that costs more than the imbalance of one pulse (profiles/r05d_as_rank_pulses_*.log)
+        const uint32_t base = n_pulses / world, left = n_pulses - base * world;
+        const uint32_t first = rank * base + std::min(rank, left), count = base + (rank < left ? 1u : 0u);
+        for (uint32_t i = 0; i < count; i++) plan.push_back(item(first + i, 1, 0));
     } else {
         const uint32_t base = n_pulses / world, left = n_pulses - base * world;
         for (uint32_t i = 0; i < base; i++) plan.push_back(item(rank * base + i, 1, 0));

@@ -264,6 +264,14 @@ struct RtsScene {
                      d_verts_local.release(); d_normals_local.release(); d_nodes4.release(); d_nodes4v.release(); d_leaf_prim.release(); }
 };
 
+// The tile-cost HISTORY (what every wave tile of the W^3 lattice cost the launch that traced it last: the cost order, the cooperative kernel's
+// head and the dead part of the order are built from it, rts_post.hip) belongs to the handles that SHARE A SCENE on a device (round 5): they trace
+// consecutive pulses of one interval, so what one of them measured is the best estimate the others have -- three handles in flight learn three times
+// as fast, a handle's first launch finds the schedule its neighbours built, and a 20-pulse run is no longer mostly schedules settling.  Entries are
+// single words replaced whole: a neighbour's merge racing with this handle's order build reads an old record or a new one, both valid estimates.
+// (RTS_SHARE_HISTORY=0: every handle its own.)
+struct RtsTileHist { std::atomic<int> refs{1}; DevBuf<uint32_t> d; uint32_t n = 0; bool any = false; uint32_t head_hint = 0; bool head_hint_valid = false; };
+
 #define RTS_SMALL_CAP32 4096u         // received rays the one-block ordering kernels take with 32-bit sort keys (rts_post.hip) ...
 #define RTS_SMALL_CAP64 2048u         // ... and with 64-bit keys; a speculatively enqueued post-processing chain is sized for the smaller of its two sorts
 struct RtsSpecParams { std::vector<double> rcs; double wl = 0, gt = 0, gr = 0, carrier = 0, cspeed = 0; int32_t cube_pulse = -1; uint64_t base = 0;
@@ -308,7 +316,8 @@ struct RtsContext {
     // per pulse
     uint64_t ray_first = 0; uint32_t n_rays = 0;
     DevBuf<RtsEndRecord> d_recv, d_all; DevBuf<unsigned long long> d_block_counters, d_timeline; unsigned long long* p_counters = nullptr;      // (the 16 counters live behind the draw counters: one fill zeroes both)
-    DevBuf<uint32_t> d_tile_cost, d_tile_key, d_tile_key_sorted, d_tile_id, d_tile_order, d_tile_hist, d_tile_ctr;
+    DevBuf<uint32_t> d_tile_cost, d_tile_key, d_tile_key_sorted, d_tile_id, d_tile_order, d_tile_ctr;
+    RtsTileHist* hist = nullptr; bool share_history = true;      // never null after rts_create; shared with the handles of the same scene (rts_share_scene) unless RTS_SHARE_HISTORY=0
     uint32_t coop_floor = 7500;         // ... more than this many cost units (shader clocks >> 6; 7 500 = 0.2 ms of one wave) (RTS_COOP_FLOOR)
     uint32_t coop_walk_steps_lo = 400; double coop_mid = 1.5;      // LONGISH WALKS (RTS_COOP_STEPS_LO) go to the head only if the tile cost more than coop_mid x the balanced time (RTS_COOP_MID; 0: never).  3 in round 4;
                                         // re-scanned in round 5, when the dead work had left the balanced time and the cooperative records had stopped flip-flopping (rts_record_to_keep): 1.5 takes a lone
@@ -324,7 +333,7 @@ struct RtsContext {
                                         // the launch's duration did not change (0.70-0.77 ms, peaks of 1.0 ms as before) and the handle's first such launch takes 10 ms)
     uint32_t async_idle0 = 0, async_idle1 = 8, async_age = 7500;   // RTS_ASYNC_IDLE0 / _IDLE1 / _AGE (rts_trace_unit_async; idle0 = 0: the lock-step kernel)
     double coop_frac = 0.5;            // a tile costing more than this fraction of the launch's balanced time is traced as cooperative units (RTS_COOP_FRAC; 0: never)
-    bool tile_cost_pending = false, tile_hist_any = false; uint64_t tile_cost_sig[4] = {0, 0, 0, 0}; uint32_t tile_hist_n = 0;   // per-global-tile cost history (rts_post.hip)
+    bool tile_cost_pending = false; uint64_t tile_cost_sig[4] = {0, 0, 0, 0};   // this handle's last launch left cost records that are not merged into the history yet (rts_post.hip)
     // tiles DEALT to this handle (rts_set_tile_list: ray sharding balanced by last-seen cost instead of interleaved parts): ascending tile
     // numbers in units of il_list_tile launch indices; a pulse with interleave_parts == RTS_INTERLEAVE_LIST traces them
     DevBuf<uint32_t> d_il_list; uint32_t il_list_n = 0, il_list_tile = 0, il_list_gen = 0; uint32_t il_list_last = 0;

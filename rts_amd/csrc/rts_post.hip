@@ -415,21 +415,21 @@ int rts_tile_costs_flush(RtsContext* c)
 {
     if (!c->tile_cost_pending) return RTS_OK;
     c->tile_cost_pending = false; c->order_sum_valid = false;
-    if (c->tile_hist_n == 0 || !c->d_tile_cost.p || !c->d_tile_hist.p) return RTS_OK;
+    if (c->hist->n == 0 || !c->d_tile_cost.p || !c->hist->d.p) return RTS_OK;
     const RtsTileShape p = rts_shape_of(c, c->tile_cost_sig);
     if (p.n_tiles == 0) return RTS_OK;
-    k_tile_merge<<<blocks_for(p.n_tiles, 256), 256, 0, c->stream>>>(c->d_tile_cost.p, p, c->d_tile_hist.p, c->tile_hist_n, nullptr, nullptr);
+    k_tile_merge<<<blocks_for(p.n_tiles, 256), 256, 0, c->stream>>>(c->d_tile_cost.p, p, c->hist->d.p, c->hist->n, nullptr, nullptr);
     RTS_HIP(hipGetLastError());
-    c->tile_hist_any = true;
+    c->hist->any = true;
     return RTS_OK;
 }
 int rts_tile_records_masked(RtsContext* c, uint32_t* d_out, uint32_t n)
 {
     RTS_HIP(hipMemsetAsync(d_out, 0, sizeof(uint32_t) * n, c->stream));
-    if (!c->tile_last_valid || c->tile_hist_n == 0 || !c->d_tile_hist.p) return RTS_OK;
+    if (!c->tile_last_valid || c->hist->n == 0 || !c->hist->d.p) return RTS_OK;
     const RtsTileShape p = rts_shape_of(c, c->tile_last_sig);
     if (p.n_tiles == 0) return RTS_OK;
-    k_tile_records_masked<<<blocks_for(p.n_tiles, 256), 256, 0, c->stream>>>(c->d_tile_hist.p, std::min(c->tile_hist_n, n), p, d_out);
+    k_tile_records_masked<<<blocks_for(p.n_tiles, 256), 256, 0, c->stream>>>(c->hist->d.p, std::min(c->hist->n, n), p, d_out);
     RTS_HIP(hipGetLastError());
     return RTS_OK;
 }
@@ -438,7 +438,7 @@ int rts_tile_records_masked(RtsContext* c, uint32_t* d_out, uint32_t n)
 int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_valid, const uint64_t* cur_sig, uint32_t n_tiles_cur, uint32_t resident_waves)
 {
     hipStream_t st = c->stream;
-    const uint32_t n_hist = c->tile_hist_n;
+    const uint32_t n_hist = c->hist->n;
     // (a launch over a dealt tile list has il_parts = RTS_INTERLEAVE_LIST and the list's generation in il_part; the list on the device is
     // the one BOTH shapes mean: rts_set_tile_list merges pending cost records before it replaces the list)
     auto shape = [c](const uint64_t* sig) { RtsTileShape s; s.first = sig[1]; s.il_tile = (uint32_t)(sig[2] & 0xffffffffu); s.il_parts = (uint32_t)(sig[2] >> 32); s.il_part = (uint32_t)sig[3];
@@ -457,21 +457,21 @@ int rts_tile_order_build(RtsContext* c, const uint64_t* prev_sig, bool prev_vali
         RTS_HIP(c->d_tile_key.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_order.reserve(n_tiles_cur)); RTS_HIP(c->d_xcd.reserve(64));
         unsigned long long* persist = reinterpret_cast<unsigned long long*>(c->d_xcd.p + 32);
         const uint32_t per = (n_tiles_cur + (256u << 10) - 1u) / (256u << 10), fat = blocks_for(n_tiles_cur, 256u * per);      // at most 1 024 blocks
-        k_tile_merge_keys<<<fat, 256, 0, st>>>(c->d_tile_cost.p, cur2, c->d_tile_hist.p, n_hist, reinterpret_cast<unsigned long long*>(head), persist, head ? head + 2 : nullptr, rule2, c->d_tile_key.p, bins, per);
+        k_tile_merge_keys<<<fat, 256, 0, st>>>(c->d_tile_cost.p, cur2, c->hist->d.p, n_hist, reinterpret_cast<unsigned long long*>(head), persist, head ? head + 2 : nullptr, rule2, c->d_tile_key.p, bins, per);
         k_tile_scan_scatter<<<fat, 256, 0, st>>>(c->d_tile_key.p, n_tiles_cur, bins, c->d_tile_ctr.p + RTS_OFF_COARSE, c->d_tile_order.p, reinterpret_cast<const unsigned long long*>(head), head ? persist : nullptr, per, c->d_tile_ctr.p + RTS_OFF_LIVE);
         RTS_HIP(hipGetLastError());
         return RTS_OK;
     }
     bool merged = false;
-    if (!prev_valid && head) { const RtsTileShape cur0 = shape(cur_sig); k_tile_est_sum<<<blocks_for(n_tiles_cur, 256), 256, 0, st>>>(c->d_tile_hist.p, n_hist, cur0, reinterpret_cast<unsigned long long*>(head)); }
-    if (prev_valid) { const RtsTileShape p = shape(prev_sig); if (p.n_tiles) { k_tile_merge<<<blocks_for(p.n_tiles, 256), 256, 0, st>>>(c->d_tile_cost.p, p, c->d_tile_hist.p, n_hist, reinterpret_cast<unsigned long long*>(head), coarse); merged = p.n_tiles == n_tiles_cur; } }
+    if (!prev_valid && head) { const RtsTileShape cur0 = shape(cur_sig); k_tile_est_sum<<<blocks_for(n_tiles_cur, 256), 256, 0, st>>>(c->hist->d.p, n_hist, cur0, reinterpret_cast<unsigned long long*>(head)); }
+    if (prev_valid) { const RtsTileShape p = shape(prev_sig); if (p.n_tiles) { k_tile_merge<<<blocks_for(p.n_tiles, 256), 256, 0, st>>>(c->d_tile_cost.p, p, c->hist->d.p, n_hist, reinterpret_cast<unsigned long long*>(head), coarse); merged = p.n_tiles == n_tiles_cur; } }
     RTS_HIP(c->d_tile_key.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_key_sorted.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_id.reserve(n_tiles_cur)); RTS_HIP(c->d_tile_order.reserve(n_tiles_cur));
     const RtsTileShape cur = shape(cur_sig);
     const RtsHeadRule rule = {c->coop_frac, c->coop_big_now, c->coop_mid, c->coop_floor, resident_waves};
     // (the bands in force were computed by the previous build's scan from the launch before last; a launch of another shape, or no
     // build yet: equal counts)
     const uint32_t* bnd = affine && c->xcd_bnd_tiles == n_tiles_cur ? c->d_xcd.p + 16 : nullptr;
-    k_tile_keys<<<blocks_for(n_tiles_cur, 256), 256, 0, st>>>(c->d_tile_hist.p, n_hist, cur, c->d_tile_key.p, c->d_tile_id.p, reinterpret_cast<const unsigned long long*>(head), head ? head + 2 : nullptr, rule, bins,
+    k_tile_keys<<<blocks_for(n_tiles_cur, 256), 256, 0, st>>>(c->hist->d.p, n_hist, cur, c->d_tile_key.p, c->d_tile_id.p, reinterpret_cast<const unsigned long long*>(head), head ? head + 2 : nullptr, rule, bins,
                                                               affine ? 1 : 0, bnd);
     if (bins) {
         k_tile_bucket_scan<<<1, RTS_TILE_BUCKETS, 0, st>>>(bins, affine ? c->d_xcd.p : nullptr, coarse, n_tiles_cur, affine ? nullptr : c->d_tile_ctr.p + RTS_OFF_LIVE);      // (the affine keys use other bins)

@@ -104,6 +104,13 @@ def plan_rays(total_rays, n_pulses, rank, world, min_items=0):
     return _plan(total_rays, n_pulses, rank, world, 1, min_items)
 
 
+def plan_whole(total_rays, n_pulses, rank, world, min_items=0):
+    """whole pulses only (rts_plan_cpi, RTS_SHARD_PULSES_WHOLE): contiguous runs, the first n_pulses % world ranks one pulse more; with fewer
+    pulses than ranks the left-over rule of plan_cpi.  No launch of a new shape: on a short interval of small pulses that beats splitting the
+    left-over pulses (profiles/r05d_as_rank_pulses_*.log)"""
+    return _plan(total_rays, n_pulses, rank, world, 2, min_items)
+
+
 def refine_plan(plan, min_items):
     """split items until the rank owns at least `min_items` of them, so that it can keep that many pulses (or pulse
     parts) in flight: part p of P (tile T) splits into parts p and p + P of 2P -- every other one of its tiles.  (Same

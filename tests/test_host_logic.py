@@ -122,6 +122,21 @@ def test_file_mesh_reports_malformed_lines(rts, tmp_path, where, damage):
     assert t.shape == (12, 3) and np.isfinite(v).all() and np.isfinite(n).all()
 
 
+def test_plan_whole_pulses(rts):
+    """rts_plan_cpi, RTS_SHARD_PULSES_WHOLE (round 5; bench.py's strong-scaling default): whole pulses only, contiguous runs, every pulse exactly once, the
+    workers' counts at most one apart; with fewer pulses than workers the left-over rule of RTS_SHARD_PULSES (groups of workers share a pulse)"""
+    from rts_amd import multigpu as M
+    total = 97 ** 3
+    for K, N in [(20, 8), (21, 8), (7, 3), (16, 8), (8, 8), (1000, 7), (5, 1)]:
+        plans = [M.plan_whole(total, K, r, N) for r in range(N)]
+        assert all(il is None and first == 0 and count == total for p in plans for (_, first, count, il) in p)
+        flat = [k for p in plans for (k, _, _, _) in p]
+        assert flat == list(range(K)), (K, N)                               # contiguous runs in rank order
+        assert max(len(p) for p in plans) - min(len(p) for p in plans) <= 1
+    for K, N in [(3, 8), (1, 4), (5, 8)]:
+        assert [M.plan_whole(total, K, r, N) for r in range(N)] == [M.plan_cpi(total, K, r, N) for r in range(N)]
+
+
 def test_deal_tiles_partial_table(rts):
     """64 plan tiles, three workers, records for three tiles only (500 / 100 / 50): the 61 tiles without a record are spread by
     COUNT -- they used to enter the longest-first heap with cost 1 and all went to the two lightest workers (0 / ~6 / ~55)"""
