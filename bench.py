@@ -63,7 +63,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~
 PEAK_CLOCK_HZ = 2.4e9          # max shader clock (MI355X_MICROARCH.md)
 N_SIMD, N_CU = 1024, 256
 PRI = 1.0e-3                   # pulse repetition interval of the synthetic CPI
-PMC_TAG = "r04"                # profiles/<tag>_pmc_<workload>.json: counters of the committed kernel (tools/pmc_collect.sh + tools/pmc_derive.py)
+PMC_TAG = "r05"                # profiles/<tag>_pmc_<workload>.json: counters of the committed kernel (tools/pmc_collect.sh + tools/pmc_derive.py)
 
 
 def pulse_motion(spec, k):

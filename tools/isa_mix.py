@@ -15,7 +15,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "_Z7k_traceILb0ELb0ELb0ELb0ELb0ELb0EEv12RtsTraceArgs"      # k_trace<COUNT, KEEP_ALL, REFR, COOP, ASYNC> = all false
+KERNEL = "_Z7k_traceILb0ELb0ELb0ELb0ELb0ELb0ELb1EEv12RtsTraceArgs"      # k_trace<COUNT, KEEP_ALL, REFR, COOP, ASYNC, AFFINE, VERS>: the product kernel (octant versions walked)
 # counted by SQ_INSTS_VALU_{ADD,MUL,FMA}_F32 / _F64 / TRANS_*: priced from the counters, not from this mix
 COUNTED = re.compile(r"^v_(add|sub|subrev|mul|fma|fmac|mac|mad)_(f32|f64)$|^v_pk_(add|mul|fma)_f32$|^v_(rcp|rsq|sqrt|exp|log|sin|cos)_(f32|f64)$")
 
