@@ -139,7 +139,7 @@ def cpu_baseline(spec, seconds_target=12.0):
     threads = len(os.sched_getaffinity(0)) or 1
     sc = H.oracle_scene(O, spec, pulse_motion(spec, 0))
     tx = spec["tx"]; W = spec["W"]; total = W ** 3
-    n = 20000
+    n = max(20000, min(total // 8, 2_000_000))             # the probe that decides "whole pulses or a sample": large enough that starting (and pinning) the threads is not what it measures
     kw = dict(use_bvh=True, threads=threads, debug=False, reuse_buffers=True)
     sc.trace(tx["origin"], tx["span"], tx["dir"], W, spec["max_refl"], 0, spec["smooth"], ray_first=0, ray_stride=total // n, n_rays=n, **kw)   # builds the BVH
     t0 = time.time()
@@ -663,7 +663,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling if world > 1 else "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[%d]%s: %s, 1 Tx / %d Rx, W=%d (%d launch indices/pulse), maxRefl=%d, target moves every pulse (re-placed on the device per pulse; static target-space BVH4)"
-                                   % ({"c3": 2, "c3ecef": 2, "c3ico": 2, "c4": 3, "c5": 4}.get(args.config, 1), " at Earth-centred coordinates" if args.config == "c3ecef" else (" (both transmitters in turn: pulses [0, %d) from Tx 0, [%d, %d) from Tx 1; a receiver's noise temperature grows by the signal's once per transmitter, ray_tracer.cpp:829 -- host side, the SOARS adapter's)" % (half, half, args.steps) if two_tx else (" -- NOT a BASELINE configuration: the scene of the C++ boundary benchmark (tests/adapter/adapter_bench.cpp)" if args.config == "sphere6" else (" (target re-rotated and translated every pulse, ray_tracer.cpp:993-1014; the transmitter's boresight tracks it)" if args.config == "c5" else ""))), spec["name"], len(spec["rx"]), W, total, spec["max_refl"]),
+                                   % ({"c3": 2, "c3ecef": 2, "c3ico": 2, "c4": 3, "c5": 4}.get(args.config, 1), " at Earth-centred coordinates" if args.config == "c3ecef" else (" (both transmitters in turn: pulses [0, %d) from Tx 0, [%d, %d) from Tx 1; a receiver's noise temperature grows by the signal's once per transmitter, ray_tracer.cpp:829 -- host side, the SOARS adapter's)" % (half_of(), half_of(), args.steps) if two_tx else (" -- NOT a BASELINE configuration: the scene of the C++ boundary benchmark (tests/adapter/adapter_bench.cpp)" if args.config == "sphere6" else (" (target re-rotated and translated every pulse, ray_tracer.cpp:993-1014; the transmitter's boresight tracks it)" if args.config == "c5" else ""))), spec["name"], len(spec["rx"]), W, total, spec["max_refl"]),
                        "rays_per_pulse": total, "pulses_in_the_interval": n_int, "segments_per_pulse": seg_all / max(n_int, 1), "received_per_pulse": received_all / max(n_int, 1),
                        "hit_fraction": hit_fraction, "bounding_sphere_fraction": sphere_fraction, "primary_Mrays_per_s": total * n_int / dt / 1e6,
                        "walked_segments_per_pulse": walked_per_pulse, "walked_Mrays_per_s": walked_per_pulse * (seg_all / max(seg_serial * n_int, 1)) * n_int / dt / 1e6,
