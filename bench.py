@@ -597,9 +597,9 @@ def main():
         dense = None
         if args.config in ("c3", "c3ecef", "c3ico"):
             dtx = dict(tx, span=(0.004, 0.004, 0.1)); dn = []
-            for k in range(5):
+            for k in range(10):                              # (the beam changes shape: the handle's tile order needs a few launches to follow -- the settled ones are counted)
                 st = trs[0].trace(dtx["origin"], dtx["span"], dtx["dir"], pulse_motion(spec, args.warmup + k))
-                if k >= 1:
+                if k >= 4:
                     dn.append((st["ms_trace"], st["segments"]))
             dense = dict(Gseg_per_s=float(np.mean([s[1] for s in dn]) / np.mean([s[0] for s in dn]) / 1e6),
                          kernel_ms=float(np.mean([s[0] for s in dn])), segments=float(np.mean([s[1] for s in dn])),
