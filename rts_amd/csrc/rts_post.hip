@@ -88,8 +88,20 @@ __device__ __forceinline__ void expand_row(const RtsTraceArgs& a, const RtsEndRe
     // RCS angle rows, rebuilt from the f32 direction history
     const dvec3 kprim = unit3(rts_primary_dir(*a.lc, slot));
     if (a.max_refr == 0) {
-        dvec3 kin = kprim;
-        for (uint32_t c = 0; c < r.reflDepth && c < D; c++) { const dvec3 k1 = hist_dir(a, c, slot); put_angle(angles, j, D, c, kin, k1); kin = k1; }
+        // ... and, in the product builds, the Doppler sum the trace kernel left out (rts_trace.hip rts_shade; normal_shader.cu:302-314): per reflection
+        // V(target of the path column) . (unit(new direction) - unit(old direction)), added in bounce order from 0 -- the unit vectors are the ones of the angles.
+        dvec3 kin = kprim; double doppler = 0;
+        for (uint32_t c = 0; c < r.reflDepth; c++) {
+            const dvec3 k1 = hist_dir(a, c, slot);
+            if (c < D) put_angle(angles, j, D, c, kin, k1);
+            if (!a.keep_all) {
+                const uint32_t code = (uint32_t)(((c < 8 ? r.path_lo : r.path_hi) >> (8*(c & 7u))) & 0xff);
+                const RtsTargetDev T = a.targets[code ? code - 1u : 0u];          // (every reflection wrote its column: reflDepth <= max_refl <= D)
+                doppler += dot3(mk3(T.vx, T.vy, T.vz), sub3(k1, kin));
+            }
+            kin = k1;
+        }
+        if (!a.keep_all) rays[j].doppler = doppler;
     } else {
         const size_t P = a.max_refl + 1;
         // with refraction enabled the depth gate (normal_shader.cu:134) also shades a hit at reflDepth == maxRefl,

@@ -485,7 +485,10 @@ __device__ __forceinline__ bool rts_shade(const RtsTraceArgs& a, const RtsUnitLd
                     }
                 }
             }
-            if (end == false && rayLength > 0) {                                           // Earth sphere :438-476 (both roots require rayLength > 0, :464)
+            // Earth sphere :438-476 (both roots require rayLength > 0, :464).  It can only touch a ray that was NOT captured (end == false), and such a ray leaves no
+            // record unless every ray is kept: the block -- a quadratic, a square root and two divisions in f64 per missing bounce segment -- is compiled into the
+            // KEEP_ALL builds only (the tests' full-output comparisons, incl. every Earth branch of tests/test_capture_branches.py); what a simulator sees cannot differ.
+            if (KEEP_ALL && end == false && rayLength > 0) {
                 const double d_earthRadius = 6378136;
                 const double A = (dir.x)*(dir.x) + (dir.y)*(dir.y) + (dir.z)*(dir.z);
                 const double B = 2*(prev.x*dir.x + prev.y*dir.y + prev.z*dir.z);
@@ -587,10 +590,16 @@ __device__ __forceinline__ bool rts_shade(const RtsTraceArgs& a, const RtsUnitLd
         if (!(reflDepth < a.max_refl + 1)) return false;                          // :293 (can fail only inside a refracted chain)
         const fvec3 nd = reflect3f(dirf, nf);                              // :296
         power *= T.reflCoeff;                                              // :298
-        const dvec3 k0 = unit3(dir);                                       // :302
+        // Doppler :302-314 -- doppler += V . (unit(new dir) - unit(old dir)): two f64 normalisations (a square root and three divisions each) per shaded hit
+        // for a sum that only a RECEIVED ray ever shows.  The product builds without refraction leave it to the expansion of the received records
+        // (rts_post.hip expand_row), which forms the same unit vectors from the direction history for the RCS angles anyway and adds the same terms in the
+        // same order; the KEEP_ALL builds (every ray's record is output) and the refracting ones (the child inherits the running sum) keep it here.
+        if (KEEP_ALL || REFR) {
+            const dvec3 k0 = unit3(dir);                                   // :302
+            const dvec3 k1 = unit3(widen3(nd));                            // :304
+            doppler += dot3(mk3(T.vx, T.vy, T.vz), sub3(k1, k0));          // :314
+        }
         dir = widen3(nd);                                                  // :303
-        const dvec3 k1 = unit3(dir);                                       // :304
-        doppler += dot3(mk3(T.vx, T.vy, T.vz), sub3(k1, k0));              // :314
         {   // direction history: the RCS angles of received rays are rebuilt from it (:320-326)
             const size_t plane = REFR ? (size_t)chain * (a.max_refl + 1) + reflDepth : (size_t)(reflDepth - 1);
             float* dh = a.dir_hist + plane * 3 * a.n_rays;
@@ -601,7 +610,7 @@ __device__ __forceinline__ bool rts_shade(const RtsTraceArgs& a, const RtsUnitLd
 
 
 // End of a chain: the record of a received ray (and of every ray in the KEEP_ALL builds), ray_tracer.cu:246-253, normal_shader.cu:272-279
-template <bool KEEP_ALL, bool COOP>
+template <bool KEEP_ALL, bool REFR, bool COOP>
 __device__ __forceinline__ void rts_write_back(const RtsTraceArgs& a, const RtsUnitLds& L_, const uint32_t tid, const uint32_t lane, const uint32_t slot, const uint32_t chain,
                                                const RtsRay& S, const uint32_t pending, const uint32_t refr_code0)
 {
@@ -611,7 +620,7 @@ __device__ __forceinline__ void rts_write_back(const RtsTraceArgs& a, const RtsU
     const bool recv = received >= 0;
     if ((recv || KEEP_ALL) && (!COOP || lane == 0)) {
         RtsEndRecord r;
-        r.rayLength = rayLength; r.power = power; r.doppler = doppler;
+        r.rayLength = rayLength; r.power = power; r.doppler = (KEEP_ALL || REFR) ? doppler : 0.0;      // deferred: rts_shade, expand_row
         r.prevx = prev.x; r.prevy = prev.y; r.prevz = prev.z;
         r.firstx = s_first[tid]; r.firsty = s_first[RTS_BLOCK + tid]; r.firstz = s_first[2 * RTS_BLOCK + tid];
         r.path_lo = s_path[tid]; r.path_hi = s_path[RTS_BLOCK + tid]; r.slot = slot; r.received = received; r.reflDepth = reflDepth;
@@ -916,7 +925,7 @@ __device__ __forceinline__ void rts_trace_unit(const RtsTraceArgs& a, const RtsL
             if (!rts_shade<KEEP_ALL, REFR, COOP>(a, L_, tid, gtid, lane, slot, chain, D, max_refr, origin, primary, may_rx, best_t, best_leaf, best_prim, tmin, S, pending, refr_code0)) break;
         }
 
-        rts_write_back<KEEP_ALL, COOP>(a, L_, tid, lane, slot, chain, S, pending, refr_code0);
+        rts_write_back<KEEP_ALL, REFR, COOP>(a, L_, tid, lane, slot, chain, S, pending, refr_code0);
       }   // chain
 }
 
@@ -995,7 +1004,7 @@ __device__ __forceinline__ void rts_trace_unit_async(const RtsTraceArgs& a, cons
                     best_t = RTS_DEFAULT_TMAX; t_prune = RTS_DEFAULT_TMAX; best_leaf = -1; best_prim = 0xffffffffu;
                     targ = a.n_prims > 0 ? 0u : a.n_targets;
                 } else {
-                    rts_write_back<KEEP_ALL, false>(a, L_, tid, lane, slot, 0u, S, pending, refr_code0);
+                    rts_write_back<KEEP_ALL, false, false>(a, L_, tid, lane, slot, 0u, S, pending, refr_code0);
                 }
                 dir = S.dir; prev = S.prev; rayLength = S.rayLength; power = S.power; doppler = S.doppler;
                 st = (S.reflDepth & 0xffu) | (S.end ? 1u << 8 : 0u) | (S.chain_start ? 1u << 9 : 0u) | (go_on ? 1u << 10 : 0u) | (st & (1u << 11)) | ((uint32_t)(S.received + 1) << 16);
