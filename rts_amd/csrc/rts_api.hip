@@ -889,6 +889,10 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     const char* tl_path = count_trav ? getenv("RTS_TIMELINE") : nullptr;      // debug: dump the block/tile timeline of this launch
     const size_t cnt_tl = (size_t)grid * 2 + 2 * (size_t)((n + RTS_WTILE - 1) / RTS_WTILE);          // [grid][2] block ticks, [tiles] durations, [tiles] start ticks
     if (tl_path) { RTS_HIP(c->d_timeline.reserve(cnt_tl + 1)); RTS_HIP(hipMemsetAsync(c->d_timeline.p, 0, sizeof(unsigned long long) * (cnt_tl + 1), st)); a.timeline = c->d_timeline.p; }
+    c->tl_blocks = 0;
+    if (!tl_path && !count_trav && getenv("RTS_TIMELINE_BLOCKS")) {      // debug, product builds: when every block of this launch started and ended (printed by rts_trace_pulse_end)
+        RTS_HIP(c->d_timeline.reserve((size_t)grid * 2 + 1)); RTS_HIP(hipMemsetAsync(c->d_timeline.p, 0, sizeof(unsigned long long) * ((size_t)grid * 2 + 1), st)); a.timeline = c->d_timeline.p; c->tl_blocks = grid;
+    }
     c->last_args = a;
 
     lt.lap(3);
@@ -965,6 +969,16 @@ extern "C" int rts_trace_pulse_end(RtsHandle c)
     if (cnt[13]) { rts_set_error("rts_trace_pulse: %llu counter rows of the launch were never written by their blocks (counting build)", cnt[13]); return RTS_ERR_HIP; }
     if (cnt[6]) { rts_set_error("rts_trace_pulse: traversal stack overflow / malformed BVH guard tripped on %llu waves", cnt[6]); return RTS_ERR_HIP; }
     c->n_recv = cnt[0]; c->n_head_hint = (uint32_t)cnt[7]; c->hist->head_hint = c->n_head_hint; c->hist->head_hint_valid = true;
+    if (c->tl_blocks) {      // RTS_TIMELINE_BLOCKS: the launch as a bulk (every block resident) and a tail (profiles/r05h_batch_launch.log)
+        std::vector<unsigned long long> h((size_t)c->tl_blocks * 2);
+        (void)hipMemcpy(h.data(), c->d_timeline.p, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost);
+        std::vector<unsigned long long> s0, s1; for (uint32_t i = 0; i < c->tl_blocks; i++) { s0.push_back(h[2 * i]); s1.push_back(h[2 * i + 1]); }
+        std::sort(s0.begin(), s0.end()); std::sort(s1.begin(), s1.end());
+        const size_t m = s0.size();
+        fprintf(stderr, "[rts] blocks of handle %p (us, mod 1 s): start min %.1f p50 %.1f p90 %.1f max %.1f | end min %.1f p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f\n", (void*)c,
+                (s0[0] % 100000000ULL) / 100.0, (s0[m / 2] % 100000000ULL) / 100.0, (s0[m * 9 / 10] % 100000000ULL) / 100.0, (s0[m - 1] % 100000000ULL) / 100.0,
+                (s1[0] % 100000000ULL) / 100.0, (s1[m / 10] % 100000000ULL) / 100.0, (s1[m / 2] % 100000000ULL) / 100.0, (s1[m * 9 / 10] % 100000000ULL) / 100.0, (s1[m * 99 / 100] % 100000000ULL) / 100.0, (s1[m - 1] % 100000000ULL) / 100.0);
+    }
     if (c->debug_coop && c->d_xcd.p && c->d_tile_ctr.p) {      // debug: what the head rule of this launch's order build saw (blocking read-backs)
         unsigned long long sums[2] = {0, 0};
         (void)hipMemcpy(&sums[0], c->d_xcd.p + 32, sizeof(unsigned long long), hipMemcpyDeviceToHost);

@@ -1154,7 +1154,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR && COOP) ? 2 : ((REFR || COOP
     const uint32_t D = a.max_refl + max_refr;
 
     unsigned long long tl_t0 = 0;
-    if (COUNT && !COOP && a.timeline && tid == 0) { tl_t0 = wall_clock64(); a.timeline[(size_t)blockIdx.x * 2] = tl_t0; }
+    if (!COOP && a.timeline && tid == 0) { tl_t0 = wall_clock64(); a.timeline[(size_t)blockIdx.x * 2] = tl_t0; }      // (product builds: RTS_TIMELINE_BLOCKS, the blocks' ticks only)
     // Work units are WAVE TILES of 64 consecutive launch indices, taken by the waves one at a time from RTS_TILE_CTRS
     // striped counters: wave w draws k = atomicAdd(ctr[w % C]) and traces position k*C + (w % C) of the tile order.  Tile
     // durations are extremely skewed (median ~2.5 us: every ray misses; 99.9th percentile ~0.3 ms; a handful near 0.9 ms whose
@@ -1413,7 +1413,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR && COOP) ? 2 : ((REFR || COOP
      }   // tiles of the draw
       if (!ahead && lane == 0) RTS_DRAW()
     }
-    if (COUNT && !COOP && a.timeline && tid == 0) a.timeline[(size_t)blockIdx.x * 2 + 1] = wall_clock64();
+    if (!COOP && a.timeline && tid == 0) a.timeline[(size_t)blockIdx.x * 2 + 1] = wall_clock64();
 
     // ------------------------------------------------------------------ counters: wave reduce -> block reduce (LDS, the
     // traversal stack is dead by now) -> one plain store per block; k_sum_counters adds the blocks up.  (One atomic per
