@@ -578,6 +578,27 @@ def main():
             if k >= 2:
                 ser.append((st["ms_trace"], st["segments"]))
         ms_serial = float(np.mean([s[0] for s in ser])); seg_serial = float(np.mean([s[1] for s in ser]))
+        # (1b) the serial launch as a BULK and a tail: when its persistent blocks end (rts_get_block_timeline; a handle created with RTS_TIMELINE_BLOCKS=1, sharing the
+        #      scene and its tile-cost history).  Median block end = the bulk: every block resident, the chip full; the rest is a few dozen tiles that are ONE ray's chain of
+        #      ~1 000 dependent walk steps each, filled by the next pulse's blocks when pulses are pipelined
+        bulk = None
+        if hasattr(rts_amd._lib.lib(), "rts_get_block_timeline") and not os.environ.get("RTS_BENCH_COUNT"):
+            os.environ["RTS_TIMELINE_BLOCKS"] = "1"
+            try:
+                trb = api.Tracer(W, spec["max_refl"], 0, spec["smooth"], device=local_rank)
+            finally:
+                del os.environ["RTS_TIMELINE_BLOCKS"]
+            trb.share_scene(trs[0]); trb.set_receivers(spec["rx"])
+            bl = []
+            for k in range(8):
+                mo = pulse_motion(spec, args.warmup + k); tk = tx_of(0, mo)
+                st = trb.trace(tk["origin"], tk["span"], tk["dir"], mo)
+                if k >= 2:
+                    b = trb.block_timeline(); bl.append((b["end_p50"] * 1e-3, b["end_p90"] * 1e-3, b["end_last"] * 1e-3, st["ms_trace"], b["blocks"]))
+            trb.close()
+            bulk = dict(kernel_ms_bulk=float(np.median([b[0] for b in bl])), block_end_p90_ms=float(np.median([b[1] for b in bl])), block_end_last_ms=float(np.median([b[2] for b in bl])),
+                        kernel_ms_events=float(np.median([b[3] for b in bl])), blocks=int(bl[0][4]),
+                        what="lone launches of a handle that records when its persistent blocks end (100 MHz counter): kernel_ms_bulk = the median block's end -- every block resident until then; block_end_last_ms = the launch")
         # (2) traversal counts and the primary hit fraction: one pulse of the counting build, one pulse with maxRefl = 1
         #     (every primary hit then spawns exactly one more segment, so hit fraction = (segments - rays) / rays)
         trc = api.Tracer(W, spec["max_refl"], 0, spec["smooth"], device=local_rank, count_traversal=True)
@@ -617,7 +638,7 @@ def main():
                 "walked_Gseg_per_s_serial": walked_per_pulse / max(ms_serial, 1e-9) / 1e6,
                 "kernel_ms_overlapped_avg": ms_trace / launches, "gpu_ms_per_launch_timed_region": dt / args.steps * 1e3,
                 "hit_fraction": hit_fraction, "nodes_per_segment": V, "tri_tests_per_segment": T, "shaded_per_segment": Hh,
-                "dense_control": dense, "counters_source": pmc_src if pmc_ok else None}
+                "dense_control": dense, "serial_launch_anatomy": bulk, "counters_source": pmc_src if pmc_ok else None}
         # SURVEY.md section 8(d), figure (B): 288 B of ray state per segment, 128 B per BVH4 node visit, 80 B per triangle test
         # (leaf record), 96 B per shaded hit -- cache-served bytes; as a fraction of the HBM peak it is a yardstick of
         # traversal rate only and may exceed 1 (secondary field, labelled)
@@ -643,6 +664,10 @@ def main():
                             valu_cycles_per_inst=d.get("valu_cycles_per_inst_calibrated"), valu_classes=d.get("valu_classes"), frac_if_every_inst_cost_4_cycles=f_valu4)
             else:
                 roof.update(bound="vmem_issue", achieved=td / t_s / 1e9, peak=N_CU * PEAK_CLOCK_HZ / 1e9, unit="G return-path data cycles/s", frac=f_td)
+            if bulk:                                                # the same counts over the launch's BULK (all blocks resident): how busy the chip is while it is full
+                t_b = bulk["kernel_ms_bulk"] * 1e-3
+                bulk.update(valu_issue_frac=(vcyc * scale if vcyc else valu * 4.0) / (N_SIMD * PEAK_CLOCK_HZ * t_b), vmem_return_path_frac=td / (N_CU * PEAK_CLOCK_HZ * t_b),
+                            note="the launch's instruction counts over its bulk alone (an upper estimate by the tail's share of the instructions: a few dozen of ~26 000 live tiles)")
             t_w = dt / args.steps                                   # GPU time per launch in the timed region (kernels of --inflight pulses overlap)
             roof.update(valu_issue_frac=f_valu, vmem_return_path_frac=f_td, source_hash=lib_hash,
                         timed_region={"valu_issue_frac": (vcyc * scale if vcyc else valu * 4.0) / (N_SIMD * PEAK_CLOCK_HZ * t_w), "vmem_return_path_frac": td / (N_CU * PEAK_CLOCK_HZ * t_w),

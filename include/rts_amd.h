@@ -224,6 +224,9 @@ int rts_trace_pulse_begin(RtsHandle h, const RtsPulse* pulse);
 int rts_trace_pulse_end(RtsHandle h);
 int rts_link_handles(RtsHandle a, RtsHandle b);               /* same device; groups grow by linking a member to a new handle */
 int rts_get_stats(RtsHandle h, RtsStats* out);
+/* Diagnostic (handles created with RTS_TIMELINE_BLOCKS=1; product builds): when the persistent blocks of the last launch started and ended -- out[0..2] first / median /
+ * last block start, out[3..7] first / 10th percentile / median / 90th percentile / last block end, microseconds after the first start, out[8] the number of blocks. */
+int rts_get_block_timeline(RtsHandle h, double* out, uint32_t n);
 
 /* Received rays of the last pulse (ray_tracer.cpp:1186-1257 before the gain/RCS update):
  * rays[R], paths[R][D] (h_rx_intersects, D = max_refr + max_refl), rcs_angles[R][D][2],

@@ -149,7 +149,7 @@ _lib = None
 
 # every symbol include/rts_amd.h declares
 EXPORTS = ["rts_create", "rts_destroy", "rts_last_error", "rts_device_count", "rts_set_scene", "rts_share_scene", "rts_scene_info", "rts_set_receivers",
-           "rts_trace_pulse", "rts_reserve", "rts_trace_pulse_begin", "rts_trace_pulse_end", "rts_link_handles", "rts_get_stats", "rts_received_count", "rts_get_received", "rts_get_all_rays",
+           "rts_trace_pulse", "rts_reserve", "rts_trace_pulse_begin", "rts_trace_pulse_end", "rts_link_handles", "rts_get_stats", "rts_get_block_timeline", "rts_received_count", "rts_get_received", "rts_get_all_rays",
            "rts_finalise_uniform", "rts_trace_pulse_end_uniform", "rts_aggregate", "rts_group_count", "rts_get_groups", "rts_get_aggregated",
            "rts_merge_groups", "rts_groups_to_responses", "rts_kernel_wrapper", "rts_vertex_rotation",
            "rts_rotation_matrix", "rts_rect_mesh", "rts_sphere_mesh", "rts_file_mesh", "rts_rx_sphere", "rts_get_bvh",
@@ -179,6 +179,7 @@ def lib():
         "rts_trace_pulse": [vp, C.POINTER(RtsPulse)],
         "rts_reserve": [vp, u64],
         "rts_trace_pulse_begin": [vp, C.POINTER(RtsPulse)],
+        "rts_get_block_timeline": [vp, vp, u32],
         "rts_trace_pulse_end": [vp],
         "rts_link_handles": [vp, vp],
         "rts_get_stats": [vp, C.POINTER(RtsStats)],

@@ -190,6 +190,12 @@ class Tracer:
             _PY_LAP[k] = _PY_LAP.get(k, 0.0) + v
         _PY_LAP["n"] = _PY_LAP.get("n", 0) + 1
 
+    def block_timeline(self):
+        """rts_get_block_timeline (a tracer created with RTS_TIMELINE_BLOCKS=1): dict of the last launch's block start / end times in us after the first start"""
+        out = np.zeros(9, np.float64)
+        check(L.lib().rts_get_block_timeline(self.h, ptr(out), 9))
+        return dict(zip(("start_first", "start_p50", "start_last", "end_first", "end_p10", "end_p50", "end_p90", "end_last", "blocks"), out.tolist()))
+
     def trace_end(self):
         check(L.lib().rts_trace_pulse_end(self.h))
 

@@ -208,6 +208,7 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     c->hist = new RtsTileHist();
     { const char* e = getenv("RTS_SHARE_HISTORY"); if (e) c->share_history = e[0] != '0'; }
     { const char* e = getenv("RTS_RX_WINDOW_SCREEN"); if (e) c->rx_window_screen = e[0] != '0'; }
+    { const char* e = getenv("RTS_TIMELINE_BLOCKS"); if (e) c->timeline_blocks = e[0] != '0'; }
     { const char* e = getenv("RTS_DEAD_BATCH"); if (e) c->batch_dead = strcmp(e, "all") == 0 ? 2 : (e[0] != '0' ? 1 : 0); }      // dead-tile batches of the trace kernel: 0 never, 1 the order's dead part (default), all: every position is screened tile-wise first (tests)
     { const char* e = getenv("RTS_WALK_VERSIONS"); if (e) c->node_versions = e[0] != '0'; }      // (per handle: RTS_NODE_VERSIONS decides whether the scene HAS versions, this whether the handle walks them)
     { const char* e = getenv("RTS_SUM_IN_KERNEL"); if (e) c->sum_in_kernel = atoi(e) != 0; }
@@ -890,7 +891,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     const size_t cnt_tl = (size_t)grid * 2 + 2 * (size_t)((n + RTS_WTILE - 1) / RTS_WTILE);          // [grid][2] block ticks, [tiles] durations, [tiles] start ticks
     if (tl_path) { RTS_HIP(c->d_timeline.reserve(cnt_tl + 1)); RTS_HIP(hipMemsetAsync(c->d_timeline.p, 0, sizeof(unsigned long long) * (cnt_tl + 1), st)); a.timeline = c->d_timeline.p; }
     c->tl_blocks = 0;
-    if (!tl_path && !count_trav && getenv("RTS_TIMELINE_BLOCKS")) {      // debug, product builds: when every block of this launch started and ended (printed by rts_trace_pulse_end)
+    if (!tl_path && !count_trav && c->timeline_blocks) {      // debug, product builds: when every block of this launch started and ended (printed by rts_trace_pulse_end)
         RTS_HIP(c->d_timeline.reserve((size_t)grid * 2 + 1)); RTS_HIP(hipMemsetAsync(c->d_timeline.p, 0, sizeof(unsigned long long) * ((size_t)grid * 2 + 1), st)); a.timeline = c->d_timeline.p; c->tl_blocks = grid;
     }
     c->last_args = a;
@@ -969,15 +970,17 @@ extern "C" int rts_trace_pulse_end(RtsHandle c)
     if (cnt[13]) { rts_set_error("rts_trace_pulse: %llu counter rows of the launch were never written by their blocks (counting build)", cnt[13]); return RTS_ERR_HIP; }
     if (cnt[6]) { rts_set_error("rts_trace_pulse: traversal stack overflow / malformed BVH guard tripped on %llu waves", cnt[6]); return RTS_ERR_HIP; }
     c->n_recv = cnt[0]; c->n_head_hint = (uint32_t)cnt[7]; c->hist->head_hint = c->n_head_hint; c->hist->head_hint_valid = true;
-    if (c->tl_blocks) {      // RTS_TIMELINE_BLOCKS: the launch as a bulk (every block resident) and a tail (profiles/r05h_batch_launch.log)
+    if (c->tl_blocks) {      // RTS_TIMELINE_BLOCKS: the launch as a bulk (every block resident) and a tail (rts_get_block_timeline; profiles/r05h_batch_launch.log)
         std::vector<unsigned long long> h((size_t)c->tl_blocks * 2);
         (void)hipMemcpy(h.data(), c->d_timeline.p, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost);
         std::vector<unsigned long long> s0, s1; for (uint32_t i = 0; i < c->tl_blocks; i++) { s0.push_back(h[2 * i]); s1.push_back(h[2 * i + 1]); }
         std::sort(s0.begin(), s0.end()); std::sort(s1.begin(), s1.end());
-        const size_t m = s0.size();
-        fprintf(stderr, "[rts] blocks of handle %p (us, mod 1 s): start min %.1f p50 %.1f p90 %.1f max %.1f | end min %.1f p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f\n", (void*)c,
-                (s0[0] % 100000000ULL) / 100.0, (s0[m / 2] % 100000000ULL) / 100.0, (s0[m * 9 / 10] % 100000000ULL) / 100.0, (s0[m - 1] % 100000000ULL) / 100.0,
-                (s1[0] % 100000000ULL) / 100.0, (s1[m / 10] % 100000000ULL) / 100.0, (s1[m / 2] % 100000000ULL) / 100.0, (s1[m * 9 / 10] % 100000000ULL) / 100.0, (s1[m * 99 / 100] % 100000000ULL) / 100.0, (s1[m - 1] % 100000000ULL) / 100.0);
+        const size_t m = s0.size(); const unsigned long long t0 = s0[0];
+        const size_t q[8] = {0, m / 2, m - 1, 0, m / 10, m / 2, m * 9 / 10, m - 1};
+        for (int k = 0; k < 8; k++) c->tl_summary[k] = (double)((k < 3 ? s0[q[k]] : s1[q[k]]) - t0) / 100.0;      // us after the first block's start (100 MHz counter)
+        c->tl_summary[8] = (double)m;
+        if (c->debug_coop) fprintf(stderr, "[rts] blocks of handle %p (us after the first start): start p50 %.1f max %.1f | end min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f\n", (void*)c,
+                                   c->tl_summary[1], c->tl_summary[2], c->tl_summary[3], c->tl_summary[4], c->tl_summary[5], c->tl_summary[6], c->tl_summary[7]);
     }
     if (c->debug_coop && c->d_xcd.p && c->d_tile_ctr.p) {      // debug: what the head rule of this launch's order build saw (blocking read-backs)
         unsigned long long sums[2] = {0, 0};
@@ -1029,6 +1032,18 @@ extern "C" int rts_get_stats(RtsHandle c, RtsStats* out)
 // longest walk of every bounce round of every tile), out[1] of them issued to lanes that were in the round at all, out[2]
 // walk steps actually taken.  1 - out[1]/out[0]: what lanes that left their tile early cost (re-packing rays between rounds could
 // recover at most this); (out[1] - out[2])/out[0]: what waiting for the round's slowest lane costs.
+// When the persistent blocks of the handle's last launch started and ended (a handle created with RTS_TIMELINE_BLOCKS=1; product builds): out[0..2] first / median / last
+// block START, out[3..7] first / 10th percentile / median / 90th percentile / last block END, all in microseconds after the first start (the 100 MHz counter), out[8] the blocks.
+// A launch is a BULK -- every block resident; the median end -- and a tail of the few tiles that are one ray's long chain of dependent steps.
+extern "C" int rts_get_block_timeline(RtsHandle c, double* out, uint32_t n)
+{
+    if (!c || !out) { rts_set_error("rts_get_block_timeline: null argument"); return RTS_ERR_INVALID; }
+    CHECK_CLOSED(c);
+    if (!c->timeline_blocks || c->tl_summary[8] == 0.0) { rts_set_error("rts_get_block_timeline: the handle records no block timeline (create it with RTS_TIMELINE_BLOCKS=1, product build) or has not traced yet"); return RTS_ERR_INVALID; }
+    for (uint32_t k = 0; k < n && k < 9; k++) out[k] = c->tl_summary[k];
+    return RTS_OK;
+}
+
 extern "C" int rts_get_lane_stats(RtsHandle c, uint64_t* out3)
 {
     if (!c || !out3) { rts_set_error("rts_get_lane_stats: null argument"); return RTS_ERR_INVALID; }

@@ -353,6 +353,7 @@ struct RtsContext {
     DevBuf<double> d_delay, d_phase; DevBuf<int32_t> d_pathmatch; DevBuf<double> d_rcs;
     std::vector<RtsGroup> groups; bool agg_valid = false; uint64_t recv_index_base = 0;
     bool rx_window_screen = true;       // RTS_RX_WINDOW_SCREEN
+    bool timeline_blocks = false; double tl_summary[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // RTS_TIMELINE_BLOCKS (rts_get_block_timeline)
     uint32_t tl_blocks = 0;             // debug (RTS_TIMELINE_BLOCKS): blocks whose start / end ticks this launch recorded
     int batch_dead = 1;                 // dead-tile batches of the trace kernel (RTS_DEAD_BATCH = 0 / 1 / all)
     bool node_versions = true;          // the ordinary trace kernel walks the octant versions of the node records when the scene has them (RTS_NODE_VERSIONS=0: the role fetch + sorting network)

@@ -1726,3 +1726,27 @@ def test_differential_fuzz_seeds(rts):
         F.same(a, b, "seed %d: pre-filter on / off" % seed)
         F.same(a, c, "seed %d: host / device tree" % seed)
         F.against_oracle(spec, a)
+
+
+def test_block_timeline_of_a_product_launch(rts, scenes, monkeypatch):
+    """rts_get_block_timeline (handles created with RTS_TIMELINE_BLOCKS=1): when the persistent blocks of the last launch started and ended -- ordered, inside the
+    launch's event time, one entry per block; the results are the bits of a handle without it; a handle that records none says so"""
+    spec = scenes.config3(W=56, detail=0.3, rx_radius=300.0)
+    plain = H.gpu_tracer(rts, spec)
+    _, st0 = H.gpu_trace(rts, spec, tr=plain); want = plain.received()
+    from rts_amd import _lib
+    with pytest.raises(_lib.RtsError):
+        plain.block_timeline()
+    monkeypatch.setenv("RTS_TIMELINE_BLOCKS", "1")
+    tr = H.gpu_tracer(rts, spec)
+    monkeypatch.delenv("RTS_TIMELINE_BLOCKS")
+    for rep in range(2):
+        _, st = H.gpu_trace(rts, spec, tr=tr)
+        b = tr.block_timeline()
+        assert b["blocks"] >= 1 and 0.0 == b["start_first"] <= b["start_p50"] <= b["start_last"], b
+        assert 0.0 < b["end_first"] <= b["end_p10"] <= b["end_p50"] <= b["end_p90"] <= b["end_last"] <= st["ms_trace"] * 1e3 + 50.0, (b, st["ms_trace"])
+    got = tr.received()
+    assert np.array_equal(got["slots"], want["slots"]) and np.array_equal(got["path"], want["path"])
+    H.assert_prd_equal(got["results"], want["results"], "block timeline on / off")
+    assert (st["segments"], st["shaded"], st["received"]) == (st0["segments"], st0["shaded"], st0["received"])
+    tr.close(); plain.close()
