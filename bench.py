@@ -664,7 +664,9 @@ def main():
                             valu_cycles_per_inst=d.get("valu_cycles_per_inst_calibrated"), valu_classes=d.get("valu_classes"), frac_if_every_inst_cost_4_cycles=f_valu4)
             else:
                 roof.update(bound="vmem_issue", achieved=td / t_s / 1e9, peak=N_CU * PEAK_CLOCK_HZ / 1e9, unit="G return-path data cycles/s", frac=f_td)
-            if bulk:                                                # the same counts over the launch's BULK (all blocks resident): how busy the chip is while it is full
+            if bulk and pmc.get("coop_per_launch"):                # (a launch with a cooperative kernel beside the ordinary one: the counts are both kernels', the bulk the ordinary kernel's)
+                bulk.update(note="the cooperative kernel runs beside this (ordinary) kernel to the end of the launch (kernel_ms_events): the launch's instruction counts are not this bulk's")
+            elif bulk:                                              # the same counts over the launch's BULK (all blocks resident): how busy the chip is while it is full
                 t_b = bulk["kernel_ms_bulk"] * 1e-3
                 bulk.update(valu_issue_frac=(vcyc * scale if vcyc else valu * 4.0) / (N_SIMD * PEAK_CLOCK_HZ * t_b), vmem_return_path_frac=td / (N_CU * PEAK_CLOCK_HZ * t_b),
                             note="the launch's instruction counts over its bulk alone (an upper estimate by the tail's share of the instructions: a few dozen of ~26 000 live tiles)")
