@@ -209,6 +209,7 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     { const char* e = getenv("RTS_SHARE_HISTORY"); if (e) c->share_history = e[0] != '0'; }
     { const char* e = getenv("RTS_RX_WINDOW_SCREEN"); if (e) c->rx_window_screen = e[0] != '0'; }
     { const char* e = getenv("RTS_TIMELINE_BLOCKS"); if (e) c->timeline_blocks = e[0] != '0'; }
+    { const char* e = getenv("RTS_COOP_VERSIONS"); if (e) c->coop_versions = e[0] != '0'; }
     { const char* e = getenv("RTS_DEAD_BATCH"); if (e) c->batch_dead = strcmp(e, "all") == 0 ? 2 : (e[0] != '0' ? 1 : 0); }      // dead-tile batches of the trace kernel: 0 never, 1 the order's dead part (default), all: every position is screened tile-wise first (tests)
     { const char* e = getenv("RTS_WALK_VERSIONS"); if (e) c->node_versions = e[0] != '0'; }      // (per handle: RTS_NODE_VERSIONS decides whether the scene HAS versions, this whether the handle walks them)
     { const char* e = getenv("RTS_SUM_IN_KERNEL"); if (e) c->sum_in_kernel = atoi(e) != 0; }
@@ -863,6 +864,7 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
         const uint64_t sig[4] = {n, first, ((uint64_t)il_parts << 32) | il_tile, il_part};
         const bool aligned = first % RTS_WTILE == 0 && (il_parts <= 1 || il_tile % RTS_WTILE == 0);
         a.rx_window_screen = c->rx_window_screen ? 1u : 0u;
+        a.coop_versions = c->coop_versions ? 1u : 0u;
         a.batch_dead = aligned ? (uint32_t)c->batch_dead : 0u;      // (a wave tile must be 64 CONSECUTIVE launch indices for the tile-level screen: rts_tile_maybe)
         const uint32_t n_hist = (uint32_t)((total + RTS_WTILE - 1) / RTS_WTILE);
         RTS_HIP(c->d_tile_ctr.reserve(RTS_ZERO_WORDS + RTS_MASK_WORDS + 64)); c->p_counters = reinterpret_cast<unsigned long long*>(c->d_tile_ctr.p + RTS_OFF_COUNTERS); a.counters = c->p_counters;

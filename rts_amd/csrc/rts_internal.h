@@ -187,6 +187,7 @@ struct RtsTraceArgs {
     const uint32_t* tile_head_all;  // the same word whether or not this launch has a cooperative kernel (read back with the counters)
     const uint32_t* tile_live;      // != null: [1 + tiles at the front of tile_order that cost more than a dead tile last time] (0: unknown); the order behind them is drawn 64 tiles at a time, one LANE per tile (k_trace: dead-tile batches)
     uint32_t rx_window_screen;      // 1: the pre-filter also asks whether a crossing of a capture sphere can lie in the receiver's angular window (RTS_RX_WINDOW_SCREEN=0: only whether the sphere is reached)
+    uint32_t coop_versions;         // 1: the cooperative kernel walks the octant versions too (product and counting builds of the plain chain; RTS_COOP_VERSIONS=0: the plain records and the sorted children)
     uint32_t batch_dead;            // 0: never batch; 1: batch the order's dead region (needs tile_live); 2: every position goes through the tile-level test first (RTS_DEAD_BATCH=all: tests)
     uint32_t* done_ctr; uint32_t n_blocks_all; unsigned long long* host_cnt;      // the last block of the launch (ticket from done_ctr, zero at launch) sums the block counters and writes them home
     uint32_t async_idle0, async_idle1, async_age;   // asynchronous bounces (rts_trace_unit_async): idle-lane limit of a walk phase for young / old tiles (0: lock-step kernel), age in cost units
@@ -355,6 +356,7 @@ struct RtsContext {
     bool rx_window_screen = true;       // RTS_RX_WINDOW_SCREEN
     bool timeline_blocks = false; double tl_summary[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // RTS_TIMELINE_BLOCKS (rts_get_block_timeline)
     uint32_t tl_blocks = 0;             // debug (RTS_TIMELINE_BLOCKS): blocks whose start / end ticks this launch recorded
+    bool coop_versions = true;          // RTS_COOP_VERSIONS
     int batch_dead = 1;                 // dead-tile batches of the trace kernel (RTS_DEAD_BATCH = 0 / 1 / all)
     bool node_versions = true;          // the ordinary trace kernel walks the octant versions of the node records when the scene has them (RTS_NODE_VERSIONS=0: the role fetch + sorting network)
     bool debug_coop = false;            // RTS_DEBUG_COOP: one line per launch on stderr (grids, head hint, thresholds)

@@ -325,7 +325,7 @@ __device__ __forceinline__ void rts_walk_step(const RtsTraceArgs& a, int32_t* s_
 // empty stack, and entries are handed over in the iteration they are taken in, so nothing is pending then).
 __device__ __forceinline__ float rts_wave_min_f32(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o)); return v; }
 __device__ __forceinline__ unsigned long long rts_wave_min_u64(unsigned long long v) { for (int o = 32; o > 0; o >>= 1) { const unsigned long long w = __shfl_xor(v, o); v = w < v ? w : v; } return v; }
-template <bool COUNT>
+template <bool COUNT, bool VERS = false>
 __device__ __forceinline__ void rts_walk_coop(const RtsTraceArgs& a, int32_t* s_stack, int32_t* s_exch, uint32_t tid, uint32_t gtid, uint32_t lane, int lds_cap, uint32_t* n_spill_lds,
                                               int root, const RtsSlabRay& lr, const dvec3& prev, const dvec3& dir, float tmin,
                                               float& best_t, int& best_leaf, uint32_t& best_prim, float& t_prune, uint32_t& n_nodes, uint32_t& n_tris, bool& hard_overflow)
@@ -336,7 +336,7 @@ __device__ __forceinline__ void rts_walk_coop(const RtsTraceArgs& a, int32_t* s_
     int sp = 1, bot = 1;                                  // pending entries of this lane: [bot, sp)
     int node = lane == 0 ? root : SENTINEL;
     uint32_t steps = 0;
-    const RtsSlabRay lp = rts_slab_by_plane(lr);          // (this kernel reads its records straight through: rts_fetch_record_plain)
+    const RtsSlabRay lp = VERS ? lr : rts_slab_by_plane(lr);          // (this kernel reads its records straight through: rts_fetch_record_plain; the octant versions' planes are entry / exit planes already)
     for (;;) {
         const bool busy = node != SENTINEL;
         const unsigned long long busy_m = __ballot(busy);
@@ -359,7 +359,7 @@ __device__ __forceinline__ void rts_walk_coop(const RtsTraceArgs& a, int32_t* s_
         bool improved = false;
         if (node != SENTINEL) {
             const float before = t_prune;
-            rts_walk_step<COUNT, RTS_WALK_PLANES>(a, s_stack, tid, gtid, lds_cap, n_spill_lds, node, sp, lp, prev, dir, tmin, best_t, best_leaf, best_prim, t_prune, n_nodes, n_tris, hard_overflow);
+            rts_walk_step<COUNT, VERS ? RTS_WALK_VERSIONS : RTS_WALK_PLANES>(a, s_stack, tid, gtid, lds_cap, n_spill_lds, node, sp, lp, prev, dir, tmin, best_t, best_leaf, best_prim, t_prune, n_nodes, n_tris, hard_overflow);
             improved = t_prune != before;
         }
         if (__any(improved)) t_prune = rts_wave_min_f32(t_prune);
@@ -886,7 +886,7 @@ __device__ __forceinline__ void rts_trace_unit(const RtsTraceArgs& a, const RtsL
                     const int SENTINEL = RTS_STACK_SENTINEL;
                     const int lds_cap = (int)a.stack_lds;
                     if (COOP) {
-                        rts_walk_coop<COUNT>(a, s_stack, s_exch, tid, gtid, lane, lds_cap, &s_n[2 * RTS_BLOCK + tid], TG.root, lr, prev, dir, tmin, best_t, best_leaf, best_prim, t_prune,
+                        rts_walk_coop<COUNT, VERS>(a, s_stack, s_exch, tid, gtid, lane, lds_cap, &s_n[2 * RTS_BLOCK + tid], VERS ? (int)(((uint32_t)TG.root << 3) | oct) : TG.root, lr, prev, dir, tmin, best_t, best_leaf, best_prim, t_prune,
                                              n_nodes, n_tris, hard_overflow);
                         if (COUNT) steps = 1u;                                       // (the segment entered a hierarchy: RtsStats::walked_segments)
                     } else {
@@ -1500,6 +1500,14 @@ static void rts_trace_dispatch(const RtsTraceArgs& a, bool count_traversal, unsi
             case 6: k_trace<false, true, true, false, false, false, true><<<grid, RTS_BLOCK, 0, st>>>(a); break;
             default: k_trace<true, true, true, false, false, false, true><<<grid, RTS_BLOCK, 0, st>>>(a); break;
         }
+        return;
+    }
+    // (round 5, late) the cooperative kernel walks the octant versions too -- product / counting build of the plain chain: its node step loses the sorting network and the
+    // low / high selects like the ordinary kernel's did, and all 64 lanes of a unit walk ONE ray, one octant: BASELINE configs[3] lone launch 4.72 -> 4.52 ms, pipelined 5.21 -> 5.10,
+    // an eighth of the pulse 1.18 -> 1.14 ms (profiles/r05p_coop_versions.log).  RTS_COOP_VERSIONS=0: the plain records.
+    if (COOP && a.nodes4v && a.coop_versions && sel < 2) {
+        if (sel == 0) k_trace<false, false, false, true, false, false, true><<<grid, RTS_BLOCK, 0, st>>>(a);
+        else k_trace<true, false, false, true, false, false, true><<<grid, RTS_BLOCK, 0, st>>>(a);
         return;
     }
     switch (sel) {

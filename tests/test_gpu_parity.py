@@ -1177,7 +1177,9 @@ def test_cooperative_units_are_invisible(rts, oracle, scenes, monkeypatch):
     refr["meshes"] = [dict(m, refl_coeff=0.6, refr_index=1.5) for m in refr["meshes"]]
     refr["rx"] = refr["rx"] + [scenes._rx_at((200.0, 0.0, 0.0), (0, 0, 0), 90.0, 2.6)]
     cases = [("c3", c3, {}), ("c3 ecef", scenes.translate(c3, scenes.ecef_offset(lat=math.pi / 2)), {}), ("multi", multi, {}), ("refraction", refr, {}),
-             ("c3 short stack", c3, {"RTS_STACK_LDS_DEBUG": "3"}), ("miss branches", scenes.config_miss_branches(W=44), {})]
+             ("c3 short stack", c3, {"RTS_STACK_LDS_DEBUG": "3"}), ("miss branches", scenes.config_miss_branches(W=44), {}),
+             ("c3, plain records in the cooperative walk", c3, {"RTS_COOP_VERSIONS": "0"}),      # (default since round 5: the cooperative kernel of the product / counting builds walks the octant versions)
+             ("multi, plain records, short stack", multi, {"RTS_COOP_VERSIONS": "0", "RTS_STACK_LDS_DEBUG": "3"})]
     for name, spec, env in cases:
         n = spec["W"] ** 3
         for k, v in env.items():

@@ -477,7 +477,7 @@ def test_product_trace_kernels_use_no_scratch():
                 assert not in_loop or (t.startswith("scratch_load") and depth <= 2), (name, depth, t)      # wave); RELOADS of such a loop-invariant value per draw or per tile (depth <= 2), never per segment or walk step (r05:
                                                                                                             # the dead-tile batches' screen took the last register the draw counter's address had)
         assert fetch_blocks >= 1 and asm_loads == 0, (name, fetch_blocks, asm_loads)     # every asm load group ends in its own wait
-    assert seen == 15      # 4 ordinary (role fetch) + 4 ordinary (octant versions) + 4 cooperative + 2 asynchronous + 1 XCD-affine product instantiations
+    assert seen == 16      # 4 ordinary (role fetch) + 4 ordinary (octant versions) + 4 cooperative + 1 cooperative (octant versions) + 2 asynchronous + 1 XCD-affine product instantiations
 
 
 def test_fuzz_generator_versions_are_frozen(rts):
