@@ -173,6 +173,36 @@ def pulses_on_one_handle(spec, seed):
     tr.close()
 
 
+def cooperative_pulses(spec, seed):
+    """round 5: three pulses on ONE handle of the PRODUCT build and of the counting build with every tile that cost anything handed to the cooperative kernel
+    (which walks the octant versions in these two builds) -- the received set of pulses 1 and 2 against fresh launches without cooperative units"""
+    rng = np.random.default_rng(seed + 31337)
+    env = {"RTS_COOP_FRAC": "1e-12", "RTS_COOP_FLOOR": "0", "RTS_COOP_SEG": "0", "RTS_GRID_MULT": "1"}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        trp = H.gpu_tracer(api, spec); trc = H.gpu_tracer(api, spec, count_traversal=True)
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+    sp = spec; coop = 0
+    for k in range(3):
+        outs = []
+        for tr in (trp, trc):
+            _, st = H.gpu_trace(api, sp, tr=tr, motion=sp["motion"]); outs.append((tr.received(), st)); coop += st["coop_tiles"]
+        if k:
+            ref = run(sp, pre_filter=False)
+            for (rec, st), what in zip(outs, ("product", "counting")):
+                assert np.array_equal(rec["slots"], ref[1]["slots"]) and np.array_equal(rec["path"], ref[1]["path"]), (seed, k, what, "cooperative pulses: rows / paths")
+                H.assert_prd_equal(rec["results"], ref[1]["results"], "seed %d: pulse %d, cooperative kernel forced, %s build" % (seed, k, what))
+                assert rec["rcs_angle"].tobytes() == ref[1]["rcs_angle"].tobytes(), (seed, k, what)
+                assert (st["segments"], st["shaded"], st["received"]) == (ref[2]["segments"], ref[2]["shaded"], ref[2]["received"]), (seed, k, what, st, ref[2])
+        sp = moved(sp, rng)
+    trp.close(); trc.close()
+    return coop
+
+
 def dealt_parts(spec, seed, whole):
     """the launch split into 2-4 parts by a RANDOM map of plan tiles (rts_set_tile_list, RTS_INTERLEAVE_LIST): the parts' received sets,
     merged by buffer row, and their segment / shaded counts are the whole launch's"""
@@ -256,6 +286,8 @@ def main():
                 pulses_on_one_handle(spec, seed)
             if seed % 3 == 0:
                 dealt_parts(spec, seed, a)
+            if seed % 2 == 1:
+                tot["coop_tiles"] = tot.get("coop_tiles", 0) + cooperative_pulses(spec, seed)
         except Exception as e:
             print("FAILED seed %d (%s, aimed %s, W=%d, refl=%d, refr=%s): %r" % (seed, place, aim, spec["W"], spec["max_refl"], "max_refr" in spec, e), flush=True)
             raise
