@@ -275,6 +275,8 @@ def main():
         spec = scenes.config2(W=args.width or 100)
     else:
         spec = scenes.config2_file(W=args.width or 100)
+    if os.environ.get("RTS_BENCH_RX_FAR"):                     # diagnostic: the receivers moved 1 000 km away -- the same launches, nothing received (what a received set costs the pipeline)
+        spec["rx"] = [dict(r, centre=tuple(np.add(r["centre"], (1.0e6, 0.0, 0.0)))) for r in spec["rx"]]
     W = spec["W"]; total = W ** 3
     tx = spec["tx"]; wl = spec["c"] / spec["carrier"]
     if args.tx != "0" and "tx_list" not in spec:
