@@ -185,7 +185,6 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     if (e != hipSuccess) { delete c->gate; (void)hipStreamDestroy(c->stream); delete c; rts_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return RTS_ERR_HIP; }
     c->tstream = c->gate->tstream; c->tstream_now = c->tstream;
     e = hipEventCreateWithFlags(&c->ev_spec, hipEventDisableTiming); if (e != hipSuccess) { delete c; rts_set_error("hipEventCreate: %s", hipGetErrorString(e)); return RTS_ERR_HIP; }
-    for (int i = 0; i < 2; i++) { e = hipEventCreateWithFlags(&c->ev_gate[i], hipEventDisableTiming); if (e != hipSuccess) { delete c; rts_set_error("hipEventCreate: %s", hipGetErrorString(e)); return RTS_ERR_HIP; } }
     for (int i = 0; i < 2; i++) { e = hipEventCreateWithFlags(&c->ev_coop[i], hipEventDisableTiming); if (e != hipSuccess) { delete c; rts_set_error("hipEventCreate: %s", hipGetErrorString(e)); return RTS_ERR_HIP; } }
     for (int i = 0; i < 9; i++) { e = hipEventCreate(&c->ev[i]); if (e != hipSuccess) { delete c; rts_set_error("hipEventCreate: %s", hipGetErrorString(e)); return RTS_ERR_HIP; } }
     e = hipHostMalloc((void**)&c->pin, sizeof(RtsPinned), hipHostMallocDefault);
@@ -211,7 +210,6 @@ extern "C" int rts_create(const RtsParams* p, RtsHandle* out)
     { const char* e = getenv("RTS_RX_WINDOW_SCREEN"); if (e) c->rx_window_screen = e[0] != '0'; }
     { const char* e = getenv("RTS_TIMELINE_BLOCKS"); if (e) c->timeline_blocks = e[0] != '0'; }
     { const char* e = getenv("RTS_COOP_VERSIONS"); if (e) c->coop_versions = e[0] != '0'; }
-    { const char* e = getenv("RTS_TRACE_GATE"); if (e) c->trace_gate = std::max(0, std::min(8, atoi(e))); }
     { const char* e = getenv("RTS_DEAD_BATCH"); if (e) c->batch_dead = strcmp(e, "all") == 0 ? 2 : (e[0] != '0' ? 1 : 0); }      // dead-tile batches of the trace kernel: 0 never, 1 the order's dead part (default), all: every position is screened tile-wise first (tests)
     { const char* e = getenv("RTS_WALK_VERSIONS"); if (e) c->node_versions = e[0] != '0'; }      // (per handle: RTS_NODE_VERSIONS decides whether the scene HAS versions, this whether the handle walks them)
     { const char* e = getenv("RTS_SUM_IN_KERNEL"); if (e) c->sum_in_kernel = atoi(e) != 0; }
@@ -255,14 +253,6 @@ struct RtsLapTimer {
 // pulses begun and not yet ended, per device: a trace launch that will share the GPU with another pulse's kernels leaves block
 // slots free for them (RtsContext::grid_spare), a lone pulse takes the whole chip
 static std::atomic<int> g_open_pulses[64];
-// THE TRACE GATE (round 5, late).  A handle's cycle -- trace, the post-processing chain of seven short launches, the next pulse's placement and order -- is ~1.5 ms of which the chip
-// needs 0.41 (the launch's bulk): three handles give 0.50 ms per pulse whatever the chip could do, and a fourth made it worse, because three trace kernels resident at once share
-// the block slots between them and ALL finish late (processor sharing instead of first-in-first-out).  With the gate a trace kernel waits -- on the device, an event -- for the
-// completion of the trace kernel launched `depth` launches before it on this device: never more than `depth` of them resident (the older in its tail, the newer in its bulk), however
-// many handles have their pulses prepared behind them.  Per device: the completion events of the last launches, in launch order (owned by the handles; a handle that is destroyed
-// takes its entries out).  RTS_TRACE_GATE = depth (0: no gate).
-struct RtsGateRing { std::mutex mu; std::vector<std::pair<RtsContext*, hipEvent_t>> last; };
-static RtsGateRing g_gate[64];
 static std::mutex g_hist_mu;      // (re)allocation of a shared tile-cost history (RtsTileHist)
 
 extern "C" int rts_destroy(RtsHandle c)
@@ -277,9 +267,6 @@ extern "C" int rts_destroy(RtsHandle c)
         fprintf(stderr, "\n");
     }
     if (c->pulse_open || c->spec_pending) { c->pulse_open = false; c->spec_pending = false; g_open_pulses[c->device & 63]--; }
-    { RtsGateRing& g = g_gate[c->device & 63]; std::lock_guard<std::mutex> lk(g.mu);
-      for (size_t i = 0; i < g.last.size();) { if (g.last[i].first == c) g.last.erase(g.last.begin() + i); else i++; } }
-    if (c->tstream) (void)hipStreamSynchronize(c->tstream);
     rts_comm_cache_forget(c);
     if (c->scene && --c->scene->refs == 0) { c->scene->release(); delete c->scene; }
     c->scene = nullptr;
@@ -303,7 +290,6 @@ extern "C" int rts_destroy(RtsHandle c)
     for (int i = 0; i < 9; i++) (void)hipEventDestroy(c->ev[i]);
     if (c->ev_spec) (void)hipEventDestroy(c->ev_spec);
     for (int i = 0; i < 2; i++) (void)hipEventDestroy(c->ev_coop[i]);
-    for (int i = 0; i < 2; i++) if (c->ev_gate[i]) (void)hipEventDestroy(c->ev_gate[i]);
     if (c->cstream) { (void)hipStreamSynchronize(c->cstream); (void)hipStreamDestroy(c->cstream); }
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -923,13 +909,6 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
         RTS_HIP(hipEventRecord(c->ev[8], st));                   // scene + per-pulse buffers of this handle are ready
         RTS_HIP(hipStreamWaitEvent(c->tstream_now, c->ev[8], 0));
     }
-    if (c->trace_gate > 0 && !count_trav) {                     // the trace gate: this kernel starts after the one launched trace_gate launches ago on this device has ended
-        RtsGateRing& g = g_gate[c->device & 63]; std::lock_guard<std::mutex> lk(g.mu);
-        if (g.last.size() >= (size_t)c->trace_gate) {
-            const auto& e = g.last[g.last.size() - (size_t)c->trace_gate];
-            if (e.first != c) RTS_HIP(hipStreamWaitEvent(c->tstream_now, e.second, 0));      // (its own earlier launch: the stream orders them already)
-        }
-    }
     RTS_HIP(hipEventRecord(c->ev[2], c->tstream_now));
     // the cooperative kernel (tiles at the head of the cost order, one launch index per wave): its grid follows the head count
     // of the handle's previous order build (the count of THIS build is on the device; a grid too small or too large only costs
@@ -951,12 +930,6 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     RTS_STAGE(c, "k_trace");
     RTS_HIP(hipEventRecord(c->ev[3], c->tstream_now));
     if (c->tstream_now != st) RTS_HIP(hipStreamWaitEvent(st, c->ev[3], 0));      // everything later on this handle's stream follows its trace
-    if (c->trace_gate > 0 && !count_trav) {
-        RtsGateRing& g = g_gate[c->device & 63]; std::lock_guard<std::mutex> lk(g.mu);
-        RTS_HIP(hipEventRecord(c->ev_gate[c->ev_gate_i], c->tstream_now));      // (two events in turn: the one recorded by this handle's previous launch may still be waited for)
-        g.last.emplace_back(c, c->ev_gate[c->ev_gate_i]); c->ev_gate_i ^= 1;
-        if (g.last.size() > 8) g.last.erase(g.last.begin());
-    }
     lt.lap(4);
     // (the eight counters were written into the pinned block by k_sum_counters itself: no copy)
     c->pulse_open = true; g_open_pulses[c->device & 63]++;

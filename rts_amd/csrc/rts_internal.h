@@ -355,7 +355,6 @@ struct RtsContext {
     std::vector<RtsGroup> groups; bool agg_valid = false; uint64_t recv_index_base = 0;
     bool rx_window_screen = true;       // RTS_RX_WINDOW_SCREEN
     bool timeline_blocks = false; double tl_summary[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // RTS_TIMELINE_BLOCKS (rts_get_block_timeline)
-    int trace_gate = 0; hipEvent_t ev_gate[2] = {nullptr, nullptr}; int ev_gate_i = 0;      // the trace gate (rts_api.hip: g_gate; RTS_TRACE_GATE)
     uint32_t tl_blocks = 0;             // debug (RTS_TIMELINE_BLOCKS): blocks whose start / end ticks this launch recorded
     bool coop_versions = true;          // RTS_COOP_VERSIONS
     int batch_dead = 1;                 // dead-tile batches of the trace kernel (RTS_DEAD_BATCH = 0 / 1 / all)
