@@ -387,6 +387,7 @@ def main():
         t_cpi = time.perf_counter()
 
         hp = acc.setdefault("host_ms", dict(begin=0.0, end_wait=0.0, post_enqueue=0.0, collect_wait=0.0))      # where the submitting thread spends the interval
+        skip_post = os.environ.get("RTS_BENCH_SKIP_POST", "")
 
         def post(t, k):
             """everything after the trace is only ENQUEUED.  One call (rts_trace_pulse_end_uniform): on the device-side received
@@ -399,16 +400,21 @@ def main():
                 return
             t.trace_end()
             h1 = time.perf_counter()
-            t.finalise_uniform(None, wl, 1.0, 1.0, spec["carrier"], spec["c"])
-            t.cube_accumulate(k, spec["c"], spec["carrier"])
-            t.aggregate(spec["c"], spec["carrier"], rts_amd._lib.RTS_BASE_USE_ROWS, fetch=False)
+            if skip_post == "1":                                  # diagnostic (RTS_BENCH_SKIP_POST=1 | fin | cube | agg: INVALID as a bench line): the received set is ordered and expanded, (part of) the rest left out
+                hp["end_wait"] += (h1 - h0) * 1e3; return
+            if skip_post != "fin":
+                t.finalise_uniform(None, wl, 1.0, 1.0, spec["carrier"], spec["c"])
+            if skip_post != "cube":
+                t.cube_accumulate(k, spec["c"], spec["carrier"])
+            if skip_post != "agg":
+                t.aggregate(spec["c"], spec["carrier"], rts_amd._lib.RTS_BASE_USE_ROWS, fetch=False)
             h2 = time.perf_counter()
             hp["end_wait"] += (h1 - h0) * 1e3; hp["post_enqueue"] += (h2 - h1) * 1e3
 
         def collect(t, k):
             """wait for the pulse's post-processing and take its group table"""
             h0 = time.perf_counter()
-            groups = t.groups()
+            groups = t.groups() if skip_post not in ("1", "agg", "fetch") else np.zeros(0, rts_amd._lib.GROUP_DTYPE)      # (fetch: the chain runs, its table is never asked for)
             hp["collect_wait"] += (time.perf_counter() - h0) * 1e3
             st = t.stats_raw()                                # stream already drained by the table fetch
             parts.append(dict(pulse=k, groups=groups))
