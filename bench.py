@@ -417,7 +417,7 @@ def main():
             groups = t.groups() if skip_post not in ("1", "agg", "fetch") else np.zeros(0, rts_amd._lib.GROUP_DTYPE)      # (fetch: the chain runs, its table is never asked for)
             hp["collect_wait"] += (time.perf_counter() - h0) * 1e3
             st = t.stats_raw()                                # stream already drained by the table fetch
-            parts.append(dict(pulse=k, groups=groups))
+            parts.append(dict(pulse=k, groups=groups, responses=(api.groups_to_responses(groups) if (dist is None or not cur["collectives"]) and not skip_post else None)))      # (one rank: the pulse's responses are formed here, while the next pulses trace, instead of in the interval's tail)
             acc["segments"] += st.segments; acc["shaded"] += st.shaded; acc["received"] += st.received
             acc["ms_scene"] += st.ms_scene; acc["ms_trace"] += st.ms_trace; acc["ms_post"] += st.ms_compact + st.ms_aggregate
             acc["launches"] += 1

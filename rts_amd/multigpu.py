@@ -167,8 +167,8 @@ def exchange_parts(parts, dist, torch):
     """parts: [dict(pulse, groups)] of this rank -> the same list for ALL ranks.  Group tables must be keyed by
     global buffer rows (rts_aggregate(..., RTS_BASE_USE_ROWS)) so that they merge with a plain min.
     One all-gather of sizes + one all-gather of payload (meta int64 rows followed by the group records)."""
-    if dist is None:
-        return [dict(pulse=int(p["pulse"]), groups=np.ascontiguousarray(p["groups"], GROUP_DTYPE)) for p in parts]
+    if dist is None:                                         # (one rank: responses formed while the pulses were still being traced -- bench.py's collect -- travel with their tables)
+        return [dict(pulse=int(p["pulse"]), groups=np.ascontiguousarray(p["groups"], GROUP_DTYPE), responses=p.get("responses")) for p in parts]
     meta = np.array([[p["pulse"], len(p["groups"])] for p in parts], np.int64).reshape(-1, 2)
     groups = np.concatenate([np.ascontiguousarray(p["groups"], GROUP_DTYPE) for p in parts]) if parts else np.zeros(0, GROUP_DTYPE)
     payload = np.concatenate([meta.view(np.uint8).reshape(-1), groups.view(np.uint8).reshape(-1)])
@@ -200,13 +200,15 @@ def exchange_parts(parts, dist, torch):
 def merge_cpi(all_parts, depth):
     """all parts of all ranks -> {pulse: (responses, merged groups)}; response.ray = global buffer row of the
     representative ray (same order as the reference's received-list index)"""
-    by_pulse = {}
+    by_pulse = {}; ready = {}
     for p in all_parts:
         by_pulse.setdefault(p["pulse"], []).append(p["groups"])
+        if p.get("responses") is not None:
+            ready[p["pulse"]] = p["responses"]
     out = {}
     for k, tabs in by_pulse.items():
         if len(tabs) == 1:                                   # a pulse traced whole by one rank: its table is already merged
-            out[k] = (api.groups_to_responses(tabs[0]), tabs[0])
+            out[k] = (ready[k] if k in ready else api.groups_to_responses(tabs[0]), tabs[0])
         else:
             out[k] = merge_and_respond(np.concatenate(tabs), depth)
     return out
