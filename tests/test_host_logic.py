@@ -297,6 +297,30 @@ def test_merge_groups_is_shard_invariant(rts, oracle):
         np.testing.assert_allclose(ra["power"], rb["power"], rtol=1e-12)
 
 
+def test_merge_cpi_takes_responses_formed_earlier(rts, oracle):
+    """one rank (bench.py): a pulse's responses are formed when the pulse is collected and travel with its table through exchange_parts (no
+    collective); merge_cpi then uses them -- the same responses it would have formed -- and still forms them itself where none came along or
+    where a pulse's table has to be merged from several parts"""
+    from rts_amd import multigpu
+    rng = np.random.default_rng(21)
+    fc = 10e9
+    tabs = []
+    for k in range(3):
+        a, paths = random_received_set(oracle, rng, 120 + 40 * k, 3, 2, 2)
+        tabs.append(numpy_group_table(a, paths, C0, fc))
+    parts = [dict(pulse=0, groups=tabs[0], responses=rts.groups_to_responses(tabs[0])), dict(pulse=1, groups=tabs[1]),
+             dict(pulse=2, groups=tabs[2][:50], responses=None), dict(pulse=2, groups=tabs[2][50:])]
+    allp = multigpu.exchange_parts(parts, None, None)
+    assert allp[0]["responses"] is parts[0]["responses"] and allp[1]["responses"] is None
+    out = multigpu.merge_cpi(allp, 3)
+    assert out[0][0] is parts[0]["responses"]
+    for k in (0, 1):
+        want = rts.groups_to_responses(tabs[k])
+        assert out[k][0].tobytes() == want.tobytes() and out[k][1].tobytes() == np.ascontiguousarray(tabs[k]).tobytes()
+    merged = rts.merge_groups(tabs[2], 3)
+    assert out[2][0].tobytes() == rts.groups_to_responses(merged).tobytes()
+
+
 def test_empty_tables(rts):
     from rts_amd._lib import GROUP_DTYPE
     assert len(rts.merge_groups(np.zeros(0, GROUP_DTYPE), 3)) == 0
