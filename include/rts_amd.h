@@ -380,9 +380,10 @@ int rts_plan_cpi(uint64_t total_rays, uint32_t n_pulses, uint32_t rank, uint32_t
  *                          tables of workers that traced disjoint parts of a pulse merge with a plain sum (or max)
  *   rts_tile_records_set   replaces the handle's history with a merged table: its next launches order their tiles -- and pick
  *                          the cooperative kernel's head tiles -- from what ANY worker measured
- *   rts_deal_tiles         host code, deterministic (every worker computes the same map from the same table): plan tiles of `tile`
- *                          launch indices (a multiple of 64) in descending cost, each to the worker with the least cost so far;
- *                          tiles without a record are then dealt by COUNT (ascending, each to the worker holding the fewest tiles).  part_of_tile[ceil(total_rays / tile)] <- worker
+ *   rts_deal_tiles         host code, deterministic (every worker computes the same map from the same table): first the plan tiles of `tile`
+ *                          launch indices (a multiple of 64) that hold walk-length flags (the cooperative kernel's candidates), in descending
+ *                          cost, each to the worker holding the fewest flagged wave tiles so far; then the others in descending cost, each to
+ *                          the worker with the least cost so far; tiles without a record are then dealt by COUNT (ascending, each to the worker holding the fewest tiles).  part_of_tile[ceil(total_rays / tile)] <- worker
  *   rts_set_tile_list      the plan tiles (ascending, unique, < ceil(range / tile)) the handle's launches with
  *                          interleave_parts == RTS_INTERLEAVE_LIST trace; n_ids == 0 is an EMPTY list (a worker that was dealt nothing:
  *                          its launches trace no launch index and return empty sets); tile == 0 forgets the list */

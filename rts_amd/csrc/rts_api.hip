@@ -1545,21 +1545,33 @@ extern "C" int rts_deal_tiles(const uint32_t* records, uint32_t n_records, uint6
     const uint64_t n_plan64 = (total_rays + tile - 1) / tile;
     if (n_plan64 > 0xffffffffull) { rts_set_error("rts_deal_tiles: too many tiles"); return RTS_ERR_INVALID; }
     const uint32_t n_plan = (uint32_t)n_plan64, per = tile / RTS_WTILE;
-    std::vector<uint64_t> cost(n_plan);
+    std::vector<uint64_t> cost(n_plan); std::vector<uint32_t> n_long(n_plan, 0);
     for (uint32_t t = 0; t < n_plan; t++) {
         uint64_t v = 0; const uint64_t w0 = (uint64_t)t * per, w1 = std::min<uint64_t>(w0 + per, n_records);
-        for (uint64_t w = w0; w < w1; w++) v += records[w] & 0x3fffffffu;
+        for (uint64_t w = w0; w < w1; w++) { v += records[w] & 0x3fffffffu; n_long[t] += (records[w] >> 30) ? 1u : 0u; }      // (LONG or LONGISH walks: what a part's head rule may hand to the cooperative kernel)
         cost[t] = v;                                               // 0: a tile nobody traced yet
     }
-    std::vector<uint32_t> order; order.reserve(n_plan);
-    for (uint32_t t = 0; t < n_plan; t++) if (cost[t]) order.push_back(t);
+    std::vector<uint32_t> order, heads; order.reserve(n_plan);
+    for (uint32_t t = 0; t < n_plan; t++) if (cost[t]) (n_long[t] ? heads : order).push_back(t);
     std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
-    // the tiles WITH a record: longest first, each to the worker with the least cost so far -- min-heap of (load, worker)
+    std::stable_sort(heads.begin(), heads.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
     std::vector<std::pair<uint64_t, uint32_t>> heap(parts);
     for (uint32_t r = 0; r < parts; r++) heap[r] = {0, r};
+    std::vector<uint64_t> n_of(parts, 0);
+    // the tiles that hold LONG or LONGISH WALKS (bits 31 / 30 of a wave tile's record: the cooperative kernel's candidates) first, and by COUNT: a part's time follows the number of cooperative
+    // tiles it holds more closely than their recorded cost (BASELINE configs[3] dealt by cost alone: 72 .. 239 of them per eighth, 0.77 .. 1.02 ms;
+    // profiles/r05_c4_as_rank.log) -- longest first, each to the worker that holds the fewest of them so far (ties: the least cost)
+    {
+        std::vector<uint64_t> nl(parts, 0);
+        for (uint32_t t : heads) {
+            uint32_t best = 0;
+            for (uint32_t r = 1; r < parts; r++) if (nl[r] < nl[best] || (nl[r] == nl[best] && heap[r].first < heap[best].first)) best = r;
+            part_of_tile[t] = best; nl[best] += n_long[t]; heap[best].first += cost[t]; n_of[best]++;
+        }
+    }
+    // the other tiles WITH a record: longest first, each to the worker with the least cost so far -- min-heap of (load, worker)
     auto cmp = [](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& b) { return a > b; };
     std::make_heap(heap.begin(), heap.end(), cmp);
-    std::vector<uint64_t> n_of(parts, 0);
     for (uint32_t k = 0; k < (uint32_t)order.size(); k++) {
         std::pop_heap(heap.begin(), heap.end(), cmp);
         std::pair<uint64_t, uint32_t>& top = heap.back();

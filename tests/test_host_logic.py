@@ -149,6 +149,26 @@ def test_deal_tiles_partial_table(rts):
     assert sorted(int(x) for x in cost) == sorted([500 + int(cnt[part[5]]) - 1, 100 + int(cnt[part[20]]) - 1, 50 + int(cnt[part[41]]) - 1])
 
 
+def test_deal_tiles_spreads_long_walks_by_count(rts):
+    """round 5: tiles flagged LONG / LONGISH WALKS (bits 31 / 30 of a record: the cooperative kernel's candidates) are dealt first and by COUNT -- a part's time
+    follows how many of them it holds more closely than their recorded cost -- the rest longest-first by cost on top of that; every tile is dealt exactly once"""
+    from rts_amd import api
+    rng = np.random.default_rng(5)
+    n = 4096
+    rec = rng.integers(1, 200, n).astype(np.uint32)
+    flagged = rng.choice(n, 96, replace=False)
+    rec[flagged[:48]] = (rng.integers(2000, 90000, 48).astype(np.uint32)) | np.uint32(0x80000000)       # LONG WALKS, costs over two decades
+    rec[flagged[48:]] = (rng.integers(500, 3000, 48).astype(np.uint32)) | np.uint32(0x40000000)         # LONGISH
+    part, cost = api.deal_tiles(rec, n * 64, 64, 8)
+    held = np.bincount(part[flagged], minlength=8)
+    assert held.max() - held.min() <= 1 and held.sum() == 96, held                                       # by count (dealt by cost alone: 3 .. 20 per part)
+    assert np.bincount(part, minlength=8).sum() == n
+    tot = np.array([int((rec[part == r] & 0x3fffffff).sum()) for r in range(8)])
+    assert np.array_equal(np.sort(tot), np.sort(np.asarray(cost, np.int64)))
+    plain = np.array([int((rec[(part == r) & ((rec >> 30) == 0)] & 0x3fffffff).sum()) for r in range(8)])
+    assert tot.max() - tot.min() <= max(200, (rec[flagged] & 0x3fffffff).max()), (tot, plain)            # the unflagged tiles fill the parts up as far as one flagged tile's cost allows
+
+
 def check_bvh4(nodes, leaf_prim, root, tris_verts, all_reachable=True):
     """invariants of one mesh's BVH4 as the library stores it (nodes [n][32] f32 view of the 128-byte records): every node reachable
     exactly once from the root, child boxes nested in the parent's, unused slots unreachable points, every triangle in at least
