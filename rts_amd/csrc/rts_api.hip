@@ -918,7 +918,8 @@ extern "C" int rts_trace_pulse_begin(RtsHandle c, const RtsPulse* p)
     unsigned coop_grid = 0;
     if (a.tile_head) {
         if (c->hist->head_hint_valid) c->n_head_hint = c->hist->head_hint;      // (the latest head count of ANY handle that shares the history)
-        const uint64_t units = 64ULL * c->n_head_hint;
+        const bool grouped = a.nodes4v && a.coop_versions && !keep_all && !a.max_refr;      // (rts_trace_dispatch: the cooperative kernel that walks the octant versions holds 64 / RTS_COOP_GROUP rays per unit)
+        const uint64_t units = (grouped ? (uint64_t)RTS_COOP_GROUP : 64ULL) * c->n_head_hint;
         if (units == 0) a.tile_head = nullptr;
         else coop_grid = (unsigned)std::min<uint64_t>(c->coop_grid_max, std::max<uint64_t>(16, (units + 3) / 4));
         c->last_args = a;

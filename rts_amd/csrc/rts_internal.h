@@ -151,6 +151,10 @@ struct RtsLaunchConsts {
 };
 static_assert(sizeof(RtsLaunchConsts) % 8 == 0, "launch constants are copied to LDS dword by dword");
 
+// lanes that share a ray in a unit of the cooperative kernel that walks the octant versions (rts_trace.hip: rts_walk_coop): 32 = two rays per wave (measured best: profiles/r05v_coop_group.log), 16 = four, 64 = one
+#ifndef RTS_COOP_GROUP
+#define RTS_COOP_GROUP 32
+#endif
 struct RtsTraceArgs {
     const RtsLaunchConsts* lc;      // device copy of the launch constants
     uint64_t ray_first;

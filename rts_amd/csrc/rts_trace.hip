@@ -325,16 +325,23 @@ __device__ __forceinline__ void rts_walk_step(const RtsTraceArgs& a, int32_t* s_
 // empty stack, and entries are handed over in the iteration they are taken in, so nothing is pending then).
 __device__ __forceinline__ float rts_wave_min_f32(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o)); return v; }
 __device__ __forceinline__ unsigned long long rts_wave_min_u64(unsigned long long v) { for (int o = 32; o > 0; o >>= 1) { const unsigned long long w = __shfl_xor(v, o); v = w < v ? w : v; } return v; }
-template <bool COUNT, bool VERS = false>
+// GROUPS (round 5, late): CG = 64 is the walk above -- one ray per wave.  CG = 16: the wave walks FOUR rays, lanes 16 g .. 16 g + 15 the g-th (each lane holds its group's ray,
+// redundantly within the group): ballots are cut to the group's 16 bits, ranks counted inside them, the exchange row is the group's quarter of the wave's, the prune bound and the
+// winner are reduced by butterflies that stay inside the group (xor 8, 4, 2, 1).  The wave leaves when no group holds a node.  What it buys: the arithmetic outside the walk --
+// ray generation, capture, shading: ~1 500 instructions per segment that a one-ray unit issues for ONE ray -- is issued once for four.
+template <bool COUNT, bool VERS = false, uint32_t CG = 64u>
 __device__ __forceinline__ void rts_walk_coop(const RtsTraceArgs& a, int32_t* s_stack, int32_t* s_exch, uint32_t tid, uint32_t gtid, uint32_t lane, int lds_cap, uint32_t* n_spill_lds,
                                               int root, const RtsSlabRay& lr, const dvec3& prev, const dvec3& dir, float tmin,
                                               float& best_t, int& best_leaf, uint32_t& best_prim, float& t_prune, uint32_t& n_nodes, uint32_t& n_tris, bool& hard_overflow)
 {
     const int SENTINEL = RTS_STACK_SENTINEL;
-    volatile int32_t* row = s_exch + (tid & ~63u);
+    const uint32_t g0 = lane & ~(CG - 1u);                                        // first lane of this lane's group
+    const unsigned long long gmask = CG == 64u ? ~0ULL : (((1ULL << (CG & 63u)) - 1ULL) << g0);
+    const unsigned long long below_me = (1ULL << lane) - 1ULL;
+    volatile int32_t* row = s_exch + (tid & ~63u) + g0;
     s_stack[tid] = SENTINEL;
     int sp = 1, bot = 1;                                  // pending entries of this lane: [bot, sp)
-    int node = lane == 0 ? root : SENTINEL;
+    int node = (lane & (CG - 1u)) == 0u ? root : SENTINEL;
     uint32_t steps = 0;
     const RtsSlabRay lp = VERS ? lr : rts_slab_by_plane(lr);          // (this kernel reads its records straight through: rts_fetch_record_plain; the octant versions' planes are entry / exit planes already)
     for (;;) {
@@ -342,14 +349,14 @@ __device__ __forceinline__ void rts_walk_coop(const RtsTraceArgs& a, int32_t* s_
         const unsigned long long busy_m = __ballot(busy);
         if (busy_m == 0ULL) break;
         if (++steps > (1u << 24)) { hard_overflow = true; break; }                  // malformed tree guard: every wave must drain
-        const unsigned long long idle_m = ~busy_m;                                  // (a COOP unit runs with all 64 lanes)
+        const unsigned long long idle_m = __ballot(true) & ~busy_m;                 // (the lanes of the wave that are in the unit at all: a last, partial tile)
         if (idle_m != 0ULL) {
             const bool can = busy && sp > bot && bot < lds_cap;                     // something pending, and in the LDS part of the stack
             const unsigned long long can_m = __ballot(can);
             if (can_m != 0ULL) {
-                const uint32_t n_give = min((uint32_t)__popcll(idle_m), (uint32_t)__popcll(can_m));
-                const uint32_t r_can = __builtin_amdgcn_mbcnt_hi((uint32_t)(can_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)can_m, 0u));
-                const uint32_t r_idle = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
+                const unsigned long long idle_g = idle_m & gmask, can_g = can_m & gmask;
+                const uint32_t n_give = min((uint32_t)__popcll(idle_g), (uint32_t)__popcll(can_g));
+                const uint32_t r_can = (uint32_t)__popcll(can_g & below_me), r_idle = (uint32_t)__popcll(idle_g & below_me);
                 if (can && r_can < n_give) { row[r_can] = s_stack[bot * RTS_BLOCK + tid]; s_stack[bot * RTS_BLOCK + tid] = SENTINEL; bot++; }
                 __builtin_amdgcn_wave_barrier();
                 if (!busy && r_idle < n_give) { node = row[r_idle]; sp = 1; bot = 1; }      // (entry 0 of the taker still holds the sentinel)
@@ -362,14 +369,17 @@ __device__ __forceinline__ void rts_walk_coop(const RtsTraceArgs& a, int32_t* s_
             rts_walk_step<COUNT, VERS ? RTS_WALK_VERSIONS : RTS_WALK_PLANES>(a, s_stack, tid, gtid, lds_cap, n_spill_lds, node, sp, lp, prev, dir, tmin, best_t, best_leaf, best_prim, t_prune, n_nodes, n_tris, hard_overflow);
             improved = t_prune != before;
         }
-        if (__any(improved)) t_prune = rts_wave_min_f32(t_prune);
+        if (__any(improved)) { for (int o = (int)CG / 2; o > 0; o >>= 1) t_prune = fminf(t_prune, __shfl_xor(t_prune, o)); }      // (the group's minimum)
     }
-    // closest hit over the lanes: smallest f32 t (positive: its bits order like the value), then lowest global primitive id
+    // closest hit over the group's lanes: smallest f32 t (positive: its bits order like the value), then lowest global primitive id
     const unsigned long long key = best_leaf >= 0 ? (((unsigned long long)__float_as_uint(best_t) << 32) | best_prim) : ~0ULL;
-    const unsigned long long kmin = rts_wave_min_u64(key);
+    unsigned long long kmin = key;
+    for (int o = (int)CG / 2; o > 0; o >>= 1) { const unsigned long long w = __shfl_xor(kmin, o); kmin = w < kmin ? w : kmin; }
+    const unsigned long long has_m = __ballot(key == kmin) & gmask;                   // (every lane of the wave takes part in the ballot and the shuffle below)
+    const int win = has_m ? __ffsll((long long)has_m) - 1 : (int)lane;
+    const int leaf_w = __shfl(best_leaf, win);
     if (kmin != ~0ULL) {
-        const int win = __ffsll((long long)__ballot(key == kmin)) - 1;
-        best_leaf = __shfl(best_leaf, win); best_t = __uint_as_float((uint32_t)(kmin >> 32)); best_prim = (uint32_t)kmin;
+        best_leaf = leaf_w; best_t = __uint_as_float((uint32_t)(kmin >> 32)); best_prim = (uint32_t)kmin;
         t_prune = f32_next_up_pos(best_t);
     }
 }
@@ -410,7 +420,7 @@ struct RtsRay { dvec3 dir, prev; double rayLength, power, doppler, refx, refy; u
 // child, the reflected direction).  Returns true when the chain goes on with another segment.  ONE body for the three ways a
 // launch index is driven (lanes in lock step per bounce round; lanes advancing on their own, rts_trace_unit_async; one ray per
 // wave, COOP): same expressions, same operand order, bit-identical results.
-template <bool KEEP_ALL, bool REFR, bool COOP>
+template <bool KEEP_ALL, bool REFR, bool COOP, uint32_t CG = 64u>
 __device__ __forceinline__ bool rts_shade(const RtsTraceArgs& a, const RtsUnitLds& L_, const uint32_t tid, const uint32_t gtid, const uint32_t lane, const uint32_t slot,
                                           const uint32_t chain, const uint32_t D, const uint32_t max_refr, const dvec3& origin, const bool primary, const bool may_rx,
                                           const float best_t, const int best_leaf, const uint32_t best_prim, const float tmin, RtsRay& S, uint32_t& pending, uint32_t& refr_code0)
@@ -419,7 +429,7 @@ __device__ __forceinline__ bool rts_shade(const RtsTraceArgs& a, const RtsUnitLd
     dvec3& dir = S.dir; dvec3& prev = S.prev;
     double& rayLength = S.rayLength; double& power = S.power; double& doppler = S.doppler; double& refx = S.refx; double& refy = S.refy;
     uint32_t& reflDepth = S.reflDepth; uint32_t& refrDepth = S.refrDepth; int& received = S.received; bool& end = S.end; bool& chain_start = S.chain_start;
-        if (KEEP_ALL && chain == 0 && (!COOP || lane == 0)) {
+        if (KEEP_ALL && chain == 0 && (!COOP || (lane & (CG - 1u)) == 0u)) {
             const size_t hidx = (size_t)slot * (a.max_refl + 1) + reflDepth;
             a.hit_prim[hidx] = (best_leaf >= 0) ? (int32_t)best_prim : -1;
             a.hit_t[hidx] = (best_leaf >= 0) ? best_t : 0.0f;
@@ -506,7 +516,7 @@ __device__ __forceinline__ bool rts_shade(const RtsTraceArgs& a, const RtsUnitLd
 
         // ------------------------------------------------------------ closest_hit, normal_shader.cu:128-340
         if (!((end == false) && ((refrDepth < max_refr) || (reflDepth < a.max_refl)))) return false;   // gate :134 ; absorbed hit leaves the payload untouched
-        if (!COOP || lane == 0) atomicAdd(&s_n[RTS_BLOCK + tid], 1u);
+        if (!COOP || (lane & (CG - 1u)) == 0u) atomicAdd(&s_n[RTS_BLOCK + tid], 1u);
         const RtsLeafTri L = a.leaves[best_leaf];
         const RtsTargetDev T = a.targets[L.targ];
         if (refrDepth != 1) {                                              // path column (:140-146)
@@ -580,7 +590,7 @@ __device__ __forceinline__ bool rts_shade(const RtsTraceArgs& a, const RtsUnitLd
                     pending |= 1u << (chain + 1);
                     // direction history plane 0 of the child chain: RCS angle of the refraction event (:259-265)
                     float* dh = a.dir_hist + (size_t)((chain + 1) * (a.max_refl + 1)) * 3 * a.n_rays;
-                    if (!COOP || lane == 0) { dh[slot] = rd.x; dh[(size_t)a.n_rays + slot] = rd.y; dh[2*(size_t)a.n_rays + slot] = rd.z; }
+                    if (!COOP || (lane & (CG - 1u)) == 0u) { dh[slot] = rd.x; dh[(size_t)a.n_rays + slot] = rd.y; dh[2*(size_t)a.n_rays + slot] = rd.z; }
                 }
             }
         }
@@ -603,14 +613,14 @@ __device__ __forceinline__ bool rts_shade(const RtsTraceArgs& a, const RtsUnitLd
         {   // direction history: the RCS angles of received rays are rebuilt from it (:320-326)
             const size_t plane = REFR ? (size_t)chain * (a.max_refl + 1) + reflDepth : (size_t)(reflDepth - 1);
             float* dh = a.dir_hist + plane * 3 * a.n_rays;
-            if (!COOP || lane == 0) { dh[slot] = nd.x; dh[(size_t)a.n_rays + slot] = nd.y; dh[2*(size_t)a.n_rays + slot] = nd.z; }
+            if (!COOP || (lane & (CG - 1u)) == 0u) { dh[slot] = nd.x; dh[(size_t)a.n_rays + slot] = nd.y; dh[2*(size_t)a.n_rays + slot] = nd.z; }
         }
     return true;
 }
 
 
 // End of a chain: the record of a received ray (and of every ray in the KEEP_ALL builds), ray_tracer.cu:246-253, normal_shader.cu:272-279
-template <bool KEEP_ALL, bool REFR, bool COOP>
+template <bool KEEP_ALL, bool REFR, bool COOP, uint32_t CG = 64u>
 __device__ __forceinline__ void rts_write_back(const RtsTraceArgs& a, const RtsUnitLds& L_, const uint32_t tid, const uint32_t lane, const uint32_t slot, const uint32_t chain,
                                                const RtsRay& S, const uint32_t pending, const uint32_t refr_code0)
 {
@@ -618,7 +628,7 @@ __device__ __forceinline__ void rts_write_back(const RtsTraceArgs& a, const RtsU
     const dvec3& prev = S.prev; const double rayLength = S.rayLength, power = S.power, doppler = S.doppler;
     const uint32_t reflDepth = S.reflDepth, refrDepth = S.refrDepth; const int received = S.received;
     const bool recv = received >= 0;
-    if ((recv || KEEP_ALL) && (!COOP || lane == 0)) {
+    if ((recv || KEEP_ALL) && (!COOP || (lane & (CG - 1u)) == 0u)) {
         RtsEndRecord r;
         r.rayLength = rayLength; r.power = power; r.doppler = (KEEP_ALL || REFR) ? doppler : 0.0;      // deferred: rts_shade, expand_row
         r.prevx = prev.x; r.prevy = prev.y; r.prevz = prev.z;
@@ -815,6 +825,7 @@ __device__ __forceinline__ void rts_trace_unit(const RtsTraceArgs& a, const RtsL
                                                const uint32_t pre = 0u)      // pre: bit 0 = k_trace ran the pre-filter already, bits 1 / 2 = its may_target / may_rx
 {
       int32_t* const s_stack = L_.stack; int32_t* const s_exch = L_.exch; double* const s_first = L_.first; unsigned long long* const s_path = L_.path; uint32_t* const s_n = L_.n;
+      constexpr uint32_t CG = (COOP && VERS) ? (uint32_t)RTS_COOP_GROUP : 64u;      // lanes that share a ray in a cooperative unit (rts_walk_coop)
 
       uint32_t pending = 0;                   // bit k: chain k has been spawned
       uint32_t refr_code0 = 0;                // (target + 1) of chain 0's refraction, for the path prefill of rows >= 3
@@ -846,7 +857,7 @@ __device__ __forceinline__ void rts_trace_unit(const RtsTraceArgs& a, const RtsL
 
         for (;;) {
             // ------------------------------------------------------------ rtTrace: closest hit over the targets' hierarchies
-            if (!COOP || lane == 0) atomicAdd(&s_n[tid], RTS_SEG_ONE);           // (ds_add_u32, no return; bits 0-21 the lane's segments of the launch, bits 22-31 those of the current tile)
+            if (!COOP || (lane & (CG - 1u)) == 0u) atomicAdd(&s_n[tid], RTS_SEG_ONE);           // (ds_add_u32, no return; bits 0-21 the lane's segments of the launch, bits 22-31 those of the current tile)
             if (!COOP) { const unsigned long long ex_ = __ballot(true);             // one bounce round more in the tile's walk statistics (first lane still in the chain)
                          if (__builtin_amdgcn_mbcnt_hi((uint32_t)(ex_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ex_, 0u)) == 0u) atomicAdd(&L_.walk[2u * __builtin_amdgcn_readfirstlane(tid >> 6) + 1u], 1u); }
             const float tmin = chain_start ? SCENE_EPS : SCENE_EPS_R;          // ray_tracer.cu:209, normal_shader.cu:242,297
@@ -886,7 +897,7 @@ __device__ __forceinline__ void rts_trace_unit(const RtsTraceArgs& a, const RtsL
                     const int SENTINEL = RTS_STACK_SENTINEL;
                     const int lds_cap = (int)a.stack_lds;
                     if (COOP) {
-                        rts_walk_coop<COUNT, VERS>(a, s_stack, s_exch, tid, gtid, lane, lds_cap, &s_n[2 * RTS_BLOCK + tid], VERS ? (int)(((uint32_t)TG.root << 3) | oct) : TG.root, lr, prev, dir, tmin, best_t, best_leaf, best_prim, t_prune,
+                        rts_walk_coop<COUNT, VERS, CG>(a, s_stack, s_exch, tid, gtid, lane, lds_cap, &s_n[2 * RTS_BLOCK + tid], VERS ? (int)(((uint32_t)TG.root << 3) | oct) : TG.root, lr, prev, dir, tmin, best_t, best_leaf, best_prim, t_prune,
                                              n_nodes, n_tris, hard_overflow);
                         if (COUNT) steps = 1u;                                       // (the segment entered a hierarchy: RtsStats::walked_segments)
                     } else {
@@ -922,10 +933,13 @@ __device__ __forceinline__ void rts_trace_unit(const RtsTraceArgs& a, const RtsL
                 lane_stats[4] += (unsigned long long)__popcll(__ballot(steps == 0u)) * smax;      // lane-steps issued to lanes that are in the round but NEVER STARTED a walk in it -- what packing the live launch indices of several tiles into dense waves could recover
             }
             if (COUNT && COOP && steps) lane_stats[3] += 1ull;
-            if (!rts_shade<KEEP_ALL, REFR, COOP>(a, L_, tid, gtid, lane, slot, chain, D, max_refr, origin, primary, may_rx, best_t, best_leaf, best_prim, tmin, S, pending, refr_code0)) break;
+            {   // (a cooperative unit of several rays: a ray whose chain has ended waits for the unit's other rays -- the walk's ballots are the wave's)
+                const bool go_on_ = rts_shade<KEEP_ALL, REFR, COOP, CG>(a, L_, tid, gtid, lane, slot, chain, D, max_refr, origin, primary, may_rx, best_t, best_leaf, best_prim, tmin, S, pending, refr_code0);
+                if (!go_on_) break;
+            }
         }
 
-        rts_write_back<KEEP_ALL, REFR, COOP>(a, L_, tid, lane, slot, chain, S, pending, refr_code0);
+        rts_write_back<KEEP_ALL, REFR, COOP, CG>(a, L_, tid, lane, slot, chain, S, pending, refr_code0);
       }   // chain
 }
 
@@ -1176,7 +1190,9 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR && COOP) ? 2 : ((REFR || COOP
     // that ray's hierarchy together (rts_trace_unit<.., COOP = true>) -- by the COOP kernel, whose unit v is
     // (tile_order[v / 64], ray v % 64); unit v of the ordinary kernel is tile_order[n_head + v].
     const uint32_t n_head = (a.tile_head && a.tile_order) ? min(min(__builtin_amdgcn_readfirstlane(a.tile_head[0]), n_tiles), 16384u) : 0u;
-    const uint32_t n_units = COOP ? 64u * n_head : n_tiles - n_head;
+    constexpr uint32_t CG = (COOP && VERS) ? (uint32_t)RTS_COOP_GROUP : 64u;      // lanes per ray of a cooperative unit; a unit holds 64 / CG rays, a head tile is CG units (rts_walk_coop)
+    constexpr uint32_t RPU = 64u / CG;
+    const uint32_t n_units = COOP ? CG * n_head : n_tiles - n_head;
     __shared__ int32_t s_exch[COOP ? RTS_BLOCK : 1];             // exchange rows of the cooperative walk (one 64-entry row per wave)
     __shared__ uint32_t s_lane_scratch[COUNT ? 2 * (RTS_BLOCK / 64) : 1];      // (counting build: per-wave max / sum of a round's walk steps)
     __shared__ uint32_t s_walk[ASYNC ? 1 : 2 * (RTS_BLOCK / 64)];           // per wave: walk iterations of the current tile (each walk's slowest lane), walks
@@ -1272,7 +1288,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR && COOP) ? 2 : ((REFR || COOP
     if (lane == 0) RTS_DRAW()
     for (;;) {
       const uint32_t draw = __builtin_amdgcn_readfirstlane(AFFINE ? s_draw[RTS_OPAQUE_S(wave_u)] : ((COUNT || KEEP_ALL) ? s_draw[wave_u] : draw_next));      // (KEEP_ALL builds -- tests -- keep it in LDS too: their refraction instantiation parked it in scratch inside the tile loop)      // (AFFINE: in LDS like the counting builds' -- the kernel has no register for it across the tile loop, see above)
-      const uint32_t per_stripe = AFFINE ? __builtin_amdgcn_readfirstlane(RTS_Q(3)) : (COOP ? (coop_len * (64u / coop_P) + RTS_SEG_STRIPES - 1u) / RTS_SEG_STRIPES : per_stripe_all);
+      const uint32_t per_stripe = AFFINE ? __builtin_amdgcn_readfirstlane(RTS_Q(3)) : (COOP ? (coop_len * (CG / coop_P) + RTS_SEG_STRIPES - 1u) / RTS_SEG_STRIPES : per_stripe_all);
       const uint32_t single_draws = AFFINE ? __builtin_amdgcn_readfirstlane(RTS_Q(4)) : (COOP ? per_stripe : (BATCHABLE ? __builtin_amdgcn_readfirstlane(RTS_SCHED(0)) : single_draws_all));      // (COOP: one unit per draw -- units are long)
       const uint32_t four_draws = BATCHABLE ? __builtin_amdgcn_readfirstlane(RTS_SCHED(1)) : 0u, k_dead = BATCHABLE ? __builtin_amdgcn_readfirstlane(RTS_SCHED(2)) : 0u;
       const bool batch = BATCHABLE && draw >= single_draws + four_draws;      // (uniform) a batch of 64 positions of the order's dead part
@@ -1298,7 +1314,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR && COOP) ? 2 : ((REFR || COOP
           }
           continue;
       }
-      const uint32_t seg_base = AFFINE ? __builtin_amdgcn_readfirstlane(RTS_Q(1)) : 0u, seg_len = AFFINE ? __builtin_amdgcn_readfirstlane(RTS_Q(2)) : (COOP ? coop_len * (64u / coop_P) : n_units);
+      const uint32_t seg_base = AFFINE ? __builtin_amdgcn_readfirstlane(RTS_Q(1)) : 0u, seg_len = AFFINE ? __builtin_amdgcn_readfirstlane(RTS_Q(2)) : (COOP ? coop_len * (CG / coop_P) : n_units);
       // (only in the cheap part of the order: a draw made before an EXPENSIVE tile would reserve the stripe's next most
       // expensive tile for as long as this one takes -- the launch then ends with that tile, traced alone)
       const bool ahead = draw >= single_draws;
@@ -1334,7 +1350,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR && COOP) ? 2 : ((REFR || COOP
       // vpos = 64 x head tile + ray, as before)
       uint32_t vpos = seg_base + (uint32_t)vloc64;
       if (COOP) {
-          const uint32_t per = 64u / coop_P, j = (uint32_t)vloc64 / per, i = (uint32_t)vloc64 - j * per, h = (coop_x % coop_G) + coop_G * j;
+          const uint32_t per = CG / coop_P, j = (uint32_t)vloc64 / per, i = (uint32_t)vloc64 - j * per, h = (coop_x % coop_G) + coop_G * j;      // (CG units per head tile: unit q holds its rays RPU q .. RPU q + RPU - 1)
           vpos = (h << 6) | ((((coop_x - h) & (RTS_XCD - 1u)) / coop_G) + coop_P * i);
       }
       const bool coop_unit = COOP;
@@ -1342,7 +1358,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR && COOP) ? 2 : ((REFR || COOP
       // no history yet (first launch of the handle): centre-out over the launch range -- the beam is normally centred on
       // the targets, so the expensive tiles sit in the middle of the lattice and should be started first
       const uint32_t tile = a.tile_order ? a.tile_order[tpos] : ((tpos & 1u) ? (n_tiles - 1u) / 2u + (tpos + 1u) / 2u : (n_tiles - 1u) / 2u - tpos / 2u);
-      const uint32_t slot = coop_unit ? tile * 64u + (vpos & 63u) : tile * 64u + lane;
+      const uint32_t slot = coop_unit ? tile * 64u + (vpos & 63u) * RPU + lane / CG : tile * 64u + lane;
       // A DEAD tile -- the pre-filter clears every one of its launch indices (most tiles of a pulse: the beam is wider than the
       // targets) -- ends here: its launch indices' one segment each is counted, nothing else of the per-tile machinery runs
       // (payload initialisation, the bounce loop's tests, clocks, the cost record's arithmetic: half of the ~190 vector and ~90 scalar
@@ -1405,7 +1421,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR && COOP) ? 2 : ((REFR || COOP
           // instead of 8.5, profiles/r04_c4_cost_glitch.log.  Such a tile leaves no record; the history keeps what it had.)
           if (a.tile_cost && dt >= (1ULL << 26)) atomicAdd(&a.counters[12], 1ULL);      // (cannot happen on the constant-rate counter; counted -- RtsStats::cost_records_dropped -- instead of assumed)
           if (a.tile_cost && dt < (1ULL << 26)) {
-              if (COOP) { atomicAdd(&a.tile_cost[tile], (unsigned int)(dt > 0x00fffffeULL ? 0x00fffffeULL : dt) + 1u); if ((vpos & 63u) == 0u) atomicOr(&a.tile_cost[tile], 0x80000000u); }
+              if (COOP) { atomicAdd(&a.tile_cost[tile], ((unsigned int)(dt > 0x00fffffeULL ? 0x00fffffeULL : dt) + 1u) * RPU); if ((vpos & 63u) == 0u) atomicOr(&a.tile_cost[tile], 0x80000000u); }      // (x RPU: a unit of several rays stands for as many one-ray units in the head rule's sums)
               else a.tile_cost[tile] = ((unsigned int)(dt > 0x3ffffffeULL ? 0x3ffffffeULL : dt) + 1u) | (long_walks ? 0x80000000u : 0u) | (longish_walks ? 0x40000000u : 0u);
           }
           if (COUNT && a.timeline && !coop_unit) { a.timeline[(size_t)gridDim.x * 2 + tile] = wall_clock64() - tl_tile; a.timeline[(size_t)gridDim.x * 2 + n_tiles + tile] = tl_tile; }   // debug timeline (RTS_TIMELINE): duration, start tick
@@ -1419,7 +1435,7 @@ __global__ void __launch_bounds__(RTS_BLOCK, (REFR && COOP) ? 2 : ((REFR || COOP
     // traversal stack is dead by now) -> one plain store per block; k_sum_counters adds the blocks up.  (One atomic per
     // wave on the same two addresses -- 32 k same-line L2 atomics -- cost a fixed ~0.35 ms at the tail of every launch.)
     if (COUNT && !COOP && lane == 0 && lane_stats[0]) { atomicAdd(&a.counters[8], lane_stats[0]); atomicAdd(&a.counters[9], lane_stats[1]); atomicAdd(&a.counters[10], lane_stats[2]); }
-    if (COUNT && lane == 0 && lane_stats[3]) atomicAdd(&a.counters[11], lane_stats[3]);
+    if (COUNT && (lane & (CG - 1u)) == 0u && lane_stats[3]) atomicAdd(&a.counters[11], lane_stats[3]);
     if (COUNT && !COOP && lane == 0 && lane_stats[4]) atomicAdd(&a.counters[15], lane_stats[4]);
     // (the thread index is re-formed here from the wave's number -- scalar, kept since the start -- and the lane number instead of
     // being carried through the kernel: the allocator, at its 128-register limit, otherwise parks threadIdx.x in scratch in the
