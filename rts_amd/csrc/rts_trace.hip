@@ -682,11 +682,18 @@ __device__ __forceinline__ bool rts_rx_maybe(const float* K, const float dx, con
         dt = qd * (1.0f + (2.0f * fabsf(b) + qd) / (1.7f * s));
     }
     const float et = 0.75f * e2 / s + 1.0e-6f * qn;
+    // The SMALL root through the product of the roots, t_small t_large = |q|^2 - r^2: that constant does not depend on the direction, so for EVERY ray of a bundle
+    // |t_small| <= (| |q|^2 - r^2 | + e2) / (|t_large| - et - dt) -- and with the transmitter ON the capture sphere (the monostatic case: |q| = r) that is ~1e-4 m whatever
+    // the direction, where b - s carries the whole bundle's spread dt (0.5 m for a wave tile's rays from 50 m: the tile-level screen then said "maybe" for every tile
+    // of a monostatic scene -- BASELINE configs[4]: an empty launch 0.23 instead of 0.03 ms, profiles/r05z_monostatic_bundle.log).
+    const float tl_min = fabsf(b >= 0.0f ? b + s : b - s) - et - dt;
+    const bool small_gone = tl_min > 0.0f && (fabsf(K[RTS_RXP_QQ] - K[RTS_RXP_R2]) + e2) / tl_min + et < 0.004999f;      // the small root is certainly below the reference's t > SCENE_EPS
     bool maybe = false;
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         const float t = k == 0 ? b - s : b + s;
         if (t + et + dt < 0.004999f) continue;                   // certainly not a valid root (ray_tracer.cu:314: t >= 0, rayLength + t > SCENE_EPS)
+        if (small_gone && (k == 0) == (b >= 0.0f)) continue;     // (the small root: b - s for b >= 0, b + s else)
         const float px = __builtin_fmaf(t, dx, -qx), py = __builtin_fmaf(t, dy, -qy), pz = __builtin_fmaf(t, dz, -qz);
         const float ep = et + dt + (fabsf(t) + qn) * (2.0e-6f + delta);
         const float rho = __builtin_sqrtf(px*px + py*py);
