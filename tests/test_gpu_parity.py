@@ -1752,3 +1752,36 @@ def test_block_timeline_of_a_product_launch(rts, scenes, monkeypatch):
     H.assert_prd_equal(got["results"], want["results"], "block timeline on / off")
     assert (st["segments"], st["shaded"], st["received"]) == (st0["segments"], st0["shaded"], st0["received"])
     tr.close(); plain.close()
+
+
+def test_monostatic_tiles_are_dead_at_tile_level(rts, oracle, scenes, monkeypatch):
+    """round 5: the transmitter ON the capture sphere of a receiver that looks back at it (BASELINE configs[4]'s monostatic radar): every primary ray has a root at
+    t ~ 0 that the reference ignores (t > SCENE_EPS) and one on the far side, outside the window.  The tile-level screen has to see that for a whole wave tile's
+    bundle of directions (the small root through the product of the roots, rts_rx_maybe) -- else every tile of the pulse is looked at ray by ray.  Same received set
+    with the batches on / off / every position screened tile-wise first, against the oracle's brute force for the received rays, and most tiles dead at tile level"""
+    spec = scenes.config3(W=80, detail=0.3, n_rx=1, rx_radius=250.0)
+    tx = spec["tx"]; n = spec["W"] ** 3
+    assert abs(np.linalg.norm(np.subtract(spec["rx"][0]["centre"], tx["origin"])) - spec["rx"][0]["radius"]) < 1e-9      # ON the sphere
+    monkeypatch.setenv("RTS_GRID_MULT", "1")
+    out = {}
+    for mode in ("0", "1", "all"):
+        monkeypatch.setenv("RTS_DEAD_BATCH", mode)
+        tr = H.gpu_tracer(rts, spec)
+        for rep in range(3):
+            _, st = H.gpu_trace(rts, spec, tr=tr)
+        out[mode] = (tr.received(), st, tr.tile_records_get())
+        tr.close()
+    monkeypatch.delenv("RTS_DEAD_BATCH")
+    for mode in ("1", "all"):
+        a, b = out["0"], out[mode]
+        assert np.array_equal(a[0]["slots"], b[0]["slots"]) and np.array_equal(a[0]["path"], b[0]["path"]), mode
+        H.assert_prd_equal(a[0]["results"], b[0]["results"], "monostatic, batches %s" % mode)
+        assert (a[1]["segments"], a[1]["shaded"], a[1]["received"]) == (b[1]["segments"], b[1]["shaded"], b[1]["received"]), mode
+        assert np.array_equal(a[2] == 1, b[2] == 1), mode                                  # the same tiles are dead
+    rec, st, tiles = out["all"]
+    assert st["received"] > 0 and (tiles == 1).sum() > 0.5 * len(tiles), (st["received"], (tiles == 1).sum(), len(tiles))
+    sc = H.oracle_scene(oracle, spec)
+    for i in rec["slots"][:: max(len(rec["slots"]) // 60, 1)].astype(np.int64)[:60]:
+        o = sc.trace(tx["origin"], tx["span"], tx["dir"], spec["W"], spec["max_refl"], 0, spec["smooth"], ray_first=int(i), ray_stride=1, n_rays=1, use_bvh=False)
+        j = int(np.searchsorted(rec["slots"], i))
+        H.assert_prd_equal(o["results"][:1], rec["results"][j:j + 1], "launch index %d of the monostatic pulse against the brute-force oracle" % i)
